@@ -1,0 +1,91 @@
+"""Seeded synthetic ScanNet-like scenes (SURVEY.md 8(d) "Synthetic scene generator").
+
+The reference ships no data and no benchmark; its input contract is defined by
+`segdino3d/datasets/dataset/scannet200.py:198-289` (points [N,6] f32 = xyz + normalised rgb,
+`extra_features` = points_2dfeats [N,256], query2d_feats [M,256], query2d_pos [M,3],
+super_point_masks [N] i64) and `evaluation/evaluator_3d.py:80-86`.  This module synthesises
+scenes with the same layout so that the forward path can be exercised and timed without
+ScanNet: surface-like geometry (room shell + cuboid "objects") so that voxel occupancy per
+level resembles a real scan.
+
+All randomness comes from `torch.Generator().manual_seed(1234 + scene_idx)` on the CPU, so a
+scene is bit-identical in the build container and on the GPU box.
+"""
+from __future__ import annotations
+
+import torch
+
+from .gtypes import GD3DTarget
+
+ROOM = (8.0, 6.0, 3.0)
+
+
+def _sample_box_surface(n: int, lo: torch.Tensor, hi: torch.Tensor, g: torch.Generator) -> torch.Tensor:
+    """n points uniformly (area-weighted) on the six faces of the axis-aligned box [lo, hi]."""
+    ext = hi - lo
+    area = torch.stack([ext[1] * ext[2], ext[1] * ext[2], ext[0] * ext[2],
+                        ext[0] * ext[2], ext[0] * ext[1], ext[0] * ext[1]])
+    face = torch.multinomial(area / area.sum(), n, replacement=True, generator=g)
+    p = lo + torch.rand(n, 3, generator=g) * ext
+    axis = face // 2
+    side = (face % 2).to(p.dtype)
+    fixed = lo[axis] + side * ext[axis]
+    p[torch.arange(n), axis] = fixed
+    return p
+
+
+def make_scene(scene_idx: int = 0, n_points: int = 150_000, n_superpoints: int = 3000,
+               n_query2d: int = 300, feat2d_dim: int = 256, n_objects: int = 20,
+               device: str | torch.device = "cpu"):
+    """Returns (points [N,6] f32, GD3DTarget) laid out like the reference dataset output."""
+    g = torch.Generator(device="cpu")
+    g.manual_seed(1234 + scene_idx)
+    room = torch.tensor(ROOM)
+    n_room = n_points // 2
+    n_obj_total = n_points - n_room
+    pts = [_sample_box_surface(n_room, torch.zeros(3), room, g)]
+    per = [n_obj_total // n_objects] * n_objects
+    per[-1] += n_obj_total - sum(per)
+    for k in range(n_objects):
+        edge = 0.3 + 1.2 * torch.rand(3, generator=g)
+        lo = torch.rand(3, generator=g) * (room - edge)
+        lo[2] = 0.0 if k % 2 == 0 else lo[2]          # half of the objects stand on the floor
+        pts.append(_sample_box_surface(per[k], lo, lo + edge, g))
+    xyz = torch.cat(pts) + 0.005 * torch.randn(n_points, 3, generator=g)
+    perm = torch.randperm(n_points, generator=g)          # scans are not spatially sorted
+    xyz = xyz[perm].contiguous()
+    rgb = torch.randn(n_points, 3, generator=g)
+    points = torch.cat([xyz, rgb], dim=1).float().contiguous()
+    feats2d = torch.randn(n_points, feat2d_dim, generator=g)
+
+    # superpoints = Voronoi cells of S seed points drawn from the cloud: every id 0..S-1 is used
+    seed_idx = torch.randperm(n_points, generator=g)[:n_superpoints]
+    seeds = xyz[seed_idx]
+    sp = torch.empty(n_points, dtype=torch.long)
+    chunk = 16384
+    for s in range(0, n_points, chunk):
+        d = torch.cdist(xyz[s:s + chunk], seeds)
+        sp[s:s + chunk] = d.argmin(dim=1)
+    sp[seed_idx] = torch.arange(n_superpoints)
+
+    q_idx = torch.randint(0, n_points, (n_query2d,), generator=g)
+    q_pos = xyz[q_idx] + 0.1 * torch.randn(n_query2d, 3, generator=g)
+    q_feat = torch.randn(n_query2d, feat2d_dim, generator=g)
+
+    masks = torch.zeros(1, n_points, 1, dtype=torch.bool)
+    masks[0, : n_points // 10, 0] = True
+    target = GD3DTarget(
+        labels=torch.zeros(1, dtype=torch.long),
+        masks=masks,
+        scene_id=f"synthetic_{scene_idx:04d}",
+        extra_features={
+            "points_2dfeats": feats2d.contiguous(),
+            "query2d_feats": q_feat.contiguous(),
+            "query2d_pos": q_pos.contiguous(),
+            "super_point_masks": sp,
+        },
+    )
+    if str(device) != "cpu":
+        points = points.to(device)
+        target = target.to(device)
+    return points, target

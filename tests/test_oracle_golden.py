@@ -1,0 +1,123 @@
+"""Pins the oracle (oracle/*.py) to golden vectors captured from the imported reference
+(tests/golden/make_golden.py).  CPU only."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from _det import det_param
+from oracle import decoder_ref as D
+from oracle import postprocess_ref as P
+
+GOLDEN = os.path.join(os.path.dirname(__file__), "golden")
+
+
+def load(name):
+    z = np.load(os.path.join(GOLDEN, name + ".npz"))
+    return {k: torch.from_numpy(z[k]) if z[k].dtype != object else z[k] for k in z.files}
+
+
+def decoder_state_dict(in_channels=96, n_inst=198, n_sem=200, L=6, d=256, hidden=1024):
+    """Key names/shapes of the reference decoder state_dict; values by name."""
+    shapes = {}
+
+    def lin(name, o, i):
+        shapes[name + ".weight"] = (o, i)
+        shapes[name + ".bias"] = (o,)
+
+    def ln(name):
+        shapes[name + ".weight"] = (d,)
+        shapes[name + ".bias"] = (d,)
+
+    lin("input_proj.0", d, in_channels); ln("input_proj.1")
+    lin("query_proj.0", d, in_channels); lin("query_proj.2", d, d)
+    lin("x_mask.0", d, in_channels); lin("x_mask.2", d, d)
+    ln("out_norm"); lin("out_cls.0", d, d); lin("out_cls.2", n_inst + 1, d); lin("out_sem", n_sem + 1, d)
+    lin("ca_qpos_proj", d, d)
+    for n in ("ref_point_head",):
+        lin(n + ".layers.0", d, d); lin(n + ".layers.1", d, d)
+    lin("ref_anchor_head.layers.0", d, d); lin("ref_anchor_head.layers.1", 3, d)
+    for i in range(L):
+        lin(f"cross_attn_layers.{i}.out_proj", d, d)
+        lin(f"self_attn_layers.{i}.out_proj", d, d)
+        shapes[f"dinox_query_cross_attn_layers.{i}.attn.in_proj_weight"] = (3 * d, d)
+        shapes[f"dinox_query_cross_attn_layers.{i}.attn.in_proj_bias"] = (3 * d,)
+        lin(f"dinox_query_cross_attn_layers.{i}.attn.out_proj", d, d)
+        ln(f"dinox_query_cross_attn_layers.{i}.norm")
+        lin(f"ffn_layers.{i}.net.0", hidden, d); lin(f"ffn_layers.{i}.net.3", d, hidden); ln(f"ffn_layers.{i}.norm")
+        for n in ("ca_qcontent_proj", "ca_kcontent_proj", "ca_kpos_proj", "ca_v_proj", "ca_qpos_sine_proj",
+                  "sa_qcontent_proj", "sa_qpos_proj", "sa_kcontent_proj", "sa_kpos_proj", "sa_v_proj"):
+            lin(f"{n}.{i}", d, d)
+        ln(f"norm1.{i}"); ln(f"norm2.{i}")
+        for n in ("bbox_embed", "bbox_size_embed"):
+            lin(f"{n}.{i}.layers.0", d, d); lin(f"{n}.{i}.layers.1", d, d); lin(f"{n}.{i}.layers.2", 3, d)
+    return {"decoder." + k: det_param("decoder." + k, s) for k, s in shapes.items()}
+
+
+def test_sine_pe():
+    g = load("pe_sine")
+    out = D.sine_pe(g["xyz"][0], g["lo"][0], g["hi"][0], 20.0, 256)
+    torch.testing.assert_close(out, g["out_plain"][0], rtol=1e-5, atol=1e-5)
+    out = D.sine_pe(g["xyz"][0], g["lo"][0], g["hi"][0], 20.0, 256, modulated=g["modulated"][0])
+    torch.testing.assert_close(out, g["out_modulated"][0], rtol=1e-5, atol=1e-5)
+    assert D.pe_channel_plan(256, 3) == [86, 86, 84]
+
+
+@pytest.mark.parametrize("name,kw,cfgkw", [
+    ("decoder_s64_q64", {}, {}),
+    ("decoder_s96_q16", {}, {}),
+    ("decoder_v2_s48", dict(in_channels=32, n_inst=18, n_sem=20), dict(normalize_box_prediction=False)),
+])
+def test_decoder_matches_reference(name, kw, cfgkw):
+    g = load(name)
+    sd = decoder_state_dict(**kw)
+    cfg = D.DecoderCfg(**cfgkw)
+    ids = g["query_ids"].long()
+    out = D.decoder_forward(sd, cfg, g["x"], g["pos"], g["pos_wo"], g["x"][ids], g["pos"][ids],
+                            g["q2d_feat"], g["q2d_pos"], g["lo"], g["hi"])
+    tol = dict(rtol=2e-4, atol=2e-4)
+    for li in range(6):
+        torch.testing.assert_close(out["aux"][li]["cls_preds"], g[f"aux{li}_cls"], **tol)
+        torch.testing.assert_close(out["aux"][li]["masks"], g[f"aux{li}_masks"], **tol)
+        if li > 0:
+            torch.testing.assert_close(out["aux"][li]["centers"], g[f"aux{li}_centers"], **tol)
+            torch.testing.assert_close(out["aux"][li]["sizes"], g[f"aux{li}_sizes"], **tol)
+    for k in ("cls_preds", "sem_preds", "masks", "centers", "sizes", "hidden_states"):
+        torch.testing.assert_close(out[k], g[k], **tol)
+
+
+def test_matrix_nms():
+    g = load("matrix_nms")
+    s, l, m, keep, rec = P.matrix_nms(g["masks"], g["labels"], g["scores"], kernel="linear")
+    torch.testing.assert_close(s, g["out_scores"], rtol=1e-5, atol=1e-6)
+    assert torch.equal(l, g["out_labels"]) and torch.equal(keep, g["out_keep"]) and torch.equal(rec, g["out_record"])
+    torch.testing.assert_close(m, g["out_masks"])
+
+
+@pytest.mark.parametrize("name,query_num,box", [("arch_qall", -1, True), ("arch_q40", 40, True),
+                                                ("arch_qall_nobox", -1, False)])
+def test_architecture_eval_path(name, query_num, box):
+    g = load(name)
+    sd = decoder_state_dict()
+    cfg = D.DecoderCfg()
+    pts = g["points"]
+    lo, hi, centers, sizes = P.scene_range_and_gt_boxes(pts[:, :3], g["gt_masks"], "median")
+    torch.testing.assert_close(centers, g["instance_centers"])
+    torch.testing.assert_close(sizes, g["instance_sizes"])
+    q, qpos, ids = D.select_queries(sd, g["sp_feat"], g["sp_pos"], query_num)
+    out = D.decoder_forward(sd, cfg, g["sp_feat"], g["sp_pos"], g["sp_pos"], q, qpos, g["q2d_feat"],
+                            g["q2d_pos"], lo, hi)
+    res = P.predict_by_feat(out, g["superpoints"].long(), pts[:, :3], 198, P.TestCfg(), box, query_num)
+    n = int(g["n_points"])
+    ref_masks = torch.from_numpy(np.unpackbits(g["inst_masks_packed"].numpy(), axis=1)[:, :n].astype(bool))
+    assert res["pts_instance_mask"][0].shape == ref_masks.shape
+    torch.testing.assert_close(res["instance_scores"], g["inst_scores"], rtol=1e-4, atol=1e-6)
+    assert torch.equal(res["instance_labels"], g["inst_labels"])
+    diff = (res["pts_instance_mask"][0] != ref_masks).float().mean().item()
+    assert diff < 1e-4, diff
+    torch.testing.assert_close(res["instance_boxes"], g["inst_boxes"].float(), rtol=1e-4, atol=1e-4)
+    assert (res["pts_semantic_mask"][0] != g["sem_mask"]).float().mean() < 1e-3
+    assert (res["pts_semantic_mask"][1] != g["pan_sem"]).float().mean() < 1e-3
+    assert (res["pts_instance_mask"][1] != g["pan_inst"]).float().mean() < 1e-3
+    assert torch.equal(torch.sort(res["sort_and_mask"][0])[0], torch.sort(g["topk_idx"])[0])
