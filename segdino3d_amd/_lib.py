@@ -1,0 +1,78 @@
+"""ctypes binding of libsegdino3d_hip.so (the C ABI of include/segdino3d_hip.h).
+
+The product path has NO CPU fallback: if the shared library is missing or a tensor is not on a
+HIP device the call raises.  (The CPU restatement lives in oracle/ and is test infrastructure.)
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libsegdino3d_hip.so")
+ABI_VERSION = 1
+
+_lib = None
+
+_p = C.c_void_p
+_i = C.c_int
+_l = C.c_int64
+_z = C.c_size_t
+_f = C.c_float
+
+# name -> (restype, argtypes).  Must list every symbol include/segdino3d_hip.h declares
+# (tests/test_capi_symbols.py cross-checks this table against the header).
+SIGNATURES = {
+    "sd3d_abi_version": (_i, []),
+    "sd3d_last_error": (C.c_char_p, []),
+    "sd3d_selftest_host": (_i, []),
+    "sd3d_sort_ws_bytes": (_z, [_l]),
+    "sd3d_sort_pairs_u64": (_i, [_p, _p, _p, _p, _p, _l, _i, _i, _p, _z, _p]),
+    "sd3d_scan_ws_bytes": (_z, [_l]),
+    "sd3d_scan_exclusive_i32": (_i, [_p, _p, _l, _p, _p, _z, _p]),
+    "sd3d_keys_from_f32": (_i, [_p, _l, _i, _p, _p]),
+    "sd3d_keys_from_i64": (_i, [_p, _l, _p, _p]),
+    "sd3d_scene_stats_ws_bytes": (_z, []),
+    "sd3d_scene_stats": (_i, [_p, _i, _l, _p, _p, _z, _p]),
+    "sd3d_voxel_keys": (_i, [_p, _i, _l, _f, _p, _i, _i, _p, _p, _p, _p, _p]),
+    "sd3d_unique_ws_bytes": (_z, [_l]),
+    "sd3d_unique_sorted": (_i, [_p, _p, _l, _p, _i, _p, _p, _p, _p, _p, _z, _p]),
+    "sd3d_hash_build": (_i, [_p, _l, _p, _p, _l, _p]),
+    "sd3d_kernel_map": (_i, [_p, _l, _p, _p, _l, _p, _i, _p, _p]),
+    "sd3d_stride_maps": (_i, [_p, _p, _l, _l, _p, _p, _p, _p]),
+    "sd3d_voxel_mean": (_i, [_p, _i, _p, _i, _i, _p, _l, _p, _p, _l, _p, _i, _p]),
+    "sd3d_segment_starts": (_i, [_p, _l, _l, _p, _p]),
+    "sd3d_pool_superpoints": (_i, [_p, _i, _i, _p, _p, _f, _p, _p, _l, _p, _p, _p]),
+    "sd3d_gather_gemm": (_i, [_p, _i, _i, _p, _i, _p, _p, _i, _i, _i, _l, _p, _p, _p, _i, _p, _i, _i, _i, _p]),
+}
+
+
+class HipExtensionMissing(RuntimeError):
+    pass
+
+
+def load():
+    """Load (once) and return the ctypes library; raises HipExtensionMissing when it is not built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise HipExtensionMissing(
+            f"{LIB_PATH} not found - the HIP extension is not built.  Build it with "
+            "`python -c 'import __graft_entry__ as g; g.build()'` (or `make -C segdino3d_amd/csrc`). "
+            "There is no CPU fallback for the product path.")
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)       # AttributeError here = header/library mismatch: fail loudly
+        fn.restype = res
+        fn.argtypes = args
+    if lib.sd3d_abi_version() != ABI_VERSION:
+        raise HipExtensionMissing(f"ABI version mismatch: library {lib.sd3d_abi_version()} != binding {ABI_VERSION}")
+    _lib = lib
+    return lib
+
+
+def check(rc: int, what: str = ""):
+    if rc != 0:
+        msg = load().sd3d_last_error().decode(errors="replace")
+        raise RuntimeError(f"segdino3d_hip {what} failed with status {rc}: {msg}")

@@ -1,0 +1,247 @@
+"""Res16UNet34C sparse-voxel U-Net on the MI355X gather-GEMM (host side).
+
+Mirrors the reference operator interface `segdino3d/models/backbone/minkunet.py`:
+  - constructor kwargs `in_channels, out_channels, config{dilations, conv1_kernel_size, bn_momentum},
+    D, voxel_size, mode_fuse_2d_feat, add_positional_embedding, **ignored` (`minkunet.py:277-298`)
+  - `forward_wrapper(samples, targets, return_sp_mean_pos) -> (sp_feats[], sp_pos[], sp_pos_wo_elastic[])`
+    (`minkunet.py:603-685`)
+  - the same parameter / buffer names and shapes as the reference `state_dict`
+    (`backbone.conv0p1s1.kernel [125,259,32]`, `backbone.bn0.bn.weight`, `backbone.block1.0.conv1.kernel`,
+    `...downsample.0.kernel [Cin,Cout]`, `...downsample.1.bn.*`, `backbone.convtr4p16s2.kernel`, ...),
+    so released checkpoints load with `load_state_dict`.
+The nn.Module tree only HOLDS parameters; all arithmetic runs in libsegdino3d_hip.so:
+conv + folded BatchNorm + ReLU (+ residual) = one `gather_gemm` launch per convolution, skip
+concatenations are never materialised (two input pointers), devoxelise + superpoint mean is one
+fused kernel.  Eval mode only (training step = SURVEY.md 8(f-1), not built yet).
+"""
+from __future__ import annotations
+
+import math
+from typing import List
+
+import torch
+import torch.nn as nn
+
+from . import ops
+from .builder import BACKBONES
+from .sparse import SceneMaps
+
+BN_EPS = 1e-5      # MinkowskiBatchNorm wraps nn.BatchNorm1d with the default eps
+
+
+class MinkConv(nn.Module):
+    """Parameter holder named like ME.MinkowskiConvolution: `kernel` [K, Cin, Cout] ([Cin, Cout] for k=1)."""
+
+    def __init__(self, cin: int, cout: int, ksize: int):
+        super().__init__()
+        K = ksize ** 3
+        shape = (cin, cout) if K == 1 else (K, cin, cout)
+        self.kernel = nn.Parameter(torch.empty(*shape))
+        std = 1.0 / math.sqrt(cin * K)
+        with torch.no_grad():
+            self.kernel.uniform_(-std, std)
+        self.ksize = ksize
+
+
+class MinkBN(nn.Module):
+    """Named like ME.MinkowskiBatchNorm: the BatchNorm1d lives under `.bn` (`minkunet.py:302-304`)."""
+
+    def __init__(self, c: int, momentum: float):
+        super().__init__()
+        self.bn = nn.BatchNorm1d(c, eps=BN_EPS, momentum=momentum)
+
+
+class BasicBlock(nn.Module):
+    def __init__(self, inplanes, planes, momentum, downsample=None):
+        super().__init__()
+        self.conv1 = MinkConv(inplanes, planes, 3)
+        self.norm1 = MinkBN(planes, momentum)
+        self.conv2 = MinkConv(planes, planes, 3)
+        self.norm2 = MinkBN(planes, momentum)
+        self.downsample = downsample
+
+
+def _pack_conv(conv: MinkConv, pad_cin_to: int = 0) -> torch.Tensor:
+    """[K, Cin, Cout] -> [K, Cout, Cin(+pad)] contiguous (the gather-GEMM weight layout)."""
+    w = conv.kernel.detach()
+    if w.dim() == 2:
+        w = w.unsqueeze(0)
+    w = w.permute(0, 2, 1)
+    if pad_cin_to and pad_cin_to > w.shape[2]:
+        w = torch.nn.functional.pad(w, (0, pad_cin_to - w.shape[2]))
+    return w.contiguous().float()
+
+
+def _fold_bn(bn: MinkBN):
+    b = bn.bn
+    scale = (b.weight.detach() / torch.sqrt(b.running_var + b.eps)).float().contiguous()
+    shift = (b.bias.detach() - b.running_mean * scale).float().contiguous()
+    return scale, shift
+
+
+def _round32(c: int) -> int:
+    return (c + 31) // 32 * 32
+
+
+class Res16UNetBase(nn.Module):
+    PLANES = (32, 64, 128, 256, 256, 256, 256, 256)
+    LAYERS = (2, 2, 2, 2, 2, 2, 2, 2)
+    INIT_DIM = 32
+    KERNEL_ORDER = "x_fastest"       # MinkowskiEngine offset enumeration (see oracle/sparse_ref.py header)
+
+    def __init__(self, in_channels, out_channels=None, config=None, D=3, voxel_size=0.02,
+                 mode_fuse_2d_feat="early_fusion", add_positional_embedding=False, **kwargs):
+        super().__init__()
+        if D != 3:
+            raise NotImplementedError("only 3-D sparse tensors are supported")
+        if mode_fuse_2d_feat == "only_rgb":
+            in_channels = 3
+        elif mode_fuse_2d_feat != "early_fusion":
+            raise NotImplementedError(f"Mode fuse 2d feat {mode_fuse_2d_feat} not implemented")
+        config = config or {}
+        self.voxel_size = voxel_size
+        self.mode_fuse_2d_feat = mode_fuse_2d_feat
+        self.add_positional_embedding = add_positional_embedding
+        self.in_channels = in_channels
+        self.conv1_kernel_size = int(config.get("conv1_kernel_size", 5))
+        mom = float(config.get("bn_momentum", 0.1))
+        P, Ly = self.PLANES, self.LAYERS
+
+        self.inplanes = self.INIT_DIM
+        self.conv0p1s1 = MinkConv(in_channels, self.inplanes, self.conv1_kernel_size)
+        self.bn0 = MinkBN(self.inplanes, mom)
+        for i, (cname, bname) in enumerate((("conv1p1s2", "bn1"), ("conv2p2s2", "bn2"), ("conv3p4s2", "bn3"),
+                                            ("conv4p8s2", "bn4"))):
+            setattr(self, cname, MinkConv(self.inplanes, self.inplanes, 2))
+            setattr(self, bname, MinkBN(self.inplanes, mom))
+            setattr(self, f"block{i + 1}", self._make_layer(P[i], Ly[i], mom))
+        skips = (P[2], P[1], P[0], self.INIT_DIM)
+        for i, (cname, bname) in enumerate((("convtr4p16s2", "bntr4"), ("convtr5p8s2", "bntr5"),
+                                            ("convtr6p4s2", "bntr6"), ("convtr7p2s2", "bntr7"))):
+            setattr(self, cname, MinkConv(self.inplanes, P[4 + i], 2))
+            setattr(self, bname, MinkBN(P[4 + i], mom))
+            self.inplanes = P[4 + i] + skips[i]
+            setattr(self, f"block{5 + i}", self._make_layer(P[4 + i], Ly[4 + i], mom))
+        self.out_planes = P[7]
+        self._packed = None
+        self.last_maps = None          # SceneMaps of the most recent scene (bench.py reads rulebook sizes)
+
+    def _make_layer(self, planes, blocks, mom):
+        down = None
+        if self.inplanes != planes:
+            down = nn.Sequential(MinkConv(self.inplanes, planes, 1), MinkBN(planes, mom))
+        layers = [BasicBlock(self.inplanes, planes, mom, down)]
+        self.inplanes = planes
+        for _ in range(1, blocks):
+            layers.append(BasicBlock(planes, planes, mom))
+        return nn.Sequential(*layers)
+
+    # ---- weight packing ------------------------------------------------------------------------
+    def _apply(self, fn, *a, **k):
+        self._packed = None
+        return super()._apply(fn, *a, **k)
+
+    def load_state_dict(self, *a, **k):
+        self._packed = None
+        return super().load_state_dict(*a, **k)
+
+    def _load_from_state_dict(self, *a, **k):
+        self._packed = None
+        return super()._load_from_state_dict(*a, **k)
+
+    def invalidate_packed_weights(self):
+        self._packed = None
+
+    def packed(self):
+        """name -> (wt [K,Cout,Cin], scale, shift) in the device layout; rebuilt after .to()/load."""
+        if self._packed is None:
+            pk = {}
+            convs = {n: m for n, m in self.named_modules() if isinstance(m, MinkConv)}
+            bns = {n: m for n, m in self.named_modules() if isinstance(m, MinkBN)}
+            for n, m in convs.items():
+                pad = _round32(self.in_channels) if n == "conv0p1s1" else 0
+                pk[n] = _pack_conv(m, pad)
+            for n, m in bns.items():
+                pk[n] = _fold_bn(m)
+            self._packed = pk
+        return self._packed
+
+    # ---- network ---------------------------------------------------------------------------------
+    def _cbr(self, pk, x, conv, bn, nbr, x2=None, M=None):
+        s, b = pk[bn]
+        return ops.gather_gemm(x, pk[conv], nbr=nbr, x2=x2, scale=s, shift=b, act="relu", M=M)
+
+    def _stage(self, pk, name, nblocks, x, nbr, x2=None):
+        for j in range(nblocks):
+            p = f"{name}.{j}"
+            s1, b1 = pk[p + ".norm1"]
+            h = ops.gather_gemm(x, pk[p + ".conv1"], nbr=nbr, x2=x2, scale=s1, shift=b1, act="relu")
+            if (p + ".downsample.0") in pk:
+                sd, bd = pk[p + ".downsample.1"]
+                res = ops.gather_gemm(x, pk[p + ".downsample.0"], x2=x2, scale=sd, shift=bd)
+            else:
+                res = x
+            s2, b2 = pk[p + ".norm2"]
+            x = ops.gather_gemm(h, pk[p + ".conv2"], nbr=nbr, scale=s2, shift=b2, res=res, act="relu")
+            x2 = None
+        return x
+
+    def forward_sparse(self, maps: SceneMaps, vox_feats: torch.Tensor) -> torch.Tensor:
+        """`Res16UNetBase.forward` (`minkunet.py:531-601`): [V0, Cin_padded] -> [V0, 96]."""
+        if self.training:
+            raise NotImplementedError("segdino3d_amd backbone: eval-mode forward only (training step not built)")
+        pk = self.packed()
+        Ly = self.LAYERS
+        k3 = [maps.same(l, 3) for l in range(5)]
+        out_p1 = self._cbr(pk, vox_feats, "conv0p1s1", "bn0", maps.same(0, self.conv1_kernel_size))
+        out = self._cbr(pk, out_p1, "conv1p1s2", "bn1", maps.down(0))
+        out_b1p2 = self._stage(pk, "block1", Ly[0], out, k3[1])
+        out = self._cbr(pk, out_b1p2, "conv2p2s2", "bn2", maps.down(1))
+        out_b2p4 = self._stage(pk, "block2", Ly[1], out, k3[2])
+        out = self._cbr(pk, out_b2p4, "conv3p4s2", "bn3", maps.down(2))
+        out_b3p8 = self._stage(pk, "block3", Ly[2], out, k3[3])
+        out = self._cbr(pk, out_b3p8, "conv4p8s2", "bn4", maps.down(3))
+        out = self._stage(pk, "block4", Ly[3], out, k3[4])
+        out = self._cbr(pk, out, "convtr4p16s2", "bntr4", maps.up(3))
+        out = self._stage(pk, "block5", Ly[4], out, k3[3], x2=out_b3p8)
+        out = self._cbr(pk, out, "convtr5p8s2", "bntr5", maps.up(2))
+        out = self._stage(pk, "block6", Ly[5], out, k3[2], x2=out_b2p4)
+        out = self._cbr(pk, out, "convtr6p4s2", "bntr6", maps.up(1))
+        out = self._stage(pk, "block7", Ly[6], out, k3[1], x2=out_b1p2)
+        out = self._cbr(pk, out, "convtr7p2s2", "bntr7", maps.up(0))
+        out = self._stage(pk, "block8", Ly[7], out, k3[0], x2=out_p1)
+        return out
+
+    def forward_wrapper(self, samples: List[torch.Tensor], targets, return_sp_mean_pos=False):
+        feats, pos = [], []
+        for pts, tgt in zip(samples, targets):
+            if "elastic_coords" in tgt:
+                raise NotImplementedError("elastic_coords (train-time augmentation) is not supported in the eval path")
+            ef = tgt["extra_features"]
+            pts = pts.float().contiguous()
+            sp = ef["super_point_masks"].contiguous()
+            if self.mode_fuse_2d_feat == "early_fusion":
+                f2d, mode = ef["points_2dfeats"].float().contiguous(), 0
+            else:
+                f2d, mode = None, 1
+            maps = SceneMaps(pts, self.voxel_size, 5, shift_to_min=False, order=self.KERNEL_ORDER, superpoints=sp)
+            self.last_maps = maps
+            vf = maps.voxel_features(pts, f2d, mode, _round32(self.in_channels))
+            x = self.forward_sparse(maps, vf)
+            f, p = maps.pool(x, self.out_planes)
+            feats.append(f)
+            pos.append(p)
+        sp_pos = pos if self.add_positional_embedding else None
+        if return_sp_mean_pos:
+            # eval: no elastic distortion, so the "without elastic" positions are the same tensor values
+            return feats, sp_pos, [p.clone() for p in pos]
+        return feats, sp_pos, None
+
+
+class Res16UNet34(Res16UNetBase):
+    LAYERS = (2, 3, 4, 6, 2, 2, 2, 2)
+
+
+@BACKBONES.register_module()
+class Res16UNet34C(Res16UNet34):
+    PLANES = (32, 64, 128, 256, 256, 128, 96, 96)

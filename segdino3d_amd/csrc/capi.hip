@@ -1,0 +1,140 @@
+// extern "C" entry points declared in include/segdino3d_hip.h.  Thin argument checking + launch.
+#include "common.h"
+#include "../../include/segdino3d_hip.h"
+#include <string.h>
+#include <stdio.h>
+
+static thread_local char g_err[512] = "";
+
+int sd3d_set_error(int code, const char* msg) {
+    snprintf(g_err, sizeof(g_err), "%s", msg ? msg : "unknown error");
+    return code;
+}
+
+// ---- internal launchers (defined in the other translation units)
+size_t sort_ws_bytes(int64_t n);
+int sort_pairs_u64(uint64_t*, uint32_t*, uint64_t*, uint32_t*, int64_t, int, int, void*, size_t, hipStream_t, uint32_t*);
+size_t scan_ws_bytes(int64_t n);
+int scan_exclusive_i32(const int*, int*, int64_t, const int*, int*, void*, size_t, hipStream_t);
+int launch_f32_to_sortkey(const float*, int64_t, int, uint64_t*, hipStream_t);
+int launch_i64_to_sortkey(const int64_t*, int64_t, uint64_t*, hipStream_t);
+int launch_scene_stats(const float*, int, int64_t, float*, void*, size_t, hipStream_t);
+size_t unique_ws_bytes(int64_t);
+int launch_unique_sorted(const uint64_t*, const uint32_t*, int64_t, const int*, int, uint64_t*, int32_t*, int32_t*, int32_t*,
+                         void*, size_t, hipStream_t);
+int launch_hash_build(const uint64_t*, int64_t, uint64_t*, int32_t*, int64_t, hipStream_t);
+int launch_kernel_map(const uint64_t*, int64_t, const uint64_t*, const int32_t*, int64_t, const int8_t*, int, int32_t*, hipStream_t);
+int launch_stride_maps(const uint64_t*, const int32_t*, int64_t, int64_t, const int32_t*, int32_t*, int32_t*, hipStream_t);
+int launch_voxel_mean(const float*, int, const float*, int, int, const float*, int64_t, const uint32_t*, const int32_t*, int64_t,
+                      float*, int, hipStream_t);
+int launch_segment_starts(const uint64_t*, int64_t, int64_t, int32_t*, hipStream_t);
+int launch_pool_superpoints(const float*, int, int, const int32_t*, const int32_t*, float, const uint32_t*, const int32_t*,
+                            int64_t, float*, float*, hipStream_t);
+int launch_voxel_keys(const float*, int, int64_t, float, const float*, int, int, int32_t*, uint64_t*, int32_t*, int32_t*, hipStream_t);
+
+struct GGParams {
+    const float* in0; int ld0; int C0;
+    const float* in1; int ld1;
+    const int32_t* nbr;
+    const float* wt;
+    int K, Cin, Cout;
+    int64_t M;
+    const float* scale; const float* shift;
+    const float* res; int ld_res;
+    float* out; int ld_out;
+    int act;
+    int col_groups;
+};
+int launch_gather_gemm(const GGParams&, int, hipStream_t);
+
+#define ST ((hipStream_t)stream)
+
+extern "C" {
+
+int sd3d_abi_version(void) { return SD3D_ABI_VERSION; }
+const char* sd3d_last_error(void) { return g_err; }
+
+int sd3d_selftest_host(void) {
+    // Z-order codec round trip + parent relation (runs on the host, no GPU needed)
+    uint32_t s = 12345u;
+    for (int it = 0; it < 20000; ++it) {
+        s = s * 1664525u + 1013904223u; const uint32_t x = (s >> 8) & 0xFFFF;
+        s = s * 1664525u + 1013904223u; const uint32_t y = (s >> 8) & 0xFFFF;
+        s = s * 1664525u + 1013904223u; const uint32_t z = (s >> 8) & 0xFFFF;
+        const uint64_t m = morton_encode(x, y, z);
+        uint32_t a, b, c;
+        morton_decode(m, a, b, c);
+        if (a != x || b != y || c != z) return sd3d_set_error(-100, "morton round trip failed");
+        if ((m >> 3) != morton_encode(x >> 1, y >> 1, z >> 1)) return sd3d_set_error(-101, "morton parent relation failed");
+        if ((m & 7ull) != ((x & 1) | ((y & 1) << 1) | ((z & 1) << 2))) return sd3d_set_error(-102, "morton child bits failed");
+        if (m >> 48) return sd3d_set_error(-103, "morton exceeds 48 bits");
+    }
+    return 0;
+}
+
+size_t sd3d_sort_ws_bytes(int64_t n) { return sort_ws_bytes(n); }
+int sd3d_sort_pairs_u64(uint64_t* keys_in, uint32_t* vals_in, uint64_t* keys_out, uint32_t* vals_out, uint32_t* vals_scratch,
+                        int64_t n, int begin_bit, int end_bit, void* ws, size_t ws_bytes, void* stream) {
+    if (n < 0 || begin_bit < 0 || end_bit > 64 || end_bit <= begin_bit) return sd3d_set_error(SD3D_ERR_ARG, "sort: bad arguments");
+    return sort_pairs_u64(keys_in, vals_in, keys_out, vals_out, n, begin_bit, end_bit, ws, ws_bytes, ST, vals_scratch);
+}
+size_t sd3d_scan_ws_bytes(int64_t n) { return scan_ws_bytes(n > 0 ? n : 1); }
+int sd3d_scan_exclusive_i32(const int32_t* in, int32_t* out, int64_t n, int32_t* total_dev, void* ws, size_t ws_bytes, void* stream) {
+    return scan_exclusive_i32(in, out, n, nullptr, total_dev, ws, ws_bytes, ST);
+}
+int sd3d_keys_from_f32(const float* x, int64_t n, int descending, uint64_t* keys, void* stream) {
+    return launch_f32_to_sortkey(x, n, descending, keys, ST);
+}
+int sd3d_keys_from_i64(const int64_t* x, int64_t n, uint64_t* keys, void* stream) { return launch_i64_to_sortkey(x, n, keys, ST); }
+
+size_t sd3d_scene_stats_ws_bytes(void) { return 256 * 9 * sizeof(float); }
+int sd3d_scene_stats(const float* points, int ld, int64_t n, float* stats, void* ws, size_t ws_bytes, void* stream) {
+    return launch_scene_stats(points, ld, n, stats, ws, ws_bytes, ST);
+}
+int sd3d_voxel_keys(const float* points, int ld, int64_t n, float inv_voxel, const float* stats, int shift_to_min,
+                    int batch_index, int32_t* origin, uint64_t* keys, int32_t* icoords, int32_t* err_flag, void* stream) {
+    return launch_voxel_keys(points, ld, n, inv_voxel, stats, shift_to_min, batch_index, origin, keys, icoords, err_flag, ST);
+}
+size_t sd3d_unique_ws_bytes(int64_t n_cap) { return unique_ws_bytes(n_cap > 0 ? n_cap : 1); }
+int sd3d_unique_sorted(const uint64_t* keys, const uint32_t* src_idx, int64_t n_cap, const int32_t* n_dev, int shift,
+                       uint64_t* ukeys, int32_t* seg_start, int32_t* map, int32_t* n_unique_dev, void* ws, size_t ws_bytes,
+                       void* stream) {
+    return launch_unique_sorted(keys, src_idx, n_cap, n_dev, shift, ukeys, seg_start, map, n_unique_dev, ws, ws_bytes, ST);
+}
+int sd3d_hash_build(const uint64_t* ukeys, int64_t n, uint64_t* table_keys, int32_t* table_vals, int64_t capacity, void* stream) {
+    return launch_hash_build(ukeys, n, table_keys, table_vals, capacity, ST);
+}
+int sd3d_kernel_map(const uint64_t* out_keys, int64_t n_out, const uint64_t* table_keys, const int32_t* table_vals,
+                    int64_t capacity, const int8_t* offsets, int K, int32_t* nbr, void* stream) {
+    if (capacity <= 0 || (capacity & (capacity - 1))) return sd3d_set_error(SD3D_ERR_ARG, "kernel_map: capacity must be a power of two");
+    return launch_kernel_map(out_keys, n_out, table_keys, table_vals, capacity, offsets, K, nbr, ST);
+}
+int sd3d_stride_maps(const uint64_t* fine_keys, const int32_t* parent, int64_t n_fine, int64_t n_coarse, const int32_t* perm8,
+                     int32_t* nbr_down, int32_t* nbr_up, void* stream) {
+    return launch_stride_maps(fine_keys, parent, n_fine, n_coarse, perm8, nbr_down, nbr_up, ST);
+}
+int sd3d_voxel_mean(const float* points, int ld_points, const float* feats2d, int F, int mode, const float* stats,
+                    int64_t n_points, const uint32_t* sorted_idx, const int32_t* seg_start, int64_t n_vox, float* out,
+                    int ld_out, void* stream) {
+    return launch_voxel_mean(points, ld_points, feats2d, F, mode, stats, n_points, sorted_idx, seg_start, n_vox, out, ld_out, ST);
+}
+int sd3d_segment_starts(const uint64_t* sorted_ids, int64_t n, int64_t S, int32_t* start, void* stream) {
+    return launch_segment_starts(sorted_ids, n, S, start, ST);
+}
+int sd3d_pool_superpoints(const float* feat, int ld_feat, int C, const int32_t* inverse, const int32_t* icoords,
+                          float voxel_size, const uint32_t* sorted_idx, const int32_t* start, int64_t S, float* out_feat,
+                          float* out_pos, void* stream) {
+    return launch_pool_superpoints(feat, ld_feat, C, inverse, icoords, voxel_size, sorted_idx, start, S, out_feat, out_pos, ST);
+}
+
+int sd3d_gather_gemm(const float* in0, int ld0, int C0, const float* in1, int ld1, const int32_t* nbr, const float* wt, int K,
+                     int Cin, int Cout, int64_t M, const float* scale, const float* shift, const float* res, int ld_res,
+                     float* out, int ld_out, int act, int nt, void* stream) {
+    GGParams p;
+    p.in0 = in0; p.ld0 = ld0; p.C0 = C0; p.in1 = in1; p.ld1 = ld1; p.nbr = nbr; p.wt = wt; p.K = K; p.Cin = Cin; p.Cout = Cout;
+    p.M = M; p.scale = scale; p.shift = shift; p.res = res; p.ld_res = ld_res; p.out = out; p.ld_out = ld_out; p.act = act;
+    p.col_groups = 1;
+    return launch_gather_gemm(p, nt, ST);
+}
+
+}  // extern "C"

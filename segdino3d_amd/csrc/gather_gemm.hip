@@ -1,0 +1,194 @@
+// Gather-GEMM on the fp32 matrix cores: the one kernel behind every sparse convolution of the
+// backbone (reference: ME.MinkowskiConvolution / ConvolutionTranspose, spconv SubMConv3d /
+// SparseConv3d / SparseInverseConv3d) and every dense Linear of the
+// decoder (K = 1, identity gather).
+//
+//   out[r][n] = act( scale[n] * ( sum_k sum_c  A[nbr[k][r]][c] * Wt[k][n][c] ) + shift[n] + res[r][n] )
+//
+// Output-stationary, no atomics, no scatter: one wave64 owns a 32-row x (32*NT)-column output tile
+// and keeps it in NT 32x32 accumulators (v_mfma_f32_32x32x2_f32, exact fp32 FMA chains).  For every
+// kernel offset k that has at least one neighbour among the wave's 32 rows (rows are consecutive
+// voxels on the Z-order curve, so the active offset set is small and coherent) it streams 32-channel
+// chunks: each lane loads 16 consecutive channels of its gathered input row straight from HBM/L2
+// into registers (one 128-byte line per row per chunk) and 16 channels of NT weight rows (L2
+// resident), then issues 16*NT MFMAs.  The next chunk's loads are issued before the current chunk's
+// MFMAs.  BatchNorm (folded scale/shift), residual add, ReLU/GELU are fused into the epilogue, so
+// each output row is written exactly once.
+//
+// K-dimension trick: one 32x32x2 MFMA consumes k-slices {0,1}; lane half h = lane>>5 supplies slice
+// h.  Any bijection between (instruction index kk, half h) and the 32 channels of a chunk is valid
+// as long as A and B agree, so half h takes channels h*16 + kk: 16 contiguous floats per lane,
+// loaded as 4 x dwordx4.
+#include "common.h"
+
+struct GGParams {
+    const float* in0; int ld0; int C0;        // input features, first C0 channels
+    const float* in1; int ld1;                // optional second source for channels C0..Cin-1 (skip concat)
+    const int32_t* nbr;                       // [K][M] gather indices (-1 = no neighbour) or NULL (identity, K == 1)
+    const float* wt;                          // [K][Cout][Cin]
+    int K, Cin, Cout;
+    int64_t M;                                // output rows
+    const float* scale; const float* shift;   // per-column, optional
+    const float* res; int ld_res;             // optional residual
+    float* out; int ld_out;
+    int act;                                  // 0 none, 1 relu, 2 gelu(erf), 3 sigmoid
+    int col_groups;                           // ceil(Cout / (32*NT))
+};
+
+template <int NT>
+struct Frag {
+    f32x4 a[4];
+    f32x4 b[NT][4];
+};
+
+template <int NT>
+__device__ __forceinline__ void load_frag(Frag<NT>& f, const GGParams& p, int k, int chunk, int idx, int ncol0, int j, int h) {
+    const int c = chunk * 32 + h * 16;
+    if (idx >= 0) {
+        const float* src = (c < p.C0) ? (p.in0 + (int64_t)idx * p.ld0 + c) : (p.in1 + (int64_t)idx * p.ld1 + (c - p.C0));
+#pragma unroll
+        for (int q = 0; q < 4; ++q) f.a[q] = *(const f32x4*)(src + q * 4);
+    } else {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) f.a[q] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+        int n = ncol0 + t * 32 + j;
+        n = n < p.Cout ? n : p.Cout - 1;
+        const float* w = p.wt + ((int64_t)k * p.Cout + n) * p.Cin + c;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) f.b[t][q] = *(const f32x4*)(w + q * 4);
+    }
+}
+
+template <int NT>
+__device__ __forceinline__ void mma_frag(f32x16 (&acc)[NT], const Frag<NT>& f) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+#pragma unroll
+            for (int t = 0; t < NT; ++t)
+                acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(f.a[q][e], f.b[t][q][e], acc[t], 0, 0, 0);
+}
+
+__device__ __forceinline__ int next_active(uint64_t m0, uint64_t m1, int after) {
+    // smallest set bit index > after in the 128-bit mask (m1:m0), or -1
+    int s = after + 1;
+    if (s < 64) {
+        const uint64_t r = m0 >> s;
+        if (r) return s + __builtin_ctzll(r);
+        s = 64;
+    }
+    if (s < 128) {
+        const uint64_t r = m1 >> (s - 64);
+        if (r) return s + __builtin_ctzll(r);
+    }
+    return -1;
+}
+
+template <int NT>
+__global__ __launch_bounds__(256) void gather_gemm_kernel(const GGParams p) {
+    const int lane = threadIdx.x & 63;
+    const int j = lane & 31, h = lane >> 5;
+    const int64_t wave = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int64_t row_tile = wave / p.col_groups;
+    const int cg = (int)(wave - row_tile * p.col_groups);
+    const int64_t row0 = row_tile * 32;
+    if (row0 >= p.M) return;
+    const int64_t row = row0 + j;
+    const bool row_ok = row < p.M;
+    const int ncol0 = cg * 32 * NT;
+    const int nchunks = p.Cin >> 5;
+
+    // which kernel offsets have at least one neighbour among this wave's rows?
+    uint64_t m0 = 0, m1 = 0;
+    if (p.nbr) {
+        for (int k = 0; k < p.K; ++k) {
+            const int id = row_ok ? p.nbr[(int64_t)k * p.M + row] : -1;
+            const bool any = __ballot(id >= 0) != 0ull;
+            if (any) { if (k < 64) m0 |= 1ull << k; else m1 |= 1ull << (k - 64); }
+        }
+    } else {
+        m0 = 1ull;
+    }
+
+    f32x16 acc[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+
+    int k = next_active(m0, m1, -1);
+    if (k >= 0) {
+        int chunk = 0;
+        int idx = p.nbr ? (row_ok ? p.nbr[(int64_t)k * p.M + row] : -1) : (row_ok ? (int)row : -1);
+        Frag<NT> cur;
+        load_frag<NT>(cur, p, k, chunk, idx, ncol0, j, h);
+        while (true) {
+            int nk = k, nchunk = chunk + 1, nidx = idx;
+            if (nchunk == nchunks) {
+                nchunk = 0;
+                nk = next_active(m0, m1, k);
+                if (nk >= 0) nidx = row_ok ? p.nbr[(int64_t)nk * p.M + row] : -1;
+            }
+            Frag<NT> nxt;
+            const bool has_next = nk >= 0;
+            if (has_next) load_frag<NT>(nxt, p, nk, nchunk, nidx, ncol0, j, h);
+            mma_frag<NT>(acc, cur);
+            if (!has_next) break;
+            cur = nxt;
+            k = nk; chunk = nchunk; idx = nidx;
+        }
+    }
+
+    // epilogue: acc[t][r] is (row = (r&3) + 8*(r>>2) + 4*h, col = j) of subtile t
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+        const int n = ncol0 + t * 32 + j;
+        if (n >= p.Cout) continue;
+        const float sc = p.scale ? p.scale[n] : 1.f;
+        const float sh = p.shift ? p.shift[n] : 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int64_t rr = row0 + (r & 3) + 8 * (r >> 2) + 4 * h;
+            if (rr >= p.M) continue;
+            float y = acc[t][r] * sc + sh;
+            if (p.res) y += p.res[rr * p.ld_res + n];
+            if (p.act == 1) y = fmaxf(y, 0.f);
+            else if (p.act == 2) y = 0.5f * y * (1.f + erff(y * 0.70710678118654752440f));
+            else if (p.act == 3) y = 1.f / (1.f + expf(-y));
+            p.out[rr * p.ld_out + n] = y;
+        }
+    }
+}
+
+int launch_gather_gemm(const GGParams& p_in, int nt, hipStream_t st) {
+    GGParams p = p_in;
+    if (p.M <= 0 || p.Cout <= 0) return SD3D_OK;
+    if (p.Cin <= 0 || (p.Cin & 31)) return sd3d_set_error(SD3D_ERR_ARG, "gather_gemm: Cin must be a positive multiple of 32");
+    if (p.in1 && ((p.C0 & 31) || p.C0 > p.Cin)) return sd3d_set_error(SD3D_ERR_ARG, "gather_gemm: concat split must be a multiple of 32");
+    if (!p.in1) p.C0 = p.Cin;
+    if ((p.ld0 & 3) || (p.in1 && (p.ld1 & 3))) return sd3d_set_error(SD3D_ERR_ARG, "gather_gemm: input row stride must be a multiple of 4 floats");
+    if (p.K > 128) return sd3d_set_error(SD3D_ERR_ARG, "gather_gemm: at most 128 kernel offsets");
+    if (!p.nbr && p.K != 1) return sd3d_set_error(SD3D_ERR_ARG, "gather_gemm: identity gather needs K == 1");
+    if (nt <= 0) {   // heuristic: wide tiles when there are plenty of rows, narrow ones to fill the chip otherwise
+        const int sub = (p.Cout + 31) / 32;
+        nt = sub >= 4 ? 4 : sub;
+        while (nt > 1 && cdiv(p.M, 32) * cdiv(sub, nt) < 2048) --nt;
+        if (sub % nt) { for (int c = nt; c >= 1; --c) if (sub % c == 0) { nt = c; break; } }
+    }
+    p.col_groups = (int)cdiv(p.Cout, 32 * nt);
+    const int64_t waves = cdiv(p.M, 32) * p.col_groups;
+    const dim3 grid((unsigned)cdiv(waves, 4)), block(256);
+    switch (nt) {
+        case 1: hipLaunchKernelGGL(gather_gemm_kernel<1>, grid, block, 0, st, p); break;
+        case 2: hipLaunchKernelGGL(gather_gemm_kernel<2>, grid, block, 0, st, p); break;
+        case 3: hipLaunchKernelGGL(gather_gemm_kernel<3>, grid, block, 0, st, p); break;
+        case 4: hipLaunchKernelGGL(gather_gemm_kernel<4>, grid, block, 0, st, p); break;
+        default: return sd3d_set_error(SD3D_ERR_ARG, "gather_gemm: nt must be 1..4");
+    }
+    SD3D_CHECK_LAUNCH();
+    return SD3D_OK;
+}

@@ -1,0 +1,238 @@
+// Stable LSD radix sort of (u64 key, u32 value) pairs + exclusive scan, hand-written for wave64.
+//
+// Used by: voxelisation (sort points along the Z-order curve), superpoint pooling (group points by
+// superpoint id) and post-processing (top-k / score ordering).  These are HBM-bound integer passes
+// over <= a few million elements; 8-bit digits, one histogram + one scatter kernel per digit and
+// one scan of the [256][n_blocks] histogram.  Stability (needed so that points inside one voxel /
+// superpoint stay in ascending point order => deterministic fp32 sums downstream) comes from
+// ranking each wave's elements in chunk order with ballot-built match masks.
+#include "common.h"
+
+#define RS_TILE 2048          // elements per workgroup (4 waves x 8 chunks x 64 lanes)
+#define RS_THREADS 256
+#define SCAN_TILE 2048
+
+// ----------------------------------------------------------------------------------------------
+// block-wide exclusive scan of one int per thread (256 threads)
+// ----------------------------------------------------------------------------------------------
+__device__ static inline int block_excl_scan_256(int v, int* total, int* smem4) {
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    int inc = v;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        int t = __shfl_up(inc, d);
+        if (lane >= d) inc += t;
+    }
+    if (lane == 63) smem4[w] = inc;
+    __syncthreads();
+    int base = 0;
+    for (int i = 0; i < w; ++i) base += smem4[i];
+    *total = smem4[0] + smem4[1] + smem4[2] + smem4[3];
+    __syncthreads();
+    return base + inc - v;
+}
+
+__global__ __launch_bounds__(256) void scan_tile_sums(const int* __restrict__ in, int64_t n_cap,
+                                                      const int* __restrict__ n_dev, int* __restrict__ sums) {
+    __shared__ int sm[4];
+    const int64_t n = n_dev ? min((int64_t)*n_dev, n_cap) : n_cap;
+    const int64_t base = (int64_t)blockIdx.x * SCAN_TILE + threadIdx.x * 8;
+    int s = 0;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) s += (base + i < n) ? in[base + i] : 0;
+    int total;
+    block_excl_scan_256(s, &total, sm);
+    if (threadIdx.x == 0) sums[blockIdx.x] = total;
+}
+
+// single workgroup: exclusive scan of `sums[0..nb)` in place, total -> *total_out
+__global__ __launch_bounds__(256) void scan_sums_inplace(int* __restrict__ sums, int nb, int* __restrict__ total_out) {
+    __shared__ int sm[4];
+    __shared__ int carry_s;
+    if (threadIdx.x == 0) carry_s = 0;
+    __syncthreads();
+    for (int start = 0; start < nb; start += 256 * 8) {
+        const int base = start + threadIdx.x * 8;
+        int v[8], s = 0;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) { v[i] = (base + i < nb) ? sums[base + i] : 0; s += v[i]; }
+        int total;
+        int ex = block_excl_scan_256(s, &total, sm) + carry_s;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) { if (base + i < nb) sums[base + i] = ex; ex += v[i]; }
+        __syncthreads();
+        if (threadIdx.x == 0) carry_s += total;
+        __syncthreads();
+    }
+    if (threadIdx.x == 0 && total_out) *total_out = carry_s;
+}
+
+__global__ __launch_bounds__(256) void scan_apply(const int* __restrict__ in, int64_t n_cap, const int* __restrict__ n_dev,
+                                                  const int* __restrict__ sums, int* __restrict__ out) {
+    __shared__ int sm[4];
+    const int64_t n = n_dev ? min((int64_t)*n_dev, n_cap) : n_cap;
+    const int64_t base = (int64_t)blockIdx.x * SCAN_TILE + threadIdx.x * 8;
+    int v[8], s = 0;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) { v[i] = (base + i < n) ? in[base + i] : 0; s += v[i]; }
+    int total;
+    int ex = block_excl_scan_256(s, &total, sm) + sums[blockIdx.x];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) { if (base + i < n_cap) out[base + i] = ex; ex += v[i]; }
+}
+
+size_t scan_ws_bytes(int64_t n) { return align_up((size_t)cdiv(n, SCAN_TILE) * sizeof(int), 256); }
+
+// out may alias in.  n_dev (optional, device) = live length; elements beyond it count as zero.
+int scan_exclusive_i32(const int* in, int* out, int64_t n_cap, const int* n_dev, int* total_dev, void* ws,
+                       size_t ws_bytes, hipStream_t st) {
+    if (n_cap <= 0) {
+        if (total_dev) (void)hipMemsetAsync(total_dev, 0, sizeof(int), st);
+        return SD3D_OK;
+    }
+    const int nb = (int)cdiv(n_cap, SCAN_TILE);
+    if (ws_bytes < scan_ws_bytes(n_cap)) return sd3d_set_error(SD3D_ERR_WS, "scan workspace too small");
+    int* sums = (int*)ws;
+    hipLaunchKernelGGL(scan_tile_sums, dim3(nb), dim3(256), 0, st, in, n_cap, n_dev, sums);
+    hipLaunchKernelGGL(scan_sums_inplace, dim3(1), dim3(256), 0, st, sums, nb, total_dev);
+    hipLaunchKernelGGL(scan_apply, dim3(nb), dim3(256), 0, st, in, n_cap, n_dev, sums, out);
+    SD3D_CHECK_LAUNCH();
+    return SD3D_OK;
+}
+
+// ----------------------------------------------------------------------------------------------
+// radix sort
+// ----------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(RS_THREADS) void rs_hist(const uint64_t* __restrict__ keys, int64_t n, int shift,
+                                                      int* __restrict__ hist, int nb) {
+    __shared__ int h[256];
+    h[threadIdx.x] = 0;
+    __syncthreads();
+    const int64_t base = (int64_t)blockIdx.x * RS_TILE;
+#pragma unroll
+    for (int c = 0; c < RS_TILE / RS_THREADS; ++c) {
+        const int64_t i = base + c * RS_THREADS + threadIdx.x;
+        if (i < n) atomicAdd(&h[(int)((keys[i] >> shift) & 0xFF)], 1);
+    }
+    __syncthreads();
+    hist[(int64_t)threadIdx.x * nb + blockIdx.x] = h[threadIdx.x];
+}
+
+// Each wave owns 512 consecutive elements (8 chunks of 64) of the block's 2048-element tile.
+__global__ __launch_bounds__(RS_THREADS) void rs_scatter(const uint64_t* __restrict__ keys_in,
+                                                         const uint32_t* __restrict__ vals_in,
+                                                         uint64_t* __restrict__ keys_out, uint32_t* __restrict__ vals_out,
+                                                         int64_t n, int shift, const int* __restrict__ hist_scanned, int nb) {
+    __shared__ int cnt[4][256];     // per-wave digit counts, then running output cursors
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    for (int i = threadIdx.x; i < 4 * 256; i += RS_THREADS) (&cnt[0][0])[i] = 0;
+    __syncthreads();
+    const int64_t wbase = (int64_t)blockIdx.x * RS_TILE + (int64_t)w * 512;
+    uint64_t k[8];
+    uint32_t v[8];
+#pragma unroll
+    for (int c = 0; c < 8; ++c) {
+        const int64_t i = wbase + c * 64 + lane;
+        const bool ok = i < n;
+        k[c] = ok ? keys_in[i] : 0ull;
+        v[c] = ok ? (vals_in ? vals_in[i] : (uint32_t)i) : 0u;
+        if (ok) atomicAdd(&cnt[w][(int)((k[c] >> shift) & 0xFF)], 1);
+    }
+    __syncthreads();
+    {   // thread d: turn counts into starting cursors: global base of (digit, block) + earlier waves
+        const int d = threadIdx.x;
+        int run = hist_scanned[(int64_t)d * nb + blockIdx.x];
+#pragma unroll
+        for (int ww = 0; ww < 4; ++ww) { int c = cnt[ww][d]; cnt[ww][d] = run; run += c; }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int c = 0; c < 8; ++c) {
+        const int64_t i = wbase + c * 64 + lane;
+        const bool ok = i < n;
+        const int d = (int)((k[c] >> shift) & 0xFF);
+        uint64_t same = __ballot(ok);
+#pragma unroll
+        for (int b = 0; b < 8; ++b) {
+            const uint64_t bal = __ballot((d >> b) & 1);
+            same &= ((d >> b) & 1) ? bal : ~bal;
+        }
+        const int rank = __popcll(same & ((1ull << lane) - 1ull));
+        const int num = __popcll(same);
+        int pos = 0;
+        if (ok) pos = cnt[w][d];
+        __builtin_amdgcn_wave_barrier();
+        if (ok && rank == 0) cnt[w][d] = pos + num;
+        __builtin_amdgcn_wave_barrier();
+        if (ok) {
+            keys_out[pos + rank] = k[c];
+            vals_out[pos + rank] = v[c];
+        }
+    }
+}
+
+size_t sort_ws_bytes(int64_t n) {
+    const int64_t nb = cdiv(n > 0 ? n : 1, RS_TILE);
+    return align_up((size_t)nb * 256 * sizeof(int), 256) + scan_ws_bytes(nb * 256);
+}
+
+// Sorts by bits [begin_bit, end_bit).  keys_in/vals_in are clobbered (ping-pong); the result is in
+// keys_out/vals_out.  vals_in == NULL means "value = original index".
+int sort_pairs_u64(uint64_t* keys_in, uint32_t* vals_in, uint64_t* keys_out, uint32_t* vals_out, int64_t n,
+                   int begin_bit, int end_bit, void* ws, size_t ws_bytes, hipStream_t st, uint32_t* vals_scratch) {
+    if (n <= 0) return SD3D_OK;
+    if (ws_bytes < sort_ws_bytes(n)) return sd3d_set_error(SD3D_ERR_WS, "sort workspace too small");
+    int passes = (end_bit - begin_bit + 7) / 8;
+    if (passes < 1) passes = 1;
+    if ((passes & 1) == 0) ++passes;          // odd => result lands in *_out after ping-pong
+    const int nb = (int)cdiv(n, RS_TILE);
+    int* hist = (int*)ws;
+    void* scan_ws = (char*)ws + align_up((size_t)nb * 256 * sizeof(int), 256);
+    const size_t scan_bytes = ws_bytes - align_up((size_t)nb * 256 * sizeof(int), 256);
+    // ping-pong: even passes read A (=*_in) and write B (=*_out), odd passes the other way round;
+    // with an odd pass count the last pass writes *_out.  When vals_in is NULL pass 0 synthesises
+    // value = index and the ping-pong partner of vals_out is vals_scratch.
+    uint32_t* vother = vals_in ? vals_in : vals_scratch;
+    if (!vother && passes > 1) return sd3d_set_error(SD3D_ERR_ARG, "sort: need vals_in or vals_scratch");
+    for (int p = 0; p < passes; ++p) {
+        const int shift = begin_bit + 8 * p;
+        const bool even = (p & 1) == 0;
+        const uint64_t* ksrc = even ? keys_in : keys_out;
+        uint64_t* kdst = even ? keys_out : keys_in;
+        const uint32_t* vsrc = (p == 0) ? vals_in : (even ? vother : vals_out);
+        uint32_t* vdst = even ? vals_out : vother;
+        hipLaunchKernelGGL(rs_hist, dim3(nb), dim3(RS_THREADS), 0, st, ksrc, n, shift, hist, nb);
+        int rc = scan_exclusive_i32(hist, hist, (int64_t)nb * 256, nullptr, nullptr, scan_ws, scan_bytes, st);
+        if (rc) return rc;
+        hipLaunchKernelGGL(rs_scatter, dim3(nb), dim3(RS_THREADS), 0, st, ksrc, vsrc, kdst, vdst, n, shift, hist, nb);
+    }
+    SD3D_CHECK_LAUNCH();
+    return SD3D_OK;
+}
+
+// order-preserving float -> u64 key; descending order when `desc`
+__global__ void f32_to_sortkey(const float* __restrict__ x, int64_t n, int desc, uint64_t* __restrict__ keys) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    uint32_t u = __float_as_uint(x[i]);
+    u = (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+    if (desc) u = ~u;
+    keys[i] = (uint64_t)u;
+}
+__global__ void i64_to_sortkey(const int64_t* __restrict__ x, int64_t n, uint64_t* __restrict__ keys) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) keys[i] = (uint64_t)x[i];
+}
+
+int launch_f32_to_sortkey(const float* x, int64_t n, int desc, uint64_t* keys, hipStream_t st) {
+    if (n <= 0) return SD3D_OK;
+    hipLaunchKernelGGL(f32_to_sortkey, dim3((unsigned)cdiv(n, 256)), dim3(256), 0, st, x, n, desc, keys);
+    SD3D_CHECK_LAUNCH();
+    return SD3D_OK;
+}
+int launch_i64_to_sortkey(const int64_t* x, int64_t n, uint64_t* keys, hipStream_t st) {
+    if (n <= 0) return SD3D_OK;
+    hipLaunchKernelGGL(i64_to_sortkey, dim3((unsigned)cdiv(n, 256)), dim3(256), 0, st, x, n, keys);
+    SD3D_CHECK_LAUNCH();
+    return SD3D_OK;
+}

@@ -1,0 +1,415 @@
+// Sparse-voxel coordinate machinery (reference: third-party MinkowskiEngine / spconv calls at
+// segdino3d/models/backbone/minkunet.py:624-631 and spconvunet.py:283-315; SURVEY.md 2b K1, K2, K5,
+// K10, K11, K13).  All kernels are integer / gather passes bound by HBM bandwidth and latency:
+//   scene_stats   : min / max / sum of xyz                                  (1 read of N*3 floats)
+//   voxel_keys    : floor-quantise + 48-bit Z-order key                     (N*3 f32 -> N u64 + N*3 i32)
+//   mark/emit     : run-length unique over SORTED keys -> voxel ids, segment starts, inverse map
+//   coarsen       : parent level = unique(key >> 3) (no new sort: Z-order keeps children adjacent)
+//   hash_insert   : open-addressing table key -> voxel id (linear probing, u64 CAS)
+//   kernel_map    : nbr[k][v] = id of voxel at coord(v) + offset_k (or -1), K*V hash probes
+//   stride_maps   : 2x2x2 stride-2 down / transposed-up neighbour tables from the parent array
+//   voxel_mean    : per-voxel unweighted mean of point features (wave per voxel, ascending point order)
+//   pool          : fused devoxelise + superpoint mean of features and quantised positions
+#include "common.h"
+
+// ---------------------------------------------------------------------------------------------
+// scene statistics: stats[0:3]=min xyz, [3:6]=max xyz, [6:9]=sum xyz (fp32)
+// ---------------------------------------------------------------------------------------------
+#define STAT_BLOCKS 256
+__device__ static inline float wave_min(float v) {
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) v = fminf(v, __shfl_xor(v, d));
+    return v;
+}
+__device__ static inline float wave_max(float v) {
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) v = fmaxf(v, __shfl_xor(v, d));
+    return v;
+}
+__device__ static inline float wave_sum(float v) {
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) v += __shfl_xor(v, d);
+    return v;
+}
+
+__global__ __launch_bounds__(256) void scene_stats_partial(const float* __restrict__ pts, int ld, int64_t n,
+                                                           float* __restrict__ part /*[gridDim.x][9]*/) {
+    __shared__ float sm[4][9];
+    float lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY}, su[3] = {0.f, 0.f, 0.f};
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+#pragma unroll
+        for (int a = 0; a < 3; ++a) {
+            const float x = pts[i * ld + a];
+            lo[a] = fminf(lo[a], x);
+            hi[a] = fmaxf(hi[a], x);
+            su[a] += x;
+        }
+    }
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+        const float l = wave_min(lo[a]), h = wave_max(hi[a]), s = wave_sum(su[a]);
+        if (lane == 0) { sm[w][a] = l; sm[w][3 + a] = h; sm[w][6 + a] = s; }
+    }
+    __syncthreads();
+    if (threadIdx.x < 9) {
+        const int c = threadIdx.x;
+        float r = sm[0][c];
+        for (int ww = 1; ww < 4; ++ww)
+            r = c < 3 ? fminf(r, sm[ww][c]) : (c < 6 ? fmaxf(r, sm[ww][c]) : r + sm[ww][c]);
+        part[blockIdx.x * 9 + c] = r;
+    }
+}
+__global__ void scene_stats_final(const float* __restrict__ part, int nb, float* __restrict__ stats) {
+    const int c = threadIdx.x;
+    if (c >= 9) return;
+    float r = part[c];
+    for (int b = 1; b < nb; ++b) {
+        const float v = part[b * 9 + c];
+        r = c < 3 ? fminf(r, v) : (c < 6 ? fmaxf(r, v) : r + v);
+    }
+    stats[c] = r;
+}
+
+int launch_scene_stats(const float* pts, int ld, int64_t n, float* stats, void* ws, size_t ws_bytes, hipStream_t st) {
+    if (n <= 0) return sd3d_set_error(SD3D_ERR_ARG, "scene_stats: empty scene");
+    if (ws_bytes < STAT_BLOCKS * 9 * sizeof(float)) return sd3d_set_error(SD3D_ERR_WS, "scene_stats workspace");
+    const int nb = (int)min((int64_t)STAT_BLOCKS, cdiv(n, 256));
+    hipLaunchKernelGGL(scene_stats_partial, dim3(nb), dim3(256), 0, st, pts, ld, n, (float*)ws);
+    hipLaunchKernelGGL(scene_stats_final, dim3(1), dim3(64), 0, st, (const float*)ws, nb, stats);
+    SD3D_CHECK_LAUNCH();
+    return SD3D_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// voxel keys.  c = floor(x * inv_voxel)  (reference runs `coords / voxel_size` on a CUDA tensor, where
+// ATen's div-by-CPU-scalar kernel multiplies by the fp32 reciprocal; see DESIGN.md "quantisation").
+// shift_to_min != 0 (spconv path, spconvunet.py:286): c = floor((x - min_x) * inv_voxel).
+// The key origin is a multiple of 16 (the coarsest tensor stride) so that floor(c / 2^l) of absolute
+// coordinates equals (c - origin) >> l + origin / 2^l at every level, plus 32 voxels of margin so that
+// +-2 neighbour offsets at any level never underflow.
+// ---------------------------------------------------------------------------------------------
+__device__ static inline int floor_div16(int v) { return (v >= 0) ? (v / 16) : -((-v + 15) / 16); }
+
+__global__ __launch_bounds__(256) void voxel_keys_kernel(const float* __restrict__ pts, int ld, int64_t n, float inv_voxel,
+                                                         const float* __restrict__ stats, int shift_to_min, int batch,
+                                                         int32_t* __restrict__ origin_out, uint64_t* __restrict__ keys,
+                                                         int32_t* __restrict__ icoords, int32_t* __restrict__ err_flag) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    int org[3];
+    float mn[3];
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+        mn[a] = shift_to_min ? stats[a] : 0.f;
+        const int cmin = (int)floorf((stats[a] - mn[a]) * inv_voxel);
+        org[a] = floor_div16(cmin) * 16 - 32;
+    }
+    if (i == 0 && origin_out) { origin_out[0] = org[0]; origin_out[1] = org[1]; origin_out[2] = org[2]; }
+    if (i >= n) return;
+    uint32_t r[3];
+    bool bad = false;
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+        const int c = (int)floorf((pts[i * ld + a] - mn[a]) * inv_voxel);
+        if (icoords) icoords[i * 3 + a] = c;
+        const int rel = c - org[a];
+        bad |= (rel < 32) | (rel >= 65536 - 64);
+        r[a] = (uint32_t)rel & 0xFFFFu;
+    }
+    if (bad) atomicOr(err_flag, 1);
+    keys[i] = morton_encode(r[0], r[1], r[2]) | ((uint64_t)(batch & 0xFF) << SD3D_MORTON_BITS);
+}
+
+int launch_voxel_keys(const float* pts, int ld, int64_t n, float inv_voxel, const float* stats, int shift_to_min, int batch,
+                      int32_t* origin, uint64_t* keys, int32_t* icoords, int32_t* err_flag, hipStream_t st) {
+    if (n <= 0) return sd3d_set_error(SD3D_ERR_ARG, "voxel_keys: empty scene");
+    hipLaunchKernelGGL(voxel_keys_kernel, dim3((unsigned)cdiv(n, 256)), dim3(256), 0, st, pts, ld, n, inv_voxel, stats,
+                       shift_to_min, batch, origin, keys, icoords, err_flag);
+    SD3D_CHECK_LAUNCH();
+    return SD3D_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// run-length unique over sorted keys (optionally on key >> 3 : parent level)
+// ---------------------------------------------------------------------------------------------
+__device__ static inline uint64_t level_key(uint64_t k, int shift) {
+    return ((k & SD3D_MORTON_MASK) >> shift) | (k & ~SD3D_MORTON_MASK);
+}
+
+__global__ __launch_bounds__(256) void mark_heads(const uint64_t* __restrict__ keys, int64_t n_cap,
+                                                  const int* __restrict__ n_dev, int shift, int* __restrict__ flags) {
+    const int64_t n = n_dev ? min((int64_t)*n_dev, n_cap) : n_cap;
+    const int64_t j = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (j >= n_cap) return;
+    int f = 0;
+    if (j < n) f = (j == 0) || (level_key(keys[j], shift) != level_key(keys[j - 1], shift));
+    flags[j] = f;
+}
+
+// excl = exclusive scan of flags.  id(j) = excl[j] + flags[j] - 1.
+//   ukeys[id] = level_key(keys[j])        at heads
+//   seg_start[id] = j at heads ; seg_start[V] = n            (optional)
+//   map[ src_idx ? src_idx[j] : j ] = id                      (inverse map / parent array)
+__global__ __launch_bounds__(256) void emit_unique(const uint64_t* __restrict__ keys, const uint32_t* __restrict__ src_idx,
+                                                   int64_t n_cap, const int* __restrict__ n_dev, int shift,
+                                                   const int* __restrict__ flags, const int* __restrict__ excl,
+                                                   uint64_t* __restrict__ ukeys, int32_t* __restrict__ seg_start,
+                                                   int32_t* __restrict__ map) {
+    const int64_t n = n_dev ? min((int64_t)*n_dev, n_cap) : n_cap;
+    const int64_t j = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (j >= n) return;
+    const int f = flags[j];
+    const int id = excl[j] + f - 1;
+    if (f) {
+        ukeys[id] = level_key(keys[j], shift);
+        if (seg_start) seg_start[id] = (int32_t)j;
+    }
+    if (map) map[src_idx ? (int64_t)src_idx[j] : j] = id;
+    if (j == n - 1 && seg_start) seg_start[id + 1] = (int32_t)n;
+}
+
+int scan_exclusive_i32(const int* in, int* out, int64_t n_cap, const int* n_dev, int* total_dev, void* ws,
+                       size_t ws_bytes, hipStream_t st);
+size_t scan_ws_bytes(int64_t n);
+
+size_t unique_ws_bytes(int64_t n_cap) {
+    return 2 * align_up((size_t)n_cap * sizeof(int), 256) + scan_ws_bytes(n_cap);
+}
+
+int launch_unique_sorted(const uint64_t* keys, const uint32_t* src_idx, int64_t n_cap, const int* n_dev, int shift,
+                         uint64_t* ukeys, int32_t* seg_start, int32_t* map, int32_t* n_unique_dev, void* ws,
+                         size_t ws_bytes, hipStream_t st) {
+    if (n_cap <= 0) return sd3d_set_error(SD3D_ERR_ARG, "unique_sorted: n_cap <= 0");
+    if (ws_bytes < unique_ws_bytes(n_cap)) return sd3d_set_error(SD3D_ERR_WS, "unique_sorted workspace too small");
+    const size_t a = align_up((size_t)n_cap * sizeof(int), 256);
+    int* flags = (int*)ws;
+    int* excl = (int*)((char*)ws + a);
+    void* sws = (char*)ws + 2 * a;
+    const unsigned nb = (unsigned)cdiv(n_cap, 256);
+    hipLaunchKernelGGL(mark_heads, dim3(nb), dim3(256), 0, st, keys, n_cap, n_dev, shift, flags);
+    int rc = scan_exclusive_i32(flags, excl, n_cap, n_dev, n_unique_dev, sws, ws_bytes - 2 * a, st);
+    if (rc) return rc;
+    hipLaunchKernelGGL(emit_unique, dim3(nb), dim3(256), 0, st, keys, src_idx, n_cap, n_dev, shift, flags, excl, ukeys,
+                       seg_start, map);
+    SD3D_CHECK_LAUNCH();
+    return SD3D_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// hash table (keys u64, values i32), capacity = power of two, EMPTY = all ones
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void hash_insert(const uint64_t* __restrict__ ukeys, int64_t n,
+                                                   unsigned long long* __restrict__ tkeys, int32_t* __restrict__ tvals,
+                                                   uint32_t mask) {
+    const int64_t v = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (v >= n) return;
+    const uint64_t key = ukeys[v];
+    uint32_t slot = hash_u64(key) & mask;
+    for (uint32_t probe = 0; probe <= mask; ++probe) {
+        const unsigned long long prev = atomicCAS(&tkeys[slot], (unsigned long long)SD3D_EMPTY_KEY, (unsigned long long)key);
+        if (prev == SD3D_EMPTY_KEY || prev == key) { tvals[slot] = (int32_t)v; return; }
+        slot = (slot + 1) & mask;
+    }
+}
+
+__device__ static inline int hash_lookup(const uint64_t* __restrict__ tkeys, const int32_t* __restrict__ tvals,
+                                         uint32_t mask, uint64_t key) {
+    uint32_t slot = hash_u64(key) & mask;
+    for (uint32_t probe = 0; probe <= mask; ++probe) {
+        const uint64_t k = tkeys[slot];
+        if (k == key) return tvals[slot];
+        if (k == SD3D_EMPTY_KEY) return -1;
+        slot = (slot + 1) & mask;
+    }
+    return -1;
+}
+
+int launch_hash_build(const uint64_t* ukeys, int64_t n, uint64_t* tkeys, int32_t* tvals, int64_t capacity, hipStream_t st) {
+    if (capacity <= 0 || (capacity & (capacity - 1)) || capacity < n + 1)
+        return sd3d_set_error(SD3D_ERR_ARG, "hash_build: capacity must be a power of two > n");
+    (void)hipMemsetAsync(tkeys, 0xFF, (size_t)capacity * sizeof(uint64_t), st);
+    if (n > 0)
+        hipLaunchKernelGGL(hash_insert, dim3((unsigned)cdiv(n, 256)), dim3(256), 0, st, ukeys, n,
+                           (unsigned long long*)tkeys, tvals, (uint32_t)(capacity - 1));
+    SD3D_CHECK_LAUNCH();
+    return SD3D_OK;
+}
+
+// nbr[k * n_out + v] = id (in the table's level) of the voxel at coord(v) + off[k], or -1.
+// Coordinates are in units of the level's own stride (the keys of level l hold (c - origin) >> l).
+__global__ __launch_bounds__(256) void kernel_map_kernel(const uint64_t* __restrict__ okeys, int64_t n_out,
+                                                         const uint64_t* __restrict__ tkeys, const int32_t* __restrict__ tvals,
+                                                         uint32_t mask, const int8_t* __restrict__ offs, int K,
+                                                         int32_t* __restrict__ nbr) {
+    const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (t >= (int64_t)K * n_out) return;
+    const int k = (int)(t / n_out);
+    const int64_t v = t - (int64_t)k * n_out;
+    const uint64_t key = okeys[v];
+    uint32_t x, y, z;
+    morton_decode(key & SD3D_MORTON_MASK, x, y, z);
+    const int nx = (int)x + offs[k * 3 + 0], ny = (int)y + offs[k * 3 + 1], nz = (int)z + offs[k * 3 + 2];
+    int id = -1;
+    if (((nx | ny | nz) >= 0) && nx < 65536 && ny < 65536 && nz < 65536) {
+        const uint64_t q = morton_encode((uint32_t)nx, (uint32_t)ny, (uint32_t)nz) | (key & ~SD3D_MORTON_MASK);
+        id = hash_lookup(tkeys, tvals, mask, q);
+    }
+    nbr[t] = id;
+}
+
+int launch_kernel_map(const uint64_t* okeys, int64_t n_out, const uint64_t* tkeys, const int32_t* tvals, int64_t capacity,
+                      const int8_t* offs_dev, int K, int32_t* nbr, hipStream_t st) {
+    if (n_out <= 0 || K <= 0) return SD3D_OK;
+    const int64_t total = (int64_t)K * n_out;
+    hipLaunchKernelGGL(kernel_map_kernel, dim3((unsigned)cdiv(total, 256)), dim3(256), 0, st, okeys, n_out, tkeys, tvals,
+                       (uint32_t)(capacity - 1), offs_dev, K, nbr);
+    SD3D_CHECK_LAUNCH();
+    return SD3D_OK;
+}
+
+// Stride-2, kernel-2 maps from the parent array.  The child's position inside its parent is the low
+// three Z-order bits (x | y<<1 | z<<2); perm8 maps it to the weight index of the library whose
+// checkpoint is loaded (identity for MinkowskiEngine's x-fastest order, bit-reversal for spconv).
+//   nbr_down[k][p] = child j of p sitting at kernel offset k (else -1)      (conv k=2 s=2)
+//   nbr_up[k][j]   = parent p of j if j sits at offset k (else -1)          (transposed conv)
+__global__ __launch_bounds__(256) void stride_maps_kernel(const uint64_t* __restrict__ fkeys, const int32_t* __restrict__ parent,
+                                                          int64_t n_fine, int64_t n_coarse, const int32_t* __restrict__ perm8,
+                                                          int32_t* __restrict__ nbr_down, int32_t* __restrict__ nbr_up) {
+    const int64_t j = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (j >= n_fine) return;
+    const int k = perm8[(int)(fkeys[j] & 7ull)];
+    const int p = parent[j];
+    if (p < 0) return;       // child dropped by the library's output-extent rule
+    if (nbr_down) nbr_down[(int64_t)k * n_coarse + p] = (int32_t)j;
+    if (nbr_up) nbr_up[(int64_t)k * n_fine + j] = p;
+}
+
+int launch_stride_maps(const uint64_t* fkeys, const int32_t* parent, int64_t n_fine, int64_t n_coarse, const int32_t* perm8,
+                       int32_t* nbr_down, int32_t* nbr_up, hipStream_t st) {
+    if (nbr_down) (void)hipMemsetAsync(nbr_down, 0xFF, (size_t)8 * n_coarse * sizeof(int32_t), st);
+    if (nbr_up) (void)hipMemsetAsync(nbr_up, 0xFF, (size_t)8 * n_fine * sizeof(int32_t), st);
+    if (n_fine > 0)
+        hipLaunchKernelGGL(stride_maps_kernel, dim3((unsigned)cdiv(n_fine, 256)), dim3(256), 0, st, fkeys, parent, n_fine,
+                           n_coarse, perm8, nbr_down, nbr_up);
+    SD3D_CHECK_LAUNCH();
+    return SD3D_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// per-voxel mean of the assembled point feature row (one wave per voxel)
+//   mode 0: [rgb(3) | f2d(F)]              Res16UNet34C early_fusion (minkunet.py:616-618)
+//   mode 1: [rgb(3)]                       only_rgb
+//   mode 2: [rgb(3) | xyz - mean(3) | f2d] SpConvUNet early_fusion (spconvunet.py:287)
+// Members of a voxel are visited in ascending point index (stable sort) => deterministic sum.
+// Columns C..ld_out-1 are written as zero (K padding for the first convolution).
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void voxel_mean_kernel(const float* __restrict__ pts, int ld_pts,
+                                                         const float* __restrict__ f2d, int F, int mode,
+                                                         const float* __restrict__ stats, float inv_n,
+                                                         const uint32_t* __restrict__ sidx, const int32_t* __restrict__ seg_start,
+                                                         int64_t n_vox, float* __restrict__ out, int ld_out) {
+    const int lane = threadIdx.x & 63;
+    const int64_t v = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (v >= n_vox) return;
+    const int j0 = seg_start[v], j1 = seg_start[v + 1];
+    const int C = (mode == 0) ? 3 + F : (mode == 1 ? 3 : 6 + F);
+    const float cnt = (float)(j1 - j0);
+    for (int c = lane; c < ld_out; c += 64) {
+        float s = 0.f;
+        if (c < C) {
+            for (int j = j0; j < j1; ++j) {
+                const int64_t p = sidx[j];
+                float x;
+                if (c < 3) x = pts[p * ld_pts + 3 + c];
+                else if (mode == 2 && c < 6) x = pts[p * ld_pts + (c - 3)] - stats[6 + (c - 3)] * inv_n;
+                else x = f2d[p * F + (c - (mode == 2 ? 6 : 3))];
+                s += x;
+            }
+            s = s / cnt;                      // sum / count, like the reference's average pooling
+        }
+        out[v * ld_out + c] = s;
+    }
+}
+
+int launch_voxel_mean(const float* pts, int ld_pts, const float* f2d, int F, int mode, const float* stats, int64_t n_points,
+                      const uint32_t* sidx, const int32_t* seg_start, int64_t n_vox, float* out, int ld_out, hipStream_t st) {
+    if (n_vox <= 0) return SD3D_OK;
+    if (mode != 1 && !f2d) return sd3d_set_error(SD3D_ERR_ARG, "voxel_mean: 2D features missing");
+    hipLaunchKernelGGL(voxel_mean_kernel, dim3((unsigned)cdiv(n_vox, 4)), dim3(256), 0, st, pts, ld_pts, f2d, F, mode, stats,
+                       1.0f / (float)n_points, sidx, seg_start, n_vox, out, ld_out);
+    SD3D_CHECK_LAUNCH();
+    return SD3D_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// superpoint pooling: segment starts from sorted superpoint ids, then fused devoxelise
+// (`x.slice(field)` = F[inverse[p]]) + scatter_mean of features and of floor-quantised positions
+// (minkunet.py:631-656).  One wave per superpoint; the wave's two 32-lane halves take alternate
+// members (C/4 lanes x float4 each, 3 more lanes for xyz) and are combined with one cross-half
+// shuffle, so the summation order is fixed.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void segment_starts_kernel(const uint64_t* __restrict__ sorted_ids, int64_t n, int64_t S,
+                                                             int32_t* __restrict__ start /*[S+1]*/) {
+    const int64_t j = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (j > n) return;
+    const int64_t prev = (j == 0) ? -1 : (int64_t)sorted_ids[j - 1];
+    int64_t cur = (j == n) ? S : (int64_t)sorted_ids[j];
+    if (cur > S) cur = S;
+    for (int64_t s = prev + 1; s <= cur; ++s) start[s] = (int32_t)j;
+}
+
+__global__ __launch_bounds__(256) void pool_superpoints_kernel(const float* __restrict__ feat, int ld_feat, int C,
+                                                               const int32_t* __restrict__ inverse,
+                                                               const int32_t* __restrict__ icoords, float voxel_size,
+                                                               const uint32_t* __restrict__ sidx, const int32_t* __restrict__ start,
+                                                               int64_t S, float* __restrict__ out_feat, float* __restrict__ out_pos) {
+    const int lane = threadIdx.x & 63;
+    const int64_t s = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (s >= S) return;
+    const int half = lane >> 5, li = lane & 31;
+    const int nvec = C >> 2;
+    const int j0 = start[s], j1 = start[s + 1];
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    float pacc = 0.f;
+    for (int j = j0 + half; j < j1; j += 2) {
+        const int64_t p = sidx[j];
+        if (li < nvec) {
+            const int64_t v = inverse[p];
+            const f32x4 x = *(const f32x4*)(feat + v * ld_feat + li * 4);
+            acc += x;
+        } else if (li < nvec + 3) {
+            pacc += (float)icoords[p * 3 + (li - nvec)] * voxel_size;
+        }
+    }
+#pragma unroll
+    for (int q = 0; q < 4; ++q) acc[q] += __shfl_xor(acc[q], 32);
+    pacc += __shfl_xor(pacc, 32);
+    const int cnt = j1 - j0;
+    const float den = (float)(cnt > 0 ? cnt : 1);       // torch_scatter: count clamped to >= 1
+    if (half == 0) {
+        if (li < nvec) {
+            f32x4 r = acc / den;
+            *(f32x4*)(out_feat + s * C + li * 4) = r;
+        } else if (li < nvec + 3 && out_pos) {
+            out_pos[s * 3 + (li - nvec)] = pacc / den;
+        }
+    }
+}
+
+int launch_segment_starts(const uint64_t* sorted_ids, int64_t n, int64_t S, int32_t* start, hipStream_t st) {
+    hipLaunchKernelGGL(segment_starts_kernel, dim3((unsigned)cdiv(n + 1, 256)), dim3(256), 0, st, sorted_ids, n, S, start);
+    SD3D_CHECK_LAUNCH();
+    return SD3D_OK;
+}
+
+int launch_pool_superpoints(const float* feat, int ld_feat, int C, const int32_t* inverse, const int32_t* icoords,
+                            float voxel_size, const uint32_t* sidx, const int32_t* start, int64_t S, float* out_feat,
+                            float* out_pos, hipStream_t st) {
+    if (S <= 0) return SD3D_OK;
+    if ((C & 3) || (C >> 2) + 3 > 32 || (ld_feat & 3))
+        return sd3d_set_error(SD3D_ERR_ARG, "pool_superpoints: C must be a multiple of 4 and <= 116");
+    hipLaunchKernelGGL(pool_superpoints_kernel, dim3((unsigned)cdiv(S, 4)), dim3(256), 0, st, feat, ld_feat, C, inverse,
+                       icoords, voxel_size, sidx, start, S, out_feat, out_pos);
+    SD3D_CHECK_LAUNCH();
+    return SD3D_OK;
+}

@@ -1,0 +1,253 @@
+"""Python operator layer over the C ABI: torch tensors in, torch tensors out.
+
+torch is used here for device memory (caching allocator) and the current HIP stream only; all
+arithmetic happens in libsegdino3d_hip.so.  Every op raises if a tensor is not on a HIP device -
+there is deliberately no CPU path (the CPU restatement is oracle/, test infrastructure).
+"""
+from __future__ import annotations
+
+from typing import Optional
+
+import torch
+
+from . import _lib
+
+ACT = {None: 0, "none": 0, "relu": 1, "gelu": 2, "sigmoid": 3}
+
+
+def _stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _ptr(t: Optional[torch.Tensor], dtype=None, name="tensor"):
+    if t is None:
+        return None
+    if not t.is_cuda:
+        raise RuntimeError(f"{name}: expected a tensor on the HIP device, got {t.device} (no CPU fallback)")
+    if dtype is not None and t.dtype != dtype:
+        raise TypeError(f"{name}: expected {dtype}, got {t.dtype}")
+    if not t.is_contiguous():
+        raise ValueError(f"{name}: must be contiguous")
+    return t.data_ptr()
+
+
+def _rows(t: torch.Tensor, name="tensor"):
+    """2-D fp32 tensor whose rows may be strided (last dim contiguous) -> (ptr, ld)."""
+    if not t.is_cuda:
+        raise RuntimeError(f"{name}: expected a tensor on the HIP device, got {t.device} (no CPU fallback)")
+    if t.dtype != torch.float32 or t.dim() != 2 or t.stride(1) != 1:
+        raise ValueError(f"{name}: expected a 2-D fp32 tensor with contiguous rows")
+    return t.data_ptr(), t.stride(0)
+
+
+class Workspace:
+    """Grow-only scratch buffer (bytes) per device."""
+
+    def __init__(self):
+        self.buf = None
+
+    def get(self, nbytes: int, device):
+        nbytes = max(int(nbytes), 256)
+        if self.buf is None or self.buf.numel() < nbytes or self.buf.device != torch.device(device):
+            self.buf = torch.empty(nbytes, dtype=torch.uint8, device=device)
+        return self.buf
+
+
+_WS = Workspace()
+
+
+# --------------------------------------------------------------------------------------------
+# sort / scan
+# --------------------------------------------------------------------------------------------
+def sort_pairs(keys: torch.Tensor, vals: Optional[torch.Tensor] = None, begin_bit=0, end_bit=64):
+    """Stable ascending sort of uint64-as-int64 keys; returns (sorted_keys, sorted_vals[int32]).
+    `keys` (int64 storage of u64 bit patterns) is clobbered."""
+    lib = _lib.load()
+    n = keys.numel()
+    dev = keys.device
+    keys_out = torch.empty_like(keys)
+    vals_out = torch.empty(n, dtype=torch.int32, device=dev)
+    scratch = torch.empty(n, dtype=torch.int32, device=dev) if vals is None else None
+    ws = _WS.get(lib.sd3d_sort_ws_bytes(n), dev)
+    _lib.check(lib.sd3d_sort_pairs_u64(_ptr(keys, torch.int64, "keys"), _ptr(vals, torch.int32, "vals"),
+                                       _ptr(keys_out), _ptr(vals_out), _ptr(scratch), n, begin_bit, end_bit,
+                                       ws.data_ptr(), ws.numel(), _stream()), "sort_pairs")
+    return keys_out, vals_out
+
+
+def scan_exclusive(x: torch.Tensor):
+    lib = _lib.load()
+    n = x.numel()
+    out = torch.empty_like(x)
+    total = torch.empty(1, dtype=torch.int32, device=x.device)
+    ws = _WS.get(lib.sd3d_scan_ws_bytes(n), x.device)
+    _lib.check(lib.sd3d_scan_exclusive_i32(_ptr(x, torch.int32, "x"), _ptr(out), n, _ptr(total), ws.data_ptr(),
+                                           ws.numel(), _stream()), "scan_exclusive")
+    return out, total
+
+
+def keys_from_f32(x: torch.Tensor, descending=False):
+    lib = _lib.load()
+    keys = torch.empty(x.numel(), dtype=torch.int64, device=x.device)
+    _lib.check(lib.sd3d_keys_from_f32(_ptr(x, torch.float32, "x"), x.numel(), int(descending), _ptr(keys), _stream()),
+               "keys_from_f32")
+    return keys
+
+
+def keys_from_i64(x: torch.Tensor):
+    lib = _lib.load()
+    keys = torch.empty(x.numel(), dtype=torch.int64, device=x.device)
+    _lib.check(lib.sd3d_keys_from_i64(_ptr(x, torch.int64, "x"), x.numel(), _ptr(keys), _stream()), "keys_from_i64")
+    return keys
+
+
+# --------------------------------------------------------------------------------------------
+# voxelisation / coordinate maps
+# --------------------------------------------------------------------------------------------
+def scene_stats(points: torch.Tensor):
+    """points [N, >=3] fp32 -> stats[9] = (min xyz, max xyz, sum xyz)."""
+    lib = _lib.load()
+    p, ld = _rows(points, "points")
+    stats = torch.empty(9, dtype=torch.float32, device=points.device)
+    ws = _WS.get(lib.sd3d_scene_stats_ws_bytes(), points.device)
+    _lib.check(lib.sd3d_scene_stats(p, ld, points.shape[0], _ptr(stats), ws.data_ptr(), ws.numel(), _stream()),
+               "scene_stats")
+    return stats
+
+
+def voxel_keys(points, inv_voxel: float, stats, shift_to_min=False, batch_index=0, want_icoords=True):
+    lib = _lib.load()
+    p, ld = _rows(points, "points")
+    n = points.shape[0]
+    dev = points.device
+    keys = torch.empty(n, dtype=torch.int64, device=dev)
+    icoords = torch.empty(n, 3, dtype=torch.int32, device=dev) if want_icoords else None
+    origin = torch.empty(3, dtype=torch.int32, device=dev)
+    err = torch.zeros(1, dtype=torch.int32, device=dev)
+    _lib.check(lib.sd3d_voxel_keys(p, ld, n, float(inv_voxel), _ptr(stats, torch.float32, "stats"), int(shift_to_min),
+                                   int(batch_index), _ptr(origin), _ptr(keys), _ptr(icoords), _ptr(err), _stream()),
+               "voxel_keys")
+    return keys, icoords, origin, err
+
+
+def unique_sorted(keys, src_idx, n_cap, n_dev=None, shift=0, want_seg_start=False, want_map=True, map_size=None):
+    """Run-length unique over sorted keys.  Returns (ukeys[n_cap], seg_start[n_cap+1]|None, map|None, n_unique[1])."""
+    lib = _lib.load()
+    dev = keys.device
+    ukeys = torch.empty(n_cap, dtype=torch.int64, device=dev)
+    seg = torch.empty(n_cap + 1, dtype=torch.int32, device=dev) if want_seg_start else None
+    mp = torch.empty(map_size if map_size is not None else n_cap, dtype=torch.int32, device=dev) if want_map else None
+    nuniq = torch.empty(1, dtype=torch.int32, device=dev)
+    ws = _WS.get(lib.sd3d_unique_ws_bytes(n_cap), dev)
+    _lib.check(lib.sd3d_unique_sorted(_ptr(keys, torch.int64, "keys"), _ptr(src_idx, torch.int32, "src_idx"), n_cap,
+                                      _ptr(n_dev, torch.int32, "n_dev"), shift, _ptr(ukeys), _ptr(seg), _ptr(mp),
+                                      _ptr(nuniq), ws.data_ptr(), ws.numel(), _stream()), "unique_sorted")
+    return ukeys, seg, mp, nuniq
+
+
+def hash_build(ukeys: torch.Tensor, n: int):
+    lib = _lib.load()
+    cap = 1
+    while cap < 2 * n + 2:
+        cap *= 2
+    tk = torch.empty(cap, dtype=torch.int64, device=ukeys.device)
+    tv = torch.empty(cap, dtype=torch.int32, device=ukeys.device)
+    _lib.check(lib.sd3d_hash_build(_ptr(ukeys, torch.int64, "ukeys"), n, _ptr(tk), _ptr(tv), cap, _stream()), "hash_build")
+    return tk, tv
+
+
+def kernel_map(out_keys, n_out, table, offsets_i8):
+    """offsets_i8: int8 [K,3] device tensor.  Returns nbr int32 [K, n_out]."""
+    lib = _lib.load()
+    tk, tv = table
+    K = offsets_i8.shape[0]
+    nbr = torch.empty(K, n_out, dtype=torch.int32, device=out_keys.device)
+    _lib.check(lib.sd3d_kernel_map(_ptr(out_keys, torch.int64, "out_keys"), n_out, _ptr(tk), _ptr(tv), tk.numel(),
+                                   _ptr(offsets_i8, torch.int8, "offsets"), K, _ptr(nbr), _stream()), "kernel_map")
+    return nbr
+
+
+def stride_maps(fine_keys, parent, n_fine, n_coarse, perm8, want_down=True, want_up=True):
+    lib = _lib.load()
+    dev = fine_keys.device
+    down = torch.empty(8, n_coarse, dtype=torch.int32, device=dev) if want_down else None
+    up = torch.empty(8, n_fine, dtype=torch.int32, device=dev) if want_up else None
+    _lib.check(lib.sd3d_stride_maps(_ptr(fine_keys, torch.int64, "fine_keys"), _ptr(parent, torch.int32, "parent"),
+                                    n_fine, n_coarse, _ptr(perm8, torch.int32, "perm8"), _ptr(down), _ptr(up),
+                                    _stream()), "stride_maps")
+    return down, up
+
+
+def voxel_mean(points, feats2d, mode, stats, sorted_idx, seg_start, n_vox, ld_out):
+    lib = _lib.load()
+    p, ld = _rows(points, "points")
+    F = 0 if feats2d is None else feats2d.shape[1]
+    out = torch.empty(n_vox, ld_out, dtype=torch.float32, device=points.device)
+    _lib.check(lib.sd3d_voxel_mean(p, ld, _ptr(feats2d, torch.float32, "feats2d"), F, mode,
+                                   _ptr(stats, torch.float32, "stats"), points.shape[0],
+                                   _ptr(sorted_idx, torch.int32, "sorted_idx"), _ptr(seg_start, torch.int32, "seg_start"),
+                                   n_vox, _ptr(out), ld_out, _stream()), "voxel_mean")
+    return out
+
+
+def segment_starts(sorted_ids, n, S):
+    lib = _lib.load()
+    start = torch.empty(S + 1, dtype=torch.int32, device=sorted_ids.device)
+    _lib.check(lib.sd3d_segment_starts(_ptr(sorted_ids, torch.int64, "sorted_ids"), n, S, _ptr(start), _stream()),
+               "segment_starts")
+    return start
+
+
+def pool_superpoints(feat, C, inverse, icoords, voxel_size, sorted_idx, start, S):
+    lib = _lib.load()
+    f, ld = _rows(feat, "feat")
+    out_feat = torch.empty(S, C, dtype=torch.float32, device=feat.device)
+    out_pos = torch.empty(S, 3, dtype=torch.float32, device=feat.device)
+    _lib.check(lib.sd3d_pool_superpoints(f, ld, C, _ptr(inverse, torch.int32, "inverse"),
+                                         _ptr(icoords, torch.int32, "icoords"), float(voxel_size),
+                                         _ptr(sorted_idx, torch.int32, "sorted_idx"), _ptr(start, torch.int32, "start"),
+                                         S, _ptr(out_feat), _ptr(out_pos), _stream()), "pool_superpoints")
+    return out_feat, out_pos
+
+
+# --------------------------------------------------------------------------------------------
+# gather-GEMM
+# --------------------------------------------------------------------------------------------
+def gather_gemm(x, wt, nbr=None, x2=None, scale=None, shift=None, res=None, act=None, out=None, M=None, nt=0):
+    """out[r, n] = act(scale[n] * sum_k sum_c X[nbr[k, r], c] * wt[k, n, c] + shift[n] + res[r, n]).
+
+    x [V_in, C0] (rows may be strided), optional x2 [V_in, C1] = concatenated channels,
+    wt [K, Cout, Cin] contiguous, nbr int32 [K, M] or None (identity rows, K = 1)."""
+    lib = _lib.load()
+    if wt.dim() == 2:
+        wt = wt.unsqueeze(0)
+    K, Cout, Cin = wt.shape
+    p0, ld0 = _rows(x, "x")
+    C0 = x.shape[1]
+    p1, ld1 = (None, 0)
+    if x2 is not None:
+        p1, ld1 = _rows(x2, "x2")
+        if C0 + x2.shape[1] != Cin:
+            raise ValueError(f"concat channels {C0}+{x2.shape[1]} != Cin {Cin}")
+    elif C0 != Cin:
+        raise ValueError(f"input channels {C0} != Cin {Cin}")
+    if M is None:
+        M = nbr.shape[1] if nbr is not None else x.shape[0]
+    if nbr is not None and (nbr.shape[0] != K or nbr.shape[1] != M):
+        raise ValueError(f"nbr shape {tuple(nbr.shape)} != ({K}, {M})")
+    if out is None:
+        out = torch.empty(M, Cout, dtype=torch.float32, device=x.device)
+    po, ldo = _rows(out, "out")
+    pr, ldr = (None, 0)
+    if res is not None:
+        pr, ldr = _rows(res, "res")
+    _lib.check(lib.sd3d_gather_gemm(p0, ld0, C0, p1, ld1, _ptr(nbr, torch.int32, "nbr"), _ptr(wt, torch.float32, "wt"),
+                                    K, Cin, Cout, M, _ptr(scale, torch.float32, "scale"),
+                                    _ptr(shift, torch.float32, "shift"), pr, ldr, po, ldo, ACT[act], nt, _stream()),
+               "gather_gemm")
+    return out
+
+
+def linear(x, weight, bias=None, act=None, res=None, out=None):
+    """y = act(x @ weight.T + bias (+ res)); weight [Cout, Cin] as stored by nn.Linear."""
+    return gather_gemm(x, weight, shift=bias, act=act, res=res, out=out)

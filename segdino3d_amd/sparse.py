@@ -1,0 +1,155 @@
+"""Device-side sparse-voxel coordinate hierarchy for one scene (host orchestration of csrc/voxel.hip).
+
+Plays the role MinkowskiEngine's CoordinateManager / spconv's indice-pair cache play for the
+reference (`minkunet.py:624-631`, `spconvunet.py:283-315, 383-388`): voxelise the points once, derive
+the coarser tensor strides, and hand out cached neighbour tables (`nbr[k, v]`) for each
+(level, kernel) the network asks for.
+
+HBM layout per scene (V_l voxels at level l, Z-order sorted, so a voxel's children/parents and
+spatial neighbours are close in memory):
+    keys_l   int64 [V_l]        Z-order key of (coord - origin) >> l  (+ batch bits)
+    hash_l   int64/int32 [cap]  open-addressing table key -> voxel id (cap = pow2 >= 2 V_l)
+    nbr      int32 [K, V_out]   gather table of one convolution kernel (K-major: coalesced per offset)
+    parent_l int32 [V_l]        id of the parent voxel at level l+1
+    inverse  int32 [N]          point -> level-0 voxel id
+    sidx/seg int32 [N], [V_0+1] points sorted by voxel + segment starts (ascending point order inside)
+Exactly one host synchronisation per scene: the voxel counts of all levels (needed to size the
+launches) are read back together with the overflow flag and the superpoint count.
+"""
+from __future__ import annotations
+
+from typing import Dict, Optional, Tuple
+
+import numpy as np
+import torch
+
+from . import ops
+
+_OFFSET_CACHE: Dict[Tuple[int, str, str], torch.Tensor] = {}
+
+
+def kernel_offsets_np(ksize: int, order: str) -> np.ndarray:
+    """[K,3] offsets in units of the tensor stride.  Odd kernels are centred, even kernels use
+    {0..k-1}.  order 'x_fastest' = MinkowskiEngine enumeration, 'z_fastest' = spconv weight layout
+    [k0,k1,k2] row-major.  (Same table as oracle.sparse_ref.kernel_offsets; tests compare them.)"""
+    r = np.arange(ksize) - (ksize - 1) // 2 if ksize % 2 else np.arange(ksize)
+    if order == "x_fastest":
+        z, y, x = np.meshgrid(r, r, r, indexing="ij")
+    elif order == "z_fastest":
+        x, y, z = np.meshgrid(r, r, r, indexing="ij")
+    else:
+        raise ValueError(order)
+    return np.stack([x.ravel(), y.ravel(), z.ravel()], axis=1).astype(np.int8)
+
+
+def offsets_device(ksize: int, order: str, device) -> torch.Tensor:
+    key = (ksize, order, str(device))
+    if key not in _OFFSET_CACHE:
+        _OFFSET_CACHE[key] = torch.from_numpy(kernel_offsets_np(ksize, order)).to(device)
+    return _OFFSET_CACHE[key]
+
+
+def child_perm(order: str) -> np.ndarray:
+    """Z-order child position (x | y<<1 | z<<2) -> weight index of a 2x2x2 kernel."""
+    if order == "x_fastest":
+        return np.arange(8, dtype=np.int32)
+    p = np.zeros(8, dtype=np.int32)
+    for c in range(8):
+        x, y, z = c & 1, (c >> 1) & 1, (c >> 2) & 1
+        p[c] = (x * 2 + y) * 2 + z
+    return p
+
+
+class SceneMaps:
+    """Voxelisation + coordinate levels + neighbour tables of ONE scene, all on the HIP device."""
+
+    def __init__(self, points: torch.Tensor, voxel_size: float, n_levels: int, shift_to_min: bool = False,
+                 order: str = "x_fastest", superpoints: Optional[torch.Tensor] = None):
+        if not points.is_cuda:
+            raise RuntimeError("SceneMaps needs device-resident points (no CPU fallback in the product path)")
+        self.order = order
+        self.device = points.device
+        self.voxel_size = float(voxel_size)
+        N = points.shape[0]
+        self.n_points = N
+        inv = float(np.float32(1.0) / np.float32(voxel_size))
+        self.stats = ops.scene_stats(points)
+        keys, self.icoords, self.origin, err = ops.voxel_keys(points, inv, self.stats, shift_to_min)
+        skeys, self.sidx = ops.sort_pairs(keys, None, 0, 56)
+        ukeys, self.seg_start, self.inverse, n0 = ops.unique_sorted(
+            skeys, self.sidx, N, None, 0, want_seg_start=True, want_map=True, map_size=N)
+        keys_l, counts, parents = [ukeys], [n0], []
+        cap = N
+        for _ in range(1, n_levels):
+            uk, _, parent, nl = ops.unique_sorted(keys_l[-1], None, cap, counts[-1], 3, want_seg_start=False, want_map=True)
+            keys_l.append(uk)
+            counts.append(nl)
+            parents.append(parent)
+        extra = [err]
+        if superpoints is not None:
+            sp_keys = ops.keys_from_i64(superpoints)
+            self.sp_sorted, self.sp_sidx = ops.sort_pairs(sp_keys, None, 0, 32)
+            extra.append(self.sp_sorted[-1:].to(torch.int32))
+        host = torch.cat(counts + extra).cpu().tolist()          # the one synchronisation of the scene
+        self.n_vox = [int(v) for v in host[:n_levels]]
+        if host[n_levels] != 0:
+            raise RuntimeError("scene exceeds the 16-bit-per-axis voxel key range (extent > ~1.3 km at 2 cm)")
+        self.n_superpoints = int(host[n_levels + 1]) + 1 if superpoints is not None else 0
+        self.keys = [k[: self.n_vox[l]] for l, k in enumerate(keys_l)]
+        self.parents = [p[: self.n_vox[l]] for l, p in enumerate(parents)]
+        self.seg_start = self.seg_start[: self.n_vox[0] + 1]
+        self._hash: Dict[int, Tuple[torch.Tensor, torch.Tensor]] = {}
+        self._same: Dict[Tuple[int, int], torch.Tensor] = {}
+        self._stride: Dict[int, Tuple[torch.Tensor, torch.Tensor]] = {}
+        self._perm8 = torch.from_numpy(child_perm(order)).to(self.device)
+        self._sp_start = None
+
+    # ------------------------------------------------------------------------------------------
+    def table(self, level: int):
+        if level not in self._hash:
+            self._hash[level] = ops.hash_build(self.keys[level], self.n_vox[level])
+        return self._hash[level]
+
+    def same(self, level: int, ksize: int) -> torch.Tensor:
+        """nbr [k^3, V_l] of a stride-1 convolution on level `level`."""
+        key = (level, ksize)
+        if key not in self._same:
+            offs = offsets_device(ksize, self.order, self.device)
+            self._same[key] = ops.kernel_map(self.keys[level], self.n_vox[level], self.table(level), offs)
+        return self._same[key]
+
+    def _stride_maps(self, level: int):
+        if level not in self._stride:
+            self._stride[level] = ops.stride_maps(self.keys[level], self.parents[level], self.n_vox[level],
+                                                  self.n_vox[level + 1], self._perm8)
+        return self._stride[level]
+
+    def down(self, level: int) -> torch.Tensor:
+        """nbr [8, V_{l+1}] of the k=2 s=2 convolution level -> level+1."""
+        return self._stride_maps(level)[0]
+
+    def up(self, level: int) -> torch.Tensor:
+        """nbr [8, V_l] of the transposed k=2 s=2 convolution level+1 -> level."""
+        return self._stride_maps(level)[1]
+
+    # ------------------------------------------------------------------------------------------
+    def voxel_features(self, points, feats2d, mode: int, ld_out: int) -> torch.Tensor:
+        return ops.voxel_mean(points, feats2d, mode, self.stats, self.sidx, self.seg_start, self.n_vox[0], ld_out)
+
+    def pool(self, feat: torch.Tensor, C: int):
+        """Fused devoxelise + superpoint mean: ([S,C] features, [S,3] quantised mean positions)."""
+        if self._sp_start is None:
+            self._sp_start = ops.segment_starts(self.sp_sorted, self.n_points, self.n_superpoints)
+        return ops.pool_superpoints(feat, C, self.inverse, self.icoords, self.voxel_size, self.sp_sidx,
+                                    self._sp_start, self.n_superpoints)
+
+    def rulebook_sizes(self):
+        """{(kind, level[, k]): number of (in, out, offset) pairs} of the tables built so far (for the
+        roofline accounting of bench.py; costs a sync)."""
+        out = {}
+        for (lvl, k), t in self._same.items():
+            out[("same", lvl, k)] = int((t >= 0).sum())
+        for lvl, (d, u) in self._stride.items():
+            out[("down", lvl)] = int((d >= 0).sum())
+            out[("up", lvl)] = int((u >= 0).sum())
+        return out

@@ -1,0 +1,184 @@
+"""GPU parity tests of the sparse path (through the C ABI via segdino3d_amd.ops) against the oracle.
+Integer work (sort, unique, maps) is bit-exact; fp32 work within the tolerance written in each test."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from _det import det_param, det_randn  # noqa: E402
+
+
+def dev():
+    if not torch.cuda.is_available():
+        pytest.skip("needs a HIP device")
+    return torch.device("cuda:0")
+
+
+# ------------------------------------------------------------------------------------------------
+def test_sort_pairs_stable_and_scan():
+    from segdino3d_amd import ops
+    d = dev()
+    g = torch.Generator().manual_seed(0)
+    for n in (1, 63, 64, 65, 2047, 2048, 2049, 150_000):
+        keys = torch.randint(0, 1 << 40, (n,), generator=g, dtype=torch.int64)
+        keys[::3] = keys[0]                       # many duplicates -> exercises stability
+        sk, sv = ops.sort_pairs(keys.to(d).clone(), None, 0, 48)
+        ref_k, ref_i = torch.sort(keys, stable=True)
+        assert torch.equal(sk.cpu(), ref_k), f"keys mismatch at n={n}"
+        assert torch.equal(sv.cpu().long(), ref_i), f"stability/values mismatch at n={n}"
+        x = torch.randint(0, 5, (n,), generator=g, dtype=torch.int32)
+        ex, tot = ops.scan_exclusive(x.to(d))
+        ref = torch.cumsum(x, 0) - x
+        assert torch.equal(ex.cpu(), ref.int()) and int(tot.item()) == int(x.sum())
+    f = torch.randn(5000, generator=g)
+    k = ops.keys_from_f32(f.to(d), descending=True)
+    sk, sv = ops.sort_pairs(k, None, 0, 32)
+    assert torch.equal(f[sv.cpu().long()], torch.sort(f, descending=True)[0])
+
+
+def _scene(n=20000, S=200, M=20, idx=11):
+    from segdino3d_amd.synth import make_scene
+    return make_scene(idx, n_points=n, n_superpoints=S, n_query2d=M)
+
+
+def test_voxelise_levels_maps_match_oracle():
+    from oracle import sparse_ref as R
+    from segdino3d_amd.sparse import SceneMaps
+    from helpers import device_level_coords, match_rows, pairs_from_nbr
+    d = dev()
+    pts, tgt = _scene()
+    pts[:, :3] -= torch.tensor([4.0, 3.0, 1.0])        # negative coordinates too
+    sp = tgt.extra_features["super_point_masks"]
+    maps = SceneMaps(pts.to(d), 0.02, 5, superpoints=sp.to(d))
+    c = R.floor_voxel(pts[:, :3], 0.02)
+    assert np.array_equal(maps.icoords.cpu().numpy(), c), "floor quantisation differs"
+    lo, hi = pts[:, :3].min(0)[0], pts[:, :3].max(0)[0]
+    st = maps.stats.cpu()
+    assert torch.equal(st[:3], lo) and torch.equal(st[3:6], hi)
+    uc, inv = R.unique_voxels(c)
+    lv = R.MinkLevels(uc)
+    perms = {}
+    for l in range(5):
+        dc = device_level_coords(maps, l)
+        perms[l] = match_rows(dc, lv.coords[1 << l])
+    # inverse map: point -> voxel
+    assert np.array_equal(perms[0][maps.inverse.cpu().numpy()], inv)
+    # kernel maps: same-level k=3 on every level, k=5 on level 0, stride maps
+    def canon(pairs, perm_in, perm_out):
+        return [set(zip(perm_in[i].tolist(), perm_out[o].tolist())) for (i, o) in pairs]
+    for l in range(5):
+        got = canon(pairs_from_nbr(maps.same(l, 3)), perms[l], perms[l])
+        ref = [set(zip(i.tolist(), o.tolist())) for (i, o) in lv.same(1 << l, 3)]
+        assert got == ref, f"k=3 kernel map differs on level {l}"
+    got = canon(pairs_from_nbr(maps.same(0, 5)), perms[0], perms[0])
+    ref = [set(zip(i.tolist(), o.tolist())) for (i, o) in lv.same(1, 5)]
+    assert got == ref, "k=5 kernel map differs"
+    for l in range(4):
+        got = canon(pairs_from_nbr(maps.down(l)), perms[l], perms[l + 1])
+        ref = [set(zip(i.tolist(), o.tolist())) for (i, o) in lv.down(1 << l)]
+        assert got == ref, f"stride-2 map differs on level {l}"
+        got = canon(pairs_from_nbr(maps.up(l)), perms[l + 1], perms[l])
+        ref = [set(zip(i.tolist(), o.tolist())) for (i, o) in lv.up(1 << l)]
+        assert got == ref, f"transposed map differs on level {l}"
+    assert maps.n_superpoints == int(sp.max()) + 1
+
+
+def test_voxel_mean_and_pool_match_oracle():
+    from oracle import sparse_ref as R
+    from segdino3d_amd.sparse import SceneMaps
+    from helpers import device_level_coords, match_rows
+    d = dev()
+    pts, tgt = _scene(idx=12)
+    f2d = tgt.extra_features["points_2dfeats"]
+    sp = tgt.extra_features["super_point_masks"]
+    maps = SceneMaps(pts.to(d), 0.02, 5, superpoints=sp.to(d))
+    c = R.floor_voxel(pts[:, :3], 0.02)
+    uc, inv = R.unique_voxels(c)
+    perm = match_rows(device_level_coords(maps, 0), uc)
+    vf = maps.voxel_features(pts.to(d), f2d.to(d), 0, 288).cpu()
+    ref = R.segment_mean(torch.cat([pts[:, 3:], f2d], 1), inv, len(uc))[perm]
+    torch.testing.assert_close(vf[:, :259], ref, rtol=1e-6, atol=1e-6)
+    assert (vf[:, 259:] == 0).all()
+    # pooling of an arbitrary 96-channel voxel feature
+    x = det_randn("pool.x", (len(uc), 96))
+    S = int(sp.max()) + 1
+    f, p = maps.pool(x[perm].to(d).contiguous(), 96)
+    rf = R.segment_mean(x[torch.from_numpy(inv)], sp.numpy(), S)
+    rp = R.segment_mean(torch.from_numpy(c).float() * 0.02, sp.numpy(), S)
+    torch.testing.assert_close(f.cpu(), rf, rtol=1e-5, atol=1e-5)
+    torch.testing.assert_close(p.cpu(), rp, rtol=1e-5, atol=1e-5)
+
+
+@pytest.mark.parametrize("M,Cin,Cout,act", [(200, 96, 256, "relu"), (33, 256, 199, None), (3000, 256, 1024, "gelu"),
+                                            (777, 1024, 256, None), (64, 32, 3, "sigmoid")])
+def test_linear_matches_torch(M, Cin, Cout, act):
+    from segdino3d_amd import ops
+    d = dev()
+    x = det_randn(f"lin.x{M}", (M, Cin))
+    w = det_randn(f"lin.w{Cout}", (Cout, Cin), Cin ** -0.5)
+    b = det_randn(f"lin.b{Cout}", (Cout,))
+    r = det_randn(f"lin.r{M}", (M, Cout))
+    y = ops.linear(x.to(d), w.to(d), b.to(d), act=act, res=r.to(d)).cpu()
+    ref = torch.nn.functional.linear(x.double(), w.double(), b.double()) + r.double()
+    ref = {"relu": torch.relu, "gelu": torch.nn.functional.gelu, "sigmoid": torch.sigmoid, None: lambda t: t}[act](ref)
+    torch.testing.assert_close(y.double(), ref, rtol=1e-4, atol=1e-4)
+
+
+def test_sparse_conv_matches_oracle():
+    from oracle import sparse_ref as R
+    from segdino3d_amd import ops
+    from segdino3d_amd.sparse import SceneMaps
+    from helpers import device_level_coords, match_rows
+    d = dev()
+    pts, tgt = _scene(n=30000, idx=13)
+    maps = SceneMaps(pts.to(d), 0.02, 5, superpoints=tgt.extra_features["super_point_masks"].to(d))
+    uc, _ = R.unique_voxels(R.floor_voxel(pts[:, :3], 0.02))
+    lv = R.MinkLevels(uc)
+    perm = {l: match_rows(device_level_coords(maps, l), lv.coords[1 << l]) for l in range(5)}
+    inv_perm = {l: np.argsort(perm[l]) for l in range(5)}
+    def to_dev(x_ref, l):      # oracle row order -> device row order
+        return x_ref[perm[l]].to(d).contiguous()
+    for (l, k, cin, cout) in [(0, 3, 96, 96), (0, 5, 288, 32), (1, 3, 128, 96), (3, 3, 128, 256), (4, 3, 256, 256)]:
+        x = det_randn(f"sc.x{l}{k}", (lv.n(1 << l), cin))
+        w = det_randn(f"sc.w{l}{k}", (k ** 3, cin, cout), (cin * k ** 3) ** -0.5)
+        ref = R.sparse_conv(x, lv.same(1 << l, k), w, lv.n(1 << l))
+        got = ops.gather_gemm(to_dev(x, l), w.permute(0, 2, 1).contiguous().to(d), nbr=maps.same(l, k)).cpu()
+        torch.testing.assert_close(got, ref[perm[l]], rtol=2e-4, atol=2e-4, msg=lambda m: f"same conv l={l} k={k}: {m}")
+    # stride-2 down + transposed up, with fused scale/shift/residual/relu and a two-source (concat) input
+    x = det_randn("sc.xd", (lv.n(1), 64))
+    w = det_randn("sc.wd", (8, 64, 32), 512 ** -0.5)
+    ref = R.sparse_conv(x, lv.down(1), w, lv.n(2))
+    xd = to_dev(x, 0)
+    got = ops.gather_gemm(xd[:, :32], w.permute(0, 2, 1).contiguous().to(d), nbr=maps.down(0), x2=xd[:, 32:]).cpu()
+    torch.testing.assert_close(got, ref[perm[1]], rtol=2e-4, atol=2e-4)
+    wt = det_randn("sc.wt", (8, 32, 96), 32 ** -0.5)
+    sc, sh = det_randn("sc.s", (96,)), det_randn("sc.h", (96,))
+    res = det_randn("sc.res", (lv.n(1), 96))
+    ref_up = torch.relu(R.sparse_conv(ref, lv.up(1), wt, lv.n(1)) * sc + sh + res)
+    got_up = ops.gather_gemm(to_dev(ref, 1), wt.permute(0, 2, 1).contiguous().to(d), nbr=maps.up(0), scale=sc.to(d),
+                             shift=sh.to(d), res=to_dev(res, 0), act="relu").cpu()
+    torch.testing.assert_close(got_up, ref_up[perm[0]], rtol=2e-4, atol=2e-4)
+
+
+def test_res16unet34c_forward_wrapper_matches_oracle():
+    from oracle import sparse_ref as R
+    from segdino3d_amd.backbone_mink import Res16UNet34C
+    d = dev()
+    pts, tgt = _scene(n=20000, S=150, idx=14)
+    m = Res16UNet34C(in_channels=259, out_channels=96, config=dict(dilations=[1, 1, 1, 1], conv1_kernel_size=5,
+                     bn_momentum=0.02), voxel_size=0.02, mode_fuse_2d_feat="early_fusion",
+                     add_positional_embedding=True).eval()
+    sd = {k: det_param("backbone." + k, v.shape).to(v.dtype) for k, v in m.state_dict().items()}
+    m.load_state_dict(sd)
+    m.to(d)
+    f, pos, pos_wo = m.forward_wrapper([pts.to(d)], [tgt.to(d)], return_sp_mean_pos=True)
+    tgt = tgt.to("cpu")
+    ref_sd = {"backbone." + k: v for k, v in sd.items()}
+    rf, rp, _ = R.mink_forward_wrapper(ref_sd, pts, tgt.extra_features["points_2dfeats"],
+                                       tgt.extra_features["super_point_masks"])
+    torch.testing.assert_close(pos[0].cpu(), rp, rtol=1e-5, atol=1e-5)
+    torch.testing.assert_close(pos_wo[0].cpu(), rp, rtol=1e-5, atol=1e-5)
+    err = (f[0].cpu() - rf).abs().max().item()
+    scale = rf.abs().max().item()
+    assert err <= 2e-3 * max(scale, 1.0), f"backbone features differ: max abs err {err} (scale {scale})"
