@@ -109,6 +109,71 @@ int sd3d_gather_gemm(const float* in0, int ld0, int C0, const float* in1, int ld
                      int K, int Cin, int Cout, int64_t M, const float* scale, const float* shift, const float* res,
                      int ld_res, float* out, int ld_out, int act, int nt, void* stream);
 
+/* ---------------------------------------------------------------------------------------------
+ * Decoder kernels (segdino3d/models/decoder/instance_seg_3d_decoder.py:606-799,
+ * segdino3d/models/module/attention.py:186-395, segdino3d/models/module/utils.py:53-105)
+ * ------------------------------------------------------------------------------------------- */
+/* out = act(LayerNorm(x + res) * w + b); nn.LayerNorm (+ the residual adds at decoder :690-691,
+ * :708-709, :82-84, :187-188).  act: 0 none, 1 ReLU (input_proj, :228-229). */
+int sd3d_layernorm(const float* x, int ld_x, const float* res, int ld_res, const float* w, const float* b, float eps,
+                   int64_t M, int D, float* out, int ld_out, int act, void* stream);
+/* PositionEmbeddingCoordsSine.get_sine_embeddings (utils.py:53-105) incl. shift_scale_points
+ * (pc_util.py:48-76).  range = (lo[3], hi[3]); dim_t / axis: per output channel (host tables);
+ * optional box modulation out *= mod_num / mod_den (decoder :660-663; ld_den may be 0 = broadcast). */
+int sd3d_sine_pe(const float* xyz, int ld_xyz, int64_t n, const float* range, const float* dim_t, const int8_t* axis,
+                 int d_pos, const float* mod_num, int ld_num, const float* mod_den, int ld_den, float* out, int ld_out,
+                 void* stream);
+/* Fused multi-head attention (replaces bmm + masked_fill + softmax + bmm of attention.py:361-385 and
+ * nn.MultiheadAttention's SDPA at decoder :79).  Heads are 32-channel slices; nsrc = 2 concatenates
+ * [q0|q1] . [k0|k1] per head (decoder :681-687).  mask_bits [Lq, ceil(Lk/32)]: bit = 1 -> blocked. */
+int sd3d_attention(const float* q0, int ldq0, const float* q1, int ldq1, const float* k0, int ldk0, const float* k1,
+                   int ldk1, const float* v, int ldv, const uint32_t* mask_bits, int Lq, int Lk, int H, float scale,
+                   float* out, int ldo, void* stream);
+/* _forward_head mask part (:567-572): bits = sigmoid(logits) < thr, dead rows reset to open. */
+int sd3d_mask_bits(const float* logits, int ld, int64_t Q, int S, float thr, uint32_t* bits, int nwords, void* stream);
+/* (dist < thr) of torch.cdist(p=1) (:721) as bits near[M, ceil(S/32)]. */
+int sd3d_near_bits(const float* sp_pos, int64_t S, const float* centers, int64_t M, float thr, uint32_t* near, int nwords,
+                   void* stream);
+/* mask_ = ((~attn_mask).float() @ near.float()) == 0, plus the always-open dummy key (:722-726). */
+int sd3d_dinox_mask_bits(const uint32_t* blocked, const uint32_t* near, int nwords, int64_t Q, int64_t M, uint32_t* out,
+                         int nwords_out, void* stream);
+/* centre / size refinement (:735-759, :768-772). d_size may be NULL (no size head). */
+int sd3d_box_refine(const float* ref_points, const float* d_center, const float* size_prev, int ld_size_prev,
+                    const float* d_size, const float* range, int normalize, int64_t Q, float* center, float* size,
+                    float* size_metric, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Post-processing (segdino3d/models/architecture/baseline3d.py)
+ * ------------------------------------------------------------------------------------------- */
+/* softmax(cls)[:, :C] flattened (:427) and/or its row maximum (:236-238). Either output may be NULL. */
+int sd3d_class_scores(const float* cls, int ld, int64_t Q, int C, float* scores, float* rowmax, void* stream);
+/* labels / query index of the selected flat indices + mask-quality rescoring (:436-446). */
+int sd3d_mask_scores(const float* masks, int ld, int S, const uint32_t* flat_idx, const float* score_in, int n, int C,
+                     int normalize, int32_t* labels, int32_t* qidx, float* score_out, void* stream);
+/* sig[r] = sigmoid(masks[qidx[order[r]]]) zero-padded to ld_out, area[r] = sum (:441, :66, :80-81). */
+int sd3d_gather_sigmoid(const float* masks, int ld, int S, const int32_t* qidx, const uint32_t* order, int n, float* sig,
+                        int ld_out, float* area, void* stream);
+/* matrix-NMS decay from inter = sig . sig^T (:85-119); comp_ws [n] scratch. */
+int sd3d_nms_decay(const float* inter, int ld, const float* area, const int32_t* labels, int n, int gaussian,
+                   float sigma, const float* score_in, float* comp_ws, float* score_out, void* stream);
+/* superpoint -> point broadcast + threshold + point count + optional box filter (:453-454, :464, :348-371).
+ * out [n, N] bytes (0/1); count[n] counts BEFORE the box filter; boxes [n,6] or NULL. */
+int sd3d_expand_masks(const float* sig, int ld_sig, const uint32_t* src_row, int n, const int64_t* superpoints,
+                      const float* points, int ld_points, int64_t N, float sp_thr, const float* boxes, float loose_ratio,
+                      uint8_t* out, int32_t* count, void* stream);
+/* argmax over selected columns (:504) and table gather (:504-507). */
+int sd3d_row_argmax(const float* x, int ld, int64_t Q, const int32_t* cols, int ncols, int64_t* out, void* stream);
+int sd3d_gather_i64(const int64_t* table, const int64_t* idx, int64_t N, int use_index, int64_t* out, void* stream);
+/* panoptic paint + small-segment removal + map composition (:532-556).  rows_desc[n]: mask rows in
+ * descending score order; inst_ws [N], hist_ws [n + n_stuff + 1] scratch. */
+int sd3d_panoptic(const uint8_t* masks, int64_t N, const int32_t* rows_desc, const int32_t* labels_desc, int n, int n_stuff,
+                  int npoint_thr, const int64_t* sem_stuff, int32_t* inst_ws, int32_t* hist_ws, int64_t* sem_map,
+                  int64_t* inst_map, void* stream);
+/* GT instance centres / sizes attached to the targets before inference (:289-305).  masks: bool bytes,
+ * row stride mask_stride; mode 0 = "mean" centre, 1 = "median" (= bbox centre, :299-300). */
+int sd3d_instance_boxes(const float* points, int ld, int64_t N, const uint8_t* masks, int64_t mask_stride, int n_inst,
+                        int mode, float* centers, float* sizes, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

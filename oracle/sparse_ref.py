@@ -44,8 +44,13 @@ def pack(c: np.ndarray) -> np.ndarray:
 
 
 def floor_voxel(xyz: torch.Tensor, voxel_size: float) -> np.ndarray:
-    """batch_sparse_collate on float coords: floor(xyz / voxel_size) as int32 (minkunet.py:624-626)."""
-    return torch.floor(xyz / voxel_size).to(torch.int32).numpy()
+    """batch_sparse_collate on float coords (minkunet.py:624-626): floor(xyz / voxel_size) as int32.
+    The reference evaluates `coords / self.voxel_size` on a CUDA tensor, where ATen's
+    div-by-CPU-scalar kernel multiplies by the fp32 reciprocal (1/0.02f rounds to exactly 50.0f); that
+    deployed behaviour is what is restated here (a true division differs only for coordinates that are
+    exact multiples of the voxel size)."""
+    inv = float(np.float32(1.0) / np.float32(voxel_size))
+    return torch.floor(xyz * inv).to(torch.int32).numpy()
 
 
 def unique_voxels(c: np.ndarray):

@@ -44,6 +44,22 @@ SIGNATURES = {
     "sd3d_segment_starts": (_i, [_p, _l, _l, _p, _p]),
     "sd3d_pool_superpoints": (_i, [_p, _i, _i, _p, _p, _f, _p, _p, _l, _p, _p, _p]),
     "sd3d_gather_gemm": (_i, [_p, _i, _i, _p, _i, _p, _p, _i, _i, _i, _l, _p, _p, _p, _i, _p, _i, _i, _i, _p]),
+    "sd3d_layernorm": (_i, [_p, _i, _p, _i, _p, _p, _f, _l, _i, _p, _i, _i, _p]),
+    "sd3d_sine_pe": (_i, [_p, _i, _l, _p, _p, _p, _i, _p, _i, _p, _i, _p, _i, _p]),
+    "sd3d_attention": (_i, [_p, _i, _p, _i, _p, _i, _p, _i, _p, _i, _p, _i, _i, _i, _f, _p, _i, _p]),
+    "sd3d_mask_bits": (_i, [_p, _i, _l, _i, _f, _p, _i, _p]),
+    "sd3d_near_bits": (_i, [_p, _l, _p, _l, _f, _p, _i, _p]),
+    "sd3d_dinox_mask_bits": (_i, [_p, _p, _i, _l, _l, _p, _i, _p]),
+    "sd3d_box_refine": (_i, [_p, _p, _p, _i, _p, _p, _i, _l, _p, _p, _p, _p]),
+    "sd3d_class_scores": (_i, [_p, _i, _l, _i, _p, _p, _p]),
+    "sd3d_mask_scores": (_i, [_p, _i, _i, _p, _p, _i, _i, _i, _p, _p, _p, _p]),
+    "sd3d_gather_sigmoid": (_i, [_p, _i, _i, _p, _p, _i, _p, _i, _p, _p]),
+    "sd3d_nms_decay": (_i, [_p, _i, _p, _p, _i, _i, _f, _p, _p, _p, _p]),
+    "sd3d_expand_masks": (_i, [_p, _i, _p, _i, _p, _p, _i, _l, _f, _p, _f, _p, _p, _p]),
+    "sd3d_row_argmax": (_i, [_p, _i, _l, _p, _i, _p, _p]),
+    "sd3d_gather_i64": (_i, [_p, _p, _l, _i, _p, _p]),
+    "sd3d_panoptic": (_i, [_p, _l, _p, _p, _i, _i, _i, _p, _p, _p, _p, _p, _p]),
+    "sd3d_instance_boxes": (_i, [_p, _i, _l, _p, _l, _i, _i, _p, _p, _p]),
 }
 
 

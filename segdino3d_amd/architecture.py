@@ -1,0 +1,255 @@
+"""Baseline3D: eval-mode forward of SegDINO3D on the MI355X kernels (host side).
+
+Mirrors the reference operator interface `segdino3d/models/architecture/baseline3d.py:144-556`:
+same constructor kwargs (:146-160), same attributes (`backbone`, `decoder`, `criterion`, `test_cfg`,
+`query_num`, ...), `forward(samples, targets)` returning the SAME `targets` list with
+`targets[0].pred_pts_seg` attached in eval mode (:333-338), `pred_pts_seg` holding the fields of the
+reference `PointData` (:397-404).  The arithmetic (post-processing included) runs through
+segdino3d_amd.ops; torch is used for tensor bookkeeping (row gathers by index, concatenation, D2H).
+"""
+from __future__ import annotations
+
+from typing import Dict, List, Optional
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+from . import ops
+from .builder import ARCHITECTURES, LOSSES, build_backbone, build_decoder, build_loss, build_text_encoder
+
+try:  # pragma: no cover - mmdet3d is absent from the build image
+    from mmdet3d.structures import PointData  # type: ignore
+except Exception:  # noqa: BLE001
+    class PointData:
+        """Minimal stand-in for mmdet3d.structures.PointData: attribute container with `.items()`."""
+
+        def __init__(self, **fields):
+            self.__dict__.update(fields)
+
+        def items(self):
+            return self.__dict__.items()
+
+        def keys(self):
+            return self.__dict__.keys()
+
+        def __getitem__(self, k):
+            return self.__dict__[k]
+
+        def __contains__(self, k):
+            return k in self.__dict__
+
+
+if LOSSES.get("ScanNetUnifiedCriterion") is None:
+    @LOSSES.register_module()
+    class ScanNetUnifiedCriterion:
+        """Config-surface placeholder: the shipped configs name this criterion (`configs/models/base_3d.py:37-55`).
+        The training step (loss + matcher + backward) is SURVEY.md 8(f-1), not built yet."""
+
+        def __init__(self, **cfg):
+            self.cfg = cfg
+
+        def __call__(self, *a, **k):
+            raise NotImplementedError("segdino3d_amd: the training criterion (SURVEY.md 8(f-1)) is not built; eval-mode forward only")
+
+
+def _cfg_get(cfg, key, default=None):
+    if cfg is None:
+        return default
+    if isinstance(cfg, dict):
+        return cfg.get(key, default)
+    return getattr(cfg, key, default) if not hasattr(cfg, "get") else cfg.get(key, default)
+
+
+def _sorted_desc(score: torch.Tensor):
+    """indices (int32) that sort `score` descending (stable) via the radix sort kernels."""
+    keys = ops.keys_from_f32(score, descending=True)
+    _, idx = ops.sort_pairs(keys, None, 0, 32)
+    return idx
+
+
+@ARCHITECTURES.register_module()
+class Baseline3D(nn.Module):
+    def __init__(self, num_classes: int, pointcloud_backbone_cfg: Dict, decoder_cfg: Dict = None, criterion_cfg: Dict = None,
+                 text_encoder_cfg: Dict = None, use_sim_classifier: bool = False, query_thr: float = 0.5, test_cfg=None,
+                 add_positional_embedding=False, mode_3d_center: str = "mean", query_num=-1,
+                 filter_outofbox_points_eval: bool = False):
+        super().__init__()
+        self.backbone = build_backbone(pointcloud_backbone_cfg)
+        self.decoder = build_decoder(decoder_cfg)
+        self.criterion = build_loss(criterion_cfg)
+        if text_encoder_cfg is not None:
+            self.text_encoder = build_text_encoder(text_encoder_cfg)
+        self.use_sim_classifier = use_sim_classifier
+        if self.use_sim_classifier:
+            assert text_encoder_cfg is not None, "Text encoder must be provided when using sim classifier."
+        self.query_thr = query_thr
+        self.num_classes = num_classes
+        self.test_cfg = test_cfg
+        self.add_positional_embedding = add_positional_embedding
+        self.mode_3d_center = mode_3d_center
+        self.query_num = query_num
+        self.filter_outofbox_points_eval = filter_outofbox_points_eval
+        if self.filter_outofbox_points_eval:
+            assert self.decoder.add_box_size_pred, \
+                "When filter_outofbox_points_eval is True, decoder must have add_box_size_pred set to True."
+        self.to_host = True          # False: keep post-processed outputs on the device (bench.py forward timing)
+
+    # ---- get_extra_instance_data (:266-306) ------------------------------------------------------
+    def get_extra_instance_data(self, samples, targets, add_instance_centers=False, add_instance_axis_aligned_box=False):
+        if not (add_instance_centers or add_instance_axis_aligned_box):
+            return None
+        scene_range = []
+        for i in range(len(targets)):
+            if "elastic_coords" in targets[i]:
+                raise NotImplementedError("elastic_coords (train-time augmentation) is not supported in the eval path")
+            pts = samples[i]
+            stats = ops.scene_stats(pts)
+            scene_range.append((stats[0:3], stats[3:6]))
+            masks = targets[i].get("masks") if hasattr(targets[i], "get") else targets[i]["masks"]
+            if masks is not None:
+                m = masks[..., 0] if masks.dim() == 3 else masks
+                centers, sizes = ops.instance_boxes(pts, m, self.mode_3d_center)
+                if add_instance_centers:
+                    targets[i].instance_centers = centers
+                if add_instance_axis_aligned_box:
+                    targets[i].instance_sizes = sizes
+        return scene_range
+
+    def forward_backbone(self, samples, targets):
+        return self.backbone.forward_wrapper(samples, targets, return_sp_mean_pos=True)
+
+    def forward_decoder(self, sp_features_3d, sp_pos, sp_pos_wo_elastic, queries, queries_pos, targets, scene_range):
+        if self.decoder.add_dinox_query_ca:
+            query2d_feat = [t["extra_features"]["query2d_feats"] for t in targets]
+            query2d_pos = [t["extra_features"]["query2d_pos"] for t in targets]
+        else:
+            query2d_feat = query2d_pos = None
+        return self.decoder(sp_features_3d, sp_pos, sp_pos_wo_elastic, queries, queries_pos, query2d_feat, query2d_pos,
+                            scene_range)
+
+    # ---- _select_queries (:207-264), eval branches -----------------------------------------------------
+    def _select_queries(self, x, x_pos=None, targets=None):
+        if self.training:
+            raise NotImplementedError("segdino3d_amd: training-time query sampling (SURVEY.md 8(f-1)) is not built")
+        if self.query_num == -1:
+            return x, x_pos, targets
+        queries, queries_pos = [], ([] if self.add_positional_embedding else None)
+        for i in range(len(x)):
+            if self.query_num > 0 and x[i].shape[0] > self.query_num:
+                score = self.decoder.select_scores(x[i])
+                ids = _sorted_desc(score)[: self.query_num].long()
+            else:
+                ids = torch.arange(x[i].shape[0], device=x[i].device)
+            queries.append(x[i][ids])
+            if targets is not None and "sp_inst_sem_masks" in targets[i]:
+                targets[i].query_inst_sem_masks = targets[i].sp_inst_sem_masks[:, ids]
+            if x_pos is not None and queries_pos is not None:
+                queries_pos.append(x_pos[i][ids])
+        return queries, queries_pos, targets
+
+    # ---- forward (:308-346) --------------------------------------------------------------------------------
+    def forward(self, samples, targets: List = None):
+        if self.training:
+            raise NotImplementedError("segdino3d_amd: eval-mode forward only; the training step (criterion + backward, "
+                                      "SURVEY.md 8(f-1)) is not built")
+        samples = [s.float().contiguous() for s in samples]
+        scene_range = self.get_extra_instance_data(samples, targets, self.add_positional_embedding,
+                                                   self.decoder.add_box_size_pred)
+        sp_features_3d, sp_pos, sp_pos_wo_elastic = self.forward_backbone(samples, targets)
+        queries, queries_pos, targets = self._select_queries(sp_features_3d, sp_pos, targets)
+        self.decoder.return_hidden_states = True
+        self.decoder.return_aux_outputs = True
+        outputs = self.forward_decoder(sp_features_3d, sp_pos, sp_pos_wo_elastic, queries, queries_pos, targets, scene_range)
+        self.last_outputs = outputs
+        pred = self.predict_by_feat(samples, outputs, targets[0]["extra_features"]["super_point_masks"])  # bs = 1 (:335)
+        targets[0].pred_pts_seg = pred[0]
+        return targets
+
+    # ---- post-processing -------------------------------------------------------------------------------------
+    def _instances_common(self, samples, out, superpoints):
+        """Everything of predict_by_feat_instance (:406-486) that does not depend on the score threshold;
+        the reference runs it twice (inst_score_thr and pan_score_thr), here it runs once."""
+        cfg = self.test_cfg
+        cls = out["cls_preds"][0]
+        logits = out["masks"][0]
+        pts = samples[0]
+        C = self.num_classes
+        Q, S = cls.shape[0], logits.shape[1]
+        k = int(_cfg_get(cfg, "topk_insts"))
+        if Q * C < k:
+            raise ValueError(f"topk_insts={k} needs at least {k} (query, class) pairs, got {Q * C}")
+        flat, _ = ops.class_scores(cls, C)
+        order0 = _sorted_desc(flat)[:k].contiguous()                    # top-k (query, class) pairs (:434)
+        top_scores = flat[order0.long()]
+        labels, qidx, scores = ops.mask_scores(logits, S, order0, top_scores, C, bool(_cfg_get(cfg, "obj_normalization", None)))
+        S_pad = (S + 31) // 32 * 32
+        if _cfg_get(cfg, "nms", None):
+            order1 = _sorted_desc(scores)                                # mask_matrix_nms first sort (:71)
+            sig, area = ops.gather_sigmoid(logits, S, qidx, order1, S_pad)
+            labels1 = labels[order1.long()].contiguous()
+            scores1 = scores[order1.long()].contiguous()
+            inter = ops.gather_gemm(sig, sig)                            # torch.mm(masks, masks^T) (:87)
+            scores2 = ops.nms_decay(inter, area, labels1, scores1, kernel=_cfg_get(cfg, "matrix_nms_kernel"))
+            order2 = _sorted_desc(scores2)                               # final sort (:133)
+            o2 = order2.long()
+            final_scores, final_labels = scores2[o2], labels1[o2]
+            record = order1.long()[o2]                                   # sort_inds_record (:139)
+            src_row = order2.contiguous()
+        else:
+            # the reference leaves sort_inds_record undefined here; identity is the sane reading
+            ident = torch.arange(k, dtype=torch.int32, device=cls.device)
+            sig, area = ops.gather_sigmoid(logits, S, qidx, ident, S_pad)
+            final_scores, final_labels, record, src_row = scores, labels, ident.long(), ident
+        centers = out["centers"][0] if "centers" in out else None
+        sizes = out["sizes"][0] if "sizes" in out else None
+        boxes = None
+        if centers is not None and sizes is not None:
+            q_rec = qidx.long()[record]
+            boxes = torch.cat([centers[q_rec], sizes[q_rec]], dim=-1).contiguous()
+        masks_u8, count = ops.expand_masks(sig, src_row, superpoints.contiguous(), pts, float(_cfg_get(cfg, "sp_score_thr")),
+                                           boxes if self.filter_outofbox_points_eval else None)
+        return dict(scores=final_scores, labels=final_labels, masks=masks_u8, count=count, boxes=boxes, topk_idx=qidx.long())
+
+    def _select(self, common, score_threshold):
+        cfg = self.test_cfg
+        score_mask = common["scores"] > score_threshold
+        npoint_all = common["count"] > int(_cfg_get(cfg, "npoint_thr"))
+        npoint_mask = npoint_all[score_mask]
+        keep = (score_mask & npoint_all).nonzero().squeeze(1)
+        return keep, score_mask, npoint_mask
+
+    def predict_by_feat(self, samples, out, superpoints):
+        cfg = self.test_cfg
+        com = self._instances_common(samples, out, superpoints)
+        keep, score_mask, npoint_mask = self._select(com, float(_cfg_get(cfg, "inst_score_thr")))
+        inst_masks = com["masks"][keep].view(torch.bool)
+        inst_labels, inst_scores = com["labels"][keep].long(), com["scores"][keep]
+        inst_boxes = com["boxes"][keep] if com["boxes"] is not None else None
+        # semantic (:488-507)
+        sem = out["sem_preds"][0]
+        n_sem = sem.shape[1] - 1
+        use_index = self.query_num == -1
+        sem_res = ops.gather_i64(ops.row_argmax(sem, ncols=n_sem), superpoints, use_index)
+        # panoptic (:509-556)
+        stuff = list(_cfg_get(cfg, "stuff_classes"))
+        cols = torch.tensor(stuff, dtype=torch.int32, device=sem.device)
+        sem_stuff = ops.gather_i64(ops.row_argmax(sem, cols=cols), superpoints, use_index)
+        pkeep, _, _ = self._select(com, float(_cfg_get(cfg, "pan_score_thr")))
+        if pkeep.numel() == 0:
+            pan_sem, pan_inst = sem_stuff, sem_stuff
+        else:
+            pan_sem, pan_inst = ops.panoptic(com["masks"], pkeep.int().contiguous(), com["labels"][pkeep].int().contiguous(),
+                                             len(stuff), int(_cfg_get(cfg, "npoint_thr")), sem_stuff)
+        sort_and_mask = (com["topk_idx"], score_mask, npoint_mask)
+        if not self.to_host:
+            return [PointData(pts_semantic_mask=[sem_res, pan_sem], pts_instance_mask=[inst_masks, pan_inst],
+                              instance_labels=inst_labels, instance_scores=inst_scores, sort_and_mask=sort_and_mask,
+                              instance_boxes=inst_boxes)]
+        n = inst_scores.shape[0]
+        return [PointData(
+            pts_semantic_mask=[sem_res.cpu().numpy(), pan_sem.cpu().numpy()],
+            pts_instance_mask=[inst_masks.cpu().numpy(), pan_inst.cpu().numpy()],
+            instance_labels=inst_labels.cpu().numpy(), instance_scores=inst_scores.cpu().numpy(),
+            sort_and_mask=sort_and_mask,
+            instance_boxes=inst_boxes.cpu().numpy() if inst_boxes is not None else np.zeros((n, 6)))]

@@ -47,6 +47,32 @@ struct GGParams {
 };
 int launch_gather_gemm(const GGParams&, int, hipStream_t);
 
+int launch_layernorm(const float*, int, const float*, int, const float*, const float*, float, int64_t, int, float*, int, int, hipStream_t);
+int launch_sine_pe(const float*, int, int64_t, const float*, const float*, const int8_t*, int, const float*, int, const float*, int, float*, int, hipStream_t);
+struct AttnParams {
+    const float* q[2]; int ldq[2];
+    const float* k[2]; int ldk[2];
+    const float* v; int ldv;
+    const uint32_t* bits; int nwords;
+    float* out; int ldo;
+    int Lq, Lk, H;
+    float scale;
+};
+int launch_attention(const AttnParams&, int, hipStream_t);
+int launch_mask_bits(const float*, int, int64_t, int, float, uint32_t*, int, hipStream_t);
+int launch_near_bits(const float*, int64_t, const float*, int64_t, float, uint32_t*, int, hipStream_t);
+int launch_dinox_mask_bits(const uint32_t*, const uint32_t*, int, int64_t, int64_t, uint32_t*, int, hipStream_t);
+int launch_box_refine(const float*, const float*, const float*, int, const float*, const float*, int, int64_t, float*, float*, float*, hipStream_t);
+int launch_class_scores(const float*, int, int64_t, int, float*, float*, hipStream_t);
+int launch_mask_scores(const float*, int, int, const uint32_t*, const float*, int, int, int, int32_t*, int32_t*, float*, hipStream_t);
+int launch_gather_sigmoid(const float*, int, int, const int32_t*, const uint32_t*, int, float*, int, float*, hipStream_t);
+int launch_nms_decay(const float*, int, const float*, const int32_t*, int, int, float, const float*, float*, float*, hipStream_t);
+int launch_expand_masks(const float*, int, const uint32_t*, int, const int64_t*, const float*, int, int64_t, float, const float*, float, uint8_t*, int32_t*, hipStream_t);
+int launch_row_argmax(const float*, int, int64_t, const int32_t*, int, int64_t*, hipStream_t);
+int launch_gather_i64(const int64_t*, const int64_t*, int64_t, int, int64_t*, hipStream_t);
+int launch_panoptic(const uint8_t*, int64_t, const int32_t*, const int32_t*, int, int, int, const int64_t*, int32_t*, int32_t*, int64_t*, int64_t*, hipStream_t);
+int launch_instance_boxes(const float*, int, int64_t, const uint8_t*, int64_t, int, int, float*, float*, hipStream_t);
+
 #define ST ((hipStream_t)stream)
 
 extern "C" {
@@ -135,6 +161,76 @@ int sd3d_gather_gemm(const float* in0, int ld0, int C0, const float* in1, int ld
     p.M = M; p.scale = scale; p.shift = shift; p.res = res; p.ld_res = ld_res; p.out = out; p.ld_out = ld_out; p.act = act;
     p.col_groups = 1;
     return launch_gather_gemm(p, nt, ST);
+}
+
+int sd3d_layernorm(const float* x, int ld_x, const float* res, int ld_res, const float* w, const float* b, float eps, int64_t M,
+                   int D, float* out, int ld_out, int act, void* stream) {
+    return launch_layernorm(x, ld_x, res, ld_res, w, b, eps, M, D, out, ld_out, act, ST);
+}
+int sd3d_sine_pe(const float* xyz, int ld_xyz, int64_t n, const float* range, const float* dim_t, const int8_t* axis, int d_pos,
+                 const float* mod_num, int ld_num, const float* mod_den, int ld_den, float* out, int ld_out, void* stream) {
+    if (mod_num && !mod_den) return sd3d_set_error(SD3D_ERR_ARG, "sine_pe: mod_den missing");
+    return launch_sine_pe(xyz, ld_xyz, n, range, dim_t, axis, d_pos, mod_num, ld_num, mod_den, ld_den, out, ld_out, ST);
+}
+int sd3d_attention(const float* q0, int ldq0, const float* q1, int ldq1, const float* k0, int ldk0, const float* k1, int ldk1,
+                   const float* v, int ldv, const uint32_t* mask_bits, int Lq, int Lk, int H, float scale, float* out, int ldo,
+                   void* stream) {
+    if ((q1 == nullptr) != (k1 == nullptr)) return sd3d_set_error(SD3D_ERR_ARG, "attention: q1 and k1 must be given together");
+    AttnParams p;
+    p.q[0] = q0; p.ldq[0] = ldq0; p.q[1] = q1; p.ldq[1] = ldq1;
+    p.k[0] = k0; p.ldk[0] = ldk0; p.k[1] = k1; p.ldk[1] = ldk1;
+    p.v = v; p.ldv = ldv; p.bits = mask_bits; p.nwords = (Lk + 31) / 32; p.out = out; p.ldo = ldo;
+    p.Lq = Lq; p.Lk = Lk; p.H = H; p.scale = scale;
+    return launch_attention(p, q1 ? 2 : 1, ST);
+}
+int sd3d_mask_bits(const float* logits, int ld, int64_t Q, int S, float thr, uint32_t* bits, int nwords, void* stream) {
+    return launch_mask_bits(logits, ld, Q, S, thr, bits, nwords, ST);
+}
+int sd3d_near_bits(const float* sp_pos, int64_t S, const float* centers, int64_t M, float thr, uint32_t* near, int nwords, void* stream) {
+    return launch_near_bits(sp_pos, S, centers, M, thr, near, nwords, ST);
+}
+int sd3d_dinox_mask_bits(const uint32_t* blocked, const uint32_t* near, int nwords, int64_t Q, int64_t M, uint32_t* out,
+                         int nwords_out, void* stream) {
+    return launch_dinox_mask_bits(blocked, near, nwords, Q, M, out, nwords_out, ST);
+}
+int sd3d_box_refine(const float* ref_points, const float* d_center, const float* size_prev, int ld_size_prev, const float* d_size,
+                    const float* range, int normalize, int64_t Q, float* center, float* size, float* size_metric, void* stream) {
+    return launch_box_refine(ref_points, d_center, size_prev, ld_size_prev, d_size, range, normalize, Q, center, size, size_metric, ST);
+}
+int sd3d_class_scores(const float* cls, int ld, int64_t Q, int C, float* scores, float* rowmax, void* stream) {
+    return launch_class_scores(cls, ld, Q, C, scores, rowmax, ST);
+}
+int sd3d_mask_scores(const float* masks, int ld, int S, const uint32_t* flat_idx, const float* score_in, int n, int C, int normalize,
+                     int32_t* labels, int32_t* qidx, float* score_out, void* stream) {
+    return launch_mask_scores(masks, ld, S, flat_idx, score_in, n, C, normalize, labels, qidx, score_out, ST);
+}
+int sd3d_gather_sigmoid(const float* masks, int ld, int S, const int32_t* qidx, const uint32_t* order, int n, float* sig, int ld_out,
+                        float* area, void* stream) {
+    return launch_gather_sigmoid(masks, ld, S, qidx, order, n, sig, ld_out, area, ST);
+}
+int sd3d_nms_decay(const float* inter, int ld, const float* area, const int32_t* labels, int n, int gaussian, float sigma,
+                   const float* score_in, float* comp_ws, float* score_out, void* stream) {
+    return launch_nms_decay(inter, ld, area, labels, n, gaussian, sigma, score_in, comp_ws, score_out, ST);
+}
+int sd3d_expand_masks(const float* sig, int ld_sig, const uint32_t* src_row, int n, const int64_t* superpoints, const float* points,
+                      int ld_points, int64_t N, float sp_thr, const float* boxes, float loose_ratio, uint8_t* out, int32_t* count,
+                      void* stream) {
+    return launch_expand_masks(sig, ld_sig, src_row, n, superpoints, points, ld_points, N, sp_thr, boxes, loose_ratio, out, count, ST);
+}
+int sd3d_row_argmax(const float* x, int ld, int64_t Q, const int32_t* cols, int ncols, int64_t* out, void* stream) {
+    return launch_row_argmax(x, ld, Q, cols, ncols, out, ST);
+}
+int sd3d_gather_i64(const int64_t* table, const int64_t* idx, int64_t N, int use_index, int64_t* out, void* stream) {
+    return launch_gather_i64(table, idx, N, use_index, out, ST);
+}
+int sd3d_panoptic(const uint8_t* masks, int64_t N, const int32_t* rows_desc, const int32_t* labels_desc, int n, int n_stuff,
+                  int npoint_thr, const int64_t* sem_stuff, int32_t* inst_ws, int32_t* hist_ws, int64_t* sem_map, int64_t* inst_map,
+                  void* stream) {
+    return launch_panoptic(masks, N, rows_desc, labels_desc, n, n_stuff, npoint_thr, sem_stuff, inst_ws, hist_ws, sem_map, inst_map, ST);
+}
+int sd3d_instance_boxes(const float* points, int ld, int64_t N, const uint8_t* masks, int64_t mask_stride, int n_inst, int mode,
+                        float* centers, float* sizes, void* stream) {
+    return launch_instance_boxes(points, ld, N, masks, mask_stride, n_inst, mode, centers, sizes, ST);
 }
 
 }  // extern "C"

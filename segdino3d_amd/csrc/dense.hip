@@ -1,0 +1,402 @@
+// Decoder kernels (reference: segdino3d/models/decoder/instance_seg_3d_decoder.py:606-799 and
+// segdino3d/models/module/{attention.py:186-395, utils.py:53-105}).
+//   layernorm        : y = act(LN(x + res))                       one wave per row
+//   sine_pe          : box-modulated sine positional encoding      elementwise, fp32 sin/cos
+//   attention        : fused masked multi-head attention, fp32 MFMA, online softmax, bit-packed mask;
+//                      never materialises the [H, Q, S] score tensor (K16, K17)
+//   mask_bits        : sigmoid(logit) < thr -> bit-packed attention mask + dead-row reset (K18)
+//   near_bits / dinox_mask_bits : boolean (mask . distance) product as AND/any over bit words (K19)
+//   box_refine       : iterative centre / size refinement (:735-759)
+#include "common.h"
+
+__device__ static inline float wsum(float v) {
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) v += __shfl_xor(v, d);
+    return v;
+}
+
+// ---------------------------------------------------------------------------------------------
+// LayerNorm over the last dim D (multiple of 4, <= 1024): two-pass mean / variance in fp32.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict__ x, int ld_x, const float* __restrict__ res,
+                                                        int ld_res, const float* __restrict__ w, const float* __restrict__ b,
+                                                        float eps, int64_t M, int D, float* __restrict__ out, int ld_out, int act) {
+    const int lane = threadIdx.x & 63;
+    const int64_t r = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (r >= M) return;
+    f32x4 v[4];                       // up to 1024 columns: 4 x (64 lanes x 4)
+    float s = 0.f;
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {
+        const int c = (it * 64 + lane) * 4;
+        v[it] = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (c < D) {
+            v[it] = *(const f32x4*)(x + r * ld_x + c);
+            if (res) v[it] += *(const f32x4*)(res + r * ld_res + c);
+            s += v[it][0] + v[it][1] + v[it][2] + v[it][3];
+        }
+    }
+    const float mean = wsum(s) / (float)D;
+    float q = 0.f;
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {
+        const int c = (it * 64 + lane) * 4;
+        if (c < D) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { const float dlt = v[it][e] - mean; q += dlt * dlt; }
+        }
+    }
+    const float rstd = 1.0f / sqrtf(wsum(q) / (float)D + eps);
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {
+        const int c = (it * 64 + lane) * 4;
+        if (c < D) {
+            const f32x4 ww = *(const f32x4*)(w + c), bb = *(const f32x4*)(b + c);
+            f32x4 y;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                y[e] = (v[it][e] - mean) * rstd * ww[e] + bb[e];
+                if (act == 1) y[e] = fmaxf(y[e], 0.f);
+            }
+            *(f32x4*)(out + r * ld_out + c) = y;
+        }
+    }
+}
+
+int launch_layernorm(const float* x, int ld_x, const float* res, int ld_res, const float* w, const float* b, float eps,
+                     int64_t M, int D, float* out, int ld_out, int act, hipStream_t st) {
+    if (M <= 0) return SD3D_OK;
+    if ((D & 3) || D > 1024 || (ld_x & 3) || (ld_out & 3) || (res && (ld_res & 3)))
+        return sd3d_set_error(SD3D_ERR_ARG, "layernorm: D must be a multiple of 4 and <= 1024, strides multiples of 4");
+    hipLaunchKernelGGL(layernorm_kernel, dim3((unsigned)cdiv(M, 4)), dim3(256), 0, st, x, ld_x, res, ld_res, w, b, eps, M, D, out,
+                       ld_out, act);
+    SD3D_CHECK_LAUNCH();
+    return SD3D_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// sine positional encoding (utils.py:53-105).  Per output channel c the host supplies axis[c] in
+// {0,1,2} and dim_t[c]; even channels are sin, odd cos.  rng = (lo[3], hi[3]) device.
+//   pos = ((x - lo) * 1 / (hi - lo) + 0) * 2pi / dim_t        (same operation order as the reference)
+//   out = f(pos) * (mod_num / mod_den)     (box modulation, optional; mod_den row stride may be 0)
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void sine_pe_kernel(const float* __restrict__ xyz, int ld_xyz, int64_t n,
+                                                      const float* __restrict__ rng, const float* __restrict__ dim_t,
+                                                      const int8_t* __restrict__ axis, int d_pos,
+                                                      const float* __restrict__ mod_num, int ld_num,
+                                                      const float* __restrict__ mod_den, int ld_den,
+                                                      float* __restrict__ out, int ld_out) {
+    const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (t >= n * d_pos) return;
+    const int64_t r = t / d_pos;
+    const int c = (int)(t - r * d_pos);
+    const int a = axis[c];
+    const float lo = rng[a], hi = rng[3 + a];
+    float p = ((xyz[r * ld_xyz + a] - lo) * 1.0f) / (hi - lo) + 0.0f;
+    p = p * 6.283185307179586f;
+    p = p / dim_t[c];
+    float y = (c & 1) ? cosf(p) : sinf(p);
+    if (mod_num) y *= mod_num[r * ld_num + a] / mod_den[r * ld_den + a];
+    out[r * ld_out + c] = y;
+}
+
+int launch_sine_pe(const float* xyz, int ld_xyz, int64_t n, const float* rng, const float* dim_t, const int8_t* axis, int d_pos,
+                   const float* mod_num, int ld_num, const float* mod_den, int ld_den, float* out, int ld_out, hipStream_t st) {
+    if (n <= 0) return SD3D_OK;
+    hipLaunchKernelGGL(sine_pe_kernel, dim3((unsigned)cdiv(n * d_pos, 256)), dim3(256), 0, st, xyz, ld_xyz, n, rng, dim_t, axis,
+                       d_pos, mod_num, ld_num, mod_den, ld_den, out, ld_out);
+    SD3D_CHECK_LAUNCH();
+    return SD3D_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Fused multi-head attention, head slices of 32 channels, NSRC concatenated sources per head.
+//   score(q, key) = scale * sum_src  q_src[q, head*32 : +32] . k_src[key, head*32 : +32]
+//   (NSRC = 2 is the reference's per-head [content | positional] concatenation, decoder :681-687,
+//    without ever building the 512-wide tensors)
+//   out[q, head*32 : +32] = softmax_keys(score masked by bits) @ v[key, head*32 : +32]
+// One workgroup = (32-query tile, head); its NW waves split the key tiles and are merged through
+// LDS in a fixed order.  Per wave and 32-key tile:
+//   S^T  = K_tile . Q_tile^T        16*NSRC MFMA 32x32x2 : lane (col = query) holds 16 keys of ITS query
+//   online softmax is therefore lane-local (+1 cross-half shuffle for the max)
+//   O^T += V_tile^T . P^T           16 MFMA             : P registers feed the B operand unchanged
+// mask bits: word [q][tile], bit b = 1 -> key tile*32+b is blocked.
+// ---------------------------------------------------------------------------------------------
+struct AttnParams {
+    const float* q[2]; int ldq[2];
+    const float* k[2]; int ldk[2];
+    const float* v; int ldv;
+    const uint32_t* bits; int nwords;
+    float* out; int ldo;
+    int Lq, Lk, H;
+    float scale;
+};
+
+template <int NSRC>
+__global__ __launch_bounds__(512) void attention_kernel(const AttnParams p) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int nw = blockDim.x >> 6;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int i = lane & 31, h = lane >> 5;
+    const int head = blockIdx.y;
+    const int q0 = blockIdx.x * 32;
+    const int qi = min(q0 + i, p.Lq - 1);
+    const int hc = head * 32 + h * 16;
+
+    float qreg[NSRC][16];
+#pragma unroll
+    for (int s = 0; s < NSRC; ++s) {
+        const float* src = p.q[s] + (int64_t)qi * p.ldq[s] + hc;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const f32x4 t = *(const f32x4*)(src + e * 4);
+#pragma unroll
+            for (int c = 0; c < 4; ++c) qreg[s][e * 4 + c] = t[c] * p.scale;
+        }
+    }
+    f32x16 O;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) O[r] = 0.f;
+    float m = -INFINITY, l = 0.f;
+
+    const int ntiles = (p.Lk + 31) >> 5;
+    for (int t = wave; t < ntiles; t += nw) {
+        const int kt0 = t * 32;
+        const int kr = min(kt0 + i, p.Lk - 1);          // A-operand row = key
+        f32x16 S;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) S[r] = 0.f;
+#pragma unroll
+        for (int s = 0; s < NSRC; ++s) {
+            const float* src = p.k[s] + (int64_t)kr * p.ldk[s] + hc;
+            f32x4 kk[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) kk[e] = *(const f32x4*)(src + e * 4);
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+#pragma unroll
+                for (int c = 0; c < 4; ++c)
+                    S = __builtin_amdgcn_mfma_f32_32x32x2f32(kk[e][c], qreg[s][e * 4 + c], S, 0, 0, 0);
+        }
+        // S[r] = score(key = kt0 + (r&3) + 8*(r>>2) + 4*h, query = q0 + i)
+        const uint32_t word = p.bits ? p.bits[(int64_t)qi * p.nwords + t] : 0u;
+        float tmax = -INFINITY;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int kb = (r & 3) + 8 * (r >> 2) + 4 * h;
+            const bool blocked = ((word >> kb) & 1u) || (kt0 + kb >= p.Lk);
+            S[r] = blocked ? -INFINITY : S[r];
+            tmax = fmaxf(tmax, S[r]);
+        }
+        tmax = fmaxf(tmax, __shfl_xor(tmax, 32));
+        const float mn = fmaxf(m, tmax);
+        float alpha = 1.f;
+        float pr[16];
+        if (mn == -INFINITY) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) pr[r] = 0.f;
+        } else {
+            alpha = expf(m - mn);                       // m = -inf -> 0
+            float ls = 0.f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { pr[r] = expf(S[r] - mn); ls += pr[r]; }
+            l = l * alpha + ls;
+            m = mn;
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) O[r] *= alpha;
+        // O^T[dv][query] += sum_key V[key][dv] * P[query][key];  A = V^T (row = dv = i), B = P^T
+        const float* vsrc = p.v + head * 32 + i;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int key = min(kt0 + (r & 3) + 8 * (r >> 2) + 4 * h, p.Lk - 1);
+            const float vv = vsrc[(int64_t)key * p.ldv];
+            O = __builtin_amdgcn_mfma_f32_32x32x2f32(vv, pr[r], O, 0, 0, 0);
+        }
+    }
+    l += __shfl_xor(l, 32);
+
+    // ---- merge the NW partial results: smem layout per wave: m[32], l[32], O[32 dv][32 q]
+    float* wm = smem + wave * (64 + 1024);
+    float* wl = wm + 32;
+    float* wo = wl + 32;
+    if (h == 0) { wm[i] = m; wl[i] = l; }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) wo[((r & 3) + 8 * (r >> 2) + 4 * h) * 32 + i] = O[r];
+    __syncthreads();
+    for (int e = threadIdx.x; e < 1024; e += blockDim.x) {
+        const int qq = e >> 5, dv = e & 31;             // consecutive threads -> consecutive dv (coalesced store)
+        float M = -INFINITY;
+        for (int w = 0; w < nw; ++w) M = fmaxf(M, smem[w * (64 + 1024) + qq]);
+        float L = 0.f, acc = 0.f;
+        for (int w = 0; w < nw; ++w) {
+            const float* base = smem + w * (64 + 1024);
+            const float mw = base[qq];
+            const float f = (mw == -INFINITY) ? 0.f : expf(mw - M);
+            L += base[32 + qq] * f;
+            acc += base[64 + dv * 32 + qq] * f;
+        }
+        if (q0 + qq < p.Lq) p.out[(int64_t)(q0 + qq) * p.ldo + head * 32 + dv] = acc / L;
+    }
+}
+
+int launch_attention(const AttnParams& p, int nsrc, hipStream_t st) {
+    if (p.Lq <= 0 || p.Lk <= 0) return sd3d_set_error(SD3D_ERR_ARG, "attention: empty query or key set");
+    for (int s = 0; s < nsrc; ++s)
+        if ((p.ldq[s] & 3) || (p.ldk[s] & 3)) return sd3d_set_error(SD3D_ERR_ARG, "attention: q/k strides must be multiples of 4");
+    const int ntiles = (p.Lk + 31) / 32;
+    int nw = ntiles >= 32 ? 8 : (ntiles >= 8 ? 4 : (ntiles >= 2 ? 2 : 1));
+    const dim3 grid((unsigned)cdiv(p.Lq, 32), (unsigned)p.H), block(64 * nw);
+    const size_t sm = (size_t)nw * (64 + 1024) * sizeof(float);
+    if (nsrc == 1) hipLaunchKernelGGL(attention_kernel<1>, grid, block, sm, st, p);
+    else if (nsrc == 2) hipLaunchKernelGGL(attention_kernel<2>, grid, block, sm, st, p);
+    else return sd3d_set_error(SD3D_ERR_ARG, "attention: nsrc must be 1 or 2");
+    SD3D_CHECK_LAUNCH();
+    return SD3D_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// mask head bits (_forward_head :567-572): blocked = sigmoid(logit) < thr; a row with every real
+// column blocked is reset to all-open.  Bits beyond S are always 1 (blocked).  One wave per row.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void mask_bits_kernel(const float* __restrict__ logits, int ld, int64_t Q, int S, float thr,
+                                                        uint32_t* __restrict__ bits, int nwords) {
+    const int lane = threadIdx.x & 63;
+    const int64_t q = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (q >= Q) return;
+    bool any_open = false;
+    for (int w0 = 0; w0 < nwords; w0 += 64) {
+        const int w = w0 + lane;
+        uint32_t word = 0xFFFFFFFFu;
+        if (w < nwords) {
+            word = 0u;
+            for (int b = 0; b < 32; ++b) {
+                const int s = w * 32 + b;
+                bool blk = true;
+                if (s < S) {
+                    const float sg = 1.0f / (1.0f + expf(-logits[q * ld + s]));
+                    blk = sg < thr;
+                    any_open |= !blk;
+                }
+                word |= (blk ? 1u : 0u) << b;
+            }
+            bits[q * nwords + w] = word;
+        }
+    }
+    if (__ballot(any_open) == 0ull) {       // dead row -> attend everywhere (real columns only)
+        for (int w = lane; w < nwords; w += 64) {
+            const int rem = S - w * 32;
+            bits[q * nwords + w] = rem >= 32 ? 0u : (0xFFFFFFFFu << rem);
+        }
+    }
+}
+
+int launch_mask_bits(const float* logits, int ld, int64_t Q, int S, float thr, uint32_t* bits, int nwords, hipStream_t st) {
+    if (Q <= 0) return SD3D_OK;
+    if (nwords != (S + 31) / 32) return sd3d_set_error(SD3D_ERR_ARG, "mask_bits: nwords != ceil(S/32)");
+    hipLaunchKernelGGL(mask_bits_kernel, dim3((unsigned)cdiv(Q, 4)), dim3(256), 0, st, logits, ld, Q, S, thr, bits, nwords);
+    SD3D_CHECK_LAUNCH();
+    return SD3D_OK;
+}
+
+// near[m][w] bit b = 1  <=>  L1(pos[w*32+b], ctr[m]) < thr        (torch.cdist(p=1) < thr, :721-722)
+__global__ __launch_bounds__(256) void near_bits_kernel(const float* __restrict__ pos, int64_t S, const float* __restrict__ ctr,
+                                                        int64_t Mq, float thr, uint32_t* __restrict__ near, int nwords) {
+    const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (t >= Mq * nwords) return;
+    const int64_t m = t / nwords;
+    const int w = (int)(t - m * nwords);
+    const float cx = ctr[m * 3], cy = ctr[m * 3 + 1], cz = ctr[m * 3 + 2];
+    uint32_t word = 0u;
+    for (int b = 0; b < 32; ++b) {
+        const int64_t s = (int64_t)w * 32 + b;
+        if (s < S) {
+            const float d = fabsf(pos[s * 3] - cx) + fabsf(pos[s * 3 + 1] - cy) + fabsf(pos[s * 3 + 2] - cz);
+            word |= (d < thr ? 1u : 0u) << b;
+        }
+    }
+    near[t] = word;
+}
+
+// blocked2d[q] bit m = 1 <=> no superpoint is both open for query q and near 2D query m  (:722-726);
+// key Mq is the appended dummy key (always open); bits beyond Mq are blocked.
+__global__ __launch_bounds__(64) void dinox_mask_bits_kernel(const uint32_t* __restrict__ blocked, const uint32_t* __restrict__ near,
+                                                             int nwords, int64_t Q, int64_t Mq, uint32_t* __restrict__ out,
+                                                             int nwords_out) {
+    const int lane = threadIdx.x;
+    const int64_t q = blockIdx.y;
+    const int64_t m = (int64_t)blockIdx.x * 64 + lane;
+    bool blk = true;
+    if (m < Mq) {
+        bool hit = false;
+        const uint32_t* a = blocked + q * nwords;
+        const uint32_t* b = near + m * nwords;
+        for (int w = 0; w < nwords; ++w) hit |= ((~a[w]) & b[w]) != 0u;
+        blk = !hit;
+    } else if (m == Mq) {
+        blk = false;
+    }
+    const uint64_t bal = __ballot(blk);
+    if (lane == 0) {
+        const int w = blockIdx.x * 2;
+        if (w < nwords_out) out[q * nwords_out + w] = (uint32_t)bal;
+        if (w + 1 < nwords_out) out[q * nwords_out + w + 1] = (uint32_t)(bal >> 32);
+    }
+}
+
+int launch_near_bits(const float* pos, int64_t S, const float* ctr, int64_t Mq, float thr, uint32_t* near, int nwords, hipStream_t st) {
+    if (Mq <= 0 || S <= 0) return SD3D_OK;
+    hipLaunchKernelGGL(near_bits_kernel, dim3((unsigned)cdiv(Mq * nwords, 256)), dim3(256), 0, st, pos, S, ctr, Mq, thr, near, nwords);
+    SD3D_CHECK_LAUNCH();
+    return SD3D_OK;
+}
+int launch_dinox_mask_bits(const uint32_t* blocked, const uint32_t* near, int nwords, int64_t Q, int64_t Mq, uint32_t* out,
+                           int nwords_out, hipStream_t st) {
+    if (Q <= 0) return SD3D_OK;
+    if (nwords_out != (int)((Mq + 1 + 31) / 32)) return sd3d_set_error(SD3D_ERR_ARG, "dinox_mask_bits: nwords_out != ceil((M+1)/32)");
+    hipLaunchKernelGGL(dinox_mask_bits_kernel, dim3((unsigned)cdiv(Mq + 1, 64), (unsigned)Q), dim3(64), 0, st, blocked, near, nwords,
+                       Q, Mq, out, nwords_out);
+    SD3D_CHECK_LAUNCH();
+    return SD3D_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// iterative box refinement (:735-759, 768-772), elementwise over [Q,3]:
+//   center   = ref_point + d_center
+//   size     = normalize ? sigmoid(inverse_sigmoid(size_prev) + d_size) : size_prev + d_size
+//   size_out = normalize ? size * (hi - lo) : size           (metric size reported to the caller)
+// size_prev may have row stride 0 (layer 0: one broadcast row).
+// ---------------------------------------------------------------------------------------------
+__global__ void box_refine_kernel(const float* __restrict__ ref, const float* __restrict__ dc, const float* __restrict__ sprev,
+                                  int ld_sprev, const float* __restrict__ ds, const float* __restrict__ rng, int normalize,
+                                  int64_t Q, float* __restrict__ center, float* __restrict__ size, float* __restrict__ size_out) {
+    const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (t >= Q * 3) return;
+    const int64_t q = t / 3;
+    const int a = (int)(t - q * 3);
+    center[t] = ref[t] + dc[t];
+    if (!ds) return;
+    const float sp = sprev[q * ld_sprev + a];
+    float s;
+    if (normalize) {
+        const float eps = 1e-5f;
+        const float x = fminf(fmaxf(sp, 0.f), 1.f);
+        const float x1 = fmaxf(x, eps), x2 = fmaxf(1.f - x, eps);
+        const float z = logf(x1 / x2) + ds[t];
+        s = 1.0f / (1.0f + expf(-z));
+        size_out[t] = s * (rng[3 + a] - rng[a]);
+    } else {
+        s = sp + ds[t];
+        size_out[t] = s;
+    }
+    size[t] = s;
+}
+
+int launch_box_refine(const float* ref, const float* dc, const float* sprev, int ld_sprev, const float* ds, const float* rng,
+                      int normalize, int64_t Q, float* center, float* size, float* size_out, hipStream_t st) {
+    if (Q <= 0) return SD3D_OK;
+    hipLaunchKernelGGL(box_refine_kernel, dim3((unsigned)cdiv(Q * 3, 256)), dim3(256), 0, st, ref, dc, sprev, ld_sprev, ds, rng,
+                       normalize, Q, center, size, size_out);
+    SD3D_CHECK_LAUNCH();
+    return SD3D_OK;
+}

@@ -1,0 +1,354 @@
+// Post-processing kernels (reference: segdino3d/models/architecture/baseline3d.py:22-141 matrix-NMS,
+// :348-371 box filter, :406-486 instance prediction, :488-556 semantic / panoptic maps;
+// SURVEY.md 2b K20, K21).  All HBM-bound; the [600, N] point masks are produced once, bit-tested and
+// written as bytes (torch.bool layout the evaluator reads), never as fp32.
+#include "common.h"
+
+__device__ static inline float wred_sum(float v) {
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) v += __shfl_xor(v, d);
+    return v;
+}
+__device__ static inline float wred_max(float v) {
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) v = fmaxf(v, __shfl_xor(v, d));
+    return v;
+}
+
+// scores[q*C + c] = softmax(cls[q, 0:C+1])[c], c < C   (:427)        one wave per query
+__global__ __launch_bounds__(256) void class_scores_kernel(const float* __restrict__ cls, int ld, int64_t Q, int C,
+                                                           float* __restrict__ scores, float* __restrict__ rowmax) {
+    const int lane = threadIdx.x & 63;
+    const int64_t q = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (q >= Q) return;
+    const float* row = cls + q * ld;
+    float mx = -INFINITY;
+    for (int c = lane; c <= C; c += 64) mx = fmaxf(mx, row[c]);
+    mx = wred_max(mx);
+    float s = 0.f;
+    for (int c = lane; c <= C; c += 64) s += expf(row[c] - mx);
+    s = wred_sum(s);
+    float best = -INFINITY;
+    for (int c = lane; c < C; c += 64) {
+        const float pr = expf(row[c] - mx) / s;
+        if (scores) scores[q * C + c] = pr;
+        best = fmaxf(best, pr);
+    }
+    best = wred_max(best);
+    if (rowmax && lane == 0) rowmax[q] = best;
+}
+
+// per selected instance r (flat index f = flat_idx[r] into [Q, C]):
+//   label = f % C, qidx = f / C, logit row = masks[qidx]
+//   score_out[r] = score_in[r] * sum(sigmoid * [logit > 0]) / (sum([logit > 0]) + 1e-6)     (:443-446)
+__global__ __launch_bounds__(256) void mask_scores_kernel(const float* __restrict__ masks, int ld, int S,
+                                                          const uint32_t* __restrict__ flat_idx, const float* __restrict__ score_in,
+                                                          int n, int C, int normalize, int32_t* __restrict__ labels,
+                                                          int32_t* __restrict__ qidx, float* __restrict__ score_out) {
+    const int lane = threadIdx.x & 63;
+    const int r = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (r >= n) return;
+    const uint32_t f = flat_idx[r];
+    const int q = (int)(f / (uint32_t)C);
+    const float* row = masks + (int64_t)q * ld;
+    float num = 0.f, den = 0.f;
+    for (int s = lane; s < S; s += 64) {
+        const float x = row[s];
+        if (x > 0.f) { num += 1.0f / (1.0f + expf(-x)); den += 1.f; }
+    }
+    num = wred_sum(num);
+    den = wred_sum(den);
+    if (lane == 0) {
+        labels[r] = (int32_t)(f % (uint32_t)C);
+        qidx[r] = q;
+        score_out[r] = normalize ? score_in[r] * (num / (den + 1e-6f)) : score_in[r];
+    }
+}
+
+// sig[r, :] = sigmoid(masks[qidx[order[r]], :]) (zero padded to ld_out), area[r] = sum      (:441, :66)
+__global__ __launch_bounds__(256) void gather_sigmoid_kernel(const float* __restrict__ masks, int ld, int S,
+                                                             const int32_t* __restrict__ qidx, const uint32_t* __restrict__ order,
+                                                             int n, float* __restrict__ sig, int ld_out, float* __restrict__ area) {
+    const int lane = threadIdx.x & 63;
+    const int r = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (r >= n) return;
+    const float* row = masks + (int64_t)qidx[order[r]] * ld;
+    float a = 0.f;
+    for (int s = lane; s < ld_out; s += 64) {
+        float y = 0.f;
+        if (s < S) { y = 1.0f / (1.0f + expf(-row[s])); a += y; }
+        sig[(int64_t)r * ld_out + s] = y;
+    }
+    a = wred_sum(a);
+    if (lane == 0) area[r] = a;
+}
+
+// matrix-NMS decay (:85-119).  inter [n, ld] = sig . sig^T, rows already sorted by score (desc).
+//   diou[i][j] = (i < j && label_i == label_j) ? inter / (area_i + area_j - inter) : 0
+//   comp[j]    = max_i diou[i][j]
+//   coef[j]    = min_i decay(diou[i][j]) / decay(comp[i])      (linear: 1 - x, gaussian: exp(-sigma x^2))
+__device__ static inline float nms_diou(const float* inter, int ld, const float* area, const int32_t* lab, int i, int j) {
+    if (i >= j || lab[i] != lab[j]) return 0.f;
+    const float it = inter[(int64_t)i * ld + j];
+    return it / (area[i] + area[j] - it);
+}
+__global__ void nms_comp_kernel(const float* __restrict__ inter, int ld, const float* __restrict__ area,
+                                const int32_t* __restrict__ lab, int n, float* __restrict__ comp) {
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= n) return;
+    float m = 0.f;                                // row j..n-1 of the column are zeros -> max >= 0
+    bool nan = false;
+    for (int i = 0; i < j; ++i) {
+        const float d = nms_diou(inter, ld, area, lab, i, j);
+        nan |= (d != d);
+        m = fmaxf(m, d);
+    }
+    comp[j] = nan ? NAN : m;
+}
+__global__ void nms_coef_kernel(const float* __restrict__ inter, int ld, const float* __restrict__ area,
+                                const int32_t* __restrict__ lab, const float* __restrict__ comp, int n, int gaussian, float sigma,
+                                const float* __restrict__ score_in, float* __restrict__ score_out) {
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= n) return;
+    float m = INFINITY;
+    bool nan = false;
+    for (int i = 0; i < n; ++i) {
+        const float d = nms_diou(inter, ld, area, lab, i, j);
+        const float c = comp[i];
+        const float v = gaussian ? expf(-sigma * d * d) / expf(-sigma * c * c) : (1.f - d) / (1.f - c);
+        nan |= (v != v);
+        m = fminf(m, v);
+    }
+    score_out[j] = score_in[j] * (nan ? NAN : m);
+}
+
+// Point masks (:453-454, :464-465, :348-371).  For final row r (src row = src[r] of sig), point p:
+//   bit = sig[src[r]][superpoints[p]] > sp_thr ; count[r] = number of bits BEFORE the box filter;
+//   out[r][p] = bit && inside(points[p], center[r] +- size[r] * (1 + loose) / 2)   (if boxes given)
+// One thread handles 4 consecutive points of one row (uchar4 store); grid.y = row.
+__global__ __launch_bounds__(256) void expand_masks_kernel(const float* __restrict__ sig, int ld_sig, const uint32_t* __restrict__ src,
+                                                           const int64_t* __restrict__ superpoints, const float* __restrict__ pts,
+                                                           int ld_pts, int64_t N, float sp_thr, const float* __restrict__ boxes,
+                                                           float loose, uint8_t* __restrict__ out, int32_t* __restrict__ count) {
+    const int r = blockIdx.y;
+    const int64_t p0 = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 4;
+    const float* row = sig + (int64_t)src[r] * ld_sig;
+    float lo[3] = {0, 0, 0}, hi[3] = {0, 0, 0};
+    if (boxes) {
+#pragma unroll
+        for (int a = 0; a < 3; ++a) {
+            const float c = boxes[r * 6 + a], s = boxes[r * 6 + 3 + a] * (1.f + loose);
+            lo[a] = c - s / 2.f;
+            hi[a] = c + s / 2.f;
+        }
+    }
+    int cnt = 0;
+    uint8_t res[4] = {0, 0, 0, 0};
+    if (p0 < N) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int64_t p = p0 + e;
+            if (p >= N) break;
+            bool b = row[superpoints[p]] > sp_thr;
+            cnt += b;
+            if (b && boxes) {
+#pragma unroll
+                for (int a = 0; a < 3; ++a) {
+                    const float x = pts[p * ld_pts + a];
+                    b &= (x >= lo[a]) & (x <= hi[a]);
+                }
+            }
+            res[e] = b;
+        }
+        if (p0 + 3 < N && ((N & 3) == 0)) {
+            *(uchar4*)(out + (int64_t)r * N + p0) = make_uchar4(res[0], res[1], res[2], res[3]);
+        } else {
+            for (int e = 0; e < 4 && p0 + e < N; ++e) out[(int64_t)r * N + p0 + e] = res[e];
+        }
+    }
+    // block-level count -> one atomic per wave
+    float c = wred_sum((float)cnt);
+    if ((threadIdx.x & 63) == 0 && c > 0.f) atomicAdd(&count[r], (int)c);
+}
+
+// sem_q[q] = argmax_c sem[q, classes...]: classes = first n_cls columns (n_cls = C) or an explicit list.
+__global__ __launch_bounds__(256) void row_argmax_kernel(const float* __restrict__ x, int ld, int64_t Q, const int32_t* __restrict__ cols,
+                                                         int ncols, int64_t* __restrict__ out) {
+    const int lane = threadIdx.x & 63;
+    const int64_t q = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (q >= Q) return;
+    float best = -INFINITY;
+    int bi = 0x7fffffff;
+    for (int c = lane; c < ncols; c += 64) {
+        const float v = x[q * ld + (cols ? cols[c] : c)];
+        if (v > best || (v == best && c < bi)) { best = v; bi = c; }
+    }
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) {
+        const float ob = __shfl_xor(best, d);
+        const int oi = __shfl_xor(bi, d);
+        if (ob > best || (ob == best && oi < bi)) { best = ob; bi = oi; }
+    }
+    if (lane == 0) out[q] = bi;
+}
+
+// out[p] = table[use_index ? idx[p] : 0]      (:504-507)
+__global__ void gather_i64_kernel(const int64_t* __restrict__ table, const int64_t* __restrict__ idx, int64_t N, int use_index,
+                                  int64_t* __restrict__ out) {
+    const int64_t p = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (p < N) out[p] = table[use_index ? idx[p] : 0];
+}
+
+// Panoptic paint (:532-543).  rows[0..n) = mask rows in DESCENDING score order; the reference sorts
+// ascending and takes max(inst_id * mask), i.e. the best-scoring instance covering the point wins.
+//   inst[p] = n_stuff + (n - 1 - first_hit)  or 0 ;  sem[p] = label[first_hit] + n_stuff or ... (see finalize)
+__global__ void pan_assign_kernel(const uint8_t* __restrict__ masks, int64_t N, const int32_t* __restrict__ rows, int n, int n_stuff,
+                                  int32_t* __restrict__ inst, int32_t* __restrict__ hist) {
+    const int64_t p = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (p >= N) return;
+    int id = 0;
+    for (int r = 0; r < n; ++r) {
+        if (masks[(int64_t)rows[r] * N + p]) { id = n_stuff + (n - 1 - r); break; }
+    }
+    inst[p] = id;
+    if (id) atomicAdd(&hist[id], 1);
+}
+// (:545-555): drop painted instances with <= npoint_thr points, then compose the two maps
+//   hit: asc position a = id - n_stuff -> label = labels_desc[n-1-a]
+__global__ void pan_finalize_kernel(const int32_t* __restrict__ inst, const int32_t* __restrict__ hist, int npoint_thr,
+                                    const int32_t* __restrict__ labels_desc, int n, int n_stuff, const int64_t* __restrict__ sem_stuff,
+                                    int64_t N, int64_t* __restrict__ sem_map, int64_t* __restrict__ inst_map) {
+    const int64_t p = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (p >= N) return;
+    int id = inst[p];
+    if (id != 0 && hist[id] <= npoint_thr) id = 0;
+    int64_t s = sem_stuff[p];
+    int64_t things_sem = 0;
+    if (id != 0) {
+        things_sem = labels_desc[n - 1 - (id - n_stuff)] + n_stuff;
+        s = 0;
+    }
+    inst_map[p] = s + id;
+    sem_map[p] = s + things_sem;
+}
+
+// ---------------------------------------------------------------------------------------------
+int launch_class_scores(const float* cls, int ld, int64_t Q, int C, float* scores, float* rowmax, hipStream_t st) {
+    if (Q <= 0) return SD3D_OK;
+    hipLaunchKernelGGL(class_scores_kernel, dim3((unsigned)cdiv(Q, 4)), dim3(256), 0, st, cls, ld, Q, C, scores, rowmax);
+    SD3D_CHECK_LAUNCH();
+    return SD3D_OK;
+}
+int launch_mask_scores(const float* masks, int ld, int S, const uint32_t* flat_idx, const float* score_in, int n, int C,
+                       int normalize, int32_t* labels, int32_t* qidx, float* score_out, hipStream_t st) {
+    if (n <= 0) return SD3D_OK;
+    hipLaunchKernelGGL(mask_scores_kernel, dim3((unsigned)cdiv(n, 4)), dim3(256), 0, st, masks, ld, S, flat_idx, score_in, n, C,
+                       normalize, labels, qidx, score_out);
+    SD3D_CHECK_LAUNCH();
+    return SD3D_OK;
+}
+int launch_gather_sigmoid(const float* masks, int ld, int S, const int32_t* qidx, const uint32_t* order, int n, float* sig,
+                          int ld_out, float* area, hipStream_t st) {
+    if (n <= 0) return SD3D_OK;
+    hipLaunchKernelGGL(gather_sigmoid_kernel, dim3((unsigned)cdiv(n, 4)), dim3(256), 0, st, masks, ld, S, qidx, order, n, sig, ld_out,
+                       area);
+    SD3D_CHECK_LAUNCH();
+    return SD3D_OK;
+}
+int launch_nms_decay(const float* inter, int ld, const float* area, const int32_t* labels, int n, int gaussian, float sigma,
+                     const float* score_in, float* comp_ws, float* score_out, hipStream_t st) {
+    if (n <= 0) return SD3D_OK;
+    hipLaunchKernelGGL(nms_comp_kernel, dim3((unsigned)cdiv(n, 64)), dim3(64), 0, st, inter, ld, area, labels, n, comp_ws);
+    hipLaunchKernelGGL(nms_coef_kernel, dim3((unsigned)cdiv(n, 64)), dim3(64), 0, st, inter, ld, area, labels, comp_ws, n, gaussian,
+                       sigma, score_in, score_out);
+    SD3D_CHECK_LAUNCH();
+    return SD3D_OK;
+}
+int launch_expand_masks(const float* sig, int ld_sig, const uint32_t* src, int n, const int64_t* superpoints, const float* pts,
+                        int ld_pts, int64_t N, float sp_thr, const float* boxes, float loose, uint8_t* out, int32_t* count,
+                        hipStream_t st) {
+    if (n <= 0 || N <= 0) return SD3D_OK;
+    (void)hipMemsetAsync(count, 0, (size_t)n * sizeof(int32_t), st);
+    hipLaunchKernelGGL(expand_masks_kernel, dim3((unsigned)cdiv(N, 1024), (unsigned)n), dim3(256), 0, st, sig, ld_sig, src,
+                       superpoints, pts, ld_pts, N, sp_thr, boxes, loose, out, count);
+    SD3D_CHECK_LAUNCH();
+    return SD3D_OK;
+}
+int launch_row_argmax(const float* x, int ld, int64_t Q, const int32_t* cols, int ncols, int64_t* out, hipStream_t st) {
+    if (Q <= 0) return SD3D_OK;
+    hipLaunchKernelGGL(row_argmax_kernel, dim3((unsigned)cdiv(Q, 4)), dim3(256), 0, st, x, ld, Q, cols, ncols, out);
+    SD3D_CHECK_LAUNCH();
+    return SD3D_OK;
+}
+int launch_gather_i64(const int64_t* table, const int64_t* idx, int64_t N, int use_index, int64_t* out, hipStream_t st) {
+    if (N <= 0) return SD3D_OK;
+    hipLaunchKernelGGL(gather_i64_kernel, dim3((unsigned)cdiv(N, 256)), dim3(256), 0, st, table, idx, N, use_index, out);
+    SD3D_CHECK_LAUNCH();
+    return SD3D_OK;
+}
+int launch_panoptic(const uint8_t* masks, int64_t N, const int32_t* rows, const int32_t* labels_desc, int n, int n_stuff,
+                    int npoint_thr, const int64_t* sem_stuff, int32_t* inst_ws, int32_t* hist_ws, int64_t* sem_map,
+                    int64_t* inst_map, hipStream_t st) {
+    if (N <= 0) return SD3D_OK;
+    (void)hipMemsetAsync(hist_ws, 0, (size_t)(n + n_stuff + 1) * sizeof(int32_t), st);
+    const unsigned nb = (unsigned)cdiv(N, 256);
+    hipLaunchKernelGGL(pan_assign_kernel, dim3(nb), dim3(256), 0, st, masks, N, rows, n, n_stuff, inst_ws, hist_ws);
+    hipLaunchKernelGGL(pan_finalize_kernel, dim3(nb), dim3(256), 0, st, inst_ws, hist_ws, npoint_thr, labels_desc, n, n_stuff,
+                       sem_stuff, N, sem_map, inst_map);
+    SD3D_CHECK_LAUNCH();
+    return SD3D_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// GT instance centres / sizes (get_extra_instance_data, baseline3d.py:289-305): per instance the
+// min / max / mean of the points selected by its boolean mask.  One workgroup per instance.
+//   mode 0 "mean": centre = mean ; mode 1 "median": centre = (max + min) / 2 ; size = max - min
+// Instances without points keep centre = size = 0.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void instance_boxes_kernel(const float* __restrict__ pts, int ld, int64_t N,
+                                                             const uint8_t* __restrict__ masks, int64_t mask_stride, int mode,
+                                                             float* __restrict__ centers, float* __restrict__ sizes) {
+    __shared__ float sm[4][10];
+    const int inst = blockIdx.x;
+    const uint8_t* m = masks + (int64_t)inst * mask_stride;
+    float lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY}, su[3] = {0.f, 0.f, 0.f}, cnt = 0.f;
+    for (int64_t p = threadIdx.x; p < N; p += 256) {
+        if (m[p]) {
+            cnt += 1.f;
+#pragma unroll
+            for (int a = 0; a < 3; ++a) {
+                const float x = pts[p * ld + a];
+                lo[a] = fminf(lo[a], x); hi[a] = fmaxf(hi[a], x); su[a] += x;
+            }
+        }
+    }
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+        float l = lo[a], h = hi[a];
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) { l = fminf(l, __shfl_xor(l, d)); h = fmaxf(h, __shfl_xor(h, d)); }
+        const float s = wred_sum(su[a]);
+        if (lane == 0) { sm[w][a] = l; sm[w][3 + a] = h; sm[w][6 + a] = s; }
+    }
+    const float c = wred_sum(cnt);
+    if (lane == 0) sm[w][9] = c;
+    __syncthreads();
+    if (threadIdx.x < 3) {
+        const int a = threadIdx.x;
+        float l = sm[0][a], h = sm[0][3 + a], s = sm[0][6 + a], n = sm[0][9];
+        for (int ww = 1; ww < 4; ++ww) { l = fminf(l, sm[ww][a]); h = fmaxf(h, sm[ww][3 + a]); s += sm[ww][6 + a]; n += sm[ww][9]; }
+        float ctr = 0.f, sz = 0.f;
+        if (n > 0.f) { ctr = mode == 0 ? s / n : (h + l) / 2.f; sz = h - l; }
+        centers[inst * 3 + a] = ctr;
+        sizes[inst * 3 + a] = sz;
+    }
+}
+int launch_instance_boxes(const float* pts, int ld, int64_t N, const uint8_t* masks, int64_t mask_stride, int n_inst, int mode,
+                          float* centers, float* sizes, hipStream_t st) {
+    if (n_inst <= 0) return SD3D_OK;
+    hipLaunchKernelGGL(instance_boxes_kernel, dim3((unsigned)n_inst), dim3(256), 0, st, pts, ld, N, masks, mask_stride, mode,
+                       centers, sizes);
+    SD3D_CHECK_LAUNCH();
+    return SD3D_OK;
+}

@@ -1,0 +1,365 @@
+"""ScanNetQueryDecoder on the MI355X kernels (host side).
+
+Mirrors the reference operator interface `segdino3d/models/decoder/instance_seg_3d_decoder.py`:
+  - constructor kwargs of `QueryDecoder.__init__` (:212-216) + `ScanNetQueryDecoder.__init__` (:441-445),
+    unknown kwargs tolerated;
+  - `forward(x, sp_pos, sp_pos_wo_elastic, queries, queries_pos, dinox_queries, dinox_query_pos,
+    scene_range) -> dict(cls_preds, sem_preds, masks, scores, centers, sizes[, hidden_states,
+    aux_outputs])` of per-scene lists (:417-435, :786-799);
+  - attributes the architecture touches: `add_dinox_query_ca`, `add_box_size_pred`, `query_proj`,
+    `out_norm`, `out_cls`, `return_hidden_states`, `return_aux_outputs` (baseline3d.py:180,198,233-235,321-322);
+  - the same `state_dict` key names / shapes (SURVEY.md 8(b) "Checkpoint names"): torch.nn modules are
+    used as PARAMETER HOLDERS only - their forward is never called.
+All arithmetic goes through segdino3d_amd.ops (libsegdino3d_hip.so): Linear = fp32-MFMA GEMM with
+fused bias/activation/residual, attention = fused masked MFMA kernel on bit-packed masks, the
+layer-invariant key-side projections of all layers are hoisted into two GEMMs per scene, the
+boolean (mask . distance) product is an AND/any over bit words.
+
+Supported configuration = the SegDINO3D prototypes (sine positional embedding, iterative prediction,
+mask attention, superpoint queries).  Eval mode only.
+"""
+from __future__ import annotations
+
+import copy
+from typing import List
+
+import torch
+import torch.nn as nn
+
+from . import ops
+from .builder import DECODERS
+
+
+class MLP(nn.Module):
+    """Parameter holder named like the reference MLP (`utils.py:167-179`): `layers.{i}`."""
+
+    def __init__(self, input_dim, hidden_dim, output_dim, num_layers):
+        super().__init__()
+        self.num_layers = num_layers
+        h = [hidden_dim] * (num_layers - 1)
+        self.layers = nn.ModuleList(nn.Linear(n, k) for n, k in zip([input_dim] + h, h + [output_dim]))
+
+
+class _OutProjOnly(nn.Module):
+    """The reference's projection-free MultiheadAttention owns just `out_proj` (`attention.py:100-101`)."""
+
+    def __init__(self, vdim):
+        super().__init__()
+        self.out_proj = nn.Linear(vdim, vdim)
+        nn.init.constant_(self.out_proj.bias, 0.0)
+
+
+class _CrossAttentionHolder(nn.Module):
+    """`CrossAttentionLayer` (:36-58): nn.MultiheadAttention (packed in-proj) + LayerNorm."""
+
+    def __init__(self, d_model, num_heads, dropout, fix):
+        super().__init__()
+        self.fix = fix
+        self.attn = nn.MultiheadAttention(d_model, num_heads, dropout=dropout, batch_first=True)
+        self.norm = nn.LayerNorm(d_model)
+        for p in self.parameters():
+            if p.dim() > 1:
+                nn.init.xavier_uniform_(p)
+
+
+class _FFNHolder(nn.Module):
+    def __init__(self, d_model, hidden_dim, dropout, activation_fn):
+        super().__init__()
+        self.net = nn.Sequential(nn.Linear(d_model, hidden_dim), nn.ReLU() if activation_fn == "relu" else nn.GELU(),
+                                 nn.Dropout(dropout), nn.Linear(hidden_dim, d_model), nn.Dropout(dropout))
+        self.norm = nn.LayerNorm(d_model)
+
+
+def _lin(x, layer: nn.Linear, act=None, res=None):
+    return ops.linear(x, layer.weight, layer.bias, act=act, res=res)
+
+
+def _mlp(x, mlp: MLP, final_act=None, res=None):
+    n = len(mlp.layers)
+    for i, layer in enumerate(mlp.layers):
+        last = i == n - 1
+        x = _lin(x, layer, act=(final_act if last else "relu"), res=(res if last else None))
+    return x
+
+
+@DECODERS.register_module()
+class ScanNetQueryDecoder(nn.Module):
+    def __init__(self, num_layers, num_instance_queries, num_semantic_queries, num_instance_classes,
+                 num_semantic_classes, num_semantic_linears, in_channels, d_model, num_heads, hidden_dim, dropout,
+                 activation_fn, iter_pred, attn_mask, fix_attention, objectness_flag, add_dinox_query_ca=False,
+                 add_dinox_query_ca_mask=False, dinox_query_ca_mask_threshold=0.2, mask_attention_threshold=0.5,
+                 add_positional_embedding=False, pos_type="fourier", temperature=10000, gauss_scale=1.0,
+                 add_box_size_pred=False, box_modulate_ca=False, normalize_box_prediction=False,
+                 use_activation_checkpoint=False, **kwargs):
+        super().__init__()
+        assert num_semantic_linears in [1, 2]
+        unsupported = []
+        if not add_positional_embedding or pos_type != "sine":
+            unsupported.append("add_positional_embedding=True with pos_type='sine' is required")
+        if not iter_pred or not attn_mask:
+            unsupported.append("iter_pred=True and attn_mask=True are required")
+        if num_instance_queries + num_semantic_queries != 0 or objectness_flag:
+            unsupported.append("learned query embeddings / objectness head are not built")
+        if d_model != num_heads * 32:
+            unsupported.append("attention heads must be 32 channels wide (d_model == 32 * num_heads)")
+        if dropout != 0.0:
+            unsupported.append("dropout must be 0 (eval-mode forward only)")
+        if add_dinox_query_ca and not add_dinox_query_ca_mask:
+            unsupported.append("add_dinox_query_ca requires add_dinox_query_ca_mask")
+        if box_modulate_ca:
+            assert add_positional_embedding and add_box_size_pred, \
+                " If you want to use box to modulate cross attention, you should set add_positional_embedding and add_box_size_pred to True."
+        if unsupported:
+            raise NotImplementedError("segdino3d_amd ScanNetQueryDecoder: " + "; ".join(unsupported))
+        L, d = num_layers, d_model
+        self.return_hidden_states = True
+        self.return_aux_outputs = True
+        self.num_layers, self.d_model, self.num_heads, self.in_channels = L, d, num_heads, in_channels
+        self.iter_pred, self.attn_mask, self.objectness_flag = iter_pred, attn_mask, objectness_flag
+        self.activation_fn = activation_fn
+        self.add_dinox_query_ca = add_dinox_query_ca
+        self.add_dinox_query_ca_mask = add_dinox_query_ca_mask
+        self.dinox_query_ca_mask_threshold = dinox_query_ca_mask_threshold
+        self.mask_attention_threshold = mask_attention_threshold
+        self.num_semantic_classes = num_semantic_classes
+        self.num_instance_classes = num_instance_classes
+        self.add_positional_embedding = add_positional_embedding
+        self.add_box_size_pred = add_box_size_pred
+        self.box_modulate_ca = box_modulate_ca
+        self.normalize_box_prediction = normalize_box_prediction
+        self.temperature = float(temperature)
+        self.num_queries = 0
+
+        self.input_proj = nn.Sequential(nn.Linear(in_channels, d), nn.LayerNorm(d), nn.ReLU())
+        self.query_proj = nn.Sequential(nn.Linear(in_channels, d), nn.ReLU(), nn.Linear(d, d))
+        self.cross_attn_layers = nn.ModuleList(_OutProjOnly(d) for _ in range(L))
+        self.self_attn_layers = nn.ModuleList(_OutProjOnly(d) for _ in range(L))
+        self.ffn_layers = nn.ModuleList(_FFNHolder(d, hidden_dim, dropout, activation_fn) for _ in range(L))
+        self.out_norm = nn.LayerNorm(d)
+        self.out_cls = nn.Sequential(nn.Linear(d, d), nn.ReLU(), nn.Linear(d, num_instance_classes + 1))
+        self.x_mask = nn.Sequential(nn.Linear(in_channels, d), nn.ReLU(), nn.Linear(d, d))
+        if num_semantic_linears == 2:
+            self.out_sem = nn.Sequential(nn.Linear(d, d), nn.ReLU(), nn.Linear(d, num_semantic_classes + 1))
+        else:
+            self.out_sem = nn.Linear(d, num_semantic_classes + 1)
+        if add_dinox_query_ca:
+            self.dinox_query_cross_attn_layers = nn.ModuleList(
+                _CrossAttentionHolder(d, num_heads, dropout, fix_attention) for _ in range(L))
+        self.ref_point_head = MLP(d, d, d, 2)
+        bbox = MLP(d, d, 3, 3)
+        nn.init.constant_(bbox.layers[-1].weight.data, 0)
+        nn.init.constant_(bbox.layers[-1].bias.data, 0)
+        self.bbox_embed = nn.ModuleList(copy.deepcopy(bbox) for _ in range(L))
+        mk = lambda: nn.ModuleList(nn.Linear(d, d) for _ in range(L))  # noqa: E731
+        self.ca_qcontent_proj = mk()
+        self.ca_qpos_proj = nn.Linear(d, d)
+        self.ca_kcontent_proj, self.ca_kpos_proj, self.ca_v_proj, self.ca_qpos_sine_proj = mk(), mk(), mk(), mk()
+        self.norm1 = nn.ModuleList(nn.LayerNorm(d) for _ in range(L))
+        self.sa_qcontent_proj, self.sa_qpos_proj, self.sa_kcontent_proj = mk(), mk(), mk()
+        self.sa_kpos_proj, self.sa_v_proj = mk(), mk()
+        self.norm2 = nn.ModuleList(nn.LayerNorm(d) for _ in range(L))
+        if add_box_size_pred:
+            self.bbox_size_embed = nn.ModuleList(copy.deepcopy(bbox) for _ in range(L))
+        if box_modulate_ca:
+            self.ref_anchor_head = MLP(d, d, 3, 2)
+        self._packed = None
+        self._pe_tables = {}
+
+    # ---- derived weights (hoisted / concatenated), rebuilt after .to() / load_state_dict ----------
+    def _apply(self, fn, *a, **k):
+        self._packed = None
+        self._pe_tables = {}
+        return super()._apply(fn, *a, **k)
+
+    def load_state_dict(self, *a, **k):
+        self._packed = None
+        return super().load_state_dict(*a, **k)
+
+    def invalidate_packed_weights(self):
+        self._packed = None
+
+    def packed(self):
+        if self._packed is None:
+            d, L = self.d_model, self.num_layers
+            cat = lambda mods, attr: torch.cat([getattr(m, attr).detach() for m in mods]).contiguous()  # noqa: E731
+            pk = {
+                # all layers' key-content and value projections of the superpoint features: [2*L*d, d]
+                "kv_w": torch.cat([cat(self.ca_kcontent_proj, "weight"), cat(self.ca_v_proj, "weight")]).contiguous(),
+                "kv_b": torch.cat([cat(self.ca_kcontent_proj, "bias"), cat(self.ca_v_proj, "bias")]).contiguous(),
+                "kp_w": cat(self.ca_kpos_proj, "weight"), "kp_b": cat(self.ca_kpos_proj, "bias"),
+            }
+            if self.add_dinox_query_ca:
+                ws = [m.attn.in_proj_weight.detach() for m in self.dinox_query_cross_attn_layers]
+                bs = [m.attn.in_proj_bias.detach() for m in self.dinox_query_cross_attn_layers]
+                pk["q2d_w"] = [w[:d].contiguous() for w in ws]
+                pk["q2d_b"] = [b[:d].contiguous() for b in bs]
+                pk["kv2d_w"] = torch.cat([w[d:2 * d] for w in ws] + [w[2 * d:] for w in ws]).contiguous()
+                pk["kv2d_b"] = torch.cat([b[d:2 * d] for b in bs] + [b[2 * d:] for b in bs]).contiguous()
+            self._packed = pk
+        return self._packed
+
+    def pe_tables(self, device):
+        """(dim_t [d] fp32, axis [d] int8): per-channel divisor and coordinate axis of the sine PE
+        (`utils.py:64-86`): channel split 86/86/84 for d=256, dim_t = T^(2*(i//2)/cdim)."""
+        key = str(device)
+        if key not in self._pe_tables:
+            d_pos, d_in = self.d_model, 3
+            ndim = d_pos // d_in
+            if ndim % 2:
+                ndim -= 1
+            rems = d_pos - ndim * d_in
+            dim_t, axis = [], []
+            for a in range(d_in):
+                cdim = ndim
+                if rems > 0:
+                    cdim += 2
+                    rems -= 2
+                i = torch.arange(cdim, dtype=torch.float32)
+                dim_t.append(self.temperature ** (2 * (i // 2) / cdim))
+                axis.append(torch.full((cdim,), a, dtype=torch.int8))
+            self._pe_tables[key] = (torch.cat(dim_t).to(device).contiguous(), torch.cat(axis).to(device).contiguous())
+        return self._pe_tables[key]
+
+    # ---- prediction head (:532-577) ----------------------------------------------------------------
+    def _head(self, queries, mask_feats, last_flag):
+        S = mask_feats.shape[0]
+        nq = ops.layernorm(queries, self.out_norm.weight, self.out_norm.bias)
+        cls = _lin(_lin(nq, self.out_cls[0], act="relu"), self.out_cls[2])
+        sem = None
+        if last_flag:
+            if isinstance(self.out_sem, nn.Linear):
+                sem = _lin(nq, self.out_sem)
+            else:
+                sem = _lin(_lin(nq, self.out_sem[0], act="relu"), self.out_sem[2])
+        logits = ops.gather_gemm(nq, mask_feats)                      # einsum('nd,md->nm')
+        bits = ops.mask_bits(logits, S, self.mask_attention_threshold)
+        return cls, sem, logits, bits
+
+    def select_scores(self, x):
+        """max_c softmax(out_cls(out_norm(query_proj(x))))[:-1] per superpoint (baseline3d.py:233-238)."""
+        q = _lin(_lin(x, self.query_proj[0], act="relu"), self.query_proj[2])
+        nq = ops.layernorm(q, self.out_norm.weight, self.out_norm.bias)
+        cls = _lin(_lin(nq, self.out_cls[0], act="relu"), self.out_cls[2])
+        return ops.class_scores(cls, self.num_instance_classes, want_scores=False, want_rowmax=True)[1]
+
+    # ---- one scene -----------------------------------------------------------------------------------
+    def _forward_scene(self, x, sp_pos, sp_pos_wo, q_in, q_pos, q2d_feat, q2d_pos, lo, hi):
+        if self.training:
+            raise NotImplementedError("segdino3d_amd decoder: eval-mode forward only (training step not built)")
+        dev = x.device
+        d, H, L = self.d_model, self.num_heads, self.num_layers
+        pk = self.packed()
+        dim_t, axis = self.pe_tables(dev)
+        x, sp_pos, q_in, q_pos = x.contiguous(), sp_pos.contiguous(), q_in.contiguous(), q_pos.contiguous()
+        Q = q_in.shape[0]
+        rng = torch.cat([lo.reshape(3), hi.reshape(3)]).float().contiguous()
+        memory_emb = ops.sine_pe(sp_pos, rng, dim_t, axis)
+        if self.normalize_box_prediction:
+            size_q = (1 / (hi - lo) * 0.5).float().reshape(3).contiguous()      # one row, broadcast over queries
+        else:
+            size_q = torch.full((Q, 3), 0.5, dtype=torch.float32, device=dev)
+        inst = ops.layernorm(_lin(x, self.input_proj[0]), self.input_proj[1].weight, self.input_proj[1].bias, act="relu")
+        mask_feats = _lin(_lin(x, self.x_mask[0], act="relu"), self.x_mask[2])
+        queries = _lin(_lin(q_in, self.query_proj[0], act="relu"), self.query_proj[2])
+        cls, sem, logits, bits = self._head(queries, mask_feats, False)
+        aux = [dict(cls_preds=cls, sem_preds=None, masks=logits, centers=None, sizes=None)]
+
+        # layer-invariant key side, hoisted out of the loop (the reference recomputes it per layer, :669-671)
+        kv_all = ops.linear(inst, pk["kv_w"], pk["kv_b"])                  # [S, 2*L*d]: kc_0..kc_{L-1} | v_0..v_{L-1}
+        kp_all = ops.linear(memory_emb, pk["kp_w"], pk["kp_b"])            # [S, L*d]
+        if self.add_dinox_query_ca:
+            if not isinstance(q2d_pos, torch.Tensor):
+                q2d_pos = q2d_pos.tensor.type(sp_pos_wo.dtype).to(dev)
+            keys2d = torch.cat([q2d_feat.float(), q2d_feat.new_ones(1, q2d_feat.shape[1], dtype=torch.float32)]).contiguous()
+            kv2d_all = ops.linear(keys2d, pk["kv2d_w"], pk["kv2d_b"])      # [M+1, 2*L*d]
+            near = ops.near_bits(sp_pos_wo.float().contiguous(), q2d_pos.float().contiguous(),
+                                 self.dinox_query_ca_mask_threshold)
+
+        ref_points = q_pos.float().contiguous()
+        ref_sizes = size_q
+        for i in range(L):
+            # ---- box-modulated positional query (:659-666)
+            if self.box_modulate_ca:
+                hwl = _mlp(queries, self.ref_anchor_head, final_act="sigmoid")
+                pq_emb = ops.sine_pe(ref_points, rng, dim_t, axis, mod_num=hwl, mod_den=ref_sizes)
+            else:
+                pq_emb = ops.sine_pe(ref_points, rng, dim_t, axis)
+            query_pos = _mlp(pq_emb, self.ref_point_head)
+            # ---- masked cross-attention to the superpoints (:668-691)
+            kc = kv_all[:, i * d:(i + 1) * d]
+            v = kv_all[:, (L + i) * d:(L + i + 1) * d]
+            kp = kp_all[:, i * d:(i + 1) * d]
+            if i == 0:
+                qc = _lin(queries, self.ca_qcontent_proj[0], res=_lin(query_pos, self.ca_qpos_proj))
+                kc = _lin(inst, self.ca_kcontent_proj[0], res=kp)
+            else:
+                qc = _lin(queries, self.ca_qcontent_proj[i])
+            qs = _lin(pq_emb, self.ca_qpos_sine_proj[i])
+            a = ops.attention(qc, kc, v, H, (2 * d // H) ** -0.5, mask_bits=bits, q2=qs, k2=kp)
+            a = _lin(a, self.cross_attn_layers[i].out_proj)
+            queries = ops.layernorm(a, self.norm1[i].weight, self.norm1[i].bias, res=queries)
+            # ---- self-attention (:695-709)
+            q = _lin(queries, self.sa_qcontent_proj[i], res=_lin(query_pos, self.sa_qpos_proj[i]))
+            k = _lin(queries, self.sa_kcontent_proj[i], res=_lin(query_pos, self.sa_kpos_proj[i]))
+            v = _lin(queries, self.sa_v_proj[i])
+            a = ops.attention(q, k, v, H, (d // H) ** -0.5)
+            a = _lin(a, self.self_attn_layers[i].out_proj)
+            queries = ops.layernorm(a, self.norm2[i].weight, self.norm2[i].bias, res=queries)
+            # ---- cross-attention to the cached DINO-X 2D object queries (:713-731, :60-86)
+            if self.add_dinox_query_ca:
+                layer = self.dinox_query_cross_attn_layers[i]
+                bits2d = ops.dinox_mask_bits(bits, near)
+                q = ops.linear(queries, pk["q2d_w"][i], pk["q2d_b"][i])
+                a = ops.attention(q, kv2d_all[:, i * d:(i + 1) * d], kv2d_all[:, (L + i) * d:(L + i + 1) * d], H,
+                                  (d // H) ** -0.5, mask_bits=bits2d)
+                if layer.fix:
+                    a = _lin(a, layer.attn.out_proj)
+                    queries = ops.layernorm(a, layer.norm.weight, layer.norm.bias, res=queries)
+                else:
+                    queries = _lin(a, layer.attn.out_proj, res=queries)
+            # ---- FFN (:173-190)
+            ffn = self.ffn_layers[i]
+            hdn = _lin(queries, ffn.net[0], act=("relu" if self.activation_fn == "relu" else "gelu"))
+            hdn = _lin(hdn, ffn.net[3], res=queries)
+            queries = ops.layernorm(hdn, ffn.norm.weight, ffn.norm.bias)
+            # ---- iterative box refinement (:735-759)
+            dc = _mlp(queries, self.bbox_embed[i])
+            ds = _mlp(queries, self.bbox_size_embed[i]) if self.add_box_size_pred else None
+            center, size, size_metric = ops.box_refine(ref_points, dc, size_q, ds, rng, self.normalize_box_prediction)
+            ref_points = center
+            if self.add_box_size_pred:
+                ref_sizes = size_q = size
+            last = i == L - 1
+            cls, sem, logits, bits = self._head(queries, mask_feats, last)
+            aux.append(dict(cls_preds=cls, sem_preds=sem, masks=logits, centers=center, sizes=size_metric))
+        final = aux.pop()
+        final["hidden_states"] = queries
+        final["attn_mask_bits"] = bits
+        return final, aux
+
+    # ---- reference-shaped entry point (:417-435) --------------------------------------------------
+    def forward(self, x, sp_pos=None, sp_pos_wo_elastic=None, queries=None, queries_pos=None, dinox_queries=None,
+                dinox_query_pos=None, scene_range=None):
+        assert (sp_pos is not None) and (queries_pos is not None) and (scene_range is not None)
+        finals, auxes = [], []
+        for j in range(len(x)):
+            f, a = self._forward_scene(
+                x[j], sp_pos[j], sp_pos_wo_elastic[j] if sp_pos_wo_elastic is not None else sp_pos[j], queries[j],
+                queries_pos[j], dinox_queries[j] if dinox_queries is not None else None,
+                dinox_query_pos[j] if dinox_query_pos is not None else None, scene_range[j][0], scene_range[j][1])
+            finals.append(f)
+            auxes.append(a)
+        B = len(finals)
+        result = dict(cls_preds=[f["cls_preds"] for f in finals], sem_preds=[f["sem_preds"] for f in finals],
+                      masks=[f["masks"] for f in finals], scores=[None] * B, centers=[f["centers"] for f in finals],
+                      sizes=[f["sizes"] for f in finals])
+        if getattr(self, "return_hidden_states", True):
+            result["hidden_states"] = [f["hidden_states"] for f in finals]
+        if getattr(self, "return_aux_outputs", True):
+            result["aux_outputs"] = [
+                dict(cls_preds=[a[li]["cls_preds"] for a in auxes],
+                     sem_preds=None if auxes[0][li]["sem_preds"] is None else [a[li]["sem_preds"] for a in auxes],
+                     masks=[a[li]["masks"] for a in auxes], scores=[None] * B,
+                     centers=[a[li]["centers"] for a in auxes], sizes=[a[li]["sizes"] for a in auxes])
+                for li in range(len(auxes[0]))]
+        return result

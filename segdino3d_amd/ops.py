@@ -251,3 +251,218 @@ def gather_gemm(x, wt, nbr=None, x2=None, scale=None, shift=None, res=None, act=
 def linear(x, weight, bias=None, act=None, res=None, out=None):
     """y = act(x @ weight.T + bias (+ res)); weight [Cout, Cin] as stored by nn.Linear."""
     return gather_gemm(x, weight, shift=bias, act=act, res=res, out=out)
+
+
+# --------------------------------------------------------------------------------------------
+# decoder ops
+# --------------------------------------------------------------------------------------------
+def layernorm(x, weight, bias, res=None, act=None, eps=1e-5, out=None):
+    lib = _lib.load()
+    px, ldx = _rows(x, "x")
+    pr, ldr = (None, 0) if res is None else _rows(res, "res")
+    if out is None:
+        out = torch.empty(x.shape[0], x.shape[1], dtype=torch.float32, device=x.device)
+    po, ldo = _rows(out, "out")
+    _lib.check(lib.sd3d_layernorm(px, ldx, pr, ldr, _ptr(weight, torch.float32, "weight"), _ptr(bias, torch.float32, "bias"),
+                                  float(eps), x.shape[0], x.shape[1], po, ldo, ACT[act], _stream()), "layernorm")
+    return out
+
+
+def sine_pe(xyz, rng, dim_t, axis, mod_num=None, mod_den=None):
+    """xyz [n,3]; rng [6] = (lo, hi); dim_t [d] fp32, axis [d] int8 -> [n, d]."""
+    lib = _lib.load()
+    px, ldx = _rows(xyz, "xyz")
+    n, d = xyz.shape[0], dim_t.numel()
+    out = torch.empty(n, d, dtype=torch.float32, device=xyz.device)
+    pn, ldn, pd, ldd = None, 0, None, 0
+    if mod_num is not None:
+        pn, ldn = _rows(mod_num, "mod_num")
+        if mod_den.dim() == 1:
+            pd, ldd = _ptr(mod_den, torch.float32, "mod_den"), 0
+        else:
+            pd, ldd = _rows(mod_den, "mod_den")
+    _lib.check(lib.sd3d_sine_pe(px, ldx, n, _ptr(rng, torch.float32, "rng"), _ptr(dim_t, torch.float32, "dim_t"),
+                                _ptr(axis, torch.int8, "axis"), d, pn, ldn, pd, ldd, _ptr(out), d, _stream()), "sine_pe")
+    return out
+
+
+def attention(q, k, v, num_heads, scale, mask_bits=None, q2=None, k2=None):
+    """q/k [L, H*32] (+ optional second source concatenated per head), v [Lk, H*32] -> [Lq, H*32]."""
+    lib = _lib.load()
+    pq, ldq = _rows(q, "q")
+    pk, ldk = _rows(k, "k")
+    pv, ldv = _rows(v, "v")
+    pq2, ldq2, pk2, ldk2 = None, 0, None, 0
+    if q2 is not None:
+        pq2, ldq2 = _rows(q2, "q2")
+        pk2, ldk2 = _rows(k2, "k2")
+    Lq, Lk = q.shape[0], k.shape[0]
+    if q.shape[1] != num_heads * 32 or v.shape[1] != num_heads * 32:
+        raise ValueError("attention: head slices must be 32 channels wide")
+    if mask_bits is not None and tuple(mask_bits.shape) != (Lq, (Lk + 31) // 32):
+        raise ValueError(f"attention: mask bits shape {tuple(mask_bits.shape)} != ({Lq}, {(Lk + 31) // 32})")
+    out = torch.empty(Lq, num_heads * 32, dtype=torch.float32, device=q.device)
+    _lib.check(lib.sd3d_attention(pq, ldq, pq2, ldq2, pk, ldk, pk2, ldk2, pv, ldv, _ptr(mask_bits, torch.int32, "mask_bits"),
+                                  Lq, Lk, num_heads, float(scale), _ptr(out), out.shape[1], _stream()), "attention")
+    return out
+
+
+def mask_bits(logits, S, thr):
+    lib = _lib.load()
+    pl, ld = _rows(logits, "logits")
+    Q = logits.shape[0]
+    nw = (S + 31) // 32
+    bits = torch.empty(Q, nw, dtype=torch.int32, device=logits.device)
+    _lib.check(lib.sd3d_mask_bits(pl, ld, Q, S, float(thr), _ptr(bits), nw, _stream()), "mask_bits")
+    return bits
+
+
+def near_bits(sp_pos, centers, thr):
+    lib = _lib.load()
+    S, M = sp_pos.shape[0], centers.shape[0]
+    nw = (S + 31) // 32
+    near = torch.empty(M, nw, dtype=torch.int32, device=sp_pos.device)
+    _lib.check(lib.sd3d_near_bits(_ptr(sp_pos, torch.float32, "sp_pos"), S, _ptr(centers, torch.float32, "centers"), M,
+                                  float(thr), _ptr(near), nw, _stream()), "near_bits")
+    return near
+
+
+def dinox_mask_bits(blocked, near):
+    lib = _lib.load()
+    Q, nw = blocked.shape
+    M = near.shape[0]
+    nwo = (M + 1 + 31) // 32
+    out = torch.empty(Q, nwo, dtype=torch.int32, device=blocked.device)
+    _lib.check(lib.sd3d_dinox_mask_bits(_ptr(blocked, torch.int32, "blocked"), _ptr(near, torch.int32, "near"), nw, Q, M,
+                                        _ptr(out), nwo, _stream()), "dinox_mask_bits")
+    return out
+
+
+def box_refine(ref_points, d_center, size_prev, d_size, rng, normalize):
+    lib = _lib.load()
+    Q = ref_points.shape[0]
+    dev = ref_points.device
+    center = torch.empty(Q, 3, dtype=torch.float32, device=dev)
+    size = size_metric = None
+    ps, lds = None, 0
+    if d_size is not None:
+        size = torch.empty(Q, 3, dtype=torch.float32, device=dev)
+        size_metric = torch.empty(Q, 3, dtype=torch.float32, device=dev)
+        ps = _ptr(size_prev, torch.float32, "size_prev")
+        lds = 0 if size_prev.dim() == 1 else 3
+    _lib.check(lib.sd3d_box_refine(_ptr(ref_points, torch.float32, "ref_points"), _ptr(d_center, torch.float32, "d_center"),
+                                   ps, lds, _ptr(d_size, torch.float32, "d_size"), _ptr(rng, torch.float32, "rng"),
+                                   int(normalize), Q, _ptr(center), _ptr(size), _ptr(size_metric), _stream()), "box_refine")
+    return center, size, size_metric
+
+
+# --------------------------------------------------------------------------------------------
+# post-processing ops
+# --------------------------------------------------------------------------------------------
+def class_scores(cls, C, want_scores=True, want_rowmax=False):
+    lib = _lib.load()
+    pc, ld = _rows(cls, "cls")
+    Q = cls.shape[0]
+    scores = torch.empty(Q * C, dtype=torch.float32, device=cls.device) if want_scores else None
+    rowmax = torch.empty(Q, dtype=torch.float32, device=cls.device) if want_rowmax else None
+    _lib.check(lib.sd3d_class_scores(pc, ld, Q, C, _ptr(scores), _ptr(rowmax), _stream()), "class_scores")
+    return scores, rowmax
+
+
+def mask_scores(masks, S, flat_idx, score_in, C, normalize):
+    lib = _lib.load()
+    pm, ld = _rows(masks, "masks")
+    n = flat_idx.numel()
+    dev = masks.device
+    labels = torch.empty(n, dtype=torch.int32, device=dev)
+    qidx = torch.empty(n, dtype=torch.int32, device=dev)
+    out = torch.empty(n, dtype=torch.float32, device=dev)
+    _lib.check(lib.sd3d_mask_scores(pm, ld, S, _ptr(flat_idx, torch.int32, "flat_idx"), _ptr(score_in, torch.float32, "score_in"),
+                                    n, C, int(bool(normalize)), _ptr(labels), _ptr(qidx), _ptr(out), _stream()), "mask_scores")
+    return labels, qidx, out
+
+
+def gather_sigmoid(masks, S, qidx, order, ld_out):
+    lib = _lib.load()
+    pm, ld = _rows(masks, "masks")
+    n = order.numel()
+    sig = torch.empty(n, ld_out, dtype=torch.float32, device=masks.device)
+    area = torch.empty(n, dtype=torch.float32, device=masks.device)
+    _lib.check(lib.sd3d_gather_sigmoid(pm, ld, S, _ptr(qidx, torch.int32, "qidx"), _ptr(order, torch.int32, "order"), n,
+                                       _ptr(sig), ld_out, _ptr(area), _stream()), "gather_sigmoid")
+    return sig, area
+
+
+def nms_decay(inter, area, labels, score_in, kernel="linear", sigma=2.0):
+    lib = _lib.load()
+    pi, ld = _rows(inter, "inter")
+    n = area.numel()
+    comp = torch.empty(n, dtype=torch.float32, device=inter.device)
+    out = torch.empty(n, dtype=torch.float32, device=inter.device)
+    if kernel not in ("linear", "gaussian"):
+        raise NotImplementedError(f"{kernel} kernel is not supported in matrix nms!")
+    _lib.check(lib.sd3d_nms_decay(pi, ld, _ptr(area, torch.float32, "area"), _ptr(labels, torch.int32, "labels"), n,
+                                  int(kernel == "gaussian"), float(sigma), _ptr(score_in, torch.float32, "score_in"),
+                                  _ptr(comp), _ptr(out), _stream()), "nms_decay")
+    return out
+
+
+def expand_masks(sig, src_row, superpoints, points, sp_thr, boxes=None, loose_ratio=1.5):
+    lib = _lib.load()
+    ps, lds = _rows(sig, "sig")
+    pp, ldp = _rows(points, "points")
+    n, N = src_row.numel(), superpoints.numel()
+    out = torch.empty(n, N, dtype=torch.uint8, device=sig.device)
+    count = torch.empty(n, dtype=torch.int32, device=sig.device)
+    _lib.check(lib.sd3d_expand_masks(ps, lds, _ptr(src_row, torch.int32, "src_row"), n, _ptr(superpoints, torch.int64, "superpoints"),
+                                     pp, ldp, N, float(sp_thr), _ptr(boxes, torch.float32, "boxes"), float(loose_ratio),
+                                     _ptr(out), _ptr(count), _stream()), "expand_masks")
+    return out, count
+
+
+def row_argmax(x, ncols=None, cols=None):
+    lib = _lib.load()
+    px, ld = _rows(x, "x")
+    Q = x.shape[0]
+    out = torch.empty(Q, dtype=torch.int64, device=x.device)
+    nc = cols.numel() if cols is not None else (ncols if ncols is not None else x.shape[1])
+    _lib.check(lib.sd3d_row_argmax(px, ld, Q, _ptr(cols, torch.int32, "cols"), nc, _ptr(out), _stream()), "row_argmax")
+    return out
+
+
+def gather_i64(table, idx, use_index=True):
+    lib = _lib.load()
+    N = idx.numel()
+    out = torch.empty(N, dtype=torch.int64, device=idx.device)
+    _lib.check(lib.sd3d_gather_i64(_ptr(table, torch.int64, "table"), _ptr(idx, torch.int64, "idx"), N, int(use_index),
+                                   _ptr(out), _stream()), "gather_i64")
+    return out
+
+
+def panoptic(masks_u8, rows_desc, labels_desc, n_stuff, npoint_thr, sem_stuff):
+    lib = _lib.load()
+    N = masks_u8.shape[1]
+    n = rows_desc.numel()
+    dev = masks_u8.device
+    inst_ws = torch.empty(N, dtype=torch.int32, device=dev)
+    hist = torch.empty(n + n_stuff + 1, dtype=torch.int32, device=dev)
+    sem_map = torch.empty(N, dtype=torch.int64, device=dev)
+    inst_map = torch.empty(N, dtype=torch.int64, device=dev)
+    _lib.check(lib.sd3d_panoptic(_ptr(masks_u8, torch.uint8, "masks"), N, _ptr(rows_desc, torch.int32, "rows"),
+                                 _ptr(labels_desc, torch.int32, "labels"), n, n_stuff, int(npoint_thr),
+                                 _ptr(sem_stuff, torch.int64, "sem_stuff"), _ptr(inst_ws), _ptr(hist), _ptr(sem_map),
+                                 _ptr(inst_map), _stream()), "panoptic")
+    return sem_map, inst_map
+
+
+def instance_boxes(points, masks_bool, mode):
+    """masks_bool [n_inst, N] torch.bool -> (centers [n,3], sizes [n,3])."""
+    lib = _lib.load()
+    pp, ld = _rows(points, "points")
+    n, N = masks_bool.shape
+    m = masks_bool.contiguous().view(torch.uint8)
+    centers = torch.zeros(n, 3, dtype=torch.float32, device=points.device)
+    sizes = torch.zeros(n, 3, dtype=torch.float32, device=points.device)
+    _lib.check(lib.sd3d_instance_boxes(pp, ld, N, _ptr(m, torch.uint8, "masks"), N, n, 0 if mode == "mean" else 1,
+                                       _ptr(centers), _ptr(sizes), _stream()), "instance_boxes")
+    return centers, sizes
