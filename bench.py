@@ -1,0 +1,232 @@
+#!/usr/bin/env python3
+"""Headline benchmark: scenes/sec of the eval-mode SegDINO3D forward on MI355X (BASELINE.json metric).
+
+    python bench.py --gpus N --steps K --warmup W
+
+One process per GPU (N > 1: launched by torch.distributed.run, backend "nccl" = RCCL).  A *step* is one
+eval-mode `Baseline3D.forward` (backbone + superpoint pooling + 6-layer decoder + post-processing) over
+one synthetic ScanNet200-like scene (150 k points, 3000 superpoints, 300 2D queries, `query_num=200`,
+fp32) whose inputs are already resident in HBM; outputs stay on the device.  Scenes are independent
+units, so ranks shard them with no data-path collective (weak scaling); one all-gather of per-scene
+records (scene id, points, voxels, ms) closes the run, as in the north-star's metric exchange.
+
+Prints ONE JSON line (rank 0) with the contract fields plus
+  roofline     : the dominant kernel (gather_gemm = every sparse convolution + every Linear), its
+                 algorithmic bytes (4*P*Cin + 4*V_out*Cout + 8*P + 4*K*Cin*Cout per launch,
+                 P = measured rulebook size) divided by its HIP-event-measured time, against 8 TB/s HBM
+  cpu_baseline : the oracle's whole forward timed on the host cores (rank 0, N = 1 only)
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+
+
+class GemmTimer:
+    """HIP-event pair around every gather_gemm launch on the current stream."""
+
+    def __init__(self):
+        self.records = []
+        self._cur = None
+        self.enabled = False
+
+    def before(self, meta):
+        if not self.enabled:
+            return
+        e0 = torch.cuda.Event(enable_timing=True)
+        e0.record()
+        self._cur = (e0, meta)
+
+    def after(self):
+        if not self.enabled or self._cur is None:
+            return
+        e1 = torch.cuda.Event(enable_timing=True)
+        e1.record()
+        self.records.append((self._cur[0], e1, self._cur[1]))
+        self._cur = None
+
+
+def algorithmic_bytes(meta, pair_count):
+    K, Cin, Cout, M = meta["K"], meta["Cin"], meta["Cout"], meta["M"]
+    P = pair_count
+    return 4 * P * Cin + 4 * M * Cout + 8 * P + 4 * K * Cin * Cout, 2 * P * Cin * Cout
+
+
+def build_model(query_num, device):
+    import segdino3d_amd as seg
+    from segdino3d_amd.configs import scannet200_model_cfg
+    torch.manual_seed(0)
+    model = seg.build_architecture(scannet200_model_cfg(query_num=query_num)).eval()
+    # random-init weights of the architecture; give BN non-trivial running stats so nothing degenerates
+    g = torch.Generator().manual_seed(1)
+    with torch.no_grad():
+        for m in model.modules():
+            if isinstance(m, torch.nn.BatchNorm1d):
+                m.running_mean.copy_(0.1 * torch.randn(m.num_features, generator=g))
+                m.running_var.copy_(0.5 + torch.rand(m.num_features, generator=g))
+    model.to(device)
+    model.to_host = False
+    return model
+
+
+def cpu_baseline(model, scene_args, n_timed=2):
+    """Oracle (CPU restatement) timed on the host cores with the SAME weights and scene shape."""
+    from oracle import model_ref
+    sd = {k: v.detach().cpu() for k, v in model.state_dict().items()}
+    threads = torch.get_num_threads()
+    times = []
+    from segdino3d_amd.synth import make_scene
+    for i in range(n_timed + 1):
+        pts, tgt = make_scene(1000 + i, *scene_args)
+        ef = tgt.extra_features
+        t0 = time.perf_counter()
+        model_ref.forward_eval(sd, pts, ef["points_2dfeats"], ef["super_point_masks"], ef["query2d_feats"],
+                               ef["query2d_pos"], tgt.masks, query_num=model.query_num)
+        dt = time.perf_counter() - t0
+        if i > 0:
+            times.append(dt)
+    times.sort()
+    med = times[len(times) // 2]
+    return {"value": 1.0 / med, "unit": "scenes/s", "cores": threads, "kind": "port",
+            "sample": f"{n_timed} synthetic scenes of the benchmark shape after 1 warm-up, median {med:.2f} s/scene, "
+                      f"torch CPU fp32 with {threads} threads (oracle/model_ref.forward_eval)"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--points", type=int, default=150_000)
+    ap.add_argument("--superpoints", type=int, default=3000)
+    ap.add_argument("--query2d", type=int, default=300)
+    ap.add_argument("--query-num", type=int, default=200)
+    ap.add_argument("--scene-pool", type=int, default=2, help="distinct synthetic scenes per rank (cycled)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", 0))
+    local_rank = int(os.environ.get("LOCAL_RANK", 0))
+    world = int(os.environ.get("WORLD_SIZE", 1))
+    if world != args.gpus and world > 1:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group(backend="nccl", rank=rank, world_size=world, device_id=device)
+
+    from segdino3d_amd import ops
+    from segdino3d_amd.synth import make_scene
+
+    model = build_model(args.query_num, device)
+    scene_args = (args.points, args.superpoints, args.query2d)
+    pool = []
+    for j in range(max(1, args.scene_pool)):
+        pts, tgt = make_scene(rank * 100 + j, *scene_args)
+        pool.append((pts.to(device), tgt.to(device)))
+
+    def step(i):
+        pts, tgt = pool[i % len(pool)]
+        return model([pts], [tgt])
+
+    timer = GemmTimer()
+    ops.GG_HOOK = timer
+    with torch.no_grad():
+        for i in range(args.warmup):
+            step(i)
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        timer.enabled = True
+        t0 = time.perf_counter()
+        for i in range(args.steps):
+            step(i)
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        dt = time.perf_counter() - t0
+    timer.enabled = False
+    ops.GG_HOOK = None
+
+    # max over ranks
+    if dist is not None:
+        tt = torch.tensor([dt], dtype=torch.float64, device=device)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
+    total_scenes = world * args.steps
+    value = total_scenes / dt
+
+    # ---- roofline of the dominant kernel (rank 0's launches) -------------------------------------------
+    gemm_ms = sum(e0.elapsed_time(e1) for e0, e1, _ in timer.records)
+    n_launch = len(timer.records)
+    pair_cache = {}
+    tot_bytes = tot_flops = 0
+    for _, _, meta in timer.records:
+        nbr = meta["nbr"]
+        if nbr is None:
+            P = meta["M"]
+        else:
+            key = (nbr.data_ptr(), tuple(nbr.shape))
+            if key not in pair_cache:
+                pair_cache[key] = int((nbr >= 0).sum().item())
+            P = pair_cache[key]
+        b, f = algorithmic_bytes(meta, P)
+        tot_bytes += b
+        tot_flops += f
+    achieved = tot_bytes / (gemm_ms * 1e-3) / 1e9 if gemm_ms > 0 else 0.0
+    roofline = {"bound": "hbm", "kernel": "gather_gemm_kernel", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
+                "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+                "launches_per_step": n_launch // max(1, args.steps),
+                "avg_launch_us": round(1e3 * gemm_ms / max(1, n_launch), 2),
+                "algorithmic_bytes_per_step": tot_bytes // max(1, args.steps),
+                "algorithmic_flops_per_step": tot_flops // max(1, args.steps),
+                "fp32_tflops": round(tot_flops / (gemm_ms * 1e-3) / 1e12, 2) if gemm_ms > 0 else 0.0,
+                "share_of_step_time": round(gemm_ms * 1e-3 / dt, 3)}
+
+    # ---- closing all-gather of per-scene records over RCCL/xGMI -----------------------
+    maps = model.backbone.last_maps
+    rec = torch.tensor([float(rank), float(args.points), float(maps.n_vox[0]), 1e3 * dt / args.steps],
+                       dtype=torch.float64, device=device)
+    if dist is not None:
+        gathered = [torch.empty_like(rec) for _ in range(world)]
+        dist.all_gather(gathered, rec)
+        records = torch.stack(gathered).cpu().tolist()
+    else:
+        records = [rec.cpu().tolist()]
+
+    cpu = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        cpu = cpu_baseline(model, scene_args)
+
+    if rank == 0:
+        out = {
+            "metric": "scenes/sec forward (ScanNet200 ~150k pts, 200 queries)", "value": round(value, 3), "unit": "scenes/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * dt / args.steps, 3),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "configs[1]: ScanNet-val-like scene, 1 scene per GPU per step, fp32 sparse backbone "
+                                   "(Res16UNet34C) + fp32 decoder + post-processing, device-resident in/out",
+                       "points": args.points, "superpoints": args.superpoints, "queries_2d": args.query2d,
+                       "query_num": args.query_num, "voxels_per_level": maps.n_vox, "parallelism": f"scene-sharded x{world}"},
+            "roofline": roofline, "cpu_baseline": cpu,
+            "per_rank_records": records,
+        }
+        print(json.dumps(out))
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

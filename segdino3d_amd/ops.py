@@ -14,6 +14,10 @@ from . import _lib
 
 ACT = {None: 0, "none": 0, "relu": 1, "gelu": 2, "sigmoid": 3}
 
+# Optional instrumentation for bench.py: an object with before(meta: dict) / after() called around
+# every gather_gemm launch on the current stream (meta: K, Cin, Cout, M, nbr tensor or None).
+GG_HOOK = None
+
 
 def _stream():
     return torch.cuda.current_stream().cuda_stream
@@ -241,10 +245,15 @@ def gather_gemm(x, wt, nbr=None, x2=None, scale=None, shift=None, res=None, act=
     pr, ldr = (None, 0)
     if res is not None:
         pr, ldr = _rows(res, "res")
+    hook = GG_HOOK
+    if hook is not None:
+        hook.before(dict(K=K, Cin=Cin, Cout=Cout, M=M, nbr=nbr))
     _lib.check(lib.sd3d_gather_gemm(p0, ld0, C0, p1, ld1, _ptr(nbr, torch.int32, "nbr"), _ptr(wt, torch.float32, "wt"),
                                     K, Cin, Cout, M, _ptr(scale, torch.float32, "scale"),
                                     _ptr(shift, torch.float32, "shift"), pr, ldr, po, ldo, ACT[act], nt, _stream()),
                "gather_gemm")
+    if hook is not None:
+        hook.after()
     return out
 
 
