@@ -171,8 +171,9 @@ int sd3d_panoptic(const uint8_t* masks, int64_t N, const int32_t* rows_desc, con
                   int64_t* inst_map, void* stream);
 /* GT instance centres / sizes attached to the targets before inference (:289-305).  masks: bool bytes,
  * row stride mask_stride; mode 0 = "mean" centre, 1 = "median" (= bbox centre, :299-300). */
+size_t sd3d_instance_boxes_ws_bytes(int n_inst);
 int sd3d_instance_boxes(const float* points, int ld, int64_t N, const uint8_t* masks, int64_t mask_stride, int n_inst,
-                        int mode, float* centers, float* sizes, void* stream);
+                        int mode, float* centers, float* sizes, void* ws, size_t ws_bytes, void* stream);
 
 #ifdef __cplusplus
 }

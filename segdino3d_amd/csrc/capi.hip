@@ -71,7 +71,7 @@ int launch_expand_masks(const float*, int, const uint32_t*, int, const int64_t*,
 int launch_row_argmax(const float*, int, int64_t, const int32_t*, int, int64_t*, hipStream_t);
 int launch_gather_i64(const int64_t*, const int64_t*, int64_t, int, int64_t*, hipStream_t);
 int launch_panoptic(const uint8_t*, int64_t, const int32_t*, const int32_t*, int, int, int, const int64_t*, int32_t*, int32_t*, int64_t*, int64_t*, hipStream_t);
-int launch_instance_boxes(const float*, int, int64_t, const uint8_t*, int64_t, int, int, float*, float*, hipStream_t);
+int launch_instance_boxes(const float*, int, int64_t, const uint8_t*, int64_t, int, int, float*, float*, void*, size_t, hipStream_t);
 
 #define ST ((hipStream_t)stream)
 
@@ -228,9 +228,10 @@ int sd3d_panoptic(const uint8_t* masks, int64_t N, const int32_t* rows_desc, con
                   void* stream) {
     return launch_panoptic(masks, N, rows_desc, labels_desc, n, n_stuff, npoint_thr, sem_stuff, inst_ws, hist_ws, sem_map, inst_map, ST);
 }
+size_t sd3d_instance_boxes_ws_bytes(int n_inst) { return (size_t)(n_inst > 0 ? n_inst : 1) * 64 * 10 * sizeof(float); }
 int sd3d_instance_boxes(const float* points, int ld, int64_t N, const uint8_t* masks, int64_t mask_stride, int n_inst, int mode,
-                        float* centers, float* sizes, void* stream) {
-    return launch_instance_boxes(points, ld, N, masks, mask_stride, n_inst, mode, centers, sizes, ST);
+                        float* centers, float* sizes, void* ws, size_t ws_bytes, void* stream) {
+    return launch_instance_boxes(points, ld, N, masks, mask_stride, n_inst, mode, centers, sizes, ws, ws_bytes, ST);
 }
 
 }  // extern "C"

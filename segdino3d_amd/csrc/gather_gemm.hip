@@ -88,21 +88,29 @@ __device__ __forceinline__ int next_active(uint64_t m0, uint64_t m1, int after) 
     return -1;
 }
 
-template <int NT>
+// KS = 1: every wave owns a (row tile, column group) and walks all (offset, chunk) steps.
+// KS = 4: the four waves of a workgroup share one (row tile, column group) and take the steps
+//         round-robin (split-K); partial accumulators are reduced through LDS in a fixed order by
+//         wave 0.  Used when the launch would otherwise leave most of the 1024 SIMDs idle (coarse
+//         levels of the U-Net, decoder Linears with a few hundred rows).
+template <int NT, int KS>
 __global__ __launch_bounds__(256) void gather_gemm_kernel(const GGParams p) {
+    __shared__ float red[(KS > 1) ? (KS - 1) * NT * 16 * 64 : 1];
     const int lane = threadIdx.x & 63;
     const int j = lane & 31, h = lane >> 5;
-    const int64_t wave = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
-    const int64_t row_tile = wave / p.col_groups;
-    const int cg = (int)(wave - row_tile * p.col_groups);
+    const int wv = threadIdx.x >> 6;
+    const int ks = (KS > 1) ? wv : 0;
+    const int64_t unit = (KS > 1) ? (int64_t)blockIdx.x : (int64_t)blockIdx.x * 4 + wv;
+    const int64_t row_tile = unit / p.col_groups;
+    const int cg = (int)(unit - row_tile * p.col_groups);
     const int64_t row0 = row_tile * 32;
-    if (row0 >= p.M) return;
+    if (row0 >= p.M) return;                 // uniform per workgroup when KS > 1
     const int64_t row = row0 + j;
     const bool row_ok = row < p.M;
     const int ncol0 = cg * 32 * NT;
     const int nchunks = p.Cin >> 5;
 
-    // which kernel offsets have at least one neighbour among this wave's rows?
+    // which kernel offsets have at least one neighbour among this tile's rows?
     uint64_t m0 = 0, m1 = 0;
     if (p.nbr) {
         for (int k = 0; k < p.K; ++k) {
@@ -120,27 +128,50 @@ __global__ __launch_bounds__(256) void gather_gemm_kernel(const GGParams p) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
 
+    // step cursor: (k, chunk) in lexicographic order over the active offsets; this wave owns the
+    // steps whose running number is congruent to ks modulo KS.
     int k = next_active(m0, m1, -1);
+    int chunk = 0, t_run = 0;
+    while (k >= 0 && (t_run % KS) != ks) {
+        ++t_run;
+        if (++chunk == nchunks) { chunk = 0; k = next_active(m0, m1, k); }
+    }
     if (k >= 0) {
-        int chunk = 0;
         int idx = p.nbr ? (row_ok ? p.nbr[(int64_t)k * p.M + row] : -1) : (row_ok ? (int)row : -1);
         Frag<NT> cur;
         load_frag<NT>(cur, p, k, chunk, idx, ncol0, j, h);
         while (true) {
-            int nk = k, nchunk = chunk + 1, nidx = idx;
-            if (nchunk == nchunks) {
-                nchunk = 0;
-                nk = next_active(m0, m1, k);
-                if (nk >= 0) nidx = row_ok ? p.nbr[(int64_t)nk * p.M + row] : -1;
-            }
-            Frag<NT> nxt;
+            int nk = k, nchunk = chunk, nidx = idx;
+            do {
+                ++t_run;
+                if (++nchunk == nchunks) { nchunk = 0; nk = next_active(m0, m1, nk); }
+            } while (nk >= 0 && (t_run % KS) != ks);
             const bool has_next = nk >= 0;
+            if (has_next && nk != k) nidx = row_ok ? p.nbr[(int64_t)nk * p.M + row] : -1;
+            Frag<NT> nxt;
             if (has_next) load_frag<NT>(nxt, p, nk, nchunk, nidx, ncol0, j, h);
             mma_frag<NT>(acc, cur);
             if (!has_next) break;
             cur = nxt;
             k = nk; chunk = nchunk; idx = nidx;
         }
+    }
+
+    if (KS > 1) {
+        if (ks > 0) {
+#pragma unroll
+            for (int t = 0; t < NT; ++t)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) red[(((ks - 1) * NT + t) * 16 + r) * 64 + lane] = acc[t][r];
+        }
+        __syncthreads();
+        if (ks > 0) return;
+#pragma unroll
+        for (int s = 0; s < KS - 1; ++s)
+#pragma unroll
+            for (int t = 0; t < NT; ++t)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[t][r] += red[((s * NT + t) * 16 + r) * 64 + lane];
     }
 
     // epilogue: acc[t][r] is (row = (r&3) + 8*(r>>2) + 4*h, col = j) of subtile t
@@ -173,22 +204,43 @@ int launch_gather_gemm(const GGParams& p_in, int nt, hipStream_t st) {
     if ((p.ld0 & 3) || (p.in1 && (p.ld1 & 3))) return sd3d_set_error(SD3D_ERR_ARG, "gather_gemm: input row stride must be a multiple of 4 floats");
     if (p.K > 128) return sd3d_set_error(SD3D_ERR_ARG, "gather_gemm: at most 128 kernel offsets");
     if (!p.nbr && p.K != 1) return sd3d_set_error(SD3D_ERR_ARG, "gather_gemm: identity gather needs K == 1");
-    if (nt <= 0) {   // heuristic: wide tiles when there are plenty of rows, narrow ones to fill the chip otherwise
-        const int sub = (p.Cout + 31) / 32;
+    // nt > 0: caller-chosen subtiles per wave, no split-K.  nt <= 0: heuristic - wide tiles when there
+    // are plenty of rows; narrow tiles and split-K (4 waves share a tile) when the launch would leave
+    // most SIMDs idle.  nt == -1 forces split-K with one subtile (tests).
+    const int sub = (p.Cout + 31) / 32;
+    const int64_t tiles = cdiv(p.M, 32);
+    int ks = 1;
+    if (nt <= 0) {
+        const bool force_split = nt < 0;
         nt = sub >= 4 ? 4 : sub;
-        while (nt > 1 && cdiv(p.M, 32) * cdiv(sub, nt) < 2048) --nt;
+        while (nt > 1 && tiles * cdiv(sub, nt) < 2048) --nt;
         if (sub % nt) { for (int c = nt; c >= 1; --c) if (sub % c == 0) { nt = c; break; } }
+        const int64_t steps = (int64_t)p.K * (p.Cin / 32);
+        if (force_split || (tiles * cdiv(sub, nt) < 1024 && steps >= 8)) ks = 4;
+        if (force_split) nt = 1;
+        if (ks == 4 && nt > 2) nt = (sub % 2 == 0) ? 2 : 1;
     }
     p.col_groups = (int)cdiv(p.Cout, 32 * nt);
-    const int64_t waves = cdiv(p.M, 32) * p.col_groups;
-    const dim3 grid((unsigned)cdiv(waves, 4)), block(256);
-    switch (nt) {
-        case 1: hipLaunchKernelGGL(gather_gemm_kernel<1>, grid, block, 0, st, p); break;
-        case 2: hipLaunchKernelGGL(gather_gemm_kernel<2>, grid, block, 0, st, p); break;
-        case 3: hipLaunchKernelGGL(gather_gemm_kernel<3>, grid, block, 0, st, p); break;
-        case 4: hipLaunchKernelGGL(gather_gemm_kernel<4>, grid, block, 0, st, p); break;
-        default: return sd3d_set_error(SD3D_ERR_ARG, "gather_gemm: nt must be 1..4");
+    const int64_t units = tiles * p.col_groups;
+    const dim3 block(256);
+    const dim3 grid((unsigned)(ks == 4 ? units : cdiv(units, 4)));
+#define GG_LAUNCH(NT_, KS_) hipLaunchKernelGGL((gather_gemm_kernel<NT_, KS_>), grid, block, 0, st, p)
+    if (ks == 1) {
+        switch (nt) {
+            case 1: GG_LAUNCH(1, 1); break;
+            case 2: GG_LAUNCH(2, 1); break;
+            case 3: GG_LAUNCH(3, 1); break;
+            case 4: GG_LAUNCH(4, 1); break;
+            default: return sd3d_set_error(SD3D_ERR_ARG, "gather_gemm: nt must be 1..4");
+        }
+    } else {
+        switch (nt) {
+            case 1: GG_LAUNCH(1, 4); break;
+            case 2: GG_LAUNCH(2, 4); break;
+            default: return sd3d_set_error(SD3D_ERR_ARG, "gather_gemm: split-K supports nt 1..2");
+        }
     }
+#undef GG_LAUNCH
     SD3D_CHECK_LAUNCH();
     return SD3D_OK;
 }

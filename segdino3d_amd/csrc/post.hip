@@ -125,50 +125,56 @@ __global__ void nms_coef_kernel(const float* __restrict__ inter, int ld, const f
 // Point masks (:453-454, :464-465, :348-371).  For final row r (src row = src[r] of sig), point p:
 //   bit = sig[src[r]][superpoints[p]] > sp_thr ; count[r] = number of bits BEFORE the box filter;
 //   out[r][p] = bit && inside(points[p], center[r] +- size[r] * (1 + loose) / 2)   (if boxes given)
-// One thread handles 4 consecutive points of one row (uchar4 store); grid.y = row.
+// One thread handles 4 consecutive points for EM_ROWS consecutive rows: the superpoint ids and the
+// coordinates are read once per EM_ROWS rows, each row costs 4 gathered floats (L2-resident sig row)
+// and one uchar4 store.  grid = (point quads / 256, row groups).
+#define EM_ROWS 8
 __global__ __launch_bounds__(256) void expand_masks_kernel(const float* __restrict__ sig, int ld_sig, const uint32_t* __restrict__ src,
-                                                           const int64_t* __restrict__ superpoints, const float* __restrict__ pts,
+                                                           int n, const int64_t* __restrict__ superpoints, const float* __restrict__ pts,
                                                            int ld_pts, int64_t N, float sp_thr, const float* __restrict__ boxes,
                                                            float loose, uint8_t* __restrict__ out, int32_t* __restrict__ count) {
-    const int r = blockIdx.y;
+    const int r0 = blockIdx.y * EM_ROWS;
     const int64_t p0 = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 4;
-    const float* row = sig + (int64_t)src[r] * ld_sig;
-    float lo[3] = {0, 0, 0}, hi[3] = {0, 0, 0};
-    if (boxes) {
+    const bool vec = ((N & 3) == 0);
+    int sp[4] = {0, 0, 0, 0};
+    float xyz[4][3];
+    const int np = p0 < N ? (int)min((int64_t)4, N - p0) : 0;
+    for (int e = 0; e < np; ++e) {
+        sp[e] = (int)superpoints[p0 + e];
+        if (boxes) {
 #pragma unroll
-        for (int a = 0; a < 3; ++a) {
-            const float c = boxes[r * 6 + a], s = boxes[r * 6 + 3 + a] * (1.f + loose);
-            lo[a] = c - s / 2.f;
-            hi[a] = c + s / 2.f;
+            for (int a = 0; a < 3; ++a) xyz[e][a] = pts[(p0 + e) * ld_pts + a];
         }
     }
-    int cnt = 0;
-    uint8_t res[4] = {0, 0, 0, 0};
-    if (p0 < N) {
+    for (int rr = 0; rr < EM_ROWS; ++rr) {
+        const int r = r0 + rr;
+        if (r >= n) break;                                  // uniform per block
+        const float* row = sig + (int64_t)src[r] * ld_sig;
+        float lo[3] = {0, 0, 0}, hi[3] = {0, 0, 0};
+        if (boxes) {
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            const int64_t p = p0 + e;
-            if (p >= N) break;
-            bool b = row[superpoints[p]] > sp_thr;
+            for (int a = 0; a < 3; ++a) {
+                const float c = boxes[r * 6 + a], s = boxes[r * 6 + 3 + a] * (1.f + loose);
+                lo[a] = c - s / 2.f;
+                hi[a] = c + s / 2.f;
+            }
+        }
+        int cnt = 0;
+        uint8_t res[4] = {0, 0, 0, 0};
+        for (int e = 0; e < np; ++e) {
+            bool b = row[sp[e]] > sp_thr;
             cnt += b;
             if (b && boxes) {
 #pragma unroll
-                for (int a = 0; a < 3; ++a) {
-                    const float x = pts[p * ld_pts + a];
-                    b &= (x >= lo[a]) & (x <= hi[a]);
-                }
+                for (int a = 0; a < 3; ++a) b &= (xyz[e][a] >= lo[a]) & (xyz[e][a] <= hi[a]);
             }
             res[e] = b;
         }
-        if (p0 + 3 < N && ((N & 3) == 0)) {
-            *(uchar4*)(out + (int64_t)r * N + p0) = make_uchar4(res[0], res[1], res[2], res[3]);
-        } else {
-            for (int e = 0; e < 4 && p0 + e < N; ++e) out[(int64_t)r * N + p0 + e] = res[e];
-        }
+        if (np == 4 && vec) *(uchar4*)(out + (int64_t)r * N + p0) = make_uchar4(res[0], res[1], res[2], res[3]);
+        else for (int e = 0; e < np; ++e) out[(int64_t)r * N + p0 + e] = res[e];
+        const float c = wred_sum((float)cnt);
+        if ((threadIdx.x & 63) == 0 && c > 0.f) atomicAdd(&count[r], (int)c);
     }
-    // block-level count -> one atomic per wave
-    float c = wred_sum((float)cnt);
-    if ((threadIdx.x & 63) == 0 && c > 0.f) atomicAdd(&count[r], (int)c);
 }
 
 // sem_q[q] = argmax_c sem[q, classes...]: classes = first n_cls columns (n_cls = C) or an explicit list.
@@ -269,8 +275,8 @@ int launch_expand_masks(const float* sig, int ld_sig, const uint32_t* src, int n
                         hipStream_t st) {
     if (n <= 0 || N <= 0) return SD3D_OK;
     (void)hipMemsetAsync(count, 0, (size_t)n * sizeof(int32_t), st);
-    hipLaunchKernelGGL(expand_masks_kernel, dim3((unsigned)cdiv(N, 1024), (unsigned)n), dim3(256), 0, st, sig, ld_sig, src,
-                       superpoints, pts, ld_pts, N, sp_thr, boxes, loose, out, count);
+    hipLaunchKernelGGL(expand_masks_kernel, dim3((unsigned)cdiv(N, 1024), (unsigned)cdiv(n, EM_ROWS)), dim3(256), 0, st, sig, ld_sig,
+                       src, n, superpoints, pts, ld_pts, N, sp_thr, boxes, loose, out, count);
     SD3D_CHECK_LAUNCH();
     return SD3D_OK;
 }
@@ -305,14 +311,15 @@ int launch_panoptic(const uint8_t* masks, int64_t N, const int32_t* rows, const 
 //   mode 0 "mean": centre = mean ; mode 1 "median": centre = (max + min) / 2 ; size = max - min
 // Instances without points keep centre = size = 0.
 // ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void instance_boxes_kernel(const float* __restrict__ pts, int ld, int64_t N,
-                                                             const uint8_t* __restrict__ masks, int64_t mask_stride, int mode,
-                                                             float* __restrict__ centers, float* __restrict__ sizes) {
+#define IB_CHUNKS 64
+__global__ __launch_bounds__(256) void instance_boxes_partial(const float* __restrict__ pts, int ld, int64_t N,
+                                                              const uint8_t* __restrict__ masks, int64_t mask_stride,
+                                                              float* __restrict__ part /*[n_inst][IB_CHUNKS][10]*/) {
     __shared__ float sm[4][10];
-    const int inst = blockIdx.x;
+    const int inst = blockIdx.y;
     const uint8_t* m = masks + (int64_t)inst * mask_stride;
     float lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY}, su[3] = {0.f, 0.f, 0.f}, cnt = 0.f;
-    for (int64_t p = threadIdx.x; p < N; p += 256) {
+    for (int64_t p = (int64_t)blockIdx.x * 256 + threadIdx.x; p < N; p += (int64_t)IB_CHUNKS * 256) {
         if (m[p]) {
             cnt += 1.f;
 #pragma unroll
@@ -334,20 +341,35 @@ __global__ __launch_bounds__(256) void instance_boxes_kernel(const float* __rest
     const float c = wred_sum(cnt);
     if (lane == 0) sm[w][9] = c;
     __syncthreads();
-    if (threadIdx.x < 3) {
+    if (threadIdx.x < 10) {
         const int a = threadIdx.x;
-        float l = sm[0][a], h = sm[0][3 + a], s = sm[0][6 + a], n = sm[0][9];
-        for (int ww = 1; ww < 4; ++ww) { l = fminf(l, sm[ww][a]); h = fmaxf(h, sm[ww][3 + a]); s += sm[ww][6 + a]; n += sm[ww][9]; }
-        float ctr = 0.f, sz = 0.f;
-        if (n > 0.f) { ctr = mode == 0 ? s / n : (h + l) / 2.f; sz = h - l; }
-        centers[inst * 3 + a] = ctr;
-        sizes[inst * 3 + a] = sz;
+        float r = sm[0][a];
+        for (int ww = 1; ww < 4; ++ww) r = a < 3 ? fminf(r, sm[ww][a]) : (a < 6 ? fmaxf(r, sm[ww][a]) : r + sm[ww][a]);
+        part[((int64_t)inst * IB_CHUNKS + blockIdx.x) * 10 + a] = r;
     }
 }
+__global__ void instance_boxes_final(const float* __restrict__ part, int n_inst, int mode, float* __restrict__ centers,
+                                     float* __restrict__ sizes) {
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n_inst * 3) return;
+    const int inst = t / 3, a = t - inst * 3;
+    const float* pp = part + (int64_t)inst * IB_CHUNKS * 10;
+    float l = INFINITY, h = -INFINITY, s = 0.f, n = 0.f;
+    for (int c = 0; c < IB_CHUNKS; ++c) {
+        l = fminf(l, pp[c * 10 + a]); h = fmaxf(h, pp[c * 10 + 3 + a]); s += pp[c * 10 + 6 + a]; n += pp[c * 10 + 9];
+    }
+    float ctr = 0.f, sz = 0.f;
+    if (n > 0.f) { ctr = mode == 0 ? s / n : (h + l) / 2.f; sz = h - l; }
+    centers[t] = ctr;
+    sizes[t] = sz;
+}
 int launch_instance_boxes(const float* pts, int ld, int64_t N, const uint8_t* masks, int64_t mask_stride, int n_inst, int mode,
-                          float* centers, float* sizes, hipStream_t st) {
+                          float* centers, float* sizes, void* ws, size_t ws_bytes, hipStream_t st) {
     if (n_inst <= 0) return SD3D_OK;
-    hipLaunchKernelGGL(instance_boxes_kernel, dim3((unsigned)n_inst), dim3(256), 0, st, pts, ld, N, masks, mask_stride, mode,
+    if (ws_bytes < (size_t)n_inst * IB_CHUNKS * 10 * sizeof(float)) return sd3d_set_error(SD3D_ERR_WS, "instance_boxes workspace");
+    hipLaunchKernelGGL(instance_boxes_partial, dim3(IB_CHUNKS, (unsigned)n_inst), dim3(256), 0, st, pts, ld, N, masks, mask_stride,
+                       (float*)ws);
+    hipLaunchKernelGGL(instance_boxes_final, dim3((unsigned)cdiv(n_inst * 3, 64)), dim3(64), 0, st, (const float*)ws, n_inst, mode,
                        centers, sizes);
     SD3D_CHECK_LAUNCH();
     return SD3D_OK;

@@ -472,6 +472,7 @@ def instance_boxes(points, masks_bool, mode):
     m = masks_bool.contiguous().view(torch.uint8)
     centers = torch.zeros(n, 3, dtype=torch.float32, device=points.device)
     sizes = torch.zeros(n, 3, dtype=torch.float32, device=points.device)
+    ws = _WS.get(lib.sd3d_instance_boxes_ws_bytes(n), points.device)
     _lib.check(lib.sd3d_instance_boxes(pp, ld, N, _ptr(m, torch.uint8, "masks"), N, n, 0 if mode == "mean" else 1,
-                                       _ptr(centers), _ptr(sizes), _stream()), "instance_boxes")
+                                       _ptr(centers), _ptr(sizes), ws.data_ptr(), ws.numel(), _stream()), "instance_boxes")
     return centers, sizes

@@ -123,6 +123,10 @@ def test_linear_matches_torch(M, Cin, Cout, act):
     ref = torch.nn.functional.linear(x.double(), w.double(), b.double()) + r.double()
     ref = {"relu": torch.relu, "gelu": torch.nn.functional.gelu, "sigmoid": torch.sigmoid, None: lambda t: t}[act](ref)
     torch.testing.assert_close(y.double(), ref, rtol=1e-4, atol=1e-4)
+    # every tiling of the kernel: 1..4 column subtiles per wave, and the split-K (4 waves per tile) variant
+    for nt in (1, 2, 3, 4, -1):
+        y2 = ops.gather_gemm(x.to(d), w.to(d), shift=b.to(d), act=act, res=r.to(d), nt=nt).cpu()
+        torch.testing.assert_close(y2.double(), ref, rtol=1e-4, atol=1e-4, msg=lambda m: f"nt={nt}: {m}")
 
 
 def test_sparse_conv_matches_oracle():
@@ -143,8 +147,10 @@ def test_sparse_conv_matches_oracle():
         x = det_randn(f"sc.x{l}{k}", (lv.n(1 << l), cin))
         w = det_randn(f"sc.w{l}{k}", (k ** 3, cin, cout), (cin * k ** 3) ** -0.5)
         ref = R.sparse_conv(x, lv.same(1 << l, k), w, lv.n(1 << l))
-        got = ops.gather_gemm(to_dev(x, l), w.permute(0, 2, 1).contiguous().to(d), nbr=maps.same(l, k)).cpu()
-        torch.testing.assert_close(got, ref[perm[l]], rtol=2e-4, atol=2e-4, msg=lambda m: f"same conv l={l} k={k}: {m}")
+        for nt in (0, 1, -1):
+            got = ops.gather_gemm(to_dev(x, l), w.permute(0, 2, 1).contiguous().to(d), nbr=maps.same(l, k), nt=nt).cpu()
+            torch.testing.assert_close(got, ref[perm[l]], rtol=2e-4, atol=2e-4,
+                                       msg=lambda m: f"same conv l={l} k={k} nt={nt}: {m}")
     # stride-2 down + transposed up, with fused scale/shift/residual/relu and a two-source (concat) input
     x = det_randn("sc.xd", (lv.n(1), 64))
     w = det_randn("sc.wd", (8, 64, 32), 512 ** -0.5)
