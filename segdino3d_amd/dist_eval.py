@@ -1,0 +1,68 @@
+"""Scene-sharded multi-GPU evaluation support.
+
+The reference evaluates on a single GPU ("Not support multi-card evaluation.",
+`evaluation/evaluate_3d.py:45`).  Scenes are independent units (batch size 1, BatchNorm running stats),
+so here rank r simply takes scenes r, r + W, r + 2W, ... with NO collective on the data path; the only
+exchange is one all-gather of per-scene records at the end (throughput records, or the compact output
+of the AP matching).  Records have a variable count per rank, so the exchange is length-then-padded
+payload, the same pattern as the reference's unused `all_gather` helper
+(`segdino3d/utils/dist_utils.py:148-194`), but on fixed-width numeric rows instead of pickles.
+Backend "nccl" is RCCL on ROCm (one process per GPU, xGMI); "gloo" is used by the CPU tests.
+"""
+from __future__ import annotations
+
+from typing import Callable, List, Sequence
+
+import torch
+import torch.distributed as dist
+
+
+def shard_scenes(n_scenes: int, rank: int, world: int) -> List[int]:
+    """Round-robin scene -> rank assignment (scene i on rank i mod W)."""
+    return list(range(rank, n_scenes, world))
+
+
+def all_gather_records(records: torch.Tensor, group=None) -> List[torch.Tensor]:
+    """records [n_local, width] (same width and dtype on every rank) -> list of per-rank tensors.
+
+    Two collectives: an all-gather of the row counts, then one all-gather of the payload padded to the
+    largest count.  Works with device tensors on "nccl" and CPU tensors on "gloo"."""
+    if not (dist.is_available() and dist.is_initialized()):
+        return [records]
+    world = dist.get_world_size(group)
+    if records.dim() != 2:
+        raise ValueError("records must be [n, width]")
+    n_local = torch.tensor([records.shape[0]], dtype=torch.int64, device=records.device)
+    counts = [torch.zeros_like(n_local) for _ in range(world)]
+    dist.all_gather(counts, n_local, group=group)
+    counts = [int(c.item()) for c in counts]
+    n_max = max(max(counts), 1)
+    padded = records.new_zeros((n_max, records.shape[1]))
+    padded[: records.shape[0]] = records
+    gathered = [torch.empty_like(padded) for _ in range(world)]
+    dist.all_gather(gathered, padded.contiguous(), group=group)
+    return [g[:c] for g, c in zip(gathered, counts)]
+
+
+def merge_by_scene(per_rank: Sequence[torch.Tensor], key_col: int = 0) -> torch.Tensor:
+    """Concatenate the gathered rows and order them by the scene-id column."""
+    allrows = torch.cat([t for t in per_rank if t.numel() > 0]) if any(t.numel() for t in per_rank) else per_rank[0]
+    if allrows.numel() == 0:
+        return allrows
+    order = torch.argsort(allrows[:, key_col], stable=True)
+    return allrows[order]
+
+
+def run_sharded(n_scenes: int, process_scene: Callable[[int], Sequence[float]], device="cpu") -> torch.Tensor:
+    """Each rank runs `process_scene(i)` for its scenes (returning a fixed-width numeric record whose
+    first entry is the scene id); returns the merged [n_scenes, width] table on every rank."""
+    rank = dist.get_rank() if dist.is_initialized() else 0
+    world = dist.get_world_size() if dist.is_initialized() else 1
+    rows = [list(process_scene(i)) for i in shard_scenes(n_scenes, rank, world)]
+    width = len(rows[0]) if rows else 0
+    if dist.is_initialized():                      # ranks with no scene still need the common width
+        w = torch.tensor([width], dtype=torch.int64, device=device)
+        dist.all_reduce(w, op=dist.ReduceOp.MAX)
+        width = int(w.item())
+    local = torch.tensor(rows, dtype=torch.float64, device=device).reshape(len(rows), width)
+    return merge_by_scene(all_gather_records(local))
