@@ -141,6 +141,10 @@ int sd3d_dinox_mask_bits(const uint32_t* blocked, const uint32_t* near, int nwor
 int sd3d_box_refine(const float* ref_points, const float* d_center, const float* size_prev, int ld_size_prev,
                     const float* d_size, const float* range, int normalize, int64_t Q, float* center, float* size,
                     float* size_metric, void* stream);
+/* out = act(x * scale + shift), x = [x0 (C0 channels) | x1] : pre-activation BatchNorm1d + ReLU of the
+ * spconv residual blocks (spconvunet.py:48-51, 154-156, 184-187, 227-229).  x1 may be NULL. */
+int sd3d_scale_shift_act(const float* x0, int ld0, int C0, const float* x1, int ld1, const float* scale,
+                         const float* shift, int act, int64_t M, int C, float* out, int ld_out, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Post-processing (segdino3d/models/architecture/baseline3d.py)

@@ -10,7 +10,8 @@ from .builder import *  # noqa: F401,F403
 from .builder import __all__ as _builder_all
 from .gtypes import GDType, GD3DTarget  # noqa: F401
 from .backbone_mink import Res16UNet34C  # noqa: F401
+from .backbone_spconv import SpConvUNet  # noqa: F401
 from .decoder import ScanNetQueryDecoder  # noqa: F401
 from .architecture import Baseline3D, PointData  # noqa: F401
 
-__all__ = list(_builder_all) + ["GDType", "GD3DTarget", "Res16UNet34C", "ScanNetQueryDecoder", "Baseline3D", "PointData"]
+__all__ = list(_builder_all) + ["GDType", "GD3DTarget", "Res16UNet34C", "SpConvUNet", "ScanNetQueryDecoder", "Baseline3D", "PointData"]

@@ -1,0 +1,191 @@
+"""SpConvUNet (ScanNetv2 prototype) on the MI355X gather-GEMM (host side).
+
+Mirrors the reference operator interface `segdino3d/models/backbone/spconvunet.py`:
+  - constructor kwargs `num_planes, norm_fn, block_reps, block, indice_key_id, normalize_before,
+    return_blocks, voxel_size, mode_fuse_2d_feat, main_model, min_spatial_shape,
+    add_positional_embedding` (:116-129);
+  - `forward_wrapper(samples, targets, return_sp_mean_pos) -> (sp_feats[], sp_pos[], sp_pos_wo_elastic[])`
+    (:364-399);
+  - the reference `state_dict` keys: `input_conv.0.weight [32,3,3,3,262]`,
+    `blocks.block{r}.conv_branch.{0,3}.*` (BatchNorm1d), `.conv_branch.{2,5}.weight`,
+    `.i_branch.0.weight`, `conv.{0,2}`, `u.<recursive>`, `deconv.{0,2}`, `blocks_tail.block{r}...`,
+    `output_layer.0.*` (spconv 2.x weight layout [C_out, k0, k1, k2, C_in]).
+Sub-manifold / strided / inverse convolutions all run as `gather_gemm` over neighbour tables of the
+Z-order coordinate hierarchy; the pre-activation BatchNorm+ReLU is one elementwise pass, the BN+ReLU
+between the two convolutions of a block is fused into the first convolution's epilogue and the
+residual add into the second's.  Eval mode, `early_fusion`, no elastic coordinates.
+
+Not yet reproduced: spconv's output-extent rule `(D - 2) // 2 + 1` that drops the trailing slice of an
+odd-sized grid wider than `min_spatial_shape`.
+"""
+from __future__ import annotations
+
+from typing import List
+
+import torch
+import torch.nn as nn
+
+from . import ops
+from .builder import BACKBONES
+from .sparse import SceneMaps
+
+BN_EPS = 1e-4       # spconvunet.py:35-36, 228
+
+
+class SpConv(nn.Module):
+    """Parameter holder for spconv SubMConv3d / SparseConv3d / SparseInverseConv3d: `weight` [Cout,k,k,k,Cin]."""
+
+    def __init__(self, cin, cout, ksize):
+        super().__init__()
+        self.weight = nn.Parameter(torch.empty(cout, ksize, ksize, ksize, cin))
+        nn.init.kaiming_uniform_(self.weight.view(cout, -1), a=5 ** 0.5)
+        self.ksize = ksize
+
+
+def _bn(c):
+    return nn.BatchNorm1d(c, eps=BN_EPS, momentum=0.1)
+
+
+class ResidualBlock(nn.Module):
+    def __init__(self, cin, cout):
+        super().__init__()
+        self.i_branch = nn.Sequential(nn.Identity() if cin == cout else SpConv(cin, cout, 1))
+        self.conv_branch = nn.Sequential(_bn(cin), nn.ReLU(), SpConv(cin, cout, 3), _bn(cout), nn.ReLU(), SpConv(cout, cout, 3))
+
+
+def _pack(conv: SpConv) -> torch.Tensor:
+    w = conv.weight.detach()
+    co, ci = w.shape[0], w.shape[-1]
+    w = w.reshape(co, -1, ci).permute(1, 0, 2)                 # [K (z fastest), Cout, Cin]
+    pad = (ci + 31) // 32 * 32 - ci
+    if pad:
+        w = torch.nn.functional.pad(w, (0, pad))
+    return w.contiguous().float()
+
+
+def _fold(bn: nn.BatchNorm1d):
+    scale = (bn.weight.detach() / torch.sqrt(bn.running_var + bn.eps)).float().contiguous()
+    shift = (bn.bias.detach() - bn.running_mean * scale).float().contiguous()
+    return scale, shift
+
+
+@BACKBONES.register_module()
+class SpConvUNet(nn.Module):
+    KERNEL_ORDER = "z_fastest"
+
+    def __init__(self, num_planes, norm_fn=None, block_reps=2, block=None, indice_key_id=1, normalize_before=True,
+                 return_blocks=False, voxel_size=0.02, mode_fuse_2d_feat="early_fusion", main_model=True,
+                 min_spatial_shape=128, add_positional_embedding=False):
+        super().__init__()
+        if not normalize_before:
+            raise NotImplementedError("segdino3d_amd SpConvUNet: only the pre-activation (normalize_before=True) variant is built")
+        self.return_blocks = return_blocks
+        self.num_planes = list(num_planes)
+        self.block_reps = block_reps
+        p = self.num_planes
+        self.blocks = nn.ModuleDict({f"block{i}": ResidualBlock(p[0], p[0]) for i in range(block_reps)})
+        if len(p) > 1:
+            self.conv = nn.Sequential(_bn(p[0]), nn.ReLU(), SpConv(p[0], p[1], 2))
+            self.u = SpConvUNet(p[1:], block_reps=block_reps, indice_key_id=indice_key_id + 1,
+                                return_blocks=return_blocks, main_model=False)
+            self.deconv = nn.Sequential(_bn(p[1]), nn.ReLU(), SpConv(p[1], p[0], 2))
+            self.blocks_tail = nn.ModuleDict({f"block{i}": ResidualBlock(p[0] * (2 - i), p[0]) for i in range(block_reps)})
+        self.mode_fuse_2d_feat = mode_fuse_2d_feat
+        self.voxel_size = voxel_size
+        self.min_spatial_shape = min_spatial_shape
+        self.main_model = main_model
+        if main_model:
+            if not mode_fuse_2d_feat.startswith("early_fusion"):
+                raise NotImplementedError("segdino3d_amd SpConvUNet: only early_fusion is supported (SURVEY q21)")
+            self.in_channels = 256 + 6
+            self.input_conv = nn.Sequential(SpConv(self.in_channels, 32, 3))
+            self.output_layer = nn.Sequential(_bn(32), nn.ReLU(inplace=True))
+        self.add_positional_embedding = add_positional_embedding
+        self._packed = None
+        self.last_maps = None
+
+    # ---- packing ---------------------------------------------------------------------------------
+    def _apply(self, fn, *a, **k):
+        self._packed = None
+        return super()._apply(fn, *a, **k)
+
+    def load_state_dict(self, *a, **k):
+        self._packed = None
+        return super().load_state_dict(*a, **k)
+
+    def packed(self):
+        if self._packed is None:
+            pk = {}
+            for n, m in self.named_modules():
+                if isinstance(m, SpConv):
+                    pk[n] = _pack(m)
+                elif isinstance(m, nn.BatchNorm1d):
+                    pk[n] = _fold(m)
+            self._packed = pk
+        return self._packed
+
+    # ---- network -----------------------------------------------------------------------------------
+    def _resblock(self, pk, p, x, nbr, x2=None):
+        """ResidualBlock.forward (:82-99): conv_branch(x) + i_branch(x); x may be the concat [x | x2]."""
+        s0, b0 = pk[p + ".conv_branch.0"]
+        h = ops.scale_shift_act(x, s0, b0, act="relu", x2=x2)
+        s3, b3 = pk[p + ".conv_branch.3"]
+        h = ops.gather_gemm(h, pk[p + ".conv_branch.2"], nbr=nbr, scale=s3, shift=b3, act="relu")
+        if (p + ".i_branch.0") in pk:
+            ident = ops.gather_gemm(x, pk[p + ".i_branch.0"], x2=x2)
+        else:
+            assert x2 is None
+            ident = x
+        return ops.gather_gemm(h, pk[p + ".conv_branch.5"], nbr=nbr, res=ident)
+
+    def _unet(self, pk, prefix, maps: SceneMaps, level, x):
+        nbr = maps.same(level, 3)
+        for r in range(self.block_reps):
+            x = self._resblock(pk, f"{prefix}blocks.block{r}", x, nbr)
+        n_levels = len(maps.n_vox)
+        if level < n_levels - 1:
+            ident = x
+            s, b = pk[prefix + "conv.0"]
+            h = ops.scale_shift_act(x, s, b, act="relu")
+            h = ops.gather_gemm(h, pk[prefix + "conv.2"], nbr=maps.down(level))
+            h = self._unet(pk, prefix + "u.", maps, level + 1, h)
+            s, b = pk[prefix + "deconv.0"]
+            h = ops.scale_shift_act(h, s, b, act="relu")
+            h = ops.gather_gemm(h, pk[prefix + "deconv.2"], nbr=maps.up(level))
+            x = self._resblock(pk, f"{prefix}blocks_tail.block0", ident, nbr, x2=h)
+            for r in range(1, self.block_reps):
+                x = self._resblock(pk, f"{prefix}blocks_tail.block{r}", x, nbr)
+        return x
+
+    def forward_wrapper(self, samples: List[torch.Tensor], targets, return_sp_mean_pos=True):
+        if self.training:
+            raise NotImplementedError("segdino3d_amd backbone: eval-mode forward only (training step not built)")
+        pk = self.packed()
+        feats, pos = [], []
+        for pts, tgt in zip(samples, targets):
+            if "elastic_coords" in tgt:
+                raise NotImplementedError("elastic_coords (train-time augmentation) is not supported in the eval path")
+            ef = tgt["extra_features"]
+            pts = pts.float().contiguous()
+            f2d = ef["points_2dfeats"].float().contiguous()
+            sp = ef["super_point_masks"].contiguous()
+            # network coordinates are shifted to start at 0 (:286); superpoint positions are NOT (:344-353)
+            maps = SceneMaps(pts, self.voxel_size, len(self.num_planes), shift_to_min=True, order=self.KERNEL_ORDER,
+                             superpoints=sp)
+            self.last_maps = maps
+            cin_pad = (self.in_channels + 31) // 32 * 32
+            vf = maps.voxel_features(pts, f2d, 2, cin_pad)
+            x = ops.gather_gemm(vf, pk["input_conv.0"], nbr=maps.same(0, 3))
+            x = self._unet(pk, "", maps, 0, x)
+            s, b = pk["output_layer.0"]
+            x = ops.scale_shift_act(x, s, b, act="relu")
+            f, _ = maps.pool(x, x.shape[1])
+            # positions: mean of floor(xyz / voxel) * voxel with the UN-shifted coordinates
+            pos_maps = SceneMaps(pts, self.voxel_size, 1, shift_to_min=False, order=self.KERNEL_ORDER, superpoints=sp)
+            _, p = pos_maps.pool(x.new_zeros((pos_maps.n_vox[0], 4)), 4)
+            feats.append(f)
+            pos.append(p)
+        sp_pos = pos if self.add_positional_embedding else None
+        if return_sp_mean_pos:
+            return feats, sp_pos, [p.clone() for p in pos]
+        return feats, sp_pos

@@ -72,6 +72,7 @@ int launch_row_argmax(const float*, int, int64_t, const int32_t*, int, int64_t*,
 int launch_gather_i64(const int64_t*, const int64_t*, int64_t, int, int64_t*, hipStream_t);
 int launch_panoptic(const uint8_t*, int64_t, const int32_t*, const int32_t*, int, int, int, const int64_t*, int32_t*, int32_t*, int64_t*, int64_t*, hipStream_t);
 int launch_instance_boxes(const float*, int, int64_t, const uint8_t*, int64_t, int, int, float*, float*, void*, size_t, hipStream_t);
+int launch_scale_shift_act(const float*, int, int, const float*, int, const float*, const float*, int, int64_t, int, float*, int, hipStream_t);
 
 #define ST ((hipStream_t)stream)
 
@@ -232,6 +233,10 @@ size_t sd3d_instance_boxes_ws_bytes(int n_inst) { return (size_t)(n_inst > 0 ? n
 int sd3d_instance_boxes(const float* points, int ld, int64_t N, const uint8_t* masks, int64_t mask_stride, int n_inst, int mode,
                         float* centers, float* sizes, void* ws, size_t ws_bytes, void* stream) {
     return launch_instance_boxes(points, ld, N, masks, mask_stride, n_inst, mode, centers, sizes, ws, ws_bytes, ST);
+}
+int sd3d_scale_shift_act(const float* x0, int ld0, int C0, const float* x1, int ld1, const float* scale, const float* shift, int act,
+                         int64_t M, int C, float* out, int ld_out, void* stream) {
+    return launch_scale_shift_act(x0, ld0, C0, x1, ld1, scale, shift, act, M, C, out, ld_out, ST);
 }
 
 }  // extern "C"

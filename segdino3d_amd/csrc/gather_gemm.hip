@@ -35,42 +35,40 @@ struct GGParams {
     int col_groups;                           // ceil(Cout / (32*NT))
 };
 
+// One pipeline sub-step = 4 channels per lane (one dwordx4 of A, NT dwordx4 of B, 4*NT MFMAs).
+// Keeping the software pipeline at this granularity (instead of a whole 32-channel chunk) costs
+// 4 + 4*NT live operand registers per buffer instead of 16 + 16*NT, which is what lets 4-5 waves
+// share a SIMD; consecutive sub-steps of a chunk hit the same 128-byte line of the gathered row.
 template <int NT>
 struct Frag {
-    f32x4 a[4];
-    f32x4 b[NT][4];
+    f32x4 a;
+    f32x4 b[NT];
 };
 
 template <int NT>
-__device__ __forceinline__ void load_frag(Frag<NT>& f, const GGParams& p, int k, int chunk, int idx, int ncol0, int j, int h) {
-    const int c = chunk * 32 + h * 16;
+__device__ __forceinline__ void load_frag(Frag<NT>& f, const GGParams& p, int k, int sub, int idx, int ncol0, int j, int h) {
+    const int c = (sub >> 2) * 32 + h * 16 + (sub & 3) * 4;
     if (idx >= 0) {
         const float* src = (c < p.C0) ? (p.in0 + (int64_t)idx * p.ld0 + c) : (p.in1 + (int64_t)idx * p.ld1 + (c - p.C0));
-#pragma unroll
-        for (int q = 0; q < 4; ++q) f.a[q] = *(const f32x4*)(src + q * 4);
+        f.a = *(const f32x4*)src;
     } else {
-#pragma unroll
-        for (int q = 0; q < 4; ++q) f.a[q] = f32x4{0.f, 0.f, 0.f, 0.f};
+        f.a = f32x4{0.f, 0.f, 0.f, 0.f};
     }
 #pragma unroll
     for (int t = 0; t < NT; ++t) {
         int n = ncol0 + t * 32 + j;
         n = n < p.Cout ? n : p.Cout - 1;
-        const float* w = p.wt + ((int64_t)k * p.Cout + n) * p.Cin + c;
-#pragma unroll
-        for (int q = 0; q < 4; ++q) f.b[t][q] = *(const f32x4*)(w + q * 4);
+        f.b[t] = *(const f32x4*)(p.wt + ((int64_t)k * p.Cout + n) * p.Cin + c);
     }
 }
 
 template <int NT>
 __device__ __forceinline__ void mma_frag(f32x16 (&acc)[NT], const Frag<NT>& f) {
 #pragma unroll
-    for (int q = 0; q < 4; ++q)
+    for (int e = 0; e < 4; ++e)
 #pragma unroll
-        for (int e = 0; e < 4; ++e)
-#pragma unroll
-            for (int t = 0; t < NT; ++t)
-                acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(f.a[q][e], f.b[t][q][e], acc[t], 0, 0, 0);
+        for (int t = 0; t < NT; ++t)
+            acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(f.a[e], f.b[t][e], acc[t], 0, 0, 0);
 }
 
 __device__ __forceinline__ int next_active(uint64_t m0, uint64_t m1, int after) {
@@ -108,7 +106,7 @@ __global__ __launch_bounds__(256) void gather_gemm_kernel(const GGParams p) {
     const int64_t row = row0 + j;
     const bool row_ok = row < p.M;
     const int ncol0 = cg * 32 * NT;
-    const int nchunks = p.Cin >> 5;
+    const int nchunks = p.Cin >> 3;          // pipeline sub-steps per offset (4 per 32-channel chunk)
 
     // which kernel offsets have at least one neighbour among this tile's rows?
     uint64_t m0 = 0, m1 = 0;
@@ -132,7 +130,7 @@ __global__ __launch_bounds__(256) void gather_gemm_kernel(const GGParams p) {
     // steps whose running number is congruent to ks modulo KS.
     int k = next_active(m0, m1, -1);
     int chunk = 0, t_run = 0;
-    while (k >= 0 && (t_run % KS) != ks) {
+    while (k >= 0 && ((t_run >> 2) % KS) != ks) {
         ++t_run;
         if (++chunk == nchunks) { chunk = 0; k = next_active(m0, m1, k); }
     }
@@ -145,7 +143,7 @@ __global__ __launch_bounds__(256) void gather_gemm_kernel(const GGParams p) {
             do {
                 ++t_run;
                 if (++nchunk == nchunks) { nchunk = 0; nk = next_active(m0, m1, nk); }
-            } while (nk >= 0 && (t_run % KS) != ks);
+            } while (nk >= 0 && ((t_run >> 2) % KS) != ks);
             const bool has_next = nk >= 0;
             if (has_next && nk != k) nidx = row_ok ? p.nbr[(int64_t)nk * p.M + row] : -1;
             Frag<NT> nxt;
@@ -166,12 +164,13 @@ __global__ __launch_bounds__(256) void gather_gemm_kernel(const GGParams p) {
         }
         __syncthreads();
         if (ks > 0) return;
-#pragma unroll
-        for (int s = 0; s < KS - 1; ++s)
+#pragma unroll 1
+        for (int s = 0; s < KS - 1; ++s) {          // not unrolled: keeps the live LDS reads to one partial tile
 #pragma unroll
             for (int t = 0; t < NT; ++t)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc[t][r] += red[((s * NT + t) * 16 + r) * 64 + lane];
+        }
     }
 
     // epilogue: acc[t][r] is (row = (r&3) + 8*(r>>2) + 4*h, col = j) of subtile t
@@ -215,10 +214,12 @@ int launch_gather_gemm(const GGParams& p_in, int nt, hipStream_t st) {
         nt = sub >= 4 ? 4 : sub;
         while (nt > 1 && tiles * cdiv(sub, nt) < 2048) --nt;
         if (sub % nt) { for (int c = nt; c >= 1; --c) if (sub % c == 0) { nt = c; break; } }
+        // split-K (4 waves per tile) whenever a tile has enough (offset, chunk) steps to share: it turns
+        // one long wave into four short ones, which fills the SIMDs on small launches and cuts the
+        // last-round tail on big ones (tiles / resident workgroups is only 2-4 without it).
         const int64_t steps = (int64_t)p.K * (p.Cin / 32);
-        if (force_split || (tiles * cdiv(sub, nt) < 1024 && steps >= 8)) ks = 4;
+        if (force_split || steps >= 8) ks = 4;
         if (force_split) nt = 1;
-        if (ks == 4 && nt > 2) nt = (sub % 2 == 0) ? 2 : 1;
     }
     p.col_groups = (int)cdiv(p.Cout, 32 * nt);
     const int64_t units = tiles * p.col_groups;
@@ -237,7 +238,9 @@ int launch_gather_gemm(const GGParams& p_in, int nt, hipStream_t st) {
         switch (nt) {
             case 1: GG_LAUNCH(1, 4); break;
             case 2: GG_LAUNCH(2, 4); break;
-            default: return sd3d_set_error(SD3D_ERR_ARG, "gather_gemm: split-K supports nt 1..2");
+            case 3: GG_LAUNCH(3, 4); break;
+            case 4: GG_LAUNCH(4, 4); break;
+            default: return sd3d_set_error(SD3D_ERR_ARG, "gather_gemm: nt must be 1..4");
         }
     }
 #undef GG_LAUNCH

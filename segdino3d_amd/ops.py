@@ -476,3 +476,19 @@ def instance_boxes(points, masks_bool, mode):
     _lib.check(lib.sd3d_instance_boxes(pp, ld, N, _ptr(m, torch.uint8, "masks"), N, n, 0 if mode == "mean" else 1,
                                        _ptr(centers), _ptr(sizes), ws.data_ptr(), ws.numel(), _stream()), "instance_boxes")
     return centers, sizes
+
+
+def scale_shift_act(x, scale, shift, act=None, x2=None):
+    """act(cat[x, x2] * scale + shift) -> new contiguous [M, C] tensor."""
+    lib = _lib.load()
+    p0, ld0 = _rows(x, "x")
+    C0 = x.shape[1]
+    p1, ld1, C = None, 0, C0
+    if x2 is not None:
+        p1, ld1 = _rows(x2, "x2")
+        C = C0 + x2.shape[1]
+    out = torch.empty(x.shape[0], C, dtype=torch.float32, device=x.device)
+    _lib.check(lib.sd3d_scale_shift_act(p0, ld0, C0, p1, ld1, _ptr(scale, torch.float32, "scale"),
+                                        _ptr(shift, torch.float32, "shift"), ACT[act], x.shape[0], C, _ptr(out), C,
+                                        _stream()), "scale_shift_act")
+    return out

@@ -189,3 +189,24 @@ def test_res16unet34c_forward_wrapper_matches_oracle():
     err = (f[0].cpu() - rf).abs().max().item()
     scale = rf.abs().max().item()
     assert err <= 2e-3 * max(scale, 1.0), f"backbone features differ: max abs err {err} (scale {scale})"
+
+
+def test_spconvunet_forward_wrapper_matches_oracle():
+    from oracle import sparse_ref as R
+    from segdino3d_amd.backbone_spconv import SpConvUNet
+    d = dev()
+    pts, tgt = _scene(n=10000, S=100, idx=15)              # BASELINE config #1 shape: 10 k points
+    m = SpConvUNet(num_planes=[32 * (i + 1) for i in range(5)], return_blocks=True, voxel_size=0.02,
+                   mode_fuse_2d_feat="early_fusion", add_positional_embedding=True).eval()
+    sd = {k: det_param("backbone." + k, v.shape).to(v.dtype) for k, v in m.state_dict().items()}
+    m.load_state_dict(sd)
+    m.to(d)
+    f, pos, pos_wo = m.forward_wrapper([pts.to(d)], [tgt.to(d)], return_sp_mean_pos=True)
+    tgt = tgt.to("cpu")
+    rf, rp, _ = R.spconv_forward_wrapper({"backbone." + k: v for k, v in sd.items()}, pts,
+                                         tgt.extra_features["points_2dfeats"], tgt.extra_features["super_point_masks"])
+    torch.testing.assert_close(pos[0].cpu(), rp, rtol=5e-5, atol=1e-4)
+    err = (f[0].cpu() - rf).abs().max().item()
+    scale = rf.abs().max().item()
+    assert f[0].shape == (100, 32)
+    assert err <= 2e-3 * max(scale, 1.0), f"spconv backbone features differ: max abs err {err} (scale {scale})"
