@@ -35,40 +35,42 @@ struct GGParams {
     int col_groups;                           // ceil(Cout / (32*NT))
 };
 
-// One pipeline sub-step = 4 channels per lane (one dwordx4 of A, NT dwordx4 of B, 4*NT MFMAs).
-// Keeping the software pipeline at this granularity (instead of a whole 32-channel chunk) costs
-// 4 + 4*NT live operand registers per buffer instead of 16 + 16*NT, which is what lets 4-5 waves
-// share a SIMD; consecutive sub-steps of a chunk hit the same 128-byte line of the gathered row.
 template <int NT>
 struct Frag {
-    f32x4 a;
-    f32x4 b[NT];
+    f32x4 a[4];
+    f32x4 b[NT][4];
 };
 
 template <int NT>
-__device__ __forceinline__ void load_frag(Frag<NT>& f, const GGParams& p, int k, int sub, int idx, int ncol0, int j, int h) {
-    const int c = (sub >> 2) * 32 + h * 16 + (sub & 3) * 4;
+__device__ __forceinline__ void load_frag(Frag<NT>& f, const GGParams& p, int k, int chunk, int idx, int ncol0, int j, int h) {
+    const int c = chunk * 32 + h * 16;
     if (idx >= 0) {
         const float* src = (c < p.C0) ? (p.in0 + (int64_t)idx * p.ld0 + c) : (p.in1 + (int64_t)idx * p.ld1 + (c - p.C0));
-        f.a = *(const f32x4*)src;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) f.a[q] = *(const f32x4*)(src + q * 4);
     } else {
-        f.a = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int q = 0; q < 4; ++q) f.a[q] = f32x4{0.f, 0.f, 0.f, 0.f};
     }
 #pragma unroll
     for (int t = 0; t < NT; ++t) {
         int n = ncol0 + t * 32 + j;
         n = n < p.Cout ? n : p.Cout - 1;
-        f.b[t] = *(const f32x4*)(p.wt + ((int64_t)k * p.Cout + n) * p.Cin + c);
+        const float* w = p.wt + ((int64_t)k * p.Cout + n) * p.Cin + c;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) f.b[t][q] = *(const f32x4*)(w + q * 4);
     }
 }
 
 template <int NT>
 __device__ __forceinline__ void mma_frag(f32x16 (&acc)[NT], const Frag<NT>& f) {
 #pragma unroll
-    for (int e = 0; e < 4; ++e)
+    for (int q = 0; q < 4; ++q)
 #pragma unroll
-        for (int t = 0; t < NT; ++t)
-            acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(f.a[e], f.b[t][e], acc[t], 0, 0, 0);
+        for (int e = 0; e < 4; ++e)
+#pragma unroll
+            for (int t = 0; t < NT; ++t)
+                acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(f.a[q][e], f.b[t][q][e], acc[t], 0, 0, 0);
 }
 
 __device__ __forceinline__ int next_active(uint64_t m0, uint64_t m1, int after) {
@@ -106,7 +108,7 @@ __global__ __launch_bounds__(256) void gather_gemm_kernel(const GGParams p) {
     const int64_t row = row0 + j;
     const bool row_ok = row < p.M;
     const int ncol0 = cg * 32 * NT;
-    const int nchunks = p.Cin >> 3;          // pipeline sub-steps per offset (4 per 32-channel chunk)
+    const int nchunks = p.Cin >> 5;
 
     // which kernel offsets have at least one neighbour among this tile's rows?
     uint64_t m0 = 0, m1 = 0;
@@ -130,7 +132,7 @@ __global__ __launch_bounds__(256) void gather_gemm_kernel(const GGParams p) {
     // steps whose running number is congruent to ks modulo KS.
     int k = next_active(m0, m1, -1);
     int chunk = 0, t_run = 0;
-    while (k >= 0 && ((t_run >> 2) % KS) != ks) {
+    while (k >= 0 && (t_run % KS) != ks) {
         ++t_run;
         if (++chunk == nchunks) { chunk = 0; k = next_active(m0, m1, k); }
     }
@@ -143,7 +145,7 @@ __global__ __launch_bounds__(256) void gather_gemm_kernel(const GGParams p) {
             do {
                 ++t_run;
                 if (++nchunk == nchunks) { nchunk = 0; nk = next_active(m0, m1, nk); }
-            } while (nk >= 0 && ((t_run >> 2) % KS) != ks);
+            } while (nk >= 0 && (t_run % KS) != ks);
             const bool has_next = nk >= 0;
             if (has_next && nk != k) nidx = row_ok ? p.nbr[(int64_t)nk * p.M + row] : -1;
             Frag<NT> nxt;
@@ -194,6 +196,157 @@ __global__ __launch_bounds__(256) void gather_gemm_kernel(const GGParams p) {
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// Lock-step variant with LDS-shared weights.  The four waves of a workgroup own four consecutive
+// row tiles (128 output rows) of the same column group and walk the (offset, chunk) steps together;
+// each step's weight slice W[k][cols][chunk] (32*NT rows x 128 B) is fetched from L2 ONCE per
+// workgroup, written to LDS (rows padded to 144 B: conflict-free ds_read_b128) and read by all four
+// waves - 4x less L2->CU weight traffic than the private-fragment kernel and 16*NT fewer live VGPRs.
+// A rows stay private to the wave (gathered straight into registers, prefetched one step ahead).
+// One barrier per step; the next step's global loads are in flight during the current step's MFMAs.
+// ---------------------------------------------------------------------------------------------
+#define BS_LD 36
+template <int NT>
+__global__ __launch_bounds__(256) void gather_gemm_lds_kernel(const GGParams p) {
+    __shared__ __attribute__((aligned(16))) float Bs[2][NT * 32 * BS_LD];
+    __shared__ unsigned long long wmask[4][2];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wv = tid >> 6;
+    const int j = lane & 31, h = lane >> 5;
+    const int64_t row_tile = (int64_t)blockIdx.x * 4 + wv;
+    const int cg = blockIdx.y;
+    const int64_t row0 = row_tile * 32;
+    const int64_t row = row0 + j;
+    const bool row_ok = row < p.M;
+    const int ncol0 = cg * 32 * NT;
+    const int nchunks = p.Cin >> 5;
+
+    uint64_t m0 = 0, m1 = 0;
+    if (p.nbr) {
+        for (int k = 0; k < p.K; ++k) {
+            const int id = row_ok ? p.nbr[(int64_t)k * p.M + row] : -1;
+            const bool any = __ballot(id >= 0) != 0ull;
+            if (any) { if (k < 64) m0 |= 1ull << k; else m1 |= 1ull << (k - 64); }
+        }
+    } else {
+        m0 = (row0 < p.M) ? 1ull : 0ull;
+    }
+    if (lane == 0) { wmask[wv][0] = m0; wmask[wv][1] = m1; }
+    __syncthreads();
+    const uint64_t b0 = wmask[0][0] | wmask[1][0] | wmask[2][0] | wmask[3][0];
+    const uint64_t b1 = wmask[0][1] | wmask[1][1] | wmask[2][1] | wmask[3][1];
+
+    f32x16 acc[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+
+    // cooperative staging map: NT*32 rows x 8 float4; thread handles float4 number tid + i*256
+    f32x4 bst[NT];
+    auto stage_load = [&](int k, int chunk) {
+#pragma unroll
+        for (int i = 0; i < NT; ++i) {
+            const int f = tid + i * 256;
+            int n = ncol0 + (f >> 3);
+            n = n < p.Cout ? n : p.Cout - 1;
+            bst[i] = *(const f32x4*)(p.wt + ((int64_t)k * p.Cout + n) * p.Cin + chunk * 32 + (f & 7) * 4);
+        }
+    };
+    auto stage_store = [&](int buf) {
+#pragma unroll
+        for (int i = 0; i < NT; ++i) {
+            const int f = tid + i * 256;
+            *(f32x4*)(&Bs[buf][(f >> 3) * BS_LD + (f & 7) * 4]) = bst[i];
+        }
+    };
+    auto load_a = [&](f32x4 (&a)[4], int idx, int chunk) {
+        const int c = chunk * 32 + h * 16;
+        if (idx >= 0) {
+            const float* src = (c < p.C0) ? (p.in0 + (int64_t)idx * p.ld0 + c) : (p.in1 + (int64_t)idx * p.ld1 + (c - p.C0));
+#pragma unroll
+            for (int q = 0; q < 4; ++q) a[q] = *(const f32x4*)(src + q * 4);
+        } else {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) a[q] = f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+    };
+    auto row_idx = [&](int k) -> int {
+        return p.nbr ? (row_ok ? p.nbr[(int64_t)k * p.M + row] : -1) : (row_ok ? (int)row : -1);
+    };
+
+    int k = next_active(b0, b1, -1);
+    if (k >= 0) {                                   // uniform over the workgroup
+        int chunk = 0, buf = 0;
+        int idx = row_idx(k);
+        f32x4 acur[4];
+        load_a(acur, idx, 0);
+        stage_load(k, 0);
+        stage_store(0);
+        __syncthreads();
+        while (true) {
+            int nk = k, nchunk = chunk + 1, nidx = idx;
+            if (nchunk == nchunks) {
+                nchunk = 0;
+                nk = next_active(b0, b1, k);
+                if (nk >= 0) nidx = row_idx(nk);
+            }
+            const bool has_next = nk >= 0;
+            f32x4 anxt[4];
+            if (has_next) {
+                stage_load(nk, nchunk);
+                load_a(anxt, nidx, nchunk);
+            }
+            // does this wave have any neighbour at offset k?  (wave-uniform)
+            const bool mine = (k < 64) ? ((m0 >> k) & 1ull) : ((m1 >> (k - 64)) & 1ull);
+            if (mine) {
+                const float* bb = &Bs[buf][j * BS_LD + h * 16];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    f32x4 bq[NT];
+#pragma unroll
+                    for (int t = 0; t < NT; ++t) bq[t] = *(const f32x4*)(bb + t * 32 * BS_LD + q * 4);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e)
+#pragma unroll
+                        for (int t = 0; t < NT; ++t)
+                            acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(acur[q][e], bq[t][e], acc[t], 0, 0, 0);
+                }
+            }
+            if (!has_next) break;
+            stage_store(buf ^ 1);
+            __syncthreads();
+            buf ^= 1;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) acur[q] = anxt[q];
+            k = nk; chunk = nchunk; idx = nidx;
+        }
+    }
+    if (row0 >= p.M) return;
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+        const int n = ncol0 + t * 32 + j;
+        if (n >= p.Cout) continue;
+        const float sc = p.scale ? p.scale[n] : 1.f;
+        const float sh = p.shift ? p.shift[n] : 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int64_t rr = row0 + (r & 3) + 8 * (r >> 2) + 4 * h;
+            if (rr >= p.M) continue;
+            float y = acc[t][r] * sc + sh;
+            if (p.res) y += p.res[rr * p.ld_res + n];
+            if (p.act == 1) y = fmaxf(y, 0.f);
+            else if (p.act == 2) y = 0.5f * y * (1.f + erff(y * 0.70710678118654752440f));
+            else if (p.act == 3) y = 1.f / (1.f + expf(-y));
+            p.out[rr * p.ld_out + n] = y;
+        }
+    }
+}
+
+// nt > 0            : private-fragment kernel, nt subtiles per wave, no split-K
+// nt == 0           : heuristic (see below)
+// nt == -1          : private-fragment kernel, split-K with one subtile (tests)
+// nt in [-14, -11]  : lock-step LDS-shared-weights kernel with (-nt - 10) subtiles (tests / tuning)
 int launch_gather_gemm(const GGParams& p_in, int nt, hipStream_t st) {
     GGParams p = p_in;
     if (p.M <= 0 || p.Cout <= 0) return SD3D_OK;
@@ -203,27 +356,46 @@ int launch_gather_gemm(const GGParams& p_in, int nt, hipStream_t st) {
     if ((p.ld0 & 3) || (p.in1 && (p.ld1 & 3))) return sd3d_set_error(SD3D_ERR_ARG, "gather_gemm: input row stride must be a multiple of 4 floats");
     if (p.K > 128) return sd3d_set_error(SD3D_ERR_ARG, "gather_gemm: at most 128 kernel offsets");
     if (!p.nbr && p.K != 1) return sd3d_set_error(SD3D_ERR_ARG, "gather_gemm: identity gather needs K == 1");
-    // nt > 0: caller-chosen subtiles per wave, no split-K.  nt <= 0: heuristic - wide tiles when there
-    // are plenty of rows; narrow tiles and split-K (4 waves share a tile) when the launch would leave
-    // most SIMDs idle.  nt == -1 forces split-K with one subtile (tests).
     const int sub = (p.Cout + 31) / 32;
     const int64_t tiles = cdiv(p.M, 32);
     int ks = 1;
-    if (nt <= 0) {
+    bool lds = false;
+    if (nt <= -11 && nt >= -14) {
+        lds = true;
+        nt = -nt - 10;
+    } else if (nt <= 0) {
         const bool force_split = nt < 0;
-        nt = sub >= 4 ? 4 : sub;
-        while (nt > 1 && tiles * cdiv(sub, nt) < 2048) --nt;
-        if (sub % nt) { for (int c = nt; c >= 1; --c) if (sub % c == 0) { nt = c; break; } }
-        // split-K (4 waves per tile) whenever a tile has enough (offset, chunk) steps to share: it turns
-        // one long wave into four short ones, which fills the SIMDs on small launches and cuts the
-        // last-round tail on big ones (tiles / resident workgroups is only 2-4 without it).
         const int64_t steps = (int64_t)p.K * (p.Cin / 32);
-        if (force_split || steps >= 8) ks = 4;
-        if (force_split) nt = 1;
+        if (!force_split && tiles >= 64 && steps >= 2) {
+            // enough rows for 4-tile workgroups: share the weights through LDS
+            lds = true;
+            nt = sub >= 4 ? 4 : sub;
+            while (nt > 1 && cdiv(tiles, 4) * cdiv(sub, nt) < 512) --nt;
+            if (sub % nt) { for (int c = nt; c >= 1; --c) if (sub % c == 0) { nt = c; break; } }
+        } else {
+            nt = sub >= 4 ? 4 : sub;
+            while (nt > 1 && tiles * cdiv(sub, nt) < 2048) --nt;
+            if (sub % nt) { for (int c = nt; c >= 1; --c) if (sub % c == 0) { nt = c; break; } }
+            if (force_split || (tiles * cdiv(sub, nt) < 1024 && steps >= 8)) ks = 4;
+            if (force_split) nt = 1;
+            if (ks == 4 && nt > 2) nt = (sub % 2 == 0) ? 2 : 1;
+        }
     }
     p.col_groups = (int)cdiv(p.Cout, 32 * nt);
-    const int64_t units = tiles * p.col_groups;
     const dim3 block(256);
+    if (lds) {
+        const dim3 grid((unsigned)cdiv(tiles, 4), (unsigned)p.col_groups);
+        switch (nt) {
+            case 1: hipLaunchKernelGGL(gather_gemm_lds_kernel<1>, grid, block, 0, st, p); break;
+            case 2: hipLaunchKernelGGL(gather_gemm_lds_kernel<2>, grid, block, 0, st, p); break;
+            case 3: hipLaunchKernelGGL(gather_gemm_lds_kernel<3>, grid, block, 0, st, p); break;
+            case 4: hipLaunchKernelGGL(gather_gemm_lds_kernel<4>, grid, block, 0, st, p); break;
+            default: return sd3d_set_error(SD3D_ERR_ARG, "gather_gemm: nt must be 1..4");
+        }
+        SD3D_CHECK_LAUNCH();
+        return SD3D_OK;
+    }
+    const int64_t units = tiles * p.col_groups;
     const dim3 grid((unsigned)(ks == 4 ? units : cdiv(units, 4)));
 #define GG_LAUNCH(NT_, KS_) hipLaunchKernelGGL((gather_gemm_kernel<NT_, KS_>), grid, block, 0, st, p)
     if (ks == 1) {
@@ -238,9 +410,7 @@ int launch_gather_gemm(const GGParams& p_in, int nt, hipStream_t st) {
         switch (nt) {
             case 1: GG_LAUNCH(1, 4); break;
             case 2: GG_LAUNCH(2, 4); break;
-            case 3: GG_LAUNCH(3, 4); break;
-            case 4: GG_LAUNCH(4, 4); break;
-            default: return sd3d_set_error(SD3D_ERR_ARG, "gather_gemm: nt must be 1..4");
+            default: return sd3d_set_error(SD3D_ERR_ARG, "gather_gemm: split-K supports nt 1..2");
         }
     }
 #undef GG_LAUNCH
