@@ -66,11 +66,15 @@ int sd3d_voxel_keys(const float* points, int ld, int64_t n, float inv_voxel, con
                     int batch_index, int32_t* origin, uint64_t* keys, int32_t* icoords, int32_t* err_flag, void* stream);
 /* Run-length unique over SORTED keys compared after (morton >> shift):
  *   ukeys [<=n], seg_start [<=n+1] (optional), map[src_idx ? src_idx[j] : j] = unique id (optional),
- *   *n_unique_dev = number of unique keys.  n_dev (optional) = device-resident live length <= n_cap. */
+ *   *n_unique_dev = number of unique keys.  n_dev (optional) = device-resident live length <= n_cap.
+ * clip_stats != NULL applies spconv's SparseConv3d(k=2, s=2) output-extent rule when creating level
+ * clip_level >= 1: parents outside (D - 2) / 2 + 1 per axis (D_0 = max(extent, clip_min_shape),
+ * spconvunet.py:309-310) are not created and their children map to -1. */
 size_t sd3d_unique_ws_bytes(int64_t n_cap);
 int sd3d_unique_sorted(const uint64_t* keys, const uint32_t* src_idx, int64_t n_cap, const int32_t* n_dev, int shift,
                        uint64_t* ukeys, int32_t* seg_start, int32_t* map, int32_t* n_unique_dev, void* ws,
-                       size_t ws_bytes, void* stream);
+                       size_t ws_bytes, const float* clip_stats, float clip_inv_voxel, int clip_level, int clip_min_shape,
+                       void* stream);
 /* Open-addressing hash table key -> voxel id; capacity = power of two > n. */
 int sd3d_hash_build(const uint64_t* ukeys, int64_t n, uint64_t* table_keys, int32_t* table_vals, int64_t capacity,
                     void* stream);

@@ -15,8 +15,9 @@ Z-order coordinate hierarchy; the pre-activation BatchNorm+ReLU is one elementwi
 between the two convolutions of a block is fused into the first convolution's epilogue and the
 residual add into the second's.  Eval mode, `early_fusion`, no elastic coordinates.
 
-Not yet reproduced: spconv's output-extent rule `(D - 2) // 2 + 1` that drops the trailing slice of an
-odd-sized grid wider than `min_spatial_shape`.
+spconv's output-extent rule `(D - 2) // 2 + 1` (the trailing slice of an odd-sized grid has no parent
+voxel; `spatial_shape = clip(max + 1, min_spatial_shape)`, :309-310) is applied when the coarser
+levels are created (`SceneMaps(clip_min_shape=...)`).
 """
 from __future__ import annotations
 
@@ -171,7 +172,7 @@ class SpConvUNet(nn.Module):
             sp = ef["super_point_masks"].contiguous()
             # network coordinates are shifted to start at 0 (:286); superpoint positions are NOT (:344-353)
             maps = SceneMaps(pts, self.voxel_size, len(self.num_planes), shift_to_min=True, order=self.KERNEL_ORDER,
-                             superpoints=sp)
+                             superpoints=sp, clip_min_shape=self.min_spatial_shape)
             self.last_maps = maps
             cin_pad = (self.in_channels + 31) // 32 * 32
             vf = maps.voxel_features(pts, f2d, 2, cin_pad)

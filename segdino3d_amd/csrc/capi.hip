@@ -21,7 +21,7 @@ int launch_i64_to_sortkey(const int64_t*, int64_t, uint64_t*, hipStream_t);
 int launch_scene_stats(const float*, int, int64_t, float*, void*, size_t, hipStream_t);
 size_t unique_ws_bytes(int64_t);
 int launch_unique_sorted(const uint64_t*, const uint32_t*, int64_t, const int*, int, uint64_t*, int32_t*, int32_t*, int32_t*,
-                         void*, size_t, hipStream_t);
+                         void*, size_t, const float*, float, int, int, hipStream_t);
 int launch_hash_build(const uint64_t*, int64_t, uint64_t*, int32_t*, int64_t, hipStream_t);
 int launch_kernel_map(const uint64_t*, int64_t, const uint64_t*, const int32_t*, int64_t, const int8_t*, int, int32_t*, hipStream_t);
 int launch_stride_maps(const uint64_t*, const int32_t*, int64_t, int64_t, const int32_t*, int32_t*, int32_t*, hipStream_t);
@@ -125,8 +125,9 @@ int sd3d_voxel_keys(const float* points, int ld, int64_t n, float inv_voxel, con
 size_t sd3d_unique_ws_bytes(int64_t n_cap) { return unique_ws_bytes(n_cap > 0 ? n_cap : 1); }
 int sd3d_unique_sorted(const uint64_t* keys, const uint32_t* src_idx, int64_t n_cap, const int32_t* n_dev, int shift,
                        uint64_t* ukeys, int32_t* seg_start, int32_t* map, int32_t* n_unique_dev, void* ws, size_t ws_bytes,
-                       void* stream) {
-    return launch_unique_sorted(keys, src_idx, n_cap, n_dev, shift, ukeys, seg_start, map, n_unique_dev, ws, ws_bytes, ST);
+                       const float* clip_stats, float clip_inv_voxel, int clip_level, int clip_min_shape, void* stream) {
+    return launch_unique_sorted(keys, src_idx, n_cap, n_dev, shift, ukeys, seg_start, map, n_unique_dev, ws, ws_bytes,
+                                clip_stats, clip_inv_voxel, clip_level, clip_min_shape, ST);
 }
 int sd3d_hash_build(const uint64_t* ukeys, int64_t n, uint64_t* table_keys, int32_t* table_vals, int64_t capacity, void* stream) {
     return launch_hash_build(ukeys, n, table_keys, table_vals, capacity, ST);

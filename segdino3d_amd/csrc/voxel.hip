@@ -136,22 +136,50 @@ __device__ static inline uint64_t level_key(uint64_t k, int shift) {
     return ((k & SD3D_MORTON_MASK) >> shift) | (k & ~SD3D_MORTON_MASK);
 }
 
+// Optional output-extent clip (spconv SparseConv3d k=2 s=2 p=0: output extent (D - 2) / 2 + 1, so the
+// trailing slice of an odd-sized grid has no output voxel; spconvunet.py:156-171, 309-310).  clip.level
+// is the index of the level being CREATED (>= 1); D_0 = max(cmax + 1, min_shape) per axis.
+struct ExtentClip {
+    const float* stats;   // NULL = no clipping (MinkowskiEngine semantics)
+    float inv_voxel;
+    int level;
+    int min_shape;
+};
+__device__ static inline bool parent_valid(uint64_t pkey, const ExtentClip& c) {
+    if (!c.stats) return true;
+    uint32_t x[3];
+    morton_decode(pkey & SD3D_MORTON_MASK, x[0], x[1], x[2]);
+    const int off = 32 >> c.level;                       // key origin is -32 voxels of level 0
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+        int D = (int)floorf((c.stats[3 + a] - c.stats[a]) * c.inv_voxel) + 1;
+        D = D > c.min_shape ? D : c.min_shape;
+        for (int i = 0; i < c.level; ++i) D = (D - 2) / 2 + 1;
+        if ((int)x[a] - off >= D) return false;
+    }
+    return true;
+}
+
 __global__ __launch_bounds__(256) void mark_heads(const uint64_t* __restrict__ keys, int64_t n_cap,
-                                                  const int* __restrict__ n_dev, int shift, int* __restrict__ flags) {
+                                                  const int* __restrict__ n_dev, int shift, ExtentClip clip,
+                                                  int* __restrict__ flags) {
     const int64_t n = n_dev ? min((int64_t)*n_dev, n_cap) : n_cap;
     const int64_t j = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (j >= n_cap) return;
     int f = 0;
-    if (j < n) f = (j == 0) || (level_key(keys[j], shift) != level_key(keys[j - 1], shift));
+    if (j < n) {
+        const uint64_t pk = level_key(keys[j], shift);
+        f = ((j == 0) || (pk != level_key(keys[j - 1], shift))) && parent_valid(pk, clip);
+    }
     flags[j] = f;
 }
 
 // excl = exclusive scan of flags.  id(j) = excl[j] + flags[j] - 1.
 //   ukeys[id] = level_key(keys[j])        at heads
 //   seg_start[id] = j at heads ; seg_start[V] = n            (optional)
-//   map[ src_idx ? src_idx[j] : j ] = id                      (inverse map / parent array)
+//   map[ src_idx ? src_idx[j] : j ] = id                      (inverse map / parent array; -1 if clipped)
 __global__ __launch_bounds__(256) void emit_unique(const uint64_t* __restrict__ keys, const uint32_t* __restrict__ src_idx,
-                                                   int64_t n_cap, const int* __restrict__ n_dev, int shift,
+                                                   int64_t n_cap, const int* __restrict__ n_dev, int shift, ExtentClip clip,
                                                    const int* __restrict__ flags, const int* __restrict__ excl,
                                                    uint64_t* __restrict__ ukeys, int32_t* __restrict__ seg_start,
                                                    int32_t* __restrict__ map) {
@@ -159,13 +187,15 @@ __global__ __launch_bounds__(256) void emit_unique(const uint64_t* __restrict__ 
     const int64_t j = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (j >= n) return;
     const int f = flags[j];
-    const int id = excl[j] + f - 1;
+    const uint64_t pk = level_key(keys[j], shift);
+    const bool ok = parent_valid(pk, clip);
+    const int id = ok ? excl[j] + f - 1 : -1;
     if (f) {
-        ukeys[id] = level_key(keys[j], shift);
+        ukeys[id] = pk;
         if (seg_start) seg_start[id] = (int32_t)j;
     }
     if (map) map[src_idx ? (int64_t)src_idx[j] : j] = id;
-    if (j == n - 1 && seg_start) seg_start[id + 1] = (int32_t)n;
+    if (j == n - 1 && seg_start) seg_start[excl[j] + f] = (int32_t)n;
 }
 
 int scan_exclusive_i32(const int* in, int* out, int64_t n_cap, const int* n_dev, int* total_dev, void* ws,
@@ -178,7 +208,10 @@ size_t unique_ws_bytes(int64_t n_cap) {
 
 int launch_unique_sorted(const uint64_t* keys, const uint32_t* src_idx, int64_t n_cap, const int* n_dev, int shift,
                          uint64_t* ukeys, int32_t* seg_start, int32_t* map, int32_t* n_unique_dev, void* ws,
-                         size_t ws_bytes, hipStream_t st) {
+                         size_t ws_bytes, const float* clip_stats, float clip_inv_voxel, int clip_level, int clip_min_shape,
+                         hipStream_t st) {
+    ExtentClip clip;
+    clip.stats = clip_stats; clip.inv_voxel = clip_inv_voxel; clip.level = clip_level; clip.min_shape = clip_min_shape;
     if (n_cap <= 0) return sd3d_set_error(SD3D_ERR_ARG, "unique_sorted: n_cap <= 0");
     if (ws_bytes < unique_ws_bytes(n_cap)) return sd3d_set_error(SD3D_ERR_WS, "unique_sorted workspace too small");
     const size_t a = align_up((size_t)n_cap * sizeof(int), 256);
@@ -186,10 +219,10 @@ int launch_unique_sorted(const uint64_t* keys, const uint32_t* src_idx, int64_t 
     int* excl = (int*)((char*)ws + a);
     void* sws = (char*)ws + 2 * a;
     const unsigned nb = (unsigned)cdiv(n_cap, 256);
-    hipLaunchKernelGGL(mark_heads, dim3(nb), dim3(256), 0, st, keys, n_cap, n_dev, shift, flags);
+    hipLaunchKernelGGL(mark_heads, dim3(nb), dim3(256), 0, st, keys, n_cap, n_dev, shift, clip, flags);
     int rc = scan_exclusive_i32(flags, excl, n_cap, n_dev, n_unique_dev, sws, ws_bytes - 2 * a, st);
     if (rc) return rc;
-    hipLaunchKernelGGL(emit_unique, dim3(nb), dim3(256), 0, st, keys, src_idx, n_cap, n_dev, shift, flags, excl, ukeys,
+    hipLaunchKernelGGL(emit_unique, dim3(nb), dim3(256), 0, st, keys, src_idx, n_cap, n_dev, shift, clip, flags, excl, ukeys,
                        seg_start, map);
     SD3D_CHECK_LAUNCH();
     return SD3D_OK;

@@ -17,6 +17,9 @@ ACT = {None: 0, "none": 0, "relu": 1, "gelu": 2, "sigmoid": 3}
 # Optional instrumentation for bench.py: an object with before(meta: dict) / after() called around
 # every gather_gemm launch on the current stream (meta: K, Cin, Cout, M, nbr tensor or None).
 GG_HOOK = None
+# Debug / tuning override of the gather_gemm tiling heuristic (see csrc/gather_gemm.hip launch codes).
+import os as _os
+GG_FORCE_NT = int(_os.environ["SD3D_GG_NT"]) if _os.environ.get("SD3D_GG_NT") else None
 
 
 def _stream():
@@ -134,7 +137,8 @@ def voxel_keys(points, inv_voxel: float, stats, shift_to_min=False, batch_index=
     return keys, icoords, origin, err
 
 
-def unique_sorted(keys, src_idx, n_cap, n_dev=None, shift=0, want_seg_start=False, want_map=True, map_size=None):
+def unique_sorted(keys, src_idx, n_cap, n_dev=None, shift=0, want_seg_start=False, want_map=True, map_size=None,
+                  clip=None):
     """Run-length unique over sorted keys.  Returns (ukeys[n_cap], seg_start[n_cap+1]|None, map|None, n_unique[1])."""
     lib = _lib.load()
     dev = keys.device
@@ -145,7 +149,10 @@ def unique_sorted(keys, src_idx, n_cap, n_dev=None, shift=0, want_seg_start=Fals
     ws = _WS.get(lib.sd3d_unique_ws_bytes(n_cap), dev)
     _lib.check(lib.sd3d_unique_sorted(_ptr(keys, torch.int64, "keys"), _ptr(src_idx, torch.int32, "src_idx"), n_cap,
                                       _ptr(n_dev, torch.int32, "n_dev"), shift, _ptr(ukeys), _ptr(seg), _ptr(mp),
-                                      _ptr(nuniq), ws.data_ptr(), ws.numel(), _stream()), "unique_sorted")
+                                      _ptr(nuniq), ws.data_ptr(), ws.numel(),
+                                      _ptr(clip[0], torch.float32, "clip stats") if clip else None,
+                                      float(clip[1]) if clip else 0.0, int(clip[2]) if clip else 0,
+                                      int(clip[3]) if clip else 0, _stream()), "unique_sorted")
     return ukeys, seg, mp, nuniq
 
 
@@ -245,6 +252,11 @@ def gather_gemm(x, wt, nbr=None, x2=None, scale=None, shift=None, res=None, act=
     pr, ldr = (None, 0)
     if res is not None:
         pr, ldr = _rows(res, "res")
+    if GG_FORCE_NT is not None and nt == 0:
+        sub = (Cout + 31) // 32
+        eff = GG_FORCE_NT if GG_FORCE_NT > 0 else (-GG_FORCE_NT - 10 if GG_FORCE_NT <= -11 else 1)
+        if sub % eff == 0:
+            nt = GG_FORCE_NT
     hook = GG_HOOK
     if hook is not None:
         hook.before(dict(K=K, Cin=Cin, Cout=Cout, M=M, nbr=nbr))

@@ -64,7 +64,9 @@ class SceneMaps:
     """Voxelisation + coordinate levels + neighbour tables of ONE scene, all on the HIP device."""
 
     def __init__(self, points: torch.Tensor, voxel_size: float, n_levels: int, shift_to_min: bool = False,
-                 order: str = "x_fastest", superpoints: Optional[torch.Tensor] = None):
+                 order: str = "x_fastest", superpoints: Optional[torch.Tensor] = None, clip_min_shape: int = 0):
+        """clip_min_shape > 0 enables spconv's output-extent rule for the strided levels (needs
+        shift_to_min coordinates); 0 = MinkowskiEngine semantics (every parent voxel exists)."""
         if not points.is_cuda:
             raise RuntimeError("SceneMaps needs device-resident points (no CPU fallback in the product path)")
         self.order = order
@@ -80,8 +82,10 @@ class SceneMaps:
             skeys, self.sidx, N, None, 0, want_seg_start=True, want_map=True, map_size=N)
         keys_l, counts, parents = [ukeys], [n0], []
         cap = N
-        for _ in range(1, n_levels):
-            uk, _, parent, nl = ops.unique_sorted(keys_l[-1], None, cap, counts[-1], 3, want_seg_start=False, want_map=True)
+        for lvl in range(1, n_levels):
+            clip = (self.stats, inv, lvl, clip_min_shape) if clip_min_shape > 0 else None
+            uk, _, parent, nl = ops.unique_sorted(keys_l[-1], None, cap, counts[-1], 3, want_seg_start=False, want_map=True,
+                                                  clip=clip)
             keys_l.append(uk)
             counts.append(nl)
             parents.append(parent)
