@@ -343,10 +343,100 @@ __global__ __launch_bounds__(256) void gather_gemm_lds_kernel(const GGParams p) 
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// Pair-compacted variant for LOW-DENSITY kernel maps (fine levels: only 6-30 % of the (row, offset)
+// slots are real pairs, so the output-stationary kernels above multiply mostly zeros).
+// A workgroup owns CB_ROWS = 256 consecutive output rows x (32*NT) columns, accumulated in LDS.
+// Its four waves take the kernel offsets round-robin; for its offset a wave
+//   1. compacts the rows that have a neighbour (4 ballots over the 256 rows) into an LDS list,
+//   2. runs the MFMA chunk loop over 32 PAIRS at a time (gathered input rows x W[k], private
+//      fragments, next chunk prefetched) - every MFMA row is a real pair,
+//   3. adds the 32 x (32*NT) result into the owning output rows of the LDS accumulator (ds_add_f32).
+// Weights are read once per 256 rows instead of once per 32.  The accumulation order across
+// offsets is not fixed (LDS float atomics), i.e. results may differ in the last bits from run to run.
+// ---------------------------------------------------------------------------------------------
+#define CB_ROWS 256
+template <int NT>
+__global__ __launch_bounds__(256) void gather_gemm_compact_kernel(const GGParams p) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    constexpr int CW = 32 * NT;
+    float* accL = smem;                                              // [CB_ROWS][CW]
+    int* l_idx = (int*)(accL + CB_ROWS * CW);                        // [4][CB_ROWS]
+    unsigned short* l_row = (unsigned short*)(l_idx + 4 * CB_ROWS);  // [4][CB_ROWS]
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int j = lane & 31, h = lane >> 5;
+    const int64_t row_base = (int64_t)blockIdx.x * CB_ROWS;
+    const int ncol0 = blockIdx.y * CW;
+    const int nchunks = p.Cin >> 5;
+    for (int e = tid; e < CB_ROWS * CW; e += 256) accL[e] = 0.f;
+    __syncthreads();
+    int* my_idx = l_idx + wv * CB_ROWS;
+    unsigned short* my_row = l_row + wv * CB_ROWS;
+    const uint64_t lt = (1ull << lane) - 1ull;
+    for (int k = wv; k < p.K; k += 4) {
+        int cnt = 0;
+#pragma unroll
+        for (int ps = 0; ps < CB_ROWS / 64; ++ps) {
+            const int r = ps * 64 + lane;
+            const int64_t row = row_base + r;
+            const int id = (row < p.M) ? p.nbr[(int64_t)k * p.M + row] : -1;
+            const uint64_t bal = __ballot(id >= 0);
+            if (id >= 0) {
+                const int pos = cnt + __popcll(bal & lt);
+                my_idx[pos] = id;
+                my_row[pos] = (unsigned short)r;
+            }
+            cnt += __popcll(bal);
+        }
+        __builtin_amdgcn_wave_barrier();
+        for (int pc = 0; pc * 32 < cnt; ++pc) {
+            const int pp = pc * 32 + j;
+            const int pidx = pp < cnt ? my_idx[pp] : -1;
+            f32x16 acc[NT];
+#pragma unroll
+            for (int t = 0; t < NT; ++t)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+            Frag<NT> cur;
+            load_frag<NT>(cur, p, k, 0, pidx, ncol0, j, h);
+            for (int c = 0; c < nchunks; ++c) {
+                Frag<NT> nxt;
+                if (c + 1 < nchunks) load_frag<NT>(nxt, p, k, c + 1, pidx, ncol0, j, h);
+                mma_frag<NT>(acc, cur);
+                if (c + 1 < nchunks) cur = nxt;
+            }
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int prow = pc * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+                if (prow < cnt) {
+                    const int orow = my_row[prow];
+#pragma unroll
+                    for (int t = 0; t < NT; ++t) atomicAdd(&accL[orow * CW + t * 32 + j], acc[t][r]);
+                }
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
+    __syncthreads();
+    for (int e = tid; e < CB_ROWS * CW; e += 256) {
+        const int r = e / CW, nn = e - r * CW;
+        const int64_t rr = row_base + r;
+        const int n = ncol0 + nn;
+        if (rr >= p.M || n >= p.Cout) continue;
+        float y = accL[e] * (p.scale ? p.scale[n] : 1.f) + (p.shift ? p.shift[n] : 0.f);
+        if (p.res) y += p.res[rr * p.ld_res + n];
+        if (p.act == 1) y = fmaxf(y, 0.f);
+        else if (p.act == 2) y = 0.5f * y * (1.f + erff(y * 0.70710678118654752440f));
+        else if (p.act == 3) y = 1.f / (1.f + expf(-y));
+        p.out[rr * p.ld_out + n] = y;
+    }
+}
+
 // nt > 0            : private-fragment kernel, nt subtiles per wave, no split-K
 // nt == 0           : heuristic (see below)
 // nt == -1          : private-fragment kernel, split-K with one subtile (tests)
 // nt in [-14, -11]  : lock-step LDS-shared-weights kernel with (-nt - 10) subtiles (tests / tuning)
+// nt in [-23, -21]  : pair-compacted kernel with (-nt - 20) subtiles (needs a neighbour table)
 int launch_gather_gemm(const GGParams& p_in, int nt, hipStream_t st) {
     GGParams p = p_in;
     if (p.M <= 0 || p.Cout <= 0) return SD3D_OK;
@@ -360,7 +450,29 @@ int launch_gather_gemm(const GGParams& p_in, int nt, hipStream_t st) {
     const int64_t tiles = cdiv(p.M, 32);
     int ks = 1;
     bool lds = false;
-    if (nt <= -11 && nt >= -14) {
+    if (nt <= -21 && nt >= -23) {
+        nt = -nt - 20;
+        if (!p.nbr) return sd3d_set_error(SD3D_ERR_ARG, "gather_gemm: the compacted kernel needs a neighbour table");
+        p.col_groups = (int)cdiv(p.Cout, 32 * nt);
+        const dim3 grid((unsigned)cdiv(p.M, CB_ROWS), (unsigned)p.col_groups);
+        const size_t sm = (size_t)CB_ROWS * 32 * nt * sizeof(float) + 4 * CB_ROWS * (sizeof(int) + sizeof(unsigned short));
+        switch (nt) {
+            case 1: hipLaunchKernelGGL(gather_gemm_compact_kernel<1>, grid, dim3(256), sm, st, p); break;
+            case 2: hipLaunchKernelGGL(gather_gemm_compact_kernel<2>, grid, dim3(256), sm, st, p); break;
+            case 3: {
+                static bool attr_set = false;
+                if (!attr_set) {
+                    (void)hipFuncSetAttribute((const void*)gather_gemm_compact_kernel<3>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm);
+                    attr_set = true;
+                }
+                hipLaunchKernelGGL(gather_gemm_compact_kernel<3>, grid, dim3(256), sm, st, p);
+                break;
+            }
+            default: return sd3d_set_error(SD3D_ERR_ARG, "gather_gemm: compact nt must be 1..3");
+        }
+        SD3D_CHECK_LAUNCH();
+        return SD3D_OK;
+    } else if (nt <= -11 && nt >= -14) {
         lds = true;
         nt = -nt - 10;
     } else if (nt <= 0) {

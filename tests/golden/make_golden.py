@@ -176,6 +176,14 @@ def golden_decoder(dec_mod, name, kw, S, M, query_subset=None):
     torch.manual_seed(0)
     dec = dec_mod.ScanNetQueryDecoder(**kw).eval()
     assign_det_weights(dec, "decoder.")
+    if not kw["normalize_box_prediction"]:
+        # additive size refinement (:751) starts at 0.5; keep the synthetic size head small so that the
+        # sizes stay away from 0, otherwise the modulation sigmoid(.)/size (:661) makes the fixture
+        # ill-conditioned (a 1e-6 input perturbation moved mask logits by 0.2 with unscaled weights)
+        with torch.no_grad():
+            for emb in dec.bbox_size_embed:
+                emb.layers[-1].weight.mul_(0.05)
+                emb.layers[-1].bias.mul_(0.05)
     x, pos, pos_wo, q2d_feat, q2d_pos, lo, hi = decoder_inputs(name, S, M, kw["in_channels"])
     if query_subset is None:
         q, qpos = x, pos

@@ -18,7 +18,7 @@ def load(name):
     return {k: torch.from_numpy(z[k]) if z[k].dtype != object else z[k] for k in z.files}
 
 
-def decoder_state_dict(in_channels=96, n_inst=198, n_sem=200, L=6, d=256, hidden=1024):
+def decoder_state_dict(in_channels=96, n_inst=198, n_sem=200, L=6, d=256, hidden=1024, size_embed_scale=1.0):
     """Key names/shapes of the reference decoder state_dict; values by name."""
     shapes = {}
 
@@ -52,7 +52,12 @@ def decoder_state_dict(in_channels=96, n_inst=198, n_sem=200, L=6, d=256, hidden
         ln(f"norm1.{i}"); ln(f"norm2.{i}")
         for n in ("bbox_embed", "bbox_size_embed"):
             lin(f"{n}.{i}.layers.0", d, d); lin(f"{n}.{i}.layers.1", d, d); lin(f"{n}.{i}.layers.2", 3, d)
-    return {"decoder." + k: det_param("decoder." + k, s) for k, s in shapes.items()}
+    sd = {"decoder." + k: det_param("decoder." + k, s) for k, s in shapes.items()}
+    if size_embed_scale != 1.0:          # mirrors tests/golden/make_golden.py (ScanNetv2 variant)
+        for i in range(L):
+            for leaf in ("weight", "bias"):
+                sd[f"decoder.bbox_size_embed.{i}.layers.2.{leaf}"] *= size_embed_scale
+    return sd
 
 
 def test_sine_pe():
@@ -67,7 +72,7 @@ def test_sine_pe():
 @pytest.mark.parametrize("name,kw,cfgkw", [
     ("decoder_s64_q64", {}, {}),
     ("decoder_s96_q16", {}, {}),
-    ("decoder_v2_s48", dict(in_channels=32, n_inst=18, n_sem=20), dict(normalize_box_prediction=False)),
+    ("decoder_v2_s48", dict(in_channels=32, n_inst=18, n_sem=20, size_embed_scale=0.05), dict(normalize_box_prediction=False)),
 ])
 def test_decoder_matches_reference(name, kw, cfgkw):
     g = load(name)
