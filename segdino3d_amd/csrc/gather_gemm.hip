@@ -356,26 +356,26 @@ __global__ __launch_bounds__(256) void gather_gemm_lds_kernel(const GGParams p) 
 // offsets is not fixed (LDS float atomics), i.e. results may differ in the last bits from run to run.
 // ---------------------------------------------------------------------------------------------
 #define CB_ROWS 256
-template <int NT>
-__global__ __launch_bounds__(256) void gather_gemm_compact_kernel(const GGParams p) {
+template <int NT, int NW>
+__global__ __launch_bounds__(64 * NW) void gather_gemm_compact_kernel(const GGParams p) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     constexpr int CW = 32 * NT;
     float* accL = smem;                                              // [CB_ROWS][CW]
-    int* l_idx = (int*)(accL + CB_ROWS * CW);                        // [4][CB_ROWS]
-    unsigned short* l_row = (unsigned short*)(l_idx + 4 * CB_ROWS);  // [4][CB_ROWS]
+    int* l_idx = (int*)(accL + CB_ROWS * CW);                         // [NW][CB_ROWS]
+    unsigned short* l_row = (unsigned short*)(l_idx + NW * CB_ROWS);  // [NW][CB_ROWS]
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int j = lane & 31, h = lane >> 5;
     const int64_t row_base = (int64_t)blockIdx.x * CB_ROWS;
     const int ncol0 = blockIdx.y * CW;
     const int nchunks = p.Cin >> 5;
-    for (int e = tid; e < CB_ROWS * CW; e += 256) accL[e] = 0.f;
+    for (int e = tid; e < CB_ROWS * CW; e += 64 * NW) accL[e] = 0.f;
     __syncthreads();
     int* my_idx = l_idx + wv * CB_ROWS;
     unsigned short* my_row = l_row + wv * CB_ROWS;
     const uint64_t lt = (1ull << lane) - 1ull;
-    for (int k = wv; k < p.K; k += 4) {
+    for (int k = wv; k < p.K; k += NW) {
         int cnt = 0;
-#pragma unroll
+#pragma unroll 1
         for (int ps = 0; ps < CB_ROWS / 64; ++ps) {
             const int r = ps * 64 + lane;
             const int64_t row = row_base + r;
@@ -405,7 +405,7 @@ __global__ __launch_bounds__(256) void gather_gemm_compact_kernel(const GGParams
                 mma_frag<NT>(acc, cur);
                 if (c + 1 < nchunks) cur = nxt;
             }
-#pragma unroll
+#pragma unroll 4
             for (int r = 0; r < 16; ++r) {
                 const int prow = pc * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
                 if (prow < cnt) {
@@ -418,7 +418,7 @@ __global__ __launch_bounds__(256) void gather_gemm_compact_kernel(const GGParams
         __builtin_amdgcn_wave_barrier();
     }
     __syncthreads();
-    for (int e = tid; e < CB_ROWS * CW; e += 256) {
+    for (int e = tid; e < CB_ROWS * CW; e += 64 * NW) {
         const int r = e / CW, nn = e - r * CW;
         const int64_t rr = row_base + r;
         const int n = ncol0 + nn;
@@ -436,7 +436,8 @@ __global__ __launch_bounds__(256) void gather_gemm_compact_kernel(const GGParams
 // nt == 0           : heuristic (see below)
 // nt == -1          : private-fragment kernel, split-K with one subtile (tests)
 // nt in [-14, -11]  : lock-step LDS-shared-weights kernel with (-nt - 10) subtiles (tests / tuning)
-// nt in [-23, -21]  : pair-compacted kernel with (-nt - 20) subtiles (needs a neighbour table)
+// nt in [-23, -21]  : pair-compacted kernel, 4 waves per workgroup, (-nt - 20) subtiles (needs a neighbour table)
+// nt in [-33, -31]  : pair-compacted kernel, 8 waves per workgroup, (-nt - 30) subtiles
 int launch_gather_gemm(const GGParams& p_in, int nt, hipStream_t st) {
     GGParams p = p_in;
     if (p.M <= 0 || p.Cout <= 0) return SD3D_OK;
@@ -450,26 +451,39 @@ int launch_gather_gemm(const GGParams& p_in, int nt, hipStream_t st) {
     const int64_t tiles = cdiv(p.M, 32);
     int ks = 1;
     bool lds = false;
-    if (nt <= -21 && nt >= -23) {
-        nt = -nt - 20;
+    if ((nt <= -21 && nt >= -23) || (nt <= -31 && nt >= -33)) {
+        const int nw = nt <= -31 ? 8 : 4;
+        nt = nt <= -31 ? -nt - 30 : -nt - 20;
         if (!p.nbr) return sd3d_set_error(SD3D_ERR_ARG, "gather_gemm: the compacted kernel needs a neighbour table");
         p.col_groups = (int)cdiv(p.Cout, 32 * nt);
         const dim3 grid((unsigned)cdiv(p.M, CB_ROWS), (unsigned)p.col_groups);
-        const size_t sm = (size_t)CB_ROWS * 32 * nt * sizeof(float) + 4 * CB_ROWS * (sizeof(int) + sizeof(unsigned short));
-        switch (nt) {
-            case 1: hipLaunchKernelGGL(gather_gemm_compact_kernel<1>, grid, dim3(256), sm, st, p); break;
-            case 2: hipLaunchKernelGGL(gather_gemm_compact_kernel<2>, grid, dim3(256), sm, st, p); break;
-            case 3: {
-                static bool attr_set = false;
-                if (!attr_set) {
-                    (void)hipFuncSetAttribute((const void*)gather_gemm_compact_kernel<3>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm);
-                    attr_set = true;
-                }
-                hipLaunchKernelGGL(gather_gemm_compact_kernel<3>, grid, dim3(256), sm, st, p);
-                break;
+        const size_t sm = (size_t)CB_ROWS * 32 * nt * sizeof(float) + (size_t)nw * CB_ROWS * (sizeof(int) + sizeof(unsigned short));
+#define GC_LAUNCH(NT_, NW_)                                                                                              \
+    do {                                                                                                                 \
+        static bool attr_set = false;                                                                                    \
+        if (!attr_set && sm > 65536) {                                                                                   \
+            (void)hipFuncSetAttribute((const void*)gather_gemm_compact_kernel<NT_, NW_>,                                 \
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm);                              \
+            attr_set = true;                                                                                             \
+        }                                                                                                                \
+        hipLaunchKernelGGL((gather_gemm_compact_kernel<NT_, NW_>), grid, dim3(64 * NW_), sm, st, p);                     \
+    } while (0)
+        if (nw == 4) {
+            switch (nt) {
+                case 1: GC_LAUNCH(1, 4); break;
+                case 2: GC_LAUNCH(2, 4); break;
+                case 3: GC_LAUNCH(3, 4); break;
+                default: return sd3d_set_error(SD3D_ERR_ARG, "gather_gemm: compact nt must be 1..3");
             }
-            default: return sd3d_set_error(SD3D_ERR_ARG, "gather_gemm: compact nt must be 1..3");
+        } else {
+            switch (nt) {
+                case 1: GC_LAUNCH(1, 8); break;
+                case 2: GC_LAUNCH(2, 8); break;
+                case 3: GC_LAUNCH(3, 8); break;
+                default: return sd3d_set_error(SD3D_ERR_ARG, "gather_gemm: compact nt must be 1..3");
+            }
         }
+#undef GC_LAUNCH
         SD3D_CHECK_LAUNCH();
         return SD3D_OK;
     } else if (nt <= -11 && nt >= -14) {

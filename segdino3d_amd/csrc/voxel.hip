@@ -273,9 +273,12 @@ int launch_hash_build(const uint64_t* ukeys, int64_t n, uint64_t* tkeys, int32_t
 __global__ __launch_bounds__(256) void kernel_map_kernel(const uint64_t* __restrict__ okeys, int64_t n_out,
                                                          const uint64_t* __restrict__ tkeys, const int32_t* __restrict__ tvals,
                                                          uint32_t mask, const int8_t* __restrict__ offs, int K,
-                                                         int32_t* __restrict__ nbr) {
+                                                         int32_t* __restrict__ nbr, int32_t* __restrict__ pair_count) {
     const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    if (t >= (int64_t)K * n_out) return;
+    if (t >= (int64_t)K * n_out) {
+        (void)__ballot(false);
+        return;
+    }
     const int k = (int)(t / n_out);
     const int64_t v = t - (int64_t)k * n_out;
     const uint64_t key = okeys[v];
@@ -288,14 +291,18 @@ __global__ __launch_bounds__(256) void kernel_map_kernel(const uint64_t* __restr
         id = hash_lookup(tkeys, tvals, mask, q);
     }
     nbr[t] = id;
+    if (pair_count) {                      // rulebook size = number of (in, out, offset) pairs: one atomic per wave
+        const int c = __popcll(__ballot(id >= 0));
+        if ((threadIdx.x & 63) == __ffsll((long long)__ballot(true)) - 1 && c) atomicAdd(pair_count, c);
+    }
 }
 
 int launch_kernel_map(const uint64_t* okeys, int64_t n_out, const uint64_t* tkeys, const int32_t* tvals, int64_t capacity,
-                      const int8_t* offs_dev, int K, int32_t* nbr, hipStream_t st) {
+                      const int8_t* offs_dev, int K, int32_t* nbr, int32_t* pair_count, hipStream_t st) {
     if (n_out <= 0 || K <= 0) return SD3D_OK;
     const int64_t total = (int64_t)K * n_out;
     hipLaunchKernelGGL(kernel_map_kernel, dim3((unsigned)cdiv(total, 256)), dim3(256), 0, st, okeys, n_out, tkeys, tvals,
-                       (uint32_t)(capacity - 1), offs_dev, K, nbr);
+                       (uint32_t)(capacity - 1), offs_dev, K, nbr, pair_count);
     SD3D_CHECK_LAUNCH();
     return SD3D_OK;
 }

@@ -167,14 +167,16 @@ def hash_build(ukeys: torch.Tensor, n: int):
     return tk, tv
 
 
-def kernel_map(out_keys, n_out, table, offsets_i8):
-    """offsets_i8: int8 [K,3] device tensor.  Returns nbr int32 [K, n_out]."""
+def kernel_map(out_keys, n_out, table, offsets_i8, pair_count=None):
+    """offsets_i8: int8 [K,3] device tensor.  Returns nbr int32 [K, n_out].  pair_count: optional int32 [1]
+    device counter (pre-zeroed) that receives the rulebook size."""
     lib = _lib.load()
     tk, tv = table
     K = offsets_i8.shape[0]
     nbr = torch.empty(K, n_out, dtype=torch.int32, device=out_keys.device)
     _lib.check(lib.sd3d_kernel_map(_ptr(out_keys, torch.int64, "out_keys"), n_out, _ptr(tk), _ptr(tv), tk.numel(),
-                                   _ptr(offsets_i8, torch.int8, "offsets"), K, _ptr(nbr), _stream()), "kernel_map")
+                                   _ptr(offsets_i8, torch.int8, "offsets"), K, _ptr(nbr),
+                                   _ptr(pair_count, torch.int32, "pair_count"), _stream()), "kernel_map")
     return nbr
 
 
@@ -224,7 +226,11 @@ def pool_superpoints(feat, C, inverse, icoords, voxel_size, sorted_idx, start, S
 # --------------------------------------------------------------------------------------------
 # gather-GEMM
 # --------------------------------------------------------------------------------------------
-def gather_gemm(x, wt, nbr=None, x2=None, scale=None, shift=None, res=None, act=None, out=None, M=None, nt=0):
+COMPACT_DENSITY = 0.2      # pairs / (K * M) below which the pair-compacted kernel wins (tools/bench_gg.py)
+
+
+def gather_gemm(x, wt, nbr=None, x2=None, scale=None, shift=None, res=None, act=None, out=None, M=None, nt=0,
+                density=None):
     """out[r, n] = act(scale[n] * sum_k sum_c X[nbr[k, r], c] * wt[k, n, c] + shift[n] + res[r, n]).
 
     x [V_in, C0] (rows may be strided), optional x2 [V_in, C1] = concatenated channels,
@@ -252,6 +258,8 @@ def gather_gemm(x, wt, nbr=None, x2=None, scale=None, shift=None, res=None, act=
     pr, ldr = (None, 0)
     if res is not None:
         pr, ldr = _rows(res, "res")
+    if nt == 0 and density is not None and nbr is not None and density < COMPACT_DENSITY and GG_FORCE_NT is None:
+        nt = -21                                   # pair-compacted kernel, one 32-column subtile per pass
     if GG_FORCE_NT is not None and nt == 0:
         sub = (Cout + 31) // 32
         eff = GG_FORCE_NT if GG_FORCE_NT > 0 else (-GG_FORCE_NT - 10 if GG_FORCE_NT <= -11 else 1)

@@ -107,6 +107,26 @@ class SceneMaps:
         self._stride: Dict[int, Tuple[torch.Tensor, torch.Tensor]] = {}
         self._perm8 = torch.from_numpy(child_perm(order)).to(self.device)
         self._sp_start = None
+        self.density: Dict[Tuple, float] = {}
+
+    def prepare(self, same=(), strides=()):
+        """Build the listed neighbour tables now and read their rulebook sizes back in ONE copy (the
+        second and last synchronisation of a scene): density[key] = pairs / (K * V_out) lets the host
+        pick the pair-compacted convolution kernel for sparse maps.  same: [(level, ksize)], strides: [level]."""
+        counters = torch.zeros(len(same), dtype=torch.int32, device=self.device)
+        for i, (lvl, k) in enumerate(same):
+            if (lvl, k) not in self._same:
+                offs = offsets_device(k, self.order, self.device)
+                self._same[(lvl, k)] = ops.kernel_map(self.keys[lvl], self.n_vox[lvl], self.table(lvl), offs, counters[i:i + 1])
+        for lvl in strides:
+            self._stride_maps(lvl)
+        host = counters.cpu().tolist()
+        for (lvl, k), c in zip(same, host):
+            self.density[("same", lvl, k)] = c / max(1, k ** 3 * self.n_vox[lvl])
+        for lvl in strides:
+            # every fine voxel has exactly one parent: P = V_fine pairs in both directions
+            self.density[("down", lvl)] = self.n_vox[lvl] / max(1, 8 * self.n_vox[lvl + 1])
+            self.density[("up", lvl)] = 1.0 / 8.0
 
     # ------------------------------------------------------------------------------------------
     def table(self, level: int):

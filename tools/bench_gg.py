@@ -54,7 +54,7 @@ def main():
         ("down k2 32->32 L0->1", 0, ("down",), 32, 32),
         ("up k2 96->96 L1->0", 0, ("up",), 96, 96),
     ]
-    variants = [0, 1, 3, -11, -12, -13, -21, -22, -23]
+    variants = [0, -11, -13, -21, -22, -23, -31, -32, -33]
     for name, lvl, kind, cin, cout in shapes:
         if kind[0] == "same":
             nbr = maps.same(lvl, kind[1]); vin = maps.n_vox[lvl]
@@ -70,7 +70,7 @@ def main():
         row = []
         for nt in variants:
             sub = (cout + 31) // 32
-            eff = nt if nt > 0 else (-nt - 20 if nt <= -21 else (-nt - 10 if nt <= -11 else None))
+            eff = nt if nt > 0 else (-nt - 30 if nt <= -31 else (-nt - 20 if nt <= -21 else (-nt - 10 if nt <= -11 else None)))
             if eff is not None and (eff > sub or sub % eff):
                 row.append("   -   ")
                 continue
