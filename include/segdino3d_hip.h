@@ -79,8 +79,9 @@ int sd3d_unique_sorted(const uint64_t* keys, const uint32_t* src_idx, int64_t n_
 int sd3d_hash_build(const uint64_t* ukeys, int64_t n, uint64_t* table_keys, int32_t* table_vals, int64_t capacity,
                     void* stream);
 /* nbr[k*n_out + v] = id of the voxel at coord(v) + offsets[k] in the hashed level, or -1.
- * offsets: int8 [K,3] in units of that level's stride.  pair_count (optional, device, pre-zeroed)
- * accumulates the rulebook size (number of hits) - the host uses it to pick the convolution kernel. */
+ * offsets: int8 [K,3] in units of that level's stride.  pair_count (optional, device int32[64],
+ * pre-zeroed) accumulates the rulebook size (number of hits) as 64 partial sums - the host adds them
+ * and uses the density to pick the convolution kernel. */
 int sd3d_kernel_map(const uint64_t* out_keys, int64_t n_out, const uint64_t* table_keys, const int32_t* table_vals,
                     int64_t capacity, const int8_t* offsets, int K, int32_t* nbr, int32_t* pair_count, void* stream);
 /* 2x2x2 stride-2 maps from the parent array: nbr_down [8, n_coarse], nbr_up [8, n_fine]; perm8[8]

@@ -496,7 +496,8 @@ int launch_gather_gemm(const GGParams& p_in, int nt, hipStream_t st) {
             // enough rows for 4-tile workgroups: share the weights through LDS
             lds = true;
             nt = sub >= 4 ? 4 : sub;
-            while (nt > 1 && cdiv(tiles, 4) * cdiv(sub, nt) < 512) --nt;
+            while (nt > 2 && cdiv(tiles, 4) * cdiv(sub, nt) < 256) --nt;
+            if (nt == 2 && cdiv(tiles, 4) * cdiv(sub, 2) < 192) nt = 1;
             if (sub % nt) { for (int c = nt; c >= 1; --c) if (sub % c == 0) { nt = c; break; } }
         } else {
             nt = sub >= 4 ? 4 : sub;

@@ -274,26 +274,32 @@ __global__ __launch_bounds__(256) void kernel_map_kernel(const uint64_t* __restr
                                                          const uint64_t* __restrict__ tkeys, const int32_t* __restrict__ tvals,
                                                          uint32_t mask, const int8_t* __restrict__ offs, int K,
                                                          int32_t* __restrict__ nbr, int32_t* __restrict__ pair_count) {
+    __shared__ int wsum[4];
     const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    if (t >= (int64_t)K * n_out) {
-        (void)__ballot(false);
-        return;
-    }
-    const int k = (int)(t / n_out);
-    const int64_t v = t - (int64_t)k * n_out;
-    const uint64_t key = okeys[v];
-    uint32_t x, y, z;
-    morton_decode(key & SD3D_MORTON_MASK, x, y, z);
-    const int nx = (int)x + offs[k * 3 + 0], ny = (int)y + offs[k * 3 + 1], nz = (int)z + offs[k * 3 + 2];
     int id = -1;
-    if (((nx | ny | nz) >= 0) && nx < 65536 && ny < 65536 && nz < 65536) {
-        const uint64_t q = morton_encode((uint32_t)nx, (uint32_t)ny, (uint32_t)nz) | (key & ~SD3D_MORTON_MASK);
-        id = hash_lookup(tkeys, tvals, mask, q);
+    if (t < (int64_t)K * n_out) {
+        const int k = (int)(t / n_out);
+        const int64_t v = t - (int64_t)k * n_out;
+        const uint64_t key = okeys[v];
+        uint32_t x, y, z;
+        morton_decode(key & SD3D_MORTON_MASK, x, y, z);
+        const int nx = (int)x + offs[k * 3 + 0], ny = (int)y + offs[k * 3 + 1], nz = (int)z + offs[k * 3 + 2];
+        if (((nx | ny | nz) >= 0) && nx < 65536 && ny < 65536 && nz < 65536) {
+            const uint64_t q = morton_encode((uint32_t)nx, (uint32_t)ny, (uint32_t)nz) | (key & ~SD3D_MORTON_MASK);
+            id = hash_lookup(tkeys, tvals, mask, q);
+        }
+        nbr[t] = id;
     }
-    nbr[t] = id;
-    if (pair_count) {                      // rulebook size = number of (in, out, offset) pairs: one atomic per wave
+    if (pair_count) {
+        // rulebook size = number of (in, out, offset) pairs.  One atomic per WORKGROUP, spread over 64
+        // counter words (a single word saturates at ~90 atomics/us; the host sums the 64 partials).
         const int c = __popcll(__ballot(id >= 0));
-        if ((threadIdx.x & 63) == __ffsll((long long)__ballot(true)) - 1 && c) atomicAdd(pair_count, c);
+        if ((threadIdx.x & 63) == 0) wsum[threadIdx.x >> 6] = c;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            const int tot = wsum[0] + wsum[1] + wsum[2] + wsum[3];
+            if (tot) atomicAdd(&pair_count[blockIdx.x & 63], tot);
+        }
     }
 }
 

@@ -168,8 +168,8 @@ def hash_build(ukeys: torch.Tensor, n: int):
 
 
 def kernel_map(out_keys, n_out, table, offsets_i8, pair_count=None):
-    """offsets_i8: int8 [K,3] device tensor.  Returns nbr int32 [K, n_out].  pair_count: optional int32 [1]
-    device counter (pre-zeroed) that receives the rulebook size."""
+    """offsets_i8: int8 [K,3] device tensor.  Returns nbr int32 [K, n_out].  pair_count: optional int32 [64]
+    device counters (pre-zeroed) whose sum is the rulebook size."""
     lib = _lib.load()
     tk, tv = table
     K = offsets_i8.shape[0]
