@@ -374,17 +374,22 @@ __global__ __launch_bounds__(64 * NW) void gather_gemm_compact_kernel(const GGPa
     unsigned short* my_row = l_row + wv * CB_ROWS;
     const uint64_t lt = (1ull << lane) - 1ull;
     for (int k = wv; k < p.K; k += NW) {
-        int cnt = 0;
-#pragma unroll 1
+        // all four 64-row slices of the neighbour column are requested before the first ballot, so the
+        // list costs one memory round trip instead of four
+        int ids[CB_ROWS / 64];
+#pragma unroll
         for (int ps = 0; ps < CB_ROWS / 64; ++ps) {
-            const int r = ps * 64 + lane;
-            const int64_t row = row_base + r;
-            const int id = (row < p.M) ? p.nbr[(int64_t)k * p.M + row] : -1;
-            const uint64_t bal = __ballot(id >= 0);
-            if (id >= 0) {
+            const int64_t row = row_base + ps * 64 + lane;
+            ids[ps] = (row < p.M) ? p.nbr[(int64_t)k * p.M + row] : -1;
+        }
+        int cnt = 0;
+#pragma unroll
+        for (int ps = 0; ps < CB_ROWS / 64; ++ps) {
+            const uint64_t bal = __ballot(ids[ps] >= 0);
+            if (ids[ps] >= 0) {
                 const int pos = cnt + __popcll(bal & lt);
-                my_idx[pos] = id;
-                my_row[pos] = (unsigned short)r;
+                my_idx[pos] = ids[ps];
+                my_row[pos] = (unsigned short)(ps * 64 + lane);
             }
             cnt += __popcll(bal);
         }

@@ -113,14 +113,14 @@ class SceneMaps:
         """Build the listed neighbour tables now and read their rulebook sizes back in ONE copy (the
         second and last synchronisation of a scene): density[key] = pairs / (K * V_out) lets the host
         pick the pair-compacted convolution kernel for sparse maps.  same: [(level, ksize)], strides: [level]."""
-        counters = torch.zeros(len(same), 64, dtype=torch.int32, device=self.device)
+        same = [(lvl, k) for (lvl, k) in same if ("same", lvl, k) not in self.density]
+        counters = torch.zeros(max(1, len(same)), 64, dtype=torch.int32, device=self.device)
         for i, (lvl, k) in enumerate(same):
-            if (lvl, k) not in self._same:
-                offs = offsets_device(k, self.order, self.device)
-                self._same[(lvl, k)] = ops.kernel_map(self.keys[lvl], self.n_vox[lvl], self.table(lvl), offs, counters[i])
+            offs = offsets_device(k, self.order, self.device)
+            self._same[(lvl, k)] = ops.kernel_map(self.keys[lvl], self.n_vox[lvl], self.table(lvl), offs, counters[i])
         for lvl in strides:
             self._stride_maps(lvl)
-        host = counters.cpu().sum(dim=1).tolist()
+        host = counters.cpu().sum(dim=1).tolist() if same else []
         for (lvl, k), c in zip(same, host):
             self.density[("same", lvl, k)] = c / max(1, k ** 3 * self.n_vox[lvl])
         for lvl in strides:
