@@ -109,11 +109,12 @@ int sd3d_pool_superpoints(const float* feat, int ld_feat, int C, const int32_t* 
  * (spconvunet.py:45-74, 156-201) and torch.nn.functional.linear in the decoder.
  *   in0 [*, ld0] first C0 channels, in1 [*, ld1] the remaining Cin - C0 (skip concatenation, or NULL)
  *   nbr  [K, M] or NULL (identity rows, K == 1);  wt [K, Cout, Cin] (Cin % 32 == 0)
- *   act: 0 none, 1 ReLU, 2 GELU(erf), 3 sigmoid;  nt: 32-column subtiles per wave (0 = auto)
+ *   act: 0 none, 1 ReLU, 2 GELU(erf), 3 sigmoid;  nt: tiling code (0 = auto, see csrc/gather_gemm.hip)
+ *   ws / ws_bytes: optional scratch (>= 8 * M * Cout floats enables split-K on small launches)
  * ------------------------------------------------------------------------------------------- */
 int sd3d_gather_gemm(const float* in0, int ld0, int C0, const float* in1, int ld1, const int32_t* nbr, const float* wt,
                      int K, int Cin, int Cout, int64_t M, const float* scale, const float* shift, const float* res,
-                     int ld_res, float* out, int ld_out, int act, int nt, void* stream);
+                     int ld_res, float* out, int ld_out, int act, int nt, void* ws, size_t ws_bytes, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Decoder kernels (segdino3d/models/decoder/instance_seg_3d_decoder.py:606-799,

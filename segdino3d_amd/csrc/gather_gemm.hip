@@ -33,6 +33,8 @@ struct GGParams {
     float* out; int ld_out;
     int act;                                  // 0 none, 1 relu, 2 gelu(erf), 3 sigmoid
     int col_groups;                           // ceil(Cout / (32*NT))
+    int ksplit;                               // lock-step kernel only: gridDim.z offset slices (partials -> ws)
+    float* ws;                                // [ksplit][M][Cout] partial sums when ksplit > 1
 };
 
 template <int NT>
@@ -233,8 +235,13 @@ __global__ __launch_bounds__(256) void gather_gemm_lds_kernel(const GGParams p) 
     }
     if (lane == 0) { wmask[wv][0] = m0; wmask[wv][1] = m1; }
     __syncthreads();
-    const uint64_t b0 = wmask[0][0] | wmask[1][0] | wmask[2][0] | wmask[3][0];
-    const uint64_t b1 = wmask[0][1] | wmask[1][1] | wmask[2][1] | wmask[3][1];
+    uint64_t b0 = wmask[0][0] | wmask[1][0] | wmask[2][0] | wmask[3][0];
+    uint64_t b1 = wmask[0][1] | wmask[1][1] | wmask[2][1] | wmask[3][1];
+    if (p.ksplit > 1) {            // this workgroup only walks the offsets k with k % ksplit == blockIdx.z
+        uint64_t s0 = 0, s1 = 0;
+        for (int k = blockIdx.z; k < p.K; k += p.ksplit) { if (k < 64) s0 |= 1ull << k; else s1 |= 1ull << (k - 64); }
+        b0 &= s0; b1 &= s1;
+    }
 
     f32x16 acc[NT];
 #pragma unroll
@@ -323,6 +330,20 @@ __global__ __launch_bounds__(256) void gather_gemm_lds_kernel(const GGParams p) 
         }
     }
     if (row0 >= p.M) return;
+    if (p.ksplit > 1) {            // raw partial sums; splitk_epilogue_kernel reduces them in slice order
+        float* wsz = p.ws + (int64_t)blockIdx.z * p.M * p.Cout;
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+            const int n = ncol0 + t * 32 + j;
+            if (n >= p.Cout) continue;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int64_t rr = row0 + (r & 3) + 8 * (r >> 2) + 4 * h;
+                if (rr < p.M) wsz[rr * p.Cout + n] = acc[t][r];
+            }
+        }
+        return;
+    }
 #pragma unroll
     for (int t = 0; t < NT; ++t) {
         const int n = ncol0 + t * 32 + j;
@@ -341,6 +362,22 @@ __global__ __launch_bounds__(256) void gather_gemm_lds_kernel(const GGParams p) 
             p.out[rr * p.ld_out + n] = y;
         }
     }
+}
+
+// out = act(scale * sum_z ws[z] + shift + res): fixed-order reduction of the split-K partials.
+__global__ __launch_bounds__(256) void splitk_epilogue_kernel(const GGParams p) {
+    const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (e >= p.M * p.Cout) return;
+    const int64_t rr = e / p.Cout;
+    const int n = (int)(e - rr * p.Cout);
+    float a = 0.f;
+    for (int z = 0; z < p.ksplit; ++z) a += p.ws[(int64_t)z * p.M * p.Cout + e];
+    float y = a * (p.scale ? p.scale[n] : 1.f) + (p.shift ? p.shift[n] : 0.f);
+    if (p.res) y += p.res[rr * p.ld_res + n];
+    if (p.act == 1) y = fmaxf(y, 0.f);
+    else if (p.act == 2) y = 0.5f * y * (1.f + erff(y * 0.70710678118654752440f));
+    else if (p.act == 3) y = 1.f / (1.f + expf(-y));
+    p.out[rr * p.ld_out + n] = y;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -443,8 +480,10 @@ __global__ __launch_bounds__(64 * NW) void gather_gemm_compact_kernel(const GGPa
 // nt in [-14, -11]  : lock-step LDS-shared-weights kernel with (-nt - 10) subtiles (tests / tuning)
 // nt in [-23, -21]  : pair-compacted kernel, 4 waves per workgroup, (-nt - 20) subtiles (needs a neighbour table)
 // nt in [-33, -31]  : pair-compacted kernel, 8 waves per workgroup, (-nt - 30) subtiles
-int launch_gather_gemm(const GGParams& p_in, int nt, hipStream_t st) {
+int launch_gather_gemm(const GGParams& p_in, int nt, void* ws, size_t ws_bytes, hipStream_t st) {
     GGParams p = p_in;
+    p.ksplit = 1;
+    p.ws = nullptr;
     if (p.M <= 0 || p.Cout <= 0) return SD3D_OK;
     if (p.Cin <= 0 || (p.Cin & 31)) return sd3d_set_error(SD3D_ERR_ARG, "gather_gemm: Cin must be a positive multiple of 32");
     if (p.in1 && ((p.C0 & 31) || p.C0 > p.Cin)) return sd3d_set_error(SD3D_ERR_ARG, "gather_gemm: concat split must be a multiple of 32");
@@ -516,7 +555,13 @@ int launch_gather_gemm(const GGParams& p_in, int nt, hipStream_t st) {
     p.col_groups = (int)cdiv(p.Cout, 32 * nt);
     const dim3 block(256);
     if (lds) {
-        const dim3 grid((unsigned)cdiv(tiles, 4), (unsigned)p.col_groups);
+        // few workgroups + many offsets (coarse U-Net levels): slice the offsets over gridDim.z
+        const int64_t wgs = cdiv(tiles, 4) * p.col_groups;
+        if (p.nbr && p.K >= 8 && wgs < 384) {
+            int ksp = wgs < 96 ? 8 : (wgs < 256 ? 4 : 2);
+            if ((size_t)ksp * p.M * p.Cout * sizeof(float) <= ws_bytes && ws) { p.ksplit = ksp; p.ws = (float*)ws; }
+        }
+        const dim3 grid((unsigned)cdiv(tiles, 4), (unsigned)p.col_groups, (unsigned)p.ksplit);
         switch (nt) {
             case 1: hipLaunchKernelGGL(gather_gemm_lds_kernel<1>, grid, block, 0, st, p); break;
             case 2: hipLaunchKernelGGL(gather_gemm_lds_kernel<2>, grid, block, 0, st, p); break;
@@ -524,6 +569,8 @@ int launch_gather_gemm(const GGParams& p_in, int nt, hipStream_t st) {
             case 4: hipLaunchKernelGGL(gather_gemm_lds_kernel<4>, grid, block, 0, st, p); break;
             default: return sd3d_set_error(SD3D_ERR_ARG, "gather_gemm: nt must be 1..4");
         }
+        if (p.ksplit > 1)
+            hipLaunchKernelGGL(splitk_epilogue_kernel, dim3((unsigned)cdiv(p.M * p.Cout, 256)), dim3(256), 0, st, p);
         SD3D_CHECK_LAUNCH();
         return SD3D_OK;
     }

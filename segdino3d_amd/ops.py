@@ -61,6 +61,7 @@ class Workspace:
 
 
 _WS = Workspace()
+_WS2 = Workspace()       # split-K partial sums of gather_gemm
 
 
 # --------------------------------------------------------------------------------------------
@@ -268,10 +269,14 @@ def gather_gemm(x, wt, nbr=None, x2=None, scale=None, shift=None, res=None, act=
     hook = GG_HOOK
     if hook is not None:
         hook.before(dict(K=K, Cin=Cin, Cout=Cout, M=M, nbr=nbr))
+    ws_ptr, ws_n = None, 0
+    if nbr is not None and K >= 8 and M * Cout <= (1 << 22):      # small launch: allow split-K partials
+        ws = _WS2.get(8 * M * Cout * 4, x.device)
+        ws_ptr, ws_n = ws.data_ptr(), ws.numel()
     _lib.check(lib.sd3d_gather_gemm(p0, ld0, C0, p1, ld1, _ptr(nbr, torch.int32, "nbr"), _ptr(wt, torch.float32, "wt"),
                                     K, Cin, Cout, M, _ptr(scale, torch.float32, "scale"),
-                                    _ptr(shift, torch.float32, "shift"), pr, ldr, po, ldo, ACT[act], nt, _stream()),
-               "gather_gemm")
+                                    _ptr(shift, torch.float32, "shift"), pr, ldr, po, ldo, ACT[act], nt, ws_ptr, ws_n,
+                                    _stream()), "gather_gemm")
     if hook is not None:
         hook.after()
     return out
