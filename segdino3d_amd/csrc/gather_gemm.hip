@@ -474,12 +474,144 @@ __global__ __launch_bounds__(64 * NW) void gather_gemm_compact_kernel(const GGPa
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// Pair-compacted kernel, single pass over ALL output columns (Cout = 32*NT <= 128): the gathered
+// input rows - the dominant memory traffic of a sparse convolution (4*P*Cin bytes) - are read once
+// instead of once per 32-column group.  ROWS output rows per workgroup are accumulated in LDS
+// ([ROWS][32*NT] fp32: 48 KB for 128 x 96).  Per pair-chunk the A fragment of a 32-channel chunk is
+// loaded once and reused for the NT weight subtiles; B fragments are streamed per (chunk, subtile)
+// step with one-step prefetch, which keeps the kernel at ~130 VGPRs.
+// ---------------------------------------------------------------------------------------------
+template <int NT, int ROWS>
+__global__ __launch_bounds__(256) void gather_gemm_compact2_kernel(const GGParams p) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    constexpr int CW = 32 * NT;
+    float* accL = smem;                                               // [ROWS][CW]
+    int* l_idx = (int*)(accL + ROWS * CW);                            // [4][ROWS]
+    unsigned short* l_row = (unsigned short*)(l_idx + 4 * ROWS);      // [4][ROWS]
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int j = lane & 31, h = lane >> 5;
+    const int64_t row_base = (int64_t)blockIdx.x * ROWS;
+    const int nchunks = p.Cin >> 5;
+    for (int e = tid; e < ROWS * CW; e += 256) accL[e] = 0.f;
+    __syncthreads();
+    int* my_idx = l_idx + wv * ROWS;
+    unsigned short* my_row = l_row + wv * ROWS;
+    const uint64_t lt = (1ull << lane) - 1ull;
+    for (int k = wv; k < p.K; k += 4) {
+        int ids[ROWS / 64];
+#pragma unroll
+        for (int ps = 0; ps < ROWS / 64; ++ps) {
+            const int64_t row = row_base + ps * 64 + lane;
+            ids[ps] = (row < p.M) ? p.nbr[(int64_t)k * p.M + row] : -1;
+        }
+        int cnt = 0;
+#pragma unroll
+        for (int ps = 0; ps < ROWS / 64; ++ps) {
+            const uint64_t bal = __ballot(ids[ps] >= 0);
+            if (ids[ps] >= 0) {
+                const int pos = cnt + __popcll(bal & lt);
+                my_idx[pos] = ids[ps];
+                my_row[pos] = (unsigned short)(ps * 64 + lane);
+            }
+            cnt += __popcll(bal);
+        }
+        __builtin_amdgcn_wave_barrier();
+        for (int pc = 0; pc * 32 < cnt; ++pc) {
+            const int pp = pc * 32 + j;
+            const int pidx = pp < cnt ? my_idx[pp] : -1;
+            f32x16 acc[NT];
+#pragma unroll
+            for (int t = 0; t < NT; ++t)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+            auto load_a = [&](f32x4 (&a)[4], int chunk) {
+                const int c = chunk * 32 + h * 16;
+                if (pidx >= 0) {
+                    const float* src = (c < p.C0) ? (p.in0 + (int64_t)pidx * p.ld0 + c) : (p.in1 + (int64_t)pidx * p.ld1 + (c - p.C0));
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) a[q] = *(const f32x4*)(src + q * 4);
+                } else {
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) a[q] = f32x4{0.f, 0.f, 0.f, 0.f};
+                }
+            };
+            auto load_b = [&](f32x4 (&b)[4], int chunk, int t) {
+                int n = t * 32 + j;
+                n = n < p.Cout ? n : p.Cout - 1;
+                const float* w = p.wt + ((int64_t)k * p.Cout + n) * p.Cin + chunk * 32 + h * 16;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) b[q] = *(const f32x4*)(w + q * 4);
+            };
+            f32x4 acur[4], anxt[4], bcur[4], bnxt[4];
+            load_a(acur, 0);
+            load_b(bcur, 0, 0);
+            for (int c = 0; c < nchunks; ++c) {
+                if (c + 1 < nchunks) load_a(anxt, c + 1);
+#pragma unroll
+                for (int t = 0; t < NT; ++t) {
+                    const bool last = (t == NT - 1) && (c + 1 == nchunks);
+                    if (!last) load_b(bnxt, (t == NT - 1) ? c + 1 : c, (t == NT - 1) ? 0 : t + 1);
+#pragma unroll
+                    for (int q = 0; q < 4; ++q)
+#pragma unroll
+                        for (int e = 0; e < 4; ++e)
+                            acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(acur[q][e], bcur[q][e], acc[t], 0, 0, 0);
+                    if (!last) {
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) bcur[q] = bnxt[q];
+                    }
+                }
+                if (c + 1 < nchunks) {
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) acur[q] = anxt[q];
+                }
+            }
+#pragma unroll 4
+            for (int r = 0; r < 16; ++r) {
+                const int prow = pc * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+                if (prow < cnt) {
+                    const int orow = my_row[prow];
+#pragma unroll
+                    for (int t = 0; t < NT; ++t) atomicAdd(&accL[orow * CW + t * 32 + j], acc[t][r]);
+                }
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
+    __syncthreads();
+    for (int e = tid; e < ROWS * CW; e += 256) {
+        const int r = e / CW, n = e - r * CW;
+        const int64_t rr = row_base + r;
+        if (rr >= p.M || n >= p.Cout) continue;
+        float y = accL[e] * (p.scale ? p.scale[n] : 1.f) + (p.shift ? p.shift[n] : 0.f);
+        if (p.res) y += p.res[rr * p.ld_res + n];
+        if (p.act == 1) y = fmaxf(y, 0.f);
+        else if (p.act == 2) y = 0.5f * y * (1.f + erff(y * 0.70710678118654752440f));
+        else if (p.act == 3) y = 1.f / (1.f + expf(-y));
+        p.out[rr * p.ld_out + n] = y;
+    }
+}
+
+template <int NT, int ROWS>
+static int launch_compact2(const GGParams& p, hipStream_t st) {
+    const size_t sm = (size_t)ROWS * 32 * NT * sizeof(float) + 4 * ROWS * (sizeof(int) + sizeof(unsigned short));
+    static bool attr_set = false;
+    if (!attr_set && sm > 65536) {
+        (void)hipFuncSetAttribute((const void*)gather_gemm_compact2_kernel<NT, ROWS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm);
+        attr_set = true;
+    }
+    hipLaunchKernelGGL((gather_gemm_compact2_kernel<NT, ROWS>), dim3((unsigned)cdiv(p.M, ROWS)), dim3(256), sm, st, p);
+    return 0;
+}
+
 // nt > 0            : private-fragment kernel, nt subtiles per wave, no split-K
 // nt == 0           : heuristic (see below)
 // nt == -1          : private-fragment kernel, split-K with one subtile (tests)
 // nt in [-14, -11]  : lock-step LDS-shared-weights kernel with (-nt - 10) subtiles (tests / tuning)
 // nt in [-23, -21]  : pair-compacted kernel, 4 waves per workgroup, (-nt - 20) subtiles (needs a neighbour table)
 // nt in [-33, -31]  : pair-compacted kernel, 8 waves per workgroup, (-nt - 30) subtiles
+// nt == -41 / -42    : single-pass pair-compacted kernel over all Cout <= 128 columns, 128 / 256 rows per workgroup
 int launch_gather_gemm(const GGParams& p_in, int nt, void* ws, size_t ws_bytes, hipStream_t st) {
     GGParams p = p_in;
     p.ksplit = 1;
@@ -495,6 +627,29 @@ int launch_gather_gemm(const GGParams& p_in, int nt, void* ws, size_t ws_bytes, 
     const int64_t tiles = cdiv(p.M, 32);
     int ks = 1;
     bool lds = false;
+    if (nt == -41 || nt == -42) {
+        if (!p.nbr) return sd3d_set_error(SD3D_ERR_ARG, "gather_gemm: the compacted kernel needs a neighbour table");
+        if (p.Cout > 128) return sd3d_set_error(SD3D_ERR_ARG, "gather_gemm: single-pass compacted kernel needs Cout <= 128");
+        const int ntc = (p.Cout + 31) / 32;
+        p.col_groups = 1;
+        if (nt == -41) {
+            switch (ntc) {
+                case 1: launch_compact2<1, 128>(p, st); break;
+                case 2: launch_compact2<2, 128>(p, st); break;
+                case 3: launch_compact2<3, 128>(p, st); break;
+                default: launch_compact2<4, 128>(p, st); break;
+            }
+        } else {
+            switch (ntc) {
+                case 1: launch_compact2<1, 256>(p, st); break;
+                case 2: launch_compact2<2, 256>(p, st); break;
+                case 3: launch_compact2<3, 256>(p, st); break;
+                default: launch_compact2<4, 256>(p, st); break;
+            }
+        }
+        SD3D_CHECK_LAUNCH();
+        return SD3D_OK;
+    }
     if ((nt <= -21 && nt >= -23) || (nt <= -31 && nt >= -33)) {
         const int nw = nt <= -31 ? 8 : 4;
         nt = nt <= -31 ? -nt - 30 : -nt - 20;
