@@ -84,7 +84,9 @@ def cpu_baseline(model, scene_args, n_timed=2):
     """Oracle (CPU restatement) timed on the host cores with the SAME weights and scene shape."""
     from oracle import model_ref
     sd = {k: v.detach().cpu() for k, v in model.state_dict().items()}
-    threads = torch.get_num_threads()
+    # the oracle's many small ops oversubscribe a 128-core host; 32 threads is its best setting there
+    threads = min(torch.get_num_threads(), int(os.environ.get("SD3D_CPU_THREADS", "32")))
+    torch.set_num_threads(threads)
     times = []
     from segdino3d_amd.synth import make_scene
     for i in range(n_timed + 1):
