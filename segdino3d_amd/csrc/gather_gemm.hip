@@ -20,6 +20,7 @@
 // as long as A and B agree, so half h takes channels h*16 + kk: 16 contiguous floats per lane,
 // loaded as 4 x dwordx4.
 #include "common.h"
+#include <stdlib.h>
 
 struct GGParams {
     const float* in0; int ld0; int C0;        // input features, first C0 channels
@@ -33,6 +34,7 @@ struct GGParams {
     float* out; int ld_out;
     int act;                                  // 0 none, 1 relu, 2 gelu(erf), 3 sigmoid
     int col_groups;                           // ceil(Cout / (32*NT))
+    int dbg;                                  // timing experiments only (SD3D_GG_DBG): 1 = no LDS atomics, 2 = no loads/MFMA
     int ksplit;                               // lock-step kernel only: gridDim.z offset slices (partials -> ws)
     float* ws;                                // [ksplit][M][Cout] partial sums when ksplit > 1
 };
@@ -434,11 +436,20 @@ __global__ __launch_bounds__(64 * NW) void gather_gemm_compact_kernel(const GGPa
         for (int pc = 0; pc * 32 < cnt; ++pc) {
             const int pp = pc * 32 + j;
             const int pidx = pp < cnt ? my_idx[pp] : -1;
+            // output rows of the 16 accumulator rows this lane will hold: fetched from LDS now (off the
+            // critical path) so that the scatter after the MFMAs is 16 back-to-back ds_add_f32
+            int orow[16];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int prow = pc * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+                orow[r] = prow < cnt ? (int)my_row[prow] : -1;
+            }
             f32x16 acc[NT];
 #pragma unroll
             for (int t = 0; t < NT; ++t)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+            if (!(p.dbg & 2)) {
             Frag<NT> cur;
             load_frag<NT>(cur, p, k, 0, pidx, ncol0, j, h);
             for (int c = 0; c < nchunks; ++c) {
@@ -447,14 +458,15 @@ __global__ __launch_bounds__(64 * NW) void gather_gemm_compact_kernel(const GGPa
                 mma_frag<NT>(acc, cur);
                 if (c + 1 < nchunks) cur = nxt;
             }
-#pragma unroll 4
-            for (int r = 0; r < 16; ++r) {
-                const int prow = pc * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-                if (prow < cnt) {
-                    const int orow = my_row[prow];
+            }
+            if (!(p.dbg & 1)) {
 #pragma unroll
-                    for (int t = 0; t < NT; ++t) atomicAdd(&accL[orow * CW + t * 32 + j], acc[t][r]);
+            for (int r = 0; r < 16; ++r) {
+                if (orow[r] >= 0) {
+#pragma unroll
+                    for (int t = 0; t < NT; ++t) atomicAdd(&accL[orow[r] * CW + t * 32 + j], acc[t][r]);
                 }
+            }
             }
         }
         __builtin_amdgcn_wave_barrier();
@@ -605,17 +617,290 @@ static int launch_compact2(const GGParams& p, hipStream_t st) {
     return 0;
 }
 
+// ---------------------------------------------------------------------------------------------
+// Pair-compacted kernel, pipelined across pair-chunks and offsets (32 output columns per pass).
+// Same decomposition as gather_gemm_compact_kernel, but a wave first builds the pair lists of a BATCH
+// of C3_OB of its offsets (all neighbour-column loads in flight together) and then walks ONE flat
+// stream of (offset, pair-chunk, channel-chunk) steps, always loading the next step's fragments before
+// the current step's 16 MFMAs - the gather latency, which dominates this kernel, is overlapped across
+// pair-chunk and offset boundaries instead of being paid once per pair-chunk.
+// ---------------------------------------------------------------------------------------------
+#define C3_ROWS 256
+#define C3_OB 4
+__global__ __launch_bounds__(256) void gather_gemm_compact3_kernel(const GGParams p) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* accL = smem;                                                   // [C3_ROWS][32]
+    int* l_idx = (int*)(accL + C3_ROWS * 32);                             // [4 waves][C3_OB][C3_ROWS]
+    unsigned char* l_row = (unsigned char*)(l_idx + 4 * C3_OB * C3_ROWS); // [4 waves][C3_OB][C3_ROWS]
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int j = lane & 31, h = lane >> 5;
+    const int64_t row_base = (int64_t)blockIdx.x * C3_ROWS;
+    const int ncol0 = blockIdx.y * 32;
+    const int nchunks = p.Cin >> 5;
+    for (int e = tid; e < C3_ROWS * 32; e += 256) accL[e] = 0.f;
+    __syncthreads();
+    int* my_idx = l_idx + wv * C3_OB * C3_ROWS;
+    unsigned char* my_row = l_row + wv * C3_OB * C3_ROWS;
+    const uint64_t lt = (1ull << lane) - 1ull;
+    int n = ncol0 + j;
+    n = n < p.Cout ? n : p.Cout - 1;
+
+    for (int kb = wv; kb < p.K; kb += 4 * C3_OB) {          // this wave's offsets: kb, kb+4, ..., kb+4*(C3_OB-1)
+        // ---- lists of the batch
+        int ids[C3_OB][C3_ROWS / 64];
+#pragma unroll
+        for (int b = 0; b < C3_OB; ++b) {
+            const int k = kb + 4 * b;
+#pragma unroll
+            for (int ps = 0; ps < C3_ROWS / 64; ++ps) {
+                const int64_t row = row_base + ps * 64 + lane;
+                ids[b][ps] = (k < p.K && row < p.M) ? p.nbr[(int64_t)k * p.M + row] : -1;
+            }
+        }
+        int cnt[C3_OB];
+#pragma unroll
+        for (int b = 0; b < C3_OB; ++b) {
+            int c = 0;
+#pragma unroll
+            for (int ps = 0; ps < C3_ROWS / 64; ++ps) {
+                const uint64_t bal = __ballot(ids[b][ps] >= 0);
+                if (ids[b][ps] >= 0) {
+                    const int pos = c + __popcll(bal & lt);
+                    my_idx[b * C3_ROWS + pos] = ids[b][ps];
+                    my_row[b * C3_ROWS + pos] = (unsigned char)(ps * 64 + lane);
+                }
+                c += __popcll(bal);
+            }
+            cnt[b] = c;
+        }
+        __builtin_amdgcn_wave_barrier();
+        // ---- flat step stream over (b, pc, chunk)
+        auto first_group = [&](int& b, int& pc) {           // first (b, pc) with pc*32 < cnt[b], b from `b`
+            while (b < C3_OB) {
+                int cb = 0;
+#pragma unroll
+                for (int q = 0; q < C3_OB; ++q) cb = (q == b) ? cnt[q] : cb;
+                if (pc * 32 < cb) return true;
+                ++b; pc = 0;
+            }
+            return false;
+        };
+        auto load = [&](Frag<1>& f, int b, int pc, int chunk) {
+            const int pp = pc * 32 + j;
+            int cb = 0;
+#pragma unroll
+            for (int q = 0; q < C3_OB; ++q) cb = (q == b) ? cnt[q] : cb;
+            const int pidx = pp < cb ? my_idx[b * C3_ROWS + pp] : -1;
+            const int c = chunk * 32 + h * 16;
+            if (pidx >= 0) {
+                const float* src = (c < p.C0) ? (p.in0 + (int64_t)pidx * p.ld0 + c) : (p.in1 + (int64_t)pidx * p.ld1 + (c - p.C0));
+#pragma unroll
+                for (int q = 0; q < 4; ++q) f.a[q] = *(const f32x4*)(src + q * 4);
+            } else {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) f.a[q] = f32x4{0.f, 0.f, 0.f, 0.f};
+            }
+            const float* w = p.wt + ((int64_t)(kb + 4 * b) * p.Cout + n) * p.Cin + c;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) f.b[0][q] = *(const f32x4*)(w + q * 4);
+        };
+        int b = 0, pc = 0, chunk = 0;
+        if (!first_group(b, pc)) continue;
+        f32x16 acc[1];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[0][r] = 0.f;
+        Frag<1> cur;
+        load(cur, b, pc, 0);
+        while (true) {
+            int nb = b, npc = pc, nchunk = chunk + 1;
+            bool has_next = true;
+            if (nchunk == nchunks) { nchunk = 0; ++npc; has_next = first_group(nb, npc); }
+            Frag<1> nxt;
+            if (has_next) load(nxt, nb, npc, nchunk);
+            mma_frag<1>(acc, cur);
+            if (nchunk == 0) {                              // the (b, pc) group is complete: scatter it
+                int cb = 0;
+#pragma unroll
+                for (int q = 0; q < C3_OB; ++q) cb = (q == b) ? cnt[q] : cb;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int prow = pc * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+                    if (prow < cb) atomicAdd(&accL[(int)my_row[b * C3_ROWS + prow] * 32 + j], acc[0][r]);
+                    acc[0][r] = 0.f;
+                }
+            }
+            if (!has_next) break;
+            cur = nxt;
+            b = nb; pc = npc; chunk = nchunk;
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
+    __syncthreads();
+    for (int e = tid; e < C3_ROWS * 32; e += 256) {
+        const int r = e >> 5, nn = e & 31;
+        const int64_t rr = row_base + r;
+        const int nc = ncol0 + nn;
+        if (rr >= p.M || nc >= p.Cout) continue;
+        float y = accL[e] * (p.scale ? p.scale[nc] : 1.f) + (p.shift ? p.shift[nc] : 0.f);
+        if (p.res) y += p.res[rr * p.ld_res + nc];
+        if (p.act == 1) y = fmaxf(y, 0.f);
+        else if (p.act == 2) y = 0.5f * y * (1.f + erff(y * 0.70710678118654752440f));
+        else if (p.act == 3) y = 1.f / (1.f + expf(-y));
+        p.out[rr * p.ld_out + nc] = y;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Pair-compacted kernel without LDS atomics.  ds_add_f32 turned out to be the bottleneck of the
+// compacted kernels above (ablation tools/gg_quick.py: 225 of 275 us for a 32->32 level-1 conv), so
+// here every wave accumulates into its OWN LDS copy of the 128 x 32 output tile with plain
+// read-add-write (one wave = in-order LDS queue, distinct addresses per instruction) and the four
+// copies are summed in a fixed order in the epilogue: deterministic, no atomics, 64 KB of accumulators.
+// ---------------------------------------------------------------------------------------------
+#define C4_OB 4
+template <int C4_ROWS>
+__global__ __launch_bounds__(256) void gather_gemm_compact4_kernel(const GGParams p) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* accL = smem;                                                   // [4 waves][C4_ROWS][32]: one private copy per wave
+    int* l_idx = (int*)(accL + 4 * C4_ROWS * 32);                         // [4 waves][C4_OB][C4_ROWS]
+    unsigned char* l_row = (unsigned char*)(l_idx + 4 * C4_OB * C4_ROWS); // [4 waves][C4_OB][C4_ROWS]
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int j = lane & 31, h = lane >> 5;
+    const int64_t row_base = (int64_t)blockIdx.x * C4_ROWS;
+    const int ncol0 = blockIdx.y * 32;
+    const int nchunks = p.Cin >> 5;
+    for (int e = tid; e < 4 * C4_ROWS * 32; e += 256) accL[e] = 0.f;
+    __syncthreads();
+    float* my_acc = accL + wv * C4_ROWS * 32;
+    int* my_idx = l_idx + wv * C4_OB * C4_ROWS;
+    unsigned char* my_row = l_row + wv * C4_OB * C4_ROWS;
+    const uint64_t lt = (1ull << lane) - 1ull;
+    int n = ncol0 + j;
+    n = n < p.Cout ? n : p.Cout - 1;
+
+    for (int kb = wv; kb < p.K; kb += 4 * C4_OB) {          // this wave's offsets: kb, kb+4, ..., kb+4*(C4_OB-1)
+        // ---- lists of the batch
+        int ids[C4_OB][C4_ROWS / 64];
+#pragma unroll
+        for (int b = 0; b < C4_OB; ++b) {
+            const int k = kb + 4 * b;
+#pragma unroll
+            for (int ps = 0; ps < C4_ROWS / 64; ++ps) {
+                const int64_t row = row_base + ps * 64 + lane;
+                ids[b][ps] = (k < p.K && row < p.M) ? p.nbr[(int64_t)k * p.M + row] : -1;
+            }
+        }
+        int cnt[C4_OB];
+#pragma unroll
+        for (int b = 0; b < C4_OB; ++b) {
+            int c = 0;
+#pragma unroll
+            for (int ps = 0; ps < C4_ROWS / 64; ++ps) {
+                const uint64_t bal = __ballot(ids[b][ps] >= 0);
+                if (ids[b][ps] >= 0) {
+                    const int pos = c + __popcll(bal & lt);
+                    my_idx[b * C4_ROWS + pos] = ids[b][ps];
+                    my_row[b * C4_ROWS + pos] = (unsigned char)(ps * 64 + lane);
+                }
+                c += __popcll(bal);
+            }
+            cnt[b] = c;
+        }
+        __builtin_amdgcn_wave_barrier();
+        // ---- flat step stream over (b, pc, chunk)
+        auto first_group = [&](int& b, int& pc) {           // first (b, pc) with pc*32 < cnt[b], b from `b`
+            while (b < C4_OB) {
+                int cb = 0;
+#pragma unroll
+                for (int q = 0; q < C4_OB; ++q) cb = (q == b) ? cnt[q] : cb;
+                if (pc * 32 < cb) return true;
+                ++b; pc = 0;
+            }
+            return false;
+        };
+        auto load = [&](Frag<1>& f, int b, int pc, int chunk) {
+            const int pp = pc * 32 + j;
+            int cb = 0;
+#pragma unroll
+            for (int q = 0; q < C4_OB; ++q) cb = (q == b) ? cnt[q] : cb;
+            const int pidx = pp < cb ? my_idx[b * C4_ROWS + pp] : -1;
+            const int c = chunk * 32 + h * 16;
+            if (pidx >= 0) {
+                const float* src = (c < p.C0) ? (p.in0 + (int64_t)pidx * p.ld0 + c) : (p.in1 + (int64_t)pidx * p.ld1 + (c - p.C0));
+#pragma unroll
+                for (int q = 0; q < 4; ++q) f.a[q] = *(const f32x4*)(src + q * 4);
+            } else {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) f.a[q] = f32x4{0.f, 0.f, 0.f, 0.f};
+            }
+            const float* w = p.wt + ((int64_t)(kb + 4 * b) * p.Cout + n) * p.Cin + c;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) f.b[0][q] = *(const f32x4*)(w + q * 4);
+        };
+        int b = 0, pc = 0, chunk = 0;
+        if (!first_group(b, pc)) continue;
+        f32x16 acc[1];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[0][r] = 0.f;
+        Frag<1> cur;
+        load(cur, b, pc, 0);
+        while (true) {
+            int nb = b, npc = pc, nchunk = chunk + 1;
+            bool has_next = true;
+            if (nchunk == nchunks) { nchunk = 0; ++npc; has_next = first_group(nb, npc); }
+            Frag<1> nxt;
+            if (has_next) load(nxt, nb, npc, nchunk);
+            mma_frag<1>(acc, cur);
+            if (nchunk == 0) {                              // the (b, pc) group is complete: scatter it
+                int cb = 0;
+#pragma unroll
+                for (int q = 0; q < C4_OB; ++q) cb = (q == b) ? cnt[q] : cb;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int prow = pc * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+                    if (prow < cb) {                        // wave-private rows: plain read-add-write, no atomics
+                        float* dst = &my_acc[(int)my_row[b * C4_ROWS + prow] * 32 + j];
+                        *dst += acc[0][r];
+                    }
+                    acc[0][r] = 0.f;
+                }
+            }
+            if (!has_next) break;
+            cur = nxt;
+            b = nb; pc = npc; chunk = nchunk;
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
+    __syncthreads();
+    for (int e = tid; e < C4_ROWS * 32; e += 256) {
+        const int r = e >> 5, nn = e & 31;
+        const int64_t rr = row_base + r;
+        const int nc = ncol0 + nn;
+        if (rr >= p.M || nc >= p.Cout) continue;
+        const float a4 = ((accL[e] + accL[C4_ROWS * 32 + e]) + accL[2 * C4_ROWS * 32 + e]) + accL[3 * C4_ROWS * 32 + e];
+        float y = a4 * (p.scale ? p.scale[nc] : 1.f) + (p.shift ? p.shift[nc] : 0.f);
+        if (p.res) y += p.res[rr * p.ld_res + nc];
+        if (p.act == 1) y = fmaxf(y, 0.f);
+        else if (p.act == 2) y = 0.5f * y * (1.f + erff(y * 0.70710678118654752440f));
+        else if (p.act == 3) y = 1.f / (1.f + expf(-y));
+        p.out[rr * p.ld_out + nc] = y;
+    }
+}
+
 // nt > 0            : private-fragment kernel, nt subtiles per wave, no split-K
 // nt == 0           : heuristic (see below)
 // nt == -1          : private-fragment kernel, split-K with one subtile (tests)
 // nt in [-14, -11]  : lock-step LDS-shared-weights kernel with (-nt - 10) subtiles (tests / tuning)
 // nt in [-23, -21]  : pair-compacted kernel, 4 waves per workgroup, (-nt - 20) subtiles (needs a neighbour table)
 // nt in [-33, -31]  : pair-compacted kernel, 8 waves per workgroup, (-nt - 30) subtiles
+// nt == -51          : pipelined pair-compacted kernel (32 columns per pass)
+// nt == -61          : pipelined pair-compacted kernel with per-wave private LDS accumulators (no atomics)
 // nt == -41 / -42    : single-pass pair-compacted kernel over all Cout <= 128 columns, 128 / 256 rows per workgroup
 int launch_gather_gemm(const GGParams& p_in, int nt, void* ws, size_t ws_bytes, hipStream_t st) {
     GGParams p = p_in;
     p.ksplit = 1;
     p.ws = nullptr;
+    { static int dbg = -1; if (dbg < 0) { const char* e = getenv("SD3D_GG_DBG"); dbg = e ? atoi(e) : 0; } p.dbg = dbg; }
     if (p.M <= 0 || p.Cout <= 0) return SD3D_OK;
     if (p.Cin <= 0 || (p.Cin & 31)) return sd3d_set_error(SD3D_ERR_ARG, "gather_gemm: Cin must be a positive multiple of 32");
     if (p.in1 && ((p.C0 & 31) || p.C0 > p.Cin)) return sd3d_set_error(SD3D_ERR_ARG, "gather_gemm: concat split must be a multiple of 32");
@@ -627,6 +912,31 @@ int launch_gather_gemm(const GGParams& p_in, int nt, void* ws, size_t ws_bytes, 
     const int64_t tiles = cdiv(p.M, 32);
     int ks = 1;
     bool lds = false;
+    if (nt == -61 || nt == -62) {
+        if (!p.nbr) return sd3d_set_error(SD3D_ERR_ARG, "gather_gemm: the compacted kernel needs a neighbour table");
+        p.col_groups = (int)cdiv(p.Cout, 32);
+        const int rows = nt == -61 ? 128 : 256;
+        const size_t sm = (size_t)4 * rows * 32 * sizeof(float) + (size_t)4 * C4_OB * rows * (sizeof(int) + 1);
+        static bool attr_set = false;
+        if (!attr_set) {
+            (void)hipFuncSetAttribute((const void*)gather_gemm_compact4_kernel<128>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            (void)hipFuncSetAttribute((const void*)gather_gemm_compact4_kernel<256>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            attr_set = true;
+        }
+        const dim3 grid((unsigned)cdiv(p.M, rows), (unsigned)p.col_groups);
+        if (rows == 128) hipLaunchKernelGGL(gather_gemm_compact4_kernel<128>, grid, dim3(256), sm, st, p);
+        else hipLaunchKernelGGL(gather_gemm_compact4_kernel<256>, grid, dim3(256), sm, st, p);
+        SD3D_CHECK_LAUNCH();
+        return SD3D_OK;
+    }
+    if (nt == -51) {
+        if (!p.nbr) return sd3d_set_error(SD3D_ERR_ARG, "gather_gemm: the compacted kernel needs a neighbour table");
+        p.col_groups = (int)cdiv(p.Cout, 32);
+        const size_t sm = (size_t)C3_ROWS * 32 * sizeof(float) + (size_t)4 * C3_OB * C3_ROWS * (sizeof(int) + 1);
+        hipLaunchKernelGGL(gather_gemm_compact3_kernel, dim3((unsigned)cdiv(p.M, C3_ROWS), (unsigned)p.col_groups), dim3(256), sm, st, p);
+        SD3D_CHECK_LAUNCH();
+        return SD3D_OK;
+    }
     if (nt == -41 || nt == -42) {
         if (!p.nbr) return sd3d_set_error(SD3D_ERR_ARG, "gather_gemm: the compacted kernel needs a neighbour table");
         if (p.Cout > 128) return sd3d_set_error(SD3D_ERR_ARG, "gather_gemm: single-pass compacted kernel needs Cout <= 128");

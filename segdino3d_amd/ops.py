@@ -227,7 +227,13 @@ def pool_superpoints(feat, C, inverse, icoords, voxel_size, sorted_idx, start, S
 # --------------------------------------------------------------------------------------------
 # gather-GEMM
 # --------------------------------------------------------------------------------------------
-COMPACT_DENSITY = 0.2      # pairs / (K * M) below which the pair-compacted kernel wins (tools/bench_gg.py)
+# Kernel choice by rulebook density = pairs / (K * M), from tools/gg_quick.py on MI355X:
+#   < 0.15        pair-compacted kernel with a shared LDS accumulator (ds_add_f32): 256-row tiles keep the
+#                 32-pair MFMA chunks full when only ~1 row in 9 has a given neighbour
+#   0.15 .. 0.40  pair-compacted kernel with per-wave private accumulators (no atomics, 128-row tiles)
+#   >= 0.40       dense lock-step kernel with LDS-shared weights (the zeros it multiplies cost less than compaction)
+COMPACT_ATOMIC_DENSITY = 0.15
+COMPACT_PRIVATE_DENSITY = 0.40
 
 
 def gather_gemm(x, wt, nbr=None, x2=None, scale=None, shift=None, res=None, act=None, out=None, M=None, nt=0,
@@ -259,8 +265,11 @@ def gather_gemm(x, wt, nbr=None, x2=None, scale=None, shift=None, res=None, act=
     pr, ldr = (None, 0)
     if res is not None:
         pr, ldr = _rows(res, "res")
-    if nt == 0 and density is not None and nbr is not None and density < COMPACT_DENSITY and GG_FORCE_NT is None:
-        nt = -21                                   # pair-compacted kernel, one 32-column subtile per pass
+    if nt == 0 and density is not None and nbr is not None and GG_FORCE_NT is None:
+        if density < COMPACT_ATOMIC_DENSITY:
+            nt = -21
+        elif density < COMPACT_PRIVATE_DENSITY:
+            nt = -61
     if GG_FORCE_NT is not None and nt == 0:
         sub = (Cout + 31) // 32
         eff = GG_FORCE_NT if GG_FORCE_NT > 0 else (-GG_FORCE_NT - 10 if GG_FORCE_NT <= -11 else 1)

@@ -12,9 +12,9 @@ for (lvl, k, cin, cout) in [(0, 3, 96, 96), (0, 3, 128, 96), (1, 3, 96, 96), (1,
     nbr = maps.same(lvl, k); K, M = nbr.shape
     x = torch.randn(M, cin, generator=g).to(d); w = (torch.randn(K, cout, cin, generator=g) * (K * cin) ** -0.5).to(d)
     res = []
-    for nt in (-11, -13, -21, -41, -42):
+    for nt in (-11, -21, -61, -62):
         if cout != 96 and nt == -13: continue
         ref = ops.gather_gemm(x, w, nbr=nbr, nt=1)
         err = (ops.gather_gemm(x, w, nbr=nbr, nt=nt) - ref).abs().max().item()
-        res.append(f"{nt}:{timeit(lambda: ops.gather_gemm(x, w, nbr=nbr, nt=nt), 5):.0f}" + ("(BAD %.1e)" % err if err > 1e-3 else ""))
+        res.append(f"{nt}:{timeit(lambda: ops.gather_gemm(x, w, nbr=nbr, nt=nt), 5):.0f}" + ("(BAD %.1e)" % err if err > 1e-3 and not os.environ.get('SD3D_GG_DBG') else ""))
     print(lvl, k, cin, cout, " ".join(res))
