@@ -115,6 +115,8 @@ def main():
     ap.add_argument("--query2d", type=int, default=300)
     ap.add_argument("--query-num", type=int, default=200)
     ap.add_argument("--scene-pool", type=int, default=2, help="distinct synthetic scenes per rank (cycled)")
+    ap.add_argument("--streams", type=int, default=2,
+                    help="scenes in flight per GPU (host threads x HIP streams, segdino3d_amd.dist_eval.PipelinedRunner)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
@@ -144,15 +146,30 @@ def main():
         pts, tgt = pool[i % len(pool)]
         return model([pts], [tgt])
 
+    from segdino3d_amd.dist_eval import PipelinedRunner
+    runner = PipelinedRunner(model, args.streams, device)
+    # every step gets its own target object (the forward attaches its outputs to it)
+    import copy
+    def scene_list(n):
+        return [(pool[i % len(pool)][0], copy.copy(pool[i % len(pool)][1])) for i in range(n)]
+
     with torch.no_grad():
         for i in range(args.warmup):
             step(i)
+        runner.run(scene_list(max(args.streams, 2)))           # warm the worker streams' allocator pools
         torch.cuda.synchronize()
+        # single-scene latency (one stream, back to back) for reference
+        t0 = time.perf_counter()
+        for i in range(min(5, args.steps)):
+            step(i)
+        torch.cuda.synchronize()
+        latency_ms = 1e3 * (time.perf_counter() - t0) / min(5, args.steps)
         if dist is not None:
             dist.barrier()
+        work = scene_list(args.steps)
+        torch.cuda.synchronize()
         t0 = time.perf_counter()
-        for i in range(args.steps):
-            step(i)
+        runner.run(work)                                          # EXACTLY K steps, args.streams scenes in flight
         torch.cuda.synchronize()
         if dist is not None:
             dist.barrier()
@@ -228,7 +245,8 @@ def main():
             "config": {"workload": "configs[1]: ScanNet-val-like scene, 1 scene per GPU per step, fp32 sparse backbone "
                                    "(Res16UNet34C) + fp32 decoder + post-processing, device-resident in/out",
                        "points": args.points, "superpoints": args.superpoints, "queries_2d": args.query2d,
-                       "query_num": args.query_num, "voxels_per_level": maps.n_vox, "parallelism": f"scene-sharded x{world}"},
+                       "query_num": args.query_num, "voxels_per_level": maps.n_vox, "parallelism": f"scene-sharded x{world}",
+                       "scenes_in_flight_per_gpu": args.streams, "single_stream_latency_ms": round(latency_ms, 3)},
             "roofline": roofline, "cpu_baseline": cpu,
             "per_rank_records": records,
         }

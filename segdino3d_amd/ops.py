@@ -6,6 +6,7 @@ there is deliberately no CPU path (the CPU restatement is oracle/, test infrastr
 """
 from __future__ import annotations
 
+import threading
 from typing import Optional
 
 import torch
@@ -60,8 +61,22 @@ class Workspace:
         return self.buf
 
 
-_WS = Workspace()
-_WS2 = Workspace()       # split-K partial sums of gather_gemm
+class _PerThread:
+    """One scratch buffer per host thread: each worker thread of the pipelined runner drives its own HIP
+    stream, and scratch must never be shared between streams."""
+
+    def __init__(self):
+        self._tls = threading.local()
+
+    def get(self, nbytes: int, device):
+        ws = getattr(self._tls, "ws", None)
+        if ws is None:
+            ws = self._tls.ws = Workspace()
+        return ws.get(nbytes, device)
+
+
+_WS = _PerThread()
+_WS2 = _PerThread()       # split-K partial sums of gather_gemm
 
 
 # --------------------------------------------------------------------------------------------
