@@ -125,3 +125,35 @@ def test_no_2d_queries_and_no_surviving_instances():
     ref = D.decoder_forward(sd, D.DecoderCfg(), sp_feat, sp_pos, sp_pos, sp_feat, sp_pos, torch.zeros(0, 256), torch.zeros(0, 3), lo, hi)
     err = (out["masks"][0].cpu() - ref["masks"]).abs()
     assert (err > 2e-3 + 2e-3 * ref["masks"].abs()).any(dim=1).float().mean() <= 0.1
+
+
+def test_pipelined_runner_matches_sequential():
+    """Two scenes in flight on two HIP streams (threads) give the same predictions as back-to-back runs."""
+    import copy
+    import segdino3d_amd as seg
+    from segdino3d_amd.configs import scannet200_model_cfg
+    from segdino3d_amd.dist_eval import PipelinedRunner
+    from segdino3d_amd.synth import make_scene
+    d = dev()
+    torch.manual_seed(0)
+    model = seg.build_architecture(scannet200_model_cfg(query_num=-1)).eval().to(d)
+    model.to_host = False
+    scenes = []
+    for i in range(4):
+        pts, tgt = make_scene(20 + i, n_points=6000 + 500 * i, n_superpoints=50, n_query2d=10)
+        scenes.append((pts.to(d), tgt.to(d)))
+    with torch.no_grad():
+        seq = [model([p], [copy.copy(t)])[0].pred_pts_seg for p, t in scenes]
+        seq_logits = []
+        for p, t in scenes:
+            model([p], [copy.copy(t)])
+            seq_logits.append(model.last_outputs["masks"][0].clone())
+    par = PipelinedRunner(model, 2, d).run([(p, copy.copy(t)) for p, t in scenes])
+    torch.cuda.synchronize()
+    for i, (a, res) in enumerate(zip(seq, par)):
+        b = res[0].pred_pts_seg
+        assert a.pts_instance_mask[0].shape == b.pts_instance_mask[0].shape, i
+        torch.testing.assert_close(a.instance_scores, b.instance_scores, rtol=1e-3, atol=1e-5)
+        agree = (a.pts_instance_mask[0] == b.pts_instance_mask[0]).float().mean().item() if a.pts_instance_mask[0].numel() else 1.0
+        assert agree > 0.999, (i, agree)
+        assert (a.pts_semantic_mask[0] != b.pts_semantic_mask[0]).float().mean().item() < 1e-3
