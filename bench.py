@@ -9,6 +9,10 @@ one synthetic ScanNet200-like scene (150 k points, 3000 superpoints, 300 2D quer
 fp32) whose inputs are already resident in HBM; outputs stay on the device.  Scenes are independent
 units, so ranks shard them with no data-path collective (weak scaling); one all-gather of per-scene
 records (scene id, points, voxels, ms) closes the run, as in the north-star's metric exchange.
+Inside a rank the K timed steps are issued by `--streams` host threads, each on its own HIP stream
+(segdino3d_amd.dist_eval.PipelinedRunner): a forward is ~800 dependent launches, many too small to
+fill 256 CUs, so 3 scenes in flight raise scenes/s by ~45 % over back-to-back forwards; the
+single-stream latency is reported next to it (`config.single_stream_latency_ms`).
 
 Prints ONE JSON line (rank 0) with the contract fields plus
   roofline     : the dominant kernel (gather_gemm = every sparse convolution + every Linear), its
