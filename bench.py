@@ -35,6 +35,7 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+FP32_MFMA_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense fp32 matrix peak
 
 
 class GemmTimer:
@@ -215,16 +216,30 @@ def main():
         b, f = algorithmic_bytes(meta, P)
         tot_bytes += b
         tot_flops += f
-    achieved = tot_bytes / (gemm_ms * 1e-3) / 1e9 if gemm_ms > 0 else 0.0
-    roofline = {"bound": "hbm", "kernel": "gather_gemm_kernel", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
-                "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+    # Two time lower bounds for this kernel family at fp32: its algorithmic bytes at 8 TB/s, and its
+    # algorithmic (active-pair) flops at the 157.3 TFLOP/s fp32-MFMA peak.  For the benchmark scene the second
+    # is the larger one (571 GFLOP -> 3.6 ms vs 10.8 GB -> 1.4 ms), i.e. in exact fp32 the family is bound
+    # by the matrix cores, so that is the roofline reported in bound/achieved/peak/frac; the HBM figures
+    # are kept next to it.
+    sec = gemm_ms * 1e-3
+    hbm_gbs = tot_bytes / sec / 1e9 if sec > 0 else 0.0
+    tflops = tot_flops / sec / 1e12 if sec > 0 else 0.0
+    t_hbm, t_mfma = tot_bytes / (HBM_PEAK_GBS * 1e9), tot_flops / (FP32_MFMA_PEAK_TFLOPS * 1e12)
+    mfma_bound = t_mfma >= t_hbm
+    roofline = {"bound": "mfma" if mfma_bound else "hbm", "kernel": "gather_gemm family (sd3d_gather_gemm: "
+                "gather_gemm_lds_kernel / gather_gemm_compact*_kernel / gather_gemm_kernel)",
+                "achieved": round(tflops if mfma_bound else hbm_gbs, 2),
+                "peak": FP32_MFMA_PEAK_TFLOPS if mfma_bound else HBM_PEAK_GBS,
+                "unit": "TFLOP/s" if mfma_bound else "GB/s",
+                "frac": round((tflops / FP32_MFMA_PEAK_TFLOPS) if mfma_bound else (hbm_gbs / HBM_PEAK_GBS), 4),
+                "traffic": None,
+                "hbm_achieved_gbs": round(hbm_gbs, 1), "hbm_peak_gbs": HBM_PEAK_GBS, "hbm_frac": round(hbm_gbs / HBM_PEAK_GBS, 4),
                 "launches_per_step": n_launch // max(1, args.steps),
                 "avg_launch_us": round(1e3 * gemm_ms / max(1, n_launch), 2),
                 "algorithmic_bytes_per_step": tot_bytes // max(1, args.steps),
                 "algorithmic_flops_per_step": tot_flops // max(1, args.steps),
-                "fp32_tflops": round(tot_flops / (gemm_ms * 1e-3) / 1e12, 2) if gemm_ms > 0 else 0.0,
-                "share_of_step_time": round(gemm_ms * 1e-3 / dt, 3),
-                "measured": "HIP events around every launch, instrumented replay of the timed steps"}
+                "share_of_single_stream_forward": round(gemm_ms / max(1, args.steps) / latency_ms, 3),
+                "measured": "HIP events around every launch, single-stream instrumented replay of the timed steps"}
 
     # ---- closing all-gather of per-scene records over RCCL/xGMI -----------------------
     maps = model.backbone.last_maps
