@@ -37,6 +37,7 @@ class DecoderCfg:
     box_modulate_ca: bool = True
     normalize_box_prediction: bool = True
     activation_fn: str = "gelu"
+    add_positional_embedding: bool = True
 
 
 class W:
@@ -146,9 +147,47 @@ def dinox_blocked_mask(open_mask, pos_wo, q2d_pos, thr):
     return torch.cat([blocked, blocked.new_zeros(blocked.shape[0], 1)], dim=1)
 
 
+def _packed_mha(w: W, name, q_in, kv_in, num_heads, blocked):
+    """nn.MultiheadAttention with packed in-projection on unbatched inputs (decoder :79, :146)."""
+    d = q_in.shape[1]
+    wi, bi = w(name + ".in_proj_weight"), w(name + ".in_proj_bias")
+    q = F.linear(q_in, wi[:d], bi[:d])
+    k = F.linear(kv_in, wi[d:2 * d], bi[d:2 * d])
+    v = F.linear(kv_in, wi[2 * d:], bi[2 * d:])
+    return w.lin(attention_core(q, k, v, num_heads, blocked), name + ".out_proj")
+
+
+def decoder_forward_plain(sd, cfg: DecoderCfg, x, q_in, prefix="decoder."):
+    """Non-positional variant (Baseline_ScanNet200 prototype: add_positional_embedding=False, no 2D-query
+    attention): forward_iter_pred :693, :711, :733 with CrossAttentionLayer (:60-86, fix=True),
+    SelfAttentionLayer (:133-150) and FFN; no box heads."""
+    w = W(sd, prefix)
+    H, L = cfg.num_heads, cfg.num_layers
+    inst = torch.relu(w.ln(w.lin(x, "input_proj.0"), "input_proj.1"))
+    mask_feats = w.lin(torch.relu(w.lin(x, "x_mask.0")), "x_mask.2")
+    queries = w.lin(torch.relu(w.lin(q_in, "query_proj.0")), "query_proj.2")
+    cls, sem, logits, blocked = forward_head(w, queries, mask_feats, False, cfg.mask_attention_threshold)
+    aux = [dict(cls_preds=cls, masks=logits, centers=None, sizes=None)]
+    act = F.gelu if cfg.activation_fn == "gelu" else torch.relu
+    for i in range(L):
+        a = _packed_mha(w, f"cross_attn_layers.{i}.attn", queries, inst, H, blocked)
+        queries = w.ln(a + queries, f"cross_attn_layers.{i}.norm")
+        a = _packed_mha(w, f"self_attn_layers.{i}.attn", queries, queries, H, None)
+        queries = w.ln(a + queries, f"self_attn_layers.{i}.norm")
+        h = w.lin(act(w.lin(queries, f"ffn_layers.{i}.net.0")), f"ffn_layers.{i}.net.3")
+        queries = w.ln(h + queries, f"ffn_layers.{i}.norm")
+        cls, sem, logits, blocked = forward_head(w, queries, mask_feats, i == L - 1, cfg.mask_attention_threshold)
+        aux.append(dict(cls_preds=cls, masks=logits, centers=None, sizes=None))
+    final = aux[-1]
+    return dict(cls_preds=final["cls_preds"], sem_preds=sem, masks=final["masks"], centers=None, sizes=None,
+                hidden_states=queries, aux=aux[:-1], attn_blocked=blocked)
+
+
 def decoder_forward(sd, cfg: DecoderCfg, x, sp_pos, sp_pos_wo, q_in, q_pos, q2d_feat, q2d_pos, lo, hi,
                     prefix="decoder.", trace=None):
     """Returns dict(cls_preds, sem_preds, masks, centers, sizes, hidden_states, aux=[...])."""
+    if not cfg.add_positional_embedding:
+        return decoder_forward_plain(sd, cfg, x, q_in, prefix)
     w = W(sd, prefix)
     H, L = cfg.num_heads, cfg.num_layers
     d = cfg.d_model

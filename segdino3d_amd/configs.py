@@ -59,3 +59,14 @@ def scannetv2_model_cfg(query_num=-1, voxel_size=0.02):
                             temperature=20, box_modulate_ca=True)
     m.update(add_positional_embedding=True, mode_3d_center="median", filter_outofbox_points_eval=True, query_num=query_num)
     return copy.deepcopy(m)
+
+
+def baseline_scannet200_model_cfg(query_num=-1, voxel_size=0.02):
+    """configs/prototypes/Baseline_ScanNet200.py: rgb-only backbone, no 2D-query attention, no positional embedding."""
+    m = _base(198, 200)
+    m["pointcloud_backbone_cfg"].update(voxel_size=voxel_size, mode_fuse_2d_feat="only_rgb")
+    m["decoder_cfg"].update(add_dinox_query_ca=False)
+    m["criterion_cfg"]["inst_criterion"]["matcher"]["costs"] = m["criterion_cfg"]["inst_criterion"]["matcher"]["costs"][:3]
+    m["criterion_cfg"]["inst_criterion"]["loss_weight"] = [0.5, 1.0, 1.0, 0.5]
+    m.update(query_num=query_num)
+    return copy.deepcopy(m)

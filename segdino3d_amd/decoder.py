@@ -62,12 +62,29 @@ class _CrossAttentionHolder(nn.Module):
                 nn.init.xavier_uniform_(p)
 
 
+class _SelfAttentionHolder(nn.Module):
+    """`SelfAttentionLayer` (:117-131): nn.MultiheadAttention + LayerNorm (default init)."""
+
+    def __init__(self, d_model, num_heads, dropout):
+        super().__init__()
+        self.attn = nn.MultiheadAttention(d_model, num_heads, dropout=dropout, batch_first=True)
+        self.norm = nn.LayerNorm(d_model)
+
+
 class _FFNHolder(nn.Module):
     def __init__(self, d_model, hidden_dim, dropout, activation_fn):
         super().__init__()
         self.net = nn.Sequential(nn.Linear(d_model, hidden_dim), nn.ReLU() if activation_fn == "relu" else nn.GELU(),
                                  nn.Dropout(dropout), nn.Linear(hidden_dim, d_model), nn.Dropout(dropout))
         self.norm = nn.LayerNorm(d_model)
+
+
+def ws_ca(dec):
+    return [m.attn.in_proj_weight.detach() for m in dec.cross_attn_layers]
+
+
+def bs_ca(dec):
+    return [m.attn.in_proj_bias.detach() for m in dec.cross_attn_layers]
 
 
 def _lin(x, layer: nn.Linear, act=None, res=None):
@@ -94,8 +111,10 @@ class ScanNetQueryDecoder(nn.Module):
         super().__init__()
         assert num_semantic_linears in [1, 2]
         unsupported = []
-        if not add_positional_embedding or pos_type != "sine":
-            unsupported.append("add_positional_embedding=True with pos_type='sine' is required")
+        if add_positional_embedding and pos_type != "sine":
+            unsupported.append("pos_type='sine' is required with add_positional_embedding (fourier PE is not built)")
+        if not add_positional_embedding and (add_dinox_query_ca or add_box_size_pred or box_modulate_ca):
+            unsupported.append("2D-query attention / box heads need add_positional_embedding=True")
         if not iter_pred or not attn_mask:
             unsupported.append("iter_pred=True and attn_mask=True are required")
         if num_instance_queries + num_semantic_queries != 0 or objectness_flag:
@@ -132,8 +151,12 @@ class ScanNetQueryDecoder(nn.Module):
 
         self.input_proj = nn.Sequential(nn.Linear(in_channels, d), nn.LayerNorm(d), nn.ReLU())
         self.query_proj = nn.Sequential(nn.Linear(in_channels, d), nn.ReLU(), nn.Linear(d, d))
-        self.cross_attn_layers = nn.ModuleList(_OutProjOnly(d) for _ in range(L))
-        self.self_attn_layers = nn.ModuleList(_OutProjOnly(d) for _ in range(L))
+        if add_positional_embedding:
+            self.cross_attn_layers = nn.ModuleList(_OutProjOnly(d) for _ in range(L))
+            self.self_attn_layers = nn.ModuleList(_OutProjOnly(d) for _ in range(L))
+        else:   # QueryDecoder.__init__ :244-251: CrossAttentionLayer / SelfAttentionLayer with nn.MultiheadAttention
+            self.cross_attn_layers = nn.ModuleList(_CrossAttentionHolder(d, num_heads, dropout, fix_attention) for _ in range(L))
+            self.self_attn_layers = nn.ModuleList(_SelfAttentionHolder(d, num_heads, dropout) for _ in range(L))
         self.ffn_layers = nn.ModuleList(_FFNHolder(d, hidden_dim, dropout, activation_fn) for _ in range(L))
         self.out_norm = nn.LayerNorm(d)
         self.out_cls = nn.Sequential(nn.Linear(d, d), nn.ReLU(), nn.Linear(d, num_instance_classes + 1))
@@ -145,21 +168,22 @@ class ScanNetQueryDecoder(nn.Module):
         if add_dinox_query_ca:
             self.dinox_query_cross_attn_layers = nn.ModuleList(
                 _CrossAttentionHolder(d, num_heads, dropout, fix_attention) for _ in range(L))
-        self.ref_point_head = MLP(d, d, d, 2)
-        bbox = MLP(d, d, 3, 3)
-        nn.init.constant_(bbox.layers[-1].weight.data, 0)
-        nn.init.constant_(bbox.layers[-1].bias.data, 0)
-        self.bbox_embed = nn.ModuleList(copy.deepcopy(bbox) for _ in range(L))
-        mk = lambda: nn.ModuleList(nn.Linear(d, d) for _ in range(L))  # noqa: E731
-        self.ca_qcontent_proj = mk()
-        self.ca_qpos_proj = nn.Linear(d, d)
-        self.ca_kcontent_proj, self.ca_kpos_proj, self.ca_v_proj, self.ca_qpos_sine_proj = mk(), mk(), mk(), mk()
-        self.norm1 = nn.ModuleList(nn.LayerNorm(d) for _ in range(L))
-        self.sa_qcontent_proj, self.sa_qpos_proj, self.sa_kcontent_proj = mk(), mk(), mk()
-        self.sa_kpos_proj, self.sa_v_proj = mk(), mk()
-        self.norm2 = nn.ModuleList(nn.LayerNorm(d) for _ in range(L))
-        if add_box_size_pred:
-            self.bbox_size_embed = nn.ModuleList(copy.deepcopy(bbox) for _ in range(L))
+        if add_positional_embedding:
+            self.ref_point_head = MLP(d, d, d, 2)
+            bbox = MLP(d, d, 3, 3)
+            nn.init.constant_(bbox.layers[-1].weight.data, 0)
+            nn.init.constant_(bbox.layers[-1].bias.data, 0)
+            self.bbox_embed = nn.ModuleList(copy.deepcopy(bbox) for _ in range(L))
+            mk = lambda: nn.ModuleList(nn.Linear(d, d) for _ in range(L))  # noqa: E731
+            self.ca_qcontent_proj = mk()
+            self.ca_qpos_proj = nn.Linear(d, d)
+            self.ca_kcontent_proj, self.ca_kpos_proj, self.ca_v_proj, self.ca_qpos_sine_proj = mk(), mk(), mk(), mk()
+            self.norm1 = nn.ModuleList(nn.LayerNorm(d) for _ in range(L))
+            self.sa_qcontent_proj, self.sa_qpos_proj, self.sa_kcontent_proj = mk(), mk(), mk()
+            self.sa_kpos_proj, self.sa_v_proj = mk(), mk()
+            self.norm2 = nn.ModuleList(nn.LayerNorm(d) for _ in range(L))
+            if add_box_size_pred:
+                self.bbox_size_embed = nn.ModuleList(copy.deepcopy(bbox) for _ in range(L))
         if box_modulate_ca:
             self.ref_anchor_head = MLP(d, d, 3, 2)
         self._packed = None
@@ -182,6 +206,20 @@ class ScanNetQueryDecoder(nn.Module):
         if self._packed is None:
             d, L = self.d_model, self.num_layers
             cat = lambda mods, attr: torch.cat([getattr(m, attr).detach() for m in mods]).contiguous()  # noqa: E731
+            if not self.add_positional_embedding:
+                pk = {}
+                for nm, mods in (("ca", self.cross_attn_layers), ("sa", self.self_attn_layers)):
+                    ws = [m.attn.in_proj_weight.detach() for m in mods]
+                    bs = [m.attn.in_proj_bias.detach() for m in mods]
+                    pk[nm + "_q_w"] = [w[:d].contiguous() for w in ws]
+                    pk[nm + "_q_b"] = [b[:d].contiguous() for b in bs]
+                    pk[nm + "_kv_w"] = [w[d:].contiguous() for w in ws]
+                    pk[nm + "_kv_b"] = [b[d:].contiguous() for b in bs]
+                # all layers' key/value projections of the (layer-invariant) superpoint features in one GEMM
+                pk["ca_kv_all_w"] = torch.cat([w[d:2 * d] for w in ws_ca(self)] + [w[2 * d:] for w in ws_ca(self)]).contiguous()
+                pk["ca_kv_all_b"] = torch.cat([b[d:2 * d] for b in bs_ca(self)] + [b[2 * d:] for b in bs_ca(self)]).contiguous()
+                self._packed = pk
+                return pk
             pk = {
                 # all layers' key-content and value projections of the superpoint features: [2*L*d, d]
                 "kv_w": torch.cat([cat(self.ca_kcontent_proj, "weight"), cat(self.ca_v_proj, "weight")]).contiguous(),
@@ -241,6 +279,43 @@ class ScanNetQueryDecoder(nn.Module):
         nq = ops.layernorm(q, self.out_norm.weight, self.out_norm.bias)
         cls = _lin(_lin(nq, self.out_cls[0], act="relu"), self.out_cls[2])
         return ops.class_scores(cls, self.num_instance_classes, want_scores=False, want_rowmax=True)[1]
+
+    # ---- one scene, non-positional variant (Baseline_ScanNet200 prototype; :693, :711, :733) ---------
+    def _forward_scene_plain(self, x, q_in):
+        if self.training:
+            raise NotImplementedError("segdino3d_amd decoder: eval-mode forward only (training step not built)")
+        d, H, L = self.d_model, self.num_heads, self.num_layers
+        pk = self.packed()
+        x, q_in = x.contiguous(), q_in.contiguous()
+        inst = ops.layernorm(_lin(x, self.input_proj[0]), self.input_proj[1].weight, self.input_proj[1].bias, act="relu")
+        mask_feats = _lin(_lin(x, self.x_mask[0], act="relu"), self.x_mask[2])
+        queries = _lin(_lin(q_in, self.query_proj[0], act="relu"), self.query_proj[2])
+        cls, sem, logits, bits = self._head(queries, mask_feats, False)
+        aux = [dict(cls_preds=cls, sem_preds=None, masks=logits, centers=None, sizes=None)]
+        kv_all = ops.linear(inst, pk["ca_kv_all_w"], pk["ca_kv_all_b"])          # [S, 2*L*d]: k_0..k_{L-1} | v_0..v_{L-1}
+        scale = (d // H) ** -0.5
+        for i in range(L):
+            ca, sa, ffn = self.cross_attn_layers[i], self.self_attn_layers[i], self.ffn_layers[i]
+            q = ops.linear(queries, pk["ca_q_w"][i], pk["ca_q_b"][i])
+            a = ops.attention(q, kv_all[:, i * d:(i + 1) * d], kv_all[:, (L + i) * d:(L + i + 1) * d], H, scale, mask_bits=bits)
+            if ca.fix:
+                queries = ops.layernorm(_lin(a, ca.attn.out_proj), ca.norm.weight, ca.norm.bias, res=queries)
+            else:
+                queries = _lin(a, ca.attn.out_proj, res=queries)
+            qkv = ops.linear(queries, sa.attn.in_proj_weight, sa.attn.in_proj_bias)      # [Q, 3d]
+            a = ops.attention(qkv[:, :d], qkv[:, d:2 * d], qkv[:, 2 * d:], H, scale)
+            queries = ops.layernorm(_lin(a, sa.attn.out_proj), sa.norm.weight, sa.norm.bias, res=queries)
+            hdn = _lin(queries, ffn.net[0], act=("relu" if self.activation_fn == "relu" else "gelu"))
+            hdn = _lin(hdn, ffn.net[3], res=queries)
+            queries = ops.layernorm(hdn, ffn.norm.weight, ffn.norm.bias)
+            cls, sem, logits, bits = self._head(queries, mask_feats, i == L - 1)
+            aux.append(dict(cls_preds=cls, sem_preds=sem, masks=logits, centers=None, sizes=None))
+        final = aux.pop()
+        final["hidden_states"] = queries
+        final["attn_mask_bits"] = bits
+        # the reference's aux list is one entry short in this variant (pred_centers misses the layer-0
+        # placeholder, :653-655, and the zip at :781-783 truncates): keep the same length
+        return final, aux[:-1]
 
     # ---- one scene -----------------------------------------------------------------------------------
     def _forward_scene(self, x, sp_pos, sp_pos_wo, q_in, q_pos, q2d_feat, q2d_pos, lo, hi):
@@ -340,9 +415,15 @@ class ScanNetQueryDecoder(nn.Module):
     # ---- reference-shaped entry point (:417-435) --------------------------------------------------
     def forward(self, x, sp_pos=None, sp_pos_wo_elastic=None, queries=None, queries_pos=None, dinox_queries=None,
                 dinox_query_pos=None, scene_range=None):
-        assert (sp_pos is not None) and (queries_pos is not None) and (scene_range is not None)
         finals, auxes = [], []
-        for j in range(len(x)):
+        if not self.add_positional_embedding:
+            for j in range(len(x)):
+                f, a = self._forward_scene_plain(x[j], queries[j])
+                finals.append(f)
+                auxes.append(a)
+        else:
+            assert (sp_pos is not None) and (queries_pos is not None) and (scene_range is not None)
+        for j in range(len(x) if self.add_positional_embedding else 0):
             f, a = self._forward_scene(
                 x[j], sp_pos[j], sp_pos_wo_elastic[j] if sp_pos_wo_elastic is not None else sp_pos[j], queries[j],
                 queries_pos[j], dinox_queries[j] if dinox_queries is not None else None,

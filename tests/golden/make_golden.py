@@ -138,6 +138,14 @@ DECODER_KW_SCANNET200 = dict(
 DECODER_KW_SCANNETV2 = dict(DECODER_KW_SCANNET200, num_instance_classes=18, num_semantic_classes=20,
                             in_channels=32, normalize_box_prediction=False)
 
+# Baseline_ScanNet200 prototype: no positional embedding, no 2D-query attention (configs/prototypes/Baseline_ScanNet200.py)
+DECODER_KW_PLAIN = dict(
+    add_dinox_query_ca=False, add_dinox_query_ca_mask=True, dinox_query_ca_mask_threshold=0.2,
+    num_layers=6, num_instance_queries=0, num_semantic_queries=0, num_instance_classes=198,
+    num_semantic_classes=200, num_semantic_linears=1, in_channels=96, d_model=256, num_heads=8,
+    hidden_dim=1024, dropout=0.0, activation_fn="gelu", iter_pred=True, attn_mask=True,
+    fix_attention=True, objectness_flag=False)
+
 TEST_CFG = dict(topk_insts=600, inst_score_thr=0.0, pan_score_thr=0.5, npoint_thr=100,
                 obj_normalization=True, sp_score_thr=0.4, nms=True, matrix_nms_kernel="linear",
                 stuff_classes=[0, 1])
@@ -207,6 +215,23 @@ def golden_decoder(dec_mod, name, kw, S, M, query_subset=None):
             arrays[f"aux{li}_sizes"] = aux["sizes"][0]
     save(name, **arrays)
     return dec
+
+
+def golden_decoder_plain(dec_mod, name, S):
+    torch.manual_seed(0)
+    dec = dec_mod.ScanNetQueryDecoder(**DECODER_KW_PLAIN).eval()
+    assign_det_weights(dec, "decoder.")
+    x, pos, pos_wo, q2d_feat, q2d_pos, lo, hi = decoder_inputs(name, S, 3, 96)
+    dec.return_hidden_states = True
+    dec.return_aux_outputs = True
+    with torch.no_grad():
+        out = dec([x], None, None, [x], None, None, None, None)
+    arrays = dict(x=x, cls_preds=out["cls_preds"][0], sem_preds=out["sem_preds"][0], masks=out["masks"][0],
+                  hidden_states=out["hidden_states"][0])
+    for li, aux in enumerate(out["aux_outputs"]):
+        arrays[f"aux{li}_cls"] = aux["cls_preds"][0]
+        arrays[f"aux{li}_masks"] = aux["masks"][0]
+    save(name, **arrays)
 
 
 def golden_nms(arch_mod):
@@ -285,6 +310,7 @@ def main():
     golden_decoder(dec_mod, "decoder_s64_q64", DECODER_KW_SCANNET200, S=64, M=10)
     golden_decoder(dec_mod, "decoder_s96_q16", DECODER_KW_SCANNET200, S=96, M=7, query_subset=16)
     golden_decoder(dec_mod, "decoder_v2_s48", DECODER_KW_SCANNETV2, S=48, M=5)
+    golden_decoder_plain(dec_mod, "decoder_plain_s40", S=40)
     golden_nms(arch_mod)
     golden_architecture(seg, "arch_qall", query_num=-1)
     golden_architecture(seg, "arch_q40", query_num=40)

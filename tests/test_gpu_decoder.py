@@ -241,3 +241,58 @@ def test_architecture_matches_reference_golden(name, query_num, box):
     assert (pd.pts_semantic_mask[1] != g["pan_sem"].numpy()).mean() < 5e-3
     assert (pd.pts_instance_mask[1] != g["pan_inst"].numpy()).mean() < 5e-3
     assert sorted(pd.sort_and_mask[0].cpu().tolist()) == sorted(g["topk_idx"].tolist())
+
+
+def test_plain_decoder_matches_reference_golden():
+    """Non-positional decoder variant of the Baseline_ScanNet200 prototype."""
+    from segdino3d_amd.decoder import ScanNetQueryDecoder
+    from test_oracle_golden import plain_decoder_state_dict
+    d = dev()
+    g = load("decoder_plain_s40")
+    kw = {k: v for k, v in DEC_KW.items() if k not in ("add_box_size_pred", "add_positional_embedding", "pos_type",
+                                                         "temperature", "box_modulate_ca", "normalize_box_prediction")}
+    kw["add_dinox_query_ca"] = False
+    dec = ScanNetQueryDecoder(**kw).eval()
+    sd = plain_decoder_state_dict()
+    dec.load_state_dict({k[len("decoder."):]: v for k, v in sd.items()})
+    dec.to(d)
+    out = dec([g["x"].to(d)], None, None, [g["x"].to(d)], None, None, None, None)
+    assert len(out["aux_outputs"]) == 5 and out["centers"][0] is None
+
+    def rows_ok(got, ref, what, strict):
+        err = (got.cpu() - ref).abs()
+        bad = (err > 2e-3 + 2e-3 * ref.abs()).any(dim=1).float().mean().item()
+        assert bad <= (0.0 if strict else 0.10), f"{what}: {bad:.1%} rows outside tolerance (max err {err.max().item():.3e})"
+    for li in range(5):
+        rows_ok(out["aux_outputs"][li]["cls_preds"][0], g[f"aux{li}_cls"], f"aux{li} cls", li <= 1)
+        rows_ok(out["aux_outputs"][li]["masks"][0], g[f"aux{li}_masks"], f"aux{li} masks", li <= 1)
+    for k in ("cls_preds", "sem_preds", "masks", "hidden_states"):
+        rows_ok(out[k][0], g[k], k, False)
+
+
+def test_baseline_prototype_end_to_end_matches_oracle():
+    """Baseline_ScanNet200 prototype (rgb-only Res16UNet34C + non-positional decoder) through build_architecture."""
+    import segdino3d_amd as seg
+    from oracle import decoder_ref as D, postprocess_ref as P, sparse_ref as R
+    from segdino3d_amd.configs import baseline_scannet200_model_cfg
+    from segdino3d_amd.synth import make_scene
+    d = dev()
+    pts, tgt = make_scene(31, n_points=9000, n_superpoints=60, n_query2d=5)
+    model = seg.build_architecture(baseline_scannet200_model_cfg()).eval()
+    sd = {k: det_param(k, v.shape).to(v.dtype) for k, v in model.state_dict().items()}
+    model.load_state_dict(sd)
+    model.to(d)
+    model.to_host = False
+    with torch.no_grad():
+        res = model([pts.to(d)], [tgt.to(d)])
+    out = model.last_outputs
+    sp = tgt.extra_features["super_point_masks"]
+    f, _, _ = R.mink_forward_wrapper(sd, pts, None, sp, mode="only_rgb")
+    cfg = D.DecoderCfg(add_positional_embedding=False, add_dinox_query_ca=False, add_box_size_pred=False,
+                       box_modulate_ca=False, normalize_box_prediction=False)
+    ref = D.decoder_forward(sd, cfg, f, None, None, f, None, None, None, None, None)
+    err = (out["masks"][0].cpu() - ref["masks"]).abs()
+    bad = (err > 5e-3 + 5e-3 * ref["masks"].abs()).any(dim=1).float().mean().item()
+    assert bad <= 0.15, f"{bad:.1%} of query rows differ (max err {err.max().item():.3e})"
+    pd = res[0].pred_pts_seg
+    assert pd.pts_instance_mask[0].shape[1] == pts.shape[0] and pd.instance_boxes is None

@@ -126,3 +126,46 @@ def test_architecture_eval_path(name, query_num, box):
     assert (res["pts_semantic_mask"][1] != g["pan_sem"]).float().mean() < 1e-3
     assert (res["pts_instance_mask"][1] != g["pan_inst"]).float().mean() < 1e-3
     assert torch.equal(torch.sort(res["sort_and_mask"][0])[0], torch.sort(g["topk_idx"])[0])
+
+
+def plain_decoder_state_dict(in_channels=96, n_inst=198, n_sem=200, L=6, d=256, hidden=1024):
+    """state_dict of the non-positional decoder variant (Baseline_ScanNet200 prototype)."""
+    shapes = {}
+
+    def lin(name, o, i):
+        shapes[name + ".weight"] = (o, i)
+        shapes[name + ".bias"] = (o,)
+
+    def ln(name):
+        shapes[name + ".weight"] = (d,)
+        shapes[name + ".bias"] = (d,)
+
+    lin("input_proj.0", d, in_channels); ln("input_proj.1")
+    lin("query_proj.0", d, in_channels); lin("query_proj.2", d, d)
+    lin("x_mask.0", d, in_channels); lin("x_mask.2", d, d)
+    ln("out_norm"); lin("out_cls.0", d, d); lin("out_cls.2", n_inst + 1, d); lin("out_sem", n_sem + 1, d)
+    for i in range(L):
+        for n in ("cross_attn_layers", "self_attn_layers"):
+            shapes[f"{n}.{i}.attn.in_proj_weight"] = (3 * d, d)
+            shapes[f"{n}.{i}.attn.in_proj_bias"] = (3 * d,)
+            lin(f"{n}.{i}.attn.out_proj", d, d)
+            ln(f"{n}.{i}.norm")
+        lin(f"ffn_layers.{i}.net.0", hidden, d); lin(f"ffn_layers.{i}.net.3", d, hidden); ln(f"ffn_layers.{i}.norm")
+    return {"decoder." + k: det_param("decoder." + k, s) for k, s in shapes.items()}
+
+
+def test_plain_decoder_matches_reference():
+    g = load("decoder_plain_s40")
+    sd = plain_decoder_state_dict()
+    cfg = D.DecoderCfg(add_positional_embedding=False, add_dinox_query_ca=False, add_box_size_pred=False,
+                       box_modulate_ca=False, normalize_box_prediction=False)
+    out = D.decoder_forward(sd, cfg, g["x"], None, None, g["x"], None, None, None, None, None)
+    tol = dict(rtol=2e-4, atol=2e-4)
+    # reference quirk: without positional embedding `pred_centers` is one entry shorter than `cls_preds`
+    # (:653-655 vs :758), and the zip at :781-783 therefore yields 5 aux outputs instead of 6
+    assert "aux5_cls" not in g
+    for li in range(5):
+        torch.testing.assert_close(out["aux"][li]["cls_preds"], g[f"aux{li}_cls"], **tol)
+        torch.testing.assert_close(out["aux"][li]["masks"], g[f"aux{li}_masks"], **tol)
+    for k in ("cls_preds", "sem_preds", "masks", "hidden_states"):
+        torch.testing.assert_close(out[k], g[k], **tol)
