@@ -115,6 +115,15 @@ int sd3d_pool_superpoints(const float* feat, int ld_feat, int C, const int32_t* 
 int sd3d_gather_gemm(const float* in0, int ld0, int C0, const float* in1, int ld1, const int32_t* nbr, const float* wt,
                      int K, int Cin, int Cout, int64_t M, const float* scale, const float* shift, const float* res,
                      int ld_res, float* out, int ld_out, int act, int nt, void* ws, size_t ws_bytes, void* stream);
+/* Opt-in variant of sd3d_gather_gemm that evaluates the fp32 products as sums of bf16 MFMA products
+ * (csrc/gather_gemm_split.hip).  wt_split = the fp32 weights [K, Cout, Cin] split into bf16 terms,
+ * w = t0 + t1 (+ t2) with t_i = bf16_rne(w - sum_{j<i} t_j), laid out [2 or 3][K][Cout][Cin];
+ * terms = 3 (two terms per operand, error ~2^-16 per product) or 6 (three terms, ~2^-24: fp32-grade).
+ * Not used unless the host asks for it (SD3D_GEMM_MODE); the default path is the exact fp32 MFMA. */
+int sd3d_gather_gemm_split(const float* in0, int ld0, int C0, const float* in1, int ld1, const int32_t* nbr,
+                           const uint16_t* wt_split, int terms, int K, int Cin, int Cout, int64_t M, const float* scale,
+                           const float* shift, const float* res, int ld_res, float* out, int ld_out, int act, int nt,
+                           void* ws, size_t ws_bytes, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Decoder kernels (segdino3d/models/decoder/instance_seg_3d_decoder.py:606-799,

@@ -1,5 +1,5 @@
 // extern "C" entry points declared in include/segdino3d_hip.h.  Thin argument checking + launch.
-#include "common.h"
+#include "gg_common.h"
 #include "../../include/segdino3d_hip.h"
 #include <string.h>
 #include <stdio.h>
@@ -32,23 +32,8 @@ int launch_pool_superpoints(const float*, int, int, const int32_t*, const int32_
                             int64_t, float*, float*, hipStream_t);
 int launch_voxel_keys(const float*, int, int64_t, float, const float*, int, int, int32_t*, uint64_t*, int32_t*, int32_t*, hipStream_t);
 
-struct GGParams {
-    const float* in0; int ld0; int C0;
-    const float* in1; int ld1;
-    const int32_t* nbr;
-    const float* wt;
-    int K, Cin, Cout;
-    int64_t M;
-    const float* scale; const float* shift;
-    const float* res; int ld_res;
-    float* out; int ld_out;
-    int act;
-    int col_groups;
-    int dbg;
-    int ksplit;
-    float* ws;
-};
 int launch_gather_gemm(const GGParams&, int, void*, size_t, hipStream_t);
+int launch_gather_gemm_split(const GGParams&, int, int, const void*, void*, size_t, hipStream_t);
 
 int launch_layernorm(const float*, int, const float*, int, const float*, const float*, float, int64_t, int, float*, int, int, hipStream_t);
 int launch_sine_pe(const float*, int, int64_t, const float*, const float*, const int8_t*, int, const float*, int, const float*, int, float*, int, hipStream_t);
@@ -169,6 +154,20 @@ int sd3d_gather_gemm(const float* in0, int ld0, int C0, const float* in1, int ld
     p.ksplit = 1;
     p.ws = nullptr;
     return launch_gather_gemm(p, nt, ws, ws_bytes, ST);
+}
+
+int sd3d_gather_gemm_split(const float* in0, int ld0, int C0, const float* in1, int ld1, const int32_t* nbr,
+                           const uint16_t* wt_split, int terms, int K, int Cin, int Cout, int64_t M, const float* scale,
+                           const float* shift, const float* res, int ld_res, float* out, int ld_out, int act, int nt,
+                           void* ws, size_t ws_bytes, void* stream) {
+    GGParams p;
+    p.in0 = in0; p.ld0 = ld0; p.C0 = C0; p.in1 = in1; p.ld1 = ld1; p.nbr = nbr; p.wt = nullptr; p.K = K; p.Cin = Cin; p.Cout = Cout;
+    p.M = M; p.scale = scale; p.shift = shift; p.res = res; p.ld_res = ld_res; p.out = out; p.ld_out = ld_out; p.act = act;
+    p.col_groups = 1;
+    p.dbg = 0;
+    p.ksplit = 1;
+    p.ws = nullptr;
+    return launch_gather_gemm_split(p, nt, terms, wt_split, ws, ws_bytes, ST);
 }
 
 int sd3d_layernorm(const float* x, int ld_x, const float* res, int ld_res, const float* w, const float* b, float eps, int64_t M,

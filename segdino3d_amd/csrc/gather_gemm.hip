@@ -19,25 +19,8 @@
 // h.  Any bijection between (instruction index kk, half h) and the 32 channels of a chunk is valid
 // as long as A and B agree, so half h takes channels h*16 + kk: 16 contiguous floats per lane,
 // loaded as 4 x dwordx4.
-#include "common.h"
+#include "gg_common.h"
 #include <stdlib.h>
-
-struct GGParams {
-    const float* in0; int ld0; int C0;        // input features, first C0 channels
-    const float* in1; int ld1;                // optional second source for channels C0..Cin-1 (skip concat)
-    const int32_t* nbr;                       // [K][M] gather indices (-1 = no neighbour) or NULL (identity, K == 1)
-    const float* wt;                          // [K][Cout][Cin]
-    int K, Cin, Cout;
-    int64_t M;                                // output rows
-    const float* scale; const float* shift;   // per-column, optional
-    const float* res; int ld_res;             // optional residual
-    float* out; int ld_out;
-    int act;                                  // 0 none, 1 relu, 2 gelu(erf), 3 sigmoid
-    int col_groups;                           // ceil(Cout / (32*NT))
-    int dbg;                                  // timing experiments only (SD3D_GG_DBG): 1 = no LDS atomics, 2 = no loads/MFMA
-    int ksplit;                               // lock-step kernel only: gridDim.z offset slices (partials -> ws)
-    float* ws;                                // [ksplit][M][Cout] partial sums when ksplit > 1
-};
 
 template <int NT>
 struct Frag {
@@ -75,21 +58,6 @@ __device__ __forceinline__ void mma_frag(f32x16 (&acc)[NT], const Frag<NT>& f) {
 #pragma unroll
             for (int t = 0; t < NT; ++t)
                 acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(f.a[q][e], f.b[t][q][e], acc[t], 0, 0, 0);
-}
-
-__device__ __forceinline__ int next_active(uint64_t m0, uint64_t m1, int after) {
-    // smallest set bit index > after in the 128-bit mask (m1:m0), or -1
-    int s = after + 1;
-    if (s < 64) {
-        const uint64_t r = m0 >> s;
-        if (r) return s + __builtin_ctzll(r);
-        s = 64;
-    }
-    if (s < 128) {
-        const uint64_t r = m1 >> (s - 64);
-        if (r) return s + __builtin_ctzll(r);
-    }
-    return -1;
 }
 
 // KS = 1: every wave owns a (row tile, column group) and walks all (offset, chunk) steps.
@@ -896,6 +864,10 @@ __global__ __launch_bounds__(256) void gather_gemm_compact4_kernel(const GGParam
 // nt == -51          : pipelined pair-compacted kernel (32 columns per pass)
 // nt == -61          : pipelined pair-compacted kernel with per-wave private LDS accumulators (no atomics)
 // nt == -41 / -42    : single-pass pair-compacted kernel over all Cout <= 128 columns, 128 / 256 rows per workgroup
+void launch_splitk_epilogue(const GGParams& p, hipStream_t st) {
+    hipLaunchKernelGGL(splitk_epilogue_kernel, dim3((unsigned)cdiv(p.M * p.Cout, 256)), dim3(256), 0, st, p);
+}
+
 int launch_gather_gemm(const GGParams& p_in, int nt, void* ws, size_t ws_bytes, hipStream_t st) {
     GGParams p = p_in;
     p.ksplit = 1;

@@ -249,10 +249,46 @@ def pool_superpoints(feat, C, inverse, icoords, voxel_size, sorted_idx, start, S
 #   >= 0.40       dense lock-step kernel with LDS-shared weights (the zeros it multiplies cost less than compaction)
 COMPACT_ATOMIC_DENSITY = 0.15
 COMPACT_PRIVATE_DENSITY = 0.40
+SPLIT_COMPACT_DENSITY = (0.08, 0.20)     # (atomic, private) thresholds when the dense kernel runs split-bf16
+
+
+# Opt-in arithmetic mode of the lock-step gather-GEMM (csrc/gather_gemm_split.hip): None = exact fp32 MFMA
+# (default, the mode every parity claim and the bench headline are made in), "bf16x3" / "bf16x6" = fp32
+# products evaluated as 3 / 6 bf16 MFMA products with fp32 accumulation.
+GEMM_MODE = _os.environ.get("SD3D_GEMM_MODE") or None
+if GEMM_MODE not in (None, "bf16x3", "bf16x6"):
+    raise ValueError(f"SD3D_GEMM_MODE must be bf16x3 or bf16x6, got {GEMM_MODE!r}")
+SPLIT_MIN_ROWS = 2048          # below this the launch is latency-bound and stays on the fp32 kernel
+_SPLIT_CACHE = {}
+
+
+def split_weights(wt, terms):
+    """fp32 [K, Cout, Cin] -> bf16 [terms_per_operand, K, Cout, Cin] with wt = sum of the terms (to ~2^-17 / 2^-25)."""
+    ns = {3: 2, 6: 3}[terms]
+    r = wt.detach().to(torch.float32).clone()
+    parts = []
+    for _ in range(ns):
+        t = r.to(torch.bfloat16)
+        parts.append(t)
+        r = r - t.to(torch.float32)
+    return torch.stack(parts).contiguous()
+
+
+def _cached_split(wt, terms):
+    key = (wt.data_ptr(), tuple(wt.shape), terms, wt._version)
+    hit = _SPLIT_CACHE.get(key)
+    if hit is None:
+        hit = split_weights(wt, terms)
+        _SPLIT_CACHE[key] = hit
+    return hit
+
+
+def clear_split_cache():
+    _SPLIT_CACHE.clear()
 
 
 def gather_gemm(x, wt, nbr=None, x2=None, scale=None, shift=None, res=None, act=None, out=None, M=None, nt=0,
-                density=None):
+                density=None, wt_split=None):
     """out[r, n] = act(scale[n] * sum_k sum_c X[nbr[k, r], c] * wt[k, n, c] + shift[n] + res[r, n]).
 
     x [V_in, C0] (rows may be strided), optional x2 [V_in, C1] = concatenated channels,
@@ -280,11 +316,19 @@ def gather_gemm(x, wt, nbr=None, x2=None, scale=None, shift=None, res=None, act=
     pr, ldr = (None, 0)
     if res is not None:
         pr, ldr = _rows(res, "res")
+    terms = 0
+    if wt_split is not None:
+        terms = {2: 3, 3: 6}[wt_split.shape[0]]
+    elif GEMM_MODE is not None and nt == 0 and M >= SPLIT_MIN_ROWS and Cin % 32 == 0:
+        terms = 3 if GEMM_MODE == "bf16x3" else 6
     if nt == 0 and density is not None and nbr is not None and GG_FORCE_NT is None:
-        if density < COMPACT_ATOMIC_DENSITY:
-            nt = -21
-        elif density < COMPACT_PRIVATE_DENSITY:
-            nt = -61
+        lo, hi = (COMPACT_ATOMIC_DENSITY, COMPACT_PRIVATE_DENSITY) if not terms else SPLIT_COMPACT_DENSITY
+        if density < lo:
+            nt, terms = -21, 0
+        elif density < hi:
+            nt, terms = -61, 0
+    if terms and wt_split is None:
+        wt_split = _cached_split(wt, terms)
     if GG_FORCE_NT is not None and nt == 0:
         sub = (Cout + 31) // 32
         eff = GG_FORCE_NT if GG_FORCE_NT > 0 else (-GG_FORCE_NT - 10 if GG_FORCE_NT <= -11 else 1)
@@ -297,6 +341,16 @@ def gather_gemm(x, wt, nbr=None, x2=None, scale=None, shift=None, res=None, act=
     if nbr is not None and K >= 8 and M * Cout <= (1 << 22):      # small launch: allow split-K partials
         ws = _WS2.get(8 * M * Cout * 4, x.device)
         ws_ptr, ws_n = ws.data_ptr(), ws.numel()
+    if terms:
+        if wt_split.dtype != torch.bfloat16 or not wt_split.is_contiguous() or tuple(wt_split.shape[1:]) != (K, Cout, Cin):
+            raise ValueError("wt_split must be contiguous bf16 [2|3, K, Cout, Cin]")
+        _lib.check(lib.sd3d_gather_gemm_split(p0, ld0, C0, p1, ld1, _ptr(nbr, torch.int32, "nbr"), wt_split.data_ptr(),
+                                              terms, K, Cin, Cout, M, _ptr(scale, torch.float32, "scale"),
+                                              _ptr(shift, torch.float32, "shift"), pr, ldr, po, ldo, ACT[act],
+                                              max(nt, 0), ws_ptr, ws_n, _stream()), "gather_gemm_split")
+        if hook is not None:
+            hook.after()
+        return out
     _lib.check(lib.sd3d_gather_gemm(p0, ld0, C0, p1, ld1, _ptr(nbr, torch.int32, "nbr"), _ptr(wt, torch.float32, "wt"),
                                     K, Cin, Cout, M, _ptr(scale, torch.float32, "scale"),
                                     _ptr(shift, torch.float32, "shift"), pr, ldr, po, ldo, ACT[act], nt, ws_ptr, ws_n,

@@ -210,3 +210,63 @@ def test_spconvunet_forward_wrapper_matches_oracle():
     scale = rf.abs().max().item()
     assert f[0].shape == (100, 32)
     assert err <= 2e-3 * max(scale, 1.0), f"spconv backbone features differ: max abs err {err} (scale {scale})"
+
+
+# ------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("terms,tol", [(3, 3e-5), (6, 2e-6)])
+def test_split_bf16_gather_gemm_accuracy(terms, tol):
+    """Opt-in split-bf16 MFMA mode: error against an fp64 product, relative to the row's sum of
+    |a||b| (the scale rounding errors live on).  bf16x6 must be fp32-grade (<= 2e-6, the exact-fp32
+    kernel measures ~4e-7 on the same data); bf16x3 stays within 3e-5."""
+    from segdino3d_amd import ops
+    from segdino3d_amd.sparse import SceneMaps
+    from segdino3d_amd.synth import make_scene
+    d = dev()
+    pts, tgt = make_scene(5, 30000, 400, 40)
+    maps = SceneMaps(pts.to(d), 0.02, 4, superpoints=tgt.extra_features["super_point_masks"].to(d))
+    g = torch.Generator().manual_seed(terms)
+    for lvl, cin, cout, two in [(1, 64, 64, False), (2, 128, 96, True), (3, 256, 128, False), (0, 32, 32, False)]:
+        nbr = maps.same(lvl, 3)
+        K, M = nbr.shape
+        x = torch.randn(M, cin, generator=g) * torch.exp(torch.randn(M, 1, generator=g))
+        w = torch.randn(K, cout, cin, generator=g) * (K * cin) ** -0.5
+        scale = torch.rand(cout, generator=g) + 0.5
+        shift = torch.randn(cout, generator=g)
+        xd, wd = x.to(d), w.to(d)
+        kw = dict(nbr=nbr, scale=scale.to(d), shift=shift.to(d), act="relu")
+        if two:
+            kw["x2"] = xd[:, cin // 2:]
+            xin = xd[:, :cin // 2]
+        else:
+            xin = xd
+        got = ops.gather_gemm(xin, wd, wt_split=ops.split_weights(wd, terms), **kw).double().cpu()
+        exact = ops.gather_gemm(xin, wd, **kw).double().cpu()
+        # fp64 reference and error scale
+        idx = nbr.cpu().long()
+        ref = torch.zeros(M, cout, dtype=torch.float64)
+        mag = torch.zeros(M, cout, dtype=torch.float64)
+        xx, ww = x.double(), w.double()
+        for k in range(K):
+            ok = idx[k] >= 0
+            rows = xx[idx[k].clamp(min=0)] * ok[:, None]
+            ref += rows @ ww[k].T
+            mag += rows.abs() @ ww[k].abs().T
+        ref = torch.relu(ref * scale.double() + shift.double())
+        mag = mag * scale.double() + shift.abs().double() + 1e-30
+        err = ((got - ref).abs() / mag).max().item()
+        err32 = ((exact - ref).abs() / mag).max().item()
+        assert err < tol, f"terms={terms} level {lvl}: {err:.2e} (fp32 kernel {err32:.2e})"
+        assert err32 < 2e-6
+
+
+def test_split_bf16_identity_rows_and_ragged_edges():
+    from segdino3d_amd import ops
+    d = dev()
+    g = torch.Generator().manual_seed(9)
+    for M, cin, cout in [(2048, 256, 256), (4099, 96, 201), (33, 32, 18)]:
+        x = torch.randn(M, cin, generator=g).to(d)
+        w = (torch.randn(cout, cin, generator=g) * cin ** -0.5).to(d)
+        b = torch.randn(cout, generator=g).to(d)
+        ref = torch.nn.functional.linear(x.double(), w.double(), b.double())
+        got = ops.gather_gemm(x, w, shift=b, wt_split=ops.split_weights(w.unsqueeze(0), 6))
+        assert (got.double() - ref).abs().max().item() < 5e-6 * ref.abs().max().item()
