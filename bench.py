@@ -206,6 +206,8 @@ def main():
     tot_bytes = tot_flops = 0
     for _, _, meta in timer.records:
         nbr = meta["nbr"]
+        if meta.get("pairs") is not None:              # pair-major convolution: count the real list entries
+            nbr = meta["pairs"].in_idx
         if nbr is None:
             P = meta["M"]
         else:
@@ -226,8 +228,8 @@ def main():
     tflops = tot_flops / sec / 1e12 if sec > 0 else 0.0
     t_hbm, t_mfma = tot_bytes / (HBM_PEAK_GBS * 1e9), tot_flops / (FP32_MFMA_PEAK_TFLOPS * 1e12)
     mfma_bound = t_mfma >= t_hbm
-    roofline = {"bound": "mfma" if mfma_bound else "hbm", "kernel": "gather_gemm family (sd3d_gather_gemm: "
-                "gather_gemm_lds_kernel / gather_gemm_compact*_kernel / gather_gemm_kernel)",
+    roofline = {"bound": "mfma" if mfma_bound else "hbm", "kernel": "sparse-conv / linear GEMM family (sd3d_pair_conv: pair_gemm_kernel + "
+                "pair_reduce_kernel; sd3d_gather_gemm: gather_gemm_lds_kernel / gather_gemm_kernel)",
                 "achieved": round(tflops if mfma_bound else hbm_gbs, 2),
                 "peak": FP32_MFMA_PEAK_TFLOPS if mfma_bound else HBM_PEAK_GBS,
                 "unit": "TFLOP/s" if mfma_bound else "GB/s",

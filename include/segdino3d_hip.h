@@ -125,6 +125,25 @@ int sd3d_gather_gemm_split(const float* in0, int ld0, int C0, const float* in1, 
                            const float* shift, const float* res, int ld_res, float* out, int ld_out, int act, int nt,
                            void* ws, size_t ws_bytes, void* stream);
 
+/* Pair-major sparse convolution (csrc/pair_gemm.hip) - the same contract as sd3d_gather_gemm with a
+ * neighbour table (MinkowskiConvolution / SubMConv3d + folded BN + residual + activation), evaluated
+ * over the rulebook laid out offset-major so that every MFMA row is a real (in, out) pair.
+ * sd3d_pair_lists builds, once per neighbour table nbr [K, M]:
+ *   pos [K, M]      position of pair (k, r) in the list, -1 where nbr[k][r] < 0
+ *   in_idx [p_cap]  gathered input row of each list entry; every offset's segment is padded to a
+ *                   multiple of 128 entries with -1
+ *   tile_k [p_cap/128]  offset of each 128-entry tile, -1 past the end of the list
+ * p_cap: multiple of 128, >= (number of pairs) + 127 * K (pairs beyond the capacity are dropped:
+ * size it from the pair count sd3d_kernel_map returns).
+ * sd3d_pair_conv: part = caller scratch of >= p_cap * Cout floats.  Cin % 32 == 0, Cout % 4 == 0. */
+size_t sd3d_pair_lists_ws_bytes(int K, int64_t M);
+int sd3d_pair_lists(const int32_t* nbr, int K, int64_t M, int64_t p_cap, int32_t* pos, int32_t* in_idx, int32_t* tile_k,
+                    void* ws, size_t ws_bytes, void* stream);
+int sd3d_pair_conv(const float* in0, int ld0, int C0, const float* in1, int ld1, const int32_t* in_idx,
+                   const int32_t* tile_k, int64_t p_cap, const int32_t* pos, const float* wt, int K, int Cin, int Cout,
+                   int64_t M, const float* scale, const float* shift, const float* res, int ld_res, float* out,
+                   int ld_out, int act, float* part, size_t part_bytes, void* stream);
+
 /* ---------------------------------------------------------------------------------------------
  * Decoder kernels (segdino3d/models/decoder/instance_seg_3d_decoder.py:606-799,
  * segdino3d/models/module/attention.py:186-395, segdino3d/models/module/utils.py:53-105)

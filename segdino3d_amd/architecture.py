@@ -149,6 +149,7 @@ class Baseline3D(nn.Module):
         return queries, queries_pos, targets
 
     # ---- forward (:308-346) --------------------------------------------------------------------------------
+    @ops.bound_stream
     def forward(self, samples, targets: List = None):
         if self.training:
             raise NotImplementedError("segdino3d_amd: eval-mode forward only; the training step (criterion + backward, "
@@ -219,6 +220,7 @@ class Baseline3D(nn.Module):
         keep = (score_mask & npoint_all).nonzero().squeeze(1)
         return keep, score_mask, npoint_mask
 
+    @ops.bound_stream
     def predict_by_feat(self, samples, out, superpoints):
         cfg = self.test_cfg
         com = self._instances_common(samples, out, superpoints)

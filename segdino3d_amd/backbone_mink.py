@@ -167,22 +167,22 @@ class Res16UNetBase(nn.Module):
         return self._packed
 
     # ---- network ---------------------------------------------------------------------------------
-    def _cbr(self, pk, x, conv, bn, nbr, x2=None, M=None, density=None):
+    def _cbr(self, pk, x, conv, bn, tab, x2=None):
         s, b = pk[bn]
-        return ops.gather_gemm(x, pk[conv], nbr=nbr, x2=x2, scale=s, shift=b, act="relu", M=M, density=density)
+        return ops.gather_gemm(x, pk[conv], x2=x2, scale=s, shift=b, act="relu", **tab)
 
-    def _stage(self, pk, name, nblocks, x, nbr, x2=None, density=None):
+    def _stage(self, pk, name, nblocks, x, tab, x2=None):
         for j in range(nblocks):
             p = f"{name}.{j}"
             s1, b1 = pk[p + ".norm1"]
-            h = ops.gather_gemm(x, pk[p + ".conv1"], nbr=nbr, x2=x2, scale=s1, shift=b1, act="relu", density=density)
+            h = ops.gather_gemm(x, pk[p + ".conv1"], x2=x2, scale=s1, shift=b1, act="relu", **tab)
             if (p + ".downsample.0") in pk:
                 sd, bd = pk[p + ".downsample.1"]
                 res = ops.gather_gemm(x, pk[p + ".downsample.0"], x2=x2, scale=sd, shift=bd)
             else:
                 res = x
             s2, b2 = pk[p + ".norm2"]
-            x = ops.gather_gemm(h, pk[p + ".conv2"], nbr=nbr, scale=s2, shift=b2, res=res, act="relu", density=density)
+            x = ops.gather_gemm(h, pk[p + ".conv2"], scale=s2, shift=b2, res=res, act="relu", **tab)
             x2 = None
         return x
 
@@ -194,28 +194,29 @@ class Res16UNetBase(nn.Module):
         Ly = self.LAYERS
         k1 = self.conv1_kernel_size
         maps.prepare(same=[(0, k1)] + [(l, 3) for l in range(5)], strides=[0, 1, 2, 3])
-        dn = maps.density
-        k3 = [maps.same(l, 3) for l in range(5)]
-        d3 = [dn[("same", l, 3)] for l in range(5)]
-        out_p1 = self._cbr(pk, vox_feats, "conv0p1s1", "bn0", maps.same(0, k1), density=dn[("same", 0, k1)])
-        out = self._cbr(pk, out_p1, "conv1p1s2", "bn1", maps.down(0), density=dn[("down", 0)])
-        out_b1p2 = self._stage(pk, "block1", Ly[0], out, k3[1], density=d3[1])
-        out = self._cbr(pk, out_b1p2, "conv2p2s2", "bn2", maps.down(1), density=dn[("down", 1)])
-        out_b2p4 = self._stage(pk, "block2", Ly[1], out, k3[2], density=d3[2])
-        out = self._cbr(pk, out_b2p4, "conv3p4s2", "bn3", maps.down(2), density=dn[("down", 2)])
-        out_b3p8 = self._stage(pk, "block3", Ly[2], out, k3[3], density=d3[3])
-        out = self._cbr(pk, out_b3p8, "conv4p8s2", "bn4", maps.down(3), density=dn[("down", 3)])
-        out = self._stage(pk, "block4", Ly[3], out, k3[4], density=d3[4])
-        out = self._cbr(pk, out, "convtr4p16s2", "bntr4", maps.up(3), density=dn[("up", 3)])
-        out = self._stage(pk, "block5", Ly[4], out, k3[3], x2=out_b3p8, density=d3[3])
-        out = self._cbr(pk, out, "convtr5p8s2", "bntr5", maps.up(2), density=dn[("up", 2)])
-        out = self._stage(pk, "block6", Ly[5], out, k3[2], x2=out_b2p4, density=d3[2])
-        out = self._cbr(pk, out, "convtr6p4s2", "bntr6", maps.up(1), density=dn[("up", 1)])
-        out = self._stage(pk, "block7", Ly[6], out, k3[1], x2=out_b1p2, density=d3[1])
-        out = self._cbr(pk, out, "convtr7p2s2", "bntr7", maps.up(0), density=dn[("up", 0)])
-        out = self._stage(pk, "block8", Ly[7], out, k3[0], x2=out_p1, density=d3[0])
+        k3 = [maps.conv_table("same", l, 3) for l in range(5)]
+        dn = [maps.conv_table("down", l) for l in range(4)]
+        up = [maps.conv_table("up", l) for l in range(4)]
+        out_p1 = self._cbr(pk, vox_feats, "conv0p1s1", "bn0", maps.conv_table("same", 0, k1))
+        out = self._cbr(pk, out_p1, "conv1p1s2", "bn1", dn[0])
+        out_b1p2 = self._stage(pk, "block1", Ly[0], out, k3[1])
+        out = self._cbr(pk, out_b1p2, "conv2p2s2", "bn2", dn[1])
+        out_b2p4 = self._stage(pk, "block2", Ly[1], out, k3[2])
+        out = self._cbr(pk, out_b2p4, "conv3p4s2", "bn3", dn[2])
+        out_b3p8 = self._stage(pk, "block3", Ly[2], out, k3[3])
+        out = self._cbr(pk, out_b3p8, "conv4p8s2", "bn4", dn[3])
+        out = self._stage(pk, "block4", Ly[3], out, k3[4])
+        out = self._cbr(pk, out, "convtr4p16s2", "bntr4", up[3])
+        out = self._stage(pk, "block5", Ly[4], out, k3[3], x2=out_b3p8)
+        out = self._cbr(pk, out, "convtr5p8s2", "bntr5", up[2])
+        out = self._stage(pk, "block6", Ly[5], out, k3[2], x2=out_b2p4)
+        out = self._cbr(pk, out, "convtr6p4s2", "bntr6", up[1])
+        out = self._stage(pk, "block7", Ly[6], out, k3[1], x2=out_b1p2)
+        out = self._cbr(pk, out, "convtr7p2s2", "bntr7", up[0])
+        out = self._stage(pk, "block8", Ly[7], out, k3[0], x2=out_p1)
         return out
 
+    @ops.bound_stream
     def forward_wrapper(self, samples: List[torch.Tensor], targets, return_sp_mean_pos=False):
         feats, pos = [], []
         for pts, tgt in zip(samples, targets):

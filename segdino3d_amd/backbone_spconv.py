@@ -126,38 +126,39 @@ class SpConvUNet(nn.Module):
         return self._packed
 
     # ---- network -----------------------------------------------------------------------------------
-    def _resblock(self, pk, p, x, nbr, x2=None):
+    def _resblock(self, pk, p, x, tab, x2=None):
         """ResidualBlock.forward (:82-99): conv_branch(x) + i_branch(x); x may be the concat [x | x2]."""
         s0, b0 = pk[p + ".conv_branch.0"]
         h = ops.scale_shift_act(x, s0, b0, act="relu", x2=x2)
         s3, b3 = pk[p + ".conv_branch.3"]
-        h = ops.gather_gemm(h, pk[p + ".conv_branch.2"], nbr=nbr, scale=s3, shift=b3, act="relu")
+        h = ops.gather_gemm(h, pk[p + ".conv_branch.2"], scale=s3, shift=b3, act="relu", **tab)
         if (p + ".i_branch.0") in pk:
             ident = ops.gather_gemm(x, pk[p + ".i_branch.0"], x2=x2)
         else:
             assert x2 is None
             ident = x
-        return ops.gather_gemm(h, pk[p + ".conv_branch.5"], nbr=nbr, res=ident)
+        return ops.gather_gemm(h, pk[p + ".conv_branch.5"], res=ident, **tab)
 
     def _unet(self, pk, prefix, maps: SceneMaps, level, x):
-        nbr = maps.same(level, 3)
+        tab = maps.conv_table("same", level, 3)
         for r in range(self.block_reps):
-            x = self._resblock(pk, f"{prefix}blocks.block{r}", x, nbr)
+            x = self._resblock(pk, f"{prefix}blocks.block{r}", x, tab)
         n_levels = len(maps.n_vox)
         if level < n_levels - 1:
             ident = x
             s, b = pk[prefix + "conv.0"]
             h = ops.scale_shift_act(x, s, b, act="relu")
-            h = ops.gather_gemm(h, pk[prefix + "conv.2"], nbr=maps.down(level))
+            h = ops.gather_gemm(h, pk[prefix + "conv.2"], **maps.conv_table("down", level))
             h = self._unet(pk, prefix + "u.", maps, level + 1, h)
             s, b = pk[prefix + "deconv.0"]
             h = ops.scale_shift_act(h, s, b, act="relu")
-            h = ops.gather_gemm(h, pk[prefix + "deconv.2"], nbr=maps.up(level))
-            x = self._resblock(pk, f"{prefix}blocks_tail.block0", ident, nbr, x2=h)
+            h = ops.gather_gemm(h, pk[prefix + "deconv.2"], **maps.conv_table("up", level))
+            x = self._resblock(pk, f"{prefix}blocks_tail.block0", ident, tab, x2=h)
             for r in range(1, self.block_reps):
-                x = self._resblock(pk, f"{prefix}blocks_tail.block{r}", x, nbr)
+                x = self._resblock(pk, f"{prefix}blocks_tail.block{r}", x, tab)
         return x
 
+    @ops.bound_stream
     def forward_wrapper(self, samples: List[torch.Tensor], targets, return_sp_mean_pos=True):
         if self.training:
             raise NotImplementedError("segdino3d_amd backbone: eval-mode forward only (training step not built)")
@@ -176,7 +177,9 @@ class SpConvUNet(nn.Module):
             self.last_maps = maps
             cin_pad = (self.in_channels + 31) // 32 * 32
             vf = maps.voxel_features(pts, f2d, 2, cin_pad)
-            x = ops.gather_gemm(vf, pk["input_conv.0"], nbr=maps.same(0, 3))
+            nl = len(self.num_planes)
+            maps.prepare(same=[(l, 3) for l in range(nl)], strides=list(range(nl - 1)))
+            x = ops.gather_gemm(vf, pk["input_conv.0"], **maps.conv_table("same", 0, 3))
             x = self._unet(pk, "", maps, 0, x)
             s, b = pk["output_layer.0"]
             x = ops.scale_shift_act(x, s, b, act="relu")

@@ -34,6 +34,11 @@ int launch_voxel_keys(const float*, int, int64_t, float, const float*, int, int,
 
 int launch_gather_gemm(const GGParams&, int, void*, size_t, hipStream_t);
 int launch_gather_gemm_split(const GGParams&, int, int, const void*, void*, size_t, hipStream_t);
+size_t pair_lists_ws_bytes(int K, int64_t M);
+int launch_pair_lists(const int32_t*, int, int64_t, int64_t, int32_t*, int32_t*, int32_t*, void*, size_t, hipStream_t);
+int launch_pair_conv(const float*, int, int, const float*, int, const int32_t*, const int32_t*, int64_t, const int32_t*, const float*,
+                     int, int, int, int64_t, const float*, const float*, const float*, int, float*, int, int, float*, size_t,
+                     hipStream_t);
 
 int launch_layernorm(const float*, int, const float*, int, const float*, const float*, float, int64_t, int, float*, int, int, hipStream_t);
 int launch_sine_pe(const float*, int, int64_t, const float*, const float*, const int8_t*, int, const float*, int, const float*, int, float*, int, hipStream_t);
@@ -168,6 +173,19 @@ int sd3d_gather_gemm_split(const float* in0, int ld0, int C0, const float* in1, 
     p.ksplit = 1;
     p.ws = nullptr;
     return launch_gather_gemm_split(p, nt, terms, wt_split, ws, ws_bytes, ST);
+}
+
+size_t sd3d_pair_lists_ws_bytes(int K, int64_t M) { return pair_lists_ws_bytes(K, M); }
+int sd3d_pair_lists(const int32_t* nbr, int K, int64_t M, int64_t p_cap, int32_t* pos, int32_t* in_idx, int32_t* tile_k, void* ws,
+                    size_t ws_bytes, void* stream) {
+    return launch_pair_lists(nbr, K, M, p_cap, pos, in_idx, tile_k, ws, ws_bytes, ST);
+}
+int sd3d_pair_conv(const float* in0, int ld0, int C0, const float* in1, int ld1, const int32_t* in_idx, const int32_t* tile_k,
+                   int64_t p_cap, const int32_t* pos, const float* wt, int K, int Cin, int Cout, int64_t M, const float* scale,
+                   const float* shift, const float* res, int ld_res, float* out, int ld_out, int act, float* part,
+                   size_t part_bytes, void* stream) {
+    return launch_pair_conv(in0, ld0, C0, in1, ld1, in_idx, tile_k, p_cap, pos, wt, K, Cin, Cout, M, scale, shift, res, ld_res, out,
+                            ld_out, act, part, part_bytes, ST);
 }
 
 int sd3d_layernorm(const float* x, int ld_x, const float* res, int ld_res, const float* w, const float* b, float eps, int64_t M,

@@ -1,0 +1,317 @@
+// Pair-major sparse convolution (exact fp32 MFMA).
+//
+// The output-stationary kernels of gather_gemm.hip walk all K offsets for every 32-row output tile, so
+// at rulebook density d they spend 1/d of their MFMA time on zeros (d = 0.06 .. 0.6 on a ScanNet
+// scene), and the pair-compacted variants there are limited by LDS capacity (small row tiles -> the
+// 32-pair MFMA chunks are half empty and every small tile re-reads all K weight matrices).
+//
+// Here the rulebook is laid out pair-major ONCE per neighbour table (it is shared by every
+// convolution of a U-Net level):
+//     for k in 0..K-1:  the pairs (in = nbr[k][r], out = r) with in >= 0, in row order,
+//     each k segment padded to a multiple of 128 pairs (pad entries have in = -1)
+// so that a 128-pair tile has ONE weight matrix W[k] and every MFMA row is a real pair:
+//     pass 1  part[p][:] = X[in_idx[p]][:] . W[k(p)]^T        dense 128 x Cout x Cin tiles, lock-step
+//                                                              LDS-shared weights, fp32 MFMA
+//     pass 2  out[r][:]  = act(scale * sum_k part[pos[k][r]][:] + shift + res[r][:])   k ascending
+// pos[k][r] = position of pair (k, r) in the list or -1.  Pass 2 is pure streaming (HBM-bound);
+// the partial products cost 2 x 4 x P x Cout bytes of extra traffic, cheap next to the 157 TFLOP/s
+// fp32 matrix rate (>= 16 flop per byte moved at Cin = 96).  The sum order is fixed (full Cin dot
+// product per pair, then k ascending) so results are deterministic.
+#include "gg_common.h"
+
+#define PL_ROWS 2048            // rows per workgroup of the list-building kernels
+#define PT 128                  // pairs per tile / segment padding
+#define PBS_LD 36
+
+__device__ static inline int block_excl_scan_256p(int v, int* total, int* smem4) {
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    int inc = v;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        int t = __shfl_up(inc, d);
+        if (lane >= d) inc += t;
+    }
+    if (lane == 63) smem4[w] = inc;
+    __syncthreads();
+    int base = 0;
+    for (int i = 0; i < w; ++i) base += smem4[i];
+    *total = smem4[0] + smem4[1] + smem4[2] + smem4[3];
+    __syncthreads();
+    return base + inc - v;
+}
+
+// ---- list building ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void pair_count_kernel(const int32_t* __restrict__ nbr, int64_t M, int nblk,
+                                                         int32_t* __restrict__ blk_cnt) {
+    __shared__ int sm[4];
+    const int k = blockIdx.y, blk = blockIdx.x, tid = threadIdx.x;
+    int c = 0;
+#pragma unroll
+    for (int i = 0; i < PL_ROWS / 256; ++i) {
+        const int64_t row = (int64_t)blk * PL_ROWS + i * 256 + tid;
+        const bool v = row < M && nbr[(int64_t)k * M + row] >= 0;
+        c += __popcll(__ballot(v));
+    }
+    if ((tid & 63) == 0) sm[tid >> 6] = c;
+    __syncthreads();
+    if (tid == 0) blk_cnt[(int64_t)k * nblk + blk] = sm[0] + sm[1] + sm[2] + sm[3];
+}
+
+// one workgroup per offset k: exclusive scan of its block counts (in place) and its total
+__global__ __launch_bounds__(256) void pair_scan_kernel(int32_t* __restrict__ blk_cnt, int nblk, int32_t* __restrict__ totals) {
+    __shared__ int sm[4];
+    const int k = blockIdx.x, tid = threadIdx.x;
+    int running = 0;
+    for (int base = 0; base < nblk; base += 256) {
+        const int i = base + tid;
+        const int v = i < nblk ? blk_cnt[(int64_t)k * nblk + i] : 0;
+        int total;
+        const int ex = block_excl_scan_256p(v, &total, sm);
+        if (i < nblk) blk_cnt[(int64_t)k * nblk + i] = running + ex;
+        running += total;
+    }
+    if (tid == 0) totals[k] = running;
+}
+
+__global__ __launch_bounds__(256) void pair_fill_kernel(const int32_t* __restrict__ nbr, int K, int64_t M, int nblk,
+                                                        const int32_t* __restrict__ blk_off, const int32_t* __restrict__ totals,
+                                                        int64_t p_cap, int32_t* __restrict__ pos, int32_t* __restrict__ in_idx,
+                                                        int32_t* __restrict__ tile_k) {
+    __shared__ int sm[4];
+    __shared__ int wcnt[4];
+    const int k = blockIdx.y, blk = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    // segment start of offset k = sum of the padded totals before it
+    int s = 0;
+    for (int kk = tid; kk < k; kk += 256) s += (totals[kk] + PT - 1) / PT * PT;
+    int seg;
+    block_excl_scan_256p(s, &seg, sm);
+    const int seg_len = (totals[k] + PT - 1) / PT * PT;
+    if (blk == 0)
+        for (int t = tid; t < seg_len / PT; t += 256)
+            if ((int64_t)(seg / PT + t) * PT < p_cap) tile_k[seg / PT + t] = k;
+    int base = seg + blk_off[(int64_t)k * nblk + blk];
+    const uint64_t lt = (1ull << lane) - 1ull;
+#pragma unroll 1
+    for (int i = 0; i < PL_ROWS / 256; ++i) {
+        const int64_t row = (int64_t)blk * PL_ROWS + i * 256 + tid;
+        const int id = row < M ? nbr[(int64_t)k * M + row] : -1;
+        const uint64_t bal = __ballot(id >= 0);
+        if (lane == 0) wcnt[wv] = __popcll(bal);
+        __syncthreads();
+        int before = 0;
+        for (int w = 0; w < wv; ++w) before += wcnt[w];
+        const int all = wcnt[0] + wcnt[1] + wcnt[2] + wcnt[3];
+        __syncthreads();
+        const int p = base + before + __popcll(bal & lt);
+        if (row < M) pos[(int64_t)k * M + row] = (id >= 0 && p < p_cap) ? p : -1;
+        if (id >= 0 && p < p_cap) in_idx[p] = id;
+        base += all;
+    }
+}
+
+// ---- pass 1: dense tiles over the pair list --------------------------------------------------
+struct PGParams {
+    const float* in0; int ld0; int C0;
+    const float* in1; int ld1;
+    const int32_t* in_idx;                    // [n_tiles * 128]
+    const int32_t* tile_k;                    // [n_tiles], -1 = past the end
+    const float* wt;                          // [K][Cout][Cin]
+    int Cin, Cout;
+    float* part;                              // [n_tiles * 128][Cout]
+};
+
+template <int NT>
+__global__ __launch_bounds__(256) void pair_gemm_kernel(const PGParams p) {
+    __shared__ __attribute__((aligned(16))) float Bs[2][NT * 32 * PBS_LD];
+    const int k = p.tile_k[blockIdx.x];
+    if (k < 0) return;                                         // uniform over the workgroup
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int j = lane & 31, h = lane >> 5;
+    const int64_t prow0 = (int64_t)blockIdx.x * PT + wv * 32;
+    const int idx = p.in_idx[prow0 + j];
+    const bool mine = __ballot(idx >= 0) != 0ull;              // wave-uniform: any real pair in these 32?
+    const int ncol0 = blockIdx.y * NT * 32;
+    const int nchunks = p.Cin >> 5;
+    const float* __restrict__ W = p.wt + (int64_t)k * p.Cout * p.Cin;
+
+    f32x16 acc[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+
+    f32x4 bst[NT];
+    auto stage_load = [&](int chunk) {
+#pragma unroll
+        for (int i = 0; i < NT; ++i) {
+            const int f = tid + i * 256;
+            int n = ncol0 + (f >> 3);
+            n = n < p.Cout ? n : p.Cout - 1;
+            bst[i] = *(const f32x4*)(W + (int64_t)n * p.Cin + chunk * 32 + (f & 7) * 4);
+        }
+    };
+    auto stage_store = [&](int buf) {
+#pragma unroll
+        for (int i = 0; i < NT; ++i) {
+            const int f = tid + i * 256;
+            *(f32x4*)(&Bs[buf][(f >> 3) * PBS_LD + (f & 7) * 4]) = bst[i];
+        }
+    };
+    auto load_a = [&](f32x4 (&a)[4], int chunk) {
+        const int c = chunk * 32 + h * 16;
+        if (idx >= 0) {
+            const float* src = (c < p.C0) ? (p.in0 + (int64_t)idx * p.ld0 + c) : (p.in1 + (int64_t)idx * p.ld1 + (c - p.C0));
+#pragma unroll
+            for (int q = 0; q < 4; ++q) a[q] = *(const f32x4*)(src + q * 4);
+        } else {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) a[q] = f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+    };
+
+    f32x4 acur[4];
+    load_a(acur, 0);
+    stage_load(0);
+    stage_store(0);
+    __syncthreads();
+    int buf = 0;
+    for (int chunk = 0; chunk < nchunks; ++chunk) {
+        const bool has_next = chunk + 1 < nchunks;
+        f32x4 anxt[4];
+        if (has_next) {
+            stage_load(chunk + 1);
+            load_a(anxt, chunk + 1);
+        }
+        if (mine) {
+            const float* bb = &Bs[buf][j * PBS_LD + h * 16];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                f32x4 bq[NT];
+#pragma unroll
+                for (int t = 0; t < NT; ++t) bq[t] = *(const f32x4*)(bb + t * 32 * PBS_LD + q * 4);
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+#pragma unroll
+                    for (int t = 0; t < NT; ++t)
+                        acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(acur[q][e], bq[t][e], acc[t], 0, 0, 0);
+            }
+        }
+        if (!has_next) break;
+        stage_store(buf ^ 1);
+        __syncthreads();
+        buf ^= 1;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) acur[q] = anxt[q];
+    }
+    if (!mine) return;
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+        const int n = ncol0 + t * 32 + j;
+        if (n >= p.Cout) continue;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int64_t pr = prow0 + (r & 3) + 8 * (r >> 2) + 4 * h;
+            p.part[pr * p.Cout + n] = acc[t][r];
+        }
+    }
+}
+
+// ---- pass 2: fixed-order reduction over the offsets + epilogue --------------------------------
+struct PRParams {
+    const int32_t* pos; int K; int64_t M;
+    const float* part; int Cout;
+    const float* scale; const float* shift;
+    const float* res; int ld_res;
+    float* out; int ld_out; int act;
+};
+
+__global__ __launch_bounds__(256) void pair_reduce_kernel(const PRParams p) {
+    const int c4 = p.Cout >> 2;
+    const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int64_t r = e / c4;
+    if (r >= p.M) return;
+    const int q = (int)(e - r * c4) * 4;
+    f32x4 a = {0.f, 0.f, 0.f, 0.f};
+    for (int k0 = 0; k0 < p.K; k0 += 8) {
+        int ids[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) ids[u] = (k0 + u < p.K) ? p.pos[(int64_t)(k0 + u) * p.M + r] : -1;
+        f32x4 v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u)
+            v[u] = ids[u] >= 0 ? *(const f32x4*)(p.part + (int64_t)ids[u] * p.Cout + q) : f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int u = 0; u < 8; ++u)
+            if (ids[u] >= 0) a += v[u];
+    }
+    float y[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int n = q + i;
+        float t = a[i] * (p.scale ? p.scale[n] : 1.f) + (p.shift ? p.shift[n] : 0.f);
+        if (p.res) t += p.res[r * p.ld_res + n];
+        if (p.act == 1) t = fmaxf(t, 0.f);
+        else if (p.act == 2) t = 0.5f * t * (1.f + erff(t * 0.70710678118654752440f));
+        else if (p.act == 3) t = 1.f / (1.f + expf(-t));
+        y[i] = t;
+    }
+    *(f32x4*)(p.out + r * p.ld_out + q) = f32x4{y[0], y[1], y[2], y[3]};
+}
+
+// ---- launchers --------------------------------------------------------------------------------
+size_t pair_lists_ws_bytes(int K, int64_t M) {
+    const int64_t nblk = cdiv(M, PL_ROWS);
+    return (size_t)((int64_t)K * nblk + K) * sizeof(int32_t) + 256;
+}
+
+// p_cap: capacity of in_idx in pairs (multiple of 128, >= pairs + K * 127); tile_k has p_cap / 128 entries.
+int launch_pair_lists(const int32_t* nbr, int K, int64_t M, int64_t p_cap, int32_t* pos, int32_t* in_idx, int32_t* tile_k,
+                      void* ws, size_t ws_bytes, hipStream_t st) {
+    if (K <= 0 || M <= 0) return SD3D_OK;
+    if (p_cap <= 0 || (p_cap % PT)) return sd3d_set_error(SD3D_ERR_ARG, "pair_lists: p_cap must be a positive multiple of 128");
+    if (ws_bytes < pair_lists_ws_bytes(K, M)) return sd3d_set_error(SD3D_ERR_ARG, "pair_lists: workspace too small");
+    const int nblk = (int)cdiv(M, PL_ROWS);
+    int32_t* blk_cnt = (int32_t*)ws;
+    int32_t* totals = blk_cnt + (int64_t)K * nblk;
+    if (hipMemsetAsync(in_idx, 0xFF, (size_t)p_cap * sizeof(int32_t), st) != hipSuccess ||
+        hipMemsetAsync(tile_k, 0xFF, (size_t)(p_cap / PT) * sizeof(int32_t), st) != hipSuccess)
+        return sd3d_set_error(SD3D_ERR_LAUNCH, "pair_lists: memset failed");
+    hipLaunchKernelGGL(pair_count_kernel, dim3(nblk, K), dim3(256), 0, st, nbr, M, nblk, blk_cnt);
+    hipLaunchKernelGGL(pair_scan_kernel, dim3(K), dim3(256), 0, st, blk_cnt, nblk, totals);
+    hipLaunchKernelGGL(pair_fill_kernel, dim3(nblk, K), dim3(256), 0, st, nbr, K, M, nblk, blk_cnt, totals, p_cap, pos, in_idx, tile_k);
+    SD3D_CHECK_LAUNCH();
+    return SD3D_OK;
+}
+
+int launch_pair_conv(const float* in0, int ld0, int C0, const float* in1, int ld1, const int32_t* in_idx, const int32_t* tile_k,
+                     int64_t p_cap, const int32_t* pos, const float* wt, int K, int Cin, int Cout, int64_t M, const float* scale,
+                     const float* shift, const float* res, int ld_res, float* out, int ld_out, int act, float* part,
+                     size_t part_bytes, hipStream_t st) {
+    if (M <= 0 || Cout <= 0) return SD3D_OK;
+    if (Cin <= 0 || (Cin & 31)) return sd3d_set_error(SD3D_ERR_ARG, "pair_conv: Cin must be a positive multiple of 32");
+    if (Cout & 3) return sd3d_set_error(SD3D_ERR_ARG, "pair_conv: Cout must be a multiple of 4");
+    if (in1 && ((C0 & 31) || C0 > Cin)) return sd3d_set_error(SD3D_ERR_ARG, "pair_conv: concat split must be a multiple of 32");
+    if (!in1) C0 = Cin;
+    if ((ld0 & 3) || (in1 && (ld1 & 3)) || (ld_out & 3)) return sd3d_set_error(SD3D_ERR_ARG, "pair_conv: row strides must be multiples of 4 floats");
+    if (p_cap <= 0 || (p_cap % PT)) return sd3d_set_error(SD3D_ERR_ARG, "pair_conv: p_cap must be a positive multiple of 128");
+    if (part_bytes < (size_t)p_cap * Cout * sizeof(float)) return sd3d_set_error(SD3D_ERR_ARG, "pair_conv: partial-product buffer too small");
+    PGParams g;
+    g.in0 = in0; g.ld0 = ld0; g.C0 = C0; g.in1 = in1; g.ld1 = ld1; g.in_idx = in_idx; g.tile_k = tile_k; g.wt = wt;
+    g.Cin = Cin; g.Cout = Cout; g.part = part;
+    const int sub = (Cout + 31) / 32;
+    int nt = sub >= 4 ? 4 : sub;
+    if (sub > 4 && sub % 4) { for (int c = 4; c >= 1; --c) if (sub % c == 0) { nt = c; break; } }
+    const dim3 grid((unsigned)(p_cap / PT), (unsigned)cdiv(sub, nt));
+    switch (nt) {
+        case 1: hipLaunchKernelGGL(pair_gemm_kernel<1>, grid, dim3(256), 0, st, g); break;
+        case 2: hipLaunchKernelGGL(pair_gemm_kernel<2>, grid, dim3(256), 0, st, g); break;
+        case 3: hipLaunchKernelGGL(pair_gemm_kernel<3>, grid, dim3(256), 0, st, g); break;
+        default: hipLaunchKernelGGL(pair_gemm_kernel<4>, grid, dim3(256), 0, st, g); break;
+    }
+    PRParams r;
+    r.pos = pos; r.K = K; r.M = M; r.part = part; r.Cout = Cout; r.scale = scale; r.shift = shift; r.res = res; r.ld_res = ld_res;
+    r.out = out; r.ld_out = ld_out; r.act = act;
+    hipLaunchKernelGGL(pair_reduce_kernel, dim3((unsigned)cdiv(M * (Cout / 4), 256)), dim3(256), 0, st, r);
+    SD3D_CHECK_LAUNCH();
+    return SD3D_OK;
+}

@@ -413,6 +413,7 @@ class ScanNetQueryDecoder(nn.Module):
         return final, aux
 
     # ---- reference-shaped entry point (:417-435) --------------------------------------------------
+    @ops.bound_stream
     def forward(self, x, sp_pos=None, sp_pos_wo_elastic=None, queries=None, queries_pos=None, dinox_queries=None,
                 dinox_query_pos=None, scene_range=None):
         finals, auxes = [], []

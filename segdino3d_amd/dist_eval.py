@@ -84,6 +84,7 @@ class PipelinedRunner:
         self.device = device if device is not None else torch.device("cuda", torch.cuda.current_device())
         self.streams = [torch.cuda.Stream(device=self.device) for _ in range(self.n)]
         self._threading = threading
+        self.switch_interval = 2e-4
 
     def run(self, scenes, on_result=None):
         """scenes: sequence of (points, target) already on the device.  Returns the list of model outputs."""
@@ -106,14 +107,21 @@ class PipelinedRunner:
         if self.n == 1:
             work(0)
         else:
+            import sys
             main = torch.cuda.current_stream(self.device)
             for s in self.streams:
                 s.wait_stream(main)
             threads = [self._threading.Thread(target=work, args=(w,)) for w in range(self.n)]
-            for t in threads:
-                t.start()
-            for t in threads:
-                t.join()
+            # a worker that wakes from a host sync must not wait a whole 5 ms GIL slice behind its siblings
+            prev_switch = sys.getswitchinterval()
+            sys.setswitchinterval(self.switch_interval)
+            try:
+                for t in threads:
+                    t.start()
+                for t in threads:
+                    t.join()
+            finally:
+                sys.setswitchinterval(prev_switch)
             for s in self.streams:
                 main.wait_stream(s)
         if errors:

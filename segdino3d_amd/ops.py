@@ -23,8 +23,41 @@ import os as _os
 GG_FORCE_NT = int(_os.environ["SD3D_GG_NT"]) if _os.environ.get("SD3D_GG_NT") else None
 
 
+_STREAM_TLS = threading.local()
+
+
 def _stream():
-    return torch.cuda.current_stream().cuda_stream
+    s = getattr(_STREAM_TLS, "handle", None)
+    return s if s is not None else torch.cuda.current_stream().cuda_stream
+
+
+class stream_scope:
+    """Binds this thread's current HIP stream handle for the duration of a forward.
+
+    torch.cuda.current_stream() costs ~8 us per lookup on the host - more than the launch it precedes,
+    and a forward makes ~360 of them.  Inside the scope every op enqueues on the stream that was current
+    when the outermost scope was entered; do not switch torch streams inside it."""
+
+    def __enter__(self):
+        self.prev = getattr(_STREAM_TLS, "handle", None)
+        if self.prev is None:
+            _STREAM_TLS.handle = torch.cuda.current_stream().cuda_stream
+        return self
+
+    def __exit__(self, *exc):
+        _STREAM_TLS.handle = self.prev
+        return False
+
+
+def bound_stream(fn):
+    """Decorator form of stream_scope for the public forward entry points."""
+    import functools
+
+    @functools.wraps(fn)
+    def wrapped(*a, **kw):
+        with stream_scope():
+            return fn(*a, **kw)
+    return wrapped
 
 
 def _ptr(t: Optional[torch.Tensor], dtype=None, name="tensor"):
@@ -77,6 +110,8 @@ class _PerThread:
 
 _WS = _PerThread()
 _WS2 = _PerThread()       # split-K partial sums of gather_gemm
+_WS3 = _PerThread()       # partial products of pair_conv
+_WS4 = _PerThread()       # pair_lists scratch
 
 
 # --------------------------------------------------------------------------------------------
@@ -287,8 +322,71 @@ def clear_split_cache():
     _SPLIT_CACHE.clear()
 
 
+class PairLists:
+    """Offset-major layout of one neighbour table (csrc/pair_gemm.hip): shared by every convolution that uses it."""
+    __slots__ = ("pos", "in_idx", "tile_k", "p_cap", "K", "M")
+
+    def __init__(self, pos, in_idx, tile_k, p_cap, K, M):
+        self.pos, self.in_idx, self.tile_k, self.p_cap, self.K, self.M = pos, in_idx, tile_k, p_cap, K, M
+
+
+def pair_lists(nbr, n_pairs):
+    """nbr int32 [K, M]; n_pairs = number of entries >= 0 (host int, e.g. from kernel_map's pair counter)."""
+    lib = _lib.load()
+    K, M = nbr.shape
+    p_cap = (int(n_pairs) + 127 * K + 127) // 128 * 128
+    pos = torch.empty(K, M, dtype=torch.int32, device=nbr.device)
+    in_idx = torch.empty(p_cap, dtype=torch.int32, device=nbr.device)
+    tile_k = torch.empty(p_cap // 128, dtype=torch.int32, device=nbr.device)
+    nb = lib.sd3d_pair_lists_ws_bytes(K, M)
+    ws = _WS4.get(nb, nbr.device)
+    _lib.check(lib.sd3d_pair_lists(_ptr(nbr, torch.int32, "nbr"), K, M, p_cap, pos.data_ptr(), in_idx.data_ptr(),
+                                   tile_k.data_ptr(), ws.data_ptr(), ws.numel(), _stream()), "pair_lists")
+    return PairLists(pos, in_idx, tile_k, p_cap, K, M)
+
+
+# Sparse convolutions run pair-major (pair_conv) whenever the caller hands over the table's PairLists;
+# SD3D_PAIR_CONV=0 keeps the output-stationary gather_gemm kernels (tuning / ablation).
+PAIR_CONV = _os.environ.get("SD3D_PAIR_CONV", "1") != "0"
+
+
+def pair_conv(x, wt, pairs, x2=None, scale=None, shift=None, res=None, act=None, out=None):
+    """Same contract as gather_gemm(x, wt, nbr=...) for the table `pairs` was built from."""
+    lib = _lib.load()
+    K, Cout, Cin = wt.shape
+    if K != pairs.K:
+        raise ValueError(f"weights have {K} offsets, the pair lists {pairs.K}")
+    p0, ld0 = _rows(x, "x")
+    C0 = x.shape[1]
+    p1, ld1 = (None, 0)
+    if x2 is not None:
+        p1, ld1 = _rows(x2, "x2")
+        if C0 + x2.shape[1] != Cin:
+            raise ValueError(f"concat channels {C0}+{x2.shape[1]} != Cin {Cin}")
+    elif C0 != Cin:
+        raise ValueError(f"input channels {C0} != Cin {Cin}")
+    M = pairs.M
+    if out is None:
+        out = torch.empty(M, Cout, dtype=torch.float32, device=x.device)
+    po, ldo = _rows(out, "out")
+    pr, ldr = (None, 0)
+    if res is not None:
+        pr, ldr = _rows(res, "res")
+    part = _WS3.get(pairs.p_cap * Cout * 4, x.device)
+    hook = GG_HOOK
+    if hook is not None:
+        hook.before(dict(K=K, Cin=Cin, Cout=Cout, M=M, nbr=None, pairs=pairs))
+    _lib.check(lib.sd3d_pair_conv(p0, ld0, C0, p1, ld1, pairs.in_idx.data_ptr(), pairs.tile_k.data_ptr(), pairs.p_cap,
+                                  pairs.pos.data_ptr(), _ptr(wt, torch.float32, "wt"), K, Cin, Cout, M,
+                                  _ptr(scale, torch.float32, "scale"), _ptr(shift, torch.float32, "shift"), pr, ldr, po, ldo,
+                                  ACT[act], part.data_ptr(), part.numel(), _stream()), "pair_conv")
+    if hook is not None:
+        hook.after()
+    return out
+
+
 def gather_gemm(x, wt, nbr=None, x2=None, scale=None, shift=None, res=None, act=None, out=None, M=None, nt=0,
-                density=None, wt_split=None):
+                density=None, wt_split=None, pairs=None):
     """out[r, n] = act(scale[n] * sum_k sum_c X[nbr[k, r], c] * wt[k, n, c] + shift[n] + res[r, n]).
 
     x [V_in, C0] (rows may be strided), optional x2 [V_in, C1] = concatenated channels,
@@ -296,6 +394,9 @@ def gather_gemm(x, wt, nbr=None, x2=None, scale=None, shift=None, res=None, act=
     lib = _lib.load()
     if wt.dim() == 2:
         wt = wt.unsqueeze(0)
+    if pairs is not None and PAIR_CONV and nt == 0 and wt_split is None and GEMM_MODE is None and GG_FORCE_NT is None \
+            and wt.shape[1] % 4 == 0:
+        return pair_conv(x, wt, pairs, x2=x2, scale=scale, shift=shift, res=res, act=act, out=out)
     K, Cout, Cin = wt.shape
     p0, ld0 = _rows(x, "x")
     C0 = x.shape[1]

@@ -108,6 +108,7 @@ class SceneMaps:
         self._perm8 = torch.from_numpy(child_perm(order)).to(self.device)
         self._sp_start = None
         self.density: Dict[Tuple, float] = {}
+        self.pairs: Dict[Tuple, "ops.PairLists"] = {}       # offset-major rulebooks (prepare())
 
     def prepare(self, same=(), strides=()):
         """Build the listed neighbour tables now and read their rulebook sizes back in ONE copy (the
@@ -123,10 +124,16 @@ class SceneMaps:
         host = counters.cpu().sum(dim=1).tolist() if same else []
         for (lvl, k), c in zip(same, host):
             self.density[("same", lvl, k)] = c / max(1, k ** 3 * self.n_vox[lvl])
+            if ops.PAIR_CONV:
+                self.pairs[("same", lvl, k)] = ops.pair_lists(self._same[(lvl, k)], c)
         for lvl in strides:
             # every fine voxel has exactly one parent: P = V_fine pairs in both directions
             self.density[("down", lvl)] = self.n_vox[lvl] / max(1, 8 * self.n_vox[lvl + 1])
             self.density[("up", lvl)] = 1.0 / 8.0
+            if ops.PAIR_CONV and ("down", lvl) not in self.pairs:
+                dn, up = self._stride_maps(lvl)
+                self.pairs[("down", lvl)] = ops.pair_lists(dn, self.n_vox[lvl])
+                self.pairs[("up", lvl)] = ops.pair_lists(up, self.n_vox[lvl])
 
     # ------------------------------------------------------------------------------------------
     def table(self, level: int):
@@ -155,6 +162,13 @@ class SceneMaps:
     def up(self, level: int) -> torch.Tensor:
         """nbr [8, V_l] of the transposed k=2 s=2 convolution level+1 -> level."""
         return self._stride_maps(level)[1]
+
+    def conv_table(self, kind: str, level: int, ksize: int = 0) -> dict:
+        """Keyword arguments of ops.gather_gemm for one neighbour table: nbr, its rulebook density and (after
+        prepare()) its offset-major pair lists.  kind: "same" (ksize^3 offsets), "down" / "up" (k=2 s=2)."""
+        key = (kind, level, ksize) if kind == "same" else (kind, level)
+        nbr = self.same(level, ksize) if kind == "same" else (self.down(level) if kind == "down" else self.up(level))
+        return dict(nbr=nbr, density=self.density.get(key), pairs=self.pairs.get(key))
 
     # ------------------------------------------------------------------------------------------
     def voxel_features(self, points, feats2d, mode: int, ld_out: int) -> torch.Tensor:

@@ -270,3 +270,82 @@ def test_split_bf16_identity_rows_and_ragged_edges():
         ref = torch.nn.functional.linear(x.double(), w.double(), b.double())
         got = ops.gather_gemm(x, w, shift=b, wt_split=ops.split_weights(w.unsqueeze(0), 6))
         assert (got.double() - ref).abs().max().item() < 5e-6 * ref.abs().max().item()
+
+
+# ------------------------------------------------------------------------------------------------
+def test_pair_lists_are_exact():
+    """Offset-major rulebook: pos / in_idx / tile_k are integer work -> bit-exact against numpy."""
+    from segdino3d_amd import ops
+    from segdino3d_amd.sparse import SceneMaps
+    from segdino3d_amd.synth import make_scene
+    d = dev()
+    pts, tgt = make_scene(3, 9000, 100, 10)
+    maps = SceneMaps(pts.to(d), 0.02, 3, superpoints=tgt.extra_features["super_point_masks"].to(d))
+    for nbr in (maps.same(0, 3), maps.same(2, 3), maps.down(0), maps.up(1), maps.same(0, 5)):
+        K, M = nbr.shape
+        h = nbr.cpu().numpy()
+        P = int((h >= 0).sum())
+        pl = ops.pair_lists(nbr, P)
+        pos, in_idx, tile_k = pl.pos.cpu().numpy(), pl.in_idx.cpu().numpy(), pl.tile_k.cpu().numpy()
+        assert pl.p_cap % 128 == 0 and pl.p_cap >= P + 127 * K
+        off = 0
+        exp_pos = np.full((K, M), -1, np.int32)
+        exp_idx = np.full(pl.p_cap, -1, np.int32)
+        exp_tk = np.full(pl.p_cap // 128, -1, np.int32)
+        for k in range(K):
+            rows = np.nonzero(h[k] >= 0)[0]
+            exp_pos[k, rows] = off + np.arange(len(rows))
+            exp_idx[off:off + len(rows)] = h[k, rows]
+            seg = (len(rows) + 127) // 128 * 128
+            exp_tk[off // 128:(off + seg) // 128] = k
+            off += seg
+        assert np.array_equal(pos, exp_pos) and np.array_equal(in_idx, exp_idx) and np.array_equal(tile_k, exp_tk)
+
+
+def test_pair_conv_matches_gather_gemm_and_fp64():
+    """Pair-major convolution vs the output-stationary kernel (different fp32 sum order: 2e-6 of the
+    row magnitude) and vs an fp64 product, incl. concat input, residual, ReLU, K=8 stride maps, K=125."""
+    from segdino3d_amd import ops
+    from segdino3d_amd.sparse import SceneMaps
+    from segdino3d_amd.synth import make_scene
+    d = dev()
+    pts, tgt = make_scene(6, 30000, 400, 40)
+    maps = SceneMaps(pts.to(d), 0.02, 4, superpoints=tgt.extra_features["super_point_masks"].to(d))
+    maps.prepare(same=[(0, 5), (0, 3), (1, 3), (2, 3), (3, 3)], strides=[0, 1, 2])
+    g = torch.Generator().manual_seed(2)
+    cases = [(("same", 0, 5), 32, 32, False), (("same", 0, 3), 96, 96, True), (("same", 1, 3), 64, 64, False),
+             (("same", 2, 3), 128, 256, False), (("same", 3, 3), 256, 132, True), (("down", 0), 32, 64, False),
+             (("up", 1), 128, 96, False)]
+    for key, cin, cout, two in cases:
+        tab = maps.conv_table(*key)
+        nbr, pairs = tab["nbr"], tab["pairs"]
+        assert pairs is not None
+        K, M = nbr.shape
+        n_in = int(nbr.max().item()) + 1
+        x = torch.randn(n_in, cin, generator=g) * torch.exp(0.5 * torch.randn(n_in, 1, generator=g))
+        w = torch.randn(K, cout, cin, generator=g) * (K * cin) ** -0.5
+        scale, shift = torch.rand(cout, generator=g) + 0.5, torch.randn(cout, generator=g)
+        res = torch.randn(M, cout, generator=g)
+        xd, wd = x.to(d), w.to(d)
+        kw = dict(scale=scale.to(d), shift=shift.to(d), res=res.to(d), act="relu")
+        xin, x2 = (xd[:, :cin // 2], xd[:, cin // 2:]) if two and (cin // 2) % 32 == 0 else (xd, None)
+        got = ops.pair_conv(xin, wd, pairs, x2=x2, **kw).double().cpu()
+        old = ops.gather_gemm(xin, wd, nbr=nbr, x2=x2, nt=1, **kw).double().cpu()
+        idx = nbr.cpu().long()
+        ref = torch.zeros(M, cout, dtype=torch.float64)
+        mag = torch.zeros(M, cout, dtype=torch.float64)
+        xx, ww = x.double(), w.double()
+        for k in range(K):
+            ok = idx[k] >= 0
+            rows = xx[idx[k].clamp(min=0)] * ok[:, None]
+            ref += rows @ ww[k].T
+            mag += rows.abs() @ ww[k].abs().T
+        ref = torch.relu(ref * scale.double() + shift.double() + res.double())
+        mag = mag * scale.double() + shift.abs().double() + res.abs().double() + 1e-30
+        e_new = ((got - ref).abs() / mag).max().item()
+        e_old = ((old - ref).abs() / mag).max().item()
+        assert e_new < 2e-6, f"{key} {cin}->{cout}: pair_conv {e_new:.2e} (gather_gemm {e_old:.2e})"
+        assert ((got - old).abs() / mag).max().item() < 2e-6
+        # deterministic: same bits run to run
+        again = ops.pair_conv(xin, wd, pairs, x2=x2, **kw).double().cpu()
+        assert torch.equal(got, again)
