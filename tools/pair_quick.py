@@ -1,0 +1,23 @@
+"""Micro-benchmark of the pair-major convolution on real rulebooks: time per conv, active TFLOP/s."""
+import os, sys, torch
+sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", "/root/repo"))
+from segdino3d_amd import ops
+from segdino3d_amd.sparse import SceneMaps
+from segdino3d_amd.synth import make_scene
+from tools.bench_gg import timeit
+d = torch.device("cuda:0")
+pts, tgt = make_scene(0, 150000, 3000, 300)
+maps = SceneMaps(pts.to(d), 0.02, 5, superpoints=tgt.extra_features["super_point_masks"].to(d))
+maps.prepare(same=[(0, 5)] + [(l, 3) for l in range(5)], strides=[0, 1, 2, 3])
+g = torch.Generator().manual_seed(0)
+cases = [(("same", 0, 5), 288, 32), (("same", 0, 3), 96, 96), (("same", 0, 3), 128, 96), (("same", 1, 3), 32, 32), (("same", 1, 3), 96, 96),
+         (("same", 2, 3), 64, 64), (("same", 2, 3), 128, 128), (("same", 2, 3), 192, 128), (("same", 3, 3), 128, 128), (("same", 3, 3), 256, 256),
+         (("same", 3, 3), 384, 256), (("same", 4, 3), 256, 256), (("down", 0), 32, 32), (("up", 0), 128, 96), (("up", 2), 256, 128)]
+for key, cin, cout in cases:
+    tab = maps.conv_table(*key); nbr, pairs = tab["nbr"], tab["pairs"]
+    K, M = nbr.shape
+    n_in = int(nbr.max().item()) + 1
+    x = torch.randn(n_in, cin, generator=g).to(d); w = (torch.randn(K, cout, cin, generator=g) * (K * cin) ** -0.5).to(d)
+    P = int((pairs.in_idx >= 0).sum())
+    t = timeit(lambda: ops.pair_conv(x, w, pairs), 5)
+    print(key, cin, cout, f"M={M} P={P} tiles={pairs.p_cap // 128} | {t:.0f} us | {2.0 * P * cin * cout / t / 1e6:.1f} TF/s active")

@@ -29,13 +29,14 @@ def main():
               "| kernel | calls | total ms | avg us | % |", "|---|---:|---:|---:|---:|"]
     for name, calls, tot, avg, pct in rows[:45]:
         lines.append(f"| `{name[:90]}` | {calls} | {tot / 1e3:.3f} | {avg:.1f} | {pct:.2f} |")
-    lines += ["", "## gather_gemm by launch shape", "", "| variant | workgroups | launches | avg us | total ms | vgpr | lds |",
+    lines += ["", "## GEMM family by launch shape", "", "| variant | workgroups | launches | avg us | total ms | vgpr | lds |",
               "|---|---:|---:|---:|---:|---:|---:|"]
-    q = ("select name, grid_x / workgroup_x, count(*), avg(duration), sum(duration), vgpr_count, lds_size from kernels "
-         "where name like '%gather_gemm%' group by name, grid_x order by sum(duration) desc")
-    for name, wgs, n, avg, tot, vg, lds in cur.execute(q).fetchall()[:30]:
+    q = ("select name, grid_x / workgroup_x, count(*), avg(duration), sum(duration), vgpr_count, lds_size, grid_y from kernels "
+         "where name like '%gather_gemm%' or name like '%pair_gemm%' or name like '%pair_reduce%' "
+         "group by name, grid_x, grid_y order by sum(duration) desc")
+    for name, wgs, n, avg, tot, vg, lds, gy in cur.execute(q).fetchall()[:40]:
         short = name.split("(")[0].replace("void ", "")
-        lines.append(f"| `{short}` | {wgs} | {n} | {avg / 1e3:.1f} | {tot / 1e6:.3f} | {vg} | {lds} |")
+        lines.append(f"| `{short}` | {wgs}x{gy} | {n} | {avg / 1e3:.1f} | {tot / 1e6:.3f} | {vg} | {lds} |")
     try:
         pm = cur.execute("select name, counter_name, count(*), sum(counter_value) from pmc_events group by name, counter_name").fetchall()
     except sqlite3.Error:
