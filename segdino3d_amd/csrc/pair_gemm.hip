@@ -18,6 +18,7 @@
 // fp32 matrix rate (>= 16 flop per byte moved at Cin = 96).  The sum order is fixed (full Cin dot
 // product per pair, then k ascending) so results are deterministic.
 #include "gg_common.h"
+#include <stdlib.h>
 
 #define PL_ROWS 2048            // rows per workgroup of the list-building kernels
 #define PT 128                  // pairs per tile / segment padding
@@ -118,21 +119,41 @@ struct PGParams {
     const float* wt;                          // [K][Cout][Cin]
     int Cin, Cout;
     float* part;                              // [n_tiles * 128][Cout]
+    int n_tiles;
+    int tiles_per_wg;                         // consecutive tiles one workgroup walks (software-pipelined across tiles)
+    int dbg;                                  // SD3D_PAIR_DBG ablations (timing only): 1 = clustered gather rows, 2 = no stores, 4 = no MFMA
 };
 
+// A workgroup walks `tiles_per_wg` consecutive 128-pair tiles as ONE flat stream of (tile, 32-channel
+// chunk) steps: the weight chunk of step s+1 is staged global -> registers -> LDS while step s runs on
+// the matrix cores, and the gathered activation rows are prefetched TWO steps ahead (three register
+// stages), across tile boundaries, so the dependent in_idx -> row gather latency of a new tile never
+// stalls the MFMA pipe.  The four waves share the weight chunk (lock-step, one barrier per step); each
+// owns 32 pairs x (32*NT) output columns.
 template <int NT>
-__global__ __launch_bounds__(256) void pair_gemm_kernel(const PGParams p) {
-    __shared__ __attribute__((aligned(16))) float Bs[2][NT * 32 * PBS_LD];
-    const int k = p.tile_k[blockIdx.x];
-    if (k < 0) return;                                         // uniform over the workgroup
+__device__ __forceinline__ void pair_gemm_body(const PGParams& p, float (*Bs)[NT * 32 * PBS_LD]) {
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int j = lane & 31, h = lane >> 5;
-    const int64_t prow0 = (int64_t)blockIdx.x * PT + wv * 32;
-    const int idx = p.in_idx[prow0 + j];
-    const bool mine = __ballot(idx >= 0) != 0ull;              // wave-uniform: any real pair in these 32?
+    const int tile0 = blockIdx.x * p.tiles_per_wg;
+    int ntl = 0;                                               // real tiles of this workgroup (a prefix: -1 only at the end)
+    for (int t = 0; t < p.tiles_per_wg; ++t)
+        if (tile0 + t < p.n_tiles && p.tile_k[tile0 + t] >= 0) ntl = t + 1;
+    if (ntl == 0) return;                                      // uniform over the workgroup
+    if (p.dbg & 8) {
+        // static issue priority by hardware wave slot: co-resident waves of two workgroups otherwise fall into
+        // phase (both in their MFMA segment, then both in their load/barrier segment -> idle matrix pipe)
+        const unsigned slot = __builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | ((4 - 1) << 11));   // HW_ID.wave_id
+        if (slot & 1) __builtin_amdgcn_s_setprio(2); else __builtin_amdgcn_s_setprio(0);
+    }
     const int ncol0 = blockIdx.y * NT * 32;
     const int nchunks = p.Cin >> 5;
-    const float* __restrict__ W = p.wt + (int64_t)k * p.Cout * p.Cin;
+    const int nsteps = ntl * nchunks;
+    const int64_t wstride = (int64_t)p.Cout * p.Cin;
+
+#define LOAD_IDX(lt) ((lt) < ntl ? ((p.dbg & 1) ? ((tile0 + (lt)) * 7 + wv * 32 + j) & 1023 : p.in_idx[(int64_t)(tile0 + (lt)) * PT + wv * 32 + j]) : -1)
+#define LOAD_K(lt) ((lt) < ntl ? p.tile_k[tile0 + (lt)] : 0)
+    int q0 = LOAD_IDX(0), q1 = LOAD_IDX(1), q2 = LOAD_IDX(2);  // gather rows of the current tile and the next two
+    int k_cur = LOAD_K(0), k_nxt = LOAD_K(1);
 
     f32x16 acc[NT];
 #pragma unroll
@@ -141,7 +162,8 @@ __global__ __launch_bounds__(256) void pair_gemm_kernel(const PGParams p) {
         for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
 
     f32x4 bst[NT];
-    auto stage_load = [&](int chunk) {
+    auto stage_load = [&](int k, int chunk) {
+        const float* __restrict__ W = p.wt + (int64_t)k * wstride;
 #pragma unroll
         for (int i = 0; i < NT; ++i) {
             const int f = tid + i * 256;
@@ -157,7 +179,7 @@ __global__ __launch_bounds__(256) void pair_gemm_kernel(const PGParams p) {
             *(f32x4*)(&Bs[buf][(f >> 3) * PBS_LD + (f & 7) * 4]) = bst[i];
         }
     };
-    auto load_a = [&](f32x4 (&a)[4], int chunk) {
+    auto load_a = [&](f32x4 (&a)[4], int idx, int chunk) {
         const int c = chunk * 32 + h * 16;
         if (idx >= 0) {
             const float* src = (c < p.C0) ? (p.in0 + (int64_t)idx * p.ld0 + c) : (p.in1 + (int64_t)idx * p.ld1 + (c - p.C0));
@@ -169,52 +191,94 @@ __global__ __launch_bounds__(256) void pair_gemm_kernel(const PGParams p) {
         }
     };
 
-    f32x4 acur[4];
-    load_a(acur, 0);
-    stage_load(0);
+    // prefetch pointer (pf_d tiles ahead of the current tile, chunk pf_c) = step s + 2
+    f32x4 a0[4], a1[4], a2[4];
+    int pf_d = 0, pf_c = 0;
+#define PF_IDX() (pf_d == 0 ? q0 : (pf_d == 1 ? q1 : q2))
+#define PF_ADVANCE() do { if (++pf_c == nchunks) { pf_c = 0; ++pf_d; } } while (0)
+    load_a(a0, PF_IDX(), pf_c); PF_ADVANCE();
+    if (nsteps > 1) { load_a(a1, PF_IDX(), pf_c); PF_ADVANCE(); }
+    stage_load(k_cur, 0);
     stage_store(0);
     __syncthreads();
-    int buf = 0;
-    for (int chunk = 0; chunk < nchunks; ++chunk) {
-        const bool has_next = chunk + 1 < nchunks;
-        f32x4 anxt[4];
-        if (has_next) {
-            stage_load(chunk + 1);
-            load_a(anxt, chunk + 1);
-        }
-        if (mine) {
-            const float* bb = &Bs[buf][j * PBS_LD + h * 16];
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                f32x4 bq[NT];
-#pragma unroll
-                for (int t = 0; t < NT; ++t) bq[t] = *(const f32x4*)(bb + t * 32 * PBS_LD + q * 4);
-#pragma unroll
-                for (int e = 0; e < 4; ++e)
-#pragma unroll
-                    for (int t = 0; t < NT; ++t)
-                        acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(acur[q][e], bq[t][e], acc[t], 0, 0, 0);
-            }
-        }
-        if (!has_next) break;
-        stage_store(buf ^ 1);
-        __syncthreads();
-        buf ^= 1;
-#pragma unroll
-        for (int q = 0; q < 4; ++q) acur[q] = anxt[q];
+    bool mine = __ballot(q0 >= 0) != 0ull;                     // wave-uniform: any real pair among this tile's 32?
+    int buf = 0, cur_lt = 0, cur_c = 0, s = 0;
+    // One step: CUR = this step's activation fragments, PF = the stage that receives step s+2's.  The ring is
+    // rotated by unrolling the loop three times with the roles renamed - copying a stage would make the
+    // compiler wait for the loads that are still in flight into it and cut the prefetch back to one step.
+#define PAIR_STEP(CUR, PF)                                                                                            \
+    {                                                                                                                 \
+        const bool has_next = s + 1 < nsteps;                                                                         \
+        const bool last_chunk = cur_c + 1 == nchunks;                                                                 \
+        if (has_next && !(p.dbg & 16)) stage_load(last_chunk ? k_nxt : k_cur, last_chunk ? 0 : cur_c + 1);           \
+        if (s + 2 < nsteps && !(p.dbg & 32)) { load_a(PF, PF_IDX(), pf_c); PF_ADVANCE(); }                            \
+        if (mine && !(p.dbg & 4)) {                                                                                   \
+            /* weight fragments double-buffered by hand: left alone the compiler hoists all four groups (64 VGPRs) */ \
+            const float* bb = &Bs[buf][j * PBS_LD + h * 16];                                                          \
+            f32x4 bq[2][NT];                                                                                          \
+            _Pragma("unroll") for (int t = 0; t < NT; ++t) bq[0][t] = *(const f32x4*)(bb + t * 32 * PBS_LD);          \
+            _Pragma("unroll") for (int q = 0; q < 4; ++q) {                                                           \
+                if (q < 3) {                                                                                          \
+                    _Pragma("unroll") for (int t = 0; t < NT; ++t)                                                    \
+                        bq[(q + 1) & 1][t] = *(const f32x4*)(bb + t * 32 * PBS_LD + (q + 1) * 4);                     \
+                }                                                                                                     \
+                _Pragma("unroll") for (int e = 0; e < 4; ++e)                                                         \
+                    _Pragma("unroll") for (int t = 0; t < NT; ++t)                                                    \
+                        acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(CUR[q][e], bq[q & 1][t][e], acc[t], 0, 0, 0);   \
+                __builtin_amdgcn_sched_barrier(0);                                                                    \
+            }                                                                                                         \
+        }                                                                                                             \
+        if (last_chunk) { /* tile complete: write its partial products */                                             \
+            if (mine && !(p.dbg & 2)) {                                                                               \
+                const int64_t prow0 = (int64_t)(tile0 + cur_lt) * PT + wv * 32;                                       \
+                _Pragma("unroll") for (int t = 0; t < NT; ++t) {                                                      \
+                    const int n = ncol0 + t * 32 + j;                                                                 \
+                    _Pragma("unroll") for (int r = 0; r < 16; ++r) {                                                  \
+                        const int64_t pr = prow0 + (r & 3) + 8 * (r >> 2) + 4 * h;                                    \
+                        if (n < p.Cout) p.part[pr * p.Cout + n] = acc[t][r];                                          \
+                    }                                                                                                 \
+                }                                                                                                     \
+            }                                                                                                         \
+            _Pragma("unroll") for (int t = 0; t < NT; ++t)                                                            \
+                _Pragma("unroll") for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;                                       \
+        }                                                                                                             \
+        if (!has_next) break;                                                                                         \
+        if (!(p.dbg & 16)) {                                                                                          \
+            stage_store(buf ^ 1);                                                                                     \
+            __syncthreads();                                                                                          \
+            buf ^= 1;                                                                                                 \
+        }                                                                                                             \
+        ++s;                                                                                                          \
+        if (last_chunk) {                                                                                             \
+            cur_c = 0; ++cur_lt; --pf_d;                                                                              \
+            q0 = q1; q1 = q2; q2 = LOAD_IDX(cur_lt + 2);                                                              \
+            k_cur = k_nxt; k_nxt = LOAD_K(cur_lt + 1);                                                                \
+            mine = __ballot(q0 >= 0) != 0ull;                                                                         \
+        } else {                                                                                                      \
+            ++cur_c;                                                                                                  \
+        }                                                                                                             \
     }
-    if (!mine) return;
-#pragma unroll
-    for (int t = 0; t < NT; ++t) {
-        const int n = ncol0 + t * 32 + j;
-        if (n >= p.Cout) continue;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int64_t pr = prow0 + (r & 3) + 8 * (r >> 2) + 4 * h;
-            p.part[pr * p.Cout + n] = acc[t][r];
-        }
+    for (;;) {
+        PAIR_STEP(a0, a2)
+        PAIR_STEP(a1, a0)
+        PAIR_STEP(a2, a1)
     }
+#undef PAIR_STEP
 }
+
+// One entry per column-tile count: the register budget (waves per SIMD) is pinned per variant, which
+// also stops the compiler from splitting the file into VGPR + AGPR halves with separate alignment
+// (272 registers and one wave per SIMD for NT = 4 otherwise).
+#define PAIR_GEMM_ENTRY(NT, WAVES)                                                                              \
+    __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WAVES, WAVES))) void pair_gemm_kernel_##NT( \
+        const PGParams p) {                                                                                     \
+        __shared__ __attribute__((aligned(16))) float Bs[2][NT * 32 * PBS_LD];                                  \
+        pair_gemm_body<NT>(p, Bs);                                                                              \
+    }
+PAIR_GEMM_ENTRY(1, 3)
+PAIR_GEMM_ENTRY(2, 2)
+PAIR_GEMM_ENTRY(3, 2)
+PAIR_GEMM_ENTRY(4, 2)
 
 // ---- pass 2: fixed-order reduction over the offsets + epilogue --------------------------------
 struct PRParams {
@@ -301,12 +365,21 @@ int launch_pair_conv(const float* in0, int ld0, int C0, const float* in1, int ld
     const int sub = (Cout + 31) / 32;
     int nt = sub >= 4 ? 4 : sub;
     if (sub > 4 && sub % 4) { for (int c = 4; c >= 1; --c) if (sub % c == 0) { nt = c; break; } }
-    const dim3 grid((unsigned)(p_cap / PT), (unsigned)cdiv(sub, nt));
+    const int cgs = (int)cdiv(sub, nt);
+    g.n_tiles = (int)(p_cap / PT);
+    // tiles per workgroup: long enough to amortise the pipeline fill, short enough to leave >= ~6 workgroups per CU
+    static int tpw_env = -1;
+    if (tpw_env < 0) { const char* e = getenv("SD3D_PAIR_TPW"); tpw_env = e ? atoi(e) : 0; }
+    int tpw = tpw_env > 0 ? tpw_env : (int)((int64_t)g.n_tiles * cgs / 1536);
+    tpw = tpw < 1 ? 1 : (tpw > 8 ? 8 : tpw);
+    g.tiles_per_wg = tpw;
+    { static int dbg = -1; if (dbg < 0) { const char* e = getenv("SD3D_PAIR_DBG"); dbg = e ? atoi(e) : 0; } g.dbg = dbg; }
+    const dim3 grid((unsigned)cdiv(g.n_tiles, tpw), (unsigned)cgs);
     switch (nt) {
-        case 1: hipLaunchKernelGGL(pair_gemm_kernel<1>, grid, dim3(256), 0, st, g); break;
-        case 2: hipLaunchKernelGGL(pair_gemm_kernel<2>, grid, dim3(256), 0, st, g); break;
-        case 3: hipLaunchKernelGGL(pair_gemm_kernel<3>, grid, dim3(256), 0, st, g); break;
-        default: hipLaunchKernelGGL(pair_gemm_kernel<4>, grid, dim3(256), 0, st, g); break;
+        case 1: hipLaunchKernelGGL(pair_gemm_kernel_1, grid, dim3(256), 0, st, g); break;
+        case 2: hipLaunchKernelGGL(pair_gemm_kernel_2, grid, dim3(256), 0, st, g); break;
+        case 3: hipLaunchKernelGGL(pair_gemm_kernel_3, grid, dim3(256), 0, st, g); break;
+        default: hipLaunchKernelGGL(pair_gemm_kernel_4, grid, dim3(256), 0, st, g); break;
     }
     PRParams r;
     r.pos = pos; r.K = K; r.M = M; r.part = part; r.Cout = Cout; r.scale = scale; r.shift = shift; r.res = res; r.ld_res = ld_res;
