@@ -83,7 +83,11 @@ def load():
             f"{LIB_PATH} not found - the HIP extension is not built.  Build it with "
             "`python -c 'import __graft_entry__ as g; g.build()'` (or `make -C segdino3d_amd/csrc`). "
             "There is no CPU fallback for the product path.")
-    lib = C.CDLL(LIB_PATH)
+    # PyDLL = the calls keep the GIL.  Every entry point only enqueues work (a few microseconds), and with
+    # several host threads each driving a stream (dist_eval.PipelinedRunner) releasing and re-taking the GIL
+    # around ~600 such calls per forward costs more than the calls themselves (lock convoy: measured 65 vs
+    # 120 scenes/s of GPU capacity).  SD3D_RELEASE_GIL=1 restores ctypes.CDLL behaviour.
+    lib = (C.CDLL if os.environ.get("SD3D_RELEASE_GIL") == "1" else C.PyDLL)(LIB_PATH)
     for name, (res, args) in SIGNATURES.items():
         fn = getattr(lib, name)       # AttributeError here = header/library mismatch: fail loudly
         fn.restype = res

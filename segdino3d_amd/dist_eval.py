@@ -13,6 +13,8 @@ from __future__ import annotations
 
 from typing import Callable, List, Sequence
 
+import os
+
 import torch
 import torch.distributed as dist
 
@@ -84,7 +86,7 @@ class PipelinedRunner:
         self.device = device if device is not None else torch.device("cuda", torch.cuda.current_device())
         self.streams = [torch.cuda.Stream(device=self.device) for _ in range(self.n)]
         self._threading = threading
-        self.switch_interval = 2e-4
+        self.switch_interval = float(os.environ.get("SD3D_SWITCH_INTERVAL", "2e-4"))
 
     def run(self, scenes, on_result=None):
         """scenes: sequence of (points, target) already on the device.  Returns the list of model outputs."""
