@@ -132,7 +132,8 @@ int sd3d_gather_gemm_split(const float* in0, int ld0, int C0, const float* in1, 
  *   pos [K, M]      position of pair (k, r) in the list, -1 where nbr[k][r] < 0
  *   in_idx [p_cap]  gathered input row of each list entry; every offset's segment is padded to a
  *                   multiple of 128 entries with -1
- *   tile_k [p_cap/128]  offset of each 128-entry tile, -1 past the end of the list
+ *   tile_k [p_cap/128 + 1]  offset of each 128-entry tile, -1 past the end of the list; the last entry
+ *                   receives the number of real tiles
  * p_cap: multiple of 128, >= (number of pairs) + 127 * K (pairs beyond the capacity are dropped:
  * size it from the pair count sd3d_kernel_map returns).
  * sd3d_pair_conv: part = caller scratch of >= p_cap * Cout floats.  Cin % 32 == 0, Cout % 4 == 0. */

@@ -87,9 +87,14 @@ __global__ __launch_bounds__(256) void pair_fill_kernel(const int32_t* __restric
     int seg;
     block_excl_scan_256p(s, &seg, sm);
     const int seg_len = (totals[k] + PT - 1) / PT * PT;
-    if (blk == 0)
+    if (blk == 0) {
         for (int t = tid; t < seg_len / PT; t += 256)
             if ((int64_t)(seg / PT + t) * PT < p_cap) tile_k[seg / PT + t] = k;
+        if (k == K - 1 && tid == 0) {                          // number of real tiles, after the last slot
+            const int64_t end = (int64_t)seg + seg_len;
+            tile_k[p_cap / PT] = (int)((end < p_cap ? end : p_cap) / PT);
+        }
+    }
     int base = seg + blk_off[(int64_t)k * nblk + blk];
     const uint64_t lt = (1ull << lane) - 1ull;
 #pragma unroll 1
@@ -119,12 +124,11 @@ struct PGParams {
     const float* wt;                          // [K][Cout][Cin]
     int Cin, Cout;
     float* part;                              // [n_tiles * 128][Cout]
-    int n_tiles;
-    int tiles_per_wg;                         // consecutive tiles one workgroup walks (software-pipelined across tiles)
-    int dbg;                                  // SD3D_PAIR_DBG ablations (timing only): 1 = clustered gather rows, 2 = no stores, 4 = no MFMA
+    int n_tiles;                              // capacity; the real count is tile_k[n_tiles]
+    int dbg;                                  // SD3D_PAIR_DBG (timing experiments only): 1 = clustered gather rows instead of in_idx
 };
 
-// A workgroup walks `tiles_per_wg` consecutive 128-pair tiles as ONE flat stream of (tile, 32-channel
+// A workgroup walks its range of consecutive 128-pair tiles as ONE flat stream of (tile, 32-channel
 // chunk) steps: the weight chunk of step s+1 is staged global -> registers -> LDS while step s runs on
 // the matrix cores, and the gathered activation rows are prefetched TWO steps ahead (three register
 // stages), across tile boundaries, so the dependent in_idx -> row gather latency of a new tile never
@@ -132,19 +136,15 @@ struct PGParams {
 // owns 32 pairs x (32*NT) output columns.
 template <int NT>
 __device__ __forceinline__ void pair_gemm_body(const PGParams& p, float (*Bs)[NT * 32 * PBS_LD]) {
-    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);   // wave-uniform values must live in SGPRs (scalar branches)
     const int j = lane & 31, h = lane >> 5;
-    const int tile0 = blockIdx.x * p.tiles_per_wg;
-    int ntl = 0;                                               // real tiles of this workgroup (a prefix: -1 only at the end)
-    for (int t = 0; t < p.tiles_per_wg; ++t)
-        if (tile0 + t < p.n_tiles && p.tile_k[tile0 + t] >= 0) ntl = t + 1;
-    if (ntl == 0) return;                                      // uniform over the workgroup
-    if (p.dbg & 8) {
-        // static issue priority by hardware wave slot: co-resident waves of two workgroups otherwise fall into
-        // phase (both in their MFMA segment, then both in their load/barrier segment -> idle matrix pipe)
-        const unsigned slot = __builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | ((4 - 1) << 11));   // HW_ID.wave_id
-        if (slot & 1) __builtin_amdgcn_s_setprio(2); else __builtin_amdgcn_s_setprio(0);
-    }
+    // balanced contiguous tile ranges over a grid sized to the resident workgroup slots: no wave-quantisation
+    // tail (a fixed tiles-per-workgroup grid of 2.1 rounds costs 3 rounds of time)
+    const int n_real = p.tile_k[p.n_tiles];
+    const int tile0 = (int)((int64_t)blockIdx.x * n_real / gridDim.x);
+    const int ntl = (int)((int64_t)(blockIdx.x + 1) * n_real / gridDim.x) - tile0;
+    if (ntl <= 0) return;                                      // uniform over the workgroup
     const int ncol0 = blockIdx.y * NT * 32;
     const int nchunks = p.Cin >> 5;
     const int nsteps = ntl * nchunks;
@@ -179,16 +179,20 @@ __device__ __forceinline__ void pair_gemm_body(const PGParams& p, float (*Bs)[NT
             *(f32x4*)(&Bs[buf][(f >> 3) * PBS_LD + (f & 7) * 4]) = bst[i];
         }
     };
+    // Branch-free on purpose: padding entries (idx < 0) read row 0 - their partial products are never
+    // read back - and the concat source is picked by a wave-uniform select.  Any exec-masked region here
+    // makes the compiler fall back to s_waitcnt vmcnt(0) at the next use, which drains the prefetches that
+    // were just issued (measured: the whole two-step lookahead was lost to it).
     auto load_a = [&](f32x4 (&a)[4], int idx, int chunk) {
-        const int c = chunk * 32 + h * 16;
-        if (idx >= 0) {
-            const float* src = (c < p.C0) ? (p.in0 + (int64_t)idx * p.ld0 + c) : (p.in1 + (int64_t)idx * p.ld1 + (c - p.C0));
+        const int cc = chunk * 32;                              // wave-uniform
+        const bool first = cc < p.C0;
+        const float* base = first ? p.in0 : p.in1;
+        const int ld = first ? p.ld0 : p.ld1;
+        const int coff = (first ? cc : cc - p.C0) + h * 16;
+        const int row = idx < 0 ? 0 : idx;
+        const float* src = base + (int64_t)row * ld + coff;
 #pragma unroll
-            for (int q = 0; q < 4; ++q) a[q] = *(const f32x4*)(src + q * 4);
-        } else {
-#pragma unroll
-            for (int q = 0; q < 4; ++q) a[q] = f32x4{0.f, 0.f, 0.f, 0.f};
-        }
+        for (int q = 0; q < 4; ++q) a[q] = *(const f32x4*)(src + q * 4);
     };
 
     // prefetch pointer (pf_d tiles ahead of the current tile, chunk pf_c) = step s + 2
@@ -201,7 +205,6 @@ __device__ __forceinline__ void pair_gemm_body(const PGParams& p, float (*Bs)[NT
     stage_load(k_cur, 0);
     stage_store(0);
     __syncthreads();
-    bool mine = __ballot(q0 >= 0) != 0ull;                     // wave-uniform: any real pair among this tile's 32?
     int buf = 0, cur_lt = 0, cur_c = 0, s = 0;
     // One step: CUR = this step's activation fragments, PF = the stage that receives step s+2's.  The ring is
     // rotated by unrolling the loop three times with the roles renamed - copying a stage would make the
@@ -210,9 +213,9 @@ __device__ __forceinline__ void pair_gemm_body(const PGParams& p, float (*Bs)[NT
     {                                                                                                                 \
         const bool has_next = s + 1 < nsteps;                                                                         \
         const bool last_chunk = cur_c + 1 == nchunks;                                                                 \
-        if (has_next && !(p.dbg & 16)) stage_load(last_chunk ? k_nxt : k_cur, last_chunk ? 0 : cur_c + 1);           \
-        if (s + 2 < nsteps && !(p.dbg & 32)) { load_a(PF, PF_IDX(), pf_c); PF_ADVANCE(); }                            \
-        if (mine && !(p.dbg & 4)) {                                                                                   \
+        if (has_next) stage_load(last_chunk ? k_nxt : k_cur, last_chunk ? 0 : cur_c + 1);                             \
+        load_a(PF, PF_IDX(), pf_c); PF_ADVANCE(); /* past the end: idx = -1 -> row 0, harmless */                     \
+        {                                                                                                             \
             /* weight fragments double-buffered by hand: left alone the compiler hoists all four groups (64 VGPRs) */ \
             const float* bb = &Bs[buf][j * PBS_LD + h * 16];                                                          \
             f32x4 bq[2][NT];                                                                                          \
@@ -229,7 +232,7 @@ __device__ __forceinline__ void pair_gemm_body(const PGParams& p, float (*Bs)[NT
             }                                                                                                         \
         }                                                                                                             \
         if (last_chunk) { /* tile complete: write its partial products */                                             \
-            if (mine && !(p.dbg & 2)) {                                                                               \
+            {                                                                                                         \
                 const int64_t prow0 = (int64_t)(tile0 + cur_lt) * PT + wv * 32;                                       \
                 _Pragma("unroll") for (int t = 0; t < NT; ++t) {                                                      \
                     const int n = ncol0 + t * 32 + j;                                                                 \
@@ -243,17 +246,14 @@ __device__ __forceinline__ void pair_gemm_body(const PGParams& p, float (*Bs)[NT
                 _Pragma("unroll") for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;                                       \
         }                                                                                                             \
         if (!has_next) break;                                                                                         \
-        if (!(p.dbg & 16)) {                                                                                          \
-            stage_store(buf ^ 1);                                                                                     \
-            __syncthreads();                                                                                          \
-            buf ^= 1;                                                                                                 \
-        }                                                                                                             \
+        stage_store(buf ^ 1);                                                                                         \
+        __syncthreads();                                                                                              \
+        buf ^= 1;                                                                                                     \
         ++s;                                                                                                          \
         if (last_chunk) {                                                                                             \
             cur_c = 0; ++cur_lt; --pf_d;                                                                              \
             q0 = q1; q1 = q2; q2 = LOAD_IDX(cur_lt + 2);                                                              \
             k_cur = k_nxt; k_nxt = LOAD_K(cur_lt + 1);                                                                \
-            mine = __ballot(q0 >= 0) != 0ull;                                                                         \
         } else {                                                                                                      \
             ++cur_c;                                                                                                  \
         }                                                                                                             \
@@ -279,6 +279,148 @@ PAIR_GEMM_ENTRY(1, 3)
 PAIR_GEMM_ENTRY(2, 2)
 PAIR_GEMM_ENTRY(3, 2)
 PAIR_GEMM_ENTRY(4, 2)
+
+// ---- pass 1, weight-stationary variant ----------------------------------------------------------
+// For layers whose whole W[k] (Cout x Cin fp32, Cout = 32*NT <= 128) fits in LDS next to a second
+// workgroup: the workgroup stages W[k] ONCE per run of same-offset tiles and its four waves then walk
+// their own 32-pair sub-tiles independently - no per-step barrier, no re-staging of weight chunks.
+// The MFMA is issued transposed (A = weights, B = gathered rows) so a lane owns one pair row and its
+// accumulator registers are 4-column groups: the partial products leave as dwordx4 stores.
+#define WS_RANGE_TILES 24       // most tiles one workgroup may be given: its gather indices live in LDS (12 KB)
+
+// (An inline-asm variant of the gather with hand-counted s_waitcnt vmcnt(N) was tried to keep two steps
+// of loads in flight past hipcc's conservative waits: it was not faster - latency is not what limits this
+// kernel - and the register copies the compiler places around asm outputs at the loop back-edge read
+// registers with loads still in flight.  Plain loads it is.)
+#define LOAD_A4(A, PTR)                                                                                            \
+    do { _Pragma("unroll") for (int q_ = 0; q_ < 4; ++q_) A[q_] = *(const f32x4*)((PTR) + q_ * 4); } while (0)
+
+template <int NT>
+__device__ __forceinline__ void pair_gemm_ws_body(const PGParams& p, float* Ws) {   // no __restrict__: LDS shared across waves
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);   // wave-uniform values must live in SGPRs (scalar branches)
+    const int j = lane & 31, h = lane >> 5;
+    const int n_real = p.tile_k[p.n_tiles];
+    const int tile0 = (int)((int64_t)blockIdx.x * n_real / gridDim.x);
+    const int ntl = (int)((int64_t)(blockIdx.x + 1) * n_real / gridDim.x) - tile0;   // <= WS_RANGE_TILES by the launcher
+    if (ntl <= 0) return;
+    const int nchunks = p.Cin >> 5;
+    const int ldw = p.Cin + 4;                                 // (Cin + 4) mod 64 is 4 or 36: conflict-free b128 rows
+    const int c4 = p.Cin >> 2;
+    const int npieces = 32 * NT * c4;
+    int* Ix = (int*)(Ws + 32 * NT * ldw);         // gather rows of this workgroup's pairs; padding (-1) -> row 0
+    for (int f = tid; f < ntl * PT; f += 256) {
+        const int v = (p.dbg & 1) ? ((tile0 * PT + f) * 7) & 1023 : p.in_idx[(int64_t)tile0 * PT + f];
+        Ix[f] = v < 0 ? 0 : v;                                 // their partial products are never read back
+    }
+
+    f32x16 acc[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+
+    int run_start = 0;
+    while (run_start < ntl) {                                  // runs of tiles with the same offset (uniform)
+        const int k = p.tile_k[tile0 + run_start];
+        int run_end = run_start + 1;
+        while (run_end < ntl && p.tile_k[tile0 + run_end] == k) ++run_end;
+        __syncthreads();                                       // everyone is done reading the previous W (and Ix is written)
+        {
+            const float* __restrict__ W = p.wt + (int64_t)k * p.Cout * p.Cin;
+            for (int f0 = 0; f0 < npieces; f0 += 256 * 4) {
+                f32x4 v[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int f = f0 + u * 256 + tid;
+                    if (f < npieces) v[u] = *(const f32x4*)(W + (int64_t)f * 4);
+                }
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int f = f0 + u * 256 + tid;
+                    if (f < npieces) {
+                        const int row = f / c4, col = f - row * c4;
+                        *(f32x4*)(Ws + row * ldw + col * 4) = v[u];
+                    }
+                }
+            }
+        }
+        __syncthreads();
+        // this wave's 32-pair sub-tiles of the run: local sub-tile numbers u0, u0 + 4, ...
+        const int u0 = run_start * 4 + wv;
+        const int ns = (run_end * 4 - u0 + 3) / 4;
+        const int nsteps = ns * nchunks;
+        if (nsteps > 0) {
+            // address of the fragment of step (sub-tile i, chunk c); past the end -> sub-tile 0 (harmless reload)
+            auto frag_ptr = [&](int i, int c) -> const float* {
+                const int ii = i < ns ? i : 0;
+                const int row = Ix[(u0 + 4 * ii) * 32 + j];
+                const int cc = c * 32;                          // wave-uniform
+                const bool first = cc < p.C0;
+                const float* base = first ? p.in0 : p.in1;
+                const int ld = first ? p.ld0 : p.ld1;
+                return base + (int64_t)row * ld + (first ? cc : cc - p.C0) + h * 16;
+            };
+            f32x4 a0[4], a1[4], a2[4];
+            int pf_i = 0, pf_c = 0;
+#define WS_PF_ADVANCE() do { if (++pf_c == nchunks) { pf_c = 0; ++pf_i; } } while (0)
+            { const float* q = frag_ptr(pf_i, pf_c); LOAD_A4(a0, q); WS_PF_ADVANCE(); }
+            { const float* q = frag_ptr(pf_i, pf_c); LOAD_A4(a1, q); WS_PF_ADVANCE(); }
+            int cur_i = 0, cur_c = 0, s = 0;
+#define WS_STEP(CUR, PF)                                                                                              \
+    {                                                                                                                 \
+        const bool last_chunk = cur_c + 1 == nchunks;                                                                 \
+        { const float* q = frag_ptr(pf_i, pf_c); LOAD_A4(PF, q); WS_PF_ADVANCE(); }                                   \
+        {                                                                                                             \
+            const float* wb = Ws + j * ldw + cur_c * 32 + h * 16;                                                     \
+            f32x4 wq[2][NT];                                                                                          \
+            _Pragma("unroll") for (int t = 0; t < NT; ++t) wq[0][t] = *(const f32x4*)(wb + t * 32 * ldw);             \
+            _Pragma("unroll") for (int q = 0; q < 4; ++q) {                                                           \
+                if (q < 3) {                                                                                          \
+                    _Pragma("unroll") for (int t = 0; t < NT; ++t)                                                    \
+                        wq[(q + 1) & 1][t] = *(const f32x4*)(wb + t * 32 * ldw + (q + 1) * 4);                        \
+                }                                                                                                     \
+                _Pragma("unroll") for (int e = 0; e < 4; ++e)                                                         \
+                    _Pragma("unroll") for (int t = 0; t < NT; ++t)                                                    \
+                        acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(wq[q & 1][t][e], CUR[q][e], acc[t], 0, 0, 0);   \
+                __builtin_amdgcn_sched_barrier(0);                                                                    \
+            }                                                                                                         \
+        }                                                                                                             \
+        if (last_chunk) { /* sub-tile complete: lane = pair row, register group g = columns 8g + 4h .. +3 */          \
+            float* dst = p.part + ((int64_t)(tile0 * 4 + u0 + 4 * cur_i) * 32 + j) * p.Cout + 4 * h;                 \
+            _Pragma("unroll") for (int t = 0; t < NT; ++t)                                                            \
+                _Pragma("unroll") for (int g = 0; g < 4; ++g)                                                         \
+                    *(f32x4*)(dst + t * 32 + 8 * g) =                                                                 \
+                        f32x4{acc[t][4 * g], acc[t][4 * g + 1], acc[t][4 * g + 2], acc[t][4 * g + 3]};                \
+            _Pragma("unroll") for (int t = 0; t < NT; ++t)                                                            \
+                _Pragma("unroll") for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;                                       \
+        }                                                                                                             \
+        if (s + 1 >= nsteps) break;                                                                                   \
+        ++s;                                                                                                          \
+        if (last_chunk) { cur_c = 0; ++cur_i; } else { ++cur_c; }                                                     \
+    }
+            for (;;) {
+                WS_STEP(a0, a2)
+                WS_STEP(a1, a0)
+                WS_STEP(a2, a1)
+            }
+#undef WS_STEP
+#undef WS_PF_ADVANCE
+        }
+        run_start = run_end;
+    }
+}
+
+#define PAIR_GEMM_WS_ENTRY(NT, WAVES)                                                                              \
+    __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WAVES, WAVES))) void pair_gemm_ws_kernel_##NT( \
+        const PGParams p) {                                                                                        \
+        extern __shared__ __attribute__((aligned(16))) float ws_smem[];                                            \
+        pair_gemm_ws_body<NT>(p, ws_smem);                                                                         \
+    }
+PAIR_GEMM_WS_ENTRY(1, 4)
+PAIR_GEMM_WS_ENTRY(2, 3)
+PAIR_GEMM_WS_ENTRY(3, 3)
+PAIR_GEMM_WS_ENTRY(4, 2)
 
 // ---- pass 2: fixed-order reduction over the offsets + epilogue --------------------------------
 struct PRParams {
@@ -328,7 +470,8 @@ size_t pair_lists_ws_bytes(int K, int64_t M) {
     return (size_t)((int64_t)K * nblk + K) * sizeof(int32_t) + 256;
 }
 
-// p_cap: capacity of in_idx in pairs (multiple of 128, >= pairs + K * 127); tile_k has p_cap / 128 entries.
+// p_cap: capacity of in_idx in pairs (multiple of 128, >= pairs + K * 127); tile_k has p_cap / 128 + 1 entries
+// (the last one receives the number of real tiles).
 int launch_pair_lists(const int32_t* nbr, int K, int64_t M, int64_t p_cap, int32_t* pos, int32_t* in_idx, int32_t* tile_k,
                       void* ws, size_t ws_bytes, hipStream_t st) {
     if (K <= 0 || M <= 0) return SD3D_OK;
@@ -338,7 +481,7 @@ int launch_pair_lists(const int32_t* nbr, int K, int64_t M, int64_t p_cap, int32
     int32_t* blk_cnt = (int32_t*)ws;
     int32_t* totals = blk_cnt + (int64_t)K * nblk;
     if (hipMemsetAsync(in_idx, 0xFF, (size_t)p_cap * sizeof(int32_t), st) != hipSuccess ||
-        hipMemsetAsync(tile_k, 0xFF, (size_t)(p_cap / PT) * sizeof(int32_t), st) != hipSuccess)
+        hipMemsetAsync(tile_k, 0xFF, (size_t)(p_cap / PT + 1) * sizeof(int32_t), st) != hipSuccess)
         return sd3d_set_error(SD3D_ERR_LAUNCH, "pair_lists: memset failed");
     hipLaunchKernelGGL(pair_count_kernel, dim3(nblk, K), dim3(256), 0, st, nbr, M, nblk, blk_cnt);
     hipLaunchKernelGGL(pair_scan_kernel, dim3(K), dim3(256), 0, st, blk_cnt, nblk, totals);
@@ -367,19 +510,58 @@ int launch_pair_conv(const float* in0, int ld0, int C0, const float* in1, int ld
     if (sub > 4 && sub % 4) { for (int c = 4; c >= 1; --c) if (sub % c == 0) { nt = c; break; } }
     const int cgs = (int)cdiv(sub, nt);
     g.n_tiles = (int)(p_cap / PT);
-    // tiles per workgroup: long enough to amortise the pipeline fill, short enough to leave >= ~6 workgroups per CU
-    static int tpw_env = -1;
-    if (tpw_env < 0) { const char* e = getenv("SD3D_PAIR_TPW"); tpw_env = e ? atoi(e) : 0; }
-    int tpw = tpw_env > 0 ? tpw_env : (int)((int64_t)g.n_tiles * cgs / 1536);
-    tpw = tpw < 1 ? 1 : (tpw > 8 ? 8 : tpw);
-    g.tiles_per_wg = tpw;
     { static int dbg = -1; if (dbg < 0) { const char* e = getenv("SD3D_PAIR_DBG"); dbg = e ? atoi(e) : 0; } g.dbg = dbg; }
-    const dim3 grid((unsigned)cdiv(g.n_tiles, tpw), (unsigned)cgs);
-    switch (nt) {
-        case 1: hipLaunchKernelGGL(pair_gemm_kernel_1, grid, dim3(256), 0, st, g); break;
-        case 2: hipLaunchKernelGGL(pair_gemm_kernel_2, grid, dim3(256), 0, st, g); break;
-        case 3: hipLaunchKernelGGL(pair_gemm_kernel_3, grid, dim3(256), 0, st, g); break;
-        default: hipLaunchKernelGGL(pair_gemm_kernel_4, grid, dim3(256), 0, st, g); break;
+    static int slots_env = -1;                                 // SD3D_PAIR_SLOTS: workgroups per CU override (tuning)
+    if (slots_env < 0) { const char* e = getenv("SD3D_PAIR_SLOTS"); slots_env = e ? atoi(e) : 0; }
+    static int n_cu = 0;
+    if (!n_cu) {
+        int dev = 0; hipDeviceProp_t prop;
+        if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return sd3d_set_error(SD3D_ERR_LAUNCH, "pair_conv: no device");
+        n_cu = prop.multiProcessorCount;
+    }
+    // weight-stationary variant: Cout = 32 * nt <= 128 and W[k] (padded rows) <= 68 KB of LDS
+    static int ws_env = -1;
+    if (ws_env < 0) { const char* e = getenv("SD3D_PAIR_WS"); ws_env = e ? atoi(e) : 1; }
+    const size_t w_lds = (size_t)Cout * (Cin + 4) * sizeof(float);
+    if (ws_env && cgs == 1 && Cout == 32 * nt && w_lds <= 68 * 1024) {
+        static bool attr_done = false;
+        if (!attr_done) {
+            (void)hipFuncSetAttribute((const void*)pair_gemm_ws_kernel_1, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
+            (void)hipFuncSetAttribute((const void*)pair_gemm_ws_kernel_2, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
+            (void)hipFuncSetAttribute((const void*)pair_gemm_ws_kernel_3, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
+            (void)hipFuncSetAttribute((const void*)pair_gemm_ws_kernel_4, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
+            attr_done = true;
+        }
+        // resident workgroups per CU: the pinned register budgets allow 4 / 3 / 3 / 2; LDS (160 KB) may allow fewer
+        int per_cu = nt == 1 ? 4 : (nt == 4 ? 2 : 3);
+        const int by_lds = (int)((160 * 1024) / (w_lds + WS_RANGE_TILES * PT * sizeof(int32_t) + 256));
+        per_cu = per_cu < by_lds ? per_cu : by_lds;
+        if (slots_env > 0) per_cu = slots_env;
+        int gx = n_cu * per_cu;
+        gx = gx < g.n_tiles ? gx : g.n_tiles;
+        { static int gx_env = -1; if (gx_env < 0) { const char* e = getenv("SD3D_PAIR_GX"); gx_env = e ? atoi(e) : 0; } if (gx_env > 0) gx = gx_env; }
+        const int need = (int)cdiv(g.n_tiles, WS_RANGE_TILES);  // a range must fit the LDS index buffer
+        gx = gx > need ? gx : need;
+        const dim3 wgrid((unsigned)gx);
+        const size_t lds = w_lds + (size_t)WS_RANGE_TILES * PT * sizeof(int32_t);
+        switch (nt) {
+            case 1: hipLaunchKernelGGL(pair_gemm_ws_kernel_1, wgrid, dim3(256), lds, st, g); break;
+            case 2: hipLaunchKernelGGL(pair_gemm_ws_kernel_2, wgrid, dim3(256), lds, st, g); break;
+            case 3: hipLaunchKernelGGL(pair_gemm_ws_kernel_3, wgrid, dim3(256), lds, st, g); break;
+            default: hipLaunchKernelGGL(pair_gemm_ws_kernel_4, wgrid, dim3(256), lds, st, g); break;
+        }
+    } else {
+        int per_cu = nt == 1 ? 3 : 2;
+        if (slots_env > 0) per_cu = slots_env;
+        int gx = n_cu * per_cu / cgs;
+        gx = gx < 1 ? 1 : (gx < g.n_tiles ? gx : g.n_tiles);
+        const dim3 grid((unsigned)gx, (unsigned)cgs);
+        switch (nt) {
+            case 1: hipLaunchKernelGGL(pair_gemm_kernel_1, grid, dim3(256), 0, st, g); break;
+            case 2: hipLaunchKernelGGL(pair_gemm_kernel_2, grid, dim3(256), 0, st, g); break;
+            case 3: hipLaunchKernelGGL(pair_gemm_kernel_3, grid, dim3(256), 0, st, g); break;
+            default: hipLaunchKernelGGL(pair_gemm_kernel_4, grid, dim3(256), 0, st, g); break;
+        }
     }
     PRParams r;
     r.pos = pos; r.K = K; r.M = M; r.part = part; r.Cout = Cout; r.scale = scale; r.shift = shift; r.res = res; r.ld_res = ld_res;

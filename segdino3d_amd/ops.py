@@ -337,7 +337,7 @@ def pair_lists(nbr, n_pairs):
     p_cap = (int(n_pairs) + 127 * K + 127) // 128 * 128
     pos = torch.empty(K, M, dtype=torch.int32, device=nbr.device)
     in_idx = torch.empty(p_cap, dtype=torch.int32, device=nbr.device)
-    tile_k = torch.empty(p_cap // 128, dtype=torch.int32, device=nbr.device)
+    tile_k = torch.empty(p_cap // 128 + 1, dtype=torch.int32, device=nbr.device)     # last entry: number of real tiles
     nb = lib.sd3d_pair_lists_ws_bytes(K, M)
     ws = _WS4.get(nb, nbr.device)
     _lib.check(lib.sd3d_pair_lists(_ptr(nbr, torch.int32, "nbr"), K, M, p_cap, pos.data_ptr(), in_idx.data_ptr(),

@@ -291,7 +291,7 @@ def test_pair_lists_are_exact():
         off = 0
         exp_pos = np.full((K, M), -1, np.int32)
         exp_idx = np.full(pl.p_cap, -1, np.int32)
-        exp_tk = np.full(pl.p_cap // 128, -1, np.int32)
+        exp_tk = np.full(pl.p_cap // 128 + 1, -1, np.int32)
         for k in range(K):
             rows = np.nonzero(h[k] >= 0)[0]
             exp_pos[k, rows] = off + np.arange(len(rows))
@@ -299,6 +299,7 @@ def test_pair_lists_are_exact():
             seg = (len(rows) + 127) // 128 * 128
             exp_tk[off // 128:(off + seg) // 128] = k
             off += seg
+        exp_tk[-1] = off // 128
         assert np.array_equal(pos, exp_pos) and np.array_equal(in_idx, exp_idx) and np.array_equal(tile_k, exp_tk)
 
 
@@ -349,3 +350,31 @@ def test_pair_conv_matches_gather_gemm_and_fp64():
         # deterministic: same bits run to run
         again = ops.pair_conv(xin, wd, pairs, x2=x2, **kw).double().cpu()
         assert torch.equal(got, again)
+
+
+def test_pair_conv_small_scene_many_offset_runs():
+    """A small scene makes every workgroup of the weight-stationary kernel walk several short offset runs
+    (W[k] re-staged in LDS between barriers) and leaves most of the persistent grid without work."""
+    from segdino3d_amd import ops
+    from segdino3d_amd.sparse import SceneMaps
+    from segdino3d_amd.synth import make_scene
+    d = dev()
+    pts, tgt = make_scene(31, n_points=9000, n_superpoints=60, n_query2d=5)
+    maps = SceneMaps(pts.to(d), 0.02, 5, superpoints=tgt.extra_features["super_point_masks"].to(d))
+    maps.prepare(same=[(0, 5)] + [(l, 3) for l in range(5)], strides=[0, 1, 2, 3])
+    g = torch.Generator().manual_seed(0)
+    cases = [(("same", 0, 5), 32, 32)] + [(("same", l, 3), c, c) for l, c in [(0, 96), (1, 32), (2, 64), (3, 128), (4, 256), (1, 96)]] + \
+            [(("down", l), ci, co) for l, ci, co in [(0, 32, 32), (1, 32, 64), (3, 128, 256)]] + \
+            [(("up", l), ci, co) for l, ci, co in [(3, 256, 256), (2, 256, 128), (0, 96, 96)]]
+    for key, cin, cout in cases:
+        tab = maps.conv_table(*key)
+        nbr, pairs = tab["nbr"], tab["pairs"]
+        K, M = nbr.shape
+        n_in = int(nbr.max().item()) + 1
+        x = torch.randn(n_in, cin, generator=g).to(d)
+        w = (torch.randn(K, cout, cin, generator=g) * (K * cin) ** -0.5).to(d)
+        ref = ops.gather_gemm(x, w, nbr=nbr, nt=1)
+        for _ in range(2):
+            got = ops.pair_conv(x, w, pairs)
+            err = (got - ref).abs().max().item()
+            assert err < 2e-5, f"{key} {cin}->{cout}: {err:.2e}"      # NaN fails this too

@@ -13,6 +13,9 @@ g = torch.Generator().manual_seed(0)
 cases = [(("same", 0, 5), 288, 32), (("same", 0, 3), 96, 96), (("same", 0, 3), 128, 96), (("same", 1, 3), 32, 32), (("same", 1, 3), 96, 96),
          (("same", 2, 3), 64, 64), (("same", 2, 3), 128, 128), (("same", 2, 3), 192, 128), (("same", 3, 3), 128, 128), (("same", 3, 3), 256, 256),
          (("same", 3, 3), 384, 256), (("same", 4, 3), 256, 256), (("down", 0), 32, 32), (("up", 0), 128, 96), (("up", 2), 256, 128)]
+sel = os.environ.get("PAIR_CASES")
+if sel:
+    cases = [cases[int(i)] for i in sel.split(",")]
 for key, cin, cout in cases:
     tab = maps.conv_table(*key); nbr, pairs = tab["nbr"], tab["pairs"]
     K, M = nbr.shape
