@@ -224,6 +224,9 @@ class Baseline3D(nn.Module):
     def predict_by_feat(self, samples, out, superpoints):
         cfg = self.test_cfg
         com = self._instances_common(samples, out, superpoints)
+        # the data-dependent selections below synchronise; wait for the scene's work by polling first so that no
+        # host thread sits inside a blocking HIP call while other scenes are being issued
+        ops.wait_event(ops.stream_event())
         keep, score_mask, npoint_mask = self._select(com, float(_cfg_get(cfg, "inst_score_thr")))
         inst_masks = com["masks"][keep].view(torch.bool)
         inst_labels, inst_scores = com["labels"][keep].long(), com["scores"][keep]

@@ -81,6 +81,50 @@ def _rows(t: torch.Tensor, name="tensor"):
     return t.data_ptr(), t.stride(0)
 
 
+class HostRead:
+    """Small device -> host read that never blocks inside the HIP runtime: asynchronous copy into pinned
+    memory + an event that is POLLED.  A blocking `.cpu()` / stream synchronise in one host thread was
+    measured to stall the kernel launches of the other threads of the pipelined runner (two processes on
+    one GPU reached 120 scenes/s where three threads of one process reached 65-93)."""
+
+    __slots__ = ("buf", "event")
+
+    def __init__(self, dev_tensor: torch.Tensor):
+        if BLOCKING_SYNC:
+            self.buf, self.event = dev_tensor.cpu(), None
+            return
+        self.buf = torch.empty(dev_tensor.shape, dtype=dev_tensor.dtype, pin_memory=True)
+        self.buf.copy_(dev_tensor, non_blocking=True)
+        self.event = torch.cuda.Event()
+        self.event.record()
+
+    def wait(self):
+        if self.event is not None:
+            wait_event(self.event)
+        return self.buf
+
+
+BLOCKING_SYNC = _os.environ.get("SD3D_BLOCKING_SYNC") == "1"      # A/B switch: blocking .cpu() / event.synchronize()
+
+
+def wait_event(ev):
+    """Poll `ev`, yielding the GIL (and the core) between polls."""
+    import time
+    if BLOCKING_SYNC:
+        ev.synchronize()
+        return
+    spins = 0
+    while not ev.query():
+        spins += 1
+        time.sleep(0 if spins < 200 else 5e-5)
+
+
+def stream_event():
+    ev = torch.cuda.Event()
+    ev.record()
+    return ev
+
+
 class Workspace:
     """Grow-only scratch buffer (bytes) per device."""
 

@@ -94,7 +94,7 @@ class SceneMaps:
             sp_keys = ops.keys_from_i64(superpoints)
             self.sp_sorted, self.sp_sidx = ops.sort_pairs(sp_keys, None, 0, 32)
             extra.append(self.sp_sorted[-1:].to(torch.int32))
-        host = torch.cat(counts + extra).cpu().tolist()          # the one synchronisation of the scene
+        host = ops.HostRead(torch.cat(counts + extra)).wait().tolist()   # synchronisation 1 of the scene (polled)
         self.n_vox = [int(v) for v in host[:n_levels]]
         if host[n_levels] != 0:
             raise RuntimeError("scene exceeds the 16-bit-per-axis voxel key range (extent > ~1.3 km at 2 cm)")
@@ -121,7 +121,7 @@ class SceneMaps:
             self._same[(lvl, k)] = ops.kernel_map(self.keys[lvl], self.n_vox[lvl], self.table(lvl), offs, counters[i])
         for lvl in strides:
             self._stride_maps(lvl)
-        host = counters.cpu().sum(dim=1).tolist() if same else []
+        host = ops.HostRead(counters.sum(dim=1)).wait().tolist() if same else []   # synchronisation 2 (polled)
         for (lvl, k), c in zip(same, host):
             self.density[("same", lvl, k)] = c / max(1, k ** 3 * self.n_vox[lvl])
             if ops.PAIR_CONV:
