@@ -145,6 +145,34 @@ int sd3d_pair_conv(const float* in0, int ld0, int C0, const float* in1, int ld1,
                    int64_t M, const float* scale, const float* shift, const float* res, int ld_res, float* out,
                    int ld_out, int act, float* part, size_t part_bytes, void* stream);
 
+/* Layer-sequence executor (csrc/executor.hip): a whole sparse U-Net forward from one call.  Replaces the
+ * Python-level module loop of Res16UNetBase.forward (minkunet.py:531-601) / UBlock.forward
+ * (spconvunet.py:156-201): the plan is built once per model, per scene the caller supplies the
+ * neighbour tables and the activation buffers (one arena, carved by the caller); the call only enqueues.
+ *   SD3D_LAYER_PAIR_CONV        out = act(scale * conv(cat[src0, src1]; table) + shift + res)   (sd3d_pair_conv)
+ *   SD3D_LAYER_DENSE            the same with identity rows, K = 1                                 (sd3d_gather_gemm)
+ *   SD3D_LAYER_SCALE_SHIFT_ACT  out = act(cat[src0, src1] * scale + shift), Cin = total channels  (sd3d_scale_shift_act) */
+enum { SD3D_LAYER_PAIR_CONV = 0, SD3D_LAYER_DENSE = 1, SD3D_LAYER_SCALE_SHIFT_ACT = 2 };
+typedef struct sd3d_layer {
+    int32_t kind, table;               /* table: index into tables[] (PAIR_CONV) */
+    int32_t src0, src1, res, dst;      /* buffer ids; src1 / res = -1 when absent */
+    int32_t K, Cin, C0, Cout, act;     /* C0 = channels taken from src0 (Cin when src1 is absent) */
+    int32_t pad_;
+    const float *wt, *scale, *shift;   /* wt [K, Cout, Cin]; scale / shift per output channel or NULL */
+} sd3d_layer;
+typedef struct sd3d_table {
+    const int32_t *in_idx, *tile_k, *pos;   /* from sd3d_pair_lists */
+    int64_t p_cap, M;                        /* M = output rows of the table */
+    int32_t K, pad_;
+} sd3d_table;
+typedef struct sd3d_buf {
+    float* ptr;
+    int64_t rows;
+    int32_t ld, pad_;
+} sd3d_buf;
+int sd3d_run_layers(const sd3d_layer* layers, int n_layers, const sd3d_table* tables, int n_tables, const sd3d_buf* bufs,
+                    int n_bufs, float* part, size_t part_bytes, void* ws, size_t ws_bytes, void* stream);
+
 /* ---------------------------------------------------------------------------------------------
  * Decoder kernels (segdino3d/models/decoder/instance_seg_3d_decoder.py:606-799,
  * segdino3d/models/module/attention.py:186-395, segdino3d/models/module/utils.py:53-105)

@@ -48,6 +48,7 @@ SIGNATURES = {
     "sd3d_pair_lists_ws_bytes": (_z, [_i, _l]),
     "sd3d_pair_lists": (_i, [_p, _i, _l, _l, _p, _p, _p, _p, _z, _p]),
     "sd3d_pair_conv": (_i, [_p, _i, _i, _p, _i, _p, _p, _l, _p, _p, _i, _i, _i, _l, _p, _p, _p, _i, _p, _i, _i, _p, _z, _p]),
+    "sd3d_run_layers": (_i, [_p, _i, _p, _i, _p, _i, _p, _z, _p, _z, _p]),
     "sd3d_layernorm": (_i, [_p, _i, _p, _i, _p, _p, _f, _l, _i, _p, _i, _i, _p]),
     "sd3d_sine_pe": (_i, [_p, _i, _l, _p, _p, _p, _i, _p, _i, _p, _i, _p, _i, _p]),
     "sd3d_attention": (_i, [_p, _i, _p, _i, _p, _i, _p, _i, _p, _i, _p, _i, _i, _i, _f, _p, _i, _p]),
@@ -96,6 +97,23 @@ def load():
         raise HipExtensionMissing(f"ABI version mismatch: library {lib.sd3d_abi_version()} != binding {ABI_VERSION}")
     _lib = lib
     return lib
+
+
+_lib_nogil = None
+
+
+def load_nogil():
+    """Second handle of the same library whose calls RELEASE the GIL (ctypes.CDLL): for the few long entry
+    points (sd3d_run_layers enqueues ~250 kernels) so that other host threads keep issuing meanwhile."""
+    global _lib_nogil
+    if _lib_nogil is None:
+        load()
+        lib = C.CDLL(LIB_PATH)
+        for name in ("sd3d_run_layers",):
+            fn = getattr(lib, name)
+            fn.restype, fn.argtypes = SIGNATURES[name]
+        _lib_nogil = lib
+    return _lib_nogil
 
 
 def check(rc: int, what: str = ""):

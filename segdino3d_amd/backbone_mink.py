@@ -22,7 +22,7 @@ from typing import List
 import torch
 import torch.nn as nn
 
-from . import ops
+from . import ops, plan
 from .builder import BACKBONES
 from .sparse import SceneMaps
 
@@ -124,6 +124,7 @@ class Res16UNetBase(nn.Module):
             setattr(self, f"block{5 + i}", self._make_layer(P[4 + i], Ly[4 + i], mom))
         self.out_planes = P[7]
         self._packed = None
+        self._plan = None
         self.last_maps = None          # SceneMaps of the most recent scene (bench.py reads rulebook sizes)
 
     def _make_layer(self, planes, blocks, mom):
@@ -139,18 +140,22 @@ class Res16UNetBase(nn.Module):
     # ---- weight packing ------------------------------------------------------------------------
     def _apply(self, fn, *a, **k):
         self._packed = None
+        self._plan = None
         return super()._apply(fn, *a, **k)
 
     def load_state_dict(self, *a, **k):
         self._packed = None
+        self._plan = None
         return super().load_state_dict(*a, **k)
 
     def _load_from_state_dict(self, *a, **k):
         self._packed = None
+        self._plan = None
         return super()._load_from_state_dict(*a, **k)
 
     def invalidate_packed_weights(self):
         self._packed = None
+        self._plan = None
 
     def packed(self):
         """name -> (wt [K,Cout,Cin], scale, shift) in the device layout; rebuilt after .to()/load."""
@@ -167,54 +172,60 @@ class Res16UNetBase(nn.Module):
         return self._packed
 
     # ---- network ---------------------------------------------------------------------------------
-    def _cbr(self, pk, x, conv, bn, tab, x2=None):
-        s, b = pk[bn]
-        return ops.gather_gemm(x, pk[conv], x2=x2, scale=s, shift=b, act="relu", **tab)
+    def _cbr(self, be, pk, x, conv, bn, key, x2=None):
+        return be.conv(x, pk[conv], pk[bn], key, x2=x2, act="relu")
 
-    def _stage(self, pk, name, nblocks, x, tab, x2=None):
+    def _stage(self, be, pk, name, nblocks, x, key, x2=None):
         for j in range(nblocks):
             p = f"{name}.{j}"
-            s1, b1 = pk[p + ".norm1"]
-            h = ops.gather_gemm(x, pk[p + ".conv1"], x2=x2, scale=s1, shift=b1, act="relu", **tab)
+            h = be.conv(x, pk[p + ".conv1"], pk[p + ".norm1"], key, x2=x2, act="relu")
             if (p + ".downsample.0") in pk:
-                sd, bd = pk[p + ".downsample.1"]
-                res = ops.gather_gemm(x, pk[p + ".downsample.0"], x2=x2, scale=sd, shift=bd)
+                res = be.dense(x, pk[p + ".downsample.0"], pk[p + ".downsample.1"], x2=x2)
             else:
                 res = x
-            s2, b2 = pk[p + ".norm2"]
-            x = ops.gather_gemm(h, pk[p + ".conv2"], scale=s2, shift=b2, res=res, act="relu", **tab)
+            x = be.conv(h, pk[p + ".conv2"], pk[p + ".norm2"], key, res=res, act="relu")
             x2 = None
         return x
+
+    def _network(self, be, pk, x):
+        """`Res16UNetBase.forward` (`minkunet.py:531-601`) against a plan backend (segdino3d_amd.plan)."""
+        Ly = self.LAYERS
+        k1 = self.conv1_kernel_size
+        k3 = [("same", l, 3) for l in range(5)]
+        dn = [("down", l) for l in range(4)]
+        up = [("up", l) for l in range(4)]
+        out_p1 = self._cbr(be, pk, x, "conv0p1s1", "bn0", ("same", 0, k1))
+        out = self._cbr(be, pk, out_p1, "conv1p1s2", "bn1", dn[0])
+        out_b1p2 = self._stage(be, pk, "block1", Ly[0], out, k3[1])
+        out = self._cbr(be, pk, out_b1p2, "conv2p2s2", "bn2", dn[1])
+        out_b2p4 = self._stage(be, pk, "block2", Ly[1], out, k3[2])
+        out = self._cbr(be, pk, out_b2p4, "conv3p4s2", "bn3", dn[2])
+        out_b3p8 = self._stage(be, pk, "block3", Ly[2], out, k3[3])
+        out = self._cbr(be, pk, out_b3p8, "conv4p8s2", "bn4", dn[3])
+        out = self._stage(be, pk, "block4", Ly[3], out, k3[4])
+        out = self._cbr(be, pk, out, "convtr4p16s2", "bntr4", up[3])
+        out = self._stage(be, pk, "block5", Ly[4], out, k3[3], x2=out_b3p8)
+        out = self._cbr(be, pk, out, "convtr5p8s2", "bntr5", up[2])
+        out = self._stage(be, pk, "block6", Ly[5], out, k3[2], x2=out_b2p4)
+        out = self._cbr(be, pk, out, "convtr6p4s2", "bntr6", up[1])
+        out = self._stage(be, pk, "block7", Ly[6], out, k3[1], x2=out_b1p2)
+        out = self._cbr(be, pk, out, "convtr7p2s2", "bntr7", up[0])
+        out = self._stage(be, pk, "block8", Ly[7], out, k3[0], x2=out_p1)
+        return out
 
     def forward_sparse(self, maps: SceneMaps, vox_feats: torch.Tensor) -> torch.Tensor:
         """`Res16UNetBase.forward` (`minkunet.py:531-601`): [V0, Cin_padded] -> [V0, 96]."""
         if self.training:
             raise NotImplementedError("segdino3d_amd backbone: eval-mode forward only (training step not built)")
         pk = self.packed()
-        Ly = self.LAYERS
         k1 = self.conv1_kernel_size
         maps.prepare(same=[(0, k1)] + [(l, 3) for l in range(5)], strides=[0, 1, 2, 3])
-        k3 = [maps.conv_table("same", l, 3) for l in range(5)]
-        dn = [maps.conv_table("down", l) for l in range(4)]
-        up = [maps.conv_table("up", l) for l in range(4)]
-        out_p1 = self._cbr(pk, vox_feats, "conv0p1s1", "bn0", maps.conv_table("same", 0, k1))
-        out = self._cbr(pk, out_p1, "conv1p1s2", "bn1", dn[0])
-        out_b1p2 = self._stage(pk, "block1", Ly[0], out, k3[1])
-        out = self._cbr(pk, out_b1p2, "conv2p2s2", "bn2", dn[1])
-        out_b2p4 = self._stage(pk, "block2", Ly[1], out, k3[2])
-        out = self._cbr(pk, out_b2p4, "conv3p4s2", "bn3", dn[2])
-        out_b3p8 = self._stage(pk, "block3", Ly[2], out, k3[3])
-        out = self._cbr(pk, out_b3p8, "conv4p8s2", "bn4", dn[3])
-        out = self._stage(pk, "block4", Ly[3], out, k3[4])
-        out = self._cbr(pk, out, "convtr4p16s2", "bntr4", up[3])
-        out = self._stage(pk, "block5", Ly[4], out, k3[3], x2=out_b3p8)
-        out = self._cbr(pk, out, "convtr5p8s2", "bntr5", up[2])
-        out = self._stage(pk, "block6", Ly[5], out, k3[2], x2=out_b2p4)
-        out = self._cbr(pk, out, "convtr6p4s2", "bntr6", up[1])
-        out = self._stage(pk, "block7", Ly[6], out, k3[1], x2=out_b1p2)
-        out = self._cbr(pk, out, "convtr7p2s2", "bntr7", up[0])
-        out = self._stage(pk, "block8", Ly[7], out, k3[0], x2=out_p1)
-        return out
+        if plan.USE_PLAN and ops.PAIR_CONV and ops.GEMM_MODE is None and ops.GG_FORCE_NT is None and ops.GG_HOOK is None:
+            if self._plan is None:                               # one C call per scene instead of ~110
+                rec = plan.Recorder(vox_feats.shape[1])
+                self._plan = rec.finish(self._network(rec, pk, rec.input))
+            return self._plan.run(maps, vox_feats)
+        return self._network(plan.EagerBackend(maps), pk, vox_feats)
 
     @ops.bound_stream
     def forward_wrapper(self, samples: List[torch.Tensor], targets, return_sp_mean_pos=False):

@@ -378,3 +378,28 @@ def test_pair_conv_small_scene_many_offset_runs():
             got = ops.pair_conv(x, w, pairs)
             err = (got - ref).abs().max().item()
             assert err < 2e-5, f"{key} {cin}->{cout}: {err:.2e}"      # NaN fails this too
+
+
+def test_layer_plan_matches_eager():
+    """The C-side layer-sequence executor (sd3d_run_layers) and the layer-by-layer Python path enqueue the
+    same kernels in the same order: bit-identical outputs."""
+    import segdino3d_amd as seg
+    from segdino3d_amd import plan
+    from segdino3d_amd.configs import scannet200_model_cfg
+    from segdino3d_amd.synth import make_scene
+    d = dev()
+    model = seg.build_architecture(scannet200_model_cfg(query_num=40)).eval().to(d)
+    bb = model.backbone
+    for seed, n in ((3, 20000), (4, 7000)):
+        pts, tgt = make_scene(seed, n, 200, 20)
+        samples, targets = [pts.to(d)], [tgt.to(d)]
+        with torch.no_grad():
+            plan.USE_PLAN = True
+            f_plan, _, p_plan = bb.forward_wrapper(samples, targets, return_sp_mean_pos=True)
+            assert bb._plan is not None
+            plan.USE_PLAN = False
+            try:
+                f_eager, _, p_eager = bb.forward_wrapper(samples, targets, return_sp_mean_pos=True)
+            finally:
+                plan.USE_PLAN = True
+        assert torch.equal(f_plan[0], f_eager[0]) and torch.equal(p_plan[0], p_eager[0])

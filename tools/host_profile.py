@@ -5,7 +5,8 @@ import bench
 from segdino3d_amd.synth import make_scene
 d = torch.device("cuda:0")
 model = bench.build_model(200, d)
-pts, tgt = make_scene(0, 150000, 3000, 300)
+N = int(sys.argv[1]) if len(sys.argv) > 1 else 150000
+pts, tgt = make_scene(0, N, 3000 if N > 10000 else 300, 300)
 pts = pts.to(d); tgt = tgt.to(d)
 with torch.no_grad():
     for _ in range(3):
@@ -24,4 +25,4 @@ with torch.no_grad():
         model([pts], [tgt])
     torch.cuda.synchronize()
     pr.disable()
-    st = pstats.Stats(pr); st.sort_stats("tottime").print_stats(28)
+    st = pstats.Stats(pr); st.sort_stats("tottime").print_stats(45)
