@@ -233,6 +233,21 @@ class ScanNetQueryDecoder(nn.Module):
                 pk["q2d_b"] = [b[:d].contiguous() for b in bs]
                 pk["kv2d_w"] = torch.cat([w[d:2 * d] for w in ws] + [w[2 * d:] for w in ws]).contiguous()
                 pk["kv2d_b"] = torch.cat([b[d:2 * d] for b in bs] + [b[2 * d:] for b in bs]).contiguous()
+            # self-attention q / k / v of one layer as ONE GEMM over the concatenated input [queries | query_pos]:
+            #   q = Wqc q + Wqp p,  k = Wkc q + Wkp p,  v = Wv q            (5 launches -> 1, :695-700)
+            sa_w, sa_b = [], []
+            for i in range(L):
+                wq = torch.cat([self.sa_qcontent_proj[i].weight, self.sa_qpos_proj[i].weight], dim=1)
+                wk = torch.cat([self.sa_kcontent_proj[i].weight, self.sa_kpos_proj[i].weight], dim=1)
+                wv = torch.cat([self.sa_v_proj[i].weight, torch.zeros_like(self.sa_v_proj[i].weight)], dim=1)
+                sa_w.append(torch.cat([wq, wk, wv]).detach().contiguous())
+                sa_b.append(torch.cat([self.sa_qcontent_proj[i].bias + self.sa_qpos_proj[i].bias,
+                                       self.sa_kcontent_proj[i].bias + self.sa_kpos_proj[i].bias,
+                                       self.sa_v_proj[i].bias]).detach().contiguous())
+            pk["sa_qkv_w"], pk["sa_qkv_b"] = sa_w, sa_b
+            # first layer's content query also takes the positional query (:672): [queries | query_pos] again
+            pk["ca_q0_w"] = torch.cat([self.ca_qcontent_proj[0].weight, self.ca_qpos_proj.weight], dim=1).detach().contiguous()
+            pk["ca_q0_b"] = (self.ca_qcontent_proj[0].bias + self.ca_qpos_proj.bias).detach().contiguous()
             self._packed = pk
         return self._packed
 
@@ -365,7 +380,7 @@ class ScanNetQueryDecoder(nn.Module):
             v = kv_all[:, (L + i) * d:(L + i + 1) * d]
             kp = kp_all[:, i * d:(i + 1) * d]
             if i == 0:
-                qc = _lin(queries, self.ca_qcontent_proj[0], res=_lin(query_pos, self.ca_qpos_proj))
+                qc = ops.gather_gemm(queries, pk["ca_q0_w"], x2=query_pos, shift=pk["ca_q0_b"])
                 kc = _lin(inst, self.ca_kcontent_proj[0], res=kp)
             else:
                 qc = _lin(queries, self.ca_qcontent_proj[i])
@@ -374,10 +389,8 @@ class ScanNetQueryDecoder(nn.Module):
             a = _lin(a, self.cross_attn_layers[i].out_proj)
             queries = ops.layernorm(a, self.norm1[i].weight, self.norm1[i].bias, res=queries)
             # ---- self-attention (:695-709)
-            q = _lin(queries, self.sa_qcontent_proj[i], res=_lin(query_pos, self.sa_qpos_proj[i]))
-            k = _lin(queries, self.sa_kcontent_proj[i], res=_lin(query_pos, self.sa_kpos_proj[i]))
-            v = _lin(queries, self.sa_v_proj[i])
-            a = ops.attention(q, k, v, H, (d // H) ** -0.5)
+            qkv = ops.gather_gemm(queries, pk["sa_qkv_w"][i], x2=query_pos, shift=pk["sa_qkv_b"][i])     # [Q, 3d]
+            a = ops.attention(qkv[:, :d], qkv[:, d:2 * d], qkv[:, 2 * d:], H, (d // H) ** -0.5)
             a = _lin(a, self.self_attn_layers[i].out_proj)
             queries = ops.layernorm(a, self.norm2[i].weight, self.norm2[i].bias, res=queries)
             # ---- cross-attention to the cached DINO-X 2D object queries (:713-731, :60-86)
