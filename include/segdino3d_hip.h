@@ -225,10 +225,12 @@ int sd3d_gather_sigmoid(const float* masks, int ld, int S, const int32_t* qidx, 
 int sd3d_nms_decay(const float* inter, int ld, const float* area, const int32_t* labels, int n, int gaussian,
                    float sigma, const float* score_in, float* comp_ws, float* score_out, void* stream);
 /* superpoint -> point broadcast + threshold + point count + optional box filter (:453-454, :464, :348-371).
- * out [n, N] bytes (0/1); count[n] counts BEFORE the box filter; boxes [n,6] or NULL. */
+ * out [n, N] bytes (0/1); count[n] counts BEFORE the box filter; boxes [n,6] or NULL.  Superpoint ids must be
+ * < ld_sig (the padded row width of sig); ws holds the thresholded rows as a bit table. */
+size_t sd3d_expand_masks_ws_bytes(int n, int ld_sig);
 int sd3d_expand_masks(const float* sig, int ld_sig, const uint32_t* src_row, int n, const int64_t* superpoints,
                       const float* points, int ld_points, int64_t N, float sp_thr, const float* boxes, float loose_ratio,
-                      uint8_t* out, int32_t* count, void* stream);
+                      uint8_t* out, int32_t* count, void* ws, size_t ws_bytes, void* stream);
 /* argmax over selected columns (:504) and table gather (:504-507). */
 int sd3d_row_argmax(const float* x, int ld, int64_t Q, const int32_t* cols, int ncols, int64_t* out, void* stream);
 int sd3d_gather_i64(const int64_t* table, const int64_t* idx, int64_t N, int use_index, int64_t* out, void* stream);

@@ -61,7 +61,8 @@ SIGNATURES = {
     "sd3d_mask_scores": (_i, [_p, _i, _i, _p, _p, _i, _i, _i, _p, _p, _p, _p]),
     "sd3d_gather_sigmoid": (_i, [_p, _i, _i, _p, _p, _i, _p, _i, _p, _p]),
     "sd3d_nms_decay": (_i, [_p, _i, _p, _p, _i, _i, _f, _p, _p, _p, _p]),
-    "sd3d_expand_masks": (_i, [_p, _i, _p, _i, _p, _p, _i, _l, _f, _p, _f, _p, _p, _p]),
+    "sd3d_expand_masks_ws_bytes": (_z, [_i, _i]),
+    "sd3d_expand_masks": (_i, [_p, _i, _p, _i, _p, _p, _i, _l, _f, _p, _f, _p, _p, _p, _z, _p]),
     "sd3d_row_argmax": (_i, [_p, _i, _l, _p, _i, _p, _p]),
     "sd3d_gather_i64": (_i, [_p, _p, _l, _i, _p, _p]),
     "sd3d_panoptic": (_i, [_p, _l, _p, _p, _i, _i, _i, _p, _p, _p, _p, _p, _p]),

@@ -60,7 +60,8 @@ int launch_class_scores(const float*, int, int64_t, int, float*, float*, hipStre
 int launch_mask_scores(const float*, int, int, const uint32_t*, const float*, int, int, int, int32_t*, int32_t*, float*, hipStream_t);
 int launch_gather_sigmoid(const float*, int, int, const int32_t*, const uint32_t*, int, float*, int, float*, hipStream_t);
 int launch_nms_decay(const float*, int, const float*, const int32_t*, int, int, float, const float*, float*, float*, hipStream_t);
-int launch_expand_masks(const float*, int, const uint32_t*, int, const int64_t*, const float*, int, int64_t, float, const float*, float, uint8_t*, int32_t*, hipStream_t);
+size_t expand_masks_ws_bytes(int n, int ld_sig);
+int launch_expand_masks(const float*, int, const uint32_t*, int, const int64_t*, const float*, int, int64_t, float, const float*, float, uint8_t*, int32_t*, void*, size_t, hipStream_t);
 int launch_row_argmax(const float*, int, int64_t, const int32_t*, int, int64_t*, hipStream_t);
 int launch_gather_i64(const int64_t*, const int64_t*, int64_t, int, int64_t*, hipStream_t);
 int launch_panoptic(const uint8_t*, int64_t, const int32_t*, const int32_t*, int, int, int, const int64_t*, int32_t*, int32_t*, int64_t*, int64_t*, hipStream_t);
@@ -237,10 +238,12 @@ int sd3d_nms_decay(const float* inter, int ld, const float* area, const int32_t*
                    const float* score_in, float* comp_ws, float* score_out, void* stream) {
     return launch_nms_decay(inter, ld, area, labels, n, gaussian, sigma, score_in, comp_ws, score_out, ST);
 }
+size_t sd3d_expand_masks_ws_bytes(int n, int ld_sig) { return expand_masks_ws_bytes(n, ld_sig); }
 int sd3d_expand_masks(const float* sig, int ld_sig, const uint32_t* src_row, int n, const int64_t* superpoints, const float* points,
                       int ld_points, int64_t N, float sp_thr, const float* boxes, float loose_ratio, uint8_t* out, int32_t* count,
-                      void* stream) {
-    return launch_expand_masks(sig, ld_sig, src_row, n, superpoints, points, ld_points, N, sp_thr, boxes, loose_ratio, out, count, ST);
+                      void* ws, size_t ws_bytes, void* stream) {
+    return launch_expand_masks(sig, ld_sig, src_row, n, superpoints, points, ld_points, N, sp_thr, boxes, loose_ratio, out, count, ws,
+                               ws_bytes, ST);
 }
 int sd3d_row_argmax(const float* x, int ld, int64_t Q, const int32_t* cols, int ncols, int64_t* out, void* stream) {
     return launch_row_argmax(x, ld, Q, cols, ncols, out, ST);

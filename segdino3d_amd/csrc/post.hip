@@ -128,52 +128,101 @@ __global__ void nms_coef_kernel(const float* __restrict__ inter, int ld, const f
 // One thread handles 4 consecutive points for EM_ROWS consecutive rows: the superpoint ids and the
 // coordinates are read once per EM_ROWS rows, each row costs 4 gathered floats (L2-resident sig row)
 // and one uchar4 store.  grid = (point quads / 256, row groups).
-#define EM_ROWS 8
-__global__ __launch_bounds__(256) void expand_masks_kernel(const float* __restrict__ sig, int ld_sig, const uint32_t* __restrict__ src,
-                                                           int n, const int64_t* __restrict__ superpoints, const float* __restrict__ pts,
-                                                           int ld_pts, int64_t N, float sp_thr, const float* __restrict__ boxes,
-                                                           float loose, uint8_t* __restrict__ out, int32_t* __restrict__ count) {
-    const int r0 = blockIdx.y * EM_ROWS;
+// Two passes.  (1) em_rowbits_kernel thresholds the [n, S] sigmoid rows into a bit table transposed to
+// [S][W] words (bit r of word r/32 = row r is on for superpoint s): 226 KB for 600 x 3000, L2-resident.
+// (2) em_expand_kernel: a thread owns 4 consecutive points and one 32-row word; it reads the word of
+// each point's superpoint once and emits 32 uchar4 stores (one per row) - the kernel is bound by the
+// n x N bytes it writes (the first version gathered one float per (row, point): 90 M random 4-byte loads,
+// 0.62 ms for 600 x 150 k).
+__global__ __launch_bounds__(256) void em_hist_kernel(const int64_t* __restrict__ superpoints, int64_t N, int S, int32_t* __restrict__ npts) {
+    const int64_t p = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (p >= N) return;
+    const int64_t sp = superpoints[p];
+    if (sp >= 0 && sp < S) atomicAdd(&npts[sp], 1);
+}
+
+// also count[r] = number of points whose superpoint is on in row r = sum_s bit[r][s] * npts[s]: done here at
+// superpoint granularity (S / 64 atomics per row) instead of one atomic per (row, wave of points) in the expand
+// pass (2344 per row, serialised on 600 addresses: it was most of that kernel's time)
+__global__ __launch_bounds__(256) void em_rowbits_kernel(const float* __restrict__ sig, int ld_sig, const uint32_t* __restrict__ src,
+                                                         int n, int S, float thr, const int32_t* __restrict__ npts,
+                                                         uint32_t* __restrict__ bits, int W, int32_t* __restrict__ count) {
+    const int sp = blockIdx.x * 256 + threadIdx.x;
+    const int g = blockIdx.y;
+    uint32_t w = 0;
+    if (sp < S) {
+        for (int rr = 0; rr < 32; ++rr) {
+            const int r = g * 32 + rr;
+            if (r < n && sig[(int64_t)src[r] * ld_sig + sp] > thr) w |= 1u << rr;
+        }
+        bits[(int64_t)sp * W + g] = w;
+    }
+    const float np = sp < S ? (float)npts[sp] : 0.f;       // exact in fp32 up to 2^24 points per wave sum
+    for (int rr = 0; rr < 32; ++rr) {
+        const int r = g * 32 + rr;
+        if (r >= n) break;
+        const float c = wred_sum(((w >> rr) & 1u) ? np : 0.f);
+        if ((threadIdx.x & 63) == 0 && c > 0.f) atomicAdd(&count[r], (int)c);
+    }
+}
+
+#define EM_WORDS 4               // 32-row words per workgroup: superpoint ids / coordinates are re-read W / 4 times
+__global__ __launch_bounds__(256) void em_expand_kernel(const uint32_t* __restrict__ bits, int W, int n, int S,
+                                                        const int64_t* __restrict__ superpoints, const float* __restrict__ pts,
+                                                        int ld_pts, int64_t N, const float* __restrict__ boxes, float loose,
+                                                        uint8_t* __restrict__ out) {
+    const int g0 = blockIdx.y * EM_WORDS;
     const int64_t p0 = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 4;
     const bool vec = ((N & 3) == 0);
-    int sp[4] = {0, 0, 0, 0};
-    float xyz[4][3];
     const int np = p0 < N ? (int)min((int64_t)4, N - p0) : 0;
-    for (int e = 0; e < np; ++e) {
-        sp[e] = (int)superpoints[p0 + e];
-        if (boxes) {
+    uint32_t w[EM_WORDS][4];
+    uint32_t any_pt = 0;
 #pragma unroll
-            for (int a = 0; a < 3; ++a) xyz[e][a] = pts[(p0 + e) * ld_pts + a];
+    for (int e = 0; e < 4; ++e) {
+        const int64_t sp = e < np ? superpoints[p0 + e] : -1;
+        const bool ok = sp >= 0 && sp < S;
+#pragma unroll
+        for (int u = 0; u < EM_WORDS; ++u) {
+            w[u][e] = (ok && g0 + u < W) ? bits[sp * W + g0 + u] : 0u;
+            any_pt |= w[u][e];
         }
     }
-    for (int rr = 0; rr < EM_ROWS; ++rr) {
-        const int r = r0 + rr;
-        if (r >= n) break;                                  // uniform per block
-        const float* row = sig + (int64_t)src[r] * ld_sig;
-        float lo[3] = {0, 0, 0}, hi[3] = {0, 0, 0};
-        if (boxes) {
+    float xyz[4][3] = {{0, 0, 0}, {0, 0, 0}, {0, 0, 0}, {0, 0, 0}};
+    if (boxes && any_pt) {                                  // coordinates only where some row is on
+        for (int e = 0; e < np; ++e)
 #pragma unroll
-            for (int a = 0; a < 3; ++a) {
-                const float c = boxes[r * 6 + a], s = boxes[r * 6 + 3 + a] * (1.f + loose);
-                lo[a] = c - s / 2.f;
-                hi[a] = c + s / 2.f;
-            }
-        }
-        int cnt = 0;
-        uint8_t res[4] = {0, 0, 0, 0};
-        for (int e = 0; e < np; ++e) {
-            bool b = row[sp[e]] > sp_thr;
-            cnt += b;
-            if (b && boxes) {
+            for (int a = 0; a < 3; ++a) xyz[e][a] = pts[(p0 + e) * ld_pts + a];
+    }
 #pragma unroll
-                for (int a = 0; a < 3; ++a) b &= (xyz[e][a] >= lo[a]) & (xyz[e][a] <= hi[a]);
+    for (int u = 0; u < EM_WORDS; ++u) {
+        const uint32_t any_w = w[u][0] | w[u][1] | w[u][2] | w[u][3];
+        for (int rr = 0; rr < 32; ++rr) {
+            const int r = (g0 + u) * 32 + rr;
+            if (r >= n) break;                              // uniform per block
+            uint8_t res[4] = {0, 0, 0, 0};
+            if ((any_w >> rr) & 1u) {
+                float lo[3] = {0, 0, 0}, hi[3] = {0, 0, 0};
+                if (boxes) {
+#pragma unroll
+                    for (int a = 0; a < 3; ++a) {
+                        const float c = boxes[r * 6 + a], s = boxes[r * 6 + 3 + a] * (1.f + loose);
+                        lo[a] = c - s / 2.f;
+                        hi[a] = c + s / 2.f;
+                    }
+                }
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    bool b = (w[u][e] >> rr) & 1u;
+                    if (b && boxes) {
+#pragma unroll
+                        for (int a = 0; a < 3; ++a) b &= (xyz[e][a] >= lo[a]) & (xyz[e][a] <= hi[a]);
+                    }
+                    res[e] = b;
+                }
             }
-            res[e] = b;
+            if (np == 4 && vec) *(uchar4*)(out + (int64_t)r * N + p0) = make_uchar4(res[0], res[1], res[2], res[3]);
+            else for (int e = 0; e < np; ++e) out[(int64_t)r * N + p0 + e] = res[e];
         }
-        if (np == 4 && vec) *(uchar4*)(out + (int64_t)r * N + p0) = make_uchar4(res[0], res[1], res[2], res[3]);
-        else for (int e = 0; e < np; ++e) out[(int64_t)r * N + p0 + e] = res[e];
-        const float c = wred_sum((float)cnt);
-        if ((threadIdx.x & 63) == 0 && c > 0.f) atomicAdd(&count[r], (int)c);
     }
 }
 
@@ -270,13 +319,22 @@ int launch_nms_decay(const float* inter, int ld, const float* area, const int32_
     SD3D_CHECK_LAUNCH();
     return SD3D_OK;
 }
+size_t expand_masks_ws_bytes(int n, int ld_sig) { return (size_t)ld_sig * ((n + 31) / 32 + 1) * sizeof(uint32_t) + 256; }
 int launch_expand_masks(const float* sig, int ld_sig, const uint32_t* src, int n, const int64_t* superpoints, const float* pts,
                         int ld_pts, int64_t N, float sp_thr, const float* boxes, float loose, uint8_t* out, int32_t* count,
-                        hipStream_t st) {
+                        void* ws, size_t ws_bytes, hipStream_t st) {
     if (n <= 0 || N <= 0) return SD3D_OK;
+    if (ws_bytes < expand_masks_ws_bytes(n, ld_sig)) return sd3d_set_error(SD3D_ERR_ARG, "expand_masks: workspace too small");
+    const int W = (n + 31) / 32, S = ld_sig;
+    uint32_t* bits = (uint32_t*)ws;
+    int32_t* npts = (int32_t*)(bits + (size_t)S * W);
     (void)hipMemsetAsync(count, 0, (size_t)n * sizeof(int32_t), st);
-    hipLaunchKernelGGL(expand_masks_kernel, dim3((unsigned)cdiv(N, 1024), (unsigned)cdiv(n, EM_ROWS)), dim3(256), 0, st, sig, ld_sig,
-                       src, n, superpoints, pts, ld_pts, N, sp_thr, boxes, loose, out, count);
+    (void)hipMemsetAsync(npts, 0, (size_t)S * sizeof(int32_t), st);
+    hipLaunchKernelGGL(em_hist_kernel, dim3((unsigned)cdiv(N, 256)), dim3(256), 0, st, superpoints, N, S, npts);
+    hipLaunchKernelGGL(em_rowbits_kernel, dim3((unsigned)cdiv(S, 256), (unsigned)W), dim3(256), 0, st, sig, ld_sig, src, n, S, sp_thr,
+                       npts, bits, W, count);
+    hipLaunchKernelGGL(em_expand_kernel, dim3((unsigned)cdiv(N, 1024), (unsigned)cdiv(W, EM_WORDS)), dim3(256), 0, st, bits, W, n, S,
+                       superpoints, pts, ld_pts, N, boxes, loose, out);
     SD3D_CHECK_LAUNCH();
     return SD3D_OK;
 }

@@ -156,6 +156,7 @@ _WS = _PerThread()
 _WS2 = _PerThread()       # split-K partial sums of gather_gemm
 _WS3 = _PerThread()       # partial products of pair_conv
 _WS4 = _PerThread()       # pair_lists scratch
+_WS5 = _PerThread()       # expand_masks bit table
 
 
 # --------------------------------------------------------------------------------------------
@@ -671,9 +672,10 @@ def expand_masks(sig, src_row, superpoints, points, sp_thr, boxes=None, loose_ra
     n, N = src_row.numel(), superpoints.numel()
     out = torch.empty(n, N, dtype=torch.uint8, device=sig.device)
     count = torch.empty(n, dtype=torch.int32, device=sig.device)
+    ws = _WS5.get(lib.sd3d_expand_masks_ws_bytes(n, lds), sig.device)
     _lib.check(lib.sd3d_expand_masks(ps, lds, _ptr(src_row, torch.int32, "src_row"), n, _ptr(superpoints, torch.int64, "superpoints"),
                                      pp, ldp, N, float(sp_thr), _ptr(boxes, torch.float32, "boxes"), float(loose_ratio),
-                                     _ptr(out), _ptr(count), _stream()), "expand_masks")
+                                     _ptr(out), _ptr(count), ws.data_ptr(), ws.numel(), _stream()), "expand_masks")
     return out, count
 
 
