@@ -87,24 +87,36 @@ class PipelinedRunner:
         self.streams = [torch.cuda.Stream(device=self.device) for _ in range(self.n)]
         self._threading = threading
         self.switch_interval = float(os.environ.get("SD3D_SWITCH_INTERVAL", "2e-4"))
+        # one issuing thread at a time, handed over while a thread waits for the GPU (ops.wait_event)
+        self.use_baton = os.environ.get("SD3D_BATON", "1") != "0"
 
     def run(self, scenes, on_result=None):
         """scenes: sequence of (points, target) already on the device.  Returns the list of model outputs."""
         results = [None] * len(scenes)
         errors = []
 
+        baton = self._threading.Lock() if (self.n > 1 and self.use_baton) else None
+
         def work(wid):
+            from . import ops
             try:
                 torch.cuda.set_device(self.device)
+                if baton is not None:
+                    baton.acquire()
+                    ops.set_baton(baton)
                 with torch.cuda.stream(self.streams[wid]), torch.no_grad():
                     for i in range(wid, len(scenes), self.n):
                         pts, tgt = scenes[i]
                         results[i] = self.model([pts], [tgt])
                         if on_result is not None:
                             on_result(i, results[i])
-                    self.streams[wid].synchronize()
+                    ops.wait_event(ops.stream_event())
             except BaseException as e:  # noqa: BLE001 - re-raised in the caller's thread
                 errors.append(e)
+            finally:
+                if baton is not None:
+                    ops.set_baton(None)
+                    baton.release()
 
         if self.n == 1:
             work(0)

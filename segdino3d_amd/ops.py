@@ -107,9 +107,26 @@ class HostRead:
 BLOCKING_SYNC = _os.environ.get("SD3D_BLOCKING_SYNC") == "1"      # A/B switch: blocking .cpu() / event.synchronize()
 
 
+_BATON_TLS = threading.local()
+
+
+def set_baton(lock):
+    """Install (or clear, with None) this thread's issue baton: the pipelined runner lets only the baton
+    holder run Python; a thread hands the baton over exactly while it waits for the GPU (wait_event)."""
+    _BATON_TLS.lock = lock
+
+
 def wait_event(ev):
-    """Poll `ev`, yielding the GIL (and the core) between polls."""
+    """Wait for `ev` without keeping other scene threads from issuing."""
     import time
+    baton = getattr(_BATON_TLS, "lock", None)
+    if baton is not None:
+        baton.release()
+        try:
+            ev.synchronize()                                   # blocks inside HIP with the GIL released
+        finally:
+            baton.acquire()
+        return
     if BLOCKING_SYNC:
         ev.synchronize()
         return
