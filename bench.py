@@ -20,11 +20,12 @@ Prints ONE JSON line (rank 0) with the contract fields plus
                  P = measured rulebook size) divided by its HIP-event-measured time, against 8 TB/s HBM
   cpu_baseline : the oracle's whole forward timed on the host cores (rank 0, N = 1 only)
 """
+from __future__ import annotations
+
 import os as _os
 # HIP maps streams onto 4 hardware queues by default; scenes in flight on streams that share a queue block each
 # other head-of-line (measured: 4 streams 85 -> 102 scenes/s with 8 queues).  Must be set before the runtime starts.
 _os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
-from __future__ import annotations
 
 import argparse
 import json

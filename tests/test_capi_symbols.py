@@ -55,3 +55,14 @@ def test_product_path_refuses_cpu_tensors():
         ops.linear(torch.zeros(4, 32), torch.zeros(8, 32))
     with pytest.raises(RuntimeError, match="no CPU fallback"):
         ops.scene_stats(torch.zeros(10, 6))
+
+
+def test_entry_scripts_compile():
+    """bench.py / __graft_entry__.py / tools are run on the GPU box only: at least make sure they parse here."""
+    import ast
+    import glob
+    import os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    for path in [os.path.join(root, "bench.py"), os.path.join(root, "__graft_entry__.py")] + glob.glob(os.path.join(root, "tools", "*.py")):
+        with open(path) as f:
+            ast.parse(f.read(), filename=path)
