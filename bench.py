@@ -233,13 +233,23 @@ def main():
     tflops = tot_flops / sec / 1e12 if sec > 0 else 0.0
     t_hbm, t_mfma = tot_bytes / (HBM_PEAK_GBS * 1e9), tot_flops / (FP32_MFMA_PEAK_TFLOPS * 1e12)
     mfma_bound = t_mfma >= t_hbm
+    # HBM-side bytes of the same kernel family from the committed PMC passes (rocprofv3 cannot run inside this
+    # process): FETCH_SIZE x 2 + WRITE_SIZE per forward, divided by the launches of one forward.  It exceeds
+    # the algorithmic bytes by design: the pair-major convolution writes and re-reads its partial products.
+    traffic, traffic_src = None, None
+    pmc_path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_pmc_traffic.json")
+    if os.path.exists(pmc_path):
+        with open(pmc_path) as f:
+            pmc = json.load(f)
+        traffic = int(pmc["bytes_per_forward"] / max(1, n_launch // max(1, args.steps)))
+        traffic_src = pmc["source"]
     roofline = {"bound": "mfma" if mfma_bound else "hbm", "kernel": "sparse-conv / linear GEMM family (sd3d_pair_conv: pair_gemm_kernel + "
                 "pair_reduce_kernel; sd3d_gather_gemm: gather_gemm_lds_kernel / gather_gemm_kernel)",
                 "achieved": round(tflops if mfma_bound else hbm_gbs, 2),
                 "peak": FP32_MFMA_PEAK_TFLOPS if mfma_bound else HBM_PEAK_GBS,
                 "unit": "TFLOP/s" if mfma_bound else "GB/s",
                 "frac": round((tflops / FP32_MFMA_PEAK_TFLOPS) if mfma_bound else (hbm_gbs / HBM_PEAK_GBS), 4),
-                "traffic": None,
+                "traffic": traffic, "traffic_unit": "bytes per launch", "traffic_source": traffic_src,
                 "hbm_achieved_gbs": round(hbm_gbs, 1), "hbm_peak_gbs": HBM_PEAK_GBS, "hbm_frac": round(hbm_gbs / HBM_PEAK_GBS, 4),
                 "launches_per_step": n_launch // max(1, args.steps),
                 "avg_launch_us": round(1e3 * gemm_ms / max(1, n_launch), 2),
