@@ -90,7 +90,7 @@ def build_model(query_num, device):
     return model
 
 
-def cpu_baseline(model, scene_args, n_timed=2):
+def cpu_baseline(model, scene_args, n_timed=4):
     """Oracle (CPU restatement) timed on the host cores with the SAME weights and scene shape."""
     from oracle import model_ref
     sd = {k: v.detach().cpu() for k, v in model.state_dict().items()}
