@@ -295,8 +295,14 @@ PAIR_GEMM_ENTRY(4, 2)
 #define LOAD_A4(A, PTR)                                                                                            \
     do { _Pragma("unroll") for (int q_ = 0; q_ < 4; ++q_) A[q_] = *(const f32x4*)((PTR) + q_ * 4); } while (0)
 
-template <int NT>
+// RT = 32-pair row tiles one wave multiplies per weight fragment.  RT = 4 / 2 for the narrow layers
+// (Cout = 32 / 64; 4 independent accumulators per fragment read, epilogue amortised over 64 MFMAs per step)
+// measured SLOWER than RT = 1 (stem 296 -> 333 us, 32->32 62 -> 72, 64->64 108 -> 121): those layers are
+// bound by the gathers and partial stores per flop, not by the matrix pipe, and RT costs them half their
+// resident waves.  All variants therefore run RT = 1.
+template <int NT, int RT, int ST>
 __device__ __forceinline__ void pair_gemm_ws_body(const PGParams& p, float* Ws) {   // no __restrict__: LDS shared across waves
+    constexpr int UPT = 4 / RT;                                // wave units (RT x 32 pairs) per 128-pair tile
     const int tid = threadIdx.x, lane = tid & 63;
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);   // wave-uniform values must live in SGPRs (scalar branches)
     const int j = lane & 31, h = lane >> 5;
@@ -308,17 +314,19 @@ __device__ __forceinline__ void pair_gemm_ws_body(const PGParams& p, float* Ws) 
     const int ldw = p.Cin + 4;                                 // (Cin + 4) mod 64 is 4 or 36: conflict-free b128 rows
     const int c4 = p.Cin >> 2;
     const int npieces = 32 * NT * c4;
-    int* Ix = (int*)(Ws + 32 * NT * ldw);         // gather rows of this workgroup's pairs; padding (-1) -> row 0
+    int* Ix = (int*)(Ws + 32 * NT * ldw);                      // gather rows of this workgroup's pairs; padding (-1) -> row 0
     for (int f = tid; f < ntl * PT; f += 256) {
         const int v = (p.dbg & 1) ? ((tile0 * PT + f) * 7) & 1023 : p.in_idx[(int64_t)tile0 * PT + f];
         Ix[f] = v < 0 ? 0 : v;                                 // their partial products are never read back
     }
 
-    f32x16 acc[NT];
+    f32x16 acc[RT][NT];
 #pragma unroll
-    for (int t = 0; t < NT; ++t)
+    for (int rt = 0; rt < RT; ++rt)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+        for (int t = 0; t < NT; ++t)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[rt][t][r] = 0.f;
 
     int run_start = 0;
     while (run_start < ntl) {                                  // runs of tiles with the same offset (uniform)
@@ -346,31 +354,41 @@ __device__ __forceinline__ void pair_gemm_ws_body(const PGParams& p, float* Ws) 
             }
         }
         __syncthreads();
-        // this wave's 32-pair sub-tiles of the run: local sub-tile numbers u0, u0 + 4, ...
-        const int u0 = run_start * 4 + wv;
-        const int ns = (run_end * 4 - u0 + 3) / 4;
+        // this wave's units of the run: local unit numbers u0, u0 + 4, ...
+        const int u0 = run_start * UPT + wv;
+        const int ns = (run_end * UPT - u0 + 3) / 4;
         const int nsteps = ns * nchunks;
         if (nsteps > 0) {
-            // address of the fragment of step (sub-tile i, chunk c); past the end -> sub-tile 0 (harmless reload)
-            auto frag_ptr = [&](int i, int c) -> const float* {
+            // fragments of step (unit i, chunk c); past the end -> unit 0 (harmless reload)
+            auto load_unit = [&](f32x4 (&A)[RT][4], int i, int c) {
                 const int ii = i < ns ? i : 0;
-                const int row = Ix[(u0 + 4 * ii) * 32 + j];
                 const int cc = c * 32;                          // wave-uniform
                 const bool first = cc < p.C0;
                 const float* base = first ? p.in0 : p.in1;
                 const int ld = first ? p.ld0 : p.ld1;
-                return base + (int64_t)row * ld + (first ? cc : cc - p.C0) + h * 16;
+                const int coff = (first ? cc : cc - p.C0) + h * 16;
+#pragma unroll
+                for (int rt = 0; rt < RT; ++rt) {
+                    const int row = Ix[((u0 + 4 * ii) * RT + rt) * 32 + j];
+                    const float* q = base + (int64_t)row * ld + coff;
+                    LOAD_A4(A[rt], q);
+                }
             };
-            f32x4 a0[4], a1[4], a2[4];
+            // ST register stages: the rows of step s + ST - 1 are requested while step s multiplies.  The ring is
+            // rotated by unrolling the loop ST times with the roles renamed (copying a stage would make the
+            // compiler wait for the loads still in flight into it).  Narrow layers are latency-bound and want
+            // ST = 3-4; the 96/128-column variants are better off with the registers (ST = 2).
+            f32x4 a0[RT][4], a1[RT][4], a2[RT][4], a3[RT][4];
             int pf_i = 0, pf_c = 0;
 #define WS_PF_ADVANCE() do { if (++pf_c == nchunks) { pf_c = 0; ++pf_i; } } while (0)
-            { const float* q = frag_ptr(pf_i, pf_c); LOAD_A4(a0, q); WS_PF_ADVANCE(); }
-            { const float* q = frag_ptr(pf_i, pf_c); LOAD_A4(a1, q); WS_PF_ADVANCE(); }
+            load_unit(a0, pf_i, pf_c); WS_PF_ADVANCE();
+            if (ST >= 3) { load_unit(a1, pf_i, pf_c); WS_PF_ADVANCE(); }
+            if (ST >= 4) { load_unit(a2, pf_i, pf_c); WS_PF_ADVANCE(); }
             int cur_i = 0, cur_c = 0, s = 0;
 #define WS_STEP(CUR, PF)                                                                                              \
     {                                                                                                                 \
         const bool last_chunk = cur_c + 1 == nchunks;                                                                 \
-        { const float* q = frag_ptr(pf_i, pf_c); LOAD_A4(PF, q); WS_PF_ADVANCE(); }                                   \
+        load_unit(PF, pf_i, pf_c); WS_PF_ADVANCE();             /* next step's rows while this one multiplies */      \
         {                                                                                                             \
             const float* wb = Ws + j * ldw + cur_c * 32 + h * 16;                                                     \
             f32x4 wq[2][NT];                                                                                          \
@@ -382,27 +400,45 @@ __device__ __forceinline__ void pair_gemm_ws_body(const PGParams& p, float* Ws) 
                 }                                                                                                     \
                 _Pragma("unroll") for (int e = 0; e < 4; ++e)                                                         \
                     _Pragma("unroll") for (int t = 0; t < NT; ++t)                                                    \
-                        acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(wq[q & 1][t][e], CUR[q][e], acc[t], 0, 0, 0);   \
+                        _Pragma("unroll") for (int rt = 0; rt < RT; ++rt)                                             \
+                            acc[rt][t] = __builtin_amdgcn_mfma_f32_32x32x2f32(wq[q & 1][t][e], CUR[rt][q][e],         \
+                                                                              acc[rt][t], 0, 0, 0);                   \
                 __builtin_amdgcn_sched_barrier(0);                                                                    \
             }                                                                                                         \
         }                                                                                                             \
-        if (last_chunk) { /* sub-tile complete: lane = pair row, register group g = columns 8g + 4h .. +3 */          \
-            float* dst = p.part + ((int64_t)(tile0 * 4 + u0 + 4 * cur_i) * 32 + j) * p.Cout + 4 * h;                 \
-            _Pragma("unroll") for (int t = 0; t < NT; ++t)                                                            \
-                _Pragma("unroll") for (int g = 0; g < 4; ++g)                                                         \
-                    *(f32x4*)(dst + t * 32 + 8 * g) =                                                                 \
-                        f32x4{acc[t][4 * g], acc[t][4 * g + 1], acc[t][4 * g + 2], acc[t][4 * g + 3]};                \
-            _Pragma("unroll") for (int t = 0; t < NT; ++t)                                                            \
-                _Pragma("unroll") for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;                                       \
+        if (last_chunk) { /* unit complete: lane = pair row, register group g = columns 8g + 4h .. +3 */              \
+            _Pragma("unroll") for (int rt = 0; rt < RT; ++rt) {                                                       \
+                float* dst = p.part + (((int64_t)tile0 * UPT + u0 + 4 * cur_i) * RT * 32 + rt * 32 + j) * p.Cout + 4 * h; \
+                _Pragma("unroll") for (int t = 0; t < NT; ++t)                                                        \
+                    _Pragma("unroll") for (int g = 0; g < 4; ++g)                                                     \
+                        *(f32x4*)(dst + t * 32 + 8 * g) = f32x4{acc[rt][t][4 * g], acc[rt][t][4 * g + 1],             \
+                                                                acc[rt][t][4 * g + 2], acc[rt][t][4 * g + 3]};        \
+                _Pragma("unroll") for (int t = 0; t < NT; ++t)                                                        \
+                    _Pragma("unroll") for (int r = 0; r < 16; ++r) acc[rt][t][r] = 0.f;                               \
+            }                                                                                                         \
         }                                                                                                             \
         if (s + 1 >= nsteps) break;                                                                                   \
         ++s;                                                                                                          \
         if (last_chunk) { cur_c = 0; ++cur_i; } else { ++cur_c; }                                                     \
     }
-            for (;;) {
-                WS_STEP(a0, a2)
-                WS_STEP(a1, a0)
-                WS_STEP(a2, a1)
+            if (ST == 2) {
+                for (;;) {
+                    WS_STEP(a0, a1)
+                    WS_STEP(a1, a0)
+                }
+            } else if (ST == 3) {
+                for (;;) {
+                    WS_STEP(a0, a2)
+                    WS_STEP(a1, a0)
+                    WS_STEP(a2, a1)
+                }
+            } else {
+                for (;;) {
+                    WS_STEP(a0, a3)
+                    WS_STEP(a1, a0)
+                    WS_STEP(a2, a1)
+                    WS_STEP(a3, a2)
+                }
             }
 #undef WS_STEP
 #undef WS_PF_ADVANCE
@@ -411,16 +447,16 @@ __device__ __forceinline__ void pair_gemm_ws_body(const PGParams& p, float* Ws) 
     }
 }
 
-#define PAIR_GEMM_WS_ENTRY(NT, WAVES)                                                                              \
+#define PAIR_GEMM_WS_ENTRY(NT, RT, ST, WAVES)                                                                          \
     __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WAVES, WAVES))) void pair_gemm_ws_kernel_##NT( \
         const PGParams p) {                                                                                        \
         extern __shared__ __attribute__((aligned(16))) float ws_smem[];                                            \
-        pair_gemm_ws_body<NT>(p, ws_smem);                                                                         \
+        pair_gemm_ws_body<NT, RT, ST>(p, ws_smem);                                                                     \
     }
-PAIR_GEMM_WS_ENTRY(1, 4)
-PAIR_GEMM_WS_ENTRY(2, 3)
-PAIR_GEMM_WS_ENTRY(3, 3)
-PAIR_GEMM_WS_ENTRY(4, 2)
+PAIR_GEMM_WS_ENTRY(1, 1, 3, 4)
+PAIR_GEMM_WS_ENTRY(2, 1, 3, 3)
+PAIR_GEMM_WS_ENTRY(3, 1, 2, 3)
+PAIR_GEMM_WS_ENTRY(4, 1, 2, 2)
 
 // ---- pass 2: fixed-order reduction over the offsets + epilogue --------------------------------
 struct PRParams {
