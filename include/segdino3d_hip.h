@@ -245,6 +245,16 @@ size_t sd3d_instance_boxes_ws_bytes(int n_inst);
 int sd3d_instance_boxes(const float* points, int ld, int64_t N, const uint8_t* masks, int64_t mask_stride, int n_inst,
                         int mode, float* centers, float* sizes, void* ws, size_t ws_bytes, void* stream);
 
+/* ---------------------------------------------------------------------------------------------
+ * ScanNet AP association (the caller side of the path):
+ * evaluation/utils_instance_seg_3d_eval.py:340-371 counts |pred_mask & (gt_ids == id)| per (prediction,
+ * ground truth) pair with numpy.  counts[p][c] = number of points of prediction row p (mask byte != 0) whose
+ * gt_index is c, for c in [0, n_cols); points with gt_index outside that range are not counted.  The caller
+ * maps instance ids to columns (and void points to one extra column), so vert_count = the row sum.
+ * masks [n, mask_stride] bytes; counts [n, n_cols] is zeroed by the call; n_cols <= 8192. */
+int sd3d_mask_overlaps(const uint8_t* masks, int64_t mask_stride, int n, const int32_t* gt_index, int64_t N, int n_cols,
+                       int32_t* counts, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

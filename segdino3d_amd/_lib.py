@@ -66,6 +66,7 @@ SIGNATURES = {
     "sd3d_row_argmax": (_i, [_p, _i, _l, _p, _i, _p, _p]),
     "sd3d_gather_i64": (_i, [_p, _p, _l, _i, _p, _p]),
     "sd3d_panoptic": (_i, [_p, _l, _p, _p, _i, _i, _i, _p, _p, _p, _p, _p, _p]),
+    "sd3d_mask_overlaps": (_i, [_p, _l, _i, _p, _l, _i, _p, _p]),
     "sd3d_instance_boxes_ws_bytes": (_z, [_i]),
     "sd3d_instance_boxes": (_i, [_p, _i, _l, _p, _l, _i, _i, _p, _p, _p, _z, _p]),
 }

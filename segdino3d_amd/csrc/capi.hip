@@ -61,6 +61,7 @@ int launch_mask_scores(const float*, int, int, const uint32_t*, const float*, in
 int launch_gather_sigmoid(const float*, int, int, const int32_t*, const uint32_t*, int, float*, int, float*, hipStream_t);
 int launch_nms_decay(const float*, int, const float*, const int32_t*, int, int, float, const float*, float*, float*, hipStream_t);
 size_t expand_masks_ws_bytes(int n, int ld_sig);
+int launch_mask_overlaps(const uint8_t*, int64_t, int, const int32_t*, int64_t, int, int32_t*, hipStream_t);
 int launch_expand_masks(const float*, int, const uint32_t*, int, const int64_t*, const float*, int, int64_t, float, const float*, float, uint8_t*, int32_t*, void*, size_t, hipStream_t);
 int launch_row_argmax(const float*, int, int64_t, const int32_t*, int, int64_t*, hipStream_t);
 int launch_gather_i64(const int64_t*, const int64_t*, int64_t, int, int64_t*, hipStream_t);
@@ -264,6 +265,11 @@ int sd3d_instance_boxes(const float* points, int ld, int64_t N, const uint8_t* m
 int sd3d_scale_shift_act(const float* x0, int ld0, int C0, const float* x1, int ld1, const float* scale, const float* shift, int act,
                          int64_t M, int C, float* out, int ld_out, void* stream) {
     return launch_scale_shift_act(x0, ld0, C0, x1, ld1, scale, shift, act, M, C, out, ld_out, ST);
+}
+
+int sd3d_mask_overlaps(const uint8_t* masks, int64_t mask_stride, int n, const int32_t* gt_index, int64_t N, int n_cols,
+                       int32_t* counts, void* stream) {
+    return launch_mask_overlaps(masks, mask_stride, n, gt_index, N, n_cols, counts, ST);
 }
 
 }  // extern "C"

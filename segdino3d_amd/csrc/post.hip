@@ -432,3 +432,60 @@ int launch_instance_boxes(const float* pts, int ld, int64_t N, const uint8_t* ma
     SD3D_CHECK_LAUNCH();
     return SD3D_OK;
 }
+
+// ---------------------------------------------------------------------------------------------
+// ScanNet AP association (evaluation/utils_instance_seg_3d_eval.py:340-371): the reference
+// counts |pred_mask & (gt_ids == id)| with one numpy pass over N per (prediction, ground-truth) pair.
+// Here one pass over the [n, N] byte masks builds, per prediction row, the histogram of the ground-truth
+// column of its points (column = instance index, or the "void" column): counts[p][c].
+// Workgroup = one row x one chunk of points, histogram in LDS (integer ds_add), non-zero bins flushed with
+// global atomics.  Masks are sparse, so gt_index is only read where a mask byte is set.
+// ---------------------------------------------------------------------------------------------
+#define MO_CHUNK 16384
+__global__ __launch_bounds__(256) void mask_overlaps_kernel(const uint8_t* __restrict__ masks, int64_t mask_stride, const int32_t* __restrict__ gt_index,
+                                                            int64_t N, int n_cols, int32_t* __restrict__ counts) {
+    extern __shared__ int32_t mo_hist[];
+    const int row = blockIdx.y;
+    const int64_t p_begin = (int64_t)blockIdx.x * MO_CHUNK;
+    const int64_t p_end = min(N, p_begin + MO_CHUNK);
+    for (int c = threadIdx.x; c < n_cols; c += 256) mo_hist[c] = 0;
+    __syncthreads();
+    const uint8_t* m = masks + (int64_t)row * mask_stride;
+    const bool vec = ((mask_stride & 15) == 0) && ((((uintptr_t)masks) & 15) == 0);
+    for (int64_t p = p_begin + (int64_t)threadIdx.x * 16; p < p_end; p += 256 * 16) {
+        uint32_t w[4] = {0, 0, 0, 0};
+        const int np = (int)min((int64_t)16, p_end - p);
+        if (vec && np == 16) {
+            const uint4 v = *(const uint4*)(m + p);
+            w[0] = v.x; w[1] = v.y; w[2] = v.z; w[3] = v.w;
+        } else {
+            for (int e = 0; e < np; ++e) w[e >> 2] |= (uint32_t)m[p + e] << (8 * (e & 3));
+        }
+        if ((w[0] | w[1] | w[2] | w[3]) == 0u) continue;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            if ((w[e >> 2] >> (8 * (e & 3))) & 0xffu) {
+                const int g = gt_index[p + e];
+                if (g >= 0 && g < n_cols) atomicAdd(&mo_hist[g], 1);
+            }
+        }
+    }
+    __syncthreads();
+    for (int c = threadIdx.x; c < n_cols; c += 256) {
+        const int v = mo_hist[c];
+        if (v) atomicAdd(&counts[(int64_t)row * n_cols + c], v);
+    }
+}
+
+int launch_mask_overlaps(const uint8_t* masks, int64_t mask_stride, int n, const int32_t* gt_index, int64_t N, int n_cols, int32_t* counts,
+                         hipStream_t st) {
+    if (n <= 0 || n_cols <= 0) return SD3D_OK;
+    if (n_cols > 8192) return sd3d_set_error(SD3D_ERR_ARG, "mask_overlaps: at most 8192 ground-truth columns");
+    if (hipMemsetAsync(counts, 0, (size_t)n * n_cols * sizeof(int32_t), st) != hipSuccess)
+        return sd3d_set_error(SD3D_ERR_LAUNCH, "mask_overlaps: memset failed");
+    if (N <= 0) return SD3D_OK;
+    hipLaunchKernelGGL(mask_overlaps_kernel, dim3((unsigned)cdiv(N, MO_CHUNK), (unsigned)n), dim3(256), (size_t)n_cols * sizeof(int32_t), st,
+                       masks, mask_stride, gt_index, N, n_cols, counts);
+    SD3D_CHECK_LAUNCH();
+    return SD3D_OK;
+}

@@ -141,3 +141,30 @@ class PipelinedRunner:
         if errors:
             raise errors[0]
         return results
+
+
+def all_gather_ap_records(local, device="cpu"):
+    """local: sequence of (scene_id, eval_ap.SceneRecord) evaluated on this rank -> list of (scene_id, SceneRecord)
+    of ALL ranks, ordered by scene id, on every rank.  Each record travels as one float64 row
+    [scene_id, payload length, payload..., zero padding] (eval_ap.SceneRecord.pack); ~50 KB per scene, the
+    [n_pred, N] masks never leave their GPU."""
+    import numpy as np
+    from .eval_ap import SceneRecord
+    rows = []
+    for sid, rec in local:
+        payload = rec.pack()
+        rows.append(np.concatenate([np.array([float(sid), float(len(payload))]), payload]))
+    width = max((len(r) for r in rows), default=2)
+    if dist.is_available() and dist.is_initialized():
+        w = torch.tensor([width], dtype=torch.int64, device=device)
+        dist.all_reduce(w, op=dist.ReduceOp.MAX)
+        width = int(w.item())
+    table = np.zeros((len(rows), width), dtype=np.float64)
+    for i, r in enumerate(rows):
+        table[i, :len(r)] = r
+    merged = merge_by_scene(all_gather_records(torch.from_numpy(table).to(device)))
+    out = []
+    for row in merged.cpu().numpy():
+        n = int(row[1])
+        out.append((int(row[0]), SceneRecord.unpack(row[2:2 + n])))
+    return out

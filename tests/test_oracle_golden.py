@@ -169,3 +169,51 @@ def test_plain_decoder_matches_reference():
         torch.testing.assert_close(out["aux"][li]["masks"], g[f"aux{li}_masks"], **tol)
     for k in ("cls_preds", "sem_preds", "masks", "hidden_states"):
         torch.testing.assert_close(out[k], g[k], **tol)
+
+
+# ------------------------------------------------------------------------------------------------
+# ScanNet instance-AP protocol: the oracle restatement against the reference's own output
+# ------------------------------------------------------------------------------------------------
+def _ap_fixture():
+    import json
+    z = np.load(os.path.join(GOLDEN, "ap_protocol.npz"))
+    class_labels = tuple(str(c) for c in z["class_labels"])
+    valid = tuple(int(v) for v in z["valid_class_ids"])
+    scenes = []
+    for si in range(int(z["n_scenes"])):
+        n = int(z[f"s{si}_n"])
+        masks = np.unpackbits(z[f"s{si}_masks"], axis=1)[:, :n].astype(bool)
+        scenes.append((z[f"s{si}_sem"], z[f"s{si}_inst"], masks, z[f"s{si}_labels"], z[f"s{si}_scores"]))
+    here = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    with open(os.path.join(here, "segdino3d_amd", "data", "scannet200_groups.json")) as f:
+        groups = json.load(f)
+    return z, class_labels, valid, scenes, groups
+
+
+@pytest.mark.parametrize("opt_name,options", [("default", None), ("min30", dict(min_region_sizes=np.array([30])))])
+def test_ap_protocol_oracle_matches_reference_golden(opt_name, options):
+    from oracle import eval_ref as E
+    z, class_labels, valid, scenes, groups = _ap_fixture()
+    id_to_label = {valid[i]: class_labels[i] for i in range(len(valid))}
+    preds = E.aggregate_predictions([s[2] for s in scenes], [s[3] for s in scenes], [s[4] for s in scenes], valid)
+    gts = E.rename_gt([s[0] for s in scenes], [s[1] for s in scenes], valid)
+    metrics, ap, pr_rc = E.scannet_eval(preds, gts, options, valid, class_labels, id_to_label, groups)
+    # association records: integer work, exact
+    opts = E.get_options(options)
+    rows = []
+    for si, (p, gt) in enumerate(zip(preds, gts)):
+        g2p, p2g = E.assign_instances(p, gt, opts, valid, class_labels, id_to_label)
+        for label in class_labels:
+            for pr in p2g[label]:
+                for m in pr["matched_gt"]:
+                    rows.append([si, int(pr["filename"].split("_")[1]), pr["label_id"], pr["vert_count"], pr["void_intersection"],
+                                 m["instance_id"], m["vert_count"], m["intersection"]])
+                if not pr["matched_gt"]:
+                    rows.append([si, int(pr["filename"].split("_")[1]), pr["label_id"], pr["vert_count"], pr["void_intersection"], -1, 0, 0])
+    assert np.array_equal(np.array(sorted(rows), dtype=np.int64), z[f"{opt_name}_assoc"])
+    # averages: same floating-point operations in the same order -> 1e-12
+    for k, v in zip(z[f"{opt_name}_keys"], z[f"{opt_name}_vals"]):
+        got = metrics[str(k)]
+        assert (np.isnan(got) and np.isnan(v)) or abs(got - v) < 1e-12, (k, got, v)
+    cls = np.array([[metrics["classes"][c][f] for f in ("ap", "ap50%", "ap25%", "prec50%", "rec50%")] for c in class_labels])
+    assert np.allclose(cls, z[f"{opt_name}_class_ap"], rtol=0, atol=1e-12, equal_nan=True)
