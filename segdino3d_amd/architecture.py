@@ -223,6 +223,7 @@ class Baseline3D(nn.Module):
     @ops.bound_stream
     def predict_by_feat(self, samples, out, superpoints):
         cfg = self.test_cfg
+        ops.baton_yield()
         com = self._instances_common(samples, out, superpoints)
         # the data-dependent selections below synchronise; wait for the scene's work by polling first so that no
         # host thread sits inside a blocking HIP call while other scenes are being issued

@@ -307,18 +307,14 @@ __device__ __forceinline__ void pair_gemm_ws_body(const PGParams& p, float* Ws) 
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);   // wave-uniform values must live in SGPRs (scalar branches)
     const int j = lane & 31, h = lane >> 5;
     const int n_real = p.tile_k[p.n_tiles];
-    const int tile0 = (int)((int64_t)blockIdx.x * n_real / gridDim.x);
-    const int ntl = (int)((int64_t)(blockIdx.x + 1) * n_real / gridDim.x) - tile0;   // <= WS_RANGE_TILES by the launcher
-    if (ntl <= 0) return;
+    const int range0 = (int)((int64_t)blockIdx.x * n_real / gridDim.x);
+    const int range1 = (int)((int64_t)(blockIdx.x + 1) * n_real / gridDim.x);
+    if (range1 <= range0) return;
     const int nchunks = p.Cin >> 5;
     const int ldw = p.Cin + 4;                                 // (Cin + 4) mod 64 is 4 or 36: conflict-free b128 rows
     const int c4 = p.Cin >> 2;
     const int npieces = 32 * NT * c4;
     int* Ix = (int*)(Ws + 32 * NT * ldw);                      // gather rows of this workgroup's pairs; padding (-1) -> row 0
-    for (int f = tid; f < ntl * PT; f += 256) {
-        const int v = (p.dbg & 1) ? ((tile0 * PT + f) * 7) & 1023 : p.in_idx[(int64_t)tile0 * PT + f];
-        Ix[f] = v < 0 ? 0 : v;                                 // their partial products are never read back
-    }
 
     f32x16 acc[RT][NT];
 #pragma unroll
@@ -328,6 +324,15 @@ __device__ __forceinline__ void pair_gemm_ws_body(const PGParams& p, float* Ws) 
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[rt][t][r] = 0.f;
 
+  // the range is walked in pieces whose gather indices fit the LDS buffer (the capacity-sized lists of a scene that
+  // skipped the rulebook-size read-back can make a range longer than that)
+  for (int tile0 = range0; tile0 < range1; tile0 += WS_RANGE_TILES) {
+    const int ntl = range1 - tile0 < WS_RANGE_TILES ? range1 - tile0 : WS_RANGE_TILES;
+    __syncthreads();                                           // nobody still reads the previous piece's indices
+    for (int f = tid; f < ntl * PT; f += 256) {
+        const int v = (p.dbg & 1) ? ((tile0 * PT + f) * 7) & 1023 : p.in_idx[(int64_t)tile0 * PT + f];
+        Ix[f] = v < 0 ? 0 : v;                                 // their partial products are never read back
+    }
     int run_start = 0;
     while (run_start < ntl) {                                  // runs of tiles with the same offset (uniform)
         const int k = p.tile_k[tile0 + run_start];
@@ -445,6 +450,7 @@ __device__ __forceinline__ void pair_gemm_ws_body(const PGParams& p, float* Ws) 
         }
         run_start = run_end;
     }
+  }
 }
 
 #define PAIR_GEMM_WS_ENTRY(NT, RT, ST, WAVES)                                                                          \
@@ -576,8 +582,6 @@ int launch_pair_conv(const float* in0, int ld0, int C0, const float* in1, int ld
         int gx = n_cu * per_cu;
         gx = gx < g.n_tiles ? gx : g.n_tiles;
         { static int gx_env = -1; if (gx_env < 0) { const char* e = getenv("SD3D_PAIR_GX"); gx_env = e ? atoi(e) : 0; } if (gx_env > 0) gx = gx_env; }
-        const int need = (int)cdiv(g.n_tiles, WS_RANGE_TILES);  // a range must fit the LDS index buffer
-        gx = gx > need ? gx : need;
         const dim3 wgrid((unsigned)gx);
         const size_t lds = w_lds + (size_t)WS_RANGE_TILES * PT * sizeof(int32_t);
         switch (nt) {

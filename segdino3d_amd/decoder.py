@@ -368,6 +368,7 @@ class ScanNetQueryDecoder(nn.Module):
         ref_points = q_pos.float().contiguous()
         ref_sizes = size_q
         for i in range(L):
+            ops.baton_yield()
             # ---- box-modulated positional query (:659-666)
             if self.box_modulate_ca:
                 hwl = _mlp(queries, self.ref_anchor_head, final_act="sigmoid")

@@ -116,6 +116,25 @@ def set_baton(lock):
     _BATON_TLS.lock = lock
 
 
+import collections as _collections
+_BATON_WAITERS = _collections.deque()                          # append / pop are atomic: threads that want the baton back
+BATON_YIELD = _os.environ.get("SD3D_BATON_YIELD", "1") != "0"
+
+
+def baton_yield():
+    """Called between the big issue blocks of a forward (decoder layers, post-processing): if another scene's
+    thread has finished waiting for the GPU and wants to issue its next (short) phase, let it go first - its
+    stream is empty, ours still has milliseconds of queued work."""
+    baton = getattr(_BATON_TLS, "lock", None)
+    if baton is not None and BATON_YIELD and _BATON_WAITERS:
+        import time
+        baton.release()
+        time.sleep(0)
+        _BATON_WAITERS.append(1)
+        baton.acquire()
+        _BATON_WAITERS.pop()
+
+
 def wait_event(ev):
     """Wait for `ev` without keeping other scene threads from issuing."""
     import time
@@ -125,7 +144,9 @@ def wait_event(ev):
         try:
             ev.synchronize()                                   # blocks inside HIP with the GIL released
         finally:
+            _BATON_WAITERS.append(1)
             baton.acquire()
+            _BATON_WAITERS.pop()
         return
     if BLOCKING_SYNC:
         ev.synchronize()

@@ -20,6 +20,8 @@ from __future__ import annotations
 
 from typing import Dict, Optional, Tuple
 
+import os
+
 import numpy as np
 import torch
 
@@ -58,6 +60,12 @@ def child_perm(order: str) -> np.ndarray:
         x, y, z = c & 1, (c >> 1) & 1, (c >> 2) & 1
         p[c] = (x * 2 + y) * 2 + z
     return p
+
+
+# SD3D_EXACT_PAIRS=0: do not read the rulebook sizes back (saves the second host synchronisation of a scene) and size
+# the pair lists for the worst case instead (K * V entries: 2.2 GB of partial-product scratch per stream at 150 k
+# points).  Measured the same scenes/s either way once the GPU is the limiter, so the exact sizes are the default.
+EXACT_PAIR_CAPACITY = os.environ.get("SD3D_EXACT_PAIRS", "1") == "1"
 
 
 class SceneMaps:
@@ -115,15 +123,22 @@ class SceneMaps:
         second and last synchronisation of a scene): density[key] = pairs / (K * V_out) lets the host
         pick the pair-compacted convolution kernel for sparse maps.  same: [(level, ksize)], strides: [level]."""
         same = [(lvl, k) for (lvl, k) in same if ("same", lvl, k) not in self.density]
-        counters = torch.zeros(max(1, len(same)), 64, dtype=torch.int32, device=self.device)
+        exact = EXACT_PAIR_CAPACITY or not ops.PAIR_CONV
+        counters = torch.zeros(max(1, len(same)), 64, dtype=torch.int32, device=self.device) if exact else None
         for i, (lvl, k) in enumerate(same):
             offs = offsets_device(k, self.order, self.device)
-            self._same[(lvl, k)] = ops.kernel_map(self.keys[lvl], self.n_vox[lvl], self.table(lvl), offs, counters[i])
+            self._same[(lvl, k)] = ops.kernel_map(self.keys[lvl], self.n_vox[lvl], self.table(lvl), offs,
+                                                  counters[i] if exact else None)
         for lvl in strides:
             self._stride_maps(lvl)
-        host = ops.HostRead(counters.sum(dim=1)).wait().tolist() if same else []   # synchronisation 2 (polled)
+        if exact:
+            host = ops.HostRead(counters.sum(dim=1)).wait().tolist() if same else []   # synchronisation 2 (polled)
+        else:
+            # no read-back: size the pair lists for the worst case (every offset of every voxel has a neighbour).  The
+            # kernels walk the REAL tile count, which the list builder leaves on the device; only allocations grow.
+            host = [k ** 3 * self.n_vox[lvl] for (lvl, k) in same]
         for (lvl, k), c in zip(same, host):
-            self.density[("same", lvl, k)] = c / max(1, k ** 3 * self.n_vox[lvl])
+            self.density[("same", lvl, k)] = (c / max(1, k ** 3 * self.n_vox[lvl])) if exact else None
             if ops.PAIR_CONV:
                 self.pairs[("same", lvl, k)] = ops.pair_lists(self._same[(lvl, k)], c)
         for lvl in strides:
