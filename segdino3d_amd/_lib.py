@@ -88,8 +88,8 @@ def load():
             "There is no CPU fallback for the product path.")
     # PyDLL = the calls keep the GIL.  Every entry point only enqueues work (a few microseconds), and with
     # several host threads each driving a stream (dist_eval.PipelinedRunner) releasing and re-taking the GIL
-    # around ~600 such calls per forward costs more than the calls themselves (lock convoy: measured 65 vs
-    # 120 scenes/s of GPU capacity).  SD3D_RELEASE_GIL=1 restores ctypes.CDLL behaviour.
+    # around ~600 such calls per forward costs more than the calls themselves (lock convoy: 73.6 -> 87.8 scenes/s
+    # in a same-box A/B).  SD3D_RELEASE_GIL=1 restores ctypes.CDLL behaviour.
     lib = (C.CDLL if os.environ.get("SD3D_RELEASE_GIL") == "1" else C.PyDLL)(LIB_PATH)
     for name, (res, args) in SIGNATURES.items():
         fn = getattr(lib, name)       # AttributeError here = header/library mismatch: fail loudly

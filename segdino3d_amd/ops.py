@@ -82,10 +82,8 @@ def _rows(t: torch.Tensor, name="tensor"):
 
 
 class HostRead:
-    """Small device -> host read that never blocks inside the HIP runtime: asynchronous copy into pinned
-    memory + an event that is POLLED.  A blocking `.cpu()` / stream synchronise in one host thread was
-    measured to stall the kernel launches of the other threads of the pipelined runner (two processes on
-    one GPU reached 120 scenes/s where three threads of one process reached 65-93)."""
+    """Small device -> host read: asynchronous copy into pinned memory + an event the caller waits on through
+    `wait_event` (which hands the issue baton of the pipelined runner to another scene's thread meanwhile)."""
 
     __slots__ = ("buf", "event")
 
