@@ -310,6 +310,8 @@ def main():
     golden_decoder(dec_mod, "decoder_s64_q64", DECODER_KW_SCANNET200, S=64, M=10)
     golden_decoder(dec_mod, "decoder_s96_q16", DECODER_KW_SCANNET200, S=96, M=7, query_subset=16)
     golden_decoder(dec_mod, "decoder_v2_s48", DECODER_KW_SCANNETV2, S=48, M=5)
+    # several 32-key tiles per wave and per workgroup, ragged last tile (500 = 15 * 32 + 20), 41 keys in the 2D-query attention
+    golden_decoder(dec_mod, "decoder_s500_q32", DECODER_KW_SCANNET200, S=500, M=40, query_subset=32)
     golden_decoder_plain(dec_mod, "decoder_plain_s40", S=40)
     golden_nms(arch_mod)
     golden_architecture(seg, "arch_qall", query_num=-1)

@@ -128,7 +128,7 @@ def _mask_agree(a, b, thr=0.0):
 
 
 @pytest.mark.parametrize("name,kw,sdkw", [
-    ("decoder_s64_q64", {}, {}), ("decoder_s96_q16", {}, {}),
+    ("decoder_s64_q64", {}, {}), ("decoder_s96_q16", {}, {}), ("decoder_s500_q32", {}, {}),
     ("decoder_v2_s48", dict(num_instance_classes=18, num_semantic_classes=20, in_channels=32, normalize_box_prediction=False),
      dict(in_channels=32, n_inst=18, n_sem=20, size_embed_scale=0.05))])
 def test_decoder_matches_reference_golden(name, kw, sdkw):

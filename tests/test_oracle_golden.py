@@ -72,6 +72,7 @@ def test_sine_pe():
 @pytest.mark.parametrize("name,kw,cfgkw", [
     ("decoder_s64_q64", {}, {}),
     ("decoder_s96_q16", {}, {}),
+    ("decoder_s500_q32", {}, {}),
     ("decoder_v2_s48", dict(in_channels=32, n_inst=18, n_sem=20, size_embed_scale=0.05), dict(normalize_box_prediction=False)),
 ])
 def test_decoder_matches_reference(name, kw, cfgkw):
