@@ -253,6 +253,8 @@ def main():
                 "hbm_achieved_gbs": round(hbm_gbs, 1), "hbm_peak_gbs": HBM_PEAK_GBS, "hbm_frac": round(hbm_gbs / HBM_PEAK_GBS, 4),
                 "launches_per_step": n_launch // max(1, args.steps),
                 "avg_launch_us": round(1e3 * gemm_ms / max(1, n_launch), 2),
+                # = what the rocprofv3 summary's pair_gemm* + pair_reduce + gather_gemm* rows add up to per forward
+                "family_ms_per_forward": round(gemm_ms / max(1, args.steps), 3),
                 "algorithmic_bytes_per_step": tot_bytes // max(1, args.steps),
                 "algorithmic_flops_per_step": tot_flops // max(1, args.steps),
                 "share_of_single_stream_forward": round(gemm_ms / max(1, args.steps) / latency_ms, 3),
