@@ -1,5 +1,7 @@
 """Edge cases of the hot path on the GPU: ragged / empty segments, tiny scenes, hash collisions, empty
 prediction sets, key-range overflow.  Each is checked against the oracle (or an exact expectation)."""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -160,3 +162,39 @@ def test_pipelined_runner_matches_sequential():
         base = agreement(seq[i], seq2[i])
         got = agreement(seq[i], par[i][0].pred_pts_seg)
         assert got > 0.99 and got >= base - 5e-3, (i, base, got)
+
+
+def test_scene_prefetcher_feeds_identical_scenes(tmp_path):
+    """Packed files -> pinned staging -> copy stream -> consumer stream: same tensors as a direct upload, in order,
+    and the forward on a prefetched scene equals the forward on the directly uploaded one."""
+    import copy
+    import segdino3d_amd as seg
+    from segdino3d_amd import io_scene
+    from segdino3d_amd.configs import scannet200_model_cfg
+    from segdino3d_amd.synth import make_scene
+    d = dev()
+    paths, ref = [], []
+    for i in range(5):
+        pts, tgt = make_scene(40 + i, 6000 + 500 * i, 80, 9)
+        ef = tgt.extra_features
+        sc = dict(points=pts, super_points=ef["super_point_masks"], points_2dfeats=ef["points_2dfeats"],
+                  query2d_feats=ef["query2d_feats"], query2d_pos=ef["query2d_pos"])
+        p = os.path.join(tmp_path, f"s{i}.sd3d")
+        io_scene.pack_scene(p, sc)
+        paths.append(p)
+        ref.append(sc)
+    model = seg.build_architecture(scannet200_model_cfg(query_num=30)).eval().to(d)
+    model.to_host = False
+    n = 0
+    with torch.no_grad():
+        for i, (pts, tgt) in enumerate(io_scene.ScenePrefetcher(paths, d, depth=2)):
+            assert torch.equal(pts.cpu(), ref[i]["points"])
+            assert torch.equal(tgt.extra_features["points_2dfeats"].cpu(), ref[i]["points_2dfeats"])
+            assert torch.equal(tgt.extra_features["super_point_masks"].cpu(), ref[i]["super_points"])
+            out = model([pts], [tgt])[0].pred_pts_seg
+            direct_tgt = io_scene.to_device_scene({k: v for k, v in ref[i].items()}, d, non_blocking=False)[1]
+            out2 = model([ref[i]["points"].to(d)], [direct_tgt])[0].pred_pts_seg
+            assert torch.equal(out.instance_scores, out2.instance_scores)
+            assert torch.equal(out.pts_semantic_mask[0], out2.pts_semantic_mask[0])
+            n += 1
+    assert n == 5

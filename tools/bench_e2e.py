@@ -1,0 +1,59 @@
+"""f-3 measurement: scenes/s with the inputs coming from packed files on disk through the pinned-memory prefetcher
+(disk/page cache -> pinned host -> H2D on a copy stream, overlapped with the forward) next to the device-resident
+number of bench.py, and the raw H2D rate of one scene."""
+import os, sys, time, json, copy, tempfile
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+import torch
+sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", "/root/repo"))
+import bench
+from segdino3d_amd import io_scene
+from segdino3d_amd.dist_eval import PipelinedRunner
+from segdino3d_amd.synth import make_scene
+d = torch.device("cuda:0")
+model = bench.build_model(200, d)
+tmp = tempfile.mkdtemp(prefix="sd3d_e2e_")
+paths = []
+for j in range(4):
+    pts, tgt = make_scene(j, 150000, 3000, 300)
+    ef = tgt.extra_features
+    p = os.path.join(tmp, f"s{j}.sd3d")
+    nbytes = io_scene.pack_scene(p, dict(points=pts, super_points=ef["super_point_masks"], points_2dfeats=ef["points_2dfeats"],
+                                         query2d_feats=ef["query2d_feats"], query2d_pos=ef["query2d_pos"]))
+    paths.append(p)
+R = 48
+files = [paths[i % 4] for i in range(R)]
+# raw H2D of one scene from pinned memory
+host = io_scene.load_packed(paths[0], pin=True)
+torch.cuda.synchronize()
+t0 = time.perf_counter()
+for _ in range(10):
+    dev = host["_staging"].to(d, non_blocking=True)
+torch.cuda.synchronize()
+h2d = nbytes * 10 / (time.perf_counter() - t0)
+# file read into pinned memory (page cache warm)
+t0 = time.perf_counter()
+for _ in range(5):
+    io_scene.load_packed(paths[1], pin=True, staging=host["_staging"])
+t_read = (time.perf_counter() - t0) / 5
+runner = PipelinedRunner(model, 3, d)
+with torch.no_grad():
+    warm = [(p, copy.copy(t)) for p, t in io_scene.ScenePrefetcher(paths, d, depth=2)]
+    runner.run(warm); torch.cuda.synchronize()
+    # device-resident reference
+    t0 = time.perf_counter()
+    runner.run([(warm[i % 4][0], copy.copy(warm[i % 4][1])) for i in range(R)]); torch.cuda.synchronize()
+    t_res = (time.perf_counter() - t0) / R
+    # from files: the prefetcher runs ahead of the runner, which pulls scenes lazily
+    t0 = time.perf_counter()
+    scenes = io_scene.ScenePrefetcher(files, d, depth=3)
+    batch = []
+    for item in scenes:                       # hand scenes to the runner in groups of 6 as they arrive
+        batch.append(item)
+        if len(batch) == 6:
+            runner.run(batch); batch = []
+    if batch:
+        runner.run(batch)
+    torch.cuda.synchronize()
+    t_e2e = (time.perf_counter() - t0) / R
+print(json.dumps({"scene_bytes": nbytes, "h2d_pinned_GBps": round(h2d / 1e9, 1), "file_to_pinned_ms": round(1e3 * t_read, 2),
+                  "device_resident_scenes_per_s": round(1 / t_res, 1), "from_packed_files_scenes_per_s": round(1 / t_e2e, 1)}))
