@@ -91,7 +91,11 @@ class PipelinedRunner:
         self.use_baton = os.environ.get("SD3D_BATON", "1") != "0"
 
     def run(self, scenes, on_result=None):
-        """scenes: sequence of (points, target) already on the device.  Returns the list of model outputs."""
+        """scenes: sequence of (points, target) already on the device, or an iterator that yields them lazily
+        (e.g. io_scene.ScenePrefetcher: each worker pulls its next scene when it is ready for it).  Returns the list of
+        model outputs in submission order."""
+        if not hasattr(scenes, "__getitem__"):
+            return self._run_stream(scenes, on_result)
         results = [None] * len(scenes)
         errors = []
 
@@ -168,3 +172,56 @@ def all_gather_ap_records(local, device="cpu"):
         n = int(row[1])
         out.append((int(row[0]), SceneRecord.unpack(row[2:2 + n])))
     return out
+
+
+def _pipelined_run_stream(self, it, on_result=None):
+    """Workers share one iterator (guarded by a lock; the prefetcher is itself thread-safe and ordered)."""
+    results, errors = {}, []
+    it = iter(it)
+    take = self._threading.Lock()
+    counter = [0]
+    baton = self._threading.Lock() if (self.n > 1 and self.use_baton) else None
+
+    def work(wid):
+        from . import ops
+        try:
+            torch.cuda.set_device(self.device)
+            if baton is not None:
+                baton.acquire()
+                ops.set_baton(baton)
+            with torch.cuda.stream(self.streams[wid]), torch.no_grad():
+                while True:
+                    with take:
+                        try:
+                            pts, tgt = next(it)
+                        except StopIteration:
+                            break
+                        i = counter[0]
+                        counter[0] += 1
+                    results[i] = self.model([pts], [tgt])
+                    if on_result is not None:
+                        on_result(i, results[i])
+                ops.wait_event(ops.stream_event())
+        except BaseException as e:  # noqa: BLE001 - re-raised in the caller's thread
+            errors.append(e)
+        finally:
+            if baton is not None:
+                ops.set_baton(None)
+                baton.release()
+
+    main = torch.cuda.current_stream(self.device)
+    for s in self.streams:
+        s.wait_stream(main)
+    threads = [self._threading.Thread(target=work, args=(w,)) for w in range(self.n)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    for s in self.streams:
+        main.wait_stream(s)
+    if errors:
+        raise errors[0]
+    return [results[i] for i in range(len(results))]
+
+
+PipelinedRunner._run_stream = _pipelined_run_stream

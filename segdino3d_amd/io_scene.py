@@ -153,61 +153,93 @@ def to_device_scene(host: Dict[str, torch.Tensor], device, non_blocking: bool = 
 
 
 class ScenePrefetcher:
-    """Iterates packed scene files as device-resident (points, target) pairs, `depth` scenes ahead.
+    """Iterates packed scene files as device-resident (points, target) pairs, up to `depth` scenes ahead.
 
-    A reader thread reads file i + depth into one of `depth + 1` pinned staging buffers and issues the H2D copies on a
-    dedicated stream; `__next__` makes the CURRENT stream wait on that copy's event (device-side wait) and hands the
-    tensors over.  The staging buffer is recycled when the consumer asks for the next scene."""
+    `readers` threads take file indices from a shared counter, read their file into a pinned staging buffer (one
+    sequential read, the GIL is released inside it) and issue the H2D copies on a dedicated stream; `__next__`
+    hands scenes out IN ORDER, making the consumer's current stream wait on the scene's copy event (a device-side
+    wait: the host never blocks on a transfer).  A staging buffer is recycled when the consumer asks for the scene
+    after the one that used it.  Thread-safe for several consumers (the pipelined runner's workers)."""
 
-    def __init__(self, paths: Iterable[str], device, depth: int = 2):
+    def __init__(self, paths: Iterable[str], device, depth: int = 3, readers: int = 2):
         self.paths = list(paths)
         self.device = torch.device(device)
         self.depth = max(1, depth)
         self.copy_stream = torch.cuda.Stream(device=self.device)
-        self._q: "queue.Queue" = queue.Queue(maxsize=self.depth)
+        self._cv = threading.Condition()
+        self._ready: Dict[int, tuple] = {}
+        self._next_read = 0                                               # next file index a reader may take
+        self._next_out = 0                                                # next index handed to a consumer
         self._free: "queue.Queue" = queue.Queue()
-        for _ in range(self.depth + 1):
+        for _ in range(self.depth + max(1, readers)):
             self._free.put(None)                                          # staging buffers are allocated on first use
-        self._thread = threading.Thread(target=self._reader, daemon=True)
         self._err: Optional[BaseException] = None
-        self._held = None
-        self._thread.start()
+        self._threads = [threading.Thread(target=self._reader, daemon=True) for _ in range(max(1, readers))]
+        for t in self._threads:
+            t.start()
 
     def _reader(self):
         try:
             torch.cuda.set_device(self.device)
-            for path in self.paths:
+            while True:
+                with self._cv:
+                    while self._next_read < len(self.paths) and self._next_read >= self._next_out + self.depth:
+                        self._cv.wait()                                   # far enough ahead of the consumer
+                    if self._next_read >= len(self.paths):
+                        return
+                    i = self._next_read
+                    self._next_read += 1
                 staging = self._free.get()
-                host = load_packed(path, pin=True, staging=staging)
+                host = load_packed(self.paths[i], pin=True, staging=staging)
                 with torch.cuda.stream(self.copy_stream):
                     pts, tgt = to_device_scene(host, self.device, non_blocking=True)
                     ev = torch.cuda.Event()
                     ev.record(self.copy_stream)
-                self._q.put((pts, tgt, ev, host["_staging"]))
-            self._q.put(None)
+                with self._cv:
+                    self._ready[i] = (pts, tgt, ev, host["_staging"])
+                    self._cv.notify_all()
         except BaseException as e:  # noqa: BLE001 - surfaced in the consumer
-            self._err = e
-            self._q.put(None)
+            with self._cv:
+                self._err = e
+                self._cv.notify_all()
 
     def __iter__(self):
         return self
 
+    def __len__(self):
+        return len(self.paths)
+
     def __next__(self):
-        if self._held is not None:                                        # the previous scene's staging buffer is free again
-            self._free.put(self._held)
-            self._held = None
-        item = self._q.get()
-        if item is None:
+        with self._cv:
+            i = self._next_out
+            if i >= len(self.paths):
+                raise StopIteration
+            self._next_out += 1
+            self._cv.notify_all()                                         # readers may move ahead
+            while i not in self._ready and self._err is None:
+                self._cv.wait()
             if self._err is not None:
                 raise self._err
-            raise StopIteration
-        pts, tgt, ev, staging = item
-        torch.cuda.current_stream(self.device).wait_event(ev)
-        # the tensors were allocated on the copy stream: tell the allocator the consumer's stream uses them
+            pts, tgt, ev, staging = self._ready.pop(i)
         cur = torch.cuda.current_stream(self.device)
+        cur.wait_event(ev)
+        # the tensors were allocated on the copy stream: tell the allocator the consumer's stream uses them
         pts.record_stream(cur)
         for v in tgt.extra_features.values():
             if torch.is_tensor(v):
                 v.record_stream(cur)
-        self._held = staging
+        # the H2D copy out of `staging` is complete once `ev` has fired; recycle it when that is known on the host
+        self._recycle(ev, staging)
         return pts, tgt
+
+    def _recycle(self, ev, staging):
+        pending = getattr(self, "_pending", None)
+        if pending is None:
+            pending = self._pending = []
+        pending.append((ev, staging))
+        while pending and pending[0][0].query():
+            self._free.put(pending.pop(0)[1])
+        if len(pending) > self.depth:                                     # never starve the readers
+            ev0, st0 = pending.pop(0)
+            ev0.synchronize()
+            self._free.put(st0)

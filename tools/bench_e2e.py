@@ -43,16 +43,9 @@ with torch.no_grad():
     t0 = time.perf_counter()
     runner.run([(warm[i % 4][0], copy.copy(warm[i % 4][1])) for i in range(R)]); torch.cuda.synchronize()
     t_res = (time.perf_counter() - t0) / R
-    # from files: the prefetcher runs ahead of the runner, which pulls scenes lazily
+    # from files: the runner's workers pull scenes from the prefetcher as they become free
     t0 = time.perf_counter()
-    scenes = io_scene.ScenePrefetcher(files, d, depth=3)
-    batch = []
-    for item in scenes:                       # hand scenes to the runner in groups of 6 as they arrive
-        batch.append(item)
-        if len(batch) == 6:
-            runner.run(batch); batch = []
-    if batch:
-        runner.run(batch)
+    runner.run(io_scene.ScenePrefetcher(files, d, depth=4, readers=2))
     torch.cuda.synchronize()
     t_e2e = (time.perf_counter() - t0) / R
 print(json.dumps({"scene_bytes": nbytes, "h2d_pinned_GBps": round(h2d / 1e9, 1), "file_to_pinned_ms": round(1e3 * t_read, 2),
