@@ -135,12 +135,20 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", 1))
     if world != args.gpus and world > 1:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
-    torch.cuda.set_device(local_rank)
-    device = torch.device("cuda", local_rank)
+    # SD3D_DIST_BACKEND=gloo + SD3D_SHARE_GPU=1: rehearsal of the multi-rank flow on ONE GPU (ranks share device 0,
+    # collectives on CPU tensors); the real runs use "nccl" (= RCCL over xGMI), one GPU per rank.
+    backend = os.environ.get("SD3D_DIST_BACKEND", "nccl")
+    dev_index = 0 if os.environ.get("SD3D_SHARE_GPU") == "1" else local_rank
+    torch.cuda.set_device(dev_index)
+    device = torch.device("cuda", dev_index)
+    comm_device = device if backend == "nccl" else torch.device("cpu")
     dist = None
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group(backend="nccl", rank=rank, world_size=world, device_id=device)
+        if backend == "nccl":
+            dist.init_process_group(backend="nccl", rank=rank, world_size=world, device_id=device)
+        else:
+            dist.init_process_group(backend=backend, rank=rank, world_size=world)
 
     from segdino3d_amd import ops
     from segdino3d_amd.synth import make_scene
@@ -198,7 +206,7 @@ def main():
 
     # max over ranks
     if dist is not None:
-        tt = torch.tensor([dt], dtype=torch.float64, device=device)
+        tt = torch.tensor([dt], dtype=torch.float64, device=comm_device)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
     total_scenes = world * args.steps
@@ -263,7 +271,7 @@ def main():
     # ---- closing all-gather of per-scene records over RCCL/xGMI -----------------------
     maps = model.backbone.last_maps
     rec = torch.tensor([float(rank), float(args.points), float(maps.n_vox[0]), 1e3 * dt / args.steps],
-                       dtype=torch.float64, device=device)
+                       dtype=torch.float64, device=comm_device)
     if dist is not None:
         gathered = [torch.empty_like(rec) for _ in range(world)]
         dist.all_gather(gathered, rec)
