@@ -358,16 +358,6 @@ def pool_superpoints(feat, C, inverse, icoords, voxel_size, sorted_idx, start, S
 # --------------------------------------------------------------------------------------------
 # gather-GEMM
 # --------------------------------------------------------------------------------------------
-# Kernel choice by rulebook density = pairs / (K * M), from tools/gg_quick.py on MI355X:
-#   < 0.15        pair-compacted kernel with a shared LDS accumulator (ds_add_f32): 256-row tiles keep the
-#                 32-pair MFMA chunks full when only ~1 row in 9 has a given neighbour
-#   0.15 .. 0.40  pair-compacted kernel with per-wave private accumulators (no atomics, 128-row tiles)
-#   >= 0.40       dense lock-step kernel with LDS-shared weights (the zeros it multiplies cost less than compaction)
-COMPACT_ATOMIC_DENSITY = 0.15
-COMPACT_PRIVATE_DENSITY = 0.40
-SPLIT_COMPACT_DENSITY = (0.08, 0.20)     # (atomic, private) thresholds when the dense kernel runs split-bf16
-
-
 # Opt-in arithmetic mode of the lock-step gather-GEMM (csrc/gather_gemm_split.hip): None = exact fp32 MFMA
 # (default, the mode every parity claim and the bench headline are made in), "bf16x3" / "bf16x6" = fp32
 # products evaluated as 3 / 6 bf16 MFMA products with fp32 accumulation.
@@ -471,7 +461,9 @@ def gather_gemm(x, wt, nbr=None, x2=None, scale=None, shift=None, res=None, act=
     """out[r, n] = act(scale[n] * sum_k sum_c X[nbr[k, r], c] * wt[k, n, c] + shift[n] + res[r, n]).
 
     x [V_in, C0] (rows may be strided), optional x2 [V_in, C1] = concatenated channels,
-    wt [K, Cout, Cin] contiguous, nbr int32 [K, M] or None (identity rows, K = 1)."""
+    wt [K, Cout, Cin] contiguous, nbr int32 [K, M] or None (identity rows, K = 1).  With `pairs` (the table's
+    PairLists) a sparse convolution runs pair-major (pair_conv); `density` is informational (kept for callers that
+    pass SceneMaps.conv_table(...) as keyword arguments)."""
     lib = _lib.load()
     if wt.dim() == 2:
         wt = wt.unsqueeze(0)
@@ -503,12 +495,6 @@ def gather_gemm(x, wt, nbr=None, x2=None, scale=None, shift=None, res=None, act=
         terms = {2: 3, 3: 6}[wt_split.shape[0]]
     elif GEMM_MODE is not None and nt == 0 and M >= SPLIT_MIN_ROWS and Cin % 32 == 0:
         terms = 3 if GEMM_MODE == "bf16x3" else 6
-    if nt == 0 and density is not None and nbr is not None and GG_FORCE_NT is None:
-        lo, hi = (COMPACT_ATOMIC_DENSITY, COMPACT_PRIVATE_DENSITY) if not terms else SPLIT_COMPACT_DENSITY
-        if density < lo:
-            nt, terms = -21, 0
-        elif density < hi:
-            nt, terms = -61, 0
     if terms and wt_split is None:
         wt_split = _cached_split(wt, terms)
     if GG_FORCE_NT is not None and nt == 0:

@@ -1,4 +1,5 @@
-"""f-2 measurement: per-scene AP association on the device vs the oracle (numpy) on the host, full-size scene
+"""f-2 measurement (lives under tests/ because it times the oracle): per-scene AP association on the device vs the
+oracle (numpy) on the host, full-size scene
 (600 predictions x 150 k points, ~60 ground-truth instances of a 198-class label set)."""
 import os, sys, time, json
 import numpy as np, torch

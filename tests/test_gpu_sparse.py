@@ -147,7 +147,7 @@ def test_sparse_conv_matches_oracle():
         x = det_randn(f"sc.x{l}{k}", (lv.n(1 << l), cin))
         w = det_randn(f"sc.w{l}{k}", (k ** 3, cin, cout), (cin * k ** 3) ** -0.5)
         ref = R.sparse_conv(x, lv.same(1 << l, k), w, lv.n(1 << l))
-        for nt in (0, 1, -1, -11, -21, -51, -61):
+        for nt in (0, 1, -1, -11, -12):
             got = ops.gather_gemm(to_dev(x, l), w.permute(0, 2, 1).contiguous().to(d), nbr=maps.same(l, k), nt=nt).cpu()
             torch.testing.assert_close(got, ref[perm[l]], rtol=2e-4, atol=2e-4,
                                        msg=lambda m: f"same conv l={l} k={k} nt={nt}: {m}")

@@ -4,7 +4,20 @@ sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", "/root/repo"))
 from segdino3d_amd import ops
 from segdino3d_amd.sparse import SceneMaps
 from segdino3d_amd.synth import make_scene
-from tools.bench_gg import timeit
+
+
+def timeit(fn, reps=5):
+    """Median-free simple timer: microseconds per call over `reps` calls between two HIP events."""
+    for _ in range(2):
+        fn()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(reps):
+        fn()
+    e1.record()
+    torch.cuda.synchronize()
+    return 1e3 * e0.elapsed_time(e1) / reps
+
 d = torch.device("cuda:0")
 pts, tgt = make_scene(0, 150000, 3000, 300)
 maps = SceneMaps(pts.to(d), 0.02, 5, superpoints=tgt.extra_features["super_point_masks"].to(d))
