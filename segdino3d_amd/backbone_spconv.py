@@ -26,7 +26,7 @@ from typing import List
 import torch
 import torch.nn as nn
 
-from . import ops
+from . import ops, plan
 from .builder import BACKBONES
 from .sparse import SceneMaps
 
@@ -103,15 +103,18 @@ class SpConvUNet(nn.Module):
             self.output_layer = nn.Sequential(_bn(32), nn.ReLU(inplace=True))
         self.add_positional_embedding = add_positional_embedding
         self._packed = None
+        self._plan = None
         self.last_maps = None
 
     # ---- packing ---------------------------------------------------------------------------------
     def _apply(self, fn, *a, **k):
         self._packed = None
+        self._plan = None
         return super()._apply(fn, *a, **k)
 
     def load_state_dict(self, *a, **k):
         self._packed = None
+        self._plan = None
         return super().load_state_dict(*a, **k)
 
     def packed(self):
@@ -126,37 +129,49 @@ class SpConvUNet(nn.Module):
         return self._packed
 
     # ---- network -----------------------------------------------------------------------------------
-    def _resblock(self, pk, p, x, tab, x2=None):
+    def _resblock(self, be, pk, p, x, key, x2=None):
         """ResidualBlock.forward (:82-99): conv_branch(x) + i_branch(x); x may be the concat [x | x2]."""
-        s0, b0 = pk[p + ".conv_branch.0"]
-        h = ops.scale_shift_act(x, s0, b0, act="relu", x2=x2)
-        s3, b3 = pk[p + ".conv_branch.3"]
-        h = ops.gather_gemm(h, pk[p + ".conv_branch.2"], scale=s3, shift=b3, act="relu", **tab)
+        h = be.affine(x, pk[p + ".conv_branch.0"], x2=x2, act="relu")
+        h = be.conv(h, pk[p + ".conv_branch.2"], pk[p + ".conv_branch.3"], key, act="relu")
         if (p + ".i_branch.0") in pk:
-            ident = ops.gather_gemm(x, pk[p + ".i_branch.0"], x2=x2)
+            ident = be.dense(x, pk[p + ".i_branch.0"], None, x2=x2)
         else:
             assert x2 is None
             ident = x
-        return ops.gather_gemm(h, pk[p + ".conv_branch.5"], res=ident, **tab)
+        return be.conv(h, pk[p + ".conv_branch.5"], None, key, res=ident)
 
-    def _unet(self, pk, prefix, maps: SceneMaps, level, x):
-        tab = maps.conv_table("same", level, 3)
+    def _unet(self, be, pk, prefix, n_levels, level, x):
+        key = ("same", level, 3)
         for r in range(self.block_reps):
-            x = self._resblock(pk, f"{prefix}blocks.block{r}", x, tab)
-        n_levels = len(maps.n_vox)
+            x = self._resblock(be, pk, f"{prefix}blocks.block{r}", x, key)
         if level < n_levels - 1:
             ident = x
-            s, b = pk[prefix + "conv.0"]
-            h = ops.scale_shift_act(x, s, b, act="relu")
-            h = ops.gather_gemm(h, pk[prefix + "conv.2"], **maps.conv_table("down", level))
-            h = self._unet(pk, prefix + "u.", maps, level + 1, h)
-            s, b = pk[prefix + "deconv.0"]
-            h = ops.scale_shift_act(h, s, b, act="relu")
-            h = ops.gather_gemm(h, pk[prefix + "deconv.2"], **maps.conv_table("up", level))
-            x = self._resblock(pk, f"{prefix}blocks_tail.block0", ident, tab, x2=h)
+            h = be.affine(x, pk[prefix + "conv.0"], act="relu")
+            h = be.conv(h, pk[prefix + "conv.2"], None, ("down", level))
+            h = self._unet(be, pk, prefix + "u.", n_levels, level + 1, h)
+            h = be.affine(h, pk[prefix + "deconv.0"], act="relu")
+            h = be.conv(h, pk[prefix + "deconv.2"], None, ("up", level))
+            x = self._resblock(be, pk, f"{prefix}blocks_tail.block0", ident, key, x2=h)
             for r in range(1, self.block_reps):
-                x = self._resblock(pk, f"{prefix}blocks_tail.block{r}", x, tab)
+                x = self._resblock(be, pk, f"{prefix}blocks_tail.block{r}", x, key)
         return x
+
+    def _network(self, be, pk, x, n_levels):
+        """`SpConvUNet.forward` (:233-268) against a plan backend (segdino3d_amd.plan)."""
+        x = be.conv(x, pk["input_conv.0"], None, ("same", 0, 3))
+        x = self._unet(be, pk, "", n_levels, 0, x)
+        return be.affine(x, pk["output_layer.0"], act="relu")
+
+    def forward_sparse(self, maps: SceneMaps, vox_feats: torch.Tensor) -> torch.Tensor:
+        pk = self.packed()
+        nl = len(self.num_planes)
+        maps.prepare(same=[(l, 3) for l in range(nl)], strides=list(range(nl - 1)))
+        if plan.USE_PLAN and ops.PAIR_CONV and ops.GEMM_MODE is None and ops.GG_FORCE_NT is None and ops.GG_HOOK is None:
+            if self._plan is None:                               # one C call per scene instead of ~130
+                rec = plan.Recorder(vox_feats.shape[1])
+                self._plan = rec.finish(self._network(rec, pk, rec.input, nl))
+            return self._plan.run(maps, vox_feats)
+        return self._network(plan.EagerBackend(maps), pk, vox_feats, nl)
 
     @ops.bound_stream
     def forward_wrapper(self, samples: List[torch.Tensor], targets, return_sp_mean_pos=True):
@@ -177,12 +192,7 @@ class SpConvUNet(nn.Module):
             self.last_maps = maps
             cin_pad = (self.in_channels + 31) // 32 * 32
             vf = maps.voxel_features(pts, f2d, 2, cin_pad)
-            nl = len(self.num_planes)
-            maps.prepare(same=[(l, 3) for l in range(nl)], strides=list(range(nl - 1)))
-            x = ops.gather_gemm(vf, pk["input_conv.0"], **maps.conv_table("same", 0, 3))
-            x = self._unet(pk, "", maps, 0, x)
-            s, b = pk["output_layer.0"]
-            x = ops.scale_shift_act(x, s, b, act="relu")
+            x = self.forward_sparse(maps, vf)
             f, _ = maps.pool(x, x.shape[1])
             # positions: mean of floor(xyz / voxel) * voxel with the UN-shifted coordinates
             pos_maps = SceneMaps(pts, self.voxel_size, 1, shift_to_min=False, order=self.KERNEL_ORDER, superpoints=sp)

@@ -387,9 +387,16 @@ def test_layer_plan_matches_eager():
     from segdino3d_amd import plan
     from segdino3d_amd.configs import scannet200_model_cfg
     from segdino3d_amd.synth import make_scene
+    from segdino3d_amd.configs import scannetv2_model_cfg
     d = dev()
-    model = seg.build_architecture(scannet200_model_cfg(query_num=40)).eval().to(d)
-    bb = model.backbone
+    for cfg in (scannet200_model_cfg(query_num=40), scannetv2_model_cfg()):      # Res16UNet34C and SpConvUNet
+        model = seg.build_architecture(cfg).eval().to(d)
+        _plan_vs_eager(model.backbone, d)
+
+
+def _plan_vs_eager(bb, d):
+    from segdino3d_amd import plan
+    from segdino3d_amd.synth import make_scene
     for seed, n in ((3, 20000), (4, 7000)):
         pts, tgt = make_scene(seed, n, 200, 20)
         samples, targets = [pts.to(d)], [tgt.to(d)]
