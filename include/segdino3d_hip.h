@@ -189,10 +189,13 @@ int sd3d_sine_pe(const float* xyz, int ld_xyz, int64_t n, const float* range, co
                  void* stream);
 /* Fused multi-head attention (replaces bmm + masked_fill + softmax + bmm of attention.py:361-385 and
  * nn.MultiheadAttention's SDPA at decoder :79).  Heads are 32-channel slices; nsrc = 2 concatenates
- * [q0|q1] . [k0|k1] per head (decoder :681-687).  mask_bits [Lq, ceil(Lk/32)]: bit = 1 -> blocked. */
+ * [q0|q1] . [k0|k1] per head (decoder :681-687).  mask_bits [Lq, ceil(Lk/32)]: bit = 1 -> blocked.
+ * ws / ws_bytes: optional scratch (sd3d_attention_ws_bytes) that lets few-query launches split the keys over several
+ * workgroups and merge the softmax states in a second pass; NULL = single pass. */
+size_t sd3d_attention_ws_bytes(int Lq, int H);
 int sd3d_attention(const float* q0, int ldq0, const float* q1, int ldq1, const float* k0, int ldk0, const float* k1,
                    int ldk1, const float* v, int ldv, const uint32_t* mask_bits, int Lq, int Lk, int H, float scale,
-                   float* out, int ldo, void* stream);
+                   float* out, int ldo, void* ws, size_t ws_bytes, void* stream);
 /* _forward_head mask part (:567-572): bits = sigmoid(logits) < thr, dead rows reset to open. */
 int sd3d_mask_bits(const float* logits, int ld, int64_t Q, int S, float thr, uint32_t* bits, int nwords, void* stream);
 /* (dist < thr) of torch.cdist(p=1) (:721) as bits near[M, ceil(S/32)]. */

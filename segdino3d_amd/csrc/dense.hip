@@ -130,6 +130,8 @@ struct AttnParams {
     float* out; int ldo;
     int Lq, Lk, H;
     float scale;
+    int ksplit;                               // key tiles are dealt to gridDim.z workgroups; partials -> part
+    float* part;                              // [qtile][head][ksplit][64 + 1024]: m[32], l[32], O[32 dv][32 q]
 };
 
 template <int NSRC>
@@ -160,12 +162,22 @@ __global__ __launch_bounds__(512) void attention_kernel(const AttnParams p) {
     float m = -INFINITY, l = 0.f;
 
     const int ntiles = (p.Lk + 31) >> 5;
-    for (int t = wave; t < ntiles; t += nw) {
+    for (int t = blockIdx.z * nw + wave; t < ntiles; t += nw * p.ksplit) {
         const int kt0 = t * 32;
         const int kr = min(kt0 + i, p.Lk - 1);          // A-operand row = key
         f32x16 S;
 #pragma unroll
         for (int r = 0; r < 16; ++r) S[r] = 0.f;
+        // the value rows of this tile are requested before the score MFMAs: their latency hides behind QK^T + softmax
+        float vreg[16];
+        {
+            const float* vsrc = p.v + head * 32 + i;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int key = min(kt0 + (r & 3) + 8 * (r >> 2) + 4 * h, p.Lk - 1);
+                vreg[r] = vsrc[(int64_t)key * p.ldv];
+            }
+        }
 #pragma unroll
         for (int s = 0; s < NSRC; ++s) {
             const float* src = p.k[s] + (int64_t)kr * p.ldk[s] + hc;
@@ -206,13 +218,8 @@ __global__ __launch_bounds__(512) void attention_kernel(const AttnParams p) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) O[r] *= alpha;
         // O^T[dv][query] += sum_key V[key][dv] * P[query][key];  A = V^T (row = dv = i), B = P^T
-        const float* vsrc = p.v + head * 32 + i;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int key = min(kt0 + (r & 3) + 8 * (r >> 2) + 4 * h, p.Lk - 1);
-            const float vv = vsrc[(int64_t)key * p.ldv];
-            O = __builtin_amdgcn_mfma_f32_32x32x2f32(vv, pr[r], O, 0, 0, 0);
-        }
+        for (int r = 0; r < 16; ++r) O = __builtin_amdgcn_mfma_f32_32x32x2f32(vreg[r], pr[r], O, 0, 0, 0);
     }
     l += __shfl_xor(l, 32);
 
@@ -236,21 +243,65 @@ __global__ __launch_bounds__(512) void attention_kernel(const AttnParams p) {
             L += base[32 + qq] * f;
             acc += base[64 + dv * 32 + qq] * f;
         }
+        if (p.ksplit > 1) {                             // this workgroup's share of the keys: leave (M, L, sum) for the merge pass
+            float* dst = p.part + (((int64_t)blockIdx.x * p.H + head) * p.ksplit + blockIdx.z) * (64 + 1024);
+            if (dv == 0) { dst[qq] = M; dst[32 + qq] = L; }
+            dst[64 + dv * 32 + qq] = acc;
+        } else if (q0 + qq < p.Lq) {
+            p.out[(int64_t)(q0 + qq) * p.ldo + head * 32 + dv] = acc / L;
+        }
+    }
+}
+
+// second pass of the key-split attention: combine the ksplit partial softmax states of one (query tile, head)
+__global__ __launch_bounds__(256) void attention_merge_kernel(const AttnParams p) {
+    const int head = blockIdx.y, q0 = blockIdx.x * 32;
+    const float* base = p.part + ((int64_t)blockIdx.x * p.H + head) * p.ksplit * (64 + 1024);
+    for (int e = threadIdx.x; e < 1024; e += 256) {
+        const int qq = e >> 5, dv = e & 31;
+        float M = -INFINITY;
+        for (int z = 0; z < p.ksplit; ++z) M = fmaxf(M, base[z * (64 + 1024) + qq]);
+        float L = 0.f, acc = 0.f;
+        for (int z = 0; z < p.ksplit; ++z) {
+            const float* b = base + z * (64 + 1024);
+            const float mz = b[qq];
+            const float f = (mz == -INFINITY) ? 0.f : expf(mz - M);
+            L += b[32 + qq] * f;
+            acc += b[64 + dv * 32 + qq] * f;
+        }
         if (q0 + qq < p.Lq) p.out[(int64_t)(q0 + qq) * p.ldo + head * 32 + dv] = acc / L;
     }
 }
 
-int launch_attention(const AttnParams& p, int nsrc, hipStream_t st) {
+size_t attention_ws_bytes(int Lq, int H) { return (size_t)cdiv(Lq, 32) * H * 8 * (64 + 1024) * sizeof(float); }
+
+int launch_attention(const AttnParams& p_in, int nsrc, void* ws, size_t ws_bytes, hipStream_t st) {
+    AttnParams p = p_in;
     if (p.Lq <= 0 || p.Lk <= 0) return sd3d_set_error(SD3D_ERR_ARG, "attention: empty query or key set");
     for (int s = 0; s < nsrc; ++s)
         if ((p.ldq[s] & 3) || (p.ldk[s] & 3)) return sd3d_set_error(SD3D_ERR_ARG, "attention: q/k strides must be multiples of 4");
     const int ntiles = (p.Lk + 31) / 32;
     int nw = ntiles >= 32 ? 8 : (ntiles >= 8 ? 4 : (ntiles >= 2 ? 2 : 1));
-    const dim3 grid((unsigned)cdiv(p.Lq, 32), (unsigned)p.H), block(64 * nw);
+    // few query tiles x heads (200 queries: 56 workgroups on 256 CUs) and many key tiles: deal the key tiles to several
+    // workgroups and merge their softmax states in a second, tiny pass (each wave walks its tiles serially, so the
+    // single-pass kernel is bound by ~12 dependent load -> MFMA round trips per wave)
+    const int64_t wgs = cdiv(p.Lq, 32) * p.H;
+    int ks = 1;
+    if (ws && wgs < 128 && ntiles >= 4 * nw) {
+        ks = (int)(512 / wgs);
+        const int most = ntiles / (2 * nw);
+        ks = ks > most ? most : ks;
+        ks = ks > 8 ? 8 : ks;
+        if (ks < 2 || ws_bytes < (size_t)wgs * ks * (64 + 1024) * sizeof(float)) ks = 1;
+    }
+    p.ksplit = ks;
+    p.part = (float*)ws;
+    const dim3 grid((unsigned)cdiv(p.Lq, 32), (unsigned)p.H, (unsigned)ks), block(64 * nw);
     const size_t sm = (size_t)nw * (64 + 1024) * sizeof(float);
     if (nsrc == 1) hipLaunchKernelGGL(attention_kernel<1>, grid, block, sm, st, p);
     else if (nsrc == 2) hipLaunchKernelGGL(attention_kernel<2>, grid, block, sm, st, p);
     else return sd3d_set_error(SD3D_ERR_ARG, "attention: nsrc must be 1 or 2");
+    if (ks > 1) hipLaunchKernelGGL(attention_merge_kernel, dim3((unsigned)cdiv(p.Lq, 32), (unsigned)p.H), dim3(256), 0, st, p);
     SD3D_CHECK_LAUNCH();
     return SD3D_OK;
 }

@@ -193,6 +193,7 @@ _WS2 = _PerThread()       # split-K partial sums of gather_gemm
 _WS3 = _PerThread()       # partial products of pair_conv
 _WS4 = _PerThread()       # pair_lists scratch
 _WS5 = _PerThread()       # expand_masks bit table
+_WS6 = _PerThread()       # attention key-split partial states
 
 
 # --------------------------------------------------------------------------------------------
@@ -582,8 +583,10 @@ def attention(q, k, v, num_heads, scale, mask_bits=None, q2=None, k2=None):
     if mask_bits is not None and tuple(mask_bits.shape) != (Lq, (Lk + 31) // 32):
         raise ValueError(f"attention: mask bits shape {tuple(mask_bits.shape)} != ({Lq}, {(Lk + 31) // 32})")
     out = torch.empty(Lq, num_heads * 32, dtype=torch.float32, device=q.device)
+    ws = _WS6.get(lib.sd3d_attention_ws_bytes(Lq, num_heads), q.device)
     _lib.check(lib.sd3d_attention(pq, ldq, pq2, ldq2, pk, ldk, pk2, ldk2, pv, ldv, _ptr(mask_bits, torch.int32, "mask_bits"),
-                                  Lq, Lk, num_heads, float(scale), _ptr(out), out.shape[1], _stream()), "attention")
+                                  Lq, Lk, num_heads, float(scale), _ptr(out), out.shape[1], ws.data_ptr(), ws.numel(),
+                                  _stream()), "attention")
     return out
 
 
