@@ -81,9 +81,11 @@ int sd3d_hash_build(const uint64_t* ukeys, int64_t n, uint64_t* table_keys, int3
 /* nbr[k*n_out + v] = id of the voxel at coord(v) + offsets[k] in the hashed level, or -1.
  * offsets: int8 [K,3] in units of that level's stride.  pair_count (optional, device int32[64],
  * pre-zeroed) accumulates the rulebook size (number of hits) as 64 partial sums - the host adds them
- * and uses the density to pick the convolution kernel. */
+ * and uses the density to pick the convolution kernel. 
+ * mirrored = 1: out_keys are the table's own keys and offsets[K-1-k] == -offsets[k] (centred odd kernel): only half the
+ * offsets are probed and every hit is written to both mirror slots. */
 int sd3d_kernel_map(const uint64_t* out_keys, int64_t n_out, const uint64_t* table_keys, const int32_t* table_vals,
-                    int64_t capacity, const int8_t* offsets, int K, int32_t* nbr, int32_t* pair_count, void* stream);
+                    int64_t capacity, const int8_t* offsets, int K, int mirrored, int32_t* nbr, int32_t* pair_count, void* stream);
 /* 2x2x2 stride-2 maps from the parent array: nbr_down [8, n_coarse], nbr_up [8, n_fine]; perm8[8]
  * maps the child's Z-order position (x | y<<1 | z<<2) to the weight index. */
 int sd3d_stride_maps(const uint64_t* fine_keys, const int32_t* parent, int64_t n_fine, int64_t n_coarse,

@@ -23,7 +23,7 @@ size_t unique_ws_bytes(int64_t);
 int launch_unique_sorted(const uint64_t*, const uint32_t*, int64_t, const int*, int, uint64_t*, int32_t*, int32_t*, int32_t*,
                          void*, size_t, const float*, float, int, int, hipStream_t);
 int launch_hash_build(const uint64_t*, int64_t, uint64_t*, int32_t*, int64_t, hipStream_t);
-int launch_kernel_map(const uint64_t*, int64_t, const uint64_t*, const int32_t*, int64_t, const int8_t*, int, int32_t*, int32_t*, hipStream_t);
+int launch_kernel_map(const uint64_t*, int64_t, const uint64_t*, const int32_t*, int64_t, const int8_t*, int, int, int32_t*, int32_t*, hipStream_t);
 int launch_stride_maps(const uint64_t*, const int32_t*, int64_t, int64_t, const int32_t*, int32_t*, int32_t*, hipStream_t);
 int launch_voxel_mean(const float*, int, const float*, int, int, const float*, int64_t, const uint32_t*, const int32_t*, int64_t,
                       float*, int, hipStream_t);
@@ -131,9 +131,9 @@ int sd3d_hash_build(const uint64_t* ukeys, int64_t n, uint64_t* table_keys, int3
     return launch_hash_build(ukeys, n, table_keys, table_vals, capacity, ST);
 }
 int sd3d_kernel_map(const uint64_t* out_keys, int64_t n_out, const uint64_t* table_keys, const int32_t* table_vals,
-                    int64_t capacity, const int8_t* offsets, int K, int32_t* nbr, int32_t* pair_count, void* stream) {
+                    int64_t capacity, const int8_t* offsets, int K, int mirrored, int32_t* nbr, int32_t* pair_count, void* stream) {
     if (capacity <= 0 || (capacity & (capacity - 1))) return sd3d_set_error(SD3D_ERR_ARG, "kernel_map: capacity must be a power of two");
-    return launch_kernel_map(out_keys, n_out, table_keys, table_vals, capacity, offsets, K, nbr, pair_count, ST);
+    return launch_kernel_map(out_keys, n_out, table_keys, table_vals, capacity, offsets, K, mirrored, nbr, pair_count, ST);
 }
 int sd3d_stride_maps(const uint64_t* fine_keys, const int32_t* parent, int64_t n_fine, int64_t n_coarse, const int32_t* perm8,
                      int32_t* nbr_down, int32_t* nbr_up, void* stream) {

@@ -303,9 +303,67 @@ __global__ __launch_bounds__(256) void kernel_map_kernel(const uint64_t* __restr
     }
 }
 
+// Mirrored variant for a table of a voxel set onto ITSELF with a centred odd kernel whose offset list is symmetric
+// under index reversal (off[K-1-k] = -off[k], true for both enumeration orders used here): if v has neighbour j at
+// offset k then j has neighbour v at offset K-1-k, so only the first K/2 offsets are probed and each hit is written
+// twice.  Half the hash probes and Morton arithmetic; the upper half of nbr is pre-filled with -1 by the launcher.
+__global__ __launch_bounds__(256) void kernel_map_mirrored_kernel(const uint64_t* __restrict__ keys, int64_t n,
+                                                                  const uint64_t* __restrict__ tkeys, const int32_t* __restrict__ tvals,
+                                                                  uint32_t mask, const int8_t* __restrict__ offs, int K,
+                                                                  int32_t* __restrict__ nbr, int32_t* __restrict__ pair_count) {
+    __shared__ int wsum[4];
+    const int half = K / 2;
+    const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    int found = 0;
+    if (t < (int64_t)(half + 1) * n) {
+        const int k = (int)(t / n);
+        const int64_t v = t - (int64_t)k * n;
+        if (k == half) {
+            nbr[(int64_t)half * n + v] = (int32_t)v;                 // the centre offset is the voxel itself
+            found = 1;
+        } else {
+            const uint64_t key = keys[v];
+            uint32_t x, y, z;
+            morton_decode(key & SD3D_MORTON_MASK, x, y, z);
+            const int nx = (int)x + offs[k * 3 + 0], ny = (int)y + offs[k * 3 + 1], nz = (int)z + offs[k * 3 + 2];
+            int id = -1;
+            if (((nx | ny | nz) >= 0) && nx < 65536 && ny < 65536 && nz < 65536) {
+                const uint64_t q = morton_encode((uint32_t)nx, (uint32_t)ny, (uint32_t)nz) | (key & ~SD3D_MORTON_MASK);
+                id = hash_lookup(tkeys, tvals, mask, q);
+            }
+            nbr[t] = id;
+            if (id >= 0) {
+                nbr[(int64_t)(K - 1 - k) * n + id] = (int32_t)v;
+                found = 2;
+            }
+        }
+    }
+    if (pair_count) {
+        int c = found;
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) c += __shfl_xor(c, d);
+        if ((threadIdx.x & 63) == 0) wsum[threadIdx.x >> 6] = c;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            const int tot = wsum[0] + wsum[1] + wsum[2] + wsum[3];
+            if (tot) atomicAdd(&pair_count[blockIdx.x & 63], tot);
+        }
+    }
+}
+
 int launch_kernel_map(const uint64_t* okeys, int64_t n_out, const uint64_t* tkeys, const int32_t* tvals, int64_t capacity,
-                      const int8_t* offs_dev, int K, int32_t* nbr, int32_t* pair_count, hipStream_t st) {
+                      const int8_t* offs_dev, int K, int mirrored, int32_t* nbr, int32_t* pair_count, hipStream_t st) {
     if (n_out <= 0 || K <= 0) return SD3D_OK;
+    if (mirrored) {
+        if (!(K & 1)) return sd3d_set_error(SD3D_ERR_ARG, "kernel_map: the mirrored variant needs an odd, centred kernel");
+        const int half = K / 2;
+        if (half > 0 && hipMemsetAsync(nbr + (int64_t)(half + 1) * n_out, 0xFF, (size_t)half * n_out * sizeof(int32_t), st) != hipSuccess)
+            return sd3d_set_error(SD3D_ERR_LAUNCH, "kernel_map: memset failed");
+        hipLaunchKernelGGL(kernel_map_mirrored_kernel, dim3((unsigned)cdiv((int64_t)(half + 1) * n_out, 256)), dim3(256), 0, st, okeys,
+                           n_out, tkeys, tvals, (uint32_t)(capacity - 1), offs_dev, K, nbr, pair_count);
+        SD3D_CHECK_LAUNCH();
+        return SD3D_OK;
+    }
     const int64_t total = (int64_t)K * n_out;
     hipLaunchKernelGGL(kernel_map_kernel, dim3((unsigned)cdiv(total, 256)), dim3(256), 0, st, okeys, n_out, tkeys, tvals,
                        (uint32_t)(capacity - 1), offs_dev, K, nbr, pair_count);

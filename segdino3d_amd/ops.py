@@ -300,15 +300,16 @@ def hash_build(ukeys: torch.Tensor, n: int):
     return tk, tv
 
 
-def kernel_map(out_keys, n_out, table, offsets_i8, pair_count=None):
+def kernel_map(out_keys, n_out, table, offsets_i8, pair_count=None, mirrored=False):
     """offsets_i8: int8 [K,3] device tensor.  Returns nbr int32 [K, n_out].  pair_count: optional int32 [64]
-    device counters (pre-zeroed) whose sum is the rulebook size."""
+    device counters (pre-zeroed) whose sum is the rulebook size.  mirrored: the table is the voxel set's own and
+    offsets[K-1-k] == -offsets[k] (centred odd kernel) - half the probes."""
     lib = _lib.load()
     tk, tv = table
     K = offsets_i8.shape[0]
     nbr = torch.empty(K, n_out, dtype=torch.int32, device=out_keys.device)
     _lib.check(lib.sd3d_kernel_map(_ptr(out_keys, torch.int64, "out_keys"), n_out, _ptr(tk), _ptr(tv), tk.numel(),
-                                   _ptr(offsets_i8, torch.int8, "offsets"), K, _ptr(nbr),
+                                   _ptr(offsets_i8, torch.int8, "offsets"), K, 1 if mirrored else 0, _ptr(nbr),
                                    _ptr(pair_count, torch.int32, "pair_count"), _stream()), "kernel_map")
     return nbr
 

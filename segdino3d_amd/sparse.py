@@ -68,6 +68,11 @@ def child_perm(order: str) -> np.ndarray:
 EXACT_PAIR_CAPACITY = os.environ.get("SD3D_EXACT_PAIRS", "1") == "1"
 
 
+# kernel offsets are enumerated symmetrically (kernel_offsets_np: off[K-1-k] == -off[k] for odd k), so a stride-1 table
+# needs only half its hash probes.  SD3D_MIRRORED_MAPS=0 probes every offset (cross-check).
+MIRRORED_MAPS = os.environ.get("SD3D_MIRRORED_MAPS", "1") != "0"
+
+
 class SceneMaps:
     """Voxelisation + coordinate levels + neighbour tables of ONE scene, all on the HIP device."""
 
@@ -128,7 +133,7 @@ class SceneMaps:
         for i, (lvl, k) in enumerate(same):
             offs = offsets_device(k, self.order, self.device)
             self._same[(lvl, k)] = ops.kernel_map(self.keys[lvl], self.n_vox[lvl], self.table(lvl), offs,
-                                                  counters[i] if exact else None)
+                                                  counters[i] if exact else None, mirrored=MIRRORED_MAPS and k % 2 == 1)
         for lvl in strides:
             self._stride_maps(lvl)
         if exact:
@@ -161,7 +166,8 @@ class SceneMaps:
         key = (level, ksize)
         if key not in self._same:
             offs = offsets_device(ksize, self.order, self.device)
-            self._same[key] = ops.kernel_map(self.keys[level], self.n_vox[level], self.table(level), offs)
+            self._same[key] = ops.kernel_map(self.keys[level], self.n_vox[level], self.table(level), offs,
+                                             mirrored=MIRRORED_MAPS and ksize % 2 == 1)
         return self._same[key]
 
     def _stride_maps(self, level: int):

@@ -410,3 +410,23 @@ def _plan_vs_eager(bb, d):
             finally:
                 plan.USE_PLAN = True
         assert torch.equal(f_plan[0], f_eager[0]) and torch.equal(p_plan[0], p_eager[0])
+
+
+def test_mirrored_kernel_map_equals_full_probe():
+    """Half-probe neighbour tables (mirror slots written from the hits) are bit-identical to probing every offset,
+    pair counters included."""
+    from segdino3d_amd import ops
+    from segdino3d_amd.sparse import SceneMaps, offsets_device
+    from segdino3d_amd.synth import make_scene
+    d = dev()
+    pts, tgt = make_scene(12, 40000, 300, 30)
+    maps = SceneMaps(pts.to(d), 0.02, 4, superpoints=tgt.extra_features["super_point_masks"].to(d))
+    for order in ("x_fastest", "z_fastest"):
+        for lvl, ks in [(0, 3), (0, 5), (2, 3), (3, 3)]:
+            offs = offsets_device(ks, order, d)
+            c1 = torch.zeros(64, dtype=torch.int32, device=d)
+            c2 = torch.zeros(64, dtype=torch.int32, device=d)
+            full = ops.kernel_map(maps.keys[lvl], maps.n_vox[lvl], maps.table(lvl), offs, c1, mirrored=False)
+            half = ops.kernel_map(maps.keys[lvl], maps.n_vox[lvl], maps.table(lvl), offs, c2, mirrored=True)
+            assert torch.equal(full, half), f"{order} level {lvl} k={ks}"
+            assert int(c1.sum()) == int(c2.sum()) == int((full >= 0).sum())
