@@ -125,7 +125,7 @@ def main():
     ap.add_argument("--query2d", type=int, default=300)
     ap.add_argument("--query-num", type=int, default=200)
     ap.add_argument("--scene-pool", type=int, default=2, help="distinct synthetic scenes per rank (cycled)")
-    ap.add_argument("--streams", type=int, default=3,
+    ap.add_argument("--streams", type=int, default=4,
                     help="scenes in flight per GPU (host threads x HIP streams, segdino3d_amd.dist_eval.PipelinedRunner)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
