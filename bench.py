@@ -118,8 +118,8 @@ def cpu_baseline(model, scene_args, n_timed=4):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=48)
+    ap.add_argument("--warmup", type=int, default=4)
     ap.add_argument("--points", type=int, default=150_000)
     ap.add_argument("--superpoints", type=int, default=3000)
     ap.add_argument("--query2d", type=int, default=300)
