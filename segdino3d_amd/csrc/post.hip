@@ -451,23 +451,33 @@ __global__ __launch_bounds__(256) void mask_overlaps_kernel(const uint8_t* __res
     for (int c = threadIdx.x; c < n_cols; c += 256) mo_hist[c] = 0;
     __syncthreads();
     const uint8_t* m = masks + (int64_t)row * mask_stride;
-    const bool vec = ((mask_stride & 15) == 0) && ((((uintptr_t)masks) & 15) == 0);
-    for (int64_t p = p_begin + (int64_t)threadIdx.x * 16; p < p_end; p += 256 * 16) {
-        uint32_t w[4] = {0, 0, 0, 0};
-        const int np = (int)min((int64_t)16, p_end - p);
-        if (vec && np == 16) {
-            const uint4 v = *(const uint4*)(m + p);
-            w[0] = v.x; w[1] = v.y; w[2] = v.z; w[3] = v.w;
-        } else {
-            for (int e = 0; e < np; ++e) w[e >> 2] |= (uint32_t)m[p + e] << (8 * (e & 3));
-        }
-        if ((w[0] | w[1] | w[2] | w[3]) == 0u) continue;
+    const bool vec = ((mask_stride & 15) == 0) && ((((uintptr_t)masks) & 15) == 0) && (p_end - p_begin == MO_CHUNK);
+    auto tally = [&](const uint32_t (&w)[4], int64_t p) {
+        if ((w[0] | w[1] | w[2] | w[3]) == 0u) return;
 #pragma unroll
         for (int e = 0; e < 16; ++e) {
             if ((w[e >> 2] >> (8 * (e & 3))) & 0xffu) {
                 const int g = gt_index[p + e];
                 if (g >= 0 && g < n_cols) atomicAdd(&mo_hist[g], 1);
             }
+        }
+    };
+    if (vec) {
+        // a full chunk: 4 x 16 bytes per thread, all four loads in flight before the first is looked at
+        uint4 v[MO_CHUNK / (256 * 16)];
+#pragma unroll
+        for (int u = 0; u < MO_CHUNK / (256 * 16); ++u) v[u] = *(const uint4*)(m + p_begin + (int64_t)(u * 256 + threadIdx.x) * 16);
+#pragma unroll
+        for (int u = 0; u < MO_CHUNK / (256 * 16); ++u) {
+            const uint32_t w[4] = {v[u].x, v[u].y, v[u].z, v[u].w};
+            tally(w, p_begin + (int64_t)(u * 256 + threadIdx.x) * 16);
+        }
+    } else {
+        for (int64_t p = p_begin + (int64_t)threadIdx.x * 16; p < p_end; p += 256 * 16) {
+            uint32_t w[4] = {0, 0, 0, 0};
+            const int np = (int)min((int64_t)16, p_end - p);
+            for (int e = 0; e < np; ++e) w[e >> 2] |= (uint32_t)m[p + e] << (8 * (e & 3));
+            tally(w, p);
         }
     }
     __syncthreads();
