@@ -110,3 +110,92 @@ def test_full_size_association_conserves_points():
         sel = rec.pair_pred == p
         for g_i, inter in zip(rec.pair_gt[sel], rec.pair_inter[sel]):
             assert int((row & (gt == int(rec.gt_id[g_i]))).sum()) == int(inter)
+
+
+def test_end_to_end_map_of_hip_path_equals_oracle_path():
+    """"Identical mAP": the whole HIP forward + device AP association against the whole oracle forward + numpy AP on
+    the same scene, weights and ground truth.  The ground truth is labelled from the ORACLE's own predictions, so the
+    classes that carry ground truth also carry predictions and any mask / score / label drift of the HIP path moves AP."""
+    import sys, os
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden"))
+    from oracle import eval_ref as E
+    from oracle import model_ref
+    from oracle import postprocess_ref as P
+    import segdino3d_amd as seg
+    from segdino3d_amd import eval_ap
+    from segdino3d_amd.configs import scannet200_model_cfg
+    from segdino3d_amd.synth import make_scene
+    d = dev()
+    pts, tgt = make_scene(21, n_points=8000, n_superpoints=64, n_query2d=8)
+    # iid-noise inputs and random weights give every superpoint the same features (and every mask the same points);
+    # give the scene structure instead: 2D features and colours are a per-superpoint embedding plus noise, and the mask
+    # branch is sharpened so that a prediction switches on a handful of superpoints (a few hundred points)
+    ef = tgt.extra_features
+    g = torch.Generator().manual_seed(5)
+    sp = ef["super_point_masks"]
+    ef["points_2dfeats"] = (torch.randn(64, 256, generator=g) * 2.0)[sp] + 0.1 * torch.randn(8000, 256, generator=g)
+    pts[:, 3:] = torch.randn(64, 3, generator=g)[sp]
+    cfg = scannet200_model_cfg(query_num=-1)
+    cfg["test_cfg"]["npoint_thr"] = 20
+    cfg["filter_outofbox_points_eval"] = False                            # random-weight boxes would empty every mask
+    torch.manual_seed(0)
+    model = seg.build_architecture(cfg).eval()
+    g2 = torch.Generator().manual_seed(1)
+    with torch.no_grad():
+        for m in model.modules():
+            if isinstance(m, torch.nn.BatchNorm1d):
+                m.running_mean.copy_(0.1 * torch.randn(m.num_features, generator=g2))
+                m.running_var.copy_(0.5 + torch.rand(m.num_features, generator=g2))
+        model.decoder.x_mask[2].weight.mul_(40.0)
+        model.decoder.x_mask[2].bias.zero_()
+    sd = {k: v.detach().clone() for k, v in model.state_dict().items()}
+    model.to(d)
+    model.to_host = False
+    with torch.no_grad():
+        pd = model([pts.to(d)], [tgt.to(d)])[0].pred_pts_seg
+    tgt = tgt.to("cpu")                                                  # .to() moves the target in place
+    ef = tgt.extra_features
+    ref = model_ref.forward_eval(sd, pts, ef["points_2dfeats"], ef["super_point_masks"], ef["query2d_feats"], ef["query2d_pos"],
+                                 tgt.masks, query_num=-1, test_cfg=P.TestCfg(npoint_thr=20), box_filter=False)
+    r_masks, r_labels, r_scores = ref["pts_instance_mask"][0].numpy().astype(bool), ref["instance_labels"].numpy(), ref["instance_scores"].numpy()
+    assert r_masks.shape[0] >= 10, "the scene must yield predictions for this test to mean anything"
+    # ground truth from the oracle's predictions
+    n_cls = 198
+    valid = tuple(range(2, 2 + n_cls))
+    class_labels = tuple(f"c{i}" for i in valid)
+    N = r_masks.shape[1]
+    # ground truth: the oracle's best predictions, greedily, each reduced to the points no earlier one took
+    inst = np.zeros(N, dtype=np.int64)
+    sem = np.zeros(N, dtype=np.int64)                                     # 0 = not a valid class -> void
+    taken = np.zeros(N, dtype=bool)
+    k = 0
+    for i in np.argsort(-r_scores, kind="stable"):
+        m = r_masks[i] & ~taken
+        if m.sum() >= 100 and m.sum() >= 0.5 * r_masks[i].sum():
+            k += 1
+            inst[m], sem[m] = k, valid[int(r_labels[i])]
+            taken |= m
+        if k == 10:
+            break
+    assert k >= 1, k
+    opts = dict(min_region_sizes=np.array([50]))
+    # oracle path
+    id_to_label = dict(zip(valid, class_labels))
+    preds = E.aggregate_predictions([r_masks], [r_labels], [r_scores], valid)
+    gts = E.rename_gt([sem], [inst], valid)
+    m_ref, _, _ = E.scannet_eval(preds, gts, opts, valid, class_labels, id_to_label)
+    # HIP path
+    m_hip = eval_ap.instance_seg_eval([torch.from_numpy(sem).to(d)], [torch.from_numpy(inst).to(d)], [pd.pts_instance_mask[0]],
+                                      [pd.instance_labels], [pd.instance_scores], valid, class_labels, options=opts, groups={})
+    assert m_ref["all_ap_25%"] > 0.05                                      # not a trivially-zero operating point
+    # prediction sets: every oracle prediction has a twin (same label, identical point mask) in the HIP output
+    h_masks = pd.pts_instance_mask[0].cpu().numpy().astype(bool)
+    h_labels = pd.instance_labels.cpu().numpy()
+    assert h_masks.shape == r_masks.shape
+    key = lambda lab, m: (int(lab), np.packbits(m).tobytes())  # noqa: E731
+    h_set = {key(l, m) for l, m in zip(h_labels, h_masks)}
+    twins = sum(key(l, m) in h_set for l, m in zip(r_labels, r_masks))
+    assert twins >= 0.99 * len(r_labels), f"{twins} of {len(r_labels)} oracle predictions found in the HIP output"
+    print("mAP oracle / HIP:", {k: (round(float(m_ref[k]), 5), round(float(m_hip[k]), 5)) for k in ("all_ap", "all_ap_50%", "all_ap_25%")})
+    for key in ("all_ap", "all_ap_50%", "all_ap_25%"):
+        assert abs(m_hip[key] - m_ref[key]) < 1e-3, (key, m_hip[key], m_ref[key])      # north star: mAP within +-0.1 points
