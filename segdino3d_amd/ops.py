@@ -93,7 +93,7 @@ class HostRead:
             return
         self.buf = torch.empty(dev_tensor.shape, dtype=dev_tensor.dtype, pin_memory=True)
         self.buf.copy_(dev_tensor, non_blocking=True)
-        self.event = torch.cuda.Event()
+        self.event = torch.cuda.Event(blocking=BLOCKING_EVENTS)
         self.event.record()
 
     def wait(self):
@@ -102,6 +102,9 @@ class HostRead:
         return self.buf
 
 
+# hipEventBlockingSync: a thread waiting for its scene sleeps instead of spinning on a core (8 ranks x 4 scene threads
+# share one host in the multi-GPU runs).  SD3D_SPIN_EVENTS=1 restores spinning waits.
+BLOCKING_EVENTS = _os.environ.get("SD3D_SPIN_EVENTS") != "1"
 BLOCKING_SYNC = _os.environ.get("SD3D_BLOCKING_SYNC") == "1"      # A/B switch: blocking .cpu() / event.synchronize()
 
 
@@ -156,7 +159,7 @@ def wait_event(ev):
 
 
 def stream_event():
-    ev = torch.cuda.Event()
+    ev = torch.cuda.Event(blocking=BLOCKING_EVENTS)
     ev.record()
     return ev
 
