@@ -260,6 +260,48 @@ int sd3d_instance_boxes(const float* points, int ld, int64_t N, const uint8_t* m
 int sd3d_mask_overlaps(const uint8_t* masks, int64_t mask_stride, int n, const int32_t* gt_index, int64_t N, int n_cols,
                        int32_t* counts, void* stream);
 
+/* ---------------------------------------------------------------------------------------------
+ * Training criterion, segdino3d/models/loss/loss_3d.py.  One (decoder layer, scene) per call.
+ * Shapes: cls [Q, n_cls1] (n_cls1 = instance classes + "no object"), masks [Q, S] logits over superpoints,
+ * scores [Q] / centers [Q,3] / sizes [Q,3] nullable; ground truth: labels [G] int64, masks as bit rows
+ * gt_bits [G, words] + gt_count [G] (sd3d_pack_mask_bits), gt_centers / gt_sizes [G, >=3] nullable,
+ * query_masks [G, Q] bytes nullable ("query q lies in object g", loss_3d.py:358). */
+
+/* bits[r][w] bit b = masks[r][32 w + b] != 0; counts[r] = set bits of the row (nullable). */
+int sd3d_pack_mask_bits(const uint8_t* masks, int64_t ld, int n_rows, int n_cols, uint32_t* bits, int words, int32_t* counts,
+                        void* stream);
+
+/* cost [Q, G] = w0 * QueryClassificationCost + w1 * MaskBCECost + w2 * MaskDiceCost + w3 * CenterL1Cost + w4 * SizeL1Cost
+ * (loss_3d.py:139-271 with the helpers :63-97); entries with query_masks[g][q] == 0 are 1e8 (SparseMatcher, :358-359).
+ * weights5 is a HOST array. */
+int sd3d_match_costs(const float* cls, int ld_cls, int n_cls1, const float* masks, int ld_masks, int Q, int S, const float* centers,
+                     const float* sizes, const int64_t* labels, const uint32_t* gt_bits, int words, const int32_t* gt_count, int G,
+                     const float* gt_centers, int ld_gc, const float* gt_sizes, int ld_gs, const uint8_t* query_masks,
+                     const float* weights5, float* cost, void* stream);
+
+/* SparseMatcher.__call__ (loss_3d.py:360-365): match[q][g] = cost[q][g] < (topk+1)-th smallest cost of column g. */
+int sd3d_sparse_match(const float* cost, int Q, int G, int topk, uint8_t* match, void* stream);
+
+/* InstanceCriterion's per-scene terms of one layer (loss_3d.py:459-503 / :618-663) for a given match [Q, G] (from
+ * sd3d_sparse_match, or scipy's linear_sum_assignment for the HungarianMatcher :311), and their gradients.
+ * parts8 (device) = [class CE, mask BCE, mask dice, score MSE, centre L1, size L1, matched pairs, scores kept];
+ * d_* = coef6[i] * d(parts[i]) / d(prediction): coef6 (HOST array) carries the loss weight and the batch-size factors
+ * of :505-521 / :665-679, so the d_* buffers are the gradients of the total loss.  d_cls [Q, n_cls1], d_masks [Q, S],
+ * d_scores [Q], d_centers / d_sizes [Q, 3] are fully overwritten (the nullable ones only when their prediction is given). */
+size_t sd3d_instance_loss_ws_bytes(int Q);
+int sd3d_instance_loss(const float* cls, int ld_cls, int n_cls1, const float* masks, int ld_masks, int Q, int S, const float* scores,
+                       const float* centers, const float* sizes, const int64_t* labels, const uint32_t* gt_bits, int words,
+                       const int32_t* gt_count, int G, const float* gt_centers, int ld_gc, const float* gt_sizes, int ld_gs,
+                       const uint8_t* match, const float* class_weight, const float* coef6, float* d_cls, float* d_masks,
+                       float* d_scores, float* d_centers, float* d_sizes, float* parts8, void* ws, size_t ws_bytes, void* stream);
+
+/* ScanNetSemanticCriterion for one scene (loss_3d.py:37-60): sem [Q, ld] logits of which the first n_logits count,
+ * sem_masks [n_rows, Q] bytes (target = first set row, 0 if none), rows with target == ignore_index are skipped.
+ * loss[0] = mean NLL; d_sem [Q, ld_d] = coef * d loss / d sem (columns >= n_logits are zeroed). */
+size_t sd3d_semantic_loss_ws_bytes(int Q);
+int sd3d_semantic_loss(const float* sem, int ld, int Q, int n_rows, int n_logits, const uint8_t* sem_masks, int ignore_index, float coef,
+                       float* d_sem, int ld_d, float* loss, void* ws, size_t ws_bytes, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -70,6 +70,14 @@ SIGNATURES = {
     "sd3d_mask_overlaps": (_i, [_p, _l, _i, _p, _l, _i, _p, _p]),
     "sd3d_instance_boxes_ws_bytes": (_z, [_i]),
     "sd3d_instance_boxes": (_i, [_p, _i, _l, _p, _l, _i, _i, _p, _p, _p, _z, _p]),
+    "sd3d_pack_mask_bits": (_i, [_p, _l, _i, _i, _p, _i, _p, _p]),
+    "sd3d_match_costs": (_i, [_p, _i, _i, _p, _i, _i, _i, _p, _p, _p, _p, _i, _p, _i, _p, _i, _p, _i, _p, _p, _p, _p]),
+    "sd3d_sparse_match": (_i, [_p, _i, _i, _i, _p, _p]),
+    "sd3d_instance_loss_ws_bytes": (_z, [_i]),
+    "sd3d_instance_loss": (_i, [_p, _i, _i, _p, _i, _i, _i, _p, _p, _p, _p, _p, _i, _p, _i, _p, _i, _p, _i, _p, _p, _p, _p, _p, _p, _p, _p,
+                                _p, _p, _z, _p]),
+    "sd3d_semantic_loss_ws_bytes": (_z, [_i]),
+    "sd3d_semantic_loss": (_i, [_p, _i, _i, _i, _i, _p, _i, _f, _p, _i, _p, _p, _z, _p]),
 }
 
 

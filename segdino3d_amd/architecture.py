@@ -40,17 +40,7 @@ except Exception:  # noqa: BLE001
             return k in self.__dict__
 
 
-if LOSSES.get("ScanNetUnifiedCriterion") is None:
-    @LOSSES.register_module()
-    class ScanNetUnifiedCriterion:
-        """Config-surface placeholder: the shipped configs name this criterion (`configs/models/base_3d.py:37-55`).
-        The training step (loss + matcher + backward) is SURVEY.md 8(f-1), not built yet."""
-
-        def __init__(self, **cfg):
-            self.cfg = cfg
-
-        def __call__(self, *a, **k):
-            raise NotImplementedError("segdino3d_amd: the training criterion (SURVEY.md 8(f-1)) is not built; eval-mode forward only")
+from . import criterion as _criterion  # noqa: E402,F401 - registers ScanNetUnifiedCriterion
 
 
 def _cfg_get(cfg, key, default=None):
@@ -152,8 +142,9 @@ class Baseline3D(nn.Module):
     @ops.bound_stream
     def forward(self, samples, targets: List = None):
         if self.training:
-            raise NotImplementedError("segdino3d_amd: eval-mode forward only; the training step (criterion + backward, "
-                                      "SURVEY.md 8(f-1)) is not built")
+            raise NotImplementedError("segdino3d_amd: eval-mode forward only; of the training step (SURVEY.md 8(f-1)) the criterion "
+                                      "(`model.criterion(outputs, targets)`) and the sparse-convolution backward are built, the "
+                                      "backward of the decoder is not")
         samples = [s.float().contiguous() for s in samples]
         scene_range = self.get_extra_instance_data(samples, targets, self.add_positional_embedding,
                                                    self.decoder.add_box_size_pred)
