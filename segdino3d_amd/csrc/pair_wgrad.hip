@@ -1,0 +1,225 @@
+// Weight gradient of the pair-major sparse convolution (training step):
+//     dW[k][co][ci] = sum over the pairs p of offset k of  dY[out_row(p)][co] * X[in_idx(p)][ci]
+// i.e. one [Cout x P_k] x [P_k x Cin] GEMM per kernel offset whose contraction runs over the rulebook's pairs - the
+// transpose of what MinkowskiEngine / spconv compute with their gather-GEMM-scatter backward (third-party, not in the
+// reference tree; the reference reaches it through autograd, train_engine_3d.py:88-122).  The input gradient needs no
+// kernel of its own: it is the forward pair_conv on the transposed rulebook (see ops.pair_conv_backward).
+//
+// Work split: the offset-major pair list (pair_gemm.hip) is cut into balanced contiguous tile ranges, one per
+// blockIdx.x; a workgroup accumulates a [<=128 x <=128] block of dW in MFMA accumulators (v_mfma_f32_32x32x2_f32: exact
+// fp32, the contraction index of the instruction IS the pair index) over the 32-pair steps of its range, staging the
+// gathered dY / X rows through LDS with dwordx4 loads.  Whenever the offset changes inside a range - and at its end - the
+// block goes to a partial slot; slots are numbered in list order (range index + offset changes before it), so the slots
+// of one offset are contiguous and pass 2 adds them up in a fixed order: bit-reproducible, no atomics.
+#include "common.h"
+#include "../../include/segdino3d_hip.h"
+
+#define PT 128                       // pairs per tile of the pair lists
+#define WG_STEP 32                   // pairs staged per step
+
+struct WGParams {
+    const float* dy; int ld_dy; const float* x; int ld_x;
+    const int32_t* in_idx; const int32_t* out_idx; const int32_t* tile_k; int n_tiles;
+    int Cin, Cout;
+    float* wpart; int32_t* slot_k; int n_slots;
+};
+
+__global__ __launch_bounds__(256) void pair_out_rows_kernel(const int32_t* __restrict__ pos, int K, int64_t M, int32_t* __restrict__ out_idx) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= (int64_t)K * M) return;
+    const int p = pos[i];
+    if (p >= 0) out_idx[p] = (int32_t)(i % M);
+}
+
+template <int NCO, int NCI>
+__global__ __launch_bounds__(256) void pair_wgrad_kernel(const WGParams p) {
+    constexpr int TCO = NCO * 32, TCI = NCI * 32;
+    constexpr int LDA = (TCO % 64) ? TCO : TCO + 32;           // row stride = 32 mod 64 floats: the two pair rows an MFMA reads sit in different bank halves
+    constexpr int LDB = (TCI % 64) ? TCI : TCI + 32;
+    constexpr int NT = NCO * NCI;                              // 32 x 32 output tiles of the block
+    constexpr int TPW = (NT + 3) / 4;                          // tiles per wave
+    constexpr int A4 = WG_STEP * TCO / 4, B4 = WG_STEP * TCI / 4;      // float4 pieces per step
+    constexpr int NA = (A4 + 255) / 256, NB = (B4 + 255) / 256;
+    __shared__ __attribute__((aligned(16))) float As[WG_STEP * LDA];
+    __shared__ __attribute__((aligned(16))) float Bs[WG_STEP * LDB];
+    __shared__ int red[4];
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int n_real = p.tile_k[p.n_tiles];
+    const int t0 = (int)((int64_t)blockIdx.x * n_real / gridDim.x);
+    const int t1 = (int)((int64_t)(blockIdx.x + 1) * n_real / gridDim.x);
+    if (t1 <= t0) return;
+    const int co0 = blockIdx.y * TCO, ci0 = blockIdx.z * TCI;
+    // slot of the first run = range index + offset changes in tiles (0, t0]
+    int changes = 0;
+    for (int t = 1 + tid; t <= t0; t += 256) changes += p.tile_k[t] != p.tile_k[t - 1];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) changes += __shfl_xor(changes, o, 64);
+    if (lane == 0) red[wv] = changes;
+    __syncthreads();
+    int slot = blockIdx.x + red[0] + red[1] + red[2] + red[3];
+
+    f32x16 acc[TPW];
+#pragma unroll
+    for (int i = 0; i < TPW; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+
+    // float4 piece f of a step: pair row f / (T/4), column piece f % (T/4)
+    f32x4 ra[NA], rb[NB];
+    auto fetch = [&](int tile, int sub) {
+        const int64_t pb = (int64_t)tile * PT + sub * WG_STEP;
+#pragma unroll
+        for (int u = 0; u < NA; ++u) {
+            const int f = u * 256 + tid;
+            f32x4 v = {0.f, 0.f, 0.f, 0.f};
+            if (f < A4) {
+                const int row = f / (TCO / 4), c4 = f % (TCO / 4);
+                const int r = p.out_idx[pb + row];
+                if (r >= 0 && co0 + c4 * 4 < p.Cout) v = *(const f32x4*)(p.dy + (int64_t)r * p.ld_dy + co0 + c4 * 4);
+            }
+            ra[u] = v;
+        }
+#pragma unroll
+        for (int u = 0; u < NB; ++u) {
+            const int f = u * 256 + tid;
+            f32x4 v = {0.f, 0.f, 0.f, 0.f};
+            if (f < B4) {
+                const int row = f / (TCI / 4), c4 = f % (TCI / 4);
+                const int r = p.in_idx[pb + row];
+                if (r >= 0 && ci0 + c4 * 4 < p.Cin) v = *(const f32x4*)(p.x + (int64_t)r * p.ld_x + ci0 + c4 * 4);
+            }
+            rb[u] = v;
+        }
+    };
+    auto stage = [&]() {
+#pragma unroll
+        for (int u = 0; u < NA; ++u) {
+            const int f = u * 256 + tid;
+            if (f < A4) *(f32x4*)(As + (f / (TCO / 4)) * LDA + (f % (TCO / 4)) * 4) = ra[u];
+        }
+#pragma unroll
+        for (int u = 0; u < NB; ++u) {
+            const int f = u * 256 + tid;
+            if (f < B4) *(f32x4*)(Bs + (f / (TCI / 4)) * LDB + (f % (TCI / 4)) * 4) = rb[u];
+        }
+    };
+    auto flush = [&](int k) {
+        float* dst = p.wpart + (int64_t)slot * p.Cout * p.Cin;
+#pragma unroll
+        for (int i = 0; i < TPW; ++i) {
+            const int t = wv + 4 * i;
+            if (t < NT) {
+                const int co = co0 + (t / NCI) * 32, ci = ci0 + (t % NCI) * 32 + (lane & 31);
+                if (ci < p.Cin) {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int row = co + 8 * (r >> 2) + 4 * (lane >> 5) + (r & 3);
+                        if (row < p.Cout) dst[(int64_t)row * p.Cin + ci] = acc[i][r];
+                        acc[i][r] = 0.f;
+                    }
+                }
+            }
+        }
+        if (tid == 0 && blockIdx.y == 0 && blockIdx.z == 0) p.slot_k[slot] = k;
+        ++slot;
+    };
+
+    int cur_k = p.tile_k[t0];
+    fetch(t0, 0);
+    for (int tile = t0; tile < t1; ++tile) {
+        const int k = p.tile_k[tile];
+        if (k != cur_k) { flush(cur_k); cur_k = k; }
+        for (int sub = 0; sub < PT / WG_STEP; ++sub) {
+            __syncthreads();                                   // the previous step's MFMAs have read LDS
+            stage();
+            __syncthreads();
+            // next step's rows travel while this one multiplies
+            if (sub + 1 < PT / WG_STEP) fetch(tile, sub + 1);
+            else if (tile + 1 < t1) fetch(tile + 1, 0);
+#pragma unroll
+            for (int s = 0; s < WG_STEP / 2; ++s) {
+                const float* ar = As + (2 * s + (lane >> 5)) * LDA + (lane & 31);
+                const float* br = Bs + (2 * s + (lane >> 5)) * LDB + (lane & 31);
+#pragma unroll
+                for (int i = 0; i < TPW; ++i) {
+                    const int t = wv + 4 * i;
+                    if (t < NT) acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(ar[(t / NCI) * 32], br[(t % NCI) * 32], acc[i], 0, 0, 0);
+                }
+            }
+        }
+    }
+    flush(cur_k);
+}
+
+// pass 2: dW[k] (+)= sum of the slots of offset k, in slot order
+__global__ __launch_bounds__(256) void pair_wgrad_reduce_kernel(const float* __restrict__ wpart, const int32_t* __restrict__ slot_k, int n_slots,
+                                                                int64_t elems, float* __restrict__ dw, int accumulate) {
+    __shared__ int s_first, s_last;
+    const int k = blockIdx.y;
+    if (threadIdx.x == 0) { s_first = n_slots; s_last = -1; }
+    __syncthreads();
+    for (int s = threadIdx.x; s < n_slots; s += 256)
+        if (slot_k[s] == k) { atomicMin(&s_first, s); atomicMax(&s_last, s); }
+    __syncthreads();
+    const int first = s_first, last = s_last;
+    for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < elems; e += (int64_t)gridDim.x * 256) {
+        float a = 0.f;
+        for (int s = first; s <= last; ++s)
+            if (slot_k[s] == k) a += wpart[(int64_t)s * elems + e];
+        float* d = dw + (int64_t)k * elems + e;
+        *d = accumulate ? *d + a : a;
+    }
+}
+
+static int wgrad_ranges(int Cin, int Cout) {
+    const int blocks = (int)(cdiv(Cout, 128) * cdiv(Cin, 128));
+    int r = 768 / blocks;
+    return r < 32 ? 32 : r;
+}
+
+#define ST ((hipStream_t)stream)
+extern "C" {
+
+int sd3d_pair_out_rows(const int32_t* pos, int K, int64_t M, int64_t p_cap, int32_t* out_idx, void* stream) {
+    if (K <= 0 || M <= 0) return SD3D_OK;
+    if (hipMemsetAsync(out_idx, 0xFF, (size_t)p_cap * sizeof(int32_t), ST) != hipSuccess) return sd3d_set_error(SD3D_ERR_LAUNCH, "pair_out_rows: memset failed");
+    pair_out_rows_kernel<<<(unsigned)cdiv((int64_t)K * M, 256), 256, 0, ST>>>(pos, K, M, out_idx);
+    SD3D_CHECK_LAUNCH();
+    return SD3D_OK;
+}
+
+size_t sd3d_pair_wgrad_ws_bytes(int K, int Cin, int Cout) {
+    const size_t slots = (size_t)wgrad_ranges(Cin, Cout) + K;
+    return align_up(slots * sizeof(int32_t), 256) + slots * (size_t)Cin * Cout * sizeof(float);
+}
+
+int sd3d_pair_wgrad(const float* dy, int ld_dy, const float* x, int ld_x, const int32_t* in_idx, const int32_t* out_idx,
+                    const int32_t* tile_k, int64_t p_cap, int K, int Cin, int Cout, float* dw, int accumulate, void* ws, size_t ws_bytes,
+                    void* stream) {
+    if (K <= 0 || Cin <= 0 || Cout <= 0) return SD3D_OK;
+    if ((Cin & 3) || (Cout & 3) || (ld_dy & 3) || (ld_x & 3)) return sd3d_set_error(SD3D_ERR_ARG, "pair_wgrad: channel counts and row strides must be multiples of 4");
+    if (p_cap <= 0 || (p_cap % PT)) return sd3d_set_error(SD3D_ERR_ARG, "pair_wgrad: p_cap must be a positive multiple of 128");
+    if (ws_bytes < sd3d_pair_wgrad_ws_bytes(K, Cin, Cout)) return sd3d_set_error(SD3D_ERR_WS, "pair_wgrad: workspace too small");
+    const int ranges = wgrad_ranges(Cin, Cout);
+    WGParams p;
+    p.dy = dy; p.ld_dy = ld_dy; p.x = x; p.ld_x = ld_x; p.in_idx = in_idx; p.out_idx = out_idx; p.tile_k = tile_k;
+    p.n_tiles = (int)(p_cap / PT); p.Cin = Cin; p.Cout = Cout;
+    p.n_slots = ranges + K;
+    p.slot_k = (int32_t*)ws;
+    p.wpart = (float*)((char*)ws + align_up((size_t)p.n_slots * sizeof(int32_t), 256));
+    if (hipMemsetAsync(p.slot_k, 0xFF, (size_t)p.n_slots * sizeof(int32_t), ST) != hipSuccess) return sd3d_set_error(SD3D_ERR_LAUNCH, "pair_wgrad: memset failed");
+    const int nco = Cout >= 128 ? 4 : (Cout + 31) / 32, nci = Cin >= 128 ? 4 : (Cin + 31) / 32;
+    const dim3 grid(ranges, (unsigned)cdiv(Cout, nco * 32), (unsigned)cdiv(Cin, nci * 32));
+#define WG_CASE(a, b) if (nco == a && nci == b) pair_wgrad_kernel<a, b><<<grid, 256, 0, ST>>>(p);
+    WG_CASE(1, 1) WG_CASE(1, 2) WG_CASE(1, 3) WG_CASE(1, 4)
+    WG_CASE(2, 1) WG_CASE(2, 2) WG_CASE(2, 3) WG_CASE(2, 4)
+    WG_CASE(3, 1) WG_CASE(3, 2) WG_CASE(3, 3) WG_CASE(3, 4)
+    WG_CASE(4, 1) WG_CASE(4, 2) WG_CASE(4, 3) WG_CASE(4, 4)
+#undef WG_CASE
+    const int64_t elems = (int64_t)Cin * Cout;
+    pair_wgrad_reduce_kernel<<<dim3((unsigned)(cdiv(elems, 256) < 64 ? cdiv(elems, 256) : 64), K), 256, 0, ST>>>(p.wpart, p.slot_k, p.n_slots, elems, dw, accumulate);
+    SD3D_CHECK_LAUNCH();
+    return SD3D_OK;
+}
+
+}  // extern "C"

@@ -400,10 +400,11 @@ def clear_split_cache():
 
 class PairLists:
     """Offset-major layout of one neighbour table (csrc/pair_gemm.hip): shared by every convolution that uses it."""
-    __slots__ = ("pos", "in_idx", "tile_k", "p_cap", "K", "M")
+    __slots__ = ("pos", "in_idx", "tile_k", "p_cap", "K", "M", "out_idx")
 
     def __init__(self, pos, in_idx, tile_k, p_cap, K, M):
         self.pos, self.in_idx, self.tile_k, self.p_cap, self.K, self.M = pos, in_idx, tile_k, p_cap, K, M
+        self.out_idx = None                               # output row of every pair; built on demand (train_ops.pair_out_rows)
 
 
 def pair_lists(nbr, n_pairs):

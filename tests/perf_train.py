@@ -1,0 +1,87 @@
+"""f-1 measurement (lives under tests/ because it times the oracle): the device criterion and the sparse-convolution
+backward at training size, next to the oracle / a torch CPU model on the host cores.
+  criterion: ScanNet200 training shape - 2250 queries (query_thr 0.5-1.0 of 3000 superpoints), 120 objects, 199 class
+             logits, 7 prediction sets (initial + 6 decoder layers), sparse matcher with box costs;
+  conv backward: the U-Net's layer shapes on a 150 k-point scene: forward, input gradient, weight gradient."""
+import json, os, sys, time
+import torch
+sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", "/root/repo"))
+from segdino3d_amd import ops, train_ops
+from segdino3d_amd.sparse import SceneMaps
+from segdino3d_amd.synth import make_scene
+from oracle import loss_ref
+from tests.loss_cases import as_pred
+from tests.test_gpu_criterion import _training_size_case, build
+
+d = torch.device("cuda:0")
+out = {}
+
+
+def timeit(fn, reps):
+    for _ in range(2):
+        fn()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(reps):
+        fn()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / reps
+
+
+# ---------------------------------------------------------------- criterion
+Q, S, G, n_cls, n_sem = 2250, 3000, 120, 198, 200
+t, layers = _training_size_case(5, Q, S, G, n_cls, n_sem, n_layers=7)
+cfg = dict(matcher="sparse", topk=1, cost_weights=[0.5, 1.0, 1.0, 0.5, 0.5], loss_weight=[0.5, 1.0, 1.0, 0.5, 0.5, 0.5], num_classes=n_cls,
+           num_semantic_classes=n_sem, sem_ignore_index=n_sem, sem_loss_weight=0.5, non_object_weight=0.1, fix_dice_loss_weight=True,
+           iter_matcher=True, fix_mean_loss=True)
+crit = build(cfg)
+t_d = {k: v.to(d) for k, v in t.items()}
+l_d = [{k: [None if v is None else v.to(d).requires_grad_(True) for v in lst] for k, lst in layer.items()} for layer in layers]
+pred = as_pred(l_d)
+
+
+def step_dev():
+    o = crit(pred, [t_d])
+    (o["seg_loss"] + o["inst_loss"]).backward()
+
+
+ms_dev = timeit(step_dev, 10)
+l_c = [{k: [None if v is None else v.clone().requires_grad_(True) for v in lst] for k, lst in layer.items()} for layer in layers]
+torch.set_num_threads(int(os.environ.get("SD3D_CPU_THREADS", "32")))
+t0 = time.perf_counter()
+o = loss_ref.unified_criterion(as_pred(l_c), [t], cfg)
+(o["seg_loss"] + o["inst_loss"]).backward()
+s_cpu = time.perf_counter() - t0
+bytes_alg = 7 * (Q * S * 4 * 3)                     # logits read by the cost pass and the loss pass, gradient written
+out["criterion"] = dict(ms_device=round(ms_dev, 3), s_cpu_oracle=round(s_cpu, 2), cpu_threads=torch.get_num_threads(),
+                        shape=f"Q={Q} S={S} G={G} classes={n_cls + 1} layers=7", algorithmic_GBps=round(bytes_alg / ms_dev / 1e6, 1))
+
+# ---------------------------------------------------------------- sparse convolution backward
+pts, tgt = make_scene(0, 150000, 3000, 300)
+maps = SceneMaps(pts.to(d), 0.02, 5, superpoints=tgt.extra_features["super_point_masks"].to(d))
+maps.prepare(same=[(0, 5)] + [(l, 3) for l in range(5)], strides=[0, 1, 2, 3])
+g = torch.Generator().manual_seed(0)
+rows = []
+for key, cin, cout in [(("same", 0, 3), 96, 96), (("same", 1, 3), 96, 96), (("same", 2, 3), 128, 128), (("same", 3, 3), 256, 256),
+                       (("same", 4, 3), 256, 256), (("down", 0), 32, 32), (("up", 2), 256, 128)]:
+    tab = maps.conv_table(*key)
+    nbr, pairs = tab["nbr"], tab["pairs"]
+    pairs_t = pairs if key[0] == "same" else maps.conv_table("up" if key[0] == "down" else "down", key[1])["pairs"]
+    K, M = nbr.shape
+    n_in = int(nbr.max().item()) + 1
+    x = torch.randn(n_in, cin, generator=g).to(d)
+    w = (torch.randn(K, cout, cin, generator=g) * (K * cin) ** -0.5).to(d)
+    dy = torch.randn(M, cout, generator=g).to(d)
+    wt = train_ops.transposed_weights(w, key[0] == "same")
+    P = int((pairs.in_idx >= 0).sum())
+    fl = 2.0 * P * cin * cout
+    us_f = 1e3 * timeit(lambda: ops.pair_conv(x, w, pairs), 5)
+    us_dx = 1e3 * timeit(lambda: ops.pair_conv(dy, wt, pairs_t), 5)
+    us_dw = 1e3 * timeit(lambda: train_ops.pair_wgrad(dy, x, pairs), 5)
+    rows.append(dict(layer=f"{key} {cin}->{cout}", pairs=P, fwd_us=round(us_f), dgrad_us=round(us_dx), wgrad_us=round(us_dw),
+                     fwd_TF=round(fl / us_f / 1e6, 1), dgrad_TF=round(fl / us_dx / 1e6, 1), wgrad_TF=round(fl / us_dw / 1e6, 1)))
+out["sparse_conv_backward"] = rows
+print(json.dumps(out, indent=1))
+os.makedirs("gpurun_out", exist_ok=True)
+json.dump(out, open("gpurun_out/perf_train.json", "w"), indent=1)
