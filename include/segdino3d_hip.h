@@ -315,6 +315,28 @@ int sd3d_pair_wgrad(const float* dy, int ld_dy, const float* x, int ld_x, const 
                     const int32_t* tile_k, int64_t p_cap, int K, int Cin, int Cout, float* dw, int accumulate, void* ws, size_t ws_bytes,
                     void* stream);
 
+/* ---------------------------------------------------------------------------------------------
+ * Training-mode BatchNorm over voxel rows (ME.MinkowskiBatchNorm = nn.BatchNorm1d, minkunet.py:302-304) with the
+ * BasicBlock's residual add and ReLU folded in (:234-250), and the backward of sd3d_pool_superpoints (:668-676).
+ * x, y, dy, dx, res, dres are [M, C] fp32 with row strides in floats; act: 0 none, 1 relu.
+ *   sd3d_bn_stats:    mean[c], var[c] (biased), rstd[c] = 1 / sqrt(var + eps) over the M rows
+ *   sd3d_bn_apply:    y = act((x - mean) * rstd * gamma + beta + res)            (res nullable)
+ *   sd3d_bn_backward: g = dy masked by y > 0 when act == relu; dbeta = sum g; dgamma = sum g * xhat;
+ *                     dx = gamma * rstd * (g - dbeta / M - xhat * dgamma / M); dres = g (nullable)
+ * Reductions run in a fixed order (bit-reproducible).  ws: sd3d_bn_ws_bytes(M, C). */
+size_t sd3d_bn_ws_bytes(int64_t M, int C);
+int sd3d_bn_stats(const float* x, int ld, int64_t M, int C, float eps, float* mean, float* var, float* rstd, void* ws, size_t ws_bytes,
+                  void* stream);
+int sd3d_bn_apply(const float* x, int ld_x, const float* mean, const float* rstd, const float* gamma, const float* beta, const float* res,
+                  int ld_res, int64_t M, int C, int act, float* y, int ld_y, void* stream);
+int sd3d_bn_backward(const float* dy, int ld_dy, const float* y, int ld_y, const float* x, int ld_x, const float* mean, const float* rstd,
+                     const float* gamma, int64_t M, int C, int act, float* dx, int ld_dx, float* dres, int ld_dres, float* dgamma,
+                     float* dbeta, void* ws, size_t ws_bytes, void* stream);
+/* dfeat[v] = sum over the points p of voxel v (sidx[seg_start[v] .. seg_start[v+1])) of dout[sp[p]] / max(|sp[p]|, 1),
+ * with |s| = sp_start[s+1] - sp_start[s]; dout [S, C], C <= 128. */
+int sd3d_pool_superpoints_backward(const float* dout, int C, const int64_t* superpoints, const uint32_t* sidx, const int32_t* seg_start,
+                                   const int32_t* sp_start, int64_t V, float* dfeat, int ld, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -110,9 +110,15 @@ def downsample_coords(coords: np.ndarray, new_stride: int) -> np.ndarray:
     return unique_voxels(c.astype(np.int32))[0]
 
 
+BN_TRAIN = False    # tests of the training step switch the BatchNorms to batch statistics (biased variance)
+
+
 def bn_eval(x, sd, name, eps):
     w, b = sd[name + ".weight"], sd[name + ".bias"]
-    m, v = sd[name + ".running_mean"], sd[name + ".running_var"]
+    if BN_TRAIN:
+        m, v = x.mean(dim=0), x.var(dim=0, unbiased=False)
+    else:
+        m, v = sd[name + ".running_mean"], sd[name + ".running_var"]
     return (x - m) / torch.sqrt(v + eps) * w + b
 
 

@@ -171,6 +171,21 @@ class Res16UNetBase(nn.Module):
             self._packed = pk
         return self._packed
 
+    def packed_train(self):
+        """name -> [K, Cout, Cin] autograd view of the live convolution parameter / the nn.BatchNorm1d module: what
+        `_network` runs on with train_ops.TrainBackend (training step)."""
+        pk = {}
+        for n, m in self.named_modules():
+            if isinstance(m, MinkConv):
+                w = m.kernel if m.kernel.dim() == 3 else m.kernel.unsqueeze(0)
+                w = w.permute(0, 2, 1)
+                if n == "conv0p1s1" and _round32(self.in_channels) > w.shape[2]:
+                    w = torch.nn.functional.pad(w, (0, _round32(self.in_channels) - w.shape[2]))
+                pk[n] = w.contiguous()
+            elif isinstance(m, MinkBN):
+                pk[n] = m.bn
+        return pk
+
     # ---- network ---------------------------------------------------------------------------------
     def _cbr(self, be, pk, x, conv, bn, key, x2=None):
         return be.conv(x, pk[conv], pk[bn], key, x2=x2, act="relu")
@@ -215,11 +230,12 @@ class Res16UNetBase(nn.Module):
 
     def forward_sparse(self, maps: SceneMaps, vox_feats: torch.Tensor) -> torch.Tensor:
         """`Res16UNetBase.forward` (`minkunet.py:531-601`): [V0, Cin_padded] -> [V0, 96]."""
-        if self.training:
-            raise NotImplementedError("segdino3d_amd backbone: eval-mode forward only (training step not built)")
-        pk = self.packed()
         k1 = self.conv1_kernel_size
         maps.prepare(same=[(0, k1)] + [(l, 3) for l in range(5)], strides=[0, 1, 2, 3])
+        if self.training:                                        # batch-statistics BatchNorm, autograd nodes over HIP kernels
+            from . import train_ops
+            return self._network(train_ops.TrainBackend(maps), self.packed_train(), vox_feats)
+        pk = self.packed()
         if plan.USE_PLAN and ops.PAIR_CONV and ops.GEMM_MODE is None and ops.GG_FORCE_NT is None and ops.GG_HOOK is None:
             if self._plan is None:                               # one C call per scene instead of ~110
                 rec = plan.Recorder(vox_feats.shape[1])
@@ -244,7 +260,11 @@ class Res16UNetBase(nn.Module):
             self.last_maps = maps
             vf = maps.voxel_features(pts, f2d, mode, _round32(self.in_channels))
             x = self.forward_sparse(maps, vf)
-            f, p = maps.pool(x, self.out_planes)
+            if self.training:
+                from . import train_ops
+                f, p = train_ops.pool_superpoints(x, maps, self.out_planes)
+            else:
+                f, p = maps.pool(x, self.out_planes)
             feats.append(f)
             pos.append(p)
         sp_pos = pos if self.add_positional_embedding else None

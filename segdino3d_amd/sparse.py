@@ -103,6 +103,7 @@ class SceneMaps:
             counts.append(nl)
             parents.append(parent)
         extra = [err]
+        self.superpoints = superpoints                    # int64 id per point (kept for the pooling backward, train_ops)
         if superpoints is not None:
             sp_keys = ops.keys_from_i64(superpoints)
             self.sp_sorted, self.sp_sidx = ops.sort_pairs(sp_keys, None, 0, 32)

@@ -90,3 +90,130 @@ def sparse_conv(x, w, maps, kind: str, level: int, ksize: int = 3):
         return SparseConv.apply(x, w, t["pairs"], t["pairs"], True)
     other = "up" if kind == "down" else "down"
     return SparseConv.apply(x, w, maps.conv_table(kind, level)["pairs"], maps.conv_table(other, level)["pairs"], False)
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# Training-mode BatchNorm (+ residual + ReLU) and the superpoint pooling, as autograd nodes over csrc/train.hip
+# ------------------------------------------------------------------------------------------------------------------
+_WS_BN = ops._PerThread()
+
+
+class _BatchNormAct(torch.autograd.Function):
+    """y = act(BN_batch(x) + res) for x [M, C] (`minkunet.py:234-250, 302-304`); returns (y, mean, biased var)."""
+
+    @staticmethod
+    def forward(ctx, x, gamma, beta, res, act, eps):
+        lib = _lib.load()
+        px, ldx = ops._rows(x, "x")
+        M, C = x.shape
+        dev = x.device
+        mean, var, rstd = (torch.empty(C, dtype=torch.float32, device=dev) for _ in range(3))
+        nb = lib.sd3d_bn_ws_bytes(M, C)
+        ws = _WS_BN.get(nb, dev)
+        _lib.check(lib.sd3d_bn_stats(px, ldx, M, C, float(eps), mean.data_ptr(), var.data_ptr(), rstd.data_ptr(), ws.data_ptr(), ws.numel(),
+                                     ops._stream()), "bn_stats")
+        y = torch.empty(M, C, dtype=torch.float32, device=dev)
+        pr, ldr = ops._rows(res, "res") if res is not None else (None, 0)
+        g, b = gamma.detach().float().contiguous(), beta.detach().float().contiguous()
+        _lib.check(lib.sd3d_bn_apply(px, ldx, mean.data_ptr(), rstd.data_ptr(), g.data_ptr(), b.data_ptr(), pr, ldr, M, C, ops.ACT[act],
+                                     y.data_ptr(), C, ops._stream()), "bn_apply")
+        ctx.save_for_backward(x, y, mean, rstd, g)
+        ctx.act, ctx.has_res = act, res is not None
+        ctx.mark_non_differentiable(mean, var)
+        return y, mean, var
+
+    @staticmethod
+    def backward(ctx, dy, _dm, _dv):
+        lib = _lib.load()
+        x, y, mean, rstd, g = ctx.saved_tensors
+        M, C = x.shape
+        dev = x.device
+        dy = dy.contiguous()
+        dx = torch.empty(M, C, dtype=torch.float32, device=dev)
+        dres = torch.empty(M, C, dtype=torch.float32, device=dev) if ctx.has_res else None
+        dgamma, dbeta = torch.empty(C, dtype=torch.float32, device=dev), torch.empty(C, dtype=torch.float32, device=dev)
+        px, ldx = ops._rows(x, "x")
+        nb = lib.sd3d_bn_ws_bytes(M, C)
+        ws = _WS_BN.get(nb, dev)
+        _lib.check(lib.sd3d_bn_backward(dy.data_ptr(), C, y.data_ptr(), C, px, ldx, mean.data_ptr(), rstd.data_ptr(), g.data_ptr(), M, C,
+                                        ops.ACT[ctx.act], dx.data_ptr(), C, None if dres is None else dres.data_ptr(), C, dgamma.data_ptr(),
+                                        dbeta.data_ptr(), ws.data_ptr(), ws.numel(), ops._stream()), "bn_backward")
+        return dx, dgamma, dbeta, dres, None, None
+
+
+def batch_norm_act(x, bn: "torch.nn.BatchNorm1d", res=None, act=None):
+    """Training-mode BatchNorm1d over the rows of x with the residual add and activation folded in; updates the
+    module's running statistics like nn.BatchNorm1d (momentum, unbiased variance)."""
+    y, mean, var = _BatchNormAct.apply(x, bn.weight, bn.bias, res, act, bn.eps)
+    if bn.track_running_stats and bn.running_mean is not None:
+        with torch.no_grad():
+            m = x.shape[0]
+            mom = bn.momentum if bn.momentum is not None else 1.0 / float(bn.num_batches_tracked + 1)
+            bn.running_mean.mul_(1 - mom).add_(mean, alpha=mom)
+            bn.running_var.mul_(1 - mom).add_(var * (m / max(m - 1, 1)), alpha=mom)
+            bn.num_batches_tracked += 1
+    return y
+
+
+class _PoolSuperpoints(torch.autograd.Function):
+    """SceneMaps.pool with a backward: features [V, C] -> superpoint means [S, C] (positions carry no gradient)."""
+
+    @staticmethod
+    def forward(ctx, feat, maps, C):
+        f, pos = maps.pool(feat.detach(), C)
+        ctx.maps, ctx.C, ctx.V = maps, C, feat.shape[0]
+        ctx.mark_non_differentiable(pos)
+        return f, pos
+
+    @staticmethod
+    def backward(ctx, df, _dpos):
+        lib = _lib.load()
+        maps, C = ctx.maps, ctx.C
+        df = df.contiguous()
+        out = torch.empty(ctx.V, C, dtype=torch.float32, device=df.device)
+        _lib.check(lib.sd3d_pool_superpoints_backward(df.data_ptr(), C, maps.superpoints.data_ptr(), maps.sidx.data_ptr(), maps.seg_start.data_ptr(),
+                                                      maps._sp_start.data_ptr(), ctx.V, out.data_ptr(), C, ops._stream()), "pool_superpoints_backward")
+        return out, None, None
+
+
+def pool_superpoints(feat, maps, C):
+    return _PoolSuperpoints.apply(feat, maps, C)
+
+
+class TrainBackend:
+    """The plan-backend interface of the U-Net definitions (`plan.EagerBackend`) for training: every call is an
+    autograd node over HIP kernels - sparse convolution (pair-major forward, transposed-rulebook input gradient,
+    MFMA weight gradient), then batch-statistics BatchNorm with the residual and ReLU folded in.  `affine` is the
+    layer's nn.BatchNorm1d (or None), `wt` the [K, Cout, Cin] view of its live parameter."""
+
+    IGNORE_ACT = False      # test hook: drop the ReLUs (a smooth network has no mask flips between roundings, so its
+                            # gradients can be compared with the float64 oracle at rounding-level tolerance)
+
+    def __init__(self, maps):
+        self.maps = maps
+        self._identity = {}
+
+    def _identity_pairs(self, n_rows, device):
+        if n_rows not in self._identity:
+            nbr = torch.arange(n_rows, dtype=torch.int32, device=device).unsqueeze(0).contiguous()
+            self._identity[n_rows] = ops.pair_lists(nbr, n_rows)
+        return self._identity[n_rows]
+
+    @staticmethod
+    def _cat(x, x2):
+        return x if x2 is None else torch.cat([x, x2], dim=1)
+
+    def conv(self, x, wt, affine, key, x2=None, res=None, act=None):
+        kind, level = key[0], key[1]
+        y = sparse_conv(self._cat(x, x2), wt, self.maps, kind, level, key[2] if kind == "same" else 2)
+        act = None if self.IGNORE_ACT else act
+        return batch_norm_act(y, affine, res=res, act=act) if affine is not None else y
+
+    def dense(self, x, wt, affine, x2=None, res=None, act=None):
+        xin = self._cat(x, x2)
+        if wt.dim() == 2:
+            wt = wt.unsqueeze(0)
+        pairs = self._identity_pairs(xin.shape[0], xin.device)
+        y = SparseConv.apply(xin, wt, pairs, pairs, True)                       # K = 1: its own mirror
+        act = None if self.IGNORE_ACT else act
+        return batch_norm_act(y, affine, res=res, act=act) if affine is not None else y

@@ -100,3 +100,117 @@ def test_scalar_loss_gradient_reaches_conv_weights(scene):
     x64, w64 = x.double(), w.detach().double().requires_grad_(True)
     (reference(x64, w64, maps.conv_table("same", 2, 3)["nbr"]) ** 2).mean().backward()
     assert (w.grad.double() - w64.grad).abs().max().item() <= 3e-5 * w64.grad.abs().max().item()
+
+
+def test_batch_norm_act_matches_float64(scene):
+    """Batch-statistics BatchNorm + residual + ReLU (csrc/train.hip) against torch float64: outputs, gradients of the
+    input / residual / gamma / beta, and the running statistics nn.BatchNorm1d would hold."""
+    from segdino3d_amd import train_ops
+    d = dev()
+    g = torch.Generator().manual_seed(4)
+    for M, C, act, with_res in [(30_011, 96, "relu", True), (5_000, 32, "relu", False), (777, 256, None, True), (2049, 128, None, False)]:
+        x = (torch.randn(M, C, generator=g) * 3 + 50).to(d).requires_grad_(True)       # large mean: the variance must not cancel
+        res = torch.randn(M, C, generator=g).to(d).requires_grad_(True) if with_res else None
+        bn = torch.nn.BatchNorm1d(C, eps=1e-5, momentum=0.02).to(d)
+        with torch.no_grad():
+            bn.weight.copy_(torch.rand(C, generator=g) + 0.5)
+            bn.bias.copy_(torch.randn(C, generator=g))
+        dy = torch.randn(M, C, generator=g).to(d)
+        y = train_ops.batch_norm_act(x, bn, res=res, act=act)
+        y.backward(dy)
+        bn64 = torch.nn.BatchNorm1d(C, eps=1e-5, momentum=0.02).to(d).double()
+        with torch.no_grad():
+            bn64.weight.copy_(bn.weight); bn64.bias.copy_(bn.bias)
+        x64 = x.detach().double().requires_grad_(True)
+        r64 = res.detach().double().requires_grad_(True) if with_res else None
+        y64 = bn64(x64) + (r64 if with_res else 0)
+        if act == "relu":                                   # the fp32 result's own mask: outputs within rounding of 0 may differ in sign
+            y64 = y64 * (y.detach() > 0)
+        y64.backward(dy.double())
+        tol = lambda ref: 2e-5 * max(ref.abs().max().item(), 1e-3)
+        assert (y.detach().double() - y64.detach()).abs().max().item() <= tol(y64)
+        assert (x.grad.double() - x64.grad).abs().max().item() <= tol(x64.grad)
+        assert (bn.weight.grad.double() - bn64.weight.grad).abs().max().item() <= 5e-5 * bn64.weight.grad.abs().max().item()
+        assert (bn.bias.grad.double() - bn64.bias.grad).abs().max().item() <= 5e-5 * bn64.bias.grad.abs().max().item()
+        if with_res:
+            assert (res.grad.double() - r64.grad).abs().max().item() <= tol(r64.grad)
+        assert (bn.running_mean.double() - bn64.running_mean).abs().max().item() <= 1e-5
+        assert (bn.running_var.double() - bn64.running_var).abs().max().item() <= 1e-5 * bn64.running_var.abs().max().item()
+        assert int(bn.num_batches_tracked) == 1
+
+
+def _backbone_training_case(smooth):
+    """-> (features, {param: grad}) of the HIP path, and a function dtype -> the same from the oracle."""
+    import os, sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden"))
+    from _det import det_param
+    from oracle import sparse_ref as R
+    from segdino3d_amd import train_ops
+    from segdino3d_amd.backbone_mink import Res16UNet34C
+    from segdino3d_amd.synth import make_scene
+    d = dev()
+    pts, tgt = make_scene(14, n_points=20000, n_superpoints=150, n_query2d=20)
+    m = Res16UNet34C(in_channels=259, out_channels=96, config=dict(dilations=[1, 1, 1, 1], conv1_kernel_size=5, bn_momentum=0.02),
+                     voxel_size=0.02, mode_fuse_2d_feat="early_fusion", add_positional_embedding=True)
+    sd = {k: det_param("backbone." + k, v.shape).to(v.dtype) for k, v in m.state_dict().items()}
+    m.load_state_dict(sd)
+    m.to(d).train()
+    g = torch.Generator().manual_seed(1)
+    train_ops.TrainBackend.IGNORE_ACT = smooth
+    try:
+        f, pos, _ = m.forward_wrapper([pts.to(d)], [tgt.to(d)], return_sp_mean_pos=True)
+        R_w = torch.randn(f[0].shape, generator=g)
+        (f[0] * R_w.to(d)).sum().backward()
+    finally:
+        train_ops.TrainBackend.IGNORE_ACT = False
+    tgt = tgt.to("cpu")
+
+    def oracle_grads(dtype):
+        rsd = {"backbone." + k: (v.to(dtype).requires_grad_(True) if v.is_floating_point() else v) for k, v in sd.items()}
+        R.BN_TRAIN = True
+        relu = torch.relu
+        if smooth:
+            torch.relu = lambda x: x
+        try:
+            rf, _, _ = R.mink_forward_wrapper(rsd, pts.to(dtype), tgt.extra_features["points_2dfeats"].to(dtype),
+                                              tgt.extra_features["super_point_masks"])
+            (rf * R_w.to(dtype)).sum().backward()
+        finally:
+            R.BN_TRAIN = False
+            torch.relu = relu
+        return rf.detach(), {k[len("backbone."):]: v.grad for k, v in rsd.items() if v.is_floating_point() and v.grad is not None}
+
+    return f[0].detach().cpu(), {n: p.grad.cpu() for n, p in m.named_parameters()}, oracle_grads
+
+
+def _rel(a, b):
+    return ((a.double() - b).norm() / b.norm().clamp(min=1e-30)).item()
+
+
+def test_res16unet34c_backward_without_relu_matches_float64_oracle():
+    """The whole training-mode backbone with the ReLUs dropped on both sides (convolutions, batch-statistics BatchNorm,
+    residuals, skip concatenations, superpoint pooling): a smooth function, so every parameter gradient must agree with
+    the float64 oracle to fp32 rounding (relative L2 <= 2e-4 after 34 layers)."""
+    f, grads, oracle = _backbone_training_case(smooth=True)
+    rf, ref = oracle(torch.float64)
+    assert (f.double() - rf).abs().max().item() <= 2e-4 * max(rf.abs().max().item(), 1.0)
+    worst = sorted(((_rel(grads[n], ref[n]), n) for n in grads), reverse=True)
+    assert set(grads) == set(ref)
+    assert worst[0][0] <= 2e-4, f"parameter gradients differ: {worst[:5]}"
+
+
+def test_res16unet34c_training_step_matches_float64_oracle():
+    """With the ReLUs: an output within rounding of zero switches its mask between two roundings of the same network,
+    which moves the gradients of the coarse levels (a few hundred voxels) by up to ~1 %.  The yardstick is therefore the
+    oracle itself run in float32: the HIP path must sit about as close to the float64 gradients as that does."""
+    f, grads, oracle = _backbone_training_case(smooth=False)
+    rf, ref = oracle(torch.float64)
+    _, ref32 = oracle(torch.float32)
+    err = (f.double() - rf).abs().max().item()
+    assert err <= 1e-3 * max(rf.abs().max().item(), 1.0), f"training-mode features differ: {err}"
+    rows = sorted(((_rel(grads[n], ref[n]), _rel(ref32[n], ref[n]), n) for n in grads), reverse=True)
+    floor = max(r[1] for r in rows)
+    med = lambda i: sorted(r[i] for r in rows)[len(rows) // 2]
+    print(f"gradient error vs float64: worst {rows[0][0]:.2e} (float32 oracle {floor:.2e}), median {med(0):.2e} (float32 oracle {med(1):.2e})")
+    assert rows[0][0] <= max(4.0 * floor, 2e-3), f"parameter gradients differ (mine, float32 oracle, name): {rows[:5]}"
+    assert med(0) <= max(4.0 * med(1), 1e-3), f"median gradient error {med(0)} vs float32 oracle {med(1)}"
