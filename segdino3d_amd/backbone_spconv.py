@@ -128,6 +128,23 @@ class SpConvUNet(nn.Module):
             self._packed = pk
         return self._packed
 
+    def packed_train(self):
+        """name -> [K, Cout, Cin(+pad)] autograd view of the live SpConv weight / the nn.BatchNorm1d module, for
+        train_ops.TrainBackend (training step)."""
+        pk = {}
+        for n, m in self.named_modules():
+            if isinstance(m, SpConv):
+                w = m.weight
+                co, ci = w.shape[0], w.shape[-1]
+                w = w.reshape(co, -1, ci).permute(1, 0, 2)
+                pad = (ci + 31) // 32 * 32 - ci
+                if pad:
+                    w = torch.nn.functional.pad(w, (0, pad))
+                pk[n] = w.contiguous()
+            elif isinstance(m, nn.BatchNorm1d):
+                pk[n] = m
+        return pk
+
     # ---- network -----------------------------------------------------------------------------------
     def _resblock(self, be, pk, p, x, key, x2=None):
         """ResidualBlock.forward (:82-99): conv_branch(x) + i_branch(x); x may be the concat [x | x2]."""
@@ -163,9 +180,12 @@ class SpConvUNet(nn.Module):
         return be.affine(x, pk["output_layer.0"], act="relu")
 
     def forward_sparse(self, maps: SceneMaps, vox_feats: torch.Tensor) -> torch.Tensor:
-        pk = self.packed()
         nl = len(self.num_planes)
         maps.prepare(same=[(l, 3) for l in range(nl)], strides=list(range(nl - 1)))
+        if self.training:                                        # batch-statistics BatchNorm, autograd nodes over HIP kernels
+            from . import train_ops
+            return self._network(train_ops.TrainBackend(maps), self.packed_train(), vox_feats, nl)
+        pk = self.packed()
         if plan.USE_PLAN and ops.PAIR_CONV and ops.GEMM_MODE is None and ops.GG_FORCE_NT is None and ops.GG_HOOK is None:
             if self._plan is None:                               # one C call per scene instead of ~130
                 rec = plan.Recorder(vox_feats.shape[1])
@@ -175,9 +195,6 @@ class SpConvUNet(nn.Module):
 
     @ops.bound_stream
     def forward_wrapper(self, samples: List[torch.Tensor], targets, return_sp_mean_pos=True):
-        if self.training:
-            raise NotImplementedError("segdino3d_amd backbone: eval-mode forward only (training step not built)")
-        pk = self.packed()
         feats, pos = [], []
         for pts, tgt in zip(samples, targets):
             if "elastic_coords" in tgt:
@@ -193,7 +210,11 @@ class SpConvUNet(nn.Module):
             cin_pad = (self.in_channels + 31) // 32 * 32
             vf = maps.voxel_features(pts, f2d, 2, cin_pad)
             x = self.forward_sparse(maps, vf)
-            f, _ = maps.pool(x, x.shape[1])
+            if self.training:
+                from . import train_ops
+                f, _ = train_ops.pool_superpoints(x, maps, x.shape[1])
+            else:
+                f, _ = maps.pool(x, x.shape[1])
             # positions: mean of floor(xyz / voxel) * voxel with the UN-shifted coordinates
             pos_maps = SceneMaps(pts, self.voxel_size, 1, shift_to_min=False, order=self.KERNEL_ORDER, superpoints=sp)
             _, p = pos_maps.pool(x.new_zeros((pos_maps.n_vox[0], 4)), 4)

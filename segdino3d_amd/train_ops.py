@@ -65,10 +65,10 @@ class SparseConv(torch.autograd.Function):
     convolution, the "up" lists for a "down" convolution and vice versa); `mirrored` = True for the submanifold case."""
 
     @staticmethod
-    def forward(ctx, x, w, pairs, pairs_t, mirrored):
+    def forward(ctx, x, w, pairs, pairs_t, mirrored, res=None):
         ctx.save_for_backward(x, w)
         ctx.pairs, ctx.pairs_t, ctx.mirrored = pairs, pairs_t, mirrored
-        return ops.pair_conv(x.detach(), w.detach(), pairs)
+        return ops.pair_conv(x.detach(), w.detach(), pairs, res=None if res is None else res.detach())   # residual added in pass 2
 
     @staticmethod
     def backward(ctx, dy):
@@ -79,17 +79,17 @@ class SparseConv(torch.autograd.Function):
             dx = ops.pair_conv(dy, transposed_weights(w, ctx.mirrored), ctx.pairs_t)
         if ctx.needs_input_grad[1]:
             dw = pair_wgrad(dy, x, ctx.pairs)
-        return dx, dw, None, None, None
+        return dx, dw, None, None, None, (dy if ctx.needs_input_grad[5] else None)
 
 
-def sparse_conv(x, w, maps, kind: str, level: int, ksize: int = 3):
+def sparse_conv(x, w, maps, kind: str, level: int, ksize: int = 3, res=None):
     """Differentiable sparse convolution on a scene's cached maps: kind "same" (submanifold, kernel `ksize`),
-    "down" (stride 2, level -> level + 1) or "up" (transposed, level + 1 -> level)."""
+    "down" (stride 2, level -> level + 1) or "up" (transposed, level + 1 -> level); `res` is added to the output."""
     if kind == "same":
         t = maps.conv_table("same", level, ksize)
-        return SparseConv.apply(x, w, t["pairs"], t["pairs"], True)
+        return SparseConv.apply(x, w, t["pairs"], t["pairs"], True, res)
     other = "up" if kind == "down" else "down"
-    return SparseConv.apply(x, w, maps.conv_table(kind, level)["pairs"], maps.conv_table(other, level)["pairs"], False)
+    return SparseConv.apply(x, w, maps.conv_table(kind, level)["pairs"], maps.conv_table(other, level)["pairs"], False, res)
 
 
 # ------------------------------------------------------------------------------------------------------------------
@@ -205,15 +205,28 @@ class TrainBackend:
 
     def conv(self, x, wt, affine, key, x2=None, res=None, act=None):
         kind, level = key[0], key[1]
-        y = sparse_conv(self._cat(x, x2), wt, self.maps, kind, level, key[2] if kind == "same" else 2)
         act = None if self.IGNORE_ACT else act
-        return batch_norm_act(y, affine, res=res, act=act) if affine is not None else y
+        if affine is None:
+            if act is not None:
+                raise NotImplementedError("TrainBackend: activation without BatchNorm")
+            return sparse_conv(self._cat(x, x2), wt, self.maps, kind, level, key[2] if kind == "same" else 2, res=res)
+        y = sparse_conv(self._cat(x, x2), wt, self.maps, kind, level, key[2] if kind == "same" else 2)
+        return batch_norm_act(y, affine, res=res, act=act)
 
     def dense(self, x, wt, affine, x2=None, res=None, act=None):
         xin = self._cat(x, x2)
         if wt.dim() == 2:
             wt = wt.unsqueeze(0)
         pairs = self._identity_pairs(xin.shape[0], xin.device)
-        y = SparseConv.apply(xin, wt, pairs, pairs, True)                       # K = 1: its own mirror
         act = None if self.IGNORE_ACT else act
-        return batch_norm_act(y, affine, res=res, act=act) if affine is not None else y
+        if affine is None:
+            if act is not None:
+                raise NotImplementedError("TrainBackend: activation without BatchNorm")
+            return SparseConv.apply(xin, wt, pairs, pairs, True, res)
+        y = SparseConv.apply(xin, wt, pairs, pairs, True)                       # K = 1: its own mirror
+        return batch_norm_act(y, affine, res=res, act=act)
+
+    def affine(self, x, affine, x2=None, act=None):
+        """Pre-activation BatchNorm (+ ReLU) of the spconv residual blocks (`spconv_unet.py:82-99`)."""
+        act = None if self.IGNORE_ACT else act
+        return batch_norm_act(self._cat(x, x2), affine, act=act)

@@ -214,3 +214,47 @@ def test_res16unet34c_training_step_matches_float64_oracle():
     print(f"gradient error vs float64: worst {rows[0][0]:.2e} (float32 oracle {floor:.2e}), median {med(0):.2e} (float32 oracle {med(1):.2e})")
     assert rows[0][0] <= max(4.0 * floor, 2e-3), f"parameter gradients differ (mine, float32 oracle, name): {rows[:5]}"
     assert med(0) <= max(4.0 * med(1), 1e-3), f"median gradient error {med(0)} vs float32 oracle {med(1)}"
+
+
+def test_spconvunet_backward_without_relu_matches_float64_oracle():
+    """SpConvUNet (ScanNetv2 prototype) in training mode, ReLUs dropped on both sides: pre-activation BatchNorms,
+    1x1 identity branches, stride-2 / transposed convolutions, skip concatenations - gradients of every parameter
+    against the float64 oracle (relative L2 <= 2e-4)."""
+    import os, sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden"))
+    from _det import det_param
+    from oracle import sparse_ref as R
+    from segdino3d_amd import train_ops
+    from segdino3d_amd.backbone_spconv import SpConvUNet
+    from segdino3d_amd.synth import make_scene
+    d = dev()
+    pts, tgt = make_scene(15, n_points=10000, n_superpoints=100, n_query2d=20)
+    m = SpConvUNet(num_planes=[32 * (i + 1) for i in range(5)], return_blocks=True, voxel_size=0.02,
+                   mode_fuse_2d_feat="early_fusion", add_positional_embedding=True)
+    sd = {k: det_param("backbone." + k, v.shape).to(v.dtype) for k, v in m.state_dict().items()}
+    m.load_state_dict(sd)
+    m.to(d).train()
+    g = torch.Generator().manual_seed(2)
+    train_ops.TrainBackend.IGNORE_ACT = True
+    try:
+        f, _, _ = m.forward_wrapper([pts.to(d)], [tgt.to(d)], return_sp_mean_pos=True)
+        R_w = torch.randn(f[0].shape, generator=g)
+        (f[0] * R_w.to(d)).sum().backward()
+    finally:
+        train_ops.TrainBackend.IGNORE_ACT = False
+    tgt = tgt.to("cpu")
+    rsd = {"backbone." + k: (v.double().requires_grad_(True) if v.is_floating_point() else v) for k, v in sd.items()}
+    R.BN_TRAIN = True
+    relu, floor_voxel = torch.relu, R.floor_voxel
+    torch.relu = lambda x: x
+    R.floor_voxel = lambda xyz, vs: floor_voxel(xyz.float(), vs)              # voxelise exactly as the fp32 pipeline does
+    try:
+        rf, _, _ = R.spconv_forward_wrapper(rsd, pts.double(), tgt.extra_features["points_2dfeats"].double(),
+                                            tgt.extra_features["super_point_masks"])
+        (rf * R_w.double()).sum().backward()
+    finally:
+        R.BN_TRAIN = False
+        torch.relu, R.floor_voxel = relu, floor_voxel
+    assert (f[0].detach().cpu().double() - rf.detach()).abs().max().item() <= 2e-4 * max(rf.abs().max().item(), 1.0)
+    worst = sorted(((_rel(p.grad.cpu(), rsd["backbone." + n].grad), n) for n, p in m.named_parameters()), reverse=True)
+    assert worst[0][0] <= 2e-4, f"parameter gradients differ: {worst[:5]}"
