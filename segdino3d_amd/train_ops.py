@@ -79,7 +79,8 @@ class SparseConv(torch.autograd.Function):
             dx = ops.pair_conv(dy, transposed_weights(w, ctx.mirrored), ctx.pairs_t)
         if ctx.needs_input_grad[1]:
             dw = pair_wgrad(dy, x, ctx.pairs)
-        return dx, dw, None, None, None, (dy if ctx.needs_input_grad[5] else None)
+        n_in = len(ctx.needs_input_grad)
+        return (dx, dw, None, None, None, (dy if ctx.needs_input_grad[5] else None))[:n_in] if n_in > 5 else (dx, dw, None, None, None)
 
 
 def sparse_conv(x, w, maps, kind: str, level: int, ksize: int = 3, res=None):
@@ -223,7 +224,7 @@ class TrainBackend:
             if act is not None:
                 raise NotImplementedError("TrainBackend: activation without BatchNorm")
             return SparseConv.apply(xin, wt, pairs, pairs, True, res)
-        y = SparseConv.apply(xin, wt, pairs, pairs, True)                       # K = 1: its own mirror
+        y = SparseConv.apply(xin, wt, pairs, pairs, True, None)                 # K = 1: its own mirror
         return batch_norm_act(y, affine, res=res, act=act)
 
     def affine(self, x, affine, x2=None, act=None):

@@ -82,6 +82,38 @@ for key, cin, cout in [(("same", 0, 3), 96, 96), (("same", 1, 3), 96, 96), (("sa
     rows.append(dict(layer=f"{key} {cin}->{cout}", pairs=P, fwd_us=round(us_f), dgrad_us=round(us_dx), wgrad_us=round(us_dw),
                      fwd_TF=round(fl / us_f / 1e6, 1), dgrad_TF=round(fl / us_dx / 1e6, 1), wgrad_TF=round(fl / us_dw / 1e6, 1)))
 out["sparse_conv_backward"] = rows
+# ---------------------------------------------------------------- backbone training step (forward + backward)
+import time as _t
+from segdino3d_amd.backbone_mink import Res16UNet34C
+from oracle import sparse_ref as R
+torch.manual_seed(0)
+net = Res16UNet34C(in_channels=259, out_channels=96, config=dict(dilations=[1, 1, 1, 1], conv1_kernel_size=5, bn_momentum=0.02),
+                   voxel_size=0.02, mode_fuse_2d_feat="early_fusion", add_positional_embedding=True).to(d).train()
+rows = {}
+for n_pts, n_sp in ((150000, 3000), (20000, 400)):
+    pts_s, tgt_s = make_scene(1, n_pts, n_sp, 50)
+    pd, td = pts_s.to(d), tgt_s.to(d)
+
+    def step():
+        for p_ in net.parameters():
+            p_.grad = None
+        f, _, _ = net.forward_wrapper([pd], [td], return_sp_mean_pos=True)
+        (f[0] * f[0]).mean().backward()
+
+    ms = timeit(step, 5)
+    rows[f"{n_pts}_points"] = dict(ms_device_fwd_bwd=round(ms, 2), voxels=int(net.last_maps.n_vox[0]))
+    if n_pts == 20000:                                   # the same step through the oracle + torch autograd on the host cores
+        sd = {"backbone." + k: (v.detach().cpu().clone().requires_grad_(True) if v.is_floating_point() else v.cpu())
+              for k, v in net.state_dict().items()}
+        tgt_s = tgt_s.to("cpu")                          # Target.to moves in place
+        R.BN_TRAIN = True
+        t0 = _t.perf_counter()
+        rf, _, _ = R.mink_forward_wrapper(sd, pts_s, tgt_s.extra_features["points_2dfeats"], tgt_s.extra_features["super_point_masks"])
+        (rf * rf).mean().backward()
+        rows[f"{n_pts}_points"]["s_cpu_oracle_fwd_bwd"] = round(_t.perf_counter() - t0, 2)
+        rows[f"{n_pts}_points"]["cpu_threads"] = torch.get_num_threads()
+        R.BN_TRAIN = False
+out["res16unet34c_training_step"] = rows
 print(json.dumps(out, indent=1))
 os.makedirs("gpurun_out", exist_ok=True)
 json.dump(out, open("gpurun_out/perf_train.json", "w"), indent=1)
