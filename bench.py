@@ -284,12 +284,14 @@ def main():
         cpu = cpu_baseline(model, scene_args)
 
     if rank == 0:
+        bf16_dec = getattr(model.decoder, "compute_dtype", "fp32") == "bf16"      # SD3D_DECODER_DTYPE=bf16: BASELINE configs[2]
         out = {
             "metric": "scenes/sec forward (ScanNet200 ~150k pts, 200 queries)", "value": round(value, 3), "unit": "scenes/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * dt / args.steps, 3),
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "configs[1]: ScanNet-val-like scene, 1 scene per GPU per step, fp32 sparse backbone "
-                                   "(Res16UNet34C) + fp32 decoder + post-processing, device-resident in/out",
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32 backbone + bf16 decoder contractions" if bf16_dec else "f32", "data": "synthetic",
+            "config": {"workload": ("configs[2]" if bf16_dec else "configs[1]") + ": ScanNet-val-like scene, 1 scene per GPU per step, "
+                                   "fp32 sparse backbone (Res16UNet34C) + " + ("bf16-MFMA" if bf16_dec else "fp32") +
+                                   " decoder + post-processing, device-resident in/out",
                        "points": args.points, "superpoints": args.superpoints, "queries_2d": args.query2d,
                        "query_num": args.query_num, "voxels_per_level": maps.n_vox, "parallelism": f"scene-sharded x{world}",
                        "scenes_in_flight_per_gpu": args.streams, "single_stream_latency_ms": round(latency_ms, 3)},

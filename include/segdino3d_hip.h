@@ -120,8 +120,10 @@ int sd3d_gather_gemm(const float* in0, int ld0, int C0, const float* in1, int ld
 /* Opt-in variant of sd3d_gather_gemm that evaluates the fp32 products as sums of bf16 MFMA products
  * (csrc/gather_gemm_split.hip).  wt_split = the fp32 weights [K, Cout, Cin] split into bf16 terms,
  * w = t0 + t1 (+ t2) with t_i = bf16_rne(w - sum_{j<i} t_j), laid out [2 or 3][K][Cout][Cin];
- * terms = 3 (two terms per operand, error ~2^-16 per product) or 6 (three terms, ~2^-24: fp32-grade).
- * Not used unless the host asks for it (SD3D_GEMM_MODE); the default path is the exact fp32 MFMA. */
+ * terms = 3 (two terms per operand, error ~2^-16 per product) or 6 (three terms, ~2^-24: fp32-grade), or
+ * terms = 1: plain bf16 operands with fp32 accumulation ([1][K][Cout][Cin]) - the "bf16 decoder" of BASELINE
+ * config #3 (autocast(bf16) around the decoder's nn.Linear calls in the reference, train_engine_3d.py:88-100).
+ * Not used unless the host asks for it (SD3D_GEMM_MODE / decoder compute_dtype); the default is exact fp32 MFMA. */
 int sd3d_gather_gemm_split(const float* in0, int ld0, int C0, const float* in1, int ld1, const int32_t* nbr,
                            const uint16_t* wt_split, int terms, int K, int Cin, int Cout, int64_t M, const float* scale,
                            const float* shift, const float* res, int ld_res, float* out, int ld_out, int act, int nt,
@@ -198,6 +200,11 @@ size_t sd3d_attention_ws_bytes(int Lq, int H);
 int sd3d_attention(const float* q0, int ldq0, const float* q1, int ldq1, const float* k0, int ldk0, const float* k1,
                    int ldk1, const float* v, int ldv, const uint32_t* mask_bits, int Lq, int Lk, int H, float scale,
                    float* out, int ldo, void* ws, size_t ws_bytes, void* stream);
+/* Same contract with Q, K, P and V rounded to bf16 for the two contractions (v_mfma_f32_32x32x16_bf16, fp32 accumulate;
+ * scores, mask, softmax in fp32): the attention of the "bf16 decoder", BASELINE config #3. */
+int sd3d_attention_bf16(const float* q0, int ldq0, const float* q1, int ldq1, const float* k0, int ldk0, const float* k1,
+                        int ldk1, const float* v, int ldv, const uint32_t* mask_bits, int Lq, int Lk, int H, float scale,
+                        float* out, int ldo, void* ws, size_t ws_bytes, void* stream);
 /* _forward_head mask part (:567-572): bits = sigmoid(logits) < thr, dead rows reset to open. */
 int sd3d_mask_bits(const float* logits, int ld, int64_t Q, int S, float thr, uint32_t* bits, int nwords, void* stream);
 /* (dist < thr) of torch.cdist(p=1) (:721) as bits near[M, ceil(S/32)]. */

@@ -53,6 +53,7 @@ SIGNATURES = {
     "sd3d_sine_pe": (_i, [_p, _i, _l, _p, _p, _p, _i, _p, _i, _p, _i, _p, _i, _p]),
     "sd3d_attention_ws_bytes": (_z, [_i, _i]),
     "sd3d_attention": (_i, [_p, _i, _p, _i, _p, _i, _p, _i, _p, _i, _p, _i, _i, _i, _f, _p, _i, _p, _z, _p]),
+    "sd3d_attention_bf16": (_i, [_p, _i, _p, _i, _p, _i, _p, _i, _p, _i, _p, _i, _i, _i, _f, _p, _i, _p, _z, _p]),
     "sd3d_mask_bits": (_i, [_p, _i, _l, _i, _f, _p, _i, _p]),
     "sd3d_near_bits": (_i, [_p, _l, _p, _l, _f, _p, _i, _p]),
     "sd3d_dinox_mask_bits": (_i, [_p, _p, _i, _l, _l, _p, _i, _p]),

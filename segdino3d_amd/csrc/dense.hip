@@ -132,9 +132,16 @@ struct AttnParams {
     float scale;
     int ksplit;                               // key tiles are dealt to gridDim.z workgroups; partials -> part
     float* part;                              // [qtile][head][ksplit][64 + 1024]: m[32], l[32], O[32 dv][32 q]
+    int bf16;                                 // 1: Q, K, P, V rounded to bf16 for the two contractions (fp32 accumulate, fp32 softmax)
 };
 
-template <int NSRC>
+typedef __bf16 abf16x8 __attribute__((ext_vector_type(8)));
+
+// BF16 = the "bf16 decoder" of BASELINE config #3: both contractions run on v_mfma_f32_32x32x16_bf16 (8 contraction
+// indices per lane instead of 1: 2 * NSRC + 2 MFMAs per key tile instead of 16 * NSRC + 16); scores, softmax and the
+// accumulators stay fp32.  The (lane half, register) -> (channel | key) assignment is the fp32 kernel's, which both
+// operands of each product share, so only the grouping of the contraction changes.
+template <int NSRC, bool BF16>
 __global__ __launch_bounds__(512) void attention_kernel(const AttnParams p) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int nw = blockDim.x >> 6;
@@ -155,6 +162,15 @@ __global__ __launch_bounds__(512) void attention_kernel(const AttnParams p) {
 #pragma unroll
             for (int c = 0; c < 4; ++c) qreg[s][e * 4 + c] = t[c] * p.scale;
         }
+    }
+    abf16x8 qb[NSRC][2];
+    if (BF16) {
+#pragma unroll
+        for (int s = 0; s < NSRC; ++s)
+#pragma unroll
+            for (int g = 0; g < 2; ++g)
+#pragma unroll
+                for (int c = 0; c < 8; ++c) qb[s][g][c] = (__bf16)qreg[s][g * 8 + c];
     }
     f32x16 O;
 #pragma unroll
@@ -184,11 +200,21 @@ __global__ __launch_bounds__(512) void attention_kernel(const AttnParams p) {
             f32x4 kk[4];
 #pragma unroll
             for (int e = 0; e < 4; ++e) kk[e] = *(const f32x4*)(src + e * 4);
+            if (BF16) {
 #pragma unroll
-            for (int e = 0; e < 4; ++e)
+                for (int g = 0; g < 2; ++g) {
+                    abf16x8 kb;
 #pragma unroll
-                for (int c = 0; c < 4; ++c)
-                    S = __builtin_amdgcn_mfma_f32_32x32x2f32(kk[e][c], qreg[s][e * 4 + c], S, 0, 0, 0);
+                    for (int c = 0; c < 8; ++c) kb[c] = (__bf16)kk[2 * g + (c >> 2)][c & 3];
+                    S = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kb, qb[s][g], S, 0, 0, 0);
+                }
+            } else {
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+#pragma unroll
+                    for (int c = 0; c < 4; ++c)
+                        S = __builtin_amdgcn_mfma_f32_32x32x2f32(kk[e][c], qreg[s][e * 4 + c], S, 0, 0, 0);
+            }
         }
         // S[r] = score(key = kt0 + (r&3) + 8*(r>>2) + 4*h, query = q0 + i)
         const uint32_t word = p.bits ? p.bits[(int64_t)qi * p.nwords + t] : 0u;
@@ -218,8 +244,18 @@ __global__ __launch_bounds__(512) void attention_kernel(const AttnParams p) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) O[r] *= alpha;
         // O^T[dv][query] += sum_key V[key][dv] * P[query][key];  A = V^T (row = dv = i), B = P^T
+        if (BF16) {
 #pragma unroll
-        for (int r = 0; r < 16; ++r) O = __builtin_amdgcn_mfma_f32_32x32x2f32(vreg[r], pr[r], O, 0, 0, 0);
+            for (int g = 0; g < 2; ++g) {
+                abf16x8 vb, pb;
+#pragma unroll
+                for (int c = 0; c < 8; ++c) { vb[c] = (__bf16)vreg[g * 8 + c]; pb[c] = (__bf16)pr[g * 8 + c]; }
+                O = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vb, pb, O, 0, 0, 0);
+            }
+        } else {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) O = __builtin_amdgcn_mfma_f32_32x32x2f32(vreg[r], pr[r], O, 0, 0, 0);
+        }
     }
     l += __shfl_xor(l, 32);
 
@@ -298,8 +334,10 @@ int launch_attention(const AttnParams& p_in, int nsrc, void* ws, size_t ws_bytes
     p.part = (float*)ws;
     const dim3 grid((unsigned)cdiv(p.Lq, 32), (unsigned)p.H, (unsigned)ks), block(64 * nw);
     const size_t sm = (size_t)nw * (64 + 1024) * sizeof(float);
-    if (nsrc == 1) hipLaunchKernelGGL(attention_kernel<1>, grid, block, sm, st, p);
-    else if (nsrc == 2) hipLaunchKernelGGL(attention_kernel<2>, grid, block, sm, st, p);
+    if (nsrc == 1 && !p.bf16) hipLaunchKernelGGL((attention_kernel<1, false>), grid, block, sm, st, p);
+    else if (nsrc == 2 && !p.bf16) hipLaunchKernelGGL((attention_kernel<2, false>), grid, block, sm, st, p);
+    else if (nsrc == 1) hipLaunchKernelGGL((attention_kernel<1, true>), grid, block, sm, st, p);
+    else if (nsrc == 2) hipLaunchKernelGGL((attention_kernel<2, true>), grid, block, sm, st, p);
     else return sd3d_set_error(SD3D_ERR_ARG, "attention: nsrc must be 1 or 2");
     if (ks > 1) hipLaunchKernelGGL(attention_merge_kernel, dim3((unsigned)cdiv(p.Lq, 32), (unsigned)p.H), dim3(256), 0, st, p);
     SD3D_CHECK_LAUNCH();

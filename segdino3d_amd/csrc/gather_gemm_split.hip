@@ -32,7 +32,7 @@ __device__ __forceinline__ void split8(const f32x4& v0, const f32x4& v1, bf16x8 
     }
 }
 
-// NS = number of split terms kept per operand: 2 (bf16x3) or 3 (bf16x6)
+// NS = number of split terms kept per operand: 1 (plain bf16 operands, fp32 accumulate), 2 (bf16x3) or 3 (bf16x6)
 template <int NT, int NS>
 __global__ __launch_bounds__(256) void gather_gemm_split_kernel(const GGParams p, const __bf16* __restrict__ wsplit) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
@@ -158,12 +158,14 @@ __global__ __launch_bounds__(256) void gather_gemm_split_kernel(const GGParams p
                         for (int s = 0; s < NS; ++s) bt[s] = *(const bf16x8*)(bb + (s * ROWS + t * 32) * SB_LD);
                         // smallest terms first
                         if (NS == 3) {
-                            acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(at[2], bt[0], acc[t], 0, 0, 0);
-                            acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(at[0], bt[2], acc[t], 0, 0, 0);
-                            acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(at[1], bt[1], acc[t], 0, 0, 0);
+                            acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(at[NS == 3 ? 2 : 0], bt[0], acc[t], 0, 0, 0);
+                            acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(at[0], bt[NS == 3 ? 2 : 0], acc[t], 0, 0, 0);
+                            acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(at[NS == 3 ? 1 : 0], bt[NS == 3 ? 1 : 0], acc[t], 0, 0, 0);
                         }
-                        acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(at[1], bt[0], acc[t], 0, 0, 0);
-                        acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(at[0], bt[1], acc[t], 0, 0, 0);
+                        if (NS >= 2) {
+                            acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(at[NS >= 2 ? 1 : 0], bt[0], acc[t], 0, 0, 0);
+                            acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(at[0], bt[NS >= 2 ? 1 : 0], acc[t], 0, 0, 0);
+                        }
                         acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(at[0], bt[0], acc[t], 0, 0, 0);
                     }
                 }
@@ -225,7 +227,7 @@ static void launch_one(const GGParams& p, const __bf16* w, dim3 grid, hipStream_
 
 void launch_splitk_epilogue(const GGParams& p, hipStream_t st);
 
-// terms: 3 (bf16x3) or 6 (bf16x6).  wsplit: [2 or 3][K][Cout][Cin] bf16.
+// terms: 1 (plain bf16), 3 (bf16x3) or 6 (bf16x6).  wsplit: [1, 2 or 3][K][Cout][Cin] bf16.
 int launch_gather_gemm_split(const GGParams& p_in, int nt, int terms, const void* wsplit, void* ws, size_t ws_bytes,
                              hipStream_t st) {
     GGParams p = p_in;
@@ -233,7 +235,7 @@ int launch_gather_gemm_split(const GGParams& p_in, int nt, int terms, const void
     p.ws = nullptr;
     p.dbg = 0;
     if (p.M <= 0 || p.Cout <= 0) return SD3D_OK;
-    if (terms != 3 && terms != 6) return sd3d_set_error(SD3D_ERR_ARG, "gather_gemm_split: terms must be 3 or 6");
+    if (terms != 1 && terms != 3 && terms != 6) return sd3d_set_error(SD3D_ERR_ARG, "gather_gemm_split: terms must be 1, 3 or 6");
     if (p.Cin <= 0 || (p.Cin & 31)) return sd3d_set_error(SD3D_ERR_ARG, "gather_gemm_split: Cin must be a positive multiple of 32");
     if (p.in1 && ((p.C0 & 31) || p.C0 > p.Cin)) return sd3d_set_error(SD3D_ERR_ARG, "gather_gemm_split: concat split must be a multiple of 32");
     if (!p.in1) p.C0 = p.Cin;
@@ -256,7 +258,14 @@ int launch_gather_gemm_split(const GGParams& p_in, int nt, int terms, const void
     }
     const dim3 grid((unsigned)cdiv(tiles, 4), (unsigned)p.col_groups, (unsigned)p.ksplit);
     const __bf16* w = (const __bf16*)wsplit;
-    if (terms == 3) {
+    if (terms == 1) {
+        switch (nt) {
+            case 1: launch_one<1, 1>(p, w, grid, st); break;
+            case 2: launch_one<2, 1>(p, w, grid, st); break;
+            case 3: launch_one<3, 1>(p, w, grid, st); break;
+            default: launch_one<4, 1>(p, w, grid, st); break;
+        }
+    } else if (terms == 3) {
         switch (nt) {
             case 1: launch_one<1, 2>(p, w, grid, st); break;
             case 2: launch_one<2, 2>(p, w, grid, st); break;

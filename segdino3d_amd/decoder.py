@@ -23,6 +23,8 @@ from __future__ import annotations
 import copy
 from typing import List
 
+import os
+
 import torch
 import torch.nn as nn
 
@@ -148,6 +150,12 @@ class ScanNetQueryDecoder(nn.Module):
         self.normalize_box_prediction = normalize_box_prediction
         self.temperature = float(temperature)
         self.num_queries = 0
+        # "fp32" (default, BASELINE config #2) or "bf16" (config #3: projections and both attention contractions on the bf16
+        # MFMA with fp32 accumulation; LayerNorm, softmax, positional encodings, mask logits and thresholds stay fp32).  Not a
+        # key of the reference's config surface - there bf16 comes from autocast(cfg.amp), train_engine_3d.py:88-100.
+        self.compute_dtype = str(kwargs.get("compute_dtype", os.environ.get("SD3D_DECODER_DTYPE", "fp32")))
+        if self.compute_dtype not in ("fp32", "bf16"):
+            raise ValueError(f"decoder compute_dtype must be 'fp32' or 'bf16', got {self.compute_dtype!r}")
 
         self.input_proj = nn.Sequential(nn.Linear(in_channels, d), nn.LayerNorm(d), nn.ReLU())
         self.query_proj = nn.Sequential(nn.Linear(in_channels, d), nn.ReLU(), nn.Linear(d, d))
@@ -284,7 +292,7 @@ class ScanNetQueryDecoder(nn.Module):
                 sem = _lin(nq, self.out_sem)
             else:
                 sem = _lin(_lin(nq, self.out_sem[0], act="relu"), self.out_sem[2])
-        logits = ops.gather_gemm(nq, mask_feats)                      # einsum('nd,md->nm')
+        logits = ops.gather_gemm(nq, mask_feats, exact=True)          # einsum('nd,md->nm'); fp32 in every mode: it feeds thresholds
         bits = ops.mask_bits(logits, S, self.mask_attention_threshold)
         return cls, sem, logits, bits
 
@@ -430,6 +438,10 @@ class ScanNetQueryDecoder(nn.Module):
     @ops.bound_stream
     def forward(self, x, sp_pos=None, sp_pos_wo_elastic=None, queries=None, queries_pos=None, dinox_queries=None,
                 dinox_query_pos=None, scene_range=None):
+        with ops.bf16_decoder_scope(self.compute_dtype == "bf16"):
+            return self._forward(x, sp_pos, sp_pos_wo_elastic, queries, queries_pos, dinox_queries, dinox_query_pos, scene_range)
+
+    def _forward(self, x, sp_pos, sp_pos_wo_elastic, queries, queries_pos, dinox_queries, dinox_query_pos, scene_range):
         finals, auxes = [], []
         if not self.add_positional_embedding:
             for j in range(len(x)):

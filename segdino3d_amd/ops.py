@@ -371,11 +371,38 @@ if GEMM_MODE not in (None, "bf16x3", "bf16x6"):
     raise ValueError(f"SD3D_GEMM_MODE must be bf16x3 or bf16x6, got {GEMM_MODE!r}")
 SPLIT_MIN_ROWS = 2048          # below this the launch is latency-bound and stays on the fp32 kernel
 _SPLIT_CACHE = {}
+_BF16_TLS = threading.local()
+# projections of fewer rows are launch-latency bound and measured FASTER on the exact fp32 small-M kernel (200-query decoder:
+# 2.6 ms fp32, 3.5 ms with every Linear on the bf16 kernel); exact fp32 is never less precise than the bf16 the mode allows
+BF16_MIN_ROWS = int(_os.environ.get("SD3D_BF16_MIN_ROWS", "1024"))
+
+
+class bf16_decoder_scope:
+    """BASELINE config #3 ("bf16 decoder"): inside the scope every dense projection (`linear`, `gather_gemm` without a
+    neighbour table and without `exact=True`) runs with bf16 operands and fp32 accumulation, and `attention` runs its two
+    contractions on the bf16 MFMA.  LayerNorm, softmax, the positional encodings, the mask head's logits and every
+    threshold stay fp32 ("bf16 decoder").  Per thread; nests."""
+
+    def __init__(self, enabled=True):
+        self.enabled = bool(enabled)
+
+    def __enter__(self):
+        self.prev = getattr(_BF16_TLS, "on", False)
+        _BF16_TLS.on = self.enabled or self.prev
+        return self
+
+    def __exit__(self, *exc):
+        _BF16_TLS.on = self.prev
+        return False
+
+
+def bf16_decoder_active() -> bool:
+    return getattr(_BF16_TLS, "on", False)
 
 
 def split_weights(wt, terms):
     """fp32 [K, Cout, Cin] -> bf16 [terms_per_operand, K, Cout, Cin] with wt = sum of the terms (to ~2^-17 / 2^-25)."""
-    ns = {3: 2, 6: 3}[terms]
+    ns = {1: 1, 3: 2, 6: 3}[terms]
     r = wt.detach().to(torch.float32).clone()
     parts = []
     for _ in range(ns):
@@ -463,7 +490,7 @@ def pair_conv(x, wt, pairs, x2=None, scale=None, shift=None, res=None, act=None,
 
 
 def gather_gemm(x, wt, nbr=None, x2=None, scale=None, shift=None, res=None, act=None, out=None, M=None, nt=0,
-                density=None, wt_split=None, pairs=None):
+                density=None, wt_split=None, pairs=None, exact=False):
     """out[r, n] = act(scale[n] * sum_k sum_c X[nbr[k, r], c] * wt[k, n, c] + shift[n] + res[r, n]).
 
     x [V_in, C0] (rows may be strided), optional x2 [V_in, C1] = concatenated channels,
@@ -498,7 +525,9 @@ def gather_gemm(x, wt, nbr=None, x2=None, scale=None, shift=None, res=None, act=
         pr, ldr = _rows(res, "res")
     terms = 0
     if wt_split is not None:
-        terms = {2: 3, 3: 6}[wt_split.shape[0]]
+        terms = {1: 1, 2: 3, 3: 6}[wt_split.shape[0]]
+    elif nbr is None and not exact and bf16_decoder_active() and M >= BF16_MIN_ROWS and Cin % 32 == 0 and (x2 is None or C0 % 32 == 0):
+        terms = 1                                  # bf16 decoder: plain bf16 operands (weights rounded once, cached)
     elif GEMM_MODE is not None and nt == 0 and M >= SPLIT_MIN_ROWS and Cin % 32 == 0:
         terms = 3 if GEMM_MODE == "bf16x3" else 6
     if terms and wt_split is None:
@@ -517,7 +546,7 @@ def gather_gemm(x, wt, nbr=None, x2=None, scale=None, shift=None, res=None, act=
         ws_ptr, ws_n = ws.data_ptr(), ws.numel()
     if terms:
         if wt_split.dtype != torch.bfloat16 or not wt_split.is_contiguous() or tuple(wt_split.shape[1:]) != (K, Cout, Cin):
-            raise ValueError("wt_split must be contiguous bf16 [2|3, K, Cout, Cin]")
+            raise ValueError("wt_split must be contiguous bf16 [1|2|3, K, Cout, Cin]")
         _lib.check(lib.sd3d_gather_gemm_split(p0, ld0, C0, p1, ld1, _ptr(nbr, torch.int32, "nbr"), wt_split.data_ptr(),
                                               terms, K, Cin, Cout, M, _ptr(scale, torch.float32, "scale"),
                                               _ptr(shift, torch.float32, "shift"), pr, ldr, po, ldo, ACT[act],
@@ -589,9 +618,9 @@ def attention(q, k, v, num_heads, scale, mask_bits=None, q2=None, k2=None):
         raise ValueError(f"attention: mask bits shape {tuple(mask_bits.shape)} != ({Lq}, {(Lk + 31) // 32})")
     out = torch.empty(Lq, num_heads * 32, dtype=torch.float32, device=q.device)
     ws = _WS6.get(lib.sd3d_attention_ws_bytes(Lq, num_heads), q.device)
-    _lib.check(lib.sd3d_attention(pq, ldq, pq2, ldq2, pk, ldk, pk2, ldk2, pv, ldv, _ptr(mask_bits, torch.int32, "mask_bits"),
-                                  Lq, Lk, num_heads, float(scale), _ptr(out), out.shape[1], ws.data_ptr(), ws.numel(),
-                                  _stream()), "attention")
+    fn = lib.sd3d_attention_bf16 if bf16_decoder_active() else lib.sd3d_attention
+    _lib.check(fn(pq, ldq, pq2, ldq2, pk, ldk, pk2, ldk2, pv, ldv, _ptr(mask_bits, torch.int32, "mask_bits"),
+                  Lq, Lk, num_heads, float(scale), _ptr(out), out.shape[1], ws.data_ptr(), ws.numel(), _stream()), "attention")
     return out
 
 

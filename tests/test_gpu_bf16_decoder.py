@@ -1,0 +1,126 @@
+"""BASELINE config #3 ("bf16 decoder"): projections and the two attention contractions with bf16 operands on the bf16
+MFMA, fp32 accumulation; LayerNorm / softmax / positional encodings / mask logits / thresholds fp32.
+Each kernel is checked against a float64 model with the SAME operand rounding (tight: only the fp32 accumulation
+differs), and the whole decoder against its own fp32 mode (loose: bf16 carries 8 mantissa bits)."""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from _det import det_randn  # noqa: E402
+from test_gpu_decoder import DEC_KW, _build_decoder, _mask_agree, dev  # noqa: E402
+
+
+def bf(x):
+    return x.to(torch.bfloat16).to(torch.float64)
+
+
+@pytest.mark.parametrize("M,Cin,Cout,concat,act", [(200, 256, 256, False, None), (3000, 256, 3072, False, None), (200, 512, 256, True, "relu"),
+                                                    (37, 1024, 256, False, "gelu"), (200, 256, 199, False, None), (200, 256, 3, False, "sigmoid")])
+def test_bf16_projection_matches_rounded_operands(M, Cin, Cout, concat, act):
+    from segdino3d_amd import ops
+    d = dev()
+    x = det_randn(f"bp.x{M}{Cin}", (M, Cin))
+    w = det_randn(f"bp.w{Cin}{Cout}", (Cout, Cin), Cin ** -0.5)
+    b = det_randn(f"bp.b{Cout}", (Cout,), 0.1)
+    res = det_randn(f"bp.r{M}{Cout}", (M, Cout))
+    ref = bf(x) @ bf(w).T + b.double() + res.double()
+    ref = {"relu": torch.relu, "gelu": torch.nn.functional.gelu, "sigmoid": torch.sigmoid, None: lambda t: t}[act](ref)
+    xd, wd = x.to(d), w.to(d)
+    ops.BF16_MIN_ROWS, keep = 1, ops.BF16_MIN_ROWS                        # the row threshold is a speed heuristic: test the kernel itself
+    with ops.bf16_decoder_scope():
+        if concat:
+            h = Cin // 2
+            out = ops.gather_gemm(xd[:, :h].contiguous(), wd, x2=xd[:, h:].contiguous(), shift=b.to(d), res=res.to(d), act=act)
+        else:
+            out = ops.linear(xd, wd, b.to(d), act=act, res=res.to(d))
+        exact = ops.gather_gemm(xd, wd, shift=b.to(d), res=res.to(d), act=act, exact=True)
+    ops.BF16_MIN_ROWS = keep
+    scale = (bf(x).abs() @ bf(w).abs().T).max().item()
+    assert (out.cpu().double() - ref).abs().max().item() <= 2e-6 * scale          # fp32 accumulation of exact products
+    full = {"relu": torch.relu, "gelu": torch.nn.functional.gelu, "sigmoid": torch.sigmoid, None: lambda t: t}[act](
+        x.double() @ w.double().T + b.double() + res.double())
+    assert (exact.cpu().double() - full).abs().max().item() <= 2e-6 * scale       # exact=True stays on the fp32 kernel
+    assert (out.cpu().double() - full).abs().max().item() <= 1e-2 * scale         # and bf16 is bf16
+    # outside the scope nothing changes
+    again = ops.linear(xd, wd, b.to(d), act=act, res=res.to(d))
+    assert torch.equal(again, exact)
+
+
+@pytest.mark.parametrize("Lq,Lk,nsrc,masked", [(200, 3000, 2, True), (64, 64, 1, False), (33, 311, 1, True), (300, 1000, 2, False)])
+def test_bf16_attention(Lq, Lk, nsrc, masked):
+    """Against float64 attention on bf16-rounded Q (pre-scaled), K, V with the probabilities rounded to bf16 before the
+    second contraction - the kernel's arithmetic - and, loosely, against exact attention."""
+    from segdino3d_amd import ops
+    d = dev()
+    H = 8
+    q = det_randn(f"ab.q{Lq}", (Lq, 256)); k = det_randn(f"ab.k{Lk}", (Lk, 256)); v = det_randn(f"ab.v{Lk}", (Lk, 256))
+    q2 = det_randn(f"ab.q2{Lq}", (Lq, 256)); k2 = det_randn(f"ab.k2{Lk}", (Lk, 256))
+    blocked, bits = None, None
+    if masked:
+        blocked = det_randn(f"ab.m{Lq}{Lk}", (Lq, Lk)) > 0.3
+        blocked[:, : min(40, Lk - 1)] = True
+        blocked[torch.arange(Lq), torch.arange(Lq) % Lk] = False
+        nw = (Lk + 31) // 32
+        pad = torch.ones(Lq, nw * 32, dtype=torch.bool); pad[:, :Lk] = blocked
+        words = (pad.view(Lq, nw, 32).long() << torch.arange(32)).sum(-1)
+        bits = torch.where(words >= 2 ** 31, words - 2 ** 32, words).to(torch.int32).to(d)
+    scale = (32 * nsrc) ** -0.5
+
+    def model(rounded):
+        r = bf if rounded else (lambda t: t.double())
+        s = torch.einsum("qhc,khc->hqk", r((q * scale).view(Lq, H, 32)), r(k.view(Lk, H, 32)))
+        if nsrc == 2:
+            s = s + torch.einsum("qhc,khc->hqk", r((q2 * scale).view(Lq, H, 32)), r(k2.view(Lk, H, 32)))
+        if blocked is not None:
+            s = s.masked_fill(blocked.unsqueeze(0), float("-inf"))
+        p = torch.softmax(s, dim=-1)
+        return torch.einsum("hqk,khc->qhc", p, r(v.view(Lk, H, 32))).reshape(Lq, 256)
+
+    with ops.bf16_decoder_scope():
+        out = ops.attention(q.to(d), k.to(d), v.to(d), H, scale, mask_bits=bits, q2=q2.to(d) if nsrc == 2 else None,
+                            k2=k2.to(d) if nsrc == 2 else None).cpu().double()
+    vmax = v.abs().max().item()
+    # rounded-operand model: what remains is the bf16 rounding of the unnormalised probabilities (2^-9 relative each)
+    assert (out - model(True)).abs().max().item() <= 4e-3 * vmax
+    assert (out - model(False)).abs().max().item() <= 3e-2 * vmax
+    fp32 = ops.attention(q.to(d), k.to(d), v.to(d), H, scale, mask_bits=bits, q2=q2.to(d) if nsrc == 2 else None,
+                         k2=k2.to(d) if nsrc == 2 else None).cpu().double()
+    assert (fp32 - model(False)).abs().max().item() <= 2e-4 * vmax                 # the default path is untouched
+
+
+def test_bf16_decoder_stays_close_to_fp32_decoder():
+    """Whole decoder at the benchmark shape in both modes on the same weights: class logits, mask logits and boxes of the
+    bf16 mode within 10 % (logits) / 5 % (boxes) relative L2 of the fp32 mode (thresholded attention masks make single rows diverge, so the
+    distance is taken over the whole tensor), >= 98 % of the final mask bits equal, the same top class on >= 85 % of the queries."""
+    d = dev()
+    dec, _ = _build_decoder()
+    dec.to(d)
+    S, Q, M = 1000, 200, 150
+    room = torch.tensor([8.0, 6.0, 3.0])
+    pos = torch.floor(det_randn("big.pos", (S, 3)).sigmoid() * room / 0.02) * 0.02
+    x = det_randn("big.x", (S, 96))
+    q2d_pos = pos[:M] + det_randn("big.q2dpos", (M, 3), 0.1)
+    q2d_feat = det_randn("big.q2dfeat", (M, 256))
+    lo, hi = pos.min(0)[0] - 0.03, pos.max(0)[0] + 0.05
+    ids = torch.arange(0, S, S // Q)[:Q]
+    t = lambda a: a.to(d)
+    args = ([t(x)], [t(pos)], [t(pos)], [t(x[ids])], [t(pos[ids])], [t(q2d_feat)], [t(q2d_pos)], [(t(lo), t(hi))])
+    ref = dec(*args)
+    dec.compute_dtype = "bf16"
+    out = dec(*args)
+    dec.compute_dtype = "fp32"
+    again = dec(*args)
+    assert torch.equal(again["masks"][0], ref["masks"][0])                         # switching back restores the exact path
+    assert not torch.equal(out["masks"][0], ref["masks"][0])                       # and the bf16 mode really ran
+    stats = {}
+    for k in ("cls_preds", "masks", "centers", "sizes"):
+        r = ref[k][0]
+        stats[k] = ((out[k][0] - r).norm() / r.norm()).item()
+    print("bf16 vs fp32 decoder, relative L2:", {k: round(v, 4) for k, v in stats.items()},
+          "mask bits equal:", round(_mask_agree(out["masks"][0].cpu(), ref["masks"][0].cpu()), 4))
+    for k, tol in (("cls_preds", 1e-1), ("masks", 1e-1), ("centers", 5e-2), ("sizes", 5e-2)):
+        assert stats[k] <= tol, f"{k}: relative L2 distance {stats[k]:.3e} between the bf16 and the fp32 decoder"
+    assert _mask_agree(out["masks"][0].cpu(), ref["masks"][0].cpu()) > 0.98
+    same_cls = (out["cls_preds"][0][:, :-1].argmax(1) == ref["cls_preds"][0][:, :-1].argmax(1)).float().mean().item()
+    assert same_cls >= 0.85, same_cls          # random-weight logits over 198 classes are nearly tied; a trained head separates them
