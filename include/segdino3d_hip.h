@@ -344,6 +344,22 @@ int sd3d_bn_backward(const float* dy, int ld_dy, const float* y, int ld_y, const
 int sd3d_pool_superpoints_backward(const float* dout, int C, const int64_t* superpoints, const uint32_t* sidx, const int32_t* seg_start,
                                    const int32_t* sp_start, int64_t V, float* dfeat, int ld, void* stream);
 
+/* ---------------------------------------------------------------------------------------------
+ * Train-time augmentation, segdino3d/datasets/transform/point_cloud_transforms.py.  The random draws are
+ * the caller's (numpy.random in the reference's order); trans3 / color_* are HOST arrays.
+ *   sd3d_augment_points:   in place on points[:, 0:3]: flip x / y (:112-117), rotate by `angle` about z (points @ rot_mat_T
+ *                          of mmdet3d's rotation_3d_in_axis, :284-300), scale (:312), translate (:255); with color_mean3 also
+ *                          points[:, 3:6] = (rgb - mean) / std (:382-387).  Also used for query2d_pos (ld = 3, no colour).
+ *   sd3d_voxel_units:      coords [n, 3] = points[:, 0:3] / voxel_size (:417)
+ *   sd3d_box_blur3:        scipy.ndimage.convolve(ones(3) / 3 along `axis`, mode="constant") on `grids` volumes (:455-459)
+ *   sd3d_elastic_displace: coords += mag * trilinear(noise [3, D0, D1, D2]) on the grid linspace(-(b-1) gran, (b-1) gran, b)
+ *                          per axis, zero outside (:461-470) */
+int sd3d_augment_points(float* points, int ld, int64_t n, int flip_x, int flip_y, float angle, float scale, const float* trans3,
+                        const float* color_mean3, const float* color_std3, void* stream);
+int sd3d_voxel_units(const float* points, int ld, int64_t n, float voxel_size, float* coords, void* stream);
+int sd3d_box_blur3(const float* in, float* out, int grids, int D0, int D1, int D2, int axis, void* stream);
+int sd3d_elastic_displace(float* coords, int64_t n, const float* noise, int D0, int D1, int D2, float gran, float mag, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -85,6 +85,10 @@ SIGNATURES = {
     "sd3d_bn_apply": (_i, [_p, _i, _p, _p, _p, _p, _p, _i, _l, _i, _i, _p, _i, _p]),
     "sd3d_bn_backward": (_i, [_p, _i, _p, _i, _p, _i, _p, _p, _p, _l, _i, _i, _p, _i, _p, _i, _p, _p, _p, _z, _p]),
     "sd3d_pool_superpoints_backward": (_i, [_p, _i, _p, _p, _p, _p, _l, _p, _i, _p]),
+    "sd3d_augment_points": (_i, [_p, _i, _l, _i, _i, _f, _f, _p, _p, _p, _p]),
+    "sd3d_voxel_units": (_i, [_p, _i, _l, _f, _p, _p]),
+    "sd3d_box_blur3": (_i, [_p, _p, _i, _i, _i, _i, _i, _p]),
+    "sd3d_elastic_displace": (_i, [_p, _l, _p, _i, _i, _i, _f, _f, _p]),
     "sd3d_semantic_loss_ws_bytes": (_z, [_i]),
     "sd3d_semantic_loss": (_i, [_p, _i, _i, _i, _i, _p, _i, _f, _p, _i, _p, _p, _z, _p]),
 }
