@@ -252,14 +252,15 @@ def mink_state_dict_shapes(in_channels=259, conv1_kernel_size=5):
 
 
 def mink_forward_wrapper(sd, points: torch.Tensor, feats2d, superpoints: torch.Tensor, voxel_size=0.02,
-                         mode="early_fusion", prefix="backbone.", conv1_kernel_size=5, order="x_fastest"):
+                         mode="early_fusion", prefix="backbone.", conv1_kernel_size=5, order="x_fastest", elastic=None):
     """forward_wrapper (minkunet.py:603-685), eval (no elastic coords), ONE scene.
     -> (sp_feats [S,96], sp_pos [S,3], sp_pos_wo_elastic [S,3])."""
     xyz = points[:, :3]
     f = points[:, 3:]
     if mode == "early_fusion":
         f = torch.cat([f, feats2d], dim=1)
-    c = floor_voxel(xyz, voxel_size)
+    # train-time: the scene is voxelised at its elastically distorted coordinates (voxel units * voxel_size, :606-608)
+    c = floor_voxel(xyz if elastic is None else elastic.float() * voxel_size, voxel_size)
     uc, inv = unique_voxels(c)
     vf = segment_mean(f, inv, len(uc))
     x = res16unet34c(sd, uc, vf, prefix, conv1_kernel_size, order)
@@ -267,7 +268,10 @@ def mink_forward_wrapper(sd, points: torch.Tensor, feats2d, superpoints: torch.T
     S = int(superpoints.max()) + 1
     sp_feats = segment_mean(x, superpoints.numpy(), S)
     sp_pos = segment_mean(torch.from_numpy(c).float() * voxel_size, superpoints.numpy(), S)
-    return sp_feats, sp_pos, sp_pos.clone()
+    if elastic is None:
+        return sp_feats, sp_pos, sp_pos.clone()
+    c0 = floor_voxel(xyz, voxel_size)                               # :665-682
+    return sp_feats, sp_pos, segment_mean(torch.from_numpy(c0).float() * voxel_size, superpoints.numpy(), S)
 
 
 # ------------------------------------------------------------------------------------------------
@@ -391,12 +395,16 @@ def spconv_state_dict_shapes(num_planes=(32, 64, 96, 128, 160), in_channels=262,
 
 
 def spconv_forward_wrapper(sd, points, feats2d, superpoints, voxel_size=0.02, num_planes=(32, 64, 96, 128, 160),
-                           prefix="backbone.", min_spatial_shape=128):
+                           prefix="backbone.", min_spatial_shape=128, elastic=None):
     """forward_wrapper + collate (spconvunet.py:364-399, 270-362), eval, early_fusion, ONE scene."""
     sd = {k[len(prefix):]: v for k, v in sd.items() if k.startswith(prefix)}
     xyz = points[:, :3]
     f = torch.cat([points[:, 3:], xyz - xyz.mean(0), feats2d], dim=1)
-    c = floor_voxel(xyz - xyz.min(0)[0], voxel_size)
+    if elastic is None:
+        c = floor_voxel(xyz - xyz.min(0)[0], voxel_size)
+    else:                                                           # already in voxel units (spconvunet.py:291-294)
+        el = elastic.float()
+        c = torch.floor(el - el.min(0)[0]).to(torch.int32).numpy()
     uc, inv = unique_voxels(c)
     vf = segment_mean(f, inv, len(uc))
     lv = SpLevels(uc, len(num_planes), min_spatial_shape)
@@ -407,4 +415,7 @@ def spconv_forward_wrapper(sd, points, feats2d, superpoints, voxel_size=0.02, nu
     sp_feats = segment_mean(x[torch.from_numpy(inv)], superpoints.numpy(), S)
     cq = floor_voxel(xyz, voxel_size)
     sp_pos = segment_mean(torch.from_numpy(cq).float() * voxel_size, superpoints.numpy(), S)
-    return sp_feats, sp_pos, sp_pos.clone()
+    if elastic is None:
+        return sp_feats, sp_pos, sp_pos.clone()
+    ce = torch.floor(elastic.float()).to(torch.int32)               # :337-352
+    return sp_feats, segment_mean(ce.float() * voxel_size, superpoints.numpy(), S), sp_pos

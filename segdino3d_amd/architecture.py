@@ -91,9 +91,9 @@ class Baseline3D(nn.Module):
             return None
         scene_range = []
         for i in range(len(targets)):
-            if "elastic_coords" in targets[i]:
-                raise NotImplementedError("elastic_coords (train-time augmentation) is not supported in the eval path")
             pts = samples[i]
+            if "elastic_coords" in targets[i]:                 # boxes and scene range of the distorted scene (:280-281)
+                pts = (targets[i]["elastic_coords"].to(pts.device).float() * self.backbone.voxel_size).contiguous()
             stats = ops.scene_stats(pts)
             scene_range.append((stats[0:3], stats[3:6]))
             masks = targets[i].get("masks") if hasattr(targets[i], "get") else targets[i]["masks"]

@@ -245,10 +245,8 @@ class Res16UNetBase(nn.Module):
 
     @ops.bound_stream
     def forward_wrapper(self, samples: List[torch.Tensor], targets, return_sp_mean_pos=False):
-        feats, pos = [], []
+        feats, pos, pos_wo = [], [], []
         for pts, tgt in zip(samples, targets):
-            if "elastic_coords" in tgt:
-                raise NotImplementedError("elastic_coords (train-time augmentation) is not supported in the eval path")
             ef = tgt["extra_features"]
             pts = pts.float().contiguous()
             sp = ef["super_point_masks"].contiguous()
@@ -256,9 +254,14 @@ class Res16UNetBase(nn.Module):
                 f2d, mode = ef["points_2dfeats"].float().contiguous(), 0
             else:
                 f2d, mode = None, 1
-            maps = SceneMaps(pts, self.voxel_size, 5, shift_to_min=False, order=self.KERNEL_ORDER, superpoints=sp)
+            elastic = tgt["elastic_coords"] if "elastic_coords" in tgt else None
+            geo = pts
+            if elastic is not None:                              # voxelise the elastically distorted scene (:606-608), colours as they are
+                geo = pts.clone()
+                geo[:, :3] = elastic.to(pts.device).float() * self.voxel_size
+            maps = SceneMaps(geo, self.voxel_size, 5, shift_to_min=False, order=self.KERNEL_ORDER, superpoints=sp)
             self.last_maps = maps
-            vf = maps.voxel_features(pts, f2d, mode, _round32(self.in_channels))
+            vf = maps.voxel_features(geo, f2d, mode, _round32(self.in_channels))
             x = self.forward_sparse(maps, vf)
             if self.training:
                 from . import train_ops
@@ -267,10 +270,14 @@ class Res16UNetBase(nn.Module):
                 f, p = maps.pool(x, self.out_planes)
             feats.append(f)
             pos.append(p)
+            if elastic is None:                                  # no distortion: the "without elastic" positions are the same values
+                pos_wo.append(p.clone())
+            elif return_sp_mean_pos:                             # superpoint means of the undistorted voxel coordinates (:665-682)
+                plain = SceneMaps(pts, self.voxel_size, 1, shift_to_min=False, order=self.KERNEL_ORDER, superpoints=sp)
+                pos_wo.append(plain.pool(x.new_zeros((plain.n_vox[0], 4)), 4)[1])
         sp_pos = pos if self.add_positional_embedding else None
         if return_sp_mean_pos:
-            # eval: no elastic distortion, so the "without elastic" positions are the same tensor values
-            return feats, sp_pos, [p.clone() for p in pos]
+            return feats, sp_pos, pos_wo
         return feats, sp_pos, None
 
 

@@ -195,20 +195,24 @@ class SpConvUNet(nn.Module):
 
     @ops.bound_stream
     def forward_wrapper(self, samples: List[torch.Tensor], targets, return_sp_mean_pos=True):
-        feats, pos = [], []
+        feats, pos, pos_wo = [], [], []
         for pts, tgt in zip(samples, targets):
-            if "elastic_coords" in tgt:
-                raise NotImplementedError("elastic_coords (train-time augmentation) is not supported in the eval path")
             ef = tgt["extra_features"]
             pts = pts.float().contiguous()
             f2d = ef["points_2dfeats"].float().contiguous()
             sp = ef["super_point_masks"].contiguous()
             # network coordinates are shifted to start at 0 (:286); superpoint positions are NOT (:344-353)
-            maps = SceneMaps(pts, self.voxel_size, len(self.num_planes), shift_to_min=True, order=self.KERNEL_ORDER,
-                             superpoints=sp, clip_min_shape=self.min_spatial_shape)
+            elastic = tgt["elastic_coords"] if "elastic_coords" in tgt else None
+            if elastic is None:
+                maps = SceneMaps(pts, self.voxel_size, len(self.num_planes), shift_to_min=True, order=self.KERNEL_ORDER,
+                                 superpoints=sp, clip_min_shape=self.min_spatial_shape)
+            else:                                                # distorted coordinates are already in voxel units (:291-294)
+                el = elastic.to(pts.device).float().contiguous()
+                maps = SceneMaps(el, 1.0, len(self.num_planes), shift_to_min=True, order=self.KERNEL_ORDER,
+                                 superpoints=sp, clip_min_shape=self.min_spatial_shape)
             self.last_maps = maps
             cin_pad = (self.in_channels + 31) // 32 * 32
-            vf = maps.voxel_features(pts, f2d, 2, cin_pad)
+            vf = maps.voxel_features(pts, f2d, 2, cin_pad, stats=None if elastic is None else ops.scene_stats(pts))
             x = self.forward_sparse(maps, vf)
             if self.training:
                 from . import train_ops
@@ -219,8 +223,13 @@ class SpConvUNet(nn.Module):
             pos_maps = SceneMaps(pts, self.voxel_size, 1, shift_to_min=False, order=self.KERNEL_ORDER, superpoints=sp)
             _, p = pos_maps.pool(x.new_zeros((pos_maps.n_vox[0], 4)), 4)
             feats.append(f)
-            pos.append(p)
+            pos_wo.append(p)
+            if elastic is None:
+                pos.append(p.clone())
+            else:                                                # mean of floor(elastic) * voxel_size (:337-352)
+                el_maps = SceneMaps(el, 1.0, 1, shift_to_min=False, order=self.KERNEL_ORDER, superpoints=sp)
+                pos.append(el_maps.pool(x.new_zeros((el_maps.n_vox[0], 4)), 4)[1] * self.voxel_size)
         sp_pos = pos if self.add_positional_embedding else None
         if return_sp_mean_pos:
-            return feats, sp_pos, [p.clone() for p in pos]
+            return feats, sp_pos, pos_wo
         return feats, sp_pos

@@ -193,8 +193,11 @@ class SceneMaps:
         return dict(nbr=nbr, density=self.density.get(key), pairs=self.pairs.get(key))
 
     # ------------------------------------------------------------------------------------------
-    def voxel_features(self, points, feats2d, mode: int, ld_out: int) -> torch.Tensor:
-        return ops.voxel_mean(points, feats2d, mode, self.stats, self.sidx, self.seg_start, self.n_vox[0], ld_out)
+    def voxel_features(self, points, feats2d, mode: int, ld_out: int, stats=None) -> torch.Tensor:
+        """`stats`: scene statistics of `points` when they are not the points the maps were built from (elastic coordinates
+        voxelise the scene, the features still come from the undistorted points)."""
+        return ops.voxel_mean(points, feats2d, mode, self.stats if stats is None else stats, self.sidx, self.seg_start,
+                              self.n_vox[0], ld_out)
 
     def pool(self, feat: torch.Tensor, C: int):
         """Fused devoxelise + superpoint mean: ([S,C] features, [S,3] quantised mean positions)."""

@@ -102,3 +102,51 @@ def test_cpu_tensors_are_refused():
     dev()
     with pytest.raises(RuntimeError):
         A.affine_(torch.zeros(4, 6), flip_x=True)
+
+
+def _elastic_scene(n, S, idx):
+    """A synthetic scene pushed through the device train transform (seeded so that the elastic distortion is applied)."""
+    from segdino3d_amd.augment import Scannet200Transforms
+    from segdino3d_amd.synth import make_scene
+    d = dev()
+    pts, tgt = make_scene(idx, n_points=n, n_superpoints=S, n_query2d=20)
+    pts[:, 3:] = (pts[:, 3:] * 40 + 120).clamp(0, 255)               # raw colours, as the loader hands them over
+    pts, tgt = pts.to(d), tgt.to(d)
+    np.random.seed(5)                                                # seed 5: elastic applied (tests/golden/make_golden_aug.py)
+    pts, tgt = Scannet200Transforms("train", voxel_size=0.02)(pts, tgt)
+    assert (tgt["elastic_coords"] - pts[:, :3] / 0.02).abs().max().item() > 5.0
+    return pts, tgt
+
+
+@pytest.mark.parametrize("backbone", ["mink", "spconv"])
+def test_backbones_voxelise_elastic_coordinates_like_the_oracle(backbone):
+    """forward_wrapper with targets['elastic_coords'] (minkunet.py:606-608, 665-682; spconvunet.py:291-294, 337-352):
+    features, distorted superpoint positions and undistorted positions against the oracle."""
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden"))
+    from _det import det_param
+    from oracle import sparse_ref as R
+    d = dev()
+    if backbone == "mink":
+        from segdino3d_amd.backbone_mink import Res16UNet34C
+        pts, tgt = _elastic_scene(20000, 150, 14)
+        m = Res16UNet34C(in_channels=259, out_channels=96, config=dict(dilations=[1, 1, 1, 1], conv1_kernel_size=5, bn_momentum=0.02),
+                         voxel_size=0.02, mode_fuse_2d_feat="early_fusion", add_positional_embedding=True).eval()
+    else:
+        from segdino3d_amd.backbone_spconv import SpConvUNet
+        pts, tgt = _elastic_scene(10000, 100, 15)
+        m = SpConvUNet(num_planes=[32 * (i + 1) for i in range(5)], return_blocks=True, voxel_size=0.02,
+                       mode_fuse_2d_feat="early_fusion", add_positional_embedding=True).eval()
+    sd = {k: det_param("backbone." + k, v.shape).to(v.dtype) for k, v in m.state_dict().items()}
+    m.load_state_dict(sd)
+    m.to(d)
+    f, pos, pos_wo = m.forward_wrapper([pts], [tgt], return_sp_mean_pos=True)
+    ref_sd = {"backbone." + k: v for k, v in sd.items()}
+    fn = R.mink_forward_wrapper if backbone == "mink" else R.spconv_forward_wrapper
+    ef = tgt["extra_features"]
+    rf, rp, rp_wo = fn(ref_sd, pts.cpu(), ef["points_2dfeats"].cpu(), ef["super_point_masks"].cpu(), elastic=tgt["elastic_coords"].cpu())
+    torch.testing.assert_close(pos[0].cpu(), rp, rtol=5e-5, atol=1e-4)
+    torch.testing.assert_close(pos_wo[0].cpu(), rp_wo, rtol=5e-5, atol=1e-4)
+    assert (pos[0].cpu() - pos_wo[0].cpu()).abs().max().item() > 0.1           # the distortion is visible in the positions
+    err = (f[0].cpu() - rf).abs().max().item()
+    assert err <= 2e-3 * max(rf.abs().max().item(), 1.0), f"{backbone}: features differ by {err}"
