@@ -360,6 +360,27 @@ int sd3d_voxel_units(const float* points, int ld, int64_t n, float voxel_size, f
 int sd3d_box_blur3(const float* in, float* out, int grids, int D0, int D1, int D2, int axis, void* stream);
 int sd3d_elastic_displace(float* coords, int64_t n, const float* noise, int D0, int D1, int D2, float gran, float mag, void* stream);
 
+/* ---------------------------------------------------------------------------------------------
+ * Backward pieces of the query decoder; torch autograd over nn.Linear / nn.LayerNorm / elementwise ops in
+ * the reference (instance_seg_3d_decoder.py:640-797).
+ *   sd3d_act_backward:       g[:, :C] = dy * act'(.), g[:, C:C_pad] = 0.  act as in sd3d_gather_gemm; ref = forward OUTPUT for
+ *                            relu / sigmoid, PRE-activation for gelu.  The Linear's input / weight gradients are then
+ *                            sd3d_gather_gemm(g, W^T) and sd3d_pair_wgrad on identity pair lists, its bias gradient sd3d_col_sums(g).
+ *   sd3d_col_sums:           out[c] = sum_r x[r][c], fixed order.
+ *   sd3d_layernorm_backward: for y = act(LayerNorm(x + res) * w + b): dxin = d/d(x + res) [M, D], dw, db (act 0 / 1 = relu).
+ *   sd3d_sine_pe_mod_backward: gradient of sd3d_sine_pe's box modulation w.r.t. mod_num [n, 3] (positions and mod_den are
+ *                            detached in the reference, :740, :753). */
+int sd3d_act_backward(const float* dy, int ld_dy, const float* ref, int ld_ref, int act, int64_t M, int C, int C_pad, float* g, int ld_g,
+                      void* stream);
+size_t sd3d_col_sums_ws_bytes(int64_t M, int C);
+int sd3d_col_sums(const float* x, int ld, int64_t M, int C, float* out, void* ws, size_t ws_bytes, void* stream);
+size_t sd3d_layernorm_backward_ws_bytes(int64_t M, int D);
+int sd3d_layernorm_backward(const float* dy, int ld_dy, const float* y, int ld_y, const float* x, int ld_x, const float* res, int ld_res,
+                            const float* w, float eps, int64_t M, int D, int act, float* dxin, int ld_dx, float* dw, float* db, void* ws,
+                            size_t ws_bytes, void* stream);
+int sd3d_sine_pe_mod_backward(const float* d_out, int ld_do, const float* xyz, int ld_xyz, int64_t n, const float* range, const float* dim_t,
+                              const int8_t* axis, int d_pos, const float* mod_den, int ld_den, float* d_num, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

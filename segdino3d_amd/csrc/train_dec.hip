@@ -1,0 +1,207 @@
+// Backward pieces of the query decoder: activation masks, bias (column) sums, LayerNorm, the box
+// modulation of the sine encoding.  The reference gets all of them from torch autograd over nn.Linear / nn.LayerNorm /
+// elementwise ops (instance_seg_3d_decoder.py:640-797, train_engine_3d.py:104).  The decoder's tensors are small
+// ([<= 3000, <= 1024] fp32): every kernel here is a single streaming pass, reductions in a fixed order.
+#include "common.h"
+#include "../../include/segdino3d_hip.h"
+#include <math.h>
+
+__device__ __forceinline__ float wsum64(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+
+// g = dy * act'(.) with ref = the forward OUTPUT for relu / sigmoid and the PRE-activation for gelu; columns [C, C_pad)
+// of g are zeroed (the GEMMs that consume g want 32-column multiples)
+__global__ __launch_bounds__(256) void act_bwd_kernel(const float* __restrict__ dy, int ld_dy, const float* __restrict__ ref, int ld_ref, int act,
+                                                      int64_t M, int C, int C_pad, float* __restrict__ g, int ld_g) {
+    const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (t >= M * C_pad) return;
+    const int64_t r = t / C_pad;
+    const int c = (int)(t - r * C_pad);
+    float v = 0.f;
+    if (c < C) {
+        v = dy[r * ld_dy + c];
+        if (act == 1) v = ref[r * ld_ref + c] > 0.f ? v : 0.f;
+        else if (act == 2) {                                   // d/dz [0.5 z (1 + erf(z / sqrt 2))]
+            const float z = ref[r * ld_ref + c];
+            v *= 0.5f * (1.f + erff(z * 0.70710678118654752440f)) + z * 0.39894228040143267794f * expf(-0.5f * z * z);
+        } else if (act == 3) { const float y = ref[r * ld_ref + c]; v *= y * (1.f - y); }
+    }
+    g[r * ld_g + c] = v;
+}
+
+// column sums: one workgroup per (64-column group, 1024-row chunk) -> partial[chunk][C]; then a fixed-order final pass
+#define CSUM_ROWS 1024
+__global__ __launch_bounds__(256) void col_sum_partial_kernel(const float* __restrict__ x, int ld, int64_t M, int C, float* __restrict__ partial) {
+    __shared__ float sm[4][64];
+    const int c = blockIdx.x * 64 + (threadIdx.x & 63), rl = threadIdx.x >> 6;
+    const int64_t r0 = (int64_t)blockIdx.y * CSUM_ROWS, r1 = r0 + CSUM_ROWS < M ? r0 + CSUM_ROWS : M;
+    float a = 0.f;
+    if (c < C) for (int64_t r = r0 + rl; r < r1; r += 4) a += x[r * ld + c];
+    sm[rl][threadIdx.x & 63] = a;
+    __syncthreads();
+    if (rl == 0 && c < C) partial[(int64_t)blockIdx.y * C + c] = (sm[0][threadIdx.x] + sm[1][threadIdx.x]) + (sm[2][threadIdx.x] + sm[3][threadIdx.x]);
+}
+__global__ __launch_bounds__(256) void col_sum_final_kernel(const float* __restrict__ partial, int nchunk, int C, float* __restrict__ out) {
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    if (c >= C) return;
+    double a = 0.0;
+    for (int i = 0; i < nchunk; ++i) a += (double)partial[(int64_t)i * C + c];
+    out[c] = (float)a;
+}
+
+// LayerNorm backward, one wave per row (D <= 1024): xin = x + res, xhat = (xin - mean) rstd, g = dy (masked by y > 0 for the
+// fused ReLU);  dxin = rstd (g w - mean(g w) - xhat mean(g w xhat));  gw_out = g, gxh_out = g xhat (column-summed afterwards)
+__global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restrict__ dy, int ld_dy, const float* __restrict__ y, int ld_y,
+                                                            const float* __restrict__ x, int ld_x, const float* __restrict__ res, int ld_res,
+                                                            const float* __restrict__ w, float eps, int64_t M, int D, int act,
+                                                            float* __restrict__ dxin, int ld_dx, float* __restrict__ g_out, float* __restrict__ gxh_out) {
+    const int lane = threadIdx.x & 63;
+    const int64_t r = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (r >= M) return;
+    f32x4 v[4], g[4];
+    float s = 0.f;
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {
+        const int c = (it * 64 + lane) * 4;
+        v[it] = f32x4{0.f, 0.f, 0.f, 0.f}; g[it] = v[it];
+        if (c < D) {
+            v[it] = *(const f32x4*)(x + r * ld_x + c);
+            if (res) v[it] += *(const f32x4*)(res + r * ld_res + c);
+            g[it] = *(const f32x4*)(dy + r * ld_dy + c);
+            if (act == 1) {
+                const f32x4 yy = *(const f32x4*)(y + r * ld_y + c);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) g[it][e] = yy[e] > 0.f ? g[it][e] : 0.f;
+            }
+            s += v[it][0] + v[it][1] + v[it][2] + v[it][3];
+        }
+    }
+    const float mean = wsum64(s) / (float)D;
+    float q = 0.f;
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {
+        const int c = (it * 64 + lane) * 4;
+        if (c < D) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { const float dlt = v[it][e] - mean; q += dlt * dlt; }
+        }
+    }
+    const float rstd = 1.0f / sqrtf(wsum64(q) / (float)D + eps);
+    float a = 0.f, b = 0.f;                                    // sum g w, sum g w xhat
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {
+        const int c = (it * 64 + lane) * 4;
+        if (c < D) {
+            const f32x4 ww = *(const f32x4*)(w + c);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float xh = (v[it][e] - mean) * rstd;
+                a += g[it][e] * ww[e]; b += g[it][e] * ww[e] * xh;
+            }
+        }
+    }
+    a = wsum64(a) / (float)D; b = wsum64(b) / (float)D;
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {
+        const int c = (it * 64 + lane) * 4;
+        if (c < D) {
+            const f32x4 ww = *(const f32x4*)(w + c);
+            f32x4 dx, gx;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float xh = (v[it][e] - mean) * rstd;
+                dx[e] = rstd * (g[it][e] * ww[e] - a - xh * b);
+                gx[e] = g[it][e] * xh;
+            }
+            *(f32x4*)(dxin + r * ld_dx + c) = dx;
+            *(f32x4*)(g_out + r * D + c) = g[it];
+            *(f32x4*)(gxh_out + r * D + c) = gx;
+        }
+    }
+}
+
+// d(mod_num)[r][a] = sum over the channels c of axis a of  d_out[r][c] * pe[r][c] / mod_den[r or 0][a], where
+// pe = out / (mod_num / mod_den) is recomputed as in sine_pe_kernel (dense.hip); positions and denominators are detached
+// in the reference (instance_seg_3d_decoder.py:740, 753), so this is the only gradient of the modulated encoding.
+__global__ __launch_bounds__(256) void sine_pe_mod_bwd_kernel(const float* __restrict__ d_out, int ld_do, const float* __restrict__ xyz, int ld_xyz,
+                                                              int64_t n, const float* __restrict__ rng, const float* __restrict__ dim_t,
+                                                              const int8_t* __restrict__ axis, int d_pos, const float* __restrict__ mod_den,
+                                                              int ld_den, float* __restrict__ d_num) {
+    const int lane = threadIdx.x & 63;
+    const int64_t r = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (r >= n) return;
+    float acc[3] = {0.f, 0.f, 0.f};
+    for (int c = lane; c < d_pos; c += 64) {
+        const int a = axis[c];
+        const float lo = rng[a], hi = rng[3 + a];
+        float p = ((xyz[r * ld_xyz + a] - lo) * 1.0f) / (hi - lo) + 0.0f;
+        p = p * 6.283185307179586f;
+        p = p / dim_t[c];
+        const float pe = (c & 1) ? cosf(p) : sinf(p);
+        const float v = d_out[r * ld_do + c] * pe;
+        acc[0] += a == 0 ? v : 0.f; acc[1] += a == 1 ? v : 0.f; acc[2] += a == 2 ? v : 0.f;
+    }
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+        const float t = wsum64(acc[a]);
+        if (lane == 0) d_num[r * 3 + a] = t / mod_den[(int64_t)r * ld_den + a];
+    }
+}
+
+#define ST ((hipStream_t)stream)
+extern "C" {
+
+int sd3d_act_backward(const float* dy, int ld_dy, const float* ref, int ld_ref, int act, int64_t M, int C, int C_pad, float* g, int ld_g,
+                      void* stream) {
+    if (M <= 0 || C <= 0) return SD3D_OK;
+    if (act < 0 || act > 3 || C_pad < C || ld_g < C_pad || (act != 0 && !ref)) return sd3d_set_error(SD3D_ERR_ARG, "act_backward: bad arguments");
+    act_bwd_kernel<<<(unsigned)cdiv(M * C_pad, 256), 256, 0, ST>>>(dy, ld_dy, ref, ld_ref, act, M, C, C_pad, g, ld_g);
+    SD3D_CHECK_LAUNCH();
+    return SD3D_OK;
+}
+
+size_t sd3d_col_sums_ws_bytes(int64_t M, int C) { return align_up((size_t)cdiv(M, CSUM_ROWS) * C * sizeof(float), 256); }
+
+int sd3d_col_sums(const float* x, int ld, int64_t M, int C, float* out, void* ws, size_t ws_bytes, void* stream) {
+    if (M <= 0 || C <= 0) return sd3d_set_error(SD3D_ERR_ARG, "col_sums: empty input");
+    if (ws_bytes < sd3d_col_sums_ws_bytes(M, C)) return sd3d_set_error(SD3D_ERR_WS, "col_sums: workspace too small");
+    const int nchunk = (int)cdiv(M, CSUM_ROWS);
+    col_sum_partial_kernel<<<dim3((unsigned)cdiv(C, 64), nchunk), 256, 0, ST>>>(x, ld, M, C, (float*)ws);
+    col_sum_final_kernel<<<(unsigned)cdiv(C, 256), 256, 0, ST>>>((const float*)ws, nchunk, C, out);
+    SD3D_CHECK_LAUNCH();
+    return SD3D_OK;
+}
+
+size_t sd3d_layernorm_backward_ws_bytes(int64_t M, int D) { return (size_t)2 * M * D * sizeof(float) + sd3d_col_sums_ws_bytes(M, D); }
+
+int sd3d_layernorm_backward(const float* dy, int ld_dy, const float* y, int ld_y, const float* x, int ld_x, const float* res, int ld_res,
+                            const float* w, float eps, int64_t M, int D, int act, float* dxin, int ld_dx, float* dw, float* db, void* ws,
+                            size_t ws_bytes, void* stream) {
+    if (M <= 0 || D <= 0 || (D & 3) || D > 1024 || (ld_dy & 3) || (ld_x & 3) || (ld_dx & 3) || (res && (ld_res & 3)) || act < 0 || act > 1 ||
+        (act == 1 && (!y || (ld_y & 3))))
+        return sd3d_set_error(SD3D_ERR_ARG, "layernorm_backward: D must be a multiple of 4, <= 1024; strides multiples of 4");
+    if (ws_bytes < sd3d_layernorm_backward_ws_bytes(M, D)) return sd3d_set_error(SD3D_ERR_WS, "layernorm_backward: workspace too small");
+    float* g = (float*)ws;
+    float* gxh = g + (size_t)M * D;
+    void* cws = gxh + (size_t)M * D;
+    const size_t cws_bytes = sd3d_col_sums_ws_bytes(M, D);
+    layernorm_bwd_kernel<<<(unsigned)cdiv(M, 4), 256, 0, ST>>>(dy, ld_dy, y, ld_y, x, ld_x, res, ld_res, w, eps, M, D, act, dxin, ld_dx, g, gxh);
+    SD3D_CHECK_LAUNCH();
+    int rc = sd3d_col_sums(g, D, M, D, db, cws, cws_bytes, stream);
+    if (rc != SD3D_OK) return rc;
+    return sd3d_col_sums(gxh, D, M, D, dw, cws, cws_bytes, stream);
+}
+
+int sd3d_sine_pe_mod_backward(const float* d_out, int ld_do, const float* xyz, int ld_xyz, int64_t n, const float* range, const float* dim_t,
+                              const int8_t* axis, int d_pos, const float* mod_den, int ld_den, float* d_num, void* stream) {
+    if (n <= 0) return SD3D_OK;
+    if (!mod_den) return sd3d_set_error(SD3D_ERR_ARG, "sine_pe_mod_backward: needs the modulation denominator");
+    sine_pe_mod_bwd_kernel<<<(unsigned)cdiv(n, 4), 256, 0, ST>>>(d_out, ld_do, xyz, ld_xyz, n, range, dim_t, axis, d_pos, mod_den, ld_den, d_num);
+    SD3D_CHECK_LAUNCH();
+    return SD3D_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,161 @@
+"""Autograd nodes of the query decoder over HIP kernels (in progress).
+
+The reference differentiates the decoder (`instance_seg_3d_decoder.py:640-797`) with torch autograd over nn.Linear,
+nn.LayerNorm, bmm / softmax attention and elementwise ops.  Here every node is a `torch.autograd.Function` whose forward is
+the eval path's kernel and whose backward runs on the device too:
+
+* `linear`     y = act(x W^T + b (+ res)), optionally on the concatenation [x | x2]:  g = dy act'(.) (`sd3d_act_backward`),
+               dx = g W (`sd3d_gather_gemm` on W^T), dW = g^T x (`sd3d_pair_wgrad` on identity pair lists: the fp32 MFMA
+               kernel of the sparse convolution's weight gradient), db = column sums of g (`sd3d_col_sums`);
+* `layernorm`  y = act(LN(x + res) w + b): `sd3d_layernorm_backward`;
+* `sine_pe_modulated`: gradient w.r.t. the box modulation only (positions and sizes are detached in the reference, `:740, :753`).
+
+torch pads / transposes / concatenates small weight and activation tensors (layout plumbing); no arithmetic of the
+gradients is done by torch.  No CPU fallback.
+"""
+from __future__ import annotations
+
+import torch
+
+from . import _lib, ops, train_ops
+
+_WS = ops._PerThread()
+_IDENTITY = {}
+
+
+def _identity_pairs(n_rows: int, device):
+    key = (n_rows, str(device))
+    if key not in _IDENTITY:
+        nbr = torch.arange(n_rows, dtype=torch.int32, device=device).unsqueeze(0).contiguous()
+        _IDENTITY[key] = ops.pair_lists(nbr, n_rows)
+    return _IDENTITY[key]
+
+
+def _round(n, m):
+    return (n + m - 1) // m * m
+
+
+def act_backward(dy, ref, act, c_pad):
+    lib = _lib.load()
+    M, C = dy.shape
+    g = torch.empty(M, c_pad, dtype=torch.float32, device=dy.device)
+    pd, ldd = ops._rows(dy, "dy")
+    pr, ldr = (None, 0) if ref is None else ops._rows(ref, "ref")
+    _lib.check(lib.sd3d_act_backward(pd, ldd, pr, ldr, ops.ACT[act], M, C, c_pad, g.data_ptr(), c_pad, ops._stream()), "act_backward")
+    return g
+
+
+def col_sums(x):
+    lib = _lib.load()
+    M, C = x.shape
+    px, ld = ops._rows(x, "x")
+    out = torch.empty(C, dtype=torch.float32, device=x.device)
+    nb = lib.sd3d_col_sums_ws_bytes(M, C)
+    ws = _WS.get(nb, x.device)
+    _lib.check(lib.sd3d_col_sums(px, ld, M, C, out.data_ptr(), ws.data_ptr(), ws.numel(), ops._stream()), "col_sums")
+    return out
+
+
+class _Linear(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, w, b, act, res, x2):
+        xd, wd = x.detach(), w.detach()
+        bd = None if b is None else b.detach()
+        kw = dict(x2=None if x2 is None else x2.detach(), shift=bd, res=None if res is None else res.detach())
+        y = ops.gather_gemm(xd, wd, act=act, exact=True, **kw)
+        ref = y
+        if act == "gelu":                                      # its derivative needs the pre-activation
+            ref = ops.gather_gemm(xd, wd, act=None, exact=True, **kw)
+        ctx.save_for_backward(x, w, ref if act is not None else None, x2)
+        ctx.act, ctx.has_b, ctx.has_res = act, b is not None, res is not None
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, w, ref, x2 = ctx.saved_tensors
+        cout, cin = w.shape
+        c_pad = _round(cout, 32)
+        g = act_backward(dy.contiguous(), ref, ctx.act, c_pad)                  # [M, c_pad], zero beyond cout
+        dx = dx2 = dw = db = dres = None
+        if ctx.needs_input_grad[0] or (x2 is not None and ctx.needs_input_grad[5]):
+            wt = torch.zeros(cin, c_pad, dtype=torch.float32, device=w.device)
+            wt[:, :cout] = w.detach().t()
+            dxa = ops.gather_gemm(g, wt, exact=True)                            # [M, cin]
+            if x2 is None:
+                dx = dxa
+            else:
+                c0 = x.shape[1]
+                dx, dx2 = dxa[:, :c0], dxa[:, c0:]
+        if ctx.needs_input_grad[1]:
+            xin = x.detach() if x2 is None else torch.cat([x.detach(), x2.detach()], dim=1)
+            if xin.shape[1] % 4:
+                xin = torch.nn.functional.pad(xin, (0, 4 - xin.shape[1] % 4))
+            dwp = train_ops.pair_wgrad(g, xin.contiguous(), _identity_pairs(g.shape[0], g.device))   # [1, c_pad, cin(+pad)]
+            dw = dwp[0, :cout, :cin]
+        if ctx.has_b and ctx.needs_input_grad[2]:
+            db = col_sums(g)[:cout]
+        if ctx.has_res and ctx.needs_input_grad[4]:
+            dres = g[:, :cout]
+        return dx, dw, db, None, dres, dx2
+
+
+def linear(x, weight, bias=None, act=None, res=None, x2=None):
+    """Differentiable `ops.linear` / two-source `ops.gather_gemm`: weight [Cout, Cin(total)]."""
+    return _Linear.apply(x, weight, bias, act, res, x2)
+
+
+class _LayerNorm(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, w, b, res, act, eps):
+        y = ops.layernorm(x.detach(), w.detach(), b.detach(), res=None if res is None else res.detach(), act=act, eps=eps)
+        ctx.save_for_backward(x, w, res, y if act is not None else None)
+        ctx.act, ctx.eps = act, eps
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        lib = _lib.load()
+        x, w, res, y = ctx.saved_tensors
+        M, D = x.shape
+        dev = x.device
+        dy = dy.contiguous()
+        dxin = torch.empty(M, D, dtype=torch.float32, device=dev)
+        dw, db = torch.empty(D, dtype=torch.float32, device=dev), torch.empty(D, dtype=torch.float32, device=dev)
+        nb = lib.sd3d_layernorm_backward_ws_bytes(M, D)
+        ws = _WS.get(nb, dev)
+        px, ldx = ops._rows(x.detach(), "x")
+        pr, ldr = (None, 0) if res is None else ops._rows(res.detach(), "res")
+        _lib.check(lib.sd3d_layernorm_backward(dy.data_ptr(), D, None if y is None else y.data_ptr(), D, px, ldx, pr, ldr,
+                                               w.detach().contiguous().data_ptr(), float(ctx.eps), M, D, ops.ACT[ctx.act], dxin.data_ptr(), D,
+                                               dw.data_ptr(), db.data_ptr(), ws.data_ptr(), ws.numel(), ops._stream()), "layernorm_backward")
+        return dxin, dw, db, (dxin if res is not None else None), None, None
+
+
+def layernorm(x, weight, bias, res=None, act=None, eps=1e-5):
+    return _LayerNorm.apply(x, weight, bias, res, act, eps)
+
+
+class _SinePEModulated(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, xyz, rng, dim_t, axis, mod_num, mod_den):
+        out = ops.sine_pe(xyz, rng, dim_t, axis, mod_num=mod_num.detach(), mod_den=mod_den)
+        ctx.save_for_backward(xyz, rng, dim_t, axis, mod_den)
+        return out
+
+    @staticmethod
+    def backward(ctx, d_out):
+        lib = _lib.load()
+        xyz, rng, dim_t, axis, mod_den = ctx.saved_tensors
+        n = xyz.shape[0]
+        d_out = d_out.contiguous()
+        d_num = torch.empty(n, 3, dtype=torch.float32, device=xyz.device)
+        px, ldx = ops._rows(xyz, "xyz")
+        ld_den = mod_den.stride(0) if mod_den.dim() == 2 else 0
+        _lib.check(lib.sd3d_sine_pe_mod_backward(d_out.data_ptr(), d_out.shape[1], px, ldx, n, rng.data_ptr(), dim_t.data_ptr(), axis.data_ptr(),
+                                                 dim_t.numel(), mod_den.data_ptr(), ld_den, d_num.data_ptr(), ops._stream()), "sine_pe_mod_backward")
+        return None, None, None, None, d_num, None
+
+
+def sine_pe_modulated(xyz, rng, dim_t, axis, mod_num, mod_den):
+    """`ops.sine_pe` with box modulation, differentiable w.r.t. `mod_num` ([n, 3])."""
+    return _SinePEModulated.apply(xyz, rng, dim_t, axis, mod_num, mod_den)

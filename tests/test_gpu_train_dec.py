@@ -1,0 +1,110 @@
+"""Autograd nodes of the decoder (segdino3d_amd/train_dec.py, csrc/train_dec.hip) against torch float64
+autograd of the same formulas.  Tolerance 2e-5 of the largest entry (fp32 sums over <= 3000 rows / 1024 columns)."""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from _det import det_randn  # noqa: E402
+
+
+def dev():
+    if not torch.cuda.is_available():
+        pytest.skip("needs a HIP device")
+    return torch.device("cuda:0")
+
+
+def close(got, ref, what, tol=2e-5):
+    err = (got.detach().cpu().double() - ref.detach().cpu()).abs().max().item()
+    assert err <= tol * max(ref.abs().max().item(), 1e-3), (what, err, ref.abs().max().item())
+
+
+ACT64 = {None: lambda t: t, "relu": torch.relu, "gelu": torch.nn.functional.gelu, "sigmoid": torch.sigmoid}
+
+
+@pytest.mark.parametrize("M,cin,cout,act,res,concat", [(200, 256, 256, None, False, False), (200, 256, 1024, "gelu", False, False),
+                                                       (200, 1024, 256, None, True, False), (3000, 96, 256, "relu", False, False),
+                                                       (200, 512, 256, None, False, True), (200, 256, 199, None, False, False),
+                                                       (200, 256, 3, "sigmoid", False, False), (37, 256, 201, "relu", True, False)])
+def test_linear_gradients(M, cin, cout, act, res, concat):
+    from segdino3d_amd import train_dec as T
+    d = dev()
+    x = det_randn(f"tl.x{M}{cin}", (M, cin)); w = det_randn(f"tl.w{cin}{cout}", (cout, cin), cin ** -0.5)
+    b = det_randn(f"tl.b{cout}", (cout,), 0.1); r = det_randn(f"tl.r{M}{cout}", (M, cout)) if res else None
+    dy = det_randn(f"tl.dy{M}{cout}", (M, cout))
+    leaves = [t.to(d).requires_grad_(True) for t in (x, w, b)] + ([r.to(d).requires_grad_(True)] if res else [])
+    xd, wd, bd = leaves[:3]
+    if concat:
+        h = cin // 2
+        xa, xb = xd[:, :h].detach().contiguous().requires_grad_(True), xd[:, h:].detach().contiguous().requires_grad_(True)
+        y = T.linear(xa, wd, bd, act=act, x2=xb)
+    else:
+        y = T.linear(xd, wd, bd, act=act, res=leaves[3] if res else None)
+    y.backward(dy.to(d))
+    l64 = [t.double().requires_grad_(True) for t in (x, w, b)] + ([r.double().requires_grad_(True)] if res else [])
+    y64 = ACT64[act](l64[0] @ l64[1].T + l64[2] + (l64[3] if res else 0))
+    y64.backward(dy.double())
+    close(y, y64, "y")
+    if concat:
+        close(torch.cat([xa.grad, xb.grad], 1), l64[0].grad, "dx")
+    else:
+        close(xd.grad, l64[0].grad, "dx")
+    close(wd.grad, l64[1].grad, "dw")
+    close(bd.grad, l64[2].grad, "db")
+    if res:
+        close(leaves[3].grad, l64[3].grad, "dres")
+
+
+@pytest.mark.parametrize("M,D,act,res", [(200, 256, None, True), (3000, 256, "relu", False), (37, 1024, None, True), (5, 96, None, False)])
+def test_layernorm_gradients(M, D, act, res):
+    from segdino3d_amd import train_dec as T
+    d = dev()
+    x = det_randn(f"tn.x{M}{D}", (M, D)) * 2 + 0.5; r = det_randn(f"tn.r{M}{D}", (M, D)) if res else None
+    w = 1 + det_randn(f"tn.w{D}", (D,), 0.1); b = det_randn(f"tn.b{D}", (D,), 0.1)
+    dy = det_randn(f"tn.dy{M}{D}", (M, D))
+    xd, wd, bd = (t.to(d).requires_grad_(True) for t in (x, w, b))
+    rd = r.to(d).requires_grad_(True) if res else None
+    y = T.layernorm(xd, wd, bd, res=rd, act=act)
+    y.backward(dy.to(d))
+    x64, w64, b64 = (t.double().requires_grad_(True) for t in (x, w, b))
+    r64 = r.double().requires_grad_(True) if res else None
+    y64 = torch.nn.functional.layer_norm(x64 + (r64 if res else 0), (D,), w64, b64, 1e-5)
+    if act == "relu":
+        y64 = y64 * (y.detach().cpu() > 0)                      # the fp32 result's own mask (outputs within rounding of 0)
+    y64.backward(dy.double())
+    close(y, y64, "y")
+    close(xd.grad, x64.grad, "dx")
+    close(wd.grad, w64.grad, "dw", 5e-5)
+    close(bd.grad, b64.grad, "db", 5e-5)
+    if res:
+        close(rd.grad, r64.grad, "dres")
+
+
+def test_sine_pe_modulation_gradient():
+    from segdino3d_amd import ops, train_dec as T
+    from segdino3d_amd.decoder import ScanNetQueryDecoder
+    from test_gpu_decoder import DEC_KW
+    d = dev()
+    dec = ScanNetQueryDecoder(**DEC_KW)
+    dim_t, axis = dec.pe_tables(d)
+    n = 200
+    xyz = (det_randn("tp.x", (n, 3)).sigmoid() * torch.tensor([8.0, 6.0, 3.0])).to(d)
+    rng = torch.tensor([0.0, 0.0, 0.0, 8.0, 6.0, 3.0], device=d)
+    num = det_randn("tp.n", (n, 3)).sigmoid().to(d).requires_grad_(True)
+    den = (0.2 + det_randn("tp.d", (n, 3)).sigmoid()).to(d)
+    dy = det_randn("tp.dy", (n, 256)).to(d)
+    out = T.sine_pe_modulated(xyz, rng, dim_t, axis, num, den)
+    out.backward(dy)
+    plain = ops.sine_pe(xyz, rng, dim_t, axis).double()
+    n64 = num.detach().double().requires_grad_(True)
+    coef = (n64 / den.double())[:, axis.long()]                 # [n, 256]: every channel scaled by its axis' coefficient
+    (plain * coef).backward(dy.double())
+    close(out, plain * coef, "out", 1e-5)
+    close(num.grad, n64.grad, "dnum")
+    # one modulation row for all queries (the first layer's broadcast size, ld = 0)
+    den1 = den[:1].contiguous().reshape(3)
+    num2 = num.detach().clone().requires_grad_(True)
+    T.sine_pe_modulated(xyz, rng, dim_t, axis, num2, den1).backward(dy)
+    n64 = num.detach().double().requires_grad_(True)
+    (plain * (n64 / den1.double())[:, axis.long()]).backward(dy.double())
+    close(num2.grad, n64.grad, "dnum broadcast")
