@@ -381,6 +381,19 @@ int sd3d_layernorm_backward(const float* dy, int ld_dy, const float* y, int ld_y
 int sd3d_sine_pe_mod_backward(const float* d_out, int ld_do, const float* xyz, int ld_xyz, int64_t n, const float* range, const float* dim_t,
                               const int8_t* axis, int d_pos, const float* mod_den, int ld_den, float* d_num, void* stream);
 
+/* Attention for training: sd3d_attention that also returns lse [H, Lq] = log sum exp of every masked,
+ * scaled score row, and the backward pass (gradients of attention.py:361-385 / nn.MultiheadAttention, decoder :79):
+ * given out, lse and d_out -> dq0 (dq1), dk0 (dk1), dv with the shapes / strides of their forward tensors.  Exact fp32
+ * MFMA, P recomputed tile by tile, fixed summation order.  ws: sd3d_attention_backward_ws_bytes(Lq, H). */
+int sd3d_attention_lse(const float* q0, int ldq0, const float* q1, int ldq1, const float* k0, int ldk0, const float* k1,
+                       int ldk1, const float* v, int ldv, const uint32_t* mask_bits, int Lq, int Lk, int H, float scale,
+                       float* out, int ldo, float* lse, void* ws, size_t ws_bytes, void* stream);
+size_t sd3d_attention_backward_ws_bytes(int Lq, int H);
+int sd3d_attention_backward(const float* q0, int ldq0, const float* q1, int ldq1, const float* k0, int ldk0, const float* k1, int ldk1,
+                            const float* v, int ldv, const uint32_t* mask_bits, int Lq, int Lk, int H, float scale, const float* out, int ldo,
+                            const float* lse, const float* d_out, int ld_do, float* dq0, int ld_dq0, float* dq1, int ld_dq1, float* dk0,
+                            int ld_dk0, float* dk1, int ld_dk1, float* dv, int ld_dv, void* ws, size_t ws_bytes, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -133,6 +133,7 @@ struct AttnParams {
     int ksplit;                               // key tiles are dealt to gridDim.z workgroups; partials -> part
     float* part;                              // [qtile][head][ksplit][64 + 1024]: m[32], l[32], O[32 dv][32 q]
     int bf16;                                 // 1: Q, K, P, V rounded to bf16 for the two contractions (fp32 accumulate, fp32 softmax)
+    float* lse;                               // optional [H][Lq]: log-sum-exp of every score row (kept for the backward pass)
 };
 
 typedef __bf16 abf16x8 __attribute__((ext_vector_type(8)));
@@ -285,6 +286,7 @@ __global__ __launch_bounds__(512) void attention_kernel(const AttnParams p) {
             dst[64 + dv * 32 + qq] = acc;
         } else if (q0 + qq < p.Lq) {
             p.out[(int64_t)(q0 + qq) * p.ldo + head * 32 + dv] = acc / L;
+            if (p.lse && dv == 0) p.lse[(int64_t)head * p.Lq + q0 + qq] = M + logf(L);
         }
     }
 }
@@ -305,7 +307,10 @@ __global__ __launch_bounds__(256) void attention_merge_kernel(const AttnParams p
             L += b[32 + qq] * f;
             acc += b[64 + dv * 32 + qq] * f;
         }
-        if (q0 + qq < p.Lq) p.out[(int64_t)(q0 + qq) * p.ldo + head * 32 + dv] = acc / L;
+        if (q0 + qq < p.Lq) {
+            p.out[(int64_t)(q0 + qq) * p.ldo + head * 32 + dv] = acc / L;
+            if (p.lse && dv == 0) p.lse[(int64_t)head * p.Lq + q0 + qq] = M + logf(L);
+        }
     }
 }
 

@@ -159,3 +159,55 @@ class _SinePEModulated(torch.autograd.Function):
 def sine_pe_modulated(xyz, rng, dim_t, axis, mod_num, mod_den):
     """`ops.sine_pe` with box modulation, differentiable w.r.t. `mod_num` ([n, 3])."""
     return _SinePEModulated.apply(xyz, rng, dim_t, axis, mod_num, mod_den)
+
+
+_WS_ATT = ops._PerThread()
+_WS_ATT2 = ops._PerThread()
+
+
+class _Attention(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, q, k, v, num_heads, scale, mask_bits, q2, k2):
+        lib = _lib.load()
+        qd, kd, vd = q.detach(), k.detach(), v.detach()
+        pq, ldq = ops._rows(qd, "q"); pk, ldk = ops._rows(kd, "k"); pv, ldv = ops._rows(vd, "v")
+        pq2, ldq2, pk2, ldk2 = None, 0, None, 0
+        if q2 is not None:
+            pq2, ldq2 = ops._rows(q2.detach(), "q2"); pk2, ldk2 = ops._rows(k2.detach(), "k2")
+        Lq, Lk = q.shape[0], k.shape[0]
+        out = torch.empty(Lq, num_heads * 32, dtype=torch.float32, device=q.device)
+        lse = torch.empty(num_heads, Lq, dtype=torch.float32, device=q.device)
+        ws = _WS_ATT.get(lib.sd3d_attention_ws_bytes(Lq, num_heads), q.device)
+        _lib.check(lib.sd3d_attention_lse(pq, ldq, pq2, ldq2, pk, ldk, pk2, ldk2, pv, ldv, ops._ptr(mask_bits, torch.int32, "mask_bits"),
+                                          Lq, Lk, num_heads, float(scale), out.data_ptr(), out.shape[1], lse.data_ptr(), ws.data_ptr(),
+                                          ws.numel(), ops._stream()), "attention_lse")
+        ctx.save_for_backward(q, k, v, q2, k2, mask_bits, out, lse)
+        ctx.H, ctx.scale = num_heads, float(scale)
+        return out
+
+    @staticmethod
+    def backward(ctx, d_out):
+        lib = _lib.load()
+        q, k, v, q2, k2, bits, out, lse = ctx.saved_tensors
+        d_out = d_out.contiguous()
+        Lq, Lk, H = q.shape[0], k.shape[0], ctx.H
+        dev = q.device
+        new = lambda n: torch.empty(n, H * 32, dtype=torch.float32, device=dev)
+        dq, dk, dv = new(Lq), new(Lk), new(Lk)
+        dq2, dk2 = (new(Lq), new(Lk)) if q2 is not None else (None, None)
+        pq, ldq = ops._rows(q.detach(), "q"); pk, ldk = ops._rows(k.detach(), "k"); pv, ldv = ops._rows(v.detach(), "v")
+        pq2, ldq2, pk2, ldk2 = None, 0, None, 0
+        if q2 is not None:
+            pq2, ldq2 = ops._rows(q2.detach(), "q2"); pk2, ldk2 = ops._rows(k2.detach(), "k2")
+        ws = _WS_ATT2.get(lib.sd3d_attention_backward_ws_bytes(Lq, H), dev)
+        W = H * 32
+        _lib.check(lib.sd3d_attention_backward(pq, ldq, pq2, ldq2, pk, ldk, pk2, ldk2, pv, ldv, ops._ptr(bits, torch.int32, "mask_bits"), Lq, Lk, H,
+                                               ctx.scale, out.data_ptr(), W, lse.data_ptr(), d_out.data_ptr(), W, dq.data_ptr(), W,
+                                               ops._ptr(dq2), W, dk.data_ptr(), W, ops._ptr(dk2), W, dv.data_ptr(), W, ws.data_ptr(), ws.numel(),
+                                               ops._stream()), "attention_backward")
+        return dq, dk, dv, None, None, None, dq2, dk2
+
+
+def attention(q, k, v, num_heads, scale, mask_bits=None, q2=None, k2=None):
+    """Differentiable `ops.attention` (fp32): gradients for q, k, v and the optional second source q2 / k2."""
+    return _Attention.apply(q, k, v, num_heads, scale, mask_bits, q2, k2)

@@ -108,3 +108,51 @@ def test_sine_pe_modulation_gradient():
     n64 = num.detach().double().requires_grad_(True)
     (plain * (n64 / den1.double())[:, axis.long()]).backward(dy.double())
     close(num2.grad, n64.grad, "dnum broadcast")
+
+
+@pytest.mark.parametrize("Lq,Lk,nsrc,masked", [(200, 3000, 2, True), (200, 200, 1, False), (200, 301, 1, True), (33, 311, 1, True),
+                                               (500, 700, 2, False), (16, 8, 1, True)])
+def test_attention_gradients(Lq, Lk, nsrc, masked):
+    """dq, dk, dv (and the second score source) against float64 autograd of masked softmax attention; strided views as inputs
+    (the decoder slices q / k / v out of packed projections)."""
+    from segdino3d_amd import train_dec as T
+    d = dev()
+    H = 8
+    pack_q = det_randn(f"ta.q{Lq}", (Lq, 512)); pack_k = det_randn(f"ta.k{Lk}", (Lk, 768))
+    dy = det_randn(f"ta.dy{Lq}", (Lq, 256))
+    blocked, bits = None, None
+    if masked:
+        blocked = det_randn(f"ta.m{Lq}{Lk}", (Lq, Lk)) > 0.3
+        blocked[:, : min(40, Lk - 1)] = True
+        blocked[0] = True; blocked[0, Lk - 1] = False
+        blocked[torch.arange(Lq), torch.arange(Lq) % Lk] = False
+        nw = (Lk + 31) // 32
+        pad = torch.ones(Lq, nw * 32, dtype=torch.bool); pad[:, :Lk] = blocked
+        words = (pad.view(Lq, nw, 32).long() << torch.arange(32)).sum(-1)
+        bits = torch.where(words >= 2 ** 31, words - 2 ** 32, words).to(torch.int32).to(d)
+    scale = (32 * nsrc) ** -0.5
+    pq, pk = pack_q.to(d).requires_grad_(True), pack_k.to(d).requires_grad_(True)
+    q, q2 = pq[:, :256], pq[:, 256:]
+    k, k2, v = pk[:, :256], pk[:, 256:512], pk[:, 512:]
+    out = T.attention(q, k, v, H, scale, mask_bits=bits, q2=q2 if nsrc == 2 else None, k2=k2 if nsrc == 2 else None)
+    out.backward(dy.to(d))
+    q64, k64 = pack_q.double().requires_grad_(True), pack_k.double().requires_grad_(True)
+    s = torch.einsum("qhc,khc->hqk", q64[:, :256].view(Lq, H, 32), k64[:, :256].view(Lk, H, 32))
+    if nsrc == 2:
+        s = s + torch.einsum("qhc,khc->hqk", q64[:, 256:].view(Lq, H, 32), k64[:, 256:512].view(Lk, H, 32))
+    s = s * scale
+    if blocked is not None:
+        s = s.masked_fill(blocked.unsqueeze(0), float("-inf"))
+    ref = torch.einsum("hqk,khc->qhc", torch.softmax(s, -1), k64[:, 512:].view(Lk, H, 32)).reshape(Lq, 256)
+    ref.backward(dy.double())
+    close(out, ref, "out", 2e-5)
+    gq, gk = q64.grad.clone(), k64.grad.clone()
+    if nsrc == 1:
+        assert float(pq.grad[:, 256:].abs().max()) == 0.0 and float(pk.grad[:, 256:512].abs().max()) == 0.0
+    close(pq.grad, gq, "dq", 3e-5)
+    close(pk.grad, gk, "dk / dv", 3e-5)
+    # bit-reproducible
+    pq2 = pack_q.to(d).requires_grad_(True); pk2 = pack_k.to(d).requires_grad_(True)
+    T.attention(pq2[:, :256], pk2[:, :256], pk2[:, 512:], H, scale, mask_bits=bits, q2=pq2[:, 256:] if nsrc == 2 else None,
+                k2=pk2[:, 256:512] if nsrc == 2 else None).backward(dy.to(d))
+    assert torch.equal(pq2.grad, pq.grad) and torch.equal(pk2.grad, pk.grad)
