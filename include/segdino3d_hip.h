@@ -378,6 +378,9 @@ size_t sd3d_layernorm_backward_ws_bytes(int64_t M, int D);
 int sd3d_layernorm_backward(const float* dy, int ld_dy, const float* y, int ld_y, const float* x, int ld_x, const float* res, int ld_res,
                             const float* w, float eps, int64_t M, int D, int act, float* dxin, int ld_dx, float* dw, float* db, void* ws,
                             size_t ws_bytes, void* stream);
+/* backward of sd3d_box_refine w.r.t. the two head outputs (d_center, d_size_out nullable = zero gradient). */
+int sd3d_box_refine_backward(const float* d_center, const float* d_size_out, const float* size, const float* range, int normalize, int64_t Q,
+                             float* d_dc, float* d_ds, void* stream);
 int sd3d_sine_pe_mod_backward(const float* d_out, int ld_do, const float* xyz, int ld_xyz, int64_t n, const float* range, const float* dim_t,
                               const int8_t* axis, int d_pos, const float* mod_den, int ld_den, float* d_num, void* stream);
 

@@ -262,13 +262,13 @@ def decoder_forward(sd, cfg: DecoderCfg, x, sp_pos, sp_pos_wo, q_in, q_pos, q2d_
         queries = w.ln(h + queries, f"ffn_layers.{i}.norm")
         # ---- iterative box refinement (:735-759)
         center = ref_points + w.mlp(queries, f"bbox_embed.{i}", 3)
-        ref_points = center
+        ref_points = center.detach()                    # :740 (matters for gradients only)
         if cfg.add_box_size_pred:
             delta = w.mlp(queries, f"bbox_size_embed.{i}", 3)
             size = torch.sigmoid(inverse_sigmoid(size_q) + delta) if cfg.normalize_box_prediction \
                 else size_q + delta
-            ref_sizes = size
-            size_q = size
+            ref_sizes = size.detach()                   # :753
+            size_q = ref_sizes
         else:
             size = None
         last = i == L - 1

@@ -90,6 +90,7 @@ SIGNATURES = {
     "sd3d_box_blur3": (_i, [_p, _p, _i, _i, _i, _i, _i, _p]),
     "sd3d_elastic_displace": (_i, [_p, _l, _p, _i, _i, _i, _f, _f, _p]),
     "sd3d_act_backward": (_i, [_p, _i, _p, _i, _i, _l, _i, _i, _p, _i, _p]),
+    "sd3d_box_refine_backward": (_i, [_p, _p, _p, _p, _i, _l, _p, _p, _p]),
     "sd3d_col_sums_ws_bytes": (_z, [_l, _i]),
     "sd3d_col_sums": (_i, [_p, _i, _l, _i, _p, _p, _z, _p]),
     "sd3d_layernorm_backward_ws_bytes": (_z, [_l, _i]),

@@ -151,8 +151,33 @@ __global__ __launch_bounds__(256) void sine_pe_mod_bwd_kernel(const float* __res
     }
 }
 
+// backward of box_refine_kernel (dense.hip): d(d_center) = d(center); d(d_size) = d(size_out) * (hi - lo) * s (1 - s) when the
+// sizes are normalised, d(size_out) otherwise.  Reference points and previous sizes are detached in the reference (:740, :753).
+__global__ __launch_bounds__(256) void box_refine_bwd_kernel(const float* __restrict__ d_center, const float* __restrict__ d_size_out,
+                                                             const float* __restrict__ size, const float* __restrict__ rng, int normalize, int64_t Q,
+                                                             float* __restrict__ d_dc, float* __restrict__ d_ds) {
+    const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (t >= Q * 3) return;
+    const int a = (int)(t % 3);
+    if (d_dc) d_dc[t] = d_center ? d_center[t] : 0.f;
+    if (d_ds) {
+        float g = d_size_out ? d_size_out[t] : 0.f;
+        if (normalize) { const float s = size[t]; g *= (rng[3 + a] - rng[a]) * s * (1.f - s); }
+        d_ds[t] = g;
+    }
+}
+
 #define ST ((hipStream_t)stream)
 extern "C" {
+
+int sd3d_box_refine_backward(const float* d_center, const float* d_size_out, const float* size, const float* range, int normalize, int64_t Q,
+                             float* d_dc, float* d_ds, void* stream) {
+    if (Q <= 0) return SD3D_OK;
+    if (d_ds && normalize && !size) return sd3d_set_error(SD3D_ERR_ARG, "box_refine_backward: needs the forward sizes");
+    box_refine_bwd_kernel<<<(unsigned)cdiv(Q * 3, 256), 256, 0, ST>>>(d_center, d_size_out, size, range, normalize, Q, d_dc, d_ds);
+    SD3D_CHECK_LAUNCH();
+    return SD3D_OK;
+}
 
 int sd3d_act_backward(const float* dy, int ld_dy, const float* ref, int ld_ref, int act, int64_t M, int C, int C_pad, float* g, int ld_g,
                       void* stream) {

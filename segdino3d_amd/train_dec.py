@@ -211,3 +211,36 @@ class _Attention(torch.autograd.Function):
 def attention(q, k, v, num_heads, scale, mask_bits=None, q2=None, k2=None):
     """Differentiable `ops.attention` (fp32): gradients for q, k, v and the optional second source q2 / k2."""
     return _Attention.apply(q, k, v, num_heads, scale, mask_bits, q2, k2)
+
+
+class _BoxRefine(torch.autograd.Function):
+    """`ops.box_refine`: (center, size, size_metric); gradients reach d_center and d_size through center / size_metric only
+    (the refined points and sizes that feed the next layer are detached in the reference, `:740, :753`)."""
+
+    @staticmethod
+    def forward(ctx, ref_points, d_center, size_prev, d_size, rng, normalize):
+        center, size, size_metric = ops.box_refine(ref_points, d_center.detach().contiguous(), size_prev,
+                                                   None if d_size is None else d_size.detach().contiguous(), rng, normalize)
+        ctx.save_for_backward(size, rng)
+        ctx.normalize, ctx.has_size, ctx.Q = normalize, d_size is not None, ref_points.shape[0]
+        if size is None:
+            return center, None, None
+        ctx.mark_non_differentiable(size)
+        return center, size, size_metric
+
+    @staticmethod
+    def backward(ctx, d_center, _d_size, d_metric):
+        lib = _lib.load()
+        size, rng = ctx.saved_tensors
+        dev = rng.device
+        d_dc = torch.empty(ctx.Q, 3, dtype=torch.float32, device=dev)
+        d_ds = torch.empty(ctx.Q, 3, dtype=torch.float32, device=dev) if ctx.has_size else None
+        c = None if d_center is None else d_center.contiguous()
+        m = None if d_metric is None else d_metric.contiguous()
+        _lib.check(lib.sd3d_box_refine_backward(ops._ptr(c), ops._ptr(m), ops._ptr(size), rng.data_ptr(), int(ctx.normalize), ctx.Q,
+                                                d_dc.data_ptr(), ops._ptr(d_ds), ops._stream()), "box_refine_backward")
+        return None, d_dc, None, d_ds, None, None
+
+
+def box_refine(ref_points, d_center, size_prev, d_size, rng, normalize):
+    return _BoxRefine.apply(ref_points, d_center, size_prev, d_size, rng, normalize)

@@ -156,3 +156,38 @@ def test_attention_gradients(Lq, Lk, nsrc, masked):
     T.attention(pq2[:, :256], pk2[:, :256], pk2[:, 512:], H, scale, mask_bits=bits, q2=pq2[:, 256:] if nsrc == 2 else None,
                 k2=pk2[:, 256:512] if nsrc == 2 else None).backward(dy.to(d))
     assert torch.equal(pq2.grad, pq.grad) and torch.equal(pk2.grad, pk.grad)
+
+
+def test_decoder_training_gradients_match_reference():
+    """The whole query decoder in training mode on the device (autograd nodes over HIP kernels) against the gradients of the
+    REFERENCE decoder itself (tests/golden/decoder_grad_s96_q16.npz: reference autograd, train mode, same weights / inputs):
+    every parameter's gradient norm and leading entries, d/d(superpoint features), d/d(query features), within 2e-3 (fp32;
+    the float32 oracle sits at the same distance, tests/test_decoder_grad_oracle.py)."""
+    from decoder_grad_case import Z, compare, objective
+    from test_gpu_decoder import _build_decoder
+    from test_oracle_golden import load
+    d = dev()
+    g = load("decoder_s96_q16")
+    dec, _ = _build_decoder()
+    dec.to(d).train()
+    dec.return_hidden_states = False
+    ids = g["query_ids"].long()
+    x = g["x"].detach().clone().to(d).requires_grad_(True)
+    q = g["x"].detach()[ids].clone().to(d).requires_grad_(True)
+    t = lambda a: a.to(d)
+    out = dec([x], [t(g["pos"])], [t(g["pos_wo"])], [q], [t(g["pos"][ids])], [t(g["q2d_feat"])], [t(g["q2d_pos"])], [(t(g["lo"]), t(g["hi"]))])
+    assert "hidden_states" not in out
+    assert torch.equal(out["masks"][0].detach().cpu() > 0, torch.from_numpy(Z["masks"]) > 0), "mask signs differ: gradients are not comparable"
+    pick = lambda o: {k: (None if o.get(k) is None or o[k][0] is None else o[k][0]) for k in ("cls_preds", "masks", "centers", "sizes", "sem_preds")}
+    sets = [pick(a) for a in out["aux_outputs"]] + [pick(out)]
+    obj = objective(sets)
+    obj.backward()
+    grads = {n: p.grad for n, p in dec.named_parameters()}
+    worst = compare(grads, x.grad, q.grad, obj.detach().cpu(), 2e-3)
+    print("worst parameter gradient error vs the reference:", worst)
+    # eval mode afterwards is the untouched forward path
+    dec.eval()
+    with torch.no_grad():
+        again = dec([x.detach()], [t(g["pos"])], [t(g["pos_wo"])], [q.detach()], [t(g["pos"][ids])], [t(g["q2d_feat"])], [t(g["q2d_pos"])],
+                    [(t(g["lo"]), t(g["hi"]))])
+    assert (again["masks"][0] - out["masks"][0].detach()).abs().max().item() < 1e-4
