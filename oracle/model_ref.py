@@ -35,3 +35,28 @@ def forward_eval(sd, points, feats2d, superpoints, q2d_feat, q2d_pos, gt_masks=N
         return res, dict(sp_feat=sp_feat, sp_pos=sp_pos, decoder=out, query_ids=ids, lo=lo, hi=hi,
                          instance_centers=centers, instance_sizes=sizes)
     return res
+
+
+def forward_train(sd, points, feats2d, superpoints, q2d_feat, q2d_pos, gt_masks, labels, sp_inst_sem_masks, query_ids, loss_cfg,
+                  dec_cfg: D.DecoderCfg = None, mode_3d_center="median", voxel_size=0.02):
+    """Training-mode `Baseline3D.forward` (baseline3d.py:308-346) for ONE scene, differentiable: backbone with batch-statistics
+    BatchNorm, the given query subset (`_select_queries` :250-264 draws it at random), decoder with auxiliary outputs, criterion.
+    Test infrastructure: torch autograd of this function is the reference for the device training step."""
+    from . import loss_ref as L
+    dec_cfg = dec_cfg or D.DecoderCfg()
+    lo, hi, centers, sizes = P.scene_range_and_gt_boxes(points[:, :3], gt_masks, mode_3d_center)
+    R.BN_TRAIN = True
+    try:
+        sp_feat, sp_pos, sp_pos_wo = R.mink_forward_wrapper(sd, points, feats2d, superpoints, voxel_size)
+    finally:
+        R.BN_TRAIN = False
+    sp_pos, sp_pos_wo = sp_pos.to(points.dtype), sp_pos_wo.to(points.dtype)
+    q, qpos = sp_feat[query_ids], sp_pos[query_ids]
+    out = D.decoder_forward(sd, dec_cfg, sp_feat, sp_pos, sp_pos_wo, q, qpos, q2d_feat, q2d_pos, lo, hi)
+    layer = lambda o: dict(cls_preds=[o["cls_preds"]], sem_preds=[o.get("sem_preds")], masks=[o["masks"]], scores=[None],
+                           centers=[o["centers"]], sizes=[o["sizes"]])
+    pred = layer(out)
+    pred["aux_outputs"] = [layer(a) for a in out["aux"]]
+    target = dict(sp_inst_sem_masks=sp_inst_sem_masks, query_inst_sem_masks=sp_inst_sem_masks[:, query_ids], labels=labels,
+                  instance_centers=centers, instance_sizes=sizes)
+    return L.unified_criterion(pred, [target], loss_cfg), out

@@ -118,10 +118,25 @@ class Baseline3D(nn.Module):
         return self.decoder(sp_features_3d, sp_pos, sp_pos_wo_elastic, queries, queries_pos, query2d_feat, query2d_pos,
                             scene_range)
 
-    # ---- _select_queries (:207-264), eval branches -----------------------------------------------------
+    # ---- _select_queries (:207-264) ------------------------------------------------------------------
     def _select_queries(self, x, x_pos=None, targets=None):
-        if self.training:
-            raise NotImplementedError("segdino3d_amd: training-time query sampling (SURVEY.md 8(f-1)) is not built")
+        if self.training:                                        # random subset of the superpoints as queries (:250-264)
+            queries, queries_pos = [], ([] if x_pos is not None else None)
+            for i in range(len(x)):
+                if self.query_thr < 1:
+                    n = (1 - self.query_thr) * torch.rand(1) + self.query_thr       # host RNG, like the reference
+                    n = (n * len(x[i])).int()
+                    ids = torch.randperm(len(x[i]))[:n].to(x[i].device)
+                    queries.append(x[i][ids])
+                    targets[i].query_inst_sem_masks = targets[i].sp_inst_sem_masks[:, ids]
+                    if x_pos is not None:
+                        queries_pos.append(x_pos[i][ids])
+                else:
+                    queries.append(x[i])
+                    targets[i].query_inst_sem_masks = targets[i].sp_inst_sem_masks
+                    if x_pos is not None:
+                        queries_pos.append(x_pos[i])
+            return queries, queries_pos, targets
         if self.query_num == -1:
             return x, x_pos, targets
         queries, queries_pos = [], ([] if self.add_positional_embedding else None)
@@ -141,19 +156,17 @@ class Baseline3D(nn.Module):
     # ---- forward (:308-346) --------------------------------------------------------------------------------
     @ops.bound_stream
     def forward(self, samples, targets: List = None):
-        if self.training:
-            raise NotImplementedError("segdino3d_amd: eval-mode forward only; of the training step (SURVEY.md 8(f-1)) the criterion "
-                                      "(`model.criterion(outputs, targets)`) and the sparse-convolution backward are built, the "
-                                      "backward of the decoder is not")
         samples = [s.float().contiguous() for s in samples]
         scene_range = self.get_extra_instance_data(samples, targets, self.add_positional_embedding,
                                                    self.decoder.add_box_size_pred)
         sp_features_3d, sp_pos, sp_pos_wo_elastic = self.forward_backbone(samples, targets)
         queries, queries_pos, targets = self._select_queries(sp_features_3d, sp_pos, targets)
-        self.decoder.return_hidden_states = True
+        self.decoder.return_hidden_states = not self.training
         self.decoder.return_aux_outputs = True
         outputs = self.forward_decoder(sp_features_3d, sp_pos, sp_pos_wo_elastic, queries, queries_pos, targets, scene_range)
         self.last_outputs = outputs
+        if self.training:                                        # {"seg_loss", "inst_loss"}, gradients attached (:346)
+            return self.criterion(outputs, targets)
         pred = self.predict_by_feat(samples, outputs, targets[0]["extra_features"]["super_point_masks"])  # bs = 1 (:335)
         targets[0].pred_pts_seg = pred[0]
         return targets

@@ -89,3 +89,35 @@ def make_scene(scene_idx: int = 0, n_points: int = 150_000, n_superpoints: int =
         points = points.to(device)
         target = target.to(device)
     return points, target
+
+
+def add_training_targets(points: torch.Tensor, target, n_instances: int = 12, n_semantic: int = 200, n_instance_classes: int = 198,
+                         seed: int = 0):
+    """Superpoint-coherent instance / semantic labels for the training step (the reference's losses are NaN
+    unless every superpoint carries one label): every superpoint goes to the nearest of `n_instances` random object centres
+    (or to "no object" when it is far from all of them).  Adds the keys `Baseline3D.forward` and the criterion read:
+    `masks` [G, N, 1] bool, `labels` [G], `sp_inst_sem_masks` [G + n_semantic + 1, S] bool (`scannet200.py:246-253`)."""
+    g = torch.Generator().manual_seed(4321 + seed)
+    sp = target.extra_features["super_point_masks"].cpu()
+    xyz = points[:, :3].cpu()
+    S = int(sp.max()) + 1
+    cnt = torch.bincount(sp, minlength=S).clamp(min=1).float()
+    ctr = torch.zeros(S, 3).index_add_(0, sp, xyz) / cnt[:, None]
+    seeds = ctr[torch.randperm(S, generator=g)[:n_instances]]
+    dist = torch.cdist(ctr, seeds)
+    owner = dist.argmin(1)
+    owner[dist.min(1)[0] > 1.5] = n_instances                     # background superpoints
+    keep = [k for k in range(n_instances) if bool((owner == k).any())]
+    inst = torch.stack([owner == k for k in keep])                 # [G, S]
+    G = inst.shape[0]
+    labels = torch.randint(0, n_instance_classes, (G,), generator=g)
+    sem_of = torch.randint(2, n_semantic, (G + 1,), generator=g)   # classes 0 / 1 = stuff (wall, floor)
+    sem_id = torch.full((S,), n_semantic, dtype=torch.long)        # unlabeled unless it belongs to something
+    for j, k in enumerate(keep):
+        sem_id[owner == k] = sem_of[j]
+    sem_id[(owner == n_instances) & (ctr[:, 2] < 0.3)] = 1
+    sem = torch.stack([sem_id == c for c in range(n_semantic + 1)])
+    target.sp_inst_sem_masks = torch.cat([inst, sem]).to(points.device)
+    target.masks = inst[:, sp].unsqueeze(-1).to(points.device)
+    target.labels = labels.to(points.device)
+    return target

@@ -191,3 +191,82 @@ def test_decoder_training_gradients_match_reference():
         again = dec([x.detach()], [t(g["pos"])], [t(g["pos_wo"])], [q.detach()], [t(g["pos"][ids])], [t(g["q2d_feat"])], [t(g["q2d_pos"])],
                     [(t(g["lo"]), t(g["hi"]))])
     assert (again["masks"][0] - out["masks"][0].detach()).abs().max().item() < 1e-4
+
+
+def test_full_model_training_step_matches_float64_oracle():
+    """`model.train(); losses = model(samples, targets); (seg + inst).backward()` on the device against the oracle's training
+    forward (oracle/model_ref.forward_train: backbone with batch statistics -> query subset -> decoder -> criterion) in float64
+    with torch autograd: both losses and the gradient of EVERY parameter of backbone and decoder (relative L2).
+    The backbone's ReLUs are dropped on both sides (train_ops.TrainBackend.IGNORE_ACT): a smooth backbone keeps the decoder's
+    thresholded attention masks and the matcher's choices identical between float32 and float64, so the comparison is exact
+    up to rounding; the ReLU path itself is covered by test_gpu_train_ops."""
+    import segdino3d_amd as seg
+    from oracle import decoder_ref as D, model_ref as MR, sparse_ref as R
+    from segdino3d_amd import train_ops
+    from segdino3d_amd.configs import scannet200_model_cfg
+    from segdino3d_amd.synth import add_training_targets, make_scene
+    d = dev()
+    torch.manual_seed(0)
+    model = seg.build_architecture(scannet200_model_cfg(query_num=200)).to(d).train()
+    sd = {k: v.detach().cpu().clone() for k, v in model.state_dict().items()}
+    pts, tgt = make_scene(21, n_points=20000, n_superpoints=150, n_query2d=20)
+    tgt = add_training_targets(pts, tgt, n_instances=8, seed=1)
+    cpu = dict(pts=pts.clone(), f2d=tgt.extra_features["points_2dfeats"].clone(), sp=tgt.extra_features["super_point_masks"].clone(),
+               q2d_feat=tgt.extra_features["query2d_feats"].clone(), q2d_pos=tgt.extra_features["query2d_pos"].clone(),
+               masks=tgt.masks.clone(), labels=tgt.labels.clone(), spm=tgt.sp_inst_sem_masks.clone())
+    pts_d, tgt_d = pts.to(d), tgt.to(d)
+    train_ops.TrainBackend.IGNORE_ACT = True
+    try:
+        torch.manual_seed(7)
+        losses = model([pts_d], [tgt_d])
+        (losses["seg_loss"] + losses["inst_loss"]).backward()
+    finally:
+        train_ops.TrainBackend.IGNORE_ACT = False
+    # the query subset the model drew (baseline3d.py:252-254)
+    S = 150
+    torch.manual_seed(7)
+    n = ((1 - model.query_thr) * torch.rand(1) + model.query_thr)
+    ids = torch.randperm(S)[: int((n * S).int())]
+    assert model.last_outputs["masks"][0].shape[0] == len(ids)
+    sd64 = {k: (v.double().requires_grad_(True) if v.is_floating_point() else v) for k, v in sd.items()}
+    ic = model.criterion.inst_criterion
+    loss_cfg = dict(matcher="sparse", topk=ic.topk, cost_weights=ic.cost_weights, loss_weight=ic.loss_weight, num_classes=ic.num_classes,
+                    num_semantic_classes=model.criterion.num_semantic_classes, sem_ignore_index=model.criterion.sem_criterion.ignore_index,
+                    sem_loss_weight=model.criterion.sem_criterion.loss_weight, non_object_weight=ic.class_weight[-1],
+                    fix_dice_loss_weight=ic.fix_dice_loss_weight, iter_matcher=ic.iter_matcher, fix_mean_loss=ic.fix_mean_loss)
+    relu = torch.relu
+    torch.relu = lambda t: t                                       # the oracle backbone's ReLUs (decoder_ref uses F.relu / torch.relu too:
+    try:                                                           # patch only while the backbone runs)
+        R.BN_TRAIN = True
+        sp_feat, sp_pos, sp_pos_wo = R.mink_forward_wrapper(sd64, cpu["pts"].double(), cpu["f2d"].double(), cpu["sp"])
+    finally:
+        R.BN_TRAIN = False
+        torch.relu = relu
+    orig = R.mink_forward_wrapper
+    R.mink_forward_wrapper = lambda *a, **k: (sp_feat, sp_pos, sp_pos_wo)      # forward_train reuses the smooth backbone's output
+    try:
+        ref, out64 = MR.forward_train(sd64, cpu["pts"].double(), cpu["f2d"].double(), cpu["sp"], cpu["q2d_feat"].double(), cpu["q2d_pos"].double(),
+                                      cpu["masks"], cpu["labels"], cpu["spm"], ids, loss_cfg, dec_cfg=D.DecoderCfg())
+    finally:
+        R.mink_forward_wrapper = orig
+    same_bits = torch.equal(model.last_outputs["masks"][0].detach().cpu() > 0, out64["masks"].detach() > 0)
+    assert same_bits, "mask signs differ between the float32 device run and the float64 oracle: gradients are not comparable"
+    (ref["seg_loss"] + ref["inst_loss"]).backward()
+    for k in ("seg_loss", "inst_loss"):
+        assert abs(float(losses[k].detach()) - float(ref[k].detach())) <= 2e-4 * abs(float(ref[k].detach())), (k, float(losses[k]), float(ref[k]))
+    rows = []
+    for name, p in model.named_parameters():
+        r = sd64[name].grad
+        if r is None or float(r.norm()) == 0.0:
+            assert p.grad is None or float(p.grad.abs().max()) < 1e-6, f"{name} has a gradient the oracle does not produce"
+            continue
+        assert p.grad is not None, name
+        rows.append((_rel(p.grad.cpu(), r), float(r.norm()), name))
+    floor = 1e-2 * sorted(r[1] for r in rows)[len(rows) // 2]       # key biases: true gradient zero (softmax shift invariance)
+    worst = sorted(((e * n / max(n, floor), name) for e, n, name in rows), reverse=True)
+    print(f"{len(rows)} parameters; worst relative L2 gradient error vs the float64 oracle: {worst[:3]}")
+    assert worst[0][0] <= 2e-3, worst[:6]
+
+
+def _rel(a, b):
+    return ((a.double() - b).norm() / b.norm().clamp(min=1e-30)).item()
