@@ -1,4 +1,5 @@
-"""Baseline3D: eval-mode forward of SegDINO3D on the MI355X kernels (host side).
+"""Baseline3D: forward of SegDINO3D on the MI355X kernels (host side); eval mode = the benchmarked inference path, training
+mode = the same forward with autograd nodes over HIP kernels + the criterion.
 
 Mirrors the reference operator interface `segdino3d/models/architecture/baseline3d.py:144-556`:
 same constructor kwargs (:146-160), same attributes (`backbone`, `decoder`, `criterion`, `test_cfg`,

@@ -12,7 +12,8 @@ Mirrors the reference operator interface `segdino3d/models/backbone/minkunet.py`
 The nn.Module tree only HOLDS parameters; all arithmetic runs in libsegdino3d_hip.so:
 conv + folded BatchNorm + ReLU (+ residual) = one `gather_gemm` launch per convolution, skip
 concatenations are never materialised (two input pointers), devoxelise + superpoint mean is one
-fused kernel.  Eval mode only (training step = SURVEY.md 8(f-1), not built yet).
+fused kernel.  `.train()` runs the same network definition on train_ops.TrainBackend (batch-statistics BatchNorm,
+autograd nodes over HIP kernels).
 """
 from __future__ import annotations
 

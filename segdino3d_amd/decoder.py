@@ -186,7 +186,7 @@ class ScanNetQueryDecoder(nn.Module):
         if d_model != num_heads * 32:
             unsupported.append("attention heads must be 32 channels wide (d_model == 32 * num_heads)")
         if dropout != 0.0:
-            unsupported.append("dropout must be 0 (eval-mode forward only)")
+            unsupported.append("dropout must be 0 (the shipped configs use 0.0; dropout kernels are not built)")
         if add_dinox_query_ca and not add_dinox_query_ca_mask:
             unsupported.append("add_dinox_query_ca requires add_dinox_query_ca_mask")
         if box_modulate_ca:
@@ -377,7 +377,7 @@ class ScanNetQueryDecoder(nn.Module):
     # ---- one scene, non-positional variant (Baseline_ScanNet200 prototype; :693, :711, :733) ---------
     def _forward_scene_plain(self, x, q_in):
         if self.training:
-            raise NotImplementedError("segdino3d_amd decoder: eval-mode forward only (training step not built)")
+            raise NotImplementedError("segdino3d_amd decoder: the non-positional variant is built for eval mode only")
         d, H, L = self.d_model, self.num_heads, self.num_layers
         pk = self.packed()
         x, q_in = x.contiguous(), q_in.contiguous()

@@ -114,6 +114,47 @@ for n_pts, n_sp in ((150000, 3000), (20000, 400)):
         rows[f"{n_pts}_points"]["cpu_threads"] = torch.get_num_threads()
         R.BN_TRAIN = False
 out["res16unet34c_training_step"] = rows
+
+# ---------------------------------------------------------------- whole training step (BASELINE configs[4] shape, one scene, fp32)
+import segdino3d_amd as seg
+from segdino3d_amd.configs import scannet200_model_cfg
+from segdino3d_amd.synth import add_training_targets
+torch.manual_seed(0)
+model = seg.build_architecture(scannet200_model_cfg(query_num=200)).to(d).train()
+steps = {}
+for n_pts, n_sp, n_inst in ((150000, 3000, 40), (20000, 400, 10)):
+    pts_s, tgt_s = make_scene(5, n_pts, n_sp, 300 if n_pts > 50000 else 50)
+    tgt_s = add_training_targets(pts_s, tgt_s, n_instances=n_inst, seed=2)
+    pd, td = pts_s.to(d), tgt_s.to(d)
+
+    def train_step():
+        for p_ in model.parameters():
+            p_.grad = None
+        for k_ in ("query_inst_sem_masks", "instance_centers", "instance_sizes"):
+            td.__dict__.pop(k_, None)
+        losses = model([pd], [td])
+        (losses["seg_loss"] + losses["inst_loss"]).backward()
+        return losses
+
+    ms = timeit(train_step, 5)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    with torch.no_grad():
+        for p_ in model.parameters():
+            p_.grad = None
+    fwd_only = []
+    for _ in range(3):
+        e0.record()
+        with torch.no_grad():
+            for k_ in ("query_inst_sem_masks", "instance_centers", "instance_sizes"):
+                td.__dict__.pop(k_, None)
+            model([pd], [td])
+        e1.record(); torch.cuda.synchronize()
+        fwd_only.append(e0.elapsed_time(e1))
+    l = train_step()
+    steps[f"{n_pts}_points"] = dict(ms_forward_loss_backward=round(ms, 2), ms_forward_loss_no_grad=round(min(fwd_only), 2),
+                                    queries=int(model.last_outputs["masks"][0].shape[0]), objects=int(td.labels.shape[0]),
+                                    seg_loss=round(float(l["seg_loss"]), 4), inst_loss=round(float(l["inst_loss"]), 4))
+out["full_model_training_step"] = steps
 print(json.dumps(out, indent=1))
 os.makedirs("gpurun_out", exist_ok=True)
 json.dump(out, open("gpurun_out/perf_train.json", "w"), indent=1)
