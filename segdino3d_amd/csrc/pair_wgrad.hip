@@ -171,10 +171,14 @@ __global__ __launch_bounds__(256) void pair_wgrad_reduce_kernel(const float* __r
     }
 }
 
-static int wgrad_ranges(int Cin, int Cout) {
+// tile ranges (= workgroups per output block): enough to fill the chip, never more than there are tiles (a 200-row Linear of
+// the decoder has two tiles: 768 ranges would leave 766 empty slots for pass 2 to scan)
+static int wgrad_ranges(int Cin, int Cout, int64_t p_cap) {
     const int blocks = (int)(cdiv(Cout, 128) * cdiv(Cin, 128));
     int r = 768 / blocks;
-    return r < 32 ? 32 : r;
+    r = r < 32 ? 32 : r;
+    const int64_t tiles = p_cap / PT;
+    return (int)(tiles < r ? (tiles > 0 ? tiles : 1) : r);
 }
 
 #define ST ((hipStream_t)stream)
@@ -189,7 +193,7 @@ int sd3d_pair_out_rows(const int32_t* pos, int K, int64_t M, int64_t p_cap, int3
 }
 
 size_t sd3d_pair_wgrad_ws_bytes(int K, int Cin, int Cout) {
-    const size_t slots = (size_t)wgrad_ranges(Cin, Cout) + K;
+    const size_t slots = (size_t)wgrad_ranges(Cin, Cout, (int64_t)1 << 40) + K;          // the most any p_cap can ask for
     return align_up(slots * sizeof(int32_t), 256) + slots * (size_t)Cin * Cout * sizeof(float);
 }
 
@@ -200,7 +204,7 @@ int sd3d_pair_wgrad(const float* dy, int ld_dy, const float* x, int ld_x, const 
     if ((Cin & 3) || (Cout & 3) || (ld_dy & 3) || (ld_x & 3)) return sd3d_set_error(SD3D_ERR_ARG, "pair_wgrad: channel counts and row strides must be multiples of 4");
     if (p_cap <= 0 || (p_cap % PT)) return sd3d_set_error(SD3D_ERR_ARG, "pair_wgrad: p_cap must be a positive multiple of 128");
     if (ws_bytes < sd3d_pair_wgrad_ws_bytes(K, Cin, Cout)) return sd3d_set_error(SD3D_ERR_WS, "pair_wgrad: workspace too small");
-    const int ranges = wgrad_ranges(Cin, Cout);
+    const int ranges = wgrad_ranges(Cin, Cout, p_cap);
     WGParams p;
     p.dy = dy; p.ld_dy = ld_dy; p.x = x; p.ld_x = ld_x; p.in_idx = in_idx; p.out_idx = out_idx; p.tile_k = tile_k;
     p.n_tiles = (int)(p_cap / PT); p.Cin = Cin; p.Cout = Cout;
@@ -217,7 +221,10 @@ int sd3d_pair_wgrad(const float* dy, int ld_dy, const float* x, int ld_x, const 
     WG_CASE(4, 1) WG_CASE(4, 2) WG_CASE(4, 3) WG_CASE(4, 4)
 #undef WG_CASE
     const int64_t elems = (int64_t)Cin * Cout;
-    pair_wgrad_reduce_kernel<<<dim3((unsigned)(cdiv(elems, 256) < 64 ? cdiv(elems, 256) : 64), K), 256, 0, ST>>>(p.wpart, p.slot_k, p.n_slots, elems, dw, accumulate);
+    int64_t gx = cdiv(elems, 256);                           // ~2048 workgroups over all offsets: a K = 1 Linear gets as many as a 27-offset convolution
+    const int64_t cap = 2048 / K > 64 ? 2048 / K : 64;
+    gx = gx < cap ? gx : cap;
+    pair_wgrad_reduce_kernel<<<dim3((unsigned)gx, K), 256, 0, ST>>>(p.wpart, p.slot_k, p.n_slots, elems, dw, accumulate);
     SD3D_CHECK_LAUNCH();
     return SD3D_OK;
 }

@@ -32,8 +32,8 @@ __global__ __launch_bounds__(256) void act_bwd_kernel(const float* __restrict__ 
     g[r * ld_g + c] = v;
 }
 
-// column sums: one workgroup per (64-column group, 1024-row chunk) -> partial[chunk][C]; then a fixed-order final pass
-#define CSUM_ROWS 1024
+// column sums: one workgroup per (64-column group, 64-row chunk) -> partial[chunk][C]; then a fixed-order final pass
+#define CSUM_ROWS 64
 __global__ __launch_bounds__(256) void col_sum_partial_kernel(const float* __restrict__ x, int ld, int64_t M, int C, float* __restrict__ partial) {
     __shared__ float sm[4][64];
     const int c = blockIdx.x * 64 + (threadIdx.x & 63), rl = threadIdx.x >> 6;

@@ -78,8 +78,11 @@ class _Linear(torch.autograd.Function):
         g = act_backward(dy.contiguous(), ref, ctx.act, c_pad)                  # [M, c_pad], zero beyond cout
         dx = dx2 = dw = db = dres = None
         if ctx.needs_input_grad[0] or (x2 is not None and ctx.needs_input_grad[5]):
-            wt = torch.zeros(cin, c_pad, dtype=torch.float32, device=w.device)
-            wt[:, :cout] = w.detach().t()
+            if c_pad == cout:
+                wt = w.detach().t().contiguous()
+            else:
+                wt = torch.zeros(cin, c_pad, dtype=torch.float32, device=w.device)
+                wt[:, :cout] = w.detach().t()
             dxa = ops.gather_gemm(g, wt, exact=True)                            # [M, cin]
             if x2 is None:
                 dx = dxa
