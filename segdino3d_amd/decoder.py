@@ -82,14 +82,6 @@ class _FFNHolder(nn.Module):
         self.norm = nn.LayerNorm(d_model)
 
 
-def ws_ca(dec):
-    return [m.attn.in_proj_weight.detach() for m in dec.cross_attn_layers]
-
-
-def bs_ca(dec):
-    return [m.attn.in_proj_bias.detach() for m in dec.cross_attn_layers]
-
-
 class _EvalF:
     """The decoder's differentiable building blocks in eval mode: straight calls into the forward kernels."""
 
@@ -289,8 +281,10 @@ class ScanNetQueryDecoder(nn.Module):
                     pk[nm + "_kv_w"] = [w[d:].contiguous() for w in ws]
                     pk[nm + "_kv_b"] = [b[d:].contiguous() for b in bs]
                 # all layers' key/value projections of the (layer-invariant) superpoint features in one GEMM
-                pk["ca_kv_all_w"] = torch.cat([w[d:2 * d] for w in ws_ca(self)] + [w[2 * d:] for w in ws_ca(self)]).contiguous()
-                pk["ca_kv_all_b"] = torch.cat([b[d:2 * d] for b in bs_ca(self)] + [b[2 * d:] for b in bs_ca(self)]).contiguous()
+                wca = [det(m.attn.in_proj_weight) for m in self.cross_attn_layers]
+                bca = [det(m.attn.in_proj_bias) for m in self.cross_attn_layers]
+                pk["ca_kv_all_w"] = torch.cat([w[d:2 * d] for w in wca] + [w[2 * d:] for w in wca]).contiguous()
+                pk["ca_kv_all_b"] = torch.cat([b[d:2 * d] for b in bca] + [b[2 * d:] for b in bca]).contiguous()
                 if not live:
                     self._packed = pk
                 return pk
@@ -376,32 +370,31 @@ class ScanNetQueryDecoder(nn.Module):
 
     # ---- one scene, non-positional variant (Baseline_ScanNet200 prototype; :693, :711, :733) ---------
     def _forward_scene_plain(self, x, q_in):
-        if self.training:
-            raise NotImplementedError("segdino3d_amd decoder: the non-positional variant is built for eval mode only")
         d, H, L = self.d_model, self.num_heads, self.num_layers
-        pk = self.packed()
+        F = _F()
+        pk = self.packed_train() if self.training else self.packed()
         x, q_in = x.contiguous(), q_in.contiguous()
-        inst = ops.layernorm(_lin(x, self.input_proj[0]), self.input_proj[1].weight, self.input_proj[1].bias, act="relu")
+        inst = F.layernorm(_lin(x, self.input_proj[0]), self.input_proj[1].weight, self.input_proj[1].bias, act="relu")
         mask_feats = _lin(_lin(x, self.x_mask[0], act="relu"), self.x_mask[2])
         queries = _lin(_lin(q_in, self.query_proj[0], act="relu"), self.query_proj[2])
         cls, sem, logits, bits = self._head(queries, mask_feats, False)
         aux = [dict(cls_preds=cls, sem_preds=None, masks=logits, centers=None, sizes=None)]
-        kv_all = ops.linear(inst, pk["ca_kv_all_w"], pk["ca_kv_all_b"])          # [S, 2*L*d]: k_0..k_{L-1} | v_0..v_{L-1}
+        kv_all = F.linear(inst, pk["ca_kv_all_w"], pk["ca_kv_all_b"])          # [S, 2*L*d]: k_0..k_{L-1} | v_0..v_{L-1}
         scale = (d // H) ** -0.5
         for i in range(L):
             ca, sa, ffn = self.cross_attn_layers[i], self.self_attn_layers[i], self.ffn_layers[i]
-            q = ops.linear(queries, pk["ca_q_w"][i], pk["ca_q_b"][i])
-            a = ops.attention(q, kv_all[:, i * d:(i + 1) * d], kv_all[:, (L + i) * d:(L + i + 1) * d], H, scale, mask_bits=bits)
+            q = F.linear(queries, pk["ca_q_w"][i], pk["ca_q_b"][i])
+            a = F.attention(q, kv_all[:, i * d:(i + 1) * d], kv_all[:, (L + i) * d:(L + i + 1) * d], H, scale, mask_bits=bits)
             if ca.fix:
-                queries = ops.layernorm(_lin(a, ca.attn.out_proj), ca.norm.weight, ca.norm.bias, res=queries)
+                queries = F.layernorm(_lin(a, ca.attn.out_proj), ca.norm.weight, ca.norm.bias, res=queries)
             else:
                 queries = _lin(a, ca.attn.out_proj, res=queries)
-            qkv = ops.linear(queries, sa.attn.in_proj_weight, sa.attn.in_proj_bias)      # [Q, 3d]
-            a = ops.attention(qkv[:, :d], qkv[:, d:2 * d], qkv[:, 2 * d:], H, scale)
-            queries = ops.layernorm(_lin(a, sa.attn.out_proj), sa.norm.weight, sa.norm.bias, res=queries)
+            qkv = F.linear(queries, sa.attn.in_proj_weight, sa.attn.in_proj_bias)      # [Q, 3d]
+            a = F.attention(qkv[:, :d], qkv[:, d:2 * d], qkv[:, 2 * d:], H, scale)
+            queries = F.layernorm(_lin(a, sa.attn.out_proj), sa.norm.weight, sa.norm.bias, res=queries)
             hdn = _lin(queries, ffn.net[0], act=("relu" if self.activation_fn == "relu" else "gelu"))
             hdn = _lin(hdn, ffn.net[3], res=queries)
-            queries = ops.layernorm(hdn, ffn.norm.weight, ffn.norm.bias)
+            queries = F.layernorm(hdn, ffn.norm.weight, ffn.norm.bias)
             cls, sem, logits, bits = self._head(queries, mask_feats, i == L - 1)
             aux.append(dict(cls_preds=cls, sem_preds=sem, masks=logits, centers=None, sizes=None))
         final = aux.pop()

@@ -270,3 +270,41 @@ def test_full_model_training_step_matches_float64_oracle():
 
 def _rel(a, b):
     return ((a.double() - b).norm() / b.norm().clamp(min=1e-30)).item()
+
+
+def test_plain_decoder_training_gradients_match_float64_oracle():
+    """Non-positional decoder variant (Baseline_ScanNet200 prototype) in training mode against float64 autograd of the oracle."""
+    from oracle import decoder_ref as D
+    from segdino3d_amd.decoder import ScanNetQueryDecoder
+    from test_gpu_decoder import DEC_KW
+    from test_oracle_golden import load, plain_decoder_state_dict
+    d = dev()
+    g = load("decoder_plain_s40")
+    kw = {k: v for k, v in DEC_KW.items() if k not in ("add_box_size_pred", "add_positional_embedding", "pos_type",
+                                                         "temperature", "box_modulate_ca", "normalize_box_prediction")}
+    kw["add_dinox_query_ca"] = False
+    dec = ScanNetQueryDecoder(**kw)
+    sd = plain_decoder_state_dict()
+    dec.load_state_dict({k[len("decoder."):]: v for k, v in sd.items()})
+    dec.to(d).train()
+    x = g["x"].detach().clone().to(d).requires_grad_(True)
+    q = g["x"].detach().clone().to(d).requires_grad_(True)
+    out = dec([x], None, None, [q], None, None, None, None)
+    sets = [dict(cls_preds=a["cls_preds"][0], masks=a["masks"][0]) for a in out["aux_outputs"]] + \
+           [dict(cls_preds=out["cls_preds"][0], masks=out["masks"][0], sem_preds=out["sem_preds"][0])]
+    from decoder_grad_case import objective
+    objective(sets).backward()
+    sd64 = {k: (v.double().requires_grad_(True) if v.is_floating_point() else v) for k, v in sd.items()}
+    x64 = g["x"].detach().clone().double().requires_grad_(True)
+    q64 = g["x"].detach().clone().double().requires_grad_(True)
+    cfg = D.DecoderCfg(add_positional_embedding=False, add_dinox_query_ca=False, add_box_size_pred=False, box_modulate_ca=False)
+    ref = D.decoder_forward(sd64, cfg, x64, None, None, q64, None, None, None, None, None)
+    assert torch.equal(out["masks"][0].detach().cpu() > 0, ref["masks"].detach() > 0)
+    sets64 = [dict(cls_preds=a["cls_preds"], masks=a["masks"]) for a in ref["aux"][:len(sets) - 1]] + \
+             [dict(cls_preds=ref["cls_preds"], masks=ref["masks"], sem_preds=ref["sem_preds"])]
+    objective(sets64).backward()
+    close(x.grad, x64.grad, "dx", 1e-4)
+    close(q.grad, q64.grad, "dq", 1e-4)
+    worst = sorted(((_rel(p.grad.cpu(), sd64["decoder." + n].grad), n) for n, p in dec.named_parameters()
+                    if sd64["decoder." + n].grad is not None and float(sd64["decoder." + n].grad.norm()) > 1e-6), reverse=True)
+    assert worst[0][0] <= 1e-3, worst[:5]
