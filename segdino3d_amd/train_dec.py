@@ -24,11 +24,17 @@ _IDENTITY = {}
 
 
 def _identity_pairs(n_rows: int, device):
+    """Pair lists of the identity table [1, n_rows] (a Linear is a 1-offset convolution); the query count changes from step
+    to step (random subset), so the cache is bounded."""
     key = (n_rows, str(device))
-    if key not in _IDENTITY:
+    hit = _IDENTITY.pop(key, None)
+    if hit is None:
         nbr = torch.arange(n_rows, dtype=torch.int32, device=device).unsqueeze(0).contiguous()
-        _IDENTITY[key] = ops.pair_lists(nbr, n_rows)
-    return _IDENTITY[key]
+        hit = ops.pair_lists(nbr, n_rows)
+        while len(_IDENTITY) >= 32:
+            _IDENTITY.pop(next(iter(_IDENTITY)))
+    _IDENTITY[key] = hit                                       # most recently used last
+    return hit
 
 
 def _round(n, m):
