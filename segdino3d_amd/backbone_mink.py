@@ -244,38 +244,59 @@ class Res16UNetBase(nn.Module):
             return self._plan.run(maps, vox_feats)
         return self._network(plan.EagerBackend(maps), pk, vox_feats)
 
+    def _scene_inputs(self, pts, tgt):
+        """-> (maps, voxel features, undistorted points, superpoints, elastic?) of one scene (`:604-630`)."""
+        ef = tgt["extra_features"]
+        pts = pts.float().contiguous()
+        sp = ef["super_point_masks"].contiguous()
+        if self.mode_fuse_2d_feat == "early_fusion":
+            f2d, mode = ef["points_2dfeats"].float().contiguous(), 0
+        else:
+            f2d, mode = None, 1
+        elastic = tgt["elastic_coords"] if "elastic_coords" in tgt else None
+        geo = pts
+        if elastic is not None:                                  # voxelise the elastically distorted scene (:606-608), colours as they are
+            geo = pts.clone()
+            geo[:, :3] = elastic.to(pts.device).float() * self.voxel_size
+        maps = SceneMaps(geo, self.voxel_size, 5, shift_to_min=False, order=self.KERNEL_ORDER, superpoints=sp)
+        vf = maps.voxel_features(geo, f2d, mode, _round32(self.in_channels))
+        return maps, vf, pts, sp, elastic
+
+    def _positions_wo_elastic(self, pts, sp, x):
+        """superpoint means of the undistorted voxel coordinates (:665-682)"""
+        plain = SceneMaps(pts, self.voxel_size, 1, shift_to_min=False, order=self.KERNEL_ORDER, superpoints=sp)
+        return plain.pool(x.new_zeros((plain.n_vox[0], 4)), 4)[1]
+
     @ops.bound_stream
     def forward_wrapper(self, samples: List[torch.Tensor], targets, return_sp_mean_pos=False):
         feats, pos, pos_wo = [], [], []
-        for pts, tgt in zip(samples, targets):
-            ef = tgt["extra_features"]
-            pts = pts.float().contiguous()
-            sp = ef["super_point_masks"].contiguous()
-            if self.mode_fuse_2d_feat == "early_fusion":
-                f2d, mode = ef["points_2dfeats"].float().contiguous(), 0
-            else:
-                f2d, mode = None, 1
-            elastic = tgt["elastic_coords"] if "elastic_coords" in tgt else None
-            geo = pts
-            if elastic is not None:                              # voxelise the elastically distorted scene (:606-608), colours as they are
-                geo = pts.clone()
-                geo[:, :3] = elastic.to(pts.device).float() * self.voxel_size
-            maps = SceneMaps(geo, self.voxel_size, 5, shift_to_min=False, order=self.KERNEL_ORDER, superpoints=sp)
-            self.last_maps = maps
-            vf = maps.voxel_features(geo, f2d, mode, _round32(self.in_channels))
-            x = self.forward_sparse(maps, vf)
+        scenes = [self._scene_inputs(p, t) for p, t in zip(samples, targets)]
+        if self.training and len(scenes) > 1:
+            # one block-diagonal tensor for the whole batch, as ME's batch_sparse_collate builds (:624-627): convolutions stay
+            # within their scene, every BatchNorm sees the voxels of all scenes
+            from . import train_ops
+            from .sparse import BatchedMaps
+            batch = BatchedMaps([s[0] for s in scenes])
+            self.last_maps = scenes[-1][0]
+            x_all = self.forward_sparse(batch, torch.cat([s[1] for s in scenes], dim=0))
+            outs = [x_all[slice(*batch.rows(0, i))] for i in range(len(scenes))]
+        else:
+            outs = []
+            for maps, vf, _, _, _ in scenes:
+                self.last_maps = maps
+                outs.append(self.forward_sparse(maps, vf))
+        for (maps, _, pts, sp, elastic), x in zip(scenes, outs):
             if self.training:
                 from . import train_ops
-                f, p = train_ops.pool_superpoints(x, maps, self.out_planes)
+                f, p = train_ops.pool_superpoints(x.contiguous(), maps, self.out_planes)
             else:
                 f, p = maps.pool(x, self.out_planes)
             feats.append(f)
             pos.append(p)
             if elastic is None:                                  # no distortion: the "without elastic" positions are the same values
                 pos_wo.append(p.clone())
-            elif return_sp_mean_pos:                             # superpoint means of the undistorted voxel coordinates (:665-682)
-                plain = SceneMaps(pts, self.voxel_size, 1, shift_to_min=False, order=self.KERNEL_ORDER, superpoints=sp)
-                pos_wo.append(plain.pool(x.new_zeros((plain.n_vox[0], 4)), 4)[1])
+            elif return_sp_mean_pos:
+                pos_wo.append(self._positions_wo_elastic(pts, sp, x))
         sp_pos = pos if self.add_positional_embedding else None
         if return_sp_mean_pos:
             return feats, sp_pos, pos_wo

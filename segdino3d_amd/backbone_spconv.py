@@ -196,6 +196,7 @@ class SpConvUNet(nn.Module):
     @ops.bound_stream
     def forward_wrapper(self, samples: List[torch.Tensor], targets, return_sp_mean_pos=True):
         feats, pos, pos_wo = [], [], []
+        scenes = []
         for pts, tgt in zip(samples, targets):
             ef = tgt["extra_features"]
             pts = pts.float().contiguous()
@@ -203,6 +204,7 @@ class SpConvUNet(nn.Module):
             sp = ef["super_point_masks"].contiguous()
             # network coordinates are shifted to start at 0 (:286); superpoint positions are NOT (:344-353)
             elastic = tgt["elastic_coords"] if "elastic_coords" in tgt else None
+            el = None
             if elastic is None:
                 maps = SceneMaps(pts, self.voxel_size, len(self.num_planes), shift_to_min=True, order=self.KERNEL_ORDER,
                                  superpoints=sp, clip_min_shape=self.min_spatial_shape)
@@ -210,13 +212,25 @@ class SpConvUNet(nn.Module):
                 el = elastic.to(pts.device).float().contiguous()
                 maps = SceneMaps(el, 1.0, len(self.num_planes), shift_to_min=True, order=self.KERNEL_ORDER,
                                  superpoints=sp, clip_min_shape=self.min_spatial_shape)
-            self.last_maps = maps
             cin_pad = (self.in_channels + 31) // 32 * 32
             vf = maps.voxel_features(pts, f2d, 2, cin_pad, stats=None if elastic is None else ops.scene_stats(pts))
-            x = self.forward_sparse(maps, vf)
+            scenes.append((maps, vf, pts, sp, el))
+        if self.training and len(scenes) > 1:
+            # the batch as one block-diagonal tensor (spconv's batched SparseConvTensor, :378-379): BatchNorm over all scenes
+            from .sparse import BatchedMaps
+            batch = BatchedMaps([s[0] for s in scenes])
+            self.last_maps = scenes[-1][0]
+            x_all = self.forward_sparse(batch, torch.cat([s[1] for s in scenes], dim=0))
+            outs = [x_all[slice(*batch.rows(0, i))] for i in range(len(scenes))]
+        else:
+            outs = []
+            for maps, vf, _, _, _ in scenes:
+                self.last_maps = maps
+                outs.append(self.forward_sparse(maps, vf))
+        for (maps, _, pts, sp, el), x in zip(scenes, outs):
             if self.training:
                 from . import train_ops
-                f, _ = train_ops.pool_superpoints(x, maps, x.shape[1])
+                f, _ = train_ops.pool_superpoints(x.contiguous(), maps, x.shape[1])
             else:
                 f, _ = maps.pool(x, x.shape[1])
             # positions: mean of floor(xyz / voxel) * voxel with the UN-shifted coordinates
@@ -224,7 +238,7 @@ class SpConvUNet(nn.Module):
             _, p = pos_maps.pool(x.new_zeros((pos_maps.n_vox[0], 4)), 4)
             feats.append(f)
             pos_wo.append(p)
-            if elastic is None:
+            if el is None:
                 pos.append(p.clone())
             else:                                                # mean of floor(elastic) * voxel_size (:337-352)
                 el_maps = SceneMaps(el, 1.0, 1, shift_to_min=False, order=self.KERNEL_ORDER, superpoints=sp)

@@ -18,7 +18,7 @@ launches) are read back together with the overflow flag and the superpoint count
 """
 from __future__ import annotations
 
-from typing import Dict, Optional, Tuple
+from typing import Sequence, Dict, Optional, Tuple
 
 import os
 
@@ -216,3 +216,44 @@ class SceneMaps:
             out[("down", lvl)] = int((d >= 0).sum())
             out[("up", lvl)] = int((u >= 0).sum())
         return out
+
+
+class BatchedMaps:
+    """Several scenes as ONE block-diagonal sparse tensor, for the training step: MinkowskiEngine collates the scenes of a batch
+    into one tensor (`minkunet.py:624-627`), convolutions never cross scenes, but every BatchNorm takes its statistics over the
+    voxels of ALL scenes.  Rows of level l are the scenes' rows one after the other; a neighbour table is the scenes' tables
+    side by side with the input indices shifted by the scene's row offset of the INPUT level, and gets its own pair lists.
+    Implements the part of SceneMaps the network definitions and `train_ops` use."""
+
+    def __init__(self, maps: Sequence["SceneMaps"]):
+        self.maps = list(maps)
+        self.device = self.maps[0].device
+        n_levels = len(self.maps[0].n_vox)
+        self.offsets = [[0] for _ in range(n_levels)]
+        for m in self.maps:
+            for l in range(n_levels):
+                self.offsets[l].append(self.offsets[l][-1] + int(m.n_vox[l]))
+        self.n_vox = [self.offsets[l][-1] for l in range(n_levels)]
+        self._tables: Dict[Tuple, dict] = {}
+
+    def prepare(self, same=(), strides=()):
+        for m in self.maps:
+            m.prepare(same=same, strides=strides)
+
+    def rows(self, level: int, i: int):
+        return self.offsets[level][i], self.offsets[level][i + 1]
+
+    def conv_table(self, kind: str, level: int, ksize: int = 0) -> dict:
+        key = (kind, level, ksize) if kind == "same" else (kind, level)
+        if key not in self._tables:
+            in_level = level if kind == "same" else (level if kind == "down" else level + 1)
+            parts, cap = [], 0
+            for i, m in enumerate(self.maps):
+                t = m.conv_table(kind, level, ksize)
+                nbr = t["nbr"]
+                off = self.offsets[in_level][i]
+                parts.append(torch.where(nbr >= 0, nbr + off, nbr) if off else nbr)
+                cap += int(t["pairs"].p_cap) if t.get("pairs") is not None else int(nbr.numel())
+            nbr_cat = torch.cat(parts, dim=1).contiguous()
+            self._tables[key] = dict(nbr=nbr_cat, density=None, pairs=ops.pair_lists(nbr_cat, cap))
+        return self._tables[key]

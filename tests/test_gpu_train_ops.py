@@ -258,3 +258,99 @@ def test_spconvunet_backward_without_relu_matches_float64_oracle():
     assert (f[0].detach().cpu().double() - rf.detach()).abs().max().item() <= 2e-4 * max(rf.abs().max().item(), 1.0)
     worst = sorted(((_rel(p.grad.cpu(), rsd["backbone." + n].grad), n) for n, p in m.named_parameters()), reverse=True)
     assert worst[0][0] <= 2e-4, f"parameter gradients differ: {worst[:5]}"
+
+
+def test_batched_training_uses_batch_statistics_like_minkowski():
+    """Two scenes in one training batch: ME collates them into ONE sparse tensor (minkunet.py:624-627), so every BatchNorm takes
+    its statistics over the voxels of both scenes while convolutions stay inside their scene.  Oracle: the single-scene network
+    on the union of the two voxel sets, the second shifted by 16384 voxels (a multiple of every tensor stride: no neighbour
+    relation crosses, the coarse levels stay aligned).  ReLUs dropped on both sides (smooth network, see above)."""
+    import os, sys
+    import numpy as np
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden"))
+    from _det import det_param
+    from oracle import sparse_ref as R
+    from segdino3d_amd import train_ops
+    from segdino3d_amd.backbone_mink import Res16UNet34C
+    from segdino3d_amd.synth import make_scene
+    d = dev()
+    scenes = [make_scene(40, n_points=9000, n_superpoints=90, n_query2d=10), make_scene(41, n_points=12000, n_superpoints=110, n_query2d=10)]
+    m = Res16UNet34C(in_channels=259, out_channels=96, config=dict(dilations=[1, 1, 1, 1], conv1_kernel_size=5, bn_momentum=0.02),
+                     voxel_size=0.02, mode_fuse_2d_feat="early_fusion", add_positional_embedding=True)
+    sd = {k: det_param("backbone." + k, v.shape).to(v.dtype) for k, v in m.state_dict().items()}
+    m.load_state_dict(sd)
+    m.to(d).train()
+    g = torch.Generator().manual_seed(3)
+    train_ops.TrainBackend.IGNORE_ACT = True
+    try:
+        feats, _, _ = m.forward_wrapper([p.to(d) for p, _ in scenes], [t.to(d) for _, t in scenes], return_sp_mean_pos=True)
+        R_w = [torch.randn(f.shape, generator=g) for f in feats]
+        sum((f * w.to(d)).sum() for f, w in zip(feats, R_w)).backward()
+    finally:
+        train_ops.TrainBackend.IGNORE_ACT = False
+    # ---- oracle on the union
+    rsd = {"backbone." + k: (v.double().requires_grad_(True) if v.is_floating_point() else v) for k, v in sd.items()}
+    ucs, invs, vfs = [], [], []
+    for i, (pts, tgt) in enumerate(scenes):
+        tgt = tgt.to("cpu")
+        c = R.floor_voxel(pts[:, :3], 0.02)
+        uc, inv = R.unique_voxels(c)
+        f = torch.cat([pts[:, 3:], tgt.extra_features["points_2dfeats"]], dim=1).double()
+        vfs.append(R.segment_mean(f, inv, len(uc)))
+        ucs.append(uc + np.array([16384 * i, 0, 0], dtype=uc.dtype))
+        invs.append(inv)
+    R.BN_TRAIN = True
+    relu = torch.relu
+    torch.relu = lambda t: t
+    try:
+        x = R.res16unet34c(rsd, np.concatenate(ucs), torch.cat(vfs), "backbone.", 5, "x_fastest")
+    finally:
+        R.BN_TRAIN = False
+        torch.relu = relu
+    n0 = len(ucs[0])
+    ref_feats = []
+    for i, (pts, tgt) in enumerate(scenes):
+        xi = x[:n0] if i == 0 else x[n0:]
+        sp = tgt.extra_features["super_point_masks"].cpu()
+        ref_feats.append(R.segment_mean(xi[torch.from_numpy(invs[i])], sp.numpy(), int(sp.max()) + 1))
+    sum((f * w.double()).sum() for f, w in zip(ref_feats, R_w)).backward()
+    for f, r in zip(feats, ref_feats):
+        assert (f.detach().cpu().double() - r.detach()).abs().max().item() <= 2e-4 * max(r.abs().max().item(), 1.0)
+    worst = sorted(((_rel(p.grad.cpu(), rsd["backbone." + n].grad), n) for n, p in m.named_parameters()), reverse=True)
+    assert worst[0][0] <= 2e-4, f"parameter gradients differ: {worst[:5]}"
+    # and the batch statistics really differ from per-scene statistics: one scene alone gives other features
+    m.zero_grad()
+    train_ops.TrainBackend.IGNORE_ACT = True
+    try:
+        alone, _, _ = m.forward_wrapper([scenes[0][0].to(d)], [scenes[0][1].to(d)], return_sp_mean_pos=True)
+    finally:
+        train_ops.TrainBackend.IGNORE_ACT = False
+    assert (alone[0].detach() - feats[0].detach()).abs().max().item() > 1e-3
+
+
+def test_spconv_batched_training_runs_on_one_block_diagonal_tensor():
+    """SpConvUNet with two scenes in training mode: batch-wide BatchNorm statistics (the features of a scene depend on its
+    batch mate), gradients reach every parameter, and one scene alone still matches the single-scene path."""
+    import os, sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden"))
+    from _det import det_param
+    from segdino3d_amd.backbone_spconv import SpConvUNet
+    from segdino3d_amd.synth import make_scene
+    d = dev()
+    scenes = [make_scene(50, n_points=6000, n_superpoints=60, n_query2d=10), make_scene(51, n_points=8000, n_superpoints=70, n_query2d=10)]
+    m = SpConvUNet(num_planes=[32 * (i + 1) for i in range(5)], return_blocks=True, voxel_size=0.02,
+                   mode_fuse_2d_feat="early_fusion", add_positional_embedding=True)
+    sd = {k: det_param("backbone." + k, v.shape).to(v.dtype) for k, v in m.state_dict().items()}
+    m.load_state_dict(sd)
+    m.to(d).train()
+    both, pos, pos_wo = m.forward_wrapper([p.to(d) for p, _ in scenes], [t.to(d) for _, t in scenes], return_sp_mean_pos=True)
+    sum((f * f).mean() for f in both).backward()
+    assert all(p.grad is not None and bool(torch.isfinite(p.grad).all()) for p in m.parameters())
+    assert both[0].shape == (60, 32) and both[1].shape == (70, 32) and pos[1].shape == (70, 3)
+    alone, _, _ = m.forward_wrapper([scenes[0][0].to(d)], [scenes[0][1].to(d)], return_sp_mean_pos=True)
+    assert (alone[0].detach() - both[0].detach()).abs().max().item() > 1e-4      # other statistics
+    m.eval()
+    with torch.no_grad():
+        e2, _, _ = m.forward_wrapper([p.to(d) for p, _ in scenes], [t.to(d) for _, t in scenes], return_sp_mean_pos=True)
+        e1, _, _ = m.forward_wrapper([scenes[1][0].to(d)], [scenes[1][1].to(d)], return_sp_mean_pos=True)
+    assert torch.equal(e2[1], e1[0])                                           # eval: scenes are independent
