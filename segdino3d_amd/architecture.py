@@ -10,14 +10,14 @@ segdino3d_amd.ops; torch is used for tensor bookkeeping (row gathers by index, c
 """
 from __future__ import annotations
 
-from typing import Dict, List, Optional
+from typing import Dict, List
 
 import numpy as np
 import torch
 import torch.nn as nn
 
 from . import ops
-from .builder import ARCHITECTURES, LOSSES, build_backbone, build_decoder, build_loss, build_text_encoder
+from .builder import ARCHITECTURES, build_backbone, build_decoder, build_loss, build_text_encoder
 
 try:  # pragma: no cover - mmdet3d is absent from the build image
     from mmdet3d.structures import PointData  # type: ignore

@@ -18,7 +18,7 @@ the only synchronisation.  There is no CPU fallback: CPU tensors raise.
 from __future__ import annotations
 
 import ctypes
-from typing import List, Optional, Sequence
+from typing import Optional, Sequence
 
 import numpy as np
 import torch

@@ -17,7 +17,7 @@ There is no CPU fallback: CPU tensors raise.
 from __future__ import annotations
 
 import ctypes
-from typing import Dict, List, Optional, Sequence
+from typing import Dict, List, Sequence
 
 import torch
 

@@ -21,7 +21,6 @@ mask attention, superpoint queries).  Eval mode only.
 from __future__ import annotations
 
 import copy
-from typing import List
 
 import os
 import threading

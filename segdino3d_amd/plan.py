@@ -11,9 +11,8 @@ the GIL for ~2 ms of the ~6.5 ms a forward costs on the host, and the host - not
 """
 from __future__ import annotations
 
-import ctypes as C
 import os
-from typing import Dict, List, Optional, Tuple
+from typing import List, Tuple
 
 import numpy as np
 import torch
