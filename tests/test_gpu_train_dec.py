@@ -308,3 +308,33 @@ def test_plain_decoder_training_gradients_match_float64_oracle():
     worst = sorted(((_rel(p.grad.cpu(), sd64["decoder." + n].grad), n) for n, p in dec.named_parameters()
                     if sd64["decoder." + n].grad is not None and float(sd64["decoder." + n].grad.norm()) > 1e-6), reverse=True)
     assert worst[0][0] <= 1e-3, worst[:5]
+
+
+def test_training_step_is_bit_reproducible():
+    """Same scene, same query subset, twice: every parameter gradient and both losses are bit-identical (all reductions of
+    the HIP kernels run in a fixed order; no atomics on floating-point data)."""
+    import segdino3d_amd as seg
+    from segdino3d_amd.configs import scannet200_model_cfg
+    from segdino3d_amd.synth import add_training_targets, make_scene
+    d = dev()
+    torch.manual_seed(0)
+    model = seg.build_architecture(scannet200_model_cfg(query_num=200)).to(d).train()
+    pts, tgt = make_scene(23, n_points=20000, n_superpoints=200, n_query2d=30)
+    tgt = add_training_targets(pts, tgt, n_instances=8, seed=3)
+    pts, tgt = pts.to(d), tgt.to(d)
+    runs = []
+    for _ in range(2):
+        for p in model.parameters():
+            p.grad = None
+        for k in ("query_inst_sem_masks", "instance_centers", "instance_sizes"):
+            tgt.__dict__.pop(k, None)
+        torch.manual_seed(11)
+        losses = model([pts], [tgt])
+        (losses["seg_loss"] + losses["inst_loss"]).backward()
+        runs.append((losses["seg_loss"].detach().clone(), losses["inst_loss"].detach().clone(),
+                     {n: p.grad.clone() for n, p in model.named_parameters() if p.grad is not None}))
+    assert torch.equal(runs[0][0], runs[1][0]) and torch.equal(runs[0][1], runs[1][1])
+    assert runs[0][2].keys() == runs[1][2].keys() and len(runs[0][2]) > 400
+    diff = [n for n in runs[0][2] if not torch.equal(runs[0][2][n], runs[1][2][n])]
+    assert not diff, f"{len(diff)} parameter gradients differ between two identical steps, e.g. {diff[:3]}"
+    assert all(bool(torch.isfinite(g).all()) for g in runs[0][2].values())
