@@ -391,6 +391,10 @@ int sd3d_sine_pe_mod_backward(const float* d_out, int ld_do, const float* xyz, i
 int sd3d_attention_lse(const float* q0, int ldq0, const float* q1, int ldq1, const float* k0, int ldk0, const float* k1,
                        int ldk1, const float* v, int ldv, const uint32_t* mask_bits, int Lq, int Lk, int H, float scale,
                        float* out, int ldo, float* lse, void* ws, size_t ws_bytes, void* stream);
+/* bf16 forward (section "bf16 decoder") that keeps lse: mixed-precision training runs this forward and the fp32 backward below. */
+int sd3d_attention_lse_bf16(const float* q0, int ldq0, const float* q1, int ldq1, const float* k0, int ldk0, const float* k1,
+                            int ldk1, const float* v, int ldv, const uint32_t* mask_bits, int Lq, int Lk, int H, float scale,
+                            float* out, int ldo, float* lse, void* ws, size_t ws_bytes, void* stream);
 size_t sd3d_attention_backward_ws_bytes(int Lq, int H);
 int sd3d_attention_backward(const float* q0, int ldq0, const float* q1, int ldq1, const float* k0, int ldk0, const float* k1, int ldk1,
                             const float* v, int ldv, const uint32_t* mask_bits, int Lq, int Lk, int H, float scale, const float* out, int ldo,

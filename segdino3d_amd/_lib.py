@@ -97,6 +97,7 @@ SIGNATURES = {
     "sd3d_layernorm_backward": (_i, [_p, _i, _p, _i, _p, _i, _p, _i, _p, _f, _l, _i, _i, _p, _i, _p, _p, _p, _z, _p]),
     "sd3d_sine_pe_mod_backward": (_i, [_p, _i, _p, _i, _l, _p, _p, _p, _i, _p, _i, _p, _p]),
     "sd3d_attention_lse": (_i, [_p, _i, _p, _i, _p, _i, _p, _i, _p, _i, _p, _i, _i, _i, _f, _p, _i, _p, _p, _z, _p]),
+    "sd3d_attention_lse_bf16": (_i, [_p, _i, _p, _i, _p, _i, _p, _i, _p, _i, _p, _i, _i, _i, _f, _p, _i, _p, _p, _z, _p]),
     "sd3d_attention_backward_ws_bytes": (_z, [_i, _i]),
     "sd3d_attention_backward": (_i, [_p, _i, _p, _i, _p, _i, _p, _i, _p, _i, _p, _i, _i, _i, _f, _p, _i, _p, _p, _i, _p, _i, _p, _i, _p, _i, _p, _i,
                                      _p, _i, _p, _z, _p]),

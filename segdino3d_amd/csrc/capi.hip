@@ -227,6 +227,17 @@ int sd3d_attention_lse(const float* q0, int ldq0, const float* q1, int ldq1, con
     p.Lq = Lq; p.Lk = Lk; p.H = H; p.scale = scale; p.ksplit = 1; p.part = nullptr; p.bf16 = 0; p.lse = lse;
     return launch_attention(p, q1 ? 2 : 1, ws, ws_bytes, ST);
 }
+int sd3d_attention_lse_bf16(const float* q0, int ldq0, const float* q1, int ldq1, const float* k0, int ldk0, const float* k1, int ldk1,
+                   const float* v, int ldv, const uint32_t* mask_bits, int Lq, int Lk, int H, float scale, float* out, int ldo,
+                   float* lse, void* ws, size_t ws_bytes, void* stream) {
+    if ((q1 == nullptr) != (k1 == nullptr)) return sd3d_set_error(SD3D_ERR_ARG, "attention: q1 and k1 must be given together");
+    AttnParams p;
+    p.q[0] = q0; p.ldq[0] = ldq0; p.q[1] = q1; p.ldq[1] = ldq1;
+    p.k[0] = k0; p.ldk[0] = ldk0; p.k[1] = k1; p.ldk[1] = ldk1;
+    p.v = v; p.ldv = ldv; p.bits = mask_bits; p.nwords = (Lk + 31) / 32; p.out = out; p.ldo = ldo;
+    p.Lq = Lq; p.Lk = Lk; p.H = H; p.scale = scale; p.ksplit = 1; p.part = nullptr; p.bf16 = 1; p.lse = lse;
+    return launch_attention(p, q1 ? 2 : 1, ws, ws_bytes, ST);
+}
 int sd3d_attention_bf16(const float* q0, int ldq0, const float* q1, int ldq1, const float* k0, int ldk0, const float* k1, int ldk1,
                    const float* v, int ldv, const uint32_t* mask_bits, int Lq, int Lk, int H, float scale, float* out, int ldo,
                    void* ws, size_t ws_bytes, void* stream) {

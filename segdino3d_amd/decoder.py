@@ -132,7 +132,7 @@ class _TrainF:
     @staticmethod
     def mask_logits(nq, mask_feats):
         from . import train_dec
-        return train_dec.linear(nq, mask_feats)
+        return train_dec.linear(nq, mask_feats, exact=True)
 
 
 _F_TLS = threading.local()
@@ -503,7 +503,7 @@ class ScanNetQueryDecoder(nn.Module):
         prev = getattr(_F_TLS, "f", _EvalF)
         _F_TLS.f = _TrainF if (self.training and torch.is_grad_enabled()) else _EvalF
         try:
-            with ops.bf16_decoder_scope(self.compute_dtype == "bf16" and not self.training):      # training runs in fp32
+            with ops.bf16_decoder_scope(self.compute_dtype == "bf16"):      # training: bf16 forward products, fp32 backward
                 return self._forward(x, sp_pos, sp_pos_wo_elastic, queries, queries_pos, dinox_queries, dinox_query_pos, scene_range)
         finally:
             _F_TLS.f = prev

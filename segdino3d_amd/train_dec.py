@@ -64,14 +64,18 @@ def col_sums(x):
 
 class _Linear(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, w, b, act, res, x2):
+    def forward(ctx, x, w, b, act, res, x2, force_exact=False):
         xd, wd = x.detach(), w.detach()
         bd = None if b is None else b.detach()
         kw = dict(x2=None if x2 is None else x2.detach(), shift=bd, res=None if res is None else res.detach())
-        y = ops.gather_gemm(xd, wd, act=act, exact=True, **kw)
+        # mixed precision (decoder compute_dtype "bf16"): the forward product may run with bf16 operands, every backward
+        # product stays fp32; w is a live parameter here, so no rounded copy is cached across steps
+        exact = force_exact or not ops.bf16_decoder_active()
+        ws = None if exact or xd.shape[0] < ops.BF16_MIN_ROWS or wd.shape[1] % 32 else ops.split_weights(wd.unsqueeze(0), 1)
+        y = ops.gather_gemm(xd, wd, act=act, exact=True, wt_split=ws, **kw)
         ref = y
         if act == "gelu":                                      # its derivative needs the pre-activation
-            ref = ops.gather_gemm(xd, wd, act=None, exact=True, **kw)
+            ref = ops.gather_gemm(xd, wd, act=None, exact=True, wt_split=ws, **kw)
         ctx.save_for_backward(x, w, ref if act is not None else None, x2)
         ctx.act, ctx.has_b, ctx.has_res = act, b is not None, res is not None
         return y
@@ -105,12 +109,13 @@ class _Linear(torch.autograd.Function):
             db = col_sums(g)[:cout]
         if ctx.has_res and ctx.needs_input_grad[4]:
             dres = g[:, :cout]
-        return dx, dw, db, None, dres, dx2
+        return dx, dw, db, None, dres, dx2, None
 
 
-def linear(x, weight, bias=None, act=None, res=None, x2=None):
-    """Differentiable `ops.linear` / two-source `ops.gather_gemm`: weight [Cout, Cin(total)]."""
-    return _Linear.apply(x, weight, bias, act, res, x2)
+def linear(x, weight, bias=None, act=None, res=None, x2=None, exact=False):
+    """Differentiable `ops.linear` / two-source `ops.gather_gemm`: weight [Cout, Cin(total)]; `exact` keeps the forward product
+    fp32 inside a bf16 scope (the mask head: its logits feed thresholds)."""
+    return _Linear.apply(x, weight, bias, act, res, x2, exact)
 
 
 class _LayerNorm(torch.autograd.Function):
@@ -187,9 +192,10 @@ class _Attention(torch.autograd.Function):
         out = torch.empty(Lq, num_heads * 32, dtype=torch.float32, device=q.device)
         lse = torch.empty(num_heads, Lq, dtype=torch.float32, device=q.device)
         ws = _WS_ATT.get(lib.sd3d_attention_ws_bytes(Lq, num_heads), q.device)
-        _lib.check(lib.sd3d_attention_lse(pq, ldq, pq2, ldq2, pk, ldk, pk2, ldk2, pv, ldv, ops._ptr(mask_bits, torch.int32, "mask_bits"),
-                                          Lq, Lk, num_heads, float(scale), out.data_ptr(), out.shape[1], lse.data_ptr(), ws.data_ptr(),
-                                          ws.numel(), ops._stream()), "attention_lse")
+        fn = lib.sd3d_attention_lse_bf16 if ops.bf16_decoder_active() else lib.sd3d_attention_lse
+        _lib.check(fn(pq, ldq, pq2, ldq2, pk, ldk, pk2, ldk2, pv, ldv, ops._ptr(mask_bits, torch.int32, "mask_bits"),
+                      Lq, Lk, num_heads, float(scale), out.data_ptr(), out.shape[1], lse.data_ptr(), ws.data_ptr(),
+                      ws.numel(), ops._stream()), "attention_lse")
         ctx.save_for_backward(q, k, v, q2, k2, mask_bits, out, lse)
         ctx.H, ctx.scale = num_heads, float(scale)
         return out
