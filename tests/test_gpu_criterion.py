@@ -127,3 +127,55 @@ def test_cpu_tensors_are_refused():
     crit = build(cfg)
     with pytest.raises(RuntimeError):
         crit(as_pred(layers), targets)
+
+
+def _tiny_case(G, Q=24, S=40, n_cls=5, n_sem=6, seed=0, empty_object=False):
+    g = torch.Generator().manual_seed(seed)
+    owner = torch.randint(0, max(G, 1), (S,), generator=g) if G else torch.zeros(S, dtype=torch.long)
+    inst = torch.stack([owner == k for k in range(G)]) if G else torch.zeros(0, S, dtype=torch.bool)
+    sem_id = torch.randint(0, n_sem + 1, (S,), generator=g)
+    sem = torch.stack([sem_id == k for k in range(n_sem + 1)])
+    sp = torch.cat([inst, sem])
+    ids = torch.randperm(S, generator=g)[:Q]
+    qm = sp[:, ids].clone()
+    if empty_object and G:
+        qm[0] = False                                               # no query lies inside object 0
+    t = dict(sp_inst_sem_masks=sp, query_inst_sem_masks=qm, labels=torch.randint(0, n_cls, (G,), generator=g))
+    layer = dict(cls_preds=[torch.randn(Q, n_cls + 1, generator=g)], sem_preds=[torch.randn(Q, n_sem + 1, generator=g)],
+                 masks=[torch.randn(Q, S, generator=g)], scores=[None], centers=[None], sizes=[None])
+    cfg = dict(matcher="sparse", topk=1, cost_weights=[0.5, 1.0, 1.0], loss_weight=[0.5, 1.0, 1.0, 0.5], num_classes=n_cls,
+               num_semantic_classes=n_sem, sem_ignore_index=n_sem, sem_loss_weight=0.5, non_object_weight=0.1, fix_dice_loss_weight=True,
+               iter_matcher=True, fix_mean_loss=True)
+    return t, layer, cfg
+
+
+def test_scene_without_objects_behaves_like_the_reference():
+    """No ground-truth object: the reference's mask terms are means over nothing (NaN, loss_3d.py:479-481 on empty tensors) while
+    the class term is finite (every query -> "no object"); the device criterion returns the same and finite class gradients."""
+    from oracle import loss_ref
+    d = dev()
+    t, layer, cfg = _tiny_case(G=0)
+    crit = build(cfg)
+    l_d = {k: [None if v is None else v.to(d).requires_grad_(True) for v in lst] for k, lst in layer.items()}
+    out = crit(dict(l_d), [{k: v.to(d) for k, v in t.items()}])
+    ref = loss_ref.unified_criterion(dict(layer), [t], cfg)
+    assert torch.isnan(out["inst_loss"]) and torch.isnan(ref["inst_loss"])
+    assert abs(float(out["seg_loss"].detach()) - float(ref["seg_loss"])) < 1e-5
+    parts = crit.last_parts[0].cpu()
+    assert abs(float(parts[0]) - float(ref["_parts"][0][0])) < 1e-5 and bool(torch.isnan(parts[1]))
+
+
+def test_object_without_any_query_inside_is_left_unmatched():
+    """`query_masks` row all False -> every cost of that object is 1e8 -> `cost < kth` selects nothing (loss_3d.py:358-364)."""
+    from oracle import loss_ref
+    d = dev()
+    t, layer, cfg = _tiny_case(G=4, empty_object=True, seed=3)
+    crit = build(cfg)
+    l_d = {k: [None if v is None else v.to(d).requires_grad_(True) for v in lst] for k, lst in layer.items()}
+    out = crit(dict(l_d), [{k: v.to(d) for k, v in t.items()}])
+    m = crit.last_matches[0][0].cpu()
+    assert int(m[:, 0].sum()) == 0 and int(m.sum()) == 3
+    t64 = {k: v for k, v in t.items()}
+    l64 = {k: [None if v is None else v.double() for v in lst] for k, lst in layer.items()}
+    ref = loss_ref.unified_criterion(dict(l64), [t64], cfg)
+    assert abs(float(out["inst_loss"].detach()) - float(ref["inst_loss"])) < 2e-5 * abs(float(ref["inst_loss"]))
