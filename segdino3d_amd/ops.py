@@ -489,6 +489,41 @@ def pair_conv(x, wt, pairs, x2=None, scale=None, shift=None, res=None, act=None,
     return out
 
 
+def _dense_linear(x, wt, x2, shift, res, act):
+    """Short host path of the plain Linear y = act(x wt^T + shift + res) on [x | x2] (the decoder issues ~150 of them per
+    forward; the general entry below spends ~14 us of Python per call, this one ~4): same kernel, same checks that matter -
+    device tensors, fp32, contiguous rows, matching widths."""
+    if not (x.is_cuda and wt.is_cuda):
+        raise RuntimeError("gather_gemm: expected tensors on the HIP device (no CPU fallback)")
+    if x.dtype is not torch.float32 or wt.dtype is not torch.float32 or x.dim() != 2 or x.stride(1) != 1 or not wt.is_contiguous():
+        raise ValueError("gather_gemm: expected 2-D fp32 tensors with contiguous rows")
+    rows, C0 = x.shape
+    Cout, Cin = wt.shape
+    p1, ld1 = None, 0
+    if x2 is not None:
+        if x2.dtype is not torch.float32 or x2.stride(1) != 1 or not x2.is_cuda or C0 + x2.shape[1] != Cin:
+            raise ValueError(f"gather_gemm: bad second source for Cin {Cin}")
+        p1, ld1 = x2.data_ptr(), x2.stride(0)
+    elif C0 != Cin:
+        raise ValueError(f"input channels {C0} != Cin {Cin}")
+    pr, ldr = None, 0
+    if res is not None:
+        if res.dtype is not torch.float32 or res.stride(1) != 1 or not res.is_cuda or res.shape[0] != rows or res.shape[1] != Cout:
+            raise ValueError("gather_gemm: residual must be an fp32 [rows, Cout] device tensor")
+        pr, ldr = res.data_ptr(), res.stride(0)
+    ps = None
+    if shift is not None:
+        if not shift.is_cuda or shift.dtype is not torch.float32 or shift.numel() != Cout or not shift.is_contiguous():
+            raise ValueError("gather_gemm: shift must be a contiguous fp32 [Cout] device tensor")
+        ps = shift.data_ptr()
+    out = torch.empty((rows, Cout), dtype=torch.float32, device=x.device)
+    rc = _lib.load().sd3d_gather_gemm(x.data_ptr(), x.stride(0), C0, p1, ld1, None, wt.data_ptr(), 1, Cin, Cout, rows, None, ps, pr, ldr,
+                                      out.data_ptr(), Cout, ACT[act], 0, None, 0, _stream())
+    if rc:
+        _lib.check(rc, "gather_gemm")
+    return out
+
+
 def gather_gemm(x, wt, nbr=None, x2=None, scale=None, shift=None, res=None, act=None, out=None, M=None, nt=0,
                 density=None, wt_split=None, pairs=None, exact=False):
     """out[r, n] = act(scale[n] * sum_k sum_c X[nbr[k, r], c] * wt[k, n, c] + shift[n] + res[r, n]).
@@ -497,6 +532,9 @@ def gather_gemm(x, wt, nbr=None, x2=None, scale=None, shift=None, res=None, act=
     wt [K, Cout, Cin] contiguous, nbr int32 [K, M] or None (identity rows, K = 1).  With `pairs` (the table's
     PairLists) a sparse convolution runs pair-major (pair_conv); `density` is informational (kept for callers that
     pass SceneMaps.conv_table(...) as keyword arguments)."""
+    if nbr is None and pairs is None and GG_HOOK is None and scale is None and out is None and wt_split is None and nt == 0 \
+            and M is None and GEMM_MODE is None and GG_FORCE_NT is None and wt.dim() == 2 and not getattr(_BF16_TLS, "on", False):
+        return _dense_linear(x, wt, x2, shift, res, act)
     lib = _lib.load()
     if wt.dim() == 2:
         wt = wt.unsqueeze(0)
