@@ -95,7 +95,7 @@ def main():
     blob = {}
     cases = [(0, 11), (1, 5), (2, 23), (3, 8), (4, 2)]                # (scene seed, numpy.random seed): cover flips and elastic on / off
     for ci, (sseed, rseed) in enumerate(cases):
-        pts, q = make_scene(sseed, 6000, 40)
+        pts, q = make_scene(sseed, 2400, 24)
         blob[f"c{ci}/points_in"], blob[f"c{ci}/query2d_pos_in"] = pts, q
         tf = W.Scannet200Transforms("train", voxel_size=0.02)
         np.random.seed(rseed)
@@ -112,7 +112,7 @@ def main():
         moved = np.abs(tgt["elastic_coords"].numpy() - out_pts.numpy()[:, :3] / 0.02).max()
         print(ci, "flips", blob[f"c{ci}/flags"], "elastic displacement (voxels)", float(moved))
     # val transform on one scene (colour normalisation only)
-    pts, q = make_scene(9, 3000, 10)
+    pts, q = make_scene(9, 1200, 10)
     out_pts, _ = W.Scannet200Transforms("val")(torch.from_numpy(pts.copy()), {"extra_features": {"query2d_pos": torch.from_numpy(q)}})
     blob["val/points_in"], blob["val/points"] = pts, out_pts.numpy()
     path = os.path.join(HERE, "augment.npz")
