@@ -179,3 +179,32 @@ def test_object_without_any_query_inside_is_left_unmatched():
     l64 = {k: [None if v is None else v.double() for v in lst] for k, lst in layer.items()}
     ref = loss_ref.unified_criterion(dict(l64), [t64], cfg)
     assert abs(float(out["inst_loss"].detach()) - float(ref["inst_loss"])) < 2e-5 * abs(float(ref["inst_loss"]))
+
+
+def test_shared_matches_when_iter_matcher_is_off():
+    """iter_matcher=False: the auxiliary layers reuse the last layer's matches (loss_3d.py:705-708)."""
+    from oracle import loss_ref
+    d = dev()
+    cfg, targets, layers, _ = load_case("s200", torch.float32, "cpu")
+    cfg = dict(cfg, iter_matcher=False)
+    crit = build(cfg)
+    t_d = [{k: v.to(d) for k, v in t.items()} for t in targets]
+    l_d = [{k: [None if v is None else v.to(d).requires_grad_(True) for v in lst] for k, lst in layer.items()} for layer in layers]
+    out = crit(as_pred(l_d), t_d)
+    (out["seg_loss"] + out["inst_loss"]).backward()
+    t64 = [{k: (v.double() if v.is_floating_point() else v) for k, v in t.items()} for t in targets]
+    l64 = [{k: [None if v is None else v.double().requires_grad_(True) for v in lst] for k, lst in layer.items()} for layer in layers]
+    ref = loss_ref.unified_criterion(as_pred(l64), t64, cfg)
+    (ref["seg_loss"] + ref["inst_loss"]).backward()
+    assert abs(float(out["inst_loss"].detach()) - float(ref["inst_loss"].detach())) < 2e-5 * abs(float(ref["inst_loss"].detach()))
+    for a, b in zip(l_d, l64):
+        for k in ("cls_preds", "masks", "centers", "sizes"):
+            for x, y in zip(a[k], b[k]):
+                if x is None:
+                    continue
+                gr = y.grad if y.grad is not None else torch.zeros_like(y)
+                assert (x.grad.cpu().double() - gr).abs().max().item() <= 2e-5 * max(gr.abs().max().item(), 1e-6), k
+    # every layer used the last layer's match matrices
+    for layer_matches in crit.last_matches[1:]:
+        for m, m_last in zip(layer_matches, crit.last_matches[0]):
+            assert m is m_last
