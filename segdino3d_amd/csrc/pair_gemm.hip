@@ -460,7 +460,7 @@ __device__ __forceinline__ void pair_gemm_ws_body(const PGParams& p, float* Ws) 
         pair_gemm_ws_body<NT, RT, ST>(p, ws_smem);                                                                     \
     }
 PAIR_GEMM_WS_ENTRY(1, 1, 3, 4)
-PAIR_GEMM_WS_ENTRY(2, 1, 3, 3)
+PAIR_GEMM_WS_ENTRY(2, 1, 3, 2)
 PAIR_GEMM_WS_ENTRY(3, 1, 2, 3)
 PAIR_GEMM_WS_ENTRY(4, 1, 2, 2)
 
@@ -575,7 +575,7 @@ int launch_pair_conv(const float* in0, int ld0, int C0, const float* in1, int ld
             attr_done = true;
         }
         // resident workgroups per CU: the pinned register budgets allow 4 / 3 / 3 / 2; LDS (160 KB) may allow fewer
-        int per_cu = nt == 1 ? 4 : (nt == 4 ? 2 : 3);
+        int per_cu = nt == 1 ? 4 : (nt == 3 ? 3 : 2);
         const int by_lds = (int)((160 * 1024) / (w_lds + WS_RANGE_TILES * PT * sizeof(int32_t) + 256));
         per_cu = per_cu < by_lds ? per_cu : by_lds;
         if (slots_env > 0) per_cu = slots_env;
