@@ -475,14 +475,24 @@ __global__ __launch_bounds__(256) void pool_superpoints_kernel(const float* __re
     const int j0 = start[s], j1 = start[s + 1];
     f32x4 acc = {0.f, 0.f, 0.f, 0.f};
     float pacc = 0.f;
-    for (int j = j0 + half; j < j1; j += 2) {
-        const int64_t p = sidx[j];
+    // four points per half-wave in flight: the sidx -> inverse -> feature chain is three dependent loads per point, and a
+    // superpoint has only ~50 of them (same summation order as a one-by-one loop)
+    for (int j = j0 + half; j < j1; j += 8) {
+        int64_t pp[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) pp[u] = (j + 2 * u < j1) ? (int64_t)sidx[j + 2 * u] : -1;
         if (li < nvec) {
-            const int64_t v = inverse[p];
-            const f32x4 x = *(const f32x4*)(feat + v * ld_feat + li * 4);
-            acc += x;
+            int64_t vv[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) vv[u] = pp[u] >= 0 ? (int64_t)inverse[pp[u]] : 0;
+            f32x4 xx[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) xx[u] = *(const f32x4*)(feat + vv[u] * ld_feat + li * 4);
+#pragma unroll
+            for (int u = 0; u < 4; ++u) if (pp[u] >= 0) acc += xx[u];
         } else if (li < nvec + 3) {
-            pacc += (float)icoords[p * 3 + (li - nvec)] * voxel_size;
+#pragma unroll
+            for (int u = 0; u < 4; ++u) if (pp[u] >= 0) pacc += (float)icoords[pp[u] * 3 + (li - nvec)] * voxel_size;
         }
     }
 #pragma unroll
