@@ -92,34 +92,54 @@ __device__ static inline float nms_diou(const float* inter, int ld, const float*
     const float it = inter[(int64_t)i * ld + j];
     return it / (area[i] + area[j] - it);
 }
-__global__ void nms_comp_kernel(const float* __restrict__ inter, int ld, const float* __restrict__ area,
-                                const int32_t* __restrict__ lab, int n, float* __restrict__ comp) {
-    const int j = blockIdx.x * blockDim.x + threadIdx.x;
-    if (j >= n) return;
+// 64 columns x 16 row lanes per workgroup: row lane r walks the rows i = r, r + 16, ...; max / min / "saw a NaN" are order-free,
+// so the result does not depend on the split (one thread per column walked all n rows alone: 110 - 130 us for n = 600)
+#define NMS_RL 16
+__global__ __launch_bounds__(64 * NMS_RL) void nms_comp_kernel(const float* __restrict__ inter, int ld, const float* __restrict__ area,
+                                                               const int32_t* __restrict__ lab, int n, float* __restrict__ comp) {
+    __shared__ float sm[NMS_RL][64];
+    __shared__ int sn[NMS_RL][64];
+    const int cl = threadIdx.x & 63, rl = threadIdx.x >> 6;
+    const int j = blockIdx.x * 64 + cl;
     float m = 0.f;                                // row j..n-1 of the column are zeros -> max >= 0
     bool nan = false;
-    for (int i = 0; i < j; ++i) {
-        const float d = nms_diou(inter, ld, area, lab, i, j);
-        nan |= (d != d);
-        m = fmaxf(m, d);
+    if (j < n)
+        for (int i = rl; i < j; i += NMS_RL) {
+            const float d = nms_diou(inter, ld, area, lab, i, j);
+            nan |= (d != d);
+            m = fmaxf(m, d);
+        }
+    sm[rl][cl] = m; sn[rl][cl] = nan;
+    __syncthreads();
+    if (rl == 0 && j < n) {
+        for (int r = 1; r < NMS_RL; ++r) { m = fmaxf(m, sm[r][cl]); nan |= sn[r][cl] != 0; }
+        comp[j] = nan ? NAN : m;
     }
-    comp[j] = nan ? NAN : m;
 }
-__global__ void nms_coef_kernel(const float* __restrict__ inter, int ld, const float* __restrict__ area,
-                                const int32_t* __restrict__ lab, const float* __restrict__ comp, int n, int gaussian, float sigma,
-                                const float* __restrict__ score_in, float* __restrict__ score_out) {
-    const int j = blockIdx.x * blockDim.x + threadIdx.x;
-    if (j >= n) return;
+__global__ __launch_bounds__(64 * NMS_RL) void nms_coef_kernel(const float* __restrict__ inter, int ld, const float* __restrict__ area,
+                                                               const int32_t* __restrict__ lab, const float* __restrict__ comp, int n,
+                                                               int gaussian, float sigma, const float* __restrict__ score_in,
+                                                               float* __restrict__ score_out) {
+    __shared__ float sm[NMS_RL][64];
+    __shared__ int sn[NMS_RL][64];
+    const int cl = threadIdx.x & 63, rl = threadIdx.x >> 6;
+    const int j = blockIdx.x * 64 + cl;
     float m = INFINITY;
     bool nan = false;
-    for (int i = 0; i < n; ++i) {
-        const float d = nms_diou(inter, ld, area, lab, i, j);
-        const float c = comp[i];
-        const float v = gaussian ? expf(-sigma * d * d) / expf(-sigma * c * c) : (1.f - d) / (1.f - c);
-        nan |= (v != v);
-        m = fminf(m, v);
+    if (j < n)
+        for (int i = rl; i < n; i += NMS_RL) {
+            const float d = nms_diou(inter, ld, area, lab, i, j);
+            const float c = comp[i];
+            const float v = gaussian ? expf(-sigma * d * d) / expf(-sigma * c * c) : (1.f - d) / (1.f - c);
+            nan |= (v != v);
+            m = fminf(m, v);
+        }
+    sm[rl][cl] = m; sn[rl][cl] = nan;
+    __syncthreads();
+    if (rl == 0 && j < n) {
+        for (int r = 1; r < NMS_RL; ++r) { m = fminf(m, sm[r][cl]); nan |= sn[r][cl] != 0; }
+        score_out[j] = score_in[j] * (nan ? NAN : m);
     }
-    score_out[j] = score_in[j] * (nan ? NAN : m);
 }
 
 // Point masks (:453-454, :464-465, :348-371).  For final row r (src row = src[r] of sig), point p:
@@ -313,8 +333,8 @@ int launch_gather_sigmoid(const float* masks, int ld, int S, const int32_t* qidx
 int launch_nms_decay(const float* inter, int ld, const float* area, const int32_t* labels, int n, int gaussian, float sigma,
                      const float* score_in, float* comp_ws, float* score_out, hipStream_t st) {
     if (n <= 0) return SD3D_OK;
-    hipLaunchKernelGGL(nms_comp_kernel, dim3((unsigned)cdiv(n, 64)), dim3(64), 0, st, inter, ld, area, labels, n, comp_ws);
-    hipLaunchKernelGGL(nms_coef_kernel, dim3((unsigned)cdiv(n, 64)), dim3(64), 0, st, inter, ld, area, labels, comp_ws, n, gaussian,
+    hipLaunchKernelGGL(nms_comp_kernel, dim3((unsigned)cdiv(n, 64)), dim3(64 * NMS_RL), 0, st, inter, ld, area, labels, n, comp_ws);
+    hipLaunchKernelGGL(nms_coef_kernel, dim3((unsigned)cdiv(n, 64)), dim3(64 * NMS_RL), 0, st, inter, ld, area, labels, comp_ws, n, gaussian,
                        sigma, score_in, score_out);
     SD3D_CHECK_LAUNCH();
     return SD3D_OK;
