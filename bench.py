@@ -207,8 +207,10 @@ def main():
         timer = GemmTimer()
         ops.GG_HOOK = timer
         timer.enabled = True
-        for i in range(args.steps):
-            step(i)
+        import segdino3d_amd as seg
+        with seg.capture() as cap:
+            for i in range(args.steps):
+                step(i)
         torch.cuda.synchronize()
         timer.enabled = False
         ops.GG_HOOK = None
@@ -288,7 +290,7 @@ def main():
                                         "flops_per_step": conv_flops // max(1, args.steps)}
 
     # ---- closing all-gather of per-scene records over RCCL/xGMI -----------------------
-    maps = model.backbone.last_maps
+    maps = cap.maps[-1]
     rec = torch.tensor([float(rank), float(args.points), float(maps.n_vox[0]), 1e3 * dt / args.steps],
                        dtype=torch.float64, device=comm_device)
     if dist is not None:

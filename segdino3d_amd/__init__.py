@@ -13,5 +13,6 @@ from .backbone_mink import Res16UNet34C  # noqa: F401
 from .backbone_spconv import SpConvUNet  # noqa: F401
 from .decoder import ScanNetQueryDecoder  # noqa: F401
 from .architecture import Baseline3D, PointData  # noqa: F401
+from ._trace import capture  # noqa: F401
 
-__all__ = list(_builder_all) + ["GDType", "GD3DTarget", "Res16UNet34C", "SpConvUNet", "ScanNetQueryDecoder", "Baseline3D", "PointData"]
+__all__ = list(_builder_all) + ["GDType", "GD3DTarget", "Res16UNet34C", "SpConvUNet", "ScanNetQueryDecoder", "Baseline3D", "PointData", "capture"]

@@ -16,7 +16,7 @@ import numpy as np
 import torch
 import torch.nn as nn
 
-from . import ops
+from . import _trace, ops
 from .builder import ARCHITECTURES, build_backbone, build_decoder, build_loss, build_text_encoder
 
 try:  # pragma: no cover - mmdet3d is absent from the build image
@@ -121,37 +121,39 @@ class Baseline3D(nn.Module):
 
     # ---- _select_queries (:207-264) ------------------------------------------------------------------
     def _select_queries(self, x, x_pos=None, targets=None):
-        if self.training:                                        # random subset of the superpoints as queries (:250-264)
-            queries, queries_pos = [], ([] if x_pos is not None else None)
-            for i in range(len(x)):
-                if self.query_thr < 1:
-                    n = (1 - self.query_thr) * torch.rand(1) + self.query_thr       # host RNG, like the reference
-                    n = (n * len(x[i])).int()
-                    ids = torch.randperm(len(x[i]))[:n].to(x[i].device)
-                    queries.append(x[i][ids])
-                    targets[i].query_inst_sem_masks = targets[i].sp_inst_sem_masks[:, ids]
-                    if x_pos is not None:
-                        queries_pos.append(x_pos[i][ids])
-                else:
-                    queries.append(x[i])
-                    targets[i].query_inst_sem_masks = targets[i].sp_inst_sem_masks
-                    if x_pos is not None:
-                        queries_pos.append(x_pos[i])
-            return queries, queries_pos, targets
-        if self.query_num == -1:
+        if not self.training and self.query_num == -1:           # evaluation: every superpoint is a query (:227-228)
             return x, x_pos, targets
         queries, queries_pos = [], ([] if self.add_positional_embedding else None)
-        for i in range(len(x)):
-            if self.query_num > 0 and x[i].shape[0] > self.query_num:
-                score = self.decoder.select_scores(x[i])
-                ids = _sorted_desc(score)[: self.query_num].long()
-            else:
-                ids = torch.arange(x[i].shape[0], device=x[i].device)
-            queries.append(x[i][ids])
-            if targets is not None and "sp_inst_sem_masks" in targets[i]:
+        if self.query_num > 0:                                   # top-`query_num` superpoints, training AND evaluation (:231-249)
+            for i in range(len(x)):
+                if x[i].shape[0] > self.query_num:
+                    with torch.no_grad():                        # the indices carry no gradient; x[i][ids] below does
+                        score = self.decoder.select_scores(x[i].detach())
+                    ids = _sorted_desc(score)[: self.query_num].long()
+                else:
+                    ids = torch.arange(x[i].shape[0], device=x[i].device)
+                queries.append(x[i][ids])
+                # the reference reads `sp_inst_sem_masks` unconditionally here (:246); a benchmark scene without
+                # ground truth is tolerated in evaluation, training needs it for the matcher
+                if targets is not None and (self.training or "sp_inst_sem_masks" in targets[i]):
+                    targets[i].query_inst_sem_masks = targets[i].sp_inst_sem_masks[:, ids]
+                if x_pos is not None and queries_pos is not None:
+                    queries_pos.append(x_pos[i][ids])
+            return queries, queries_pos, targets
+        for i in range(len(x)):                                  # random subset of the superpoints as queries (:250-264)
+            if self.query_thr < 1:
+                n = (1 - self.query_thr) * torch.rand(1) + self.query_thr           # host RNG, like the reference
+                n = (n * len(x[i])).int()
+                ids = torch.randperm(len(x[i]))[:n].to(x[i].device)
+                queries.append(x[i][ids])
                 targets[i].query_inst_sem_masks = targets[i].sp_inst_sem_masks[:, ids]
-            if x_pos is not None and queries_pos is not None:
-                queries_pos.append(x_pos[i][ids])
+                if x_pos is not None and queries_pos is not None:
+                    queries_pos.append(x_pos[i][ids])
+            else:
+                queries.append(x[i])
+                targets[i].query_inst_sem_masks = targets[i].sp_inst_sem_masks
+                if x_pos is not None and queries_pos is not None:
+                    queries_pos.append(x_pos[i])
         return queries, queries_pos, targets
 
     # ---- forward (:308-346) --------------------------------------------------------------------------------
@@ -165,7 +167,9 @@ class Baseline3D(nn.Module):
         self.decoder.return_hidden_states = not self.training
         self.decoder.return_aux_outputs = True
         outputs = self.forward_decoder(sp_features_3d, sp_pos, sp_pos_wo_elastic, queries, queries_pos, targets, scene_range)
-        self.last_outputs = outputs
+        cap = _trace.active()
+        if cap is not None:                                      # per-call, per-thread (segdino3d_amd/_trace.py)
+            cap.outputs, cap.sp_feats, cap.sp_pos = outputs, sp_features_3d, sp_pos
         if self.training:                                        # {"seg_loss", "inst_loss"}, gradients attached (:346)
             return self.criterion(outputs, targets)
         pred = self.predict_by_feat(samples, outputs, targets[0]["extra_features"]["super_point_masks"])  # bs = 1 (:335)

@@ -23,7 +23,8 @@ from typing import List
 import torch
 import torch.nn as nn
 
-from . import ops, plan
+from . import _trace, ops, plan
+from ._cache import DerivedWeights
 from .builder import BACKBONES
 from .sparse import SceneMaps
 
@@ -84,7 +85,7 @@ def _round32(c: int) -> int:
     return (c + 31) // 32 * 32
 
 
-class Res16UNetBase(nn.Module):
+class Res16UNetBase(DerivedWeights):
     PLANES = (32, 64, 128, 256, 256, 256, 256, 256)
     LAYERS = (2, 2, 2, 2, 2, 2, 2, 2)
     INIT_DIM = 32
@@ -126,7 +127,6 @@ class Res16UNetBase(nn.Module):
         self.out_planes = P[7]
         self._packed = None
         self._plan = None
-        self.last_maps = None          # SceneMaps of the most recent scene (bench.py reads rulebook sizes)
 
     def _make_layer(self, planes, blocks, mom):
         down = None
@@ -139,28 +139,19 @@ class Res16UNetBase(nn.Module):
         return nn.Sequential(*layers)
 
     # ---- weight packing ------------------------------------------------------------------------
-    def _apply(self, fn, *a, **k):
+    def _derived_reset(self):
+        super()._derived_reset()
         self._packed = None
         self._plan = None
-        return super()._apply(fn, *a, **k)
-
-    def load_state_dict(self, *a, **k):
-        self._packed = None
-        self._plan = None
-        return super().load_state_dict(*a, **k)
 
     def _load_from_state_dict(self, *a, **k):
-        self._packed = None
-        self._plan = None
+        self._derived_reset()
         return super()._load_from_state_dict(*a, **k)
 
-    def invalidate_packed_weights(self):
-        self._packed = None
-        self._plan = None
-
     def packed(self):
-        """name -> (wt [K,Cout,Cin], scale, shift) in the device layout; rebuilt after .to()/load."""
-        if self._packed is None:
+        """name -> (wt [K,Cout,Cin], scale, shift) in the device layout; rebuilt whenever a parameter or a BatchNorm
+        running statistic changed (segdino3d_amd/_cache.py)."""
+        if not self._derived_valid() or self._packed is None:
             pk = {}
             convs = {n: m for n, m in self.named_modules() if isinstance(m, MinkConv)}
             bns = {n: m for n, m in self.named_modules() if isinstance(m, MinkBN)}
@@ -271,19 +262,20 @@ class Res16UNetBase(nn.Module):
     def forward_wrapper(self, samples: List[torch.Tensor], targets, return_sp_mean_pos=False):
         feats, pos, pos_wo = [], [], []
         scenes = [self._scene_inputs(p, t) for p, t in zip(samples, targets)]
+        cap = _trace.active()
+        if cap is not None:
+            cap.maps.extend(s[0] for s in scenes)
         if self.training and len(scenes) > 1:
             # one block-diagonal tensor for the whole batch, as ME's batch_sparse_collate builds (:624-627): convolutions stay
             # within their scene, every BatchNorm sees the voxels of all scenes
             from . import train_ops
             from .sparse import BatchedMaps
             batch = BatchedMaps([s[0] for s in scenes])
-            self.last_maps = scenes[-1][0]
             x_all = self.forward_sparse(batch, torch.cat([s[1] for s in scenes], dim=0))
             outs = [x_all[slice(*batch.rows(0, i))] for i in range(len(scenes))]
         else:
             outs = []
             for maps, vf, _, _, _ in scenes:
-                self.last_maps = maps
                 outs.append(self.forward_sparse(maps, vf))
         for (maps, _, pts, sp, elastic), x in zip(scenes, outs):
             if self.training:

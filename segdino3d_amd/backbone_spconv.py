@@ -26,7 +26,8 @@ from typing import List
 import torch
 import torch.nn as nn
 
-from . import ops, plan
+from . import _trace, ops, plan
+from ._cache import DerivedWeights
 from .builder import BACKBONES
 from .sparse import SceneMaps
 
@@ -71,7 +72,7 @@ def _fold(bn: nn.BatchNorm1d):
 
 
 @BACKBONES.register_module()
-class SpConvUNet(nn.Module):
+class SpConvUNet(DerivedWeights):
     KERNEL_ORDER = "z_fastest"
 
     def __init__(self, num_planes, norm_fn=None, block_reps=2, block=None, indice_key_id=1, normalize_before=True,
@@ -104,21 +105,15 @@ class SpConvUNet(nn.Module):
         self.add_positional_embedding = add_positional_embedding
         self._packed = None
         self._plan = None
-        self.last_maps = None
 
     # ---- packing ---------------------------------------------------------------------------------
-    def _apply(self, fn, *a, **k):
+    def _derived_reset(self):
+        super()._derived_reset()
         self._packed = None
         self._plan = None
-        return super()._apply(fn, *a, **k)
-
-    def load_state_dict(self, *a, **k):
-        self._packed = None
-        self._plan = None
-        return super().load_state_dict(*a, **k)
 
     def packed(self):
-        if self._packed is None:
+        if not self._derived_valid() or self._packed is None:      # segdino3d_amd/_cache.py
             pk = {}
             for n, m in self.named_modules():
                 if isinstance(m, SpConv):
@@ -215,17 +210,18 @@ class SpConvUNet(nn.Module):
             cin_pad = (self.in_channels + 31) // 32 * 32
             vf = maps.voxel_features(pts, f2d, 2, cin_pad, stats=None if elastic is None else ops.scene_stats(pts))
             scenes.append((maps, vf, pts, sp, el))
+        cap = _trace.active()
+        if cap is not None:
+            cap.maps.extend(s[0] for s in scenes)
         if self.training and len(scenes) > 1:
             # the batch as one block-diagonal tensor (spconv's batched SparseConvTensor, :378-379): BatchNorm over all scenes
             from .sparse import BatchedMaps
             batch = BatchedMaps([s[0] for s in scenes])
-            self.last_maps = scenes[-1][0]
             x_all = self.forward_sparse(batch, torch.cat([s[1] for s in scenes], dim=0))
             outs = [x_all[slice(*batch.rows(0, i))] for i in range(len(scenes))]
         else:
             outs = []
             for maps, vf, _, _, _ in scenes:
-                self.last_maps = maps
                 outs.append(self.forward_sparse(maps, vf))
         for (maps, _, pts, sp, el), x in zip(scenes, outs):
             if self.training:

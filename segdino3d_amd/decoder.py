@@ -29,6 +29,7 @@ import torch
 import torch.nn as nn
 
 from . import ops
+from ._cache import DerivedWeights
 from .builder import DECODERS
 
 
@@ -155,7 +156,7 @@ def _mlp(x, mlp: MLP, final_act=None, res=None):
 
 
 @DECODERS.register_module()
-class ScanNetQueryDecoder(nn.Module):
+class ScanNetQueryDecoder(DerivedWeights):
     def __init__(self, num_layers, num_instance_queries, num_semantic_queries, num_instance_classes,
                  num_semantic_classes, num_semantic_linears, in_channels, d_model, num_heads, hidden_dim, dropout,
                  activation_fn, iter_pred, attn_mask, fix_attention, objectness_flag, add_dinox_query_ca=False,
@@ -250,24 +251,18 @@ class ScanNetQueryDecoder(nn.Module):
         self._packed = None
         self._pe_tables = {}
 
-    # ---- derived weights (hoisted / concatenated), rebuilt after .to() / load_state_dict ----------
-    def _apply(self, fn, *a, **k):
+    # ---- derived weights (hoisted / concatenated / bf16-rounded), rebuilt when their sources change (_cache.py) ----
+    def _derived_reset(self):
+        super()._derived_reset()
         self._packed = None
         self._pe_tables = {}
-        return super()._apply(fn, *a, **k)
-
-    def load_state_dict(self, *a, **k):
-        self._packed = None
-        return super().load_state_dict(*a, **k)
-
-    def invalidate_packed_weights(self):
-        self._packed = None
+        ops.clear_split_cache()          # bf16 roundings of the packed weights die with them
 
     def packed(self, live=False):
         """Packed projection weights; `live=True` keeps them attached to the parameters (training: rebuilt every step, the
         concatenations are autograd views of the live weights)."""
         det = (lambda t: t) if live else (lambda t: t.detach())  # noqa: E731
-        if live or self._packed is None:
+        if live or not self._derived_valid() or self._packed is None:
             d, L = self.d_model, self.num_layers
             cat = lambda mods, attr: torch.cat([det(getattr(m, attr)) for m in mods]).contiguous()  # noqa: E731
             if not self.add_positional_embedding:

@@ -412,13 +412,22 @@ def split_weights(wt, terms):
     return torch.stack(parts).contiguous()
 
 
+_SPLIT_CACHE_MAX = 64
+
+
 def _cached_split(wt, terms):
-    key = (wt.data_ptr(), tuple(wt.shape), terms, wt._version)
-    hit = _SPLIT_CACHE.get(key)
+    """bf16 rounding(s) of a weight tensor, cached.  An entry keeps its SOURCE tensor alive, so the address in the key
+    cannot be handed to another tensor while the entry exists (the caching allocator reuses addresses of freed blocks: a
+    rebuilt set of packed weights lands where the old one was); in-place updates move `_version`.  Least-recently-used
+    entries are dropped beyond _SPLIT_CACHE_MAX; owners drop everything with clear_split_cache() when their weights change."""
+    key = (wt.data_ptr(), tuple(wt.shape), tuple(wt.stride()), terms, wt._version)
+    hit = _SPLIT_CACHE.pop(key, None)
     if hit is None:
-        hit = split_weights(wt, terms)
-        _SPLIT_CACHE[key] = hit
-    return hit
+        hit = (split_weights(wt, terms), wt)
+        while len(_SPLIT_CACHE) >= _SPLIT_CACHE_MAX:
+            _SPLIT_CACHE.pop(next(iter(_SPLIT_CACHE)), None)
+    _SPLIT_CACHE[key] = hit                          # re-inserted last = most recently used
+    return hit[0]
 
 
 def clear_split_cache():

@@ -121,3 +121,33 @@ def add_training_targets(points: torch.Tensor, target, n_instances: int = 12, n_
     target.masks = inst[:, sp].unsqueeze(-1).to(points.device)
     target.labels = labels.to(points.device)
     return target
+
+
+def structure_scene(points: torch.Tensor, target, seed: int = 5, embed_scale: float = 2.0, noise: float = 0.1):
+    """Give a `make_scene` scene per-superpoint structure, in place: iid-noise inputs and random weights give every
+    superpoint the same features (and every predicted mask the same points), so post-processing would be exercised on
+    empty or degenerate selections.  2D features and colours become a per-superpoint embedding plus noise."""
+    g = torch.Generator().manual_seed(seed)
+    ef = target.extra_features
+    sp = ef["super_point_masks"].cpu()
+    S = int(sp.max()) + 1
+    n, c = ef["points_2dfeats"].shape
+    f2d = (torch.randn(S, c, generator=g) * embed_scale)[sp] + noise * torch.randn(n, c, generator=g)
+    rgb = torch.randn(S, 3, generator=g)[sp]
+    ef["points_2dfeats"] = f2d.to(ef["points_2dfeats"].device)
+    points[:, 3:] = rgb.to(points.device)
+    return points, target
+
+
+def sharpen_random_model(model, seed: int = 1, mask_gain: float = 40.0):
+    """Random-init weights that yield a non-trivial operating point: non-identity BatchNorm running statistics and a
+    sharpened mask branch, so that a prediction switches on a handful of superpoints.  In place; returns the model."""
+    g = torch.Generator().manual_seed(seed)
+    with torch.no_grad():
+        for m in model.modules():
+            if isinstance(m, torch.nn.BatchNorm1d):
+                m.running_mean.copy_(0.1 * torch.randn(m.num_features, generator=g))
+                m.running_var.copy_(0.5 + torch.rand(m.num_features, generator=g))
+        model.decoder.x_mask[2].weight.mul_(mask_gain)
+        model.decoder.x_mask[2].bias.zero_()
+    return model

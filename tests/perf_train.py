@@ -84,6 +84,7 @@ for key, cin, cout in [(("same", 0, 3), 96, 96), (("same", 1, 3), 96, 96), (("sa
 out["sparse_conv_backward"] = rows
 # ---------------------------------------------------------------- backbone training step (forward + backward)
 import time as _t
+import segdino3d_amd as seg
 from segdino3d_amd.backbone_mink import Res16UNet34C
 from oracle import sparse_ref as R
 torch.manual_seed(0)
@@ -101,7 +102,9 @@ for n_pts, n_sp in ((150000, 3000), (20000, 400)):
         (f[0] * f[0]).mean().backward()
 
     ms = timeit(step, 5)
-    rows[f"{n_pts}_points"] = dict(ms_device_fwd_bwd=round(ms, 2), voxels=int(net.last_maps.n_vox[0]))
+    with seg.capture() as cap_:
+        step()
+    rows[f"{n_pts}_points"] = dict(ms_device_fwd_bwd=round(ms, 2), voxels=int(cap_.maps[0].n_vox[0]))
     if n_pts == 20000:                                   # the same step through the oracle + torch autograd on the host cores
         sd = {"backbone." + k: (v.detach().cpu().clone().requires_grad_(True) if v.is_floating_point() else v.cpu())
               for k, v in net.state_dict().items()}
@@ -120,7 +123,7 @@ import segdino3d_amd as seg
 from segdino3d_amd.configs import scannet200_model_cfg
 from segdino3d_amd.synth import add_training_targets
 torch.manual_seed(0)
-model = seg.build_architecture(scannet200_model_cfg(query_num=200)).to(d).train()
+model = seg.build_architecture(scannet200_model_cfg(query_num=-1)).to(d).train()
 steps = {}
 for n_pts, n_sp, n_inst in ((150000, 3000, 40), (20000, 400, 10)):
     pts_s, tgt_s = make_scene(5, n_pts, n_sp, 300 if n_pts > 50000 else 50)
@@ -150,9 +153,10 @@ for n_pts, n_sp, n_inst in ((150000, 3000, 40), (20000, 400, 10)):
             model([pd], [td])
         e1.record(); torch.cuda.synchronize()
         fwd_only.append(e0.elapsed_time(e1))
-    l = train_step()
+    with seg.capture() as cap_:
+        l = train_step()
     steps[f"{n_pts}_points"] = dict(ms_forward_loss_backward=round(ms, 2), ms_forward_loss_no_grad=round(min(fwd_only), 2),
-                                    queries=int(model.last_outputs["masks"][0].shape[0]), objects=int(td.labels.shape[0]),
+                                    queries=int(cap_.outputs["masks"][0].shape[0]), objects=int(td.labels.shape[0]),
                                     seg_loss=round(float(l["seg_loss"]), 4), inst_loss=round(float(l["inst_loss"]), 4))
 out["full_model_training_step"] = steps
 print(json.dumps(out, indent=1))

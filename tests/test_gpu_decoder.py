@@ -284,9 +284,9 @@ def test_baseline_prototype_end_to_end_matches_oracle():
     model.to(d)
     model.to_host = False
     sp = tgt.extra_features["super_point_masks"].clone()
-    with torch.no_grad():
+    with torch.no_grad(), seg.capture() as cap:
         res = model([pts.to(d)], [tgt.to(d)])
-    out = model.last_outputs
+    out = cap.outputs
     f, _, _ = R.mink_forward_wrapper(sd, pts, None, sp, mode="only_rgb")
     cfg = D.DecoderCfg(add_positional_embedding=False, add_dinox_query_ca=False, add_box_size_pred=False,
                        box_modulate_ca=False, normalize_box_prediction=False)

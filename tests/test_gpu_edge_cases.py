@@ -118,11 +118,12 @@ def test_no_2d_queries_and_no_surviving_instances():
     model.backbone.f, model.backbone.p = sp_feat.to(d), sp_pos.to(d)
     tgt = GD3DTarget(masks=None, extra_features=dict(super_point_masks=sp, query2d_feats=torch.zeros(0, 256),
                      query2d_pos=torch.zeros(0, 3))).to(d)
-    res = model([pts.to(d)], [tgt])
+    with seg.capture() as cap:
+        res = model([pts.to(d)], [tgt])
     pd = res[0].pred_pts_seg
     assert pd.pts_instance_mask[0].shape == (0, N) and pd.instance_scores.shape == (0,) and pd.instance_boxes.shape == (0, 6)
     assert pd.pts_semantic_mask[0].shape == (N,) and np.array_equal(pd.pts_semantic_mask[1], pd.pts_instance_mask[1])
-    out = model.last_outputs
+    out = cap.outputs
     lo, hi = pts[:, :3].min(0)[0], pts[:, :3].max(0)[0]
     ref = D.decoder_forward(sd, D.DecoderCfg(), sp_feat, sp_pos, sp_pos, sp_feat, sp_pos, torch.zeros(0, 256), torch.zeros(0, 3), lo, hi)
     err = (out["masks"][0].cpu() - ref["masks"]).abs()

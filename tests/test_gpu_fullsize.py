@@ -168,11 +168,12 @@ def test_full_forward_is_deterministic_and_counts_add_up():
     pts, tgt = pts.to(d), tgt.to(d)
     import copy
     with torch.no_grad():
-        r1 = model([pts], [copy.copy(tgt)])[0].pred_pts_seg
-        out1 = {k: v[0].clone() if isinstance(v, list) and torch.is_tensor(v[0]) else v for k, v in model.last_outputs.items()
-                if k in ("masks", "cls_preds")}
-        r2 = model([pts], [copy.copy(tgt)])[0].pred_pts_seg
-        out2 = model.last_outputs
+        with seg.capture() as c1:
+            r1 = model([pts], [copy.copy(tgt)])[0].pred_pts_seg
+        out1 = {k: c1.outputs[k][0] for k in ("masks", "cls_preds")}
+        with seg.capture() as c2:
+            r2 = model([pts], [copy.copy(tgt)])[0].pred_pts_seg
+        out2 = c2.outputs
     assert torch.equal(out1["masks"], out2["masks"][0]) and torch.equal(out1["cls_preds"], out2["cls_preds"][0])
     m1, m2 = r1.pts_instance_mask[0], r2.pts_instance_mask[0]
     assert m1.shape == m2.shape and m1.shape[1] == N_POINTS and torch.equal(m1, m2)

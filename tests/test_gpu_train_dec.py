@@ -207,7 +207,7 @@ def test_full_model_training_step_matches_float64_oracle():
     from segdino3d_amd.synth import add_training_targets, make_scene
     d = dev()
     torch.manual_seed(0)
-    model = seg.build_architecture(scannet200_model_cfg(query_num=200)).to(d).train()
+    model = seg.build_architecture(scannet200_model_cfg(query_num=-1)).to(d).train()
     sd = {k: v.detach().cpu().clone() for k, v in model.state_dict().items()}
     pts, tgt = make_scene(21, n_points=20000, n_superpoints=150, n_query2d=20)
     tgt = add_training_targets(pts, tgt, n_instances=8, seed=1)
@@ -218,7 +218,8 @@ def test_full_model_training_step_matches_float64_oracle():
     train_ops.TrainBackend.IGNORE_ACT = True
     try:
         torch.manual_seed(7)
-        losses = model([pts_d], [tgt_d])
+        with seg.capture() as cap:
+            losses = model([pts_d], [tgt_d])
         (losses["seg_loss"] + losses["inst_loss"]).backward()
     finally:
         train_ops.TrainBackend.IGNORE_ACT = False
@@ -227,7 +228,7 @@ def test_full_model_training_step_matches_float64_oracle():
     torch.manual_seed(7)
     n = ((1 - model.query_thr) * torch.rand(1) + model.query_thr)
     ids = torch.randperm(S)[: int((n * S).int())]
-    assert model.last_outputs["masks"][0].shape[0] == len(ids)
+    assert cap.outputs["masks"][0].shape[0] == len(ids)
     sd64 = {k: (v.double().requires_grad_(True) if v.is_floating_point() else v) for k, v in sd.items()}
     ic = model.criterion.inst_criterion
     loss_cfg = dict(matcher="sparse", topk=ic.topk, cost_weights=ic.cost_weights, loss_weight=ic.loss_weight, num_classes=ic.num_classes,
@@ -249,7 +250,7 @@ def test_full_model_training_step_matches_float64_oracle():
                                       cpu["masks"], cpu["labels"], cpu["spm"], ids, loss_cfg, dec_cfg=D.DecoderCfg())
     finally:
         R.mink_forward_wrapper = orig
-    same_bits = torch.equal(model.last_outputs["masks"][0].detach().cpu() > 0, out64["masks"].detach() > 0)
+    same_bits = torch.equal(cap.outputs["masks"][0].detach().cpu() > 0, out64["masks"].detach() > 0)
     assert same_bits, "mask signs differ between the float32 device run and the float64 oracle: gradients are not comparable"
     (ref["seg_loss"] + ref["inst_loss"]).backward()
     for k in ("seg_loss", "inst_loss"):
@@ -318,7 +319,7 @@ def test_training_step_is_bit_reproducible():
     from segdino3d_amd.synth import add_training_targets, make_scene
     d = dev()
     torch.manual_seed(0)
-    model = seg.build_architecture(scannet200_model_cfg(query_num=200)).to(d).train()
+    model = seg.build_architecture(scannet200_model_cfg(query_num=-1)).to(d).train()
     pts, tgt = make_scene(23, n_points=20000, n_superpoints=200, n_query2d=30)
     tgt = add_training_targets(pts, tgt, n_instances=8, seed=3)
     pts, tgt = pts.to(d), tgt.to(d)

@@ -18,7 +18,7 @@ dev = torch.device("cuda", int(os.environ.get("LOCAL_RANK", "0")) if backend == 
 torch.cuda.set_device(dev)
 dist.init_process_group(backend, rank=rank, world_size=world)
 torch.manual_seed(0)
-model = seg.build_architecture(scannet200_model_cfg(query_num=200)).to(dev).train()
+model = seg.build_architecture(scannet200_model_cfg(query_num=-1)).to(dev).train()
 pts, tgt = make_scene(30 + rank, n_points=12000, n_superpoints=120, n_query2d=20)
 tgt = add_training_targets(pts, tgt, n_instances=6, seed=rank)
 pts, tgt = pts.to(dev), tgt.to(dev)

@@ -8,7 +8,7 @@ B = int(sys.argv[1]) if len(sys.argv) > 1 else 4
 n_pts = int(sys.argv[2]) if len(sys.argv) > 2 else 150000
 d = torch.device("cuda:0")
 torch.manual_seed(0)
-model = seg.build_architecture(scannet200_model_cfg(query_num=200)).to(d).train()
+model = seg.build_architecture(scannet200_model_cfg(query_num=-1)).to(d).train()
 batch = []
 for b in range(B):
     pts, tgt = make_scene(60 + b, n_pts, 3000, 300)

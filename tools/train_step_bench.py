@@ -8,7 +8,7 @@ n_pts = int(sys.argv[1]) if len(sys.argv) > 1 else 150000
 steps = int(sys.argv[2]) if len(sys.argv) > 2 else 5
 d = torch.device("cuda:0")
 torch.manual_seed(0)
-model = seg.build_architecture(scannet200_model_cfg(query_num=200)).to(d).train()
+model = seg.build_architecture(scannet200_model_cfg(query_num=-1)).to(d).train()
 pts, tgt = make_scene(5, n_pts, 3000 if n_pts > 50000 else 400, 300 if n_pts > 50000 else 50)
 tgt = add_training_targets(pts, tgt, n_instances=40 if n_pts > 50000 else 10, seed=2)
 pts, tgt = pts.to(d), tgt.to(d)
