@@ -162,7 +162,7 @@ int sd3d_gather_gemm(const float* in0, int ld0, int C0, const float* in1, int ld
     p.in0 = in0; p.ld0 = ld0; p.C0 = C0; p.in1 = in1; p.ld1 = ld1; p.nbr = nbr; p.wt = wt; p.K = K; p.Cin = Cin; p.Cout = Cout;
     p.M = M; p.scale = scale; p.shift = shift; p.res = res; p.ld_res = ld_res; p.out = out; p.ld_out = ld_out; p.act = act;
     p.col_groups = 1;
-    p.dbg = 0;
+   
     p.ksplit = 1;
     p.ws = nullptr;
     return launch_gather_gemm(p, nt, ws, ws_bytes, ST);
@@ -176,7 +176,7 @@ int sd3d_gather_gemm_split(const float* in0, int ld0, int C0, const float* in1, 
     p.in0 = in0; p.ld0 = ld0; p.C0 = C0; p.in1 = in1; p.ld1 = ld1; p.nbr = nbr; p.wt = nullptr; p.K = K; p.Cin = Cin; p.Cout = Cout;
     p.M = M; p.scale = scale; p.shift = shift; p.res = res; p.ld_res = ld_res; p.out = out; p.ld_out = ld_out; p.act = act;
     p.col_groups = 1;
-    p.dbg = 0;
+   
     p.ksplit = 1;
     p.ws = nullptr;
     return launch_gather_gemm_split(p, nt, terms, wt_split, ws, ws_bytes, ST);

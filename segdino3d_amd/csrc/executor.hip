@@ -38,7 +38,7 @@ extern "C" int sd3d_run_layers(const sd3d_layer* layers, int n_layers, const sd3
             GGParams p;
             p.in0 = a.ptr; p.ld0 = a.ld; p.C0 = L.C0; p.in1 = b ? b->ptr : nullptr; p.ld1 = b ? b->ld : 0; p.nbr = nullptr; p.wt = L.wt;
             p.K = 1; p.Cin = L.Cin; p.Cout = L.Cout; p.M = o.rows; p.scale = L.scale; p.shift = L.shift; p.res = r ? r->ptr : nullptr;
-            p.ld_res = r ? r->ld : 0; p.out = o.ptr; p.ld_out = o.ld; p.act = L.act; p.col_groups = 1; p.dbg = 0; p.ksplit = 1; p.ws = nullptr;
+            p.ld_res = r ? r->ld : 0; p.out = o.ptr; p.ld_out = o.ld; p.act = L.act; p.col_groups = 1; p.ksplit = 1; p.ws = nullptr;
             rc = launch_gather_gemm(p, 0, ws, ws_bytes, st);
         } else if (L.kind == SD3D_LAYER_SCALE_SHIFT_ACT) {
             rc = launch_scale_shift_act(a.ptr, a.ld, L.C0, b ? b->ptr : nullptr, b ? b->ld : 0, L.scale, L.shift, L.act, o.rows, L.Cin, o.ptr,

@@ -366,7 +366,7 @@ int launch_gather_gemm(const GGParams& p_in, int nt, void* ws, size_t ws_bytes, 
     GGParams p = p_in;
     p.ksplit = 1;
     p.ws = nullptr;
-    p.dbg = 0;
+   
     if (p.M <= 0 || p.Cout <= 0) return SD3D_OK;
     if (p.Cin <= 0 || (p.Cin & 31)) return sd3d_set_error(SD3D_ERR_ARG, "gather_gemm: Cin must be a positive multiple of 32");
     if (p.in1 && ((p.C0 & 31) || p.C0 > p.Cin)) return sd3d_set_error(SD3D_ERR_ARG, "gather_gemm: concat split must be a multiple of 32");

@@ -233,7 +233,7 @@ int launch_gather_gemm_split(const GGParams& p_in, int nt, int terms, const void
     GGParams p = p_in;
     p.ksplit = 1;
     p.ws = nullptr;
-    p.dbg = 0;
+   
     if (p.M <= 0 || p.Cout <= 0) return SD3D_OK;
     if (terms != 1 && terms != 3 && terms != 6) return sd3d_set_error(SD3D_ERR_ARG, "gather_gemm_split: terms must be 1, 3 or 6");
     if (p.Cin <= 0 || (p.Cin & 31)) return sd3d_set_error(SD3D_ERR_ARG, "gather_gemm_split: Cin must be a positive multiple of 32");

@@ -14,7 +14,6 @@ struct GGParams {
     float* out; int ld_out;
     int act;                                  // 0 none, 1 relu, 2 gelu(erf), 3 sigmoid
     int col_groups;                           // ceil(Cout / (32*NT))
-    int dbg;                                  // timing experiments only (SD3D_GG_DBG): 1 = no LDS atomics, 2 = no loads/MFMA
     int ksplit;                               // lock-step kernel only: gridDim.z offset slices (partials -> ws)
     float* ws;                                // [ksplit][M][Cout] partial sums when ksplit > 1
 };

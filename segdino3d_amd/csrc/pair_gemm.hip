@@ -125,7 +125,6 @@ struct PGParams {
     int Cin, Cout;
     float* part;                              // [n_tiles * 128][Cout]
     int n_tiles;                              // capacity; the real count is tile_k[n_tiles]
-    int dbg;                                  // SD3D_PAIR_DBG (timing experiments only): 1 = clustered gather rows instead of in_idx
 };
 
 // A workgroup walks its range of consecutive 128-pair tiles as ONE flat stream of (tile, 32-channel
@@ -150,7 +149,7 @@ __device__ __forceinline__ void pair_gemm_body(const PGParams& p, float (*Bs)[NT
     const int nsteps = ntl * nchunks;
     const int64_t wstride = (int64_t)p.Cout * p.Cin;
 
-#define LOAD_IDX(lt) ((lt) < ntl ? ((p.dbg & 1) ? ((tile0 + (lt)) * 7 + wv * 32 + j) & 1023 : p.in_idx[(int64_t)(tile0 + (lt)) * PT + wv * 32 + j]) : -1)
+#define LOAD_IDX(lt) ((lt) < ntl ? p.in_idx[(int64_t)(tile0 + (lt)) * PT + wv * 32 + j] : -1)
 #define LOAD_K(lt) ((lt) < ntl ? p.tile_k[tile0 + (lt)] : 0)
     int q0 = LOAD_IDX(0), q1 = LOAD_IDX(1), q2 = LOAD_IDX(2);  // gather rows of the current tile and the next two
     int k_cur = LOAD_K(0), k_nxt = LOAD_K(1);
@@ -330,7 +329,7 @@ __device__ __forceinline__ void pair_gemm_ws_body(const PGParams& p, float* Ws) 
     const int ntl = range1 - tile0 < WS_RANGE_TILES ? range1 - tile0 : WS_RANGE_TILES;
     __syncthreads();                                           // nobody still reads the previous piece's indices
     for (int f = tid; f < ntl * PT; f += 256) {
-        const int v = (p.dbg & 1) ? ((tile0 * PT + f) * 7) & 1023 : p.in_idx[(int64_t)tile0 * PT + f];
+        const int v = p.in_idx[(int64_t)tile0 * PT + f];
         Ix[f] = v < 0 ? 0 : v;                                 // their partial products are never read back
     }
     int run_start = 0;
@@ -552,7 +551,6 @@ int launch_pair_conv(const float* in0, int ld0, int C0, const float* in1, int ld
     if (sub > 4 && sub % 4) { for (int c = 4; c >= 1; --c) if (sub % c == 0) { nt = c; break; } }
     const int cgs = (int)cdiv(sub, nt);
     g.n_tiles = (int)(p_cap / PT);
-    { static int dbg = -1; if (dbg < 0) { const char* e = getenv("SD3D_PAIR_DBG"); dbg = e ? atoi(e) : 0; } g.dbg = dbg; }
     static int slots_env = -1;                                 // SD3D_PAIR_SLOTS: workgroups per CU override (tuning)
     if (slots_env < 0) { const char* e = getenv("SD3D_PAIR_SLOTS"); slots_env = e ? atoi(e) : 0; }
     static int n_cu = 0;
