@@ -36,6 +36,9 @@ int launch_gather_gemm(const GGParams&, int, void*, size_t, hipStream_t);
 int launch_gather_gemm_split(const GGParams&, int, int, const void*, void*, size_t, hipStream_t);
 size_t pair_lists_ws_bytes(int K, int64_t M);
 int launch_pair_lists(const int32_t*, int, int64_t, int64_t, int32_t*, int32_t*, int32_t*, void*, size_t, hipStream_t);
+size_t slab_conv_ws_bytes(int, int, int, int64_t, int64_t);
+int launch_slab_conv(const float*, int, int, const float*, int, const int32_t*, int64_t, const float*, int, int, int, int64_t, const float*,
+                     const float*, const float*, int, float*, int, int, void*, size_t, hipStream_t);
 int launch_pair_conv(const float*, int, int, const float*, int, const int32_t*, const int32_t*, int64_t, const int32_t*, const float*,
                      int, int, int, int64_t, const float*, const float*, const float*, int, float*, int, int, float*, size_t,
                      hipStream_t);
@@ -162,7 +165,6 @@ int sd3d_gather_gemm(const float* in0, int ld0, int C0, const float* in1, int ld
     p.in0 = in0; p.ld0 = ld0; p.C0 = C0; p.in1 = in1; p.ld1 = ld1; p.nbr = nbr; p.wt = wt; p.K = K; p.Cin = Cin; p.Cout = Cout;
     p.M = M; p.scale = scale; p.shift = shift; p.res = res; p.ld_res = ld_res; p.out = out; p.ld_out = ld_out; p.act = act;
     p.col_groups = 1;
-   
     p.ksplit = 1;
     p.ws = nullptr;
     return launch_gather_gemm(p, nt, ws, ws_bytes, ST);
@@ -176,7 +178,6 @@ int sd3d_gather_gemm_split(const float* in0, int ld0, int C0, const float* in1, 
     p.in0 = in0; p.ld0 = ld0; p.C0 = C0; p.in1 = in1; p.ld1 = ld1; p.nbr = nbr; p.wt = nullptr; p.K = K; p.Cin = Cin; p.Cout = Cout;
     p.M = M; p.scale = scale; p.shift = shift; p.res = res; p.ld_res = ld_res; p.out = out; p.ld_out = ld_out; p.act = act;
     p.col_groups = 1;
-   
     p.ksplit = 1;
     p.ws = nullptr;
     return launch_gather_gemm_split(p, nt, terms, wt_split, ws, ws_bytes, ST);
@@ -193,6 +194,14 @@ int sd3d_pair_conv(const float* in0, int ld0, int C0, const float* in1, int ld1,
                    size_t part_bytes, void* stream) {
     return launch_pair_conv(in0, ld0, C0, in1, ld1, in_idx, tile_k, p_cap, pos, wt, K, Cin, Cout, M, scale, shift, res, ld_res, out,
                             ld_out, act, part, part_bytes, ST);
+}
+
+size_t sd3d_slab_conv_ws_bytes(int K, int Cin, int Cout, int64_t M, int64_t n_pairs) { return slab_conv_ws_bytes(K, Cin, Cout, M, n_pairs); }
+int sd3d_slab_conv(const float* in0, int ld0, int C0, const float* in1, int ld1, const int32_t* nbr, int64_t n_pairs, const float* wt, int K,
+                   int Cin, int Cout, int64_t M, const float* scale, const float* shift, const float* res, int ld_res, float* out,
+                   int ld_out, int act, void* ws, size_t ws_bytes, void* stream) {
+    return launch_slab_conv(in0, ld0, C0, in1, ld1, nbr, n_pairs, wt, K, Cin, Cout, M, scale, shift, res, ld_res, out, ld_out, act, ws,
+                            ws_bytes, ST);
 }
 
 int sd3d_layernorm(const float* x, int ld_x, const float* res, int ld_res, const float* w, const float* b, float eps, int64_t M,

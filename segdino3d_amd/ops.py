@@ -197,6 +197,7 @@ _WS3 = _PerThread()       # partial products of pair_conv
 _WS4 = _PerThread()       # pair_lists scratch
 _WS5 = _PerThread()       # expand_masks bit table
 _WS6 = _PerThread()       # attention key-split partial states
+_WS7 = _PerThread()       # slab_conv: per-workgroup rulebook scratch (+ partial slabs of the offset split)
 
 
 # --------------------------------------------------------------------------------------------
@@ -493,6 +494,50 @@ def pair_conv(x, wt, pairs, x2=None, scale=None, shift=None, res=None, act=None,
                                   pairs.pos.data_ptr(), _ptr(wt, torch.float32, "wt"), K, Cin, Cout, M,
                                   _ptr(scale, torch.float32, "scale"), _ptr(shift, torch.float32, "shift"), pr, ldr, po, ldo,
                                   ACT[act], part.data_ptr(), part.numel(), _stream()), "pair_conv")
+    if hook is not None:
+        hook.after()
+    return out
+
+
+def slab_conv_supported(K, Cin, Cout, M, n_pairs) -> bool:
+    return _lib.load().sd3d_slab_conv_ws_bytes(K, Cin, Cout, M, int(n_pairs)) > 0
+
+
+def slab_conv(x, wt, nbr, n_pairs=None, x2=None, scale=None, shift=None, res=None, act=None, out=None):
+    """Same contract as gather_gemm(x, wt, nbr=...): output-stationary sparse convolution straight from the neighbour
+    table (csrc/slab_conv.hip).  `n_pairs` (entries >= 0 of `nbr`) only guides the launch geometry."""
+    lib = _lib.load()
+    K, Cout, Cin = wt.shape
+    if nbr.shape[0] != K:
+        raise ValueError(f"weights have {K} offsets, the neighbour table {nbr.shape[0]}")
+    M = nbr.shape[1]
+    p0, ld0 = _rows(x, "x")
+    C0 = x.shape[1]
+    p1, ld1 = (None, 0)
+    if x2 is not None:
+        p1, ld1 = _rows(x2, "x2")
+        if C0 + x2.shape[1] != Cin:
+            raise ValueError(f"concat channels {C0}+{x2.shape[1]} != Cin {Cin}")
+    elif C0 != Cin:
+        raise ValueError(f"input channels {C0} != Cin {Cin}")
+    if out is None:
+        out = torch.empty(M, Cout, dtype=torch.float32, device=x.device)
+    po, ldo = _rows(out, "out")
+    pr, ldr = (None, 0)
+    if res is not None:
+        pr, ldr = _rows(res, "res")
+    if n_pairs is None:
+        n_pairs = K * M // 2
+    nb = lib.sd3d_slab_conv_ws_bytes(K, Cin, Cout, M, int(n_pairs))
+    if nb == 0:
+        raise ValueError(f"slab_conv: shape K={K} Cin={Cin} Cout={Cout} is not supported")
+    ws = _WS7.get(nb, x.device)
+    hook = GG_HOOK
+    if hook is not None:
+        hook.before(dict(K=K, Cin=Cin, Cout=Cout, M=M, nbr=nbr, slab=True))
+    _lib.check(lib.sd3d_slab_conv(p0, ld0, C0, p1, ld1, _ptr(nbr, torch.int32, "nbr"), int(n_pairs), _ptr(wt, torch.float32, "wt"),
+                                  K, Cin, Cout, M, _ptr(scale, torch.float32, "scale"), _ptr(shift, torch.float32, "shift"), pr, ldr,
+                                  po, ldo, ACT[act], ws.data_ptr(), ws.numel(), _stream()), "slab_conv")
     if hook is not None:
         hook.after()
     return out
