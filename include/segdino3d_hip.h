@@ -144,6 +144,11 @@ int sd3d_gather_gemm_split(const float* in0, int ld0, int C0, const float* in1, 
 size_t sd3d_pair_lists_ws_bytes(int K, int64_t M);
 int sd3d_pair_lists(const int32_t* nbr, int K, int64_t M, int64_t p_cap, int32_t* pos, int32_t* in_idx, int32_t* tile_k,
                     void* ws, size_t ws_bytes, void* stream);
+/* The same for n <= 16 tables in ONE launch set (three kernels, no memsets): arrays of n host-side entries; ws holds the
+ * tables' scratch back to back, each rounded up to 256 bytes (sum of align256(sd3d_pair_lists_ws_bytes(K_i, M_i))). */
+int sd3d_pair_lists_batch(int n, const int32_t* const* nbr, const int* K, const int64_t* M, const int64_t* p_cap,
+                          int32_t* const* pos, int32_t* const* in_idx, int32_t* const* tile_k, void* ws, size_t ws_bytes,
+                          void* stream);
 int sd3d_pair_conv(const float* in0, int ld0, int C0, const float* in1, int ld1, const int32_t* in_idx,
                    const int32_t* tile_k, int64_t p_cap, const int32_t* pos, const float* wt, int K, int Cin, int Cout,
                    int64_t M, const float* scale, const float* shift, const float* res, int ld_res, float* out,

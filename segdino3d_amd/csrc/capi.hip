@@ -36,6 +36,8 @@ int launch_gather_gemm(const GGParams&, int, void*, size_t, hipStream_t);
 int launch_gather_gemm_split(const GGParams&, int, int, const void*, void*, size_t, hipStream_t);
 size_t pair_lists_ws_bytes(int K, int64_t M);
 int launch_pair_lists(const int32_t*, int, int64_t, int64_t, int32_t*, int32_t*, int32_t*, void*, size_t, hipStream_t);
+int launch_pair_lists_batch(int, const int32_t* const*, const int*, const int64_t*, const int64_t*, int32_t* const*, int32_t* const*,
+                            int32_t* const*, void*, size_t, hipStream_t);
 size_t slab_conv_ws_bytes(int, int, int, int64_t, int64_t);
 int launch_slab_conv(const float*, int, int, const float*, int, const int32_t*, int64_t, const float*, int, int, int, int64_t, const float*,
                      const float*, const float*, int, float*, int, int, void*, size_t, hipStream_t);
@@ -187,6 +189,10 @@ size_t sd3d_pair_lists_ws_bytes(int K, int64_t M) { return pair_lists_ws_bytes(K
 int sd3d_pair_lists(const int32_t* nbr, int K, int64_t M, int64_t p_cap, int32_t* pos, int32_t* in_idx, int32_t* tile_k, void* ws,
                     size_t ws_bytes, void* stream) {
     return launch_pair_lists(nbr, K, M, p_cap, pos, in_idx, tile_k, ws, ws_bytes, ST);
+}
+int sd3d_pair_lists_batch(int n, const int32_t* const* nbr, const int* K, const int64_t* M, const int64_t* p_cap, int32_t* const* pos,
+                          int32_t* const* in_idx, int32_t* const* tile_k, void* ws, size_t ws_bytes, void* stream) {
+    return launch_pair_lists_batch(n, nbr, K, M, p_cap, pos, in_idx, tile_k, ws, ws_bytes, ST);
 }
 int sd3d_pair_conv(const float* in0, int ld0, int C0, const float* in1, int ld1, const int32_t* in_idx, const int32_t* tile_k,
                    int64_t p_cap, const int32_t* pos, const float* wt, int K, int Cin, int Cout, int64_t M, const float* scale,

@@ -115,6 +115,104 @@ __global__ __launch_bounds__(256) void pair_fill_kernel(const int32_t* __restric
     }
 }
 
+// ---- the same three steps for SEVERAL tables in one launch set ---------------------------------------------------------------
+// A U-Net forward needs the lists of ~14 tables (one 5^3, five 3^3, four down, four up); built one by one that was 14 x (2
+// memsets + count + scan + fill) = 70 launches of a few microseconds each on the critical path of every scene.  Here a launch
+// covers all tables: a workgroup finds its (table, offset, row block) from the tables' cumulative block counts, and the fill
+// kernel writes the -1 padding itself (segment tails, the unused end of in_idx / tile_k) instead of two memsets per table.
+#define PL_MAX_TABLES 16
+struct PLTable {
+    const int32_t* nbr; int32_t* pos; int32_t* in_idx; int32_t* tile_k; int32_t* blk_cnt; int32_t* totals;
+    int64_t M, p_cap;
+    int K, nblk, wg0, k0;          // wg0: first workgroup of this table in the (K * nblk)-flattened grid; k0: first of the K-flattened grid
+};
+struct PLBatch { int n; PLTable t[PL_MAX_TABLES]; };
+
+__device__ __forceinline__ int pl_find_table(const PLBatch& b, int wg, bool by_k) {
+    int ti = 0;
+    for (int i = 1; i < b.n; ++i) if (wg >= (by_k ? b.t[i].k0 : b.t[i].wg0)) ti = i;
+    return ti;
+}
+
+__global__ __launch_bounds__(256) void pair_count_batch_kernel(const PLBatch b) {
+    __shared__ int sm[4];
+    const int ti = pl_find_table(b, blockIdx.x, false);
+    const PLTable& T = b.t[ti];
+    const int local = blockIdx.x - T.wg0, k = local / T.nblk, blk = local - k * T.nblk, tid = threadIdx.x;
+    int c = 0;
+#pragma unroll
+    for (int i = 0; i < PL_ROWS / 256; ++i) {
+        const int64_t row = (int64_t)blk * PL_ROWS + i * 256 + tid;
+        const bool v = row < T.M && T.nbr[(int64_t)k * T.M + row] >= 0;
+        c += __popcll(__ballot(v));
+    }
+    if ((tid & 63) == 0) sm[tid >> 6] = c;
+    __syncthreads();
+    if (tid == 0) T.blk_cnt[(int64_t)k * T.nblk + blk] = sm[0] + sm[1] + sm[2] + sm[3];
+}
+
+__global__ __launch_bounds__(256) void pair_scan_batch_kernel(const PLBatch b) {
+    __shared__ int sm[4];
+    const int ti = pl_find_table(b, blockIdx.x, true);
+    const PLTable& T = b.t[ti];
+    const int k = blockIdx.x - T.k0, tid = threadIdx.x;
+    int running = 0;
+    for (int base = 0; base < T.nblk; base += 256) {
+        const int i = base + tid;
+        const int v = i < T.nblk ? T.blk_cnt[(int64_t)k * T.nblk + i] : 0;
+        int total;
+        const int ex = block_excl_scan_256p(v, &total, sm);
+        if (i < T.nblk) T.blk_cnt[(int64_t)k * T.nblk + i] = running + ex;
+        running += total;
+    }
+    if (tid == 0) T.totals[k] = running;
+}
+
+__global__ __launch_bounds__(256) void pair_fill_batch_kernel(const PLBatch b) {
+    __shared__ int sm[4];
+    __shared__ int wcnt[4];
+    const int ti = pl_find_table(b, blockIdx.x, false);
+    const PLTable& T = b.t[ti];
+    const int local = blockIdx.x - T.wg0, k = local / T.nblk, blk = local - k * T.nblk;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    int s = 0;
+    for (int kk = tid; kk < k; kk += 256) s += (T.totals[kk] + PT - 1) / PT * PT;
+    int seg;
+    block_excl_scan_256p(s, &seg, sm);
+    const int tot_k = T.totals[k];
+    const int seg_len = (tot_k + PT - 1) / PT * PT;
+    if (blk == 0) {
+        for (int t = tid; t < seg_len / PT; t += 256)
+            if ((int64_t)(seg / PT + t) * PT < T.p_cap) T.tile_k[seg / PT + t] = k;
+        for (int e = tot_k + tid; e < seg_len; e += 256)       // the segment's padding
+            if ((int64_t)seg + e < T.p_cap) T.in_idx[seg + e] = -1;
+        if (k == T.K - 1) {                                    // past the last segment: unused capacity reads as "no pair"
+            const int64_t end = (int64_t)seg + seg_len < T.p_cap ? (int64_t)seg + seg_len : T.p_cap;
+            for (int64_t e = end + tid; e < T.p_cap; e += 256) T.in_idx[e] = -1;
+            for (int64_t t = end / PT + tid; t < T.p_cap / PT; t += 256) T.tile_k[t] = -1;
+            if (tid == 0) T.tile_k[T.p_cap / PT] = (int)(end / PT);
+        }
+    }
+    int base = seg + T.blk_cnt[(int64_t)k * T.nblk + blk];
+    const uint64_t lt = (1ull << lane) - 1ull;
+#pragma unroll 1
+    for (int i = 0; i < PL_ROWS / 256; ++i) {
+        const int64_t row = (int64_t)blk * PL_ROWS + i * 256 + tid;
+        const int id = row < T.M ? T.nbr[(int64_t)k * T.M + row] : -1;
+        const uint64_t bal = __ballot(id >= 0);
+        if (lane == 0) wcnt[wv] = __popcll(bal);
+        __syncthreads();
+        int before = 0;
+        for (int w = 0; w < wv; ++w) before += wcnt[w];
+        const int all = wcnt[0] + wcnt[1] + wcnt[2] + wcnt[3];
+        __syncthreads();
+        const int p = base + before + __popcll(bal & lt);
+        if (row < T.M) T.pos[(int64_t)k * T.M + row] = (id >= 0 && p < T.p_cap) ? p : -1;
+        if (id >= 0 && p < T.p_cap) T.in_idx[p] = id;
+        base += all;
+    }
+}
+
 // ---- pass 1: dense tiles over the pair list --------------------------------------------------
 struct PGParams {
     const float* in0; int ld0; int C0;
@@ -527,6 +625,36 @@ int launch_pair_lists(const int32_t* nbr, int K, int64_t M, int64_t p_cap, int32
     hipLaunchKernelGGL(pair_count_kernel, dim3(nblk, K), dim3(256), 0, st, nbr, M, nblk, blk_cnt);
     hipLaunchKernelGGL(pair_scan_kernel, dim3(K), dim3(256), 0, st, blk_cnt, nblk, totals);
     hipLaunchKernelGGL(pair_fill_kernel, dim3(nblk, K), dim3(256), 0, st, nbr, K, M, nblk, blk_cnt, totals, p_cap, pos, in_idx, tile_k);
+    SD3D_CHECK_LAUNCH();
+    return SD3D_OK;
+}
+
+// n tables at once (n <= PL_MAX_TABLES); ws of table i starts at ws_off[i] (pair_lists_ws_bytes(K_i, M_i) bytes each)
+int launch_pair_lists_batch(int n, const int32_t* const* nbr, const int* K, const int64_t* M, const int64_t* p_cap, int32_t* const* pos,
+                            int32_t* const* in_idx, int32_t* const* tile_k, void* ws, size_t ws_bytes, hipStream_t st) {
+    if (n <= 0) return SD3D_OK;
+    if (n > PL_MAX_TABLES) return sd3d_set_error(SD3D_ERR_ARG, "pair_lists_batch: at most 16 tables per call");
+    PLBatch b;
+    b.n = 0;
+    size_t off = 0;
+    int wg = 0, kk = 0;
+    for (int i = 0; i < n; ++i) {
+        if (K[i] <= 0 || M[i] <= 0) continue;
+        if (p_cap[i] <= 0 || (p_cap[i] % PT)) return sd3d_set_error(SD3D_ERR_ARG, "pair_lists_batch: p_cap must be a positive multiple of 128");
+        PLTable& T = b.t[b.n++];
+        T.nbr = nbr[i]; T.pos = pos[i]; T.in_idx = in_idx[i]; T.tile_k = tile_k[i]; T.M = M[i]; T.p_cap = p_cap[i]; T.K = K[i];
+        T.nblk = (int)cdiv(M[i], PL_ROWS);
+        T.blk_cnt = (int32_t*)((char*)ws + off);
+        T.totals = T.blk_cnt + (int64_t)T.K * T.nblk;
+        off += align_up(pair_lists_ws_bytes(K[i], M[i]), 256);
+        T.wg0 = wg; T.k0 = kk;
+        wg += T.K * T.nblk; kk += T.K;
+    }
+    if (off > ws_bytes) return sd3d_set_error(SD3D_ERR_ARG, "pair_lists_batch: workspace too small");
+    if (b.n == 0) return SD3D_OK;
+    hipLaunchKernelGGL(pair_count_batch_kernel, dim3(wg), dim3(256), 0, st, b);
+    hipLaunchKernelGGL(pair_scan_batch_kernel, dim3(kk), dim3(256), 0, st, b);
+    hipLaunchKernelGGL(pair_fill_batch_kernel, dim3(wg), dim3(256), 0, st, b);
     SD3D_CHECK_LAUNCH();
     return SD3D_OK;
 }

@@ -2,8 +2,8 @@
 //
 // Used by: voxelisation (sort points along the Z-order curve), superpoint pooling (group points by
 // superpoint id) and post-processing (top-k / score ordering).  These are HBM-bound integer passes
-// over <= a few million elements; 8-bit digits, one histogram + one scatter kernel per digit and
-// one scan of the [256][n_blocks] histogram.  Stability (needed so that points inside one voxel /
+// over <= a few million elements; 8-bit digits, one histogram + one scatter kernel per digit (the
+// scatter derives its cursors from the raw [256][n_blocks] histogram itself); arrays of <= 4096 elements are ranked by one workgroup.  Stability (needed so that points inside one voxel /
 // superpoint stay in ascending point order => deterministic fp32 sums downstream) comes from
 // ranking each wave's elements in chunk order with ballot-built match masks.
 #include "common.h"
@@ -81,6 +81,43 @@ __global__ __launch_bounds__(256) void scan_apply(const int* __restrict__ in, in
     for (int i = 0; i < 8; ++i) { if (base + i < n_cap) out[base + i] = ex; ex += v[i]; }
 }
 
+// One workgroup scans the whole array (n <= SCAN_SMALL_MAX): a single launch instead of three.  The inputs of this size are
+// latency-bound (a 19 k-entry radix histogram, 150 k voxel flags): 1024 threads walk it in 8 k-element rounds.
+#define SCAN_SMALL_MAX (1 << 18)
+__global__ __launch_bounds__(1024) void scan_small_kernel(const int* __restrict__ in, int64_t n_cap, const int* __restrict__ n_dev,
+                                                          int* __restrict__ out, int* __restrict__ total_out) {
+    __shared__ int wsum[16];
+    __shared__ int carry_s;
+    const int64_t n = n_dev ? min((int64_t)*n_dev, n_cap) : n_cap;
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    if (threadIdx.x == 0) carry_s = 0;
+    __syncthreads();
+    for (int64_t start = 0; start < n_cap; start += 1024 * 8) {
+        const int64_t base = start + (int64_t)threadIdx.x * 8;
+        int v[8], s = 0;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) { v[i] = (base + i < n) ? in[base + i] : 0; s += v[i]; }
+        int inc = s;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const int t = __shfl_up(inc, d);
+            if (lane >= d) inc += t;
+        }
+        if (lane == 63) wsum[w] = inc;
+        __syncthreads();
+        int wb = carry_s, tot = 0;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) { const int x = wsum[i]; if (i < w) wb += x; tot += x; }
+        int ex = wb + inc - s;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) { if (base + i < n_cap) out[base + i] = ex; ex += v[i]; }
+        __syncthreads();
+        if (threadIdx.x == 0) carry_s += tot;
+        __syncthreads();
+    }
+    if (threadIdx.x == 0 && total_out) *total_out = carry_s;
+}
+
 size_t scan_ws_bytes(int64_t n) { return align_up((size_t)cdiv(n, SCAN_TILE) * sizeof(int), 256); }
 
 // out may alias in.  n_dev (optional, device) = live length; elements beyond it count as zero.
@@ -88,6 +125,11 @@ int scan_exclusive_i32(const int* in, int* out, int64_t n_cap, const int* n_dev,
                        size_t ws_bytes, hipStream_t st) {
     if (n_cap <= 0) {
         if (total_dev) (void)hipMemsetAsync(total_dev, 0, sizeof(int), st);
+        return SD3D_OK;
+    }
+    if (n_cap <= SCAN_SMALL_MAX) {
+        hipLaunchKernelGGL(scan_small_kernel, dim3(1), dim3(1024), 0, st, in, n_cap, n_dev, out, total_dev);
+        SD3D_CHECK_LAUNCH();
         return SD3D_OK;
     }
     const int nb = (int)cdiv(n_cap, SCAN_TILE);
@@ -124,6 +166,7 @@ __global__ __launch_bounds__(RS_THREADS) void rs_scatter(const uint64_t* __restr
                                                          uint64_t* __restrict__ keys_out, uint32_t* __restrict__ vals_out,
                                                          int64_t n, int shift, const int* __restrict__ hist_scanned, int nb) {
     __shared__ int cnt[4][256];     // per-wave digit counts, then running output cursors
+    __shared__ int scan_sm[4];
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     for (int i = threadIdx.x; i < 4 * 256; i += RS_THREADS) (&cnt[0][0])[i] = 0;
     __syncthreads();
@@ -139,9 +182,23 @@ __global__ __launch_bounds__(RS_THREADS) void rs_scatter(const uint64_t* __restr
         if (ok) atomicAdd(&cnt[w][(int)((k[c] >> shift) & 0xFF)], 1);
     }
     __syncthreads();
-    {   // thread d: turn counts into starting cursors: global base of (digit, block) + earlier waves
+    {   // thread d: turn counts into starting cursors: global base of (digit, block) + earlier waves.  The global base is the
+        // exclusive prefix of the digit-major [256][nb] histogram at (d, this block) = (all blocks of smaller digits) + (earlier
+        // blocks of this digit); every workgroup adds it up itself from the raw histogram (nb <= a few hundred loads per
+        // thread, L2-resident) - that replaces a separate scan of the histogram, three launches per digit pass.
         const int d = threadIdx.x;
-        int run = hist_scanned[(int64_t)d * nb + blockIdx.x];
+        const int* hrow = hist_scanned + (int64_t)d * nb;
+        int before = 0, all = 0;
+        for (int b0 = 0; b0 < nb; b0 += 8) {
+            int h[8];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) h[i] = b0 + i < nb ? hrow[b0 + i] : 0;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) { all += h[i]; if (b0 + i < (int)blockIdx.x) before += h[i]; }
+        }
+        int tot;
+        const int smaller = block_excl_scan_256(all, &tot, scan_sm);
+        int run = smaller + before;
 #pragma unroll
         for (int ww = 0; ww < 4; ++ww) { int c = cnt[ww][d]; cnt[ww][d] = run; run += c; }
     }
@@ -171,6 +228,31 @@ __global__ __launch_bounds__(RS_THREADS) void rs_scatter(const uint64_t* __restr
     }
 }
 
+// n <= RANK_SORT_MAX: ONE workgroup, all key bits at once.  Every element counts the elements that sort before it (smaller key,
+// or equal key and smaller index: stable) against the whole key array held in LDS - n^2 compares, 9 M for the 3000 superpoint
+// scores of the query selection, 0.4 M for the 600 candidate instances, instead of 4-7 digit passes of two launches each.
+#define RANK_SORT_MAX 4096
+__global__ __launch_bounds__(1024) void rank_sort_kernel(const uint64_t* __restrict__ keys_in, const uint32_t* __restrict__ vals_in,
+                                                         uint64_t* __restrict__ keys_out, uint32_t* __restrict__ vals_out, int n,
+                                                         uint64_t mask) {
+    __shared__ uint64_t k[RANK_SORT_MAX];
+    for (int i = threadIdx.x; i < n; i += 1024) k[i] = keys_in[i] & mask;
+    __syncthreads();
+    for (int i = threadIdx.x; i < n; i += 1024) {
+        const uint64_t mine = k[i];
+        int rank = 0;
+        int j = 0;
+        for (; j + 4 <= n; j += 4) {                          // LDS broadcast reads: every lane walks the same j
+            const uint64_t a = k[j], b = k[j + 1], c = k[j + 2], d = k[j + 3];
+            rank += (a < mine || (a == mine && j < i)) + (b < mine || (b == mine && j + 1 < i)) +
+                    (c < mine || (c == mine && j + 2 < i)) + (d < mine || (d == mine && j + 3 < i));
+        }
+        for (; j < n; ++j) rank += (k[j] < mine || (k[j] == mine && j < i));
+        keys_out[rank] = keys_in[i];
+        vals_out[rank] = vals_in ? vals_in[i] : (uint32_t)i;
+    }
+}
+
 size_t sort_ws_bytes(int64_t n) {
     const int64_t nb = cdiv(n > 0 ? n : 1, RS_TILE);
     return align_up((size_t)nb * 256 * sizeof(int), 256) + scan_ws_bytes(nb * 256);
@@ -182,13 +264,18 @@ int sort_pairs_u64(uint64_t* keys_in, uint32_t* vals_in, uint64_t* keys_out, uin
                    int begin_bit, int end_bit, void* ws, size_t ws_bytes, hipStream_t st, uint32_t* vals_scratch) {
     if (n <= 0) return SD3D_OK;
     if (ws_bytes < sort_ws_bytes(n)) return sd3d_set_error(SD3D_ERR_WS, "sort workspace too small");
+    if (n <= RANK_SORT_MAX) {
+        const int nbits = end_bit - begin_bit;
+        const uint64_t mask = (nbits >= 64 ? ~0ull : ((1ull << (nbits > 0 ? nbits : 1)) - 1ull)) << begin_bit;
+        hipLaunchKernelGGL(rank_sort_kernel, dim3(1), dim3(1024), 0, st, keys_in, vals_in, keys_out, vals_out, (int)n, mask);
+        SD3D_CHECK_LAUNCH();
+        return SD3D_OK;
+    }
     int passes = (end_bit - begin_bit + 7) / 8;
     if (passes < 1) passes = 1;
     if ((passes & 1) == 0) ++passes;          // odd => result lands in *_out after ping-pong
     const int nb = (int)cdiv(n, RS_TILE);
     int* hist = (int*)ws;
-    void* scan_ws = (char*)ws + align_up((size_t)nb * 256 * sizeof(int), 256);
-    const size_t scan_bytes = ws_bytes - align_up((size_t)nb * 256 * sizeof(int), 256);
     // ping-pong: even passes read A (=*_in) and write B (=*_out), odd passes the other way round;
     // with an odd pass count the last pass writes *_out.  When vals_in is NULL pass 0 synthesises
     // value = index and the ping-pong partner of vals_out is vals_scratch.
@@ -202,8 +289,6 @@ int sort_pairs_u64(uint64_t* keys_in, uint32_t* vals_in, uint64_t* keys_out, uin
         const uint32_t* vsrc = (p == 0) ? vals_in : (even ? vother : vals_out);
         uint32_t* vdst = even ? vals_out : vother;
         hipLaunchKernelGGL(rs_hist, dim3(nb), dim3(RS_THREADS), 0, st, ksrc, n, shift, hist, nb);
-        int rc = scan_exclusive_i32(hist, hist, (int64_t)nb * 256, nullptr, nullptr, scan_ws, scan_bytes, st);
-        if (rc) return rc;
         hipLaunchKernelGGL(rs_scatter, dim3(nb), dim3(RS_THREADS), 0, st, ksrc, vsrc, kdst, vdst, n, shift, hist, nb);
     }
     SD3D_CHECK_LAUNCH();

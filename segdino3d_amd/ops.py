@@ -464,6 +464,34 @@ def pair_lists(nbr, n_pairs):
 PAIR_CONV = _os.environ.get("SD3D_PAIR_CONV", "1") != "0"
 
 
+def pair_lists_batch(tables):
+    """tables: list of (nbr int32 [K, M], n_pairs) -> list of PairLists, built by ONE launch set (csrc/pair_gemm.hip)."""
+    import ctypes as C
+    lib = _lib.load()
+    out = []
+    for start in range(0, len(tables), 16):
+        chunk = tables[start:start + 16]
+        n = len(chunk)
+        dev = chunk[0][0].device
+        Ks = (C.c_int * n)(); Ms = (C.c_int64 * n)(); caps = (C.c_int64 * n)()
+        nbrs = (C.c_void_p * n)(); poss = (C.c_void_p * n)(); idxs = (C.c_void_p * n)(); tks = (C.c_void_p * n)()
+        res, nb = [], 0
+        for i, (nbr, n_pairs) in enumerate(chunk):
+            K, M = nbr.shape
+            p_cap = (int(n_pairs) + 127 * K + 127) // 128 * 128
+            pos = torch.empty(K, M, dtype=torch.int32, device=dev)
+            in_idx = torch.empty(p_cap, dtype=torch.int32, device=dev)
+            tile_k = torch.empty(p_cap // 128 + 1, dtype=torch.int32, device=dev)
+            Ks[i], Ms[i], caps[i] = K, M, p_cap
+            nbrs[i], poss[i], idxs[i], tks[i] = _ptr(nbr, torch.int32, "nbr"), pos.data_ptr(), in_idx.data_ptr(), tile_k.data_ptr()
+            nb += (lib.sd3d_pair_lists_ws_bytes(K, M) + 255) // 256 * 256
+            res.append(PairLists(pos, in_idx, tile_k, p_cap, K, M))
+        ws = _WS4.get(nb, dev)
+        _lib.check(lib.sd3d_pair_lists_batch(n, nbrs, Ks, Ms, caps, poss, idxs, tks, ws.data_ptr(), ws.numel(), _stream()), "pair_lists_batch")
+        out += res
+    return out
+
+
 def pair_conv(x, wt, pairs, x2=None, scale=None, shift=None, res=None, act=None, out=None):
     """Same contract as gather_gemm(x, wt, nbr=...) for the table `pairs` was built from."""
     lib = _lib.load()

@@ -143,18 +143,22 @@ class SceneMaps:
             # no read-back: size the pair lists for the worst case (every offset of every voxel has a neighbour).  The
             # kernels walk the REAL tile count, which the list builder leaves on the device; only allocations grow.
             host = [k ** 3 * self.n_vox[lvl] for (lvl, k) in same]
+        todo = []                                               # (key, nbr, pairs): all rulebooks of the scene in one launch set
         for (lvl, k), c in zip(same, host):
             self.density[("same", lvl, k)] = (c / max(1, k ** 3 * self.n_vox[lvl])) if exact else None
             if ops.PAIR_CONV:
-                self.pairs[("same", lvl, k)] = ops.pair_lists(self._same[(lvl, k)], c)
+                todo.append((("same", lvl, k), self._same[(lvl, k)], c))
         for lvl in strides:
             # every fine voxel has exactly one parent: P = V_fine pairs in both directions
             self.density[("down", lvl)] = self.n_vox[lvl] / max(1, 8 * self.n_vox[lvl + 1])
             self.density[("up", lvl)] = 1.0 / 8.0
             if ops.PAIR_CONV and ("down", lvl) not in self.pairs:
                 dn, up = self._stride_maps(lvl)
-                self.pairs[("down", lvl)] = ops.pair_lists(dn, self.n_vox[lvl])
-                self.pairs[("up", lvl)] = ops.pair_lists(up, self.n_vox[lvl])
+                todo.append((("down", lvl), dn, self.n_vox[lvl]))
+                todo.append((("up", lvl), up, self.n_vox[lvl]))
+        if todo:
+            for (key, _, _), pl in zip(todo, ops.pair_lists_batch([(t[1], t[2]) for t in todo])):
+                self.pairs[key] = pl
 
     # ------------------------------------------------------------------------------------------
     def table(self, level: int):

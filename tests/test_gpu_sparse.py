@@ -20,7 +20,8 @@ def test_sort_pairs_stable_and_scan():
     from segdino3d_amd import ops
     d = dev()
     g = torch.Generator().manual_seed(0)
-    for n in (1, 63, 64, 65, 2047, 2048, 2049, 150_000):
+    # <= 4096: one-workgroup rank sort; above: digit passes; scans: one workgroup up to 2^18 elements, three kernels above
+    for n in (1, 63, 64, 65, 2047, 2048, 2049, 4095, 4096, 4097, 150_000, 300_000):
         keys = torch.randint(0, 1 << 40, (n,), generator=g, dtype=torch.int64)
         keys[::3] = keys[0]                       # many duplicates -> exercises stability
         sk, sv = ops.sort_pairs(keys.to(d).clone(), None, 0, 48)
@@ -281,6 +282,7 @@ def test_pair_lists_are_exact():
     d = dev()
     pts, tgt = make_scene(3, 9000, 100, 10)
     maps = SceneMaps(pts.to(d), 0.02, 3, superpoints=tgt.extra_features["super_point_masks"].to(d))
+    singles = []
     for nbr in (maps.same(0, 3), maps.same(2, 3), maps.down(0), maps.up(1), maps.same(0, 5)):
         K, M = nbr.shape
         h = nbr.cpu().numpy()
@@ -301,6 +303,16 @@ def test_pair_lists_are_exact():
             off += seg
         exp_tk[-1] = off // 128
         assert np.array_equal(pos, exp_pos) and np.array_equal(in_idx, exp_idx) and np.array_equal(tile_k, exp_tk)
+        singles.append((nbr, P, pl))
+    # all tables in ONE launch set (what SceneMaps.prepare uses): identical arrays, incl. the -1 padding the batch kernels
+    # write themselves, and a capacity larger than needed (unused tail reads as "no pair")
+    batch = ops.pair_lists_batch([(nbr, P + (1000 if i == 1 else 0)) for i, (nbr, P, _) in enumerate(singles)])
+    for i, ((nbr, P, pl), bl) in enumerate(zip(singles, batch)):
+        assert torch.equal(bl.pos, pl.pos) and bl.K == pl.K and bl.M == pl.M
+        n = min(bl.p_cap, pl.p_cap)
+        assert torch.equal(bl.in_idx[:n], pl.in_idx[:n]) and bool((bl.in_idx[n:] == -1).all())
+        assert torch.equal(bl.tile_k[: n // 128], pl.tile_k[: n // 128]) and bool((bl.tile_k[n // 128:-1] == -1).all())
+        assert int(bl.tile_k[-1]) == int(pl.tile_k[-1])
 
 
 def test_pair_conv_matches_gather_gemm_and_fp64():
