@@ -81,9 +81,38 @@ __global__ __launch_bounds__(256) void scan_apply(const int* __restrict__ in, in
     for (int i = 0; i < 8; ++i) { if (base + i < n_cap) out[base + i] = ex; ex += v[i]; }
 }
 
-// One workgroup scans the whole array (n <= SCAN_SMALL_MAX): a single launch instead of three.  The inputs of this size are
-// latency-bound (a 19 k-entry radix histogram, 150 k voxel flags): 1024 threads walk it in 8 k-element rounds.
-#define SCAN_SMALL_MAX (1 << 18)
+// Second (and last) kernel of the tiled scan: every workgroup adds up the tile sums before it by itself (<= a few hundred
+// ints, one wave-reduction) instead of waiting for a third, single-workgroup kernel to scan them; the last one stores the total.
+__global__ __launch_bounds__(256) void scan_apply_v2(const int* __restrict__ in, int64_t n_cap, const int* __restrict__ n_dev,
+                                                     const int* __restrict__ sums, int nb, int* __restrict__ out,
+                                                     int* __restrict__ total_out) {
+    __shared__ int sm[4];
+    __shared__ int base_s;
+    const int64_t n = n_dev ? min((int64_t)*n_dev, n_cap) : n_cap;
+    {
+        int part = 0;
+        for (int i = threadIdx.x; i < (int)blockIdx.x; i += 256) part += sums[i];
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) part += __shfl_xor(part, d);
+        if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = part;
+        __syncthreads();
+        if (threadIdx.x == 0) base_s = sm[0] + sm[1] + sm[2] + sm[3];
+        __syncthreads();
+    }
+    const int64_t base = (int64_t)blockIdx.x * SCAN_TILE + threadIdx.x * 8;
+    int v[8], s = 0;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) { v[i] = (base + i < n) ? in[base + i] : 0; s += v[i]; }
+    int total;
+    int ex = block_excl_scan_256(s, &total, sm) + base_s;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) { if (base + i < n_cap) out[base + i] = ex; ex += v[i]; }
+    if (total_out && blockIdx.x == nb - 1 && threadIdx.x == 0) *total_out = base_s + total;
+}
+
+// One workgroup scans the whole array (n <= SCAN_SMALL_MAX = two 8 k-element rounds): a single launch.  (A single workgroup
+// walking 150 k elements measured 113 us - 19 dependent rounds - against 14 us for the tiled path, so longer inputs stay tiled.)
+#define SCAN_SMALL_MAX (1 << 14)
 __global__ __launch_bounds__(1024) void scan_small_kernel(const int* __restrict__ in, int64_t n_cap, const int* __restrict__ n_dev,
                                                           int* __restrict__ out, int* __restrict__ total_out) {
     __shared__ int wsum[16];
@@ -136,8 +165,12 @@ int scan_exclusive_i32(const int* in, int* out, int64_t n_cap, const int* n_dev,
     if (ws_bytes < scan_ws_bytes(n_cap)) return sd3d_set_error(SD3D_ERR_WS, "scan workspace too small");
     int* sums = (int*)ws;
     hipLaunchKernelGGL(scan_tile_sums, dim3(nb), dim3(256), 0, st, in, n_cap, n_dev, sums);
-    hipLaunchKernelGGL(scan_sums_inplace, dim3(1), dim3(256), 0, st, sums, nb, total_dev);
-    hipLaunchKernelGGL(scan_apply, dim3(nb), dim3(256), 0, st, in, n_cap, n_dev, sums, out);
+    if (nb <= 4096) {
+        hipLaunchKernelGGL(scan_apply_v2, dim3(nb), dim3(256), 0, st, in, n_cap, n_dev, sums, nb, out, total_dev);
+    } else {
+        hipLaunchKernelGGL(scan_sums_inplace, dim3(1), dim3(256), 0, st, sums, nb, total_dev);
+        hipLaunchKernelGGL(scan_apply, dim3(nb), dim3(256), 0, st, in, n_cap, n_dev, sums, out);
+    }
     SD3D_CHECK_LAUNCH();
     return SD3D_OK;
 }
@@ -228,29 +261,30 @@ __global__ __launch_bounds__(RS_THREADS) void rs_scatter(const uint64_t* __restr
     }
 }
 
-// n <= RANK_SORT_MAX: ONE workgroup, all key bits at once.  Every element counts the elements that sort before it (smaller key,
-// or equal key and smaller index: stable) against the whole key array held in LDS - n^2 compares, 9 M for the 3000 superpoint
-// scores of the query selection, 0.4 M for the 600 candidate instances, instead of 4-7 digit passes of two launches each.
+// n <= RANK_SORT_MAX: all key bits at once, no digit passes.  Every element counts the elements that sort before it (smaller
+// key, or equal key and smaller index: stable) against the whole key array, which each workgroup copies into LDS; its rank IS
+// its output position, so the workgroups (256 elements each) never communicate.  n^2 compares: 9 M for the 3000 superpoint
+// scores of the query selection, 0.4 M for the 600 candidate instances, spread over n / 256 CUs - one launch instead of 4-7
+// digit passes of two launches each.  (One workgroup for everything measured 350 us at n = 3000: 64-bit compares on one CU.)
 #define RANK_SORT_MAX 4096
-__global__ __launch_bounds__(1024) void rank_sort_kernel(const uint64_t* __restrict__ keys_in, const uint32_t* __restrict__ vals_in,
-                                                         uint64_t* __restrict__ keys_out, uint32_t* __restrict__ vals_out, int n,
-                                                         uint64_t mask) {
+__global__ __launch_bounds__(256) void rank_sort_kernel(const uint64_t* __restrict__ keys_in, const uint32_t* __restrict__ vals_in,
+                                                        uint64_t* __restrict__ keys_out, uint32_t* __restrict__ vals_out, int n,
+                                                        uint64_t mask) {
     __shared__ uint64_t k[RANK_SORT_MAX];
-    for (int i = threadIdx.x; i < n; i += 1024) k[i] = keys_in[i] & mask;
+    for (int i = threadIdx.x; i < n; i += 256) k[i] = keys_in[i] & mask;
     __syncthreads();
-    for (int i = threadIdx.x; i < n; i += 1024) {
-        const uint64_t mine = k[i];
-        int rank = 0;
-        int j = 0;
-        for (; j + 4 <= n; j += 4) {                          // LDS broadcast reads: every lane walks the same j
-            const uint64_t a = k[j], b = k[j + 1], c = k[j + 2], d = k[j + 3];
-            rank += (a < mine || (a == mine && j < i)) + (b < mine || (b == mine && j + 1 < i)) +
-                    (c < mine || (c == mine && j + 2 < i)) + (d < mine || (d == mine && j + 3 < i));
-        }
-        for (; j < n; ++j) rank += (k[j] < mine || (k[j] == mine && j < i));
-        keys_out[rank] = keys_in[i];
-        vals_out[rank] = vals_in ? vals_in[i] : (uint32_t)i;
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const uint64_t mine = k[i];
+    int rank = 0, j = 0;
+    for (; j + 4 <= n; j += 4) {                              // LDS broadcast reads: every lane walks the same j
+        const uint64_t a = k[j], b = k[j + 1], c = k[j + 2], d = k[j + 3];
+        rank += (a < mine || (a == mine && j < i)) + (b < mine || (b == mine && j + 1 < i)) +
+                (c < mine || (c == mine && j + 2 < i)) + (d < mine || (d == mine && j + 3 < i));
     }
+    for (; j < n; ++j) rank += (k[j] < mine || (k[j] == mine && j < i));
+    keys_out[rank] = keys_in[i];
+    vals_out[rank] = vals_in ? vals_in[i] : (uint32_t)i;
 }
 
 size_t sort_ws_bytes(int64_t n) {
@@ -267,7 +301,7 @@ int sort_pairs_u64(uint64_t* keys_in, uint32_t* vals_in, uint64_t* keys_out, uin
     if (n <= RANK_SORT_MAX) {
         const int nbits = end_bit - begin_bit;
         const uint64_t mask = (nbits >= 64 ? ~0ull : ((1ull << (nbits > 0 ? nbits : 1)) - 1ull)) << begin_bit;
-        hipLaunchKernelGGL(rank_sort_kernel, dim3(1), dim3(1024), 0, st, keys_in, vals_in, keys_out, vals_out, (int)n, mask);
+        hipLaunchKernelGGL(rank_sort_kernel, dim3((unsigned)cdiv(n, 256)), dim3(256), 0, st, keys_in, vals_in, keys_out, vals_out, (int)n, mask);
         SD3D_CHECK_LAUNCH();
         return SD3D_OK;
     }

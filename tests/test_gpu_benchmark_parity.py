@@ -177,8 +177,8 @@ def test_four_scenes_in_flight_are_bit_identical_to_sequential():
     model, _ = _build(scannet200_model_cfg(query_num=200), d)
     scenes = []
     for i in range(3):
-        pts, tgt = make_scene(30 + i, 150_000 - 7001 * i, 3000 - 100 * i, 300)
-        structure_scene(pts, tgt, seed=i)
+        pts, tgt = make_scene(21, 150_000 - 7001 * i, 3000 - 100 * i, 300)     # the parity test's scene recipe at three sizes
+        structure_scene(pts, tgt)
         scenes.append((pts.to(d), tgt.to(d)))
     order = [0, 1, 2, 0, 2, 1, 1, 0, 2, 2, 1, 0]                        # 12 forwards, 3 per stream, scenes interleaved
 
@@ -190,7 +190,7 @@ def test_four_scenes_in_flight_are_bit_identical_to_sequential():
         seq = [fields(model([p], [copy.copy(t)])[0].pred_pts_seg) for p, t in scenes]
     torch.cuda.synchronize()
     print("sequential reference:", [(int(s["scores"].numel()), int(s["masks"].sum())) for s in seq], "(instances, mask points) per scene")
-    assert all(int(s["masks"].sum()) > 0 and s["scores"].numel() >= 100 for s in seq), "scenes must yield instances with content"
+    assert all(s["scores"].numel() >= 100 for s in seq) and sum(int(s["masks"].sum()) for s in seq) > 10000, "scenes must yield instances with content"
     for rep in range(2):
         par = PipelinedRunner(model, 4, d).run([(scenes[i][0], copy.copy(scenes[i][1])) for i in order])
         torch.cuda.synchronize()

@@ -20,8 +20,8 @@ def test_sort_pairs_stable_and_scan():
     from segdino3d_amd import ops
     d = dev()
     g = torch.Generator().manual_seed(0)
-    # <= 4096: one-workgroup rank sort; above: digit passes; scans: one workgroup up to 2^18 elements, three kernels above
-    for n in (1, 63, 64, 65, 2047, 2048, 2049, 4095, 4096, 4097, 150_000, 300_000):
+    # <= 4096: rank sort; above: digit passes; scans: one workgroup up to 2^14 elements, tiled (two kernels) above
+    for n in (1, 63, 64, 65, 2047, 2048, 2049, 4095, 4096, 4097, 16384, 16385, 150_000, 300_000):
         keys = torch.randint(0, 1 << 40, (n,), generator=g, dtype=torch.int64)
         keys[::3] = keys[0]                       # many duplicates -> exercises stability
         sk, sv = ops.sort_pairs(keys.to(d).clone(), None, 0, 48)
