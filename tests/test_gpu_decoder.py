@@ -127,6 +127,12 @@ def _mask_agree(a, b, thr=0.0):
     return ((a > thr) == (b > thr)).float().mean().item()
 
 
+# largest accepted fraction of query rows outside the tolerance at a layer after the first mask feedback, per fixture: the
+# measured value is 0 rows on every fixture (profiles/r02_parity_numbers.md); a fixture whose near-zero logit flips a mask bit
+# on some future kernel change would list its measured fraction here
+BAD_ROWS_MAX = {"decoder_s64_q64": 0.0, "decoder_s96_q16": 0.0, "decoder_s500_q32": 0.0, "decoder_v2_s48": 0.0}
+
+
 @pytest.mark.parametrize("name,kw,sdkw", [
     ("decoder_s64_q64", {}, {}), ("decoder_s96_q16", {}, {}), ("decoder_s500_q32", {}, {}),
     ("decoder_v2_s48", dict(num_instance_classes=18, num_semantic_classes=20, in_channels=32, normalize_box_prediction=False),
@@ -142,15 +148,17 @@ def test_decoder_matches_reference_golden(name, kw, sdkw):
               [t(g["q2d_pos"])], [(t(g["lo"]), t(g["hi"]))])
     # The decoder is discontinuous (sigmoid < 0.5 attention masks, :569): a single near-zero logit that
     # rounds differently flips a mask bit and that query row then legitimately diverges in later layers.
-    # Tolerance: every tensor within 2e-3 (abs + rel) on >= 90 % of the query rows at every layer, and on
-    # ALL rows for the layers before the first flip (layer 0..1 outputs have no mask feedback yet).
-    tol = 2e-3
+    # Measured on MI355X (round 2, printed below): NO row outside 2e-3 at any layer of any fixture, max abs error 1e-4 on
+    # mask logits of magnitude ~20, 8e-6 elsewhere, all mask bits equal.  Tolerance: 3e-4 (abs + rel) on EVERY row.
+    tol = 3e-4
+    report = []
 
     def rows_ok(got, ref, what, strict):
         err = (got.cpu() - ref).abs()
         lim = tol + tol * ref.abs()
         bad = (err > lim).any(dim=1).float().mean().item()
-        assert bad <= (0.0 if strict else 0.10), f"{what}: {bad:.1%} of query rows outside tolerance (max err {err.max().item():.3e})"
+        report.append(f"{what}: {bad:.1%} rows / max err {err.max().item():.1e}")
+        assert bad <= (0.0 if strict else BAD_ROWS_MAX[name]), f"{what}: {bad:.1%} of query rows outside tolerance (max err {err.max().item():.3e})"
     for li in range(6):
         aux = out["aux_outputs"][li]
         rows_ok(aux["cls_preds"][0], g[f"aux{li}_cls"], f"aux{li} cls", li <= 1)
@@ -160,7 +168,9 @@ def test_decoder_matches_reference_golden(name, kw, sdkw):
             rows_ok(aux["sizes"][0], g[f"aux{li}_sizes"], f"aux{li} sizes", li <= 1)
     for k in ("cls_preds", "sem_preds", "masks", "centers", "sizes", "hidden_states"):
         rows_ok(out[k][0], g[k], k, False)
-    assert _mask_agree(out["masks"][0].cpu(), g["masks"]) > 0.99
+    agree = _mask_agree(out["masks"][0].cpu(), g["masks"])
+    print(f"{name}: rows outside {tol:g} (abs + rel) / max abs error per tensor:\n  " + "\n  ".join(report) + f"\n  final mask bits equal: {agree:.5f}")
+    assert agree >= 0.9999
 
 
 def test_decoder_matches_oracle_at_benchmark_shape():
@@ -181,11 +191,14 @@ def test_decoder_matches_oracle_at_benchmark_shape():
     t = lambda a: a.to(d)
     out = dec([t(x)], [t(pos)], [t(pos)], [t(x[ids])], [t(pos[ids])], [t(q2d_feat)], [t(q2d_pos)], [(t(lo), t(hi))])
     # thresholded attention masks make the map discontinuous: allow a handful of rows to diverge
-    for k, tol in (("cls_preds", 5e-3), ("masks", 5e-3), ("centers", 2e-3), ("sizes", 2e-3)):
+    # measured (round 2): max abs error 5e-5 on mask logits, 5e-6 elsewhere, no row outside, all mask bits equal
+    for k, tol in (("cls_preds", 5e-5), ("masks", 5e-4), ("centers", 5e-5), ("sizes", 5e-5)):
         err = (out[k][0].cpu() - ref[k]).abs()
         bad_rows = (err.amax(dim=1) > tol * max(1.0, ref[k].abs().max().item())).float().mean().item()
-        assert bad_rows <= 0.02, f"{k}: {bad_rows:.3%} of query rows differ (max err {err.max().item():.3e})"
-    assert _mask_agree(out["masks"][0].cpu(), ref["masks"]) > 0.998
+        print(f"S=1000 Q=200 {k}: {bad_rows:.3%} of query rows outside {tol:g}, max err {err.max().item():.3e}")
+        assert bad_rows == 0.0, f"{k}: {bad_rows:.3%} of query rows differ (max err {err.max().item():.3e})"
+    print(f"S=1000 Q=200 mask bits equal: {_mask_agree(out['masks'][0].cpu(), ref['masks']):.6f}")
+    assert _mask_agree(out["masks"][0].cpu(), ref["masks"]) >= 0.9999
 
 
 class _StoredBackbone(torch.nn.Module):
@@ -261,8 +274,9 @@ def test_plain_decoder_matches_reference_golden():
 
     def rows_ok(got, ref, what, strict):
         err = (got.cpu() - ref).abs()
-        bad = (err > 2e-3 + 2e-3 * ref.abs()).any(dim=1).float().mean().item()
-        assert bad <= (0.0 if strict else 0.10), f"{what}: {bad:.1%} rows outside tolerance (max err {err.max().item():.3e})"
+        bad = (err > 3e-4 + 3e-4 * ref.abs()).any(dim=1).float().mean().item()
+        print(f"plain decoder {what}: {bad:.1%} rows outside 3e-4, max err {err.max().item():.1e}")
+        assert bad == 0.0, f"{what}: {bad:.1%} rows outside tolerance (max err {err.max().item():.3e})"
     for li in range(5):
         rows_ok(out["aux_outputs"][li]["cls_preds"][0], g[f"aux{li}_cls"], f"aux{li} cls", li <= 1)
         rows_ok(out["aux_outputs"][li]["masks"][0], g[f"aux{li}_masks"], f"aux{li} masks", li <= 1)
@@ -292,7 +306,8 @@ def test_baseline_prototype_end_to_end_matches_oracle():
                        box_modulate_ca=False, normalize_box_prediction=False)
     ref = D.decoder_forward(sd, cfg, f, None, None, f, None, None, None, None, None)
     err = (out["masks"][0].cpu() - ref["masks"]).abs()
-    bad = (err > 5e-3 + 5e-3 * ref["masks"].abs()).any(dim=1).float().mean().item()
-    assert bad <= 0.15, f"{bad:.1%} of query rows differ (max err {err.max().item():.3e})"
+    bad = (err > 5e-4 + 5e-4 * ref["masks"].abs()).any(dim=1).float().mean().item()
+    print(f"Baseline_ScanNet200 end to end, mask logits: {bad:.1%} of query rows outside 5e-4, max err {err.max().item():.3e}")
+    assert bad <= 0.02, f"{bad:.1%} of query rows differ (max err {err.max().item():.3e})"
     pd = res[0].pred_pts_seg
     assert pd.pts_instance_mask[0].shape[1] == pts.shape[0] and pd.instance_boxes is None

@@ -127,7 +127,9 @@ def test_no_2d_queries_and_no_surviving_instances():
     lo, hi = pts[:, :3].min(0)[0], pts[:, :3].max(0)[0]
     ref = D.decoder_forward(sd, D.DecoderCfg(), sp_feat, sp_pos, sp_pos, sp_feat, sp_pos, torch.zeros(0, 256), torch.zeros(0, 3), lo, hi)
     err = (out["masks"][0].cpu() - ref["masks"]).abs()
-    assert (err > 2e-3 + 2e-3 * ref["masks"].abs()).any(dim=1).float().mean() <= 0.1
+    bad = (err > 3e-4 + 3e-4 * ref["masks"].abs()).any(dim=1).float().mean().item()
+    print(f"no 2D queries: mask-logit rows outside 3e-4: {bad:.1%}, max err {err.max().item():.2e}")
+    assert bad <= 0.02
 
 
 def test_pipelined_runner_matches_sequential():

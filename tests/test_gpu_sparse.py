@@ -168,6 +168,11 @@ def test_sparse_conv_matches_oracle():
     torch.testing.assert_close(got_up, ref_up[perm[0]], rtol=2e-4, atol=2e-4)
 
 
+# whole-backbone tolerance relative to the largest feature: ~60 fp32 convolutions with different (fixed) summation orders on the
+# two sides; measured 3-6e-7 on MI355X (printed by the tests), bound = measured x ~20
+BACKBONE_REL_TOL = 1e-5
+
+
 def test_res16unet34c_forward_wrapper_matches_oracle():
     from oracle import sparse_ref as R
     from segdino3d_amd.backbone_mink import Res16UNet34C
@@ -189,7 +194,8 @@ def test_res16unet34c_forward_wrapper_matches_oracle():
     torch.testing.assert_close(pos_wo[0].cpu(), rp, rtol=5e-5, atol=1e-4)
     err = (f[0].cpu() - rf).abs().max().item()
     scale = rf.abs().max().item()
-    assert err <= 2e-3 * max(scale, 1.0), f"backbone features differ: max abs err {err} (scale {scale})"
+    print(f"Res16UNet34C superpoint features vs oracle: max abs err {err:.3e} at max |f| {scale:.3f} ({err / scale:.2e} relative)")
+    assert err <= BACKBONE_REL_TOL * max(scale, 1.0), f"backbone features differ: max abs err {err} (scale {scale})"
 
 
 def test_spconvunet_forward_wrapper_matches_oracle():
@@ -210,7 +216,8 @@ def test_spconvunet_forward_wrapper_matches_oracle():
     err = (f[0].cpu() - rf).abs().max().item()
     scale = rf.abs().max().item()
     assert f[0].shape == (100, 32)
-    assert err <= 2e-3 * max(scale, 1.0), f"spconv backbone features differ: max abs err {err} (scale {scale})"
+    print(f"SpConvUNet superpoint features vs oracle: max abs err {err:.3e} at max |f| {scale:.3f} ({err / scale:.2e} relative)")
+    assert err <= BACKBONE_REL_TOL * max(scale, 1.0), f"spconv backbone features differ: max abs err {err} (scale {scale})"
 
 
 # ------------------------------------------------------------------------------------------------
