@@ -15,9 +15,12 @@ fill 256 CUs, so 3 scenes in flight raise scenes/s by ~45 % over back-to-back fo
 single-stream latency is reported next to it (`config.single_stream_latency_ms`).
 
 Prints ONE JSON line (rank 0) with the contract fields plus
-  roofline     : the dominant kernel (gather_gemm = every sparse convolution + every Linear), its
-                 algorithmic bytes (4*P*Cin + 4*V_out*Cout + 8*P + 4*K*Cin*Cout per launch,
-                 P = measured rulebook size) divided by its HIP-event-measured time, against 8 TB/s HBM
+  roofline     : the dominant kernel = the pair-major sparse convolution (sd3d_pair_conv: pair_gemm_* + pair_reduce_kernel,
+                 55 launches per forward, 95 % of the flops): its active-pair flops 2*P*Cin*Cout (P = measured rulebook
+                 size) divided by its HIP-event-measured time against the 157.3 TFLOP/s fp32 matrix peak (the bound in exact
+                 fp32: 53 flop per algorithmic byte), its algorithmic bytes and the PMC-measured HBM-side bytes
+  single_scene : the same forward with ONE scene in flight (SURVEY 8(d) defines the metric at batch = 1 scene per GPU):
+                 latency and scenes/s, next to `value` = scenes/s with `--streams` scenes in flight per GPU
   cpu_baseline : the oracle's whole forward timed on the host cores (rank 0, N = 1 only)
 """
 from __future__ import annotations
@@ -73,11 +76,13 @@ def algorithmic_bytes(meta, pair_count):
     return 4 * P * Cin + 4 * M * Cout + 8 * P + 4 * K * Cin * Cout, 2 * P * Cin * Cout
 
 
-def build_model(query_num, device):
+def build_model(query_num, device, decoder_dtype="fp32"):
     import segdino3d_amd as seg
     from segdino3d_amd.configs import scannet200_model_cfg
     torch.manual_seed(0)
-    model = seg.build_architecture(scannet200_model_cfg(query_num=query_num)).eval()
+    cfg = scannet200_model_cfg(query_num=query_num)
+    cfg["decoder_cfg"]["compute_dtype"] = decoder_dtype
+    model = seg.build_architecture(cfg).eval()
     # random-init weights of the architecture; give BN non-trivial running stats so nothing degenerates
     g = torch.Generator().manual_seed(1)
     with torch.no_grad():
@@ -115,6 +120,25 @@ def cpu_baseline(model, scene_args, n_timed=4):
                       f"torch CPU fp32 with {threads} threads (oracle/model_ref.forward_eval)"}
 
 
+def pin_rank_to_cores(local_rank: int, local_world: int, threads_per_rank: int):
+    """One process per GPU drives `threads_per_rank` issuing threads; with 8 ranks on a node they must not migrate across each
+    other's cores (or NUMA nodes): rank r takes the r-th slice of the cores this process may run on.  Returns the slice size."""
+    try:
+        cores = sorted(os.sched_getaffinity(0))
+    except (AttributeError, OSError):
+        return 0
+    per = len(cores) // max(1, local_world)
+    if local_world <= 1 or per < 1:
+        return len(cores)
+    mine = cores[local_rank * per:(local_rank + 1) * per]
+    try:
+        os.sched_setaffinity(0, mine)
+    except OSError:
+        return len(cores)
+    torch.set_num_threads(max(1, min(per, threads_per_rank)))
+    return per
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -127,6 +151,8 @@ def main():
     ap.add_argument("--scene-pool", type=int, default=2, help="distinct synthetic scenes per rank (cycled)")
     ap.add_argument("--streams", type=int, default=4,
                     help="scenes in flight per GPU (host threads x HIP streams, segdino3d_amd.dist_eval.PipelinedRunner)")
+    ap.add_argument("--decoder-dtype", choices=("fp32", "bf16"), default=os.environ.get("SD3D_DECODER_DTYPE", "fp32"),
+                    help="bf16 = BASELINE configs[2]: bf16-MFMA attention contractions and projections, fp32 accumulation")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--preroll-seconds", type=float, default=2.0, help="untimed pipelined pre-roll before the timed K steps")
     args = ap.parse_args()
@@ -140,6 +166,7 @@ def main():
     # collectives on CPU tensors); the real runs use "nccl" (= RCCL over xGMI), one GPU per rank.
     backend = os.environ.get("SD3D_DIST_BACKEND", "nccl")
     dev_index = 0 if os.environ.get("SD3D_SHARE_GPU") == "1" else local_rank
+    cores_per_rank = pin_rank_to_cores(local_rank, int(os.environ.get("LOCAL_WORLD_SIZE", world)), args.streams)
     torch.cuda.set_device(dev_index)
     device = torch.device("cuda", dev_index)
     comm_device = device if backend == "nccl" else torch.device("cpu")
@@ -154,7 +181,7 @@ def main():
     from segdino3d_amd import ops
     from segdino3d_amd.synth import make_scene
 
-    model = build_model(args.query_num, device)
+    model = build_model(args.query_num, device, args.decoder_dtype)
     scene_args = (args.points, args.superpoints, args.query2d)
     pool = []
     for j in range(max(1, args.scene_pool)):
@@ -228,7 +255,7 @@ def main():
     n_launch = len(timer.records)
     pair_cache = {}
     tot_bytes = tot_flops = 0
-    conv_ms = conv_flops = conv_n = 0                   # the sparse convolutions alone (sd3d_pair_conv: pass 1 + pass 2)
+    conv_ms = conv_flops = conv_bytes = conv_n = 0      # the sparse convolutions alone (sd3d_pair_conv: pass 1 + pass 2)
     for e0_, e1_, meta in timer.records:
         nbr = meta["nbr"]
         if meta.get("pairs") is not None:              # pair-major convolution: count the real list entries
@@ -244,50 +271,48 @@ def main():
         tot_bytes += b
         tot_flops += f
         if meta.get("pairs") is not None:
-            conv_ms += e0_.elapsed_time(e1_); conv_flops += f; conv_n += 1
-    # Two time lower bounds for this kernel family at fp32: its algorithmic bytes at 8 TB/s, and its
-    # algorithmic (active-pair) flops at the 157.3 TFLOP/s fp32-MFMA peak.  For the benchmark scene the second
-    # is the larger one (571 GFLOP -> 3.6 ms vs 10.8 GB -> 1.4 ms), i.e. in exact fp32 the family is bound
-    # by the matrix cores, so that is the roofline reported in bound/achieved/peak/frac; the HBM figures
-    # are kept next to it.
+            conv_ms += e0_.elapsed_time(e1_); conv_flops += f; conv_bytes += b; conv_n += 1
     sec = gemm_ms * 1e-3
-    hbm_gbs = tot_bytes / sec / 1e9 if sec > 0 else 0.0
-    tflops = tot_flops / sec / 1e12 if sec > 0 else 0.0
-    t_hbm, t_mfma = tot_bytes / (HBM_PEAK_GBS * 1e9), tot_flops / (FP32_MFMA_PEAK_TFLOPS * 1e12)
-    mfma_bound = t_mfma >= t_hbm
-    # HBM-side bytes of the same kernel family from the committed PMC passes (rocprofv3 cannot run inside this
-    # process): FETCH_SIZE x 2 + WRITE_SIZE per forward, divided by the launches of one forward.  It exceeds
-    # the algorithmic bytes by design: the pair-major convolution writes and re-reads its partial products.
-    traffic, traffic_src = None, None
-    pmc_path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_pmc_traffic.json")
-    if os.path.exists(pmc_path):
-        with open(pmc_path) as f:
-            pmc = json.load(f)
-        traffic = int(pmc["bytes_per_forward"] / max(1, n_launch // max(1, args.steps)))
-        traffic_src = pmc["source"]
-    roofline = {"bound": "mfma" if mfma_bound else "hbm", "kernel": "sparse-conv / linear GEMM family (sd3d_pair_conv: pair_gemm_kernel + "
-                "pair_reduce_kernel; sd3d_gather_gemm: gather_gemm_lds_kernel / gather_gemm_kernel)",
-                "achieved": round(tflops if mfma_bound else hbm_gbs, 2),
-                "peak": FP32_MFMA_PEAK_TFLOPS if mfma_bound else HBM_PEAK_GBS,
-                "unit": "TFLOP/s" if mfma_bound else "GB/s",
-                "frac": round((tflops / FP32_MFMA_PEAK_TFLOPS) if mfma_bound else (hbm_gbs / HBM_PEAK_GBS), 4),
-                "traffic": traffic, "traffic_unit": "bytes per launch", "traffic_source": traffic_src,
-                "hbm_achieved_gbs": round(hbm_gbs, 1), "hbm_peak_gbs": HBM_PEAK_GBS, "hbm_frac": round(hbm_gbs / HBM_PEAK_GBS, 4),
-                "launches_per_step": n_launch // max(1, args.steps),
-                "avg_launch_us": round(1e3 * gemm_ms / max(1, n_launch), 2),
-                # = what the rocprofv3 summary's pair_gemm* + pair_reduce + gather_gemm* rows add up to per forward
-                "family_ms_per_forward": round(gemm_ms / max(1, args.steps), 3),
-                "algorithmic_bytes_per_step": tot_bytes // max(1, args.steps),
-                "algorithmic_flops_per_step": tot_flops // max(1, args.steps),
-                "share_of_single_stream_forward": round(gemm_ms / max(1, args.steps) / latency_ms, 3),
-                "measured": "HIP events around every launch, single-stream instrumented replay of the timed steps"}
-    if conv_ms > 0:
-        conv_tf = conv_flops / (conv_ms * 1e-3) / 1e12
-        # the family above also holds ~150 launch-bound decoder Linears per forward (10 us each for 26 MFLOP); the sparse
-        # convolutions alone - 97 % of the flops - are what the matrix-core roofline is about
-        roofline["sparse_conv_only"] = {"launches_per_step": conv_n // max(1, args.steps), "ms_per_forward": round(conv_ms / max(1, args.steps), 3),
-                                        "achieved": round(conv_tf, 2), "unit": "TFLOP/s", "frac": round(conv_tf / FP32_MFMA_PEAK_TFLOPS, 4),
-                                        "flops_per_step": conv_flops // max(1, args.steps)}
+    fam_gbs = tot_bytes / sec / 1e9 if sec > 0 else 0.0
+    fam_tf = tot_flops / sec / 1e12 if sec > 0 else 0.0
+    steps = max(1, args.steps)
+    conv_sec = conv_ms * 1e-3
+    conv_tf = conv_flops / conv_sec / 1e12 if conv_sec > 0 else 0.0
+    conv_gbs = conv_bytes / conv_sec / 1e9 if conv_sec > 0 else 0.0
+    conv_per_step = max(1, conv_n // steps)
+    # HBM-side bytes of the dominant kernel from the committed PMC passes of THIS tree (rocprofv3 cannot run inside this
+    # process): FETCH_SIZE x 2 (the guide's gfx950 correction) + WRITE_SIZE of pair_gemm_* + pair_reduce_kernel per forward.
+    # They exceed the algorithmic bytes by design: the partial products are written by pass 1 and re-read by pass 2.
+    traffic = traffic_fwd = traffic_src = None
+    for name in ("r02_pmc_traffic.json", "r01_pmc_traffic.json"):
+        pmc_path = os.path.join(ROOT, "profiles", name)
+        if os.path.exists(pmc_path):
+            with open(pmc_path) as f:
+                pmc = json.load(f)
+            traffic_fwd = int(pmc.get("conv_bytes_per_forward", pmc.get("bytes_per_forward")))
+            traffic = traffic_fwd // conv_per_step
+            traffic_src = pmc["source"]
+            break
+    roofline = {"bound": "mfma",
+                "kernel": "sd3d_pair_conv = pair_gemm_* (pass 1, fp32 MFMA over the offset-major rulebook) + pair_reduce_kernel (pass 2): "
+                          "the sparse convolutions of Res16UNet34C",
+                "achieved": round(conv_tf, 2), "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                "frac": round(conv_tf / FP32_MFMA_PEAK_TFLOPS, 4),
+                "launches_per_step": conv_per_step, "avg_launch_us": round(1e3 * conv_ms / max(1, conv_n), 2),
+                "ms_per_forward": round(conv_ms / steps, 3),
+                "algorithmic_flops_per_launch": conv_flops // max(1, conv_n), "algorithmic_bytes_per_launch": conv_bytes // max(1, conv_n),
+                "traffic": traffic, "traffic_unit": "HBM-side bytes per launch, average over the launches of one forward (PMC)",
+                "traffic_per_forward": traffic_fwd, "algorithmic_bytes_per_forward": conv_bytes // steps,
+                "traffic_over_algorithmic": round(traffic_fwd / max(1, conv_bytes // steps), 2) if traffic_fwd else None,
+                "traffic_source": traffic_src,
+                "hbm_achieved_gbs": round(conv_gbs, 1), "hbm_peak_gbs": HBM_PEAK_GBS, "hbm_frac": round(conv_gbs / HBM_PEAK_GBS, 4),
+                "share_of_single_stream_forward": round(conv_ms / steps / latency_ms, 3),
+                "measured": "HIP events around every launch on the launching stream, single-stream instrumented replay of the timed steps",
+                # every sparse convolution AND every Linear of the decoder / heads (the ~155 extra launches are 10 us each for 26 MFLOP)
+                "gemm_family": {"launches_per_step": n_launch // steps, "ms_per_forward": round(gemm_ms / steps, 3),
+                                "achieved": round(fam_tf, 2), "unit": "TFLOP/s", "frac": round(fam_tf / FP32_MFMA_PEAK_TFLOPS, 4),
+                                "hbm_achieved_gbs": round(fam_gbs, 1), "algorithmic_bytes_per_step": tot_bytes // steps,
+                                "algorithmic_flops_per_step": tot_flops // steps}}
 
     # ---- closing all-gather of per-scene records over RCCL/xGMI -----------------------
     maps = cap.maps[-1]
@@ -310,13 +335,16 @@ def main():
             "metric": "scenes/sec forward (ScanNet200 ~150k pts, 200 queries)", "value": round(value, 3), "unit": "scenes/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * dt / args.steps, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32 backbone + bf16 decoder contractions" if bf16_dec else "f32", "data": "synthetic",
-            "config": {"workload": ("configs[2]" if bf16_dec else "configs[1]") + ": ScanNet-val-like scene, 1 scene per GPU per step, "
+            "single_scene": {"scenes_per_s": round(1e3 / latency_ms, 2), "latency_ms": round(latency_ms, 3),
+                             "note": "ONE scene in flight per GPU (SURVEY 8(d) batch = 1), same forward, same process"},
+            "config": {"workload": ("configs[2]" if bf16_dec else "configs[1]") + ": ScanNet-val-like scenes, one scene per forward (step), "
+                                   f"{args.streams} independent scenes in flight per GPU (`value`) / one in flight (`single_scene`); "
                                    "fp32 sparse backbone (Res16UNet34C) + " + ("bf16-MFMA" if bf16_dec else "fp32") +
                                    " decoder + post-processing, device-resident in/out",
                        "points": args.points, "superpoints": args.superpoints, "queries_2d": args.query2d,
                        "query_num": args.query_num, "voxels_per_level": maps.n_vox, "parallelism": f"scene-sharded x{world}",
                        "scenes_in_flight_per_gpu": args.streams, "single_stream_latency_ms": round(latency_ms, 3),
-                       "untimed_preroll_scenes": n_pre},
+                       "untimed_preroll_scenes": n_pre, "host_cores_per_rank": cores_per_rank},
             "roofline": roofline, "cpu_baseline": cpu,
             "per_rank_records": records,
         }

@@ -125,3 +125,52 @@ def test_two_rank_record_exchange_gives_the_single_rank_ap():
     z = _ap_fixture()[0]
     ref = dict(zip((str(k) for k in z["default_keys"]), z["default_vals"]))["all_ap"]
     assert abs(got[0] - ref) < 1e-12 and abs(got[1] - ref) < 1e-12
+
+
+def _worker8(rank, world, port, q, n_scenes):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from segdino3d_amd import dist_eval, eval_ap
+        from segdino3d_amd.eval_ap import SceneRecord
+        z, class_labels, valid, groups, opts, id_to_label, preds, gts, recs = _records(None)
+        e = np.zeros(0, dtype=np.int64)
+        empty = SceneRecord(e, e, e, e, np.zeros(0), e, e, e, e, e, e)
+        scene = lambda i: empty if i % 5 == 4 else recs[i % len(recs)]      # every fifth scene has neither ground truth nor predictions
+        mine = [(i, scene(i)) for i in dist_eval.shard_scenes(n_scenes, rank, world)]
+        allrecs = dist_eval.all_gather_ap_records(mine)
+        assert [sid for sid, _ in allrecs] == list(range(n_scenes))
+        for sid, r in allrecs:                                              # payloads survive the padded exchange unchanged
+            want = scene(sid)
+            assert all(np.array_equal(getattr(r, f), getattr(want, f)) for f in want.__dataclass_fields__)
+        ap, pr_rc = eval_ap.evaluate_records([r for _, r in allrecs], class_labels, valid, opts)
+        q.put((rank, len(mine), eval_ap.compute_averages(ap, pr_rc, opts, class_labels)["all_ap"]))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_eight_rank_exchange_with_ragged_and_empty_ranks():
+    """The 8 x MI355X layout (BASELINE configs[3]) on gloo: 8 ranks, 3 scenes -> five ranks contribute NOTHING; 11 scenes ->
+    ragged (2, 2, 2, 1, 1, 1, 1, 1) with empty scene records inside.  Every rank ends up with the same ordered records and the
+    same AP as one process evaluating all scenes."""
+    from segdino3d_amd import eval_ap
+    from segdino3d_amd.eval_ap import SceneRecord
+    ctx = mp.get_context("spawn")
+    z, class_labels, valid, groups, opts, id_to_label, preds, gts, recs = _records(None)
+    e = np.zeros(0, dtype=np.int64)
+    empty = SceneRecord(e, e, e, e, np.zeros(0), e, e, e, e, e, e)
+    for n_scenes in (3, 11):
+        q = ctx.Queue()
+        port = 31500 + (os.getpid() % 2000) + n_scenes
+        procs = [ctx.Process(target=_worker8, args=(r, 8, port, q, n_scenes)) for r in range(8)]
+        for p in procs:
+            p.start()
+        for p in procs:
+            p.join(180)
+            assert p.exitcode == 0
+        got = sorted(q.get(timeout=10) for _ in range(8))
+        assert [g[1] for g in got] == [len(range(r, n_scenes, 8)) for r in range(8)]
+        single = [empty if i % 5 == 4 else recs[i % len(recs)] for i in range(n_scenes)]
+        ap, pr_rc = eval_ap.evaluate_records(single, class_labels, valid, opts)
+        ref = eval_ap.compute_averages(ap, pr_rc, opts, class_labels)["all_ap"]
+        assert all(abs(g[2] - ref) < 1e-12 or (np.isnan(g[2]) and np.isnan(ref)) for g in got), (got, ref)

@@ -133,7 +133,8 @@ def test_no_2d_queries_and_no_surviving_instances():
 
 
 def test_pipelined_runner_matches_sequential():
-    """Two scenes in flight on two HIP streams (threads) give the same predictions as back-to-back runs."""
+    """Two scenes in flight on two HIP streams (threads) give the same BITS as back-to-back runs (small ragged scenes; the
+    benchmarked mode - four streams, 150 k points - is tests/test_gpu_benchmark_parity.py)."""
     import copy
     import segdino3d_amd as seg
     from segdino3d_amd.configs import scannet200_model_cfg
@@ -147,24 +148,15 @@ def test_pipelined_runner_matches_sequential():
     for i in range(4):
         pts, tgt = make_scene(20 + i, n_points=6000 + 500 * i, n_superpoints=50, n_query2d=10)
         scenes.append((pts.to(d), tgt.to(d)))
-    def agreement(a, b):
-        assert a.pts_instance_mask[0].shape == b.pts_instance_mask[0].shape
-        torch.testing.assert_close(a.instance_scores, b.instance_scores, rtol=2e-3, atol=1e-5)
-        m = (a.pts_instance_mask[0] == b.pts_instance_mask[0]).float().mean().item() if a.pts_instance_mask[0].numel() else 1.0
-        s = (a.pts_semantic_mask[0] == b.pts_semantic_mask[0]).float().mean().item()
-        return min(m, s)
-
     with torch.no_grad():
         seq = [model([p], [copy.copy(t)])[0].pred_pts_seg for p, t in scenes]
-        seq2 = [model([p], [copy.copy(t)])[0].pred_pts_seg for p, t in scenes]
     par = PipelinedRunner(model, 2, d).run([(p, copy.copy(t)) for p, t in scenes])
     torch.cuda.synchronize()
-    for i in range(len(scenes)):
-        # the sparse level-0 convolutions accumulate with LDS float atomics, so two sequential runs already
-        # differ in a few near-threshold mask bits; the pipelined run must be no further away than that
-        base = agreement(seq[i], seq2[i])
-        got = agreement(seq[i], par[i][0].pred_pts_seg)
-        assert got > 0.99 and got >= base - 5e-3, (i, base, got)
+    for i in range(len(scenes)):                       # every kernel sums in a fixed order: bit-identical, not "close"
+        a, b = seq[i], par[i][0].pred_pts_seg
+        assert torch.equal(a.instance_scores, b.instance_scores) and torch.equal(a.instance_labels, b.instance_labels)
+        assert torch.equal(a.pts_instance_mask[0], b.pts_instance_mask[0]) and torch.equal(a.pts_instance_mask[1], b.pts_instance_mask[1])
+        assert torch.equal(a.pts_semantic_mask[0], b.pts_semantic_mask[0]) and torch.equal(a.pts_semantic_mask[1], b.pts_semantic_mask[1])
 
 
 def test_scene_prefetcher_feeds_identical_scenes(tmp_path):

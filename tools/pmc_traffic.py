@@ -1,0 +1,51 @@
+#!/usr/bin/env python3
+"""Condense the two PMC passes (FETCH_SIZE, WRITE_SIZE: separate rocprofv3 runs of bench.py --streams 1, summarised by
+tools/prof_summary.py) into profiles/<round>_pmc_traffic.json: HBM-side bytes per forward of the dominant kernel (pair_gemm_* +
+pair_reduce_kernel) and of the whole GEMM family.   usage: pmc_traffic.py <fetch.md> <write.md> <out.json>
+
+Corrections as MI355X_MICROARCH.md prescribes: FETCH_SIZE (KB) x 2 on gfx950 (128-B requests tallied at 64 B; calibrated for
+16 B/lane streaming reads, which is what the gathers and the pass-2 reads are), WRITE_SIZE (KB) as reported."""
+import json
+import re
+import sys
+
+
+def table(path):
+    rows, forwards = {}, 0
+    in_pmc = False
+    for line in open(path):
+        if line.startswith("## PMC counters"):
+            in_pmc = True
+            continue
+        m = re.match(r"\| `(.+?)` \| (\d+) \| (.+) \|", line)
+        if in_pmc and m:
+            vals = [v.strip() for v in m.group(3).split("|")]
+            rows[m.group(1)] = (int(m.group(2)), float(vals[0]) if vals[0] else 0.0)
+        elif not in_pmc and m and m.group(1).startswith("voxel_mean_kernel"):
+            forwards = int(m.group(2))
+    return rows, forwards
+
+
+def main():
+    fetch, nf = table(sys.argv[1])
+    write, nw = table(sys.argv[2])
+    assert nf and nf == nw, (nf, nw)
+    conv = lambda n: n.startswith("pair_gemm") or n.startswith("pair_reduce")  # noqa: E731
+    fam = lambda n: conv(n) or "gather_gemm" in n  # noqa: E731
+    out = {"source": f"{sys.argv[1]} + {sys.argv[2]} (rocprofv3 --kernel-trace --pmc FETCH_SIZE | WRITE_SIZE, separate passes, bench.py --streams 1)",
+           "forwards": nf,
+           "fetch_correction": "x2 (MI355X_MICROARCH.md: gfx950 FETCH_SIZE reports half the bytes of 16 B/lane reads)",
+           "write_correction": "none (uncalibrated)"}
+    for key, sel in (("conv", conv), ("family", fam)):
+        f_kb = sum(v[1] for n, v in fetch.items() if sel(n))
+        w_kb = sum(v[1] for n, v in write.items() if sel(n))
+        out[f"{key}_fetch_kb_sum"], out[f"{key}_write_kb_sum"] = f_kb, w_kb
+        out[f"{key}_bytes_per_forward"] = int((2.0 * f_kb + w_kb) * 1024 / nf)
+    out["bytes_per_forward"] = out["family_bytes_per_forward"]
+    out["conv_launches_per_forward"] = sum(v[0] for n, v in fetch.items() if n.startswith("pair_reduce")) // nf
+    json.dump(out, open(sys.argv[3], "w"), indent=1)
+    print(json.dumps(out, indent=1))
+
+
+if __name__ == "__main__":
+    main()
