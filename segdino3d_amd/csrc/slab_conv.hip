@@ -71,6 +71,7 @@ __device__ __forceinline__ void slab_conv_body(const SlabParams& p, float* smem)
     const int nrows = (int)((p.M - row0) < R ? (p.M - row0) : R);
     const int kb = (int)((int64_t)blockIdx.y * p.K / gridDim.y), ke = (int)((int64_t)(blockIdx.y + 1) * p.K / gridDim.y);
     const int KR = ke - kb;
+    const int col0 = blockIdx.z * p.ncols;                     // column group of this workgroup
 
     // ---- LDS carve-up
     float* slab = smem;                                        // [(R + 1)][SLD], row R = sink of the padding entries
@@ -80,7 +81,7 @@ __device__ __forceinline__ void slab_conv_body(const SlabParams& p, float* smem)
     int* meta = cnt + 128;                                     // [0] = number of units
     int4v* otbl = (int4v*)(meta + 4);                          // [KR] non-empty offsets: (k, first unit, end unit, 0)
     int2v* tbl = (int2v*)(otbl + 128);                         // [ucap] (list position, k << 8 | rows)
-    int2v* lst = p.lists + ((int64_t)blockIdx.y * gridDim.x + blockIdx.x) * ((int64_t)p.K * p.lcap + 32);
+    int2v* lst = p.lists + (((int64_t)blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x) * ((int64_t)p.K * p.lcap + 32);
 
     for (int i = tid * 4; i < (R + 1) * SLD; i += NT * 4) *(f32x4_t*)(slab + i) = f32x4_t{0.f, 0.f, 0.f, 0.f};
 
@@ -182,7 +183,7 @@ __device__ __forceinline__ void slab_conv_body(const SlabParams& p, float* smem)
         }
     };
     auto load_w = [&](f32x4_t (&Wd)[NCH * NQ], int kk) {      // this wave's 16 columns of W[kb + kk]: lane (n, g) holds W[n][16 q + 4 g ..]
-        const float* wsrc = p.wt + ((int64_t)(kb + kk) * p.Cout + p.col0 + wv * 16 + n) * p.Cin + 4 * g;
+        const float* wsrc = p.wt + ((int64_t)(kb + kk) * p.Cout + col0 + wv * 16 + n) * p.Cin + 4 * g;
 #pragma unroll
         for (int q = 0; q < NCH * NQ; ++q) Wd[q] = *(const f32x4_t*)(wsrc + 16 * q);
     };
@@ -313,7 +314,7 @@ __device__ __forceinline__ void slab_conv_body(const SlabParams& p, float* smem)
     // ---- epilogue: one coalesced write per output row
     const int c4n = SLD >> 2;
     if (p.ksplit > 1) {
-        float* dst = p.part + ((int64_t)blockIdx.y * p.M + row0) * p.Cout + p.col0;
+        float* dst = p.part + ((int64_t)blockIdx.y * p.M + row0) * p.Cout + col0;
         for (int i = tid; i < nrows * c4n; i += NT) {
             const int r = i / c4n, q = (i - r * c4n) * 4;
             *(f32x4_t*)(dst + (int64_t)r * p.Cout + q) = *(const f32x4_t*)(slab + r * SLD + q);
@@ -326,12 +327,12 @@ __device__ __forceinline__ void slab_conv_body(const SlabParams& p, float* smem)
         float y[4];
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            const int col = p.col0 + q + j;
+            const int col = col0 + q + j;
             float t = a[j] * (p.scale ? p.scale[col] : 1.f) + (p.shift ? p.shift[col] : 0.f);
             if (p.res) t += p.res[(row0 + r) * p.ld_res + col];
             y[j] = slab_act(t, p.act);
         }
-        *(f32x4_t*)(p.out + (row0 + r) * p.ld_out + p.col0 + q) = f32x4_t{y[0], y[1], y[2], y[3]};
+        *(f32x4_t*)(p.out + (row0 + r) * p.ld_out + col0 + q) = f32x4_t{y[0], y[1], y[2], y[3]};
     }
 }
 
@@ -347,6 +348,7 @@ SLAB_ENTRY(32, 1, 4, true)
 SLAB_ENTRY(64, 1, 4, true)
 SLAB_ENTRY(64, 1, 8, true)
 SLAB_ENTRY(96, 1, 6, true)
+SLAB_ENTRY(128, 1, 4, true)
 SLAB_ENTRY(128, 1, 6, true)
 SLAB_ENTRY(128, 1, 8, true)
 SLAB_ENTRY(96, 2, 8, true)
@@ -637,7 +639,9 @@ int slab_conv_plan(int K, int Cin, int Cout, int64_t M, int64_t n_pairs, int n_c
     const int max_waves = (Cin > 256) ? 8 : 16;
     while (ncb > max_waves) { if (ncb % 2) return 0; ncb /= 2; ncg *= 2; }
     static const int have[][3] = {{32, 1, 2}, {32, 1, 4}, {64, 1, 4}, {64, 1, 8}, {96, 1, 6}, {128, 1, 6}, {128, 1, 8}, {96, 2, 8},
-                                  {128, 2, 8}, {128, 3, 8}, {128, 1, 16}, {128, 2, 16}};
+                                  {128, 2, 8}, {128, 3, 8}, {128, 1, 16}, {128, 2, 16}, {128, 1, 4}};
+    { static int ncb_env = -1; if (ncb_env < 0) { const char* e = getenv("SD3D_SLAB_NCB"); ncb_env = e ? atoi(e) : 0; }
+      if (ncb_env > 0) while (ncb > ncb_env && ncb % 2 == 0) { ncb /= 2; ncg *= 2; } }
     bool ok = false;
     for (auto& h : have) ok |= (h[0] == ck && h[1] == nch && h[2] == ncb);
     if (!ok) return 0;
@@ -670,7 +674,7 @@ int slab_conv_plan(int K, int Cin, int Cout, int64_t M, int64_t n_pairs, int n_c
     pl->lcap = (R + 31) / 32 * 32;
     pl->ucap = K * (R / 32 + 2);
     pl->lds = (size_t)slab_lds_bytes(R, ncols, ck, K, pl->ucap);
-    pl->ws_bytes = (size_t)slabs * ksplit * ((size_t)K * pl->lcap + 32) * sizeof(int2v) + (ksplit > 1 ? (size_t)ksplit * M * Cout * sizeof(float) : 0) + 256;
+    pl->ws_bytes = (size_t)slabs * ksplit * ncg * ((size_t)K * pl->lcap + 32) * sizeof(int2v) + (ksplit > 1 ? (size_t)ksplit * M * Cout * sizeof(float) : 0) + 256;
     return 1;
 }
 
@@ -764,7 +768,7 @@ int launch_slab_conv(const float* in0, int ld0, int C0, const float* in1, int ld
           if (ks_env > 0) pl.ksplit = ks_env;
           pl.lcap = (pl.R + 31) / 32 * 32; pl.ucap = K * (pl.R / 32 + 2);
           pl.lds = direct ? (size_t)slab_direct_lds_bytes(pl.R, pl.ncb * 32, pl.ucap) : (size_t)slab_lds_bytes(pl.R, pl.ncb * 16, pl.ck, K, pl.ucap);
-          pl.ws_bytes = (size_t)cdiv(M, pl.R) * pl.ksplit * ((size_t)K * pl.lcap + 32) * sizeof(int2v) + (pl.ksplit > 1 ? (size_t)pl.ksplit * M * Cout * sizeof(float) : 0) + 256;
+          pl.ws_bytes = (size_t)cdiv(M, pl.R) * pl.ksplit * pl.ncg * ((size_t)K * pl.lcap + 32) * sizeof(int2v) + (pl.ksplit > 1 ? (size_t)pl.ksplit * M * Cout * sizeof(float) : 0) + 256;
       } }
     if (pl.lds > 160 * 1024) return sd3d_set_error(SD3D_ERR_ARG, "slab_conv: slab does not fit LDS");
     if (ws_bytes < pl.ws_bytes) return sd3d_set_error(SD3D_ERR_WS, "slab_conv: workspace too small (sd3d_slab_conv_ws_bytes)");
@@ -774,7 +778,7 @@ int launch_slab_conv(const float* in0, int ld0, int C0, const float* in1, int ld
     p.scale = scale; p.shift = shift; p.res = res; p.ld_res = ld_res; p.out = out; p.ld_out = ld_out; p.act = act;
     p.R = pl.R; p.lcap = pl.lcap; p.ucap = pl.ucap; p.ksplit = pl.ksplit;
     p.lists = (int2v*)ws;
-    p.part = pl.ksplit > 1 ? (float*)((char*)ws + align_up((size_t)slabs * pl.ksplit * ((size_t)K * pl.lcap + 32) * sizeof(int2v), 256)) : nullptr;
+    p.part = pl.ksplit > 1 ? (float*)((char*)ws + align_up((size_t)slabs * pl.ksplit * pl.ncg * ((size_t)K * pl.lcap + 32) * sizeof(int2v), 256)) : nullptr;
     p.ncols = pl.ncb * (direct ? 32 : 16);
     const dim3 grid((unsigned)slabs, (unsigned)pl.ksplit), block(64 * pl.ncb);
 #define SLAB_CASE(CK, NCH, NCB)                                                                                          \
@@ -782,10 +786,8 @@ int launch_slab_conv(const float* in0, int ld0, int C0, const float* in1, int ld
         static bool attr = false;                                                                                        \
         if (!attr) { (void)hipFuncSetAttribute((const void*)slab_conv_kernel_##CK##_##NCH##_##NCB,                       \
                                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr = true; }   \
-        for (int cg = 0; cg < pl.ncg; ++cg) {                                                                            \
-            p.col0 = cg * p.ncols;                                                                                       \
-            hipLaunchKernelGGL(slab_conv_kernel_##CK##_##NCH##_##NCB, grid, block, pl.lds, st, p);                       \
-        }                                                                                                                \
+        p.col0 = 0;                                                                                                      \
+        hipLaunchKernelGGL(slab_conv_kernel_##CK##_##NCH##_##NCB, dim3(grid.x, grid.y, pl.ncg), block, pl.lds, st, p);   \
     } else
 #define SLABD_CASE(CK, NCH, NW)                                                                                          \
     if (direct && pl.ck == CK && pl.nch == NCH && pl.ncb == NW) {                                                        \
@@ -801,7 +803,7 @@ int launch_slab_conv(const float* in0, int ld0, int C0, const float* in1, int ld
     SLABD_CASE(64, 2, 4) SLABD_CASE(96, 2, 4) SLABD_CASE(64, 4, 4) SLABD_CASE(64, 2, 8) SLABD_CASE(64, 4, 8)
     if (direct) { return sd3d_set_error(SD3D_ERR_ARG, "slab_conv: no kernel variant"); } else
     SLAB_CASE(32, 1, 2) SLAB_CASE(32, 1, 4) SLAB_CASE(64, 1, 4) SLAB_CASE(64, 1, 8) SLAB_CASE(96, 1, 6) SLAB_CASE(128, 1, 6)
-    SLAB_CASE(128, 1, 8) SLAB_CASE(96, 2, 8) SLAB_CASE(128, 2, 8) SLAB_CASE(128, 3, 8) SLAB_CASE(128, 1, 16) SLAB_CASE(128, 2, 16)
+    SLAB_CASE(128, 1, 8) SLAB_CASE(96, 2, 8) SLAB_CASE(128, 2, 8) SLAB_CASE(128, 3, 8) SLAB_CASE(128, 1, 16) SLAB_CASE(128, 2, 16) SLAB_CASE(128, 1, 4)
     { return sd3d_set_error(SD3D_ERR_ARG, "slab_conv: no kernel variant"); }
 #undef SLAB_CASE
     if (pl.ksplit > 1) {

@@ -49,7 +49,7 @@ def maps():
 
 CASES = [  # (table, Cin, Cout, concat split or 0)
     (("same", 1, 3), 32, 32, 0), (("same", 2, 3), 32, 64, 0), (("same", 2, 3), 64, 64, 0), (("same", 3, 3), 64, 128, 0),
-    (("same", 3, 3), 128, 128, 0), (("same", 4, 3), 128, 256, 0), (("same", 4, 3), 256, 256, 0),
+    (("same", 3, 3), 128, 128, 0), (("same", 4, 3), 128, 256, 0), (("same", 4, 3), 256, 256, 0), (("same", 3, 3), 384, 256, 256),
     (("same", 2, 3), 192, 128, 128), (("same", 1, 3), 128, 96, 96), (("same", 0, 3), 96, 96, 0), (("same", 0, 3), 128, 96, 96),
     (("down", 0), 32, 32, 0), (("down", 2), 64, 64, 0), (("up", 3), 256, 256, 0), (("up", 2), 256, 128, 0), (("up", 0), 96, 96, 0),
     (("same", 0, 5), 32, 32, 0),
@@ -92,7 +92,6 @@ def test_unsupported_shapes_are_reported_not_guessed():
     from segdino3d_amd import ops
     d = dev()
     assert not ops.slab_conv_supported(125, 288, 32, 1000, 5000)
-    assert not ops.slab_conv_supported(27, 384, 256, 1000, 5000)         # the one 384-channel layer keeps the pair-major path
     assert not ops.slab_conv_supported(27, 96, 100, 1000, 5000)
     with pytest.raises(ValueError):
         ops.slab_conv(torch.zeros(10, 288, device=d), torch.zeros(125, 32, 288, device=d), torch.zeros(125, 10, dtype=torch.int32, device=d))
