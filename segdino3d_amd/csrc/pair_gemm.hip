@@ -411,6 +411,7 @@ __device__ __forceinline__ void pair_gemm_ws_body(const PGParams& p, float* Ws) 
     const int ldw = p.Cin + 4;                                 // (Cin + 4) mod 64 is 4 or 36: conflict-free b128 rows
     const int c4 = p.Cin >> 2;
     const int npieces = 32 * NT * c4;
+    const int ncol0 = blockIdx.y * NT * 32;                    // column group (256-column layers run as two groups of 128)
     int* Ix = (int*)(Ws + 32 * NT * ldw);                      // gather rows of this workgroup's pairs; padding (-1) -> row 0
 
     f32x16 acc[RT][NT];
@@ -437,7 +438,7 @@ __device__ __forceinline__ void pair_gemm_ws_body(const PGParams& p, float* Ws) 
         while (run_end < ntl && p.tile_k[tile0 + run_end] == k) ++run_end;
         __syncthreads();                                       // everyone is done reading the previous W (and Ix is written)
         {
-            const float* __restrict__ W = p.wt + (int64_t)k * p.Cout * p.Cin;
+            const float* __restrict__ W = p.wt + ((int64_t)k * p.Cout + ncol0) * p.Cin;
             for (int f0 = 0; f0 < npieces; f0 += 256 * 4) {
                 f32x4 v[4];
 #pragma unroll
@@ -510,7 +511,7 @@ __device__ __forceinline__ void pair_gemm_ws_body(const PGParams& p, float* Ws) 
         }                                                                                                             \
         if (last_chunk) { /* unit complete: lane = pair row, register group g = columns 8g + 4h .. +3 */              \
             _Pragma("unroll") for (int rt = 0; rt < RT; ++rt) {                                                       \
-                float* dst = p.part + (((int64_t)tile0 * UPT + u0 + 4 * cur_i) * RT * 32 + rt * 32 + j) * p.Cout + 4 * h; \
+                float* dst = p.part + (((int64_t)tile0 * UPT + u0 + 4 * cur_i) * RT * 32 + rt * 32 + j) * p.Cout + ncol0 + 4 * h; \
                 _Pragma("unroll") for (int t = 0; t < NT; ++t)                                                        \
                     _Pragma("unroll") for (int g = 0; g < 4; ++g)                                                     \
                         *(f32x4*)(dst + t * 32 + 8 * g) = f32x4{acc[rt][t][4 * g], acc[rt][t][4 * g + 1],             \
@@ -691,25 +692,34 @@ int launch_pair_conv(const float* in0, int ld0, int C0, const float* in1, int ld
     static int ws_env = -1;
     if (ws_env < 0) { const char* e = getenv("SD3D_PAIR_WS"); ws_env = e ? atoi(e) : 1; }
     const size_t w_lds = (size_t)Cout * (Cin + 4) * sizeof(float);
-    if (ws_env && cgs == 1 && Cout == 32 * nt && w_lds <= 68 * 1024) {
+    const size_t w_lds_cg = (size_t)(32 * nt) * (Cin + 4) * sizeof(float);       // one column group's share of W[k]
+    const bool ws_one = ws_env && cgs == 1 && Cout == 32 * nt && w_lds <= 68 * 1024;
+    // wide layers (256 columns = two groups of 128): the group's half of W[k] (133 KB at Cin = 256) still fits LDS with ONE
+    // workgroup per CU - no per-step barrier, no re-staging of weight chunks, like the narrow layers
+    static int ws2_env = -1;
+    if (ws2_env < 0) { const char* e = getenv("SD3D_PAIR_WS2"); ws2_env = e ? atoi(e) : 1; }
+    // (measured: level-3 256->256, 1808 tiles: 358 -> 347 us; level-4, 472 tiles: 104 -> 113 us - too few tiles for half the workgroups)
+    const bool ws_two = ws_env && ws2_env && cgs == 2 && nt == 4 && Cout == 256 && g.n_tiles >= 1024 && w_lds_cg + WS_RANGE_TILES * PT * sizeof(int32_t) + 256 <= 160 * 1024;
+    if (ws_one || ws_two) {
         static bool attr_done = false;
         if (!attr_done) {
             (void)hipFuncSetAttribute((const void*)pair_gemm_ws_kernel_1, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
             (void)hipFuncSetAttribute((const void*)pair_gemm_ws_kernel_2, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
             (void)hipFuncSetAttribute((const void*)pair_gemm_ws_kernel_3, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
-            (void)hipFuncSetAttribute((const void*)pair_gemm_ws_kernel_4, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
+            (void)hipFuncSetAttribute((const void*)pair_gemm_ws_kernel_4, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
             attr_done = true;
         }
         // resident workgroups per CU: the pinned register budgets allow 4 / 3 / 3 / 2; LDS (160 KB) may allow fewer
         int per_cu = nt == 1 ? 4 : (nt == 3 ? 3 : 2);
-        const int by_lds = (int)((160 * 1024) / (w_lds + WS_RANGE_TILES * PT * sizeof(int32_t) + 256));
+        const size_t w_need = ws_two ? w_lds_cg : w_lds;
+        const int by_lds = (int)((160 * 1024) / (w_need + WS_RANGE_TILES * PT * sizeof(int32_t) + 256));
         per_cu = per_cu < by_lds ? per_cu : by_lds;
         if (slots_env > 0) per_cu = slots_env;
-        int gx = n_cu * per_cu;
-        gx = gx < g.n_tiles ? gx : g.n_tiles;
+        int gx = n_cu * per_cu / (ws_two ? 2 : 1);
+        gx = gx < 1 ? 1 : (gx < g.n_tiles ? gx : g.n_tiles);
         { static int gx_env = -1; if (gx_env < 0) { const char* e = getenv("SD3D_PAIR_GX"); gx_env = e ? atoi(e) : 0; } if (gx_env > 0) gx = gx_env; }
-        const dim3 wgrid((unsigned)gx);
-        const size_t lds = w_lds + (size_t)WS_RANGE_TILES * PT * sizeof(int32_t);
+        const dim3 wgrid((unsigned)gx, ws_two ? 2u : 1u);
+        const size_t lds = w_need + (size_t)WS_RANGE_TILES * PT * sizeof(int32_t);
         switch (nt) {
             case 1: hipLaunchKernelGGL(pair_gemm_ws_kernel_1, wgrid, dim3(256), lds, st, g); break;
             case 2: hipLaunchKernelGGL(pair_gemm_ws_kernel_2, wgrid, dim3(256), lds, st, g); break;
