@@ -117,6 +117,18 @@ int sd3d_pool_superpoints(const float* feat, int ld_feat, int C, const int32_t* 
 int sd3d_gather_gemm(const float* in0, int ld0, int C0, const float* in1, int ld1, const int32_t* nbr, const float* wt,
                      int K, int Cin, int Cout, int64_t M, const float* scale, const float* shift, const float* res,
                      int ld_res, float* out, int ld_out, int act, int nt, void* ws, size_t ws_bytes, void* stream);
+/* n <= 8 INDEPENDENT plain Linears in one launch: out_i = act_i([in0_i | in1_i] wt_i^T + shift_i + res_i), wt_i [Cout, Cin]
+ * (nn.Linear layout).  For the decoder's chains of few-hundred-row Linears (instance_seg_3d_decoder.py:656-772: the two box MLPs
+ * of a layer, projections that share an input) - the same kernel as sd3d_gather_gemm's small-M path, one dispatch. */
+typedef struct sd3d_linear_job {
+    const float *in0, *in1;            /* in1: optional second source (concatenated channels C0..Cin-1) or NULL */
+    const float *wt, *shift, *res;     /* shift / res optional */
+    float* out;
+    int64_t M;
+    int32_t ld0, C0, ld1, Cin, Cout, ld_res, ld_out, act;
+} sd3d_linear_job;
+int sd3d_linear_group(int n, const sd3d_linear_job* jobs, void* stream);
+
 /* Opt-in variant of sd3d_gather_gemm that evaluates the fp32 products as sums of bf16 MFMA products
  * (csrc/gather_gemm_split.hip).  wt_split = the fp32 weights [K, Cout, Cin] split into bf16 terms,
  * w = t0 + t1 (+ t2) with t_i = bf16_rne(w - sum_{j<i} t_j), laid out [2 or 3][K][Cout][Cin];

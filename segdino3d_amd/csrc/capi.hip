@@ -36,6 +36,7 @@ int launch_gather_gemm(const GGParams&, int, void*, size_t, hipStream_t);
 int launch_gather_gemm_split(const GGParams&, int, int, const void*, void*, size_t, hipStream_t);
 size_t pair_lists_ws_bytes(int K, int64_t M);
 int launch_pair_lists(const int32_t*, int, int64_t, int64_t, int32_t*, int32_t*, int32_t*, void*, size_t, hipStream_t);
+int launch_linear_group(int, const GGParams*, hipStream_t);
 int launch_pair_lists_batch(int, const int32_t* const*, const int*, const int64_t*, const int64_t*, int32_t* const*, int32_t* const*,
                             int32_t* const*, void*, size_t, hipStream_t);
 size_t slab_conv_ws_bytes(int, int, int, int64_t, int64_t);
@@ -183,6 +184,19 @@ int sd3d_gather_gemm_split(const float* in0, int ld0, int C0, const float* in1, 
     p.ksplit = 1;
     p.ws = nullptr;
     return launch_gather_gemm_split(p, nt, terms, wt_split, ws, ws_bytes, ST);
+}
+
+int sd3d_linear_group(int n, const sd3d_linear_job* jobs, void* stream) {
+    GGParams g[8];
+    if (n > 8) return sd3d_set_error(SD3D_ERR_ARG, "linear_group: at most 8 jobs per launch");
+    for (int i = 0; i < n; ++i) {
+        const sd3d_linear_job& J = jobs[i];
+        GGParams& p = g[i];
+        p.in0 = J.in0; p.ld0 = J.ld0; p.C0 = J.C0; p.in1 = J.in1; p.ld1 = J.ld1; p.nbr = nullptr; p.wt = J.wt; p.K = 1; p.Cin = J.Cin;
+        p.Cout = J.Cout; p.M = J.M; p.scale = nullptr; p.shift = J.shift; p.res = J.res; p.ld_res = J.ld_res; p.out = J.out;
+        p.ld_out = J.ld_out; p.act = J.act; p.col_groups = 1; p.ksplit = 1; p.ws = nullptr;
+    }
+    return launch_linear_group(n, g, ST);
 }
 
 size_t sd3d_pair_lists_ws_bytes(int K, int64_t M) { return pair_lists_ws_bytes(K, M); }

@@ -66,13 +66,12 @@ __device__ __forceinline__ void mma_frag(f32x16 (&acc)[NT], const Frag<NT>& f) {
 //         wave 0.  Used when the launch would otherwise leave most of the 1024 SIMDs idle (coarse
 //         levels of the U-Net, decoder Linears with a few hundred rows).
 template <int NT, int KS>
-__global__ __launch_bounds__(256) void gather_gemm_kernel(const GGParams p) {
-    __shared__ float red[(KS > 1) ? (KS - 1) * NT * 16 * 64 : 1];
+__device__ __forceinline__ void gather_gemm_body(const GGParams& p, const int64_t block, float* red) {
     const int lane = threadIdx.x & 63;
     const int j = lane & 31, h = lane >> 5;
     const int wv = threadIdx.x >> 6;
     const int ks = (KS > 1) ? wv : 0;
-    const int64_t unit = (KS > 1) ? (int64_t)blockIdx.x : (int64_t)blockIdx.x * 4 + wv;
+    const int64_t unit = (KS > 1) ? block : block * 4 + wv;
     const int64_t row_tile = unit / p.col_groups;
     const int cg = (int)(unit - row_tile * p.col_groups);
     const int64_t row0 = row_tile * 32;
@@ -166,6 +165,26 @@ __global__ __launch_bounds__(256) void gather_gemm_kernel(const GGParams p) {
             p.out[rr * p.ld_out + n] = y;
         }
     }
+}
+
+template <int NT, int KS>
+__global__ __launch_bounds__(256) void gather_gemm_kernel(const GGParams p) {
+    __shared__ float red[(KS > 1) ? (KS - 1) * NT * 16 * 64 : 1];
+    gather_gemm_body<NT, KS>(p, (int64_t)blockIdx.x, red);
+}
+
+// Several INDEPENDENT small Linears in one launch (blockIdx.y = job): the decoder on a few hundred queries is a chain of
+// ~140 Linears of 26-100 MFLOP each, every one a separate ~10 us launch; the ones that do not depend on each other (the two
+// box MLPs, the projections that share an input, the class head of layer i next to the first projections of layer i + 1)
+// run side by side here.  Same code path as the single launch (split-K over the four waves of a workgroup).
+#define GG_GROUP_MAX 8
+struct GGGroup { int n; GGParams job[GG_GROUP_MAX]; };
+__global__ __launch_bounds__(256) void gather_gemm_group_kernel(const GGGroup g) {
+    __shared__ float red[3 * 16 * 64];
+    const GGParams& p = g.job[blockIdx.y];
+    const int64_t units = ((p.M + 31) / 32) * p.col_groups;
+    if ((int64_t)blockIdx.x >= units) return;               // uniform per workgroup
+    gather_gemm_body<1, 4>(p, (int64_t)blockIdx.x, red);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -444,6 +463,30 @@ int launch_gather_gemm(const GGParams& p_in, int nt, void* ws, size_t ws_bytes, 
         }
     }
 #undef GG_LAUNCH
+    SD3D_CHECK_LAUNCH();
+    return SD3D_OK;
+}
+
+// n <= 8 independent plain Linears (identity rows, K = 1): out_i = act_i(x_i W_i^T + shift_i + res_i)
+int launch_linear_group(int n, const GGParams* jobs, hipStream_t st) {
+    if (n <= 0) return SD3D_OK;
+    if (n > GG_GROUP_MAX) return sd3d_set_error(SD3D_ERR_ARG, "linear_group: at most 8 jobs per launch");
+    GGGroup g;
+    g.n = n;
+    int64_t max_units = 0;
+    for (int i = 0; i < n; ++i) {
+        GGParams p = jobs[i];
+        if (p.M <= 0 || p.Cout <= 0 || p.Cin <= 0 || (p.Cin & 31)) return sd3d_set_error(SD3D_ERR_ARG, "linear_group: Cin must be a positive multiple of 32");
+        if (p.in1 && ((p.C0 & 31) || p.C0 > p.Cin)) return sd3d_set_error(SD3D_ERR_ARG, "linear_group: concat split must be a multiple of 32");
+        if (!p.in1) p.C0 = p.Cin;
+        if ((p.ld0 & 3) || (p.in1 && (p.ld1 & 3))) return sd3d_set_error(SD3D_ERR_ARG, "linear_group: input row stride must be a multiple of 4 floats");
+        p.nbr = nullptr; p.K = 1; p.ksplit = 1; p.ws = nullptr;
+        p.col_groups = (int)cdiv(p.Cout, 32);
+        const int64_t units = cdiv(p.M, 32) * p.col_groups;
+        max_units = units > max_units ? units : max_units;
+        g.job[i] = p;
+    }
+    hipLaunchKernelGGL(gather_gemm_group_kernel, dim3((unsigned)max_units, (unsigned)n), dim3(256), 0, st, g);
     SD3D_CHECK_LAUNCH();
     return SD3D_OK;
 }

@@ -89,6 +89,10 @@ class _EvalF:
     def linear(x, w, b=None, act=None, res=None, x2=None):
         return ops.gather_gemm(x, w, x2=x2, shift=b, act=act, res=res)
 
+    @staticmethod
+    def linear_group(jobs):                                      # independent small Linears: one launch (ops.linear_group)
+        return ops.linear_group(jobs)
+
     layernorm = staticmethod(ops.layernorm)
     attention = staticmethod(ops.attention)
     box_refine = staticmethod(ops.box_refine)
@@ -109,6 +113,11 @@ class _TrainF:
     def linear(x, w, b=None, act=None, res=None, x2=None):
         from . import train_dec
         return train_dec.linear(x, w, b, act=act, res=res, x2=x2)
+
+    @staticmethod
+    def linear_group(jobs):                                      # training: every Linear its own autograd node
+        from . import train_dec
+        return [train_dec.linear(x, w, b, act=act, res=res, x2=x2) for (x, w, b, act, res, x2) in jobs]
 
     @staticmethod
     def layernorm(x, w, b, res=None, act=None, eps=1e-5):
@@ -341,10 +350,12 @@ class ScanNetQueryDecoder(DerivedWeights):
         return self._pe_tables[key]
 
     # ---- prediction head (:532-577) ----------------------------------------------------------------
-    def _head(self, queries, mask_feats, last_flag):
+    def _head(self, queries, mask_feats, last_flag, defer_cls=False):
+        """-> (class logits | the normalised queries when `defer_cls`, semantic logits | None, mask logits, mask bits).  The class
+        MLP feeds nothing inside the decoder, so the positional variant runs it inside the NEXT layer's first launches."""
         S = mask_feats.shape[0]
         nq = _F().layernorm(queries, self.out_norm.weight, self.out_norm.bias)
-        cls = _lin(_lin(nq, self.out_cls[0], act="relu"), self.out_cls[2])
+        cls = nq if defer_cls else _lin(_lin(nq, self.out_cls[0], act="relu"), self.out_cls[2])
         sem = None
         if last_flag:
             if isinstance(self.out_sem, nn.Linear):
@@ -416,8 +427,12 @@ class ScanNetQueryDecoder(DerivedWeights):
         inst = F.layernorm(_lin(x, self.input_proj[0]), self.input_proj[1].weight, self.input_proj[1].bias, act="relu")
         mask_feats = _lin(_lin(x, self.x_mask[0], act="relu"), self.x_mask[2])
         queries = _lin(_lin(q_in, self.query_proj[0], act="relu"), self.query_proj[2])
-        cls, sem, logits, bits = self._head(queries, mask_feats, False)
-        aux = [dict(cls_preds=cls, sem_preds=None, masks=logits, centers=None, sizes=None)]
+        # Independent Linears on the few hundred query rows go out in ONE launch each time (F.linear_group): the class MLP of
+        # a prediction head rides with the next layer's first projections, the two box MLPs run side by side, projections that
+        # share an input are batched.  Every Linear is still the same fp32 product; only the dispatch count changes.
+        J = lambda x, layer, act=None, res=None, x2=None: (x, layer.weight, layer.bias, act, res, x2)  # noqa: E731
+        nq_pending, sem, logits, bits = self._head(queries, mask_feats, False, defer_cls=True)
+        aux = [dict(cls_preds=None, sem_preds=None, masks=logits, centers=None, sizes=None)]
 
         # layer-invariant key side, hoisted out of the loop (the reference recomputes it per layer, :669-671)
         kv_all = F.linear(inst, pk["kv_w"], pk["kv_b"])                  # [S, 2*L*d]: kc_0..kc_{L-1} | v_0..v_{L-1}
@@ -434,13 +449,29 @@ class ScanNetQueryDecoder(DerivedWeights):
         ref_sizes = size_q
         for i in range(L):
             ops.baton_yield()
+            # ---- launch A: first layer of the box-modulation MLP, this layer's content query (layers >= 1), and the first
+            #      layer of the previous head's class MLP
+            jobs, what = [], []
+            if self.box_modulate_ca:
+                jobs.append(J(queries, self.ref_anchor_head.layers[0], "relu")); what.append("anchor")
+            if i > 0:
+                jobs.append(J(queries, self.ca_qcontent_proj[i])); what.append("qc")
+            jobs.append(J(nq_pending, self.out_cls[0], "relu")); what.append("cls")
+            outs = dict(zip(what, F.linear_group(jobs)))
+            # ---- launch B: second layers of both
+            jobs, what = [J(outs["cls"], self.out_cls[2])], ["cls"]
+            if self.box_modulate_ca:
+                jobs.append(J(outs["anchor"], self.ref_anchor_head.layers[1], "sigmoid")); what.append("hwl")
+            outs2 = dict(zip(what, F.linear_group(jobs)))
+            aux[-1]["cls_preds"] = outs2["cls"]
             # ---- box-modulated positional query (:659-666)
             if self.box_modulate_ca:
-                hwl = _mlp(queries, self.ref_anchor_head, final_act="sigmoid")
-                pq_emb = F.sine_pe_mod(ref_points, rng, dim_t, axis, hwl, ref_sizes)
+                pq_emb = F.sine_pe_mod(ref_points, rng, dim_t, axis, outs2["hwl"], ref_sizes)
             else:
                 pq_emb = ops.sine_pe(ref_points, rng, dim_t, axis)
-            query_pos = _mlp(pq_emb, self.ref_point_head)
+            # ---- launch C: first layer of the positional-query MLP next to the sine projection of the cross-attention
+            h, qs = F.linear_group([J(pq_emb, self.ref_point_head.layers[0], "relu"), J(pq_emb, self.ca_qpos_sine_proj[i])])
+            query_pos = _lin(h, self.ref_point_head.layers[1])
             # ---- masked cross-attention to the superpoints (:668-691)
             kc = kv_all[:, i * d:(i + 1) * d]
             v = kv_all[:, (L + i) * d:(L + i + 1) * d]
@@ -449,8 +480,7 @@ class ScanNetQueryDecoder(DerivedWeights):
                 qc = F.linear(queries, pk["ca_q0_w"], pk["ca_q0_b"], x2=query_pos)
                 kc = _lin(inst, self.ca_kcontent_proj[0], res=kp)
             else:
-                qc = _lin(queries, self.ca_qcontent_proj[i])
-            qs = _lin(pq_emb, self.ca_qpos_sine_proj[i])
+                qc = outs["qc"]
             a = F.attention(qc, kc, v, H, (2 * d // H) ** -0.5, mask_bits=bits, q2=qs, k2=kp)
             a = _lin(a, self.cross_attn_layers[i].out_proj)
             queries = F.layernorm(a, self.norm1[i].weight, self.norm1[i].bias, res=queries)
@@ -476,16 +506,22 @@ class ScanNetQueryDecoder(DerivedWeights):
             hdn = _lin(queries, ffn.net[0], act=("relu" if self.activation_fn == "relu" else "gelu"))
             hdn = _lin(hdn, ffn.net[3], res=queries)
             queries = F.layernorm(hdn, ffn.norm.weight, ffn.norm.bias)
-            # ---- iterative box refinement (:735-759)
-            dc = _mlp(queries, self.bbox_embed[i])
-            ds = _mlp(queries, self.bbox_size_embed[i]) if self.add_box_size_pred else None
+            # ---- iterative box refinement (:735-759): the centre and the size MLP side by side, three launches for six Linears
+            if self.add_box_size_pred:
+                be, se = self.bbox_embed[i].layers, self.bbox_size_embed[i].layers
+                c1, s1 = F.linear_group([J(queries, be[0], "relu"), J(queries, se[0], "relu")])
+                c2, s2 = F.linear_group([J(c1, be[1], "relu"), J(s1, se[1], "relu")])
+                dc, ds = F.linear_group([J(c2, be[2]), J(s2, se[2])])
+            else:
+                dc, ds = _mlp(queries, self.bbox_embed[i]), None
             center, size, size_metric = F.box_refine(ref_points, dc, size_q, ds, rng, self.normalize_box_prediction)
             ref_points = center.detach()                       # `:740`
             if self.add_box_size_pred:
                 ref_sizes = size_q = size.detach()             # `:753`
             last = i == L - 1
-            cls, sem, logits, bits = self._head(queries, mask_feats, last)
-            aux.append(dict(cls_preds=cls, sem_preds=sem, masks=logits, centers=center, sizes=size_metric))
+            nq_pending, sem, logits, bits = self._head(queries, mask_feats, last, defer_cls=True)
+            aux.append(dict(cls_preds=None, sem_preds=sem, masks=logits, centers=center, sizes=size_metric))
+        aux[-1]["cls_preds"] = _lin(_lin(nq_pending, self.out_cls[0], act="relu"), self.out_cls[2])
         final = aux.pop()
         final["hidden_states"] = queries
         final["attn_mask_bits"] = bits

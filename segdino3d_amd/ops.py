@@ -527,6 +527,54 @@ def pair_conv(x, wt, pairs, x2=None, scale=None, shift=None, res=None, act=None,
     return out
 
 
+_LINEAR_JOB_DT = None
+
+
+def linear_group(jobs):
+    """jobs: list of (x, weight [Cout, Cin], bias | None, act | None, res | None, x2 | None) - INDEPENDENT plain Linears on a few
+    hundred rows each; returns their outputs.  Up to 8 per launch (csrc/gather_gemm.hip gather_gemm_group_kernel); jobs that do
+    not fit the small-row path (>= 2048 rows, bf16 decoder scope on >= BF16_MIN_ROWS rows, instrumentation hook) run one by one."""
+    global _LINEAR_JOB_DT
+    import numpy as np
+    if len(jobs) == 1 or GG_HOOK is not None or GEMM_MODE is not None or GG_FORCE_NT is not None:
+        return [gather_gemm(x, w, x2=x2, shift=b, act=act, res=res) for (x, w, b, act, res, x2) in jobs]
+    bf16 = getattr(_BF16_TLS, "on", False)
+    small = [x.shape[0] < 2048 and not (bf16 and x.shape[0] >= BF16_MIN_ROWS) and x.shape[0] > 0 for (x, *_r) in jobs]
+    if not all(small):
+        return [gather_gemm(x, w, x2=x2, shift=b, act=act, res=res) for (x, w, b, act, res, x2) in jobs]
+    if _LINEAR_JOB_DT is None:
+        _LINEAR_JOB_DT = np.dtype([("in0", "<u8"), ("in1", "<u8"), ("wt", "<u8"), ("shift", "<u8"), ("res", "<u8"), ("out", "<u8"),
+                                   ("M", "<i8"), ("ld0", "<i4"), ("C0", "<i4"), ("ld1", "<i4"), ("Cin", "<i4"), ("Cout", "<i4"),
+                                   ("ld_res", "<i4"), ("ld_out", "<i4"), ("act", "<i4")], align=True)
+        assert _LINEAR_JOB_DT.itemsize == 88
+    lib = _lib.load()
+    outs = []
+    for start in range(0, len(jobs), 8):
+        chunk = jobs[start:start + 8]
+        tab = np.zeros(len(chunk), dtype=_LINEAR_JOB_DT)
+        for i, (x, w, b, act, res, x2) in enumerate(chunk):
+            if not (x.is_cuda and w.is_cuda) or x.dtype is not torch.float32 or w.dtype is not torch.float32 or x.dim() != 2 \
+                    or x.stride(1) != 1 or not w.is_contiguous() or w.dim() != 2:
+                raise ValueError("linear_group: expected 2-D fp32 device tensors with contiguous rows")
+            M, C0 = x.shape
+            Cout, Cin = w.shape
+            if (x2 is None and C0 != Cin) or (x2 is not None and (C0 + x2.shape[1] != Cin or x2.stride(1) != 1 or x2.shape[0] != M)):
+                raise ValueError(f"linear_group: input channels do not match Cin {Cin}")
+            out = torch.empty(M, Cout, dtype=torch.float32, device=x.device)
+            if res is not None and (res.shape != out.shape or res.stride(1) != 1 or res.dtype is not torch.float32):
+                raise ValueError("linear_group: residual must be an fp32 [rows, Cout] tensor")
+            if b is not None and (b.numel() != Cout or not b.is_contiguous() or b.dtype is not torch.float32):
+                raise ValueError("linear_group: bias must be a contiguous fp32 [Cout] tensor")
+            tab[i] = (x.data_ptr(), 0 if x2 is None else x2.data_ptr(), w.data_ptr(), 0 if b is None else b.data_ptr(),
+                      0 if res is None else res.data_ptr(), out.data_ptr(), M, x.stride(0), C0, 0 if x2 is None else x2.stride(0), Cin, Cout,
+                      0 if res is None else res.stride(0), Cout, ACT[act])
+            outs.append(out)
+        rc = lib.sd3d_linear_group(len(chunk), tab.ctypes.data, _stream())
+        if rc:
+            _lib.check(rc, "linear_group")
+    return outs
+
+
 def slab_conv_supported(K, Cin, Cout, M, n_pairs) -> bool:
     return _lib.load().sd3d_slab_conv_ws_bytes(K, Cin, Cout, M, int(n_pairs)) > 0
 
