@@ -220,6 +220,10 @@ int sd3d_layernorm(const float* x, int ld_x, const float* res, int ld_res, const
 int sd3d_sine_pe(const float* xyz, int ld_xyz, int64_t n, const float* range, const float* dim_t, const int8_t* axis,
                  int d_pos, const float* mod_num, int ld_num, const float* mod_den, int ld_den, float* out, int ld_out,
                  void* stream);
+/* PositionEmbeddingCoordsSine.get_fourier_embeddings (utils.py:107-142; decoder `pos_type="fourier"`): out[:, :d/2] = sin(p),
+ * out[:, d/2:] = cos(p), p = (2 pi * shift_scale(xyz)) @ gauss_b[:, :d/2]; gauss_b [3, >= d/2] is the module's buffer. */
+int sd3d_fourier_pe(const float* xyz, int ld_xyz, int64_t n, const float* range, const float* gauss_b, int ld_b, int d_pos,
+                    float* out, int ld_out, void* stream);
 /* Fused multi-head attention (replaces bmm + masked_fill + softmax + bmm of attention.py:361-385 and
  * nn.MultiheadAttention's SDPA at decoder :79).  Heads are 32-channel slices; nsrc = 2 concatenates
  * [q0|q1] . [k0|k1] per head (decoder :681-687).  mask_bits [Lq, ceil(Lk/32)]: bit = 1 -> blocked.

@@ -38,6 +38,7 @@ class DecoderCfg:
     normalize_box_prediction: bool = True
     activation_fn: str = "gelu"
     add_positional_embedding: bool = True
+    pos_type: str = "sine"                 # "fourier": Gaussian random features, buffer position_embedding.gauss_B
 
 
 class W:
@@ -157,6 +158,13 @@ def _packed_mha(w: W, name, q_in, kv_in, num_heads, blocked):
     return w.lin(attention_core(q, k, v, num_heads, blocked), name + ".out_proj")
 
 
+def fourier_pe(xyz, lo, hi, gauss_b, d_pos=256):
+    """get_fourier_embeddings (utils.py:107-142): [sin | cos] of (2 pi * normalised xyz) @ gauss_B[:, :d_pos / 2]."""
+    x = ((xyz - lo) * 1.0 / (hi - lo) + 0.0) * (2 * math.pi)
+    proj = torch.mm(x, gauss_b[:, : d_pos // 2])
+    return torch.cat([proj.sin(), proj.cos()], dim=1)
+
+
 def decoder_forward_plain(sd, cfg: DecoderCfg, x, q_in, prefix="decoder."):
     """Non-positional variant (Baseline_ScanNet200 prototype: add_positional_embedding=False, no 2D-query
     attention): forward_iter_pred :693, :711, :733 with CrossAttentionLayer (:60-86, fix=True),
@@ -193,7 +201,11 @@ def decoder_forward(sd, cfg: DecoderCfg, x, sp_pos, sp_pos_wo, q_in, q_pos, q2d_
     d = cfg.d_model
     hd = d // H
     extent = hi - lo
-    memory_emb = sine_pe(sp_pos, lo, hi, cfg.temperature, d)
+    if cfg.pos_type == "fourier":
+        pe = lambda p: fourier_pe(p, lo, hi, w("position_embedding.gauss_B"), d)  # noqa: E731
+    else:
+        pe = lambda p: sine_pe(p, lo, hi, cfg.temperature, d)  # noqa: E731
+    memory_emb = pe(sp_pos)
     Q = q_in.shape[0]
     if cfg.normalize_box_prediction:
         size_q = (1.0 / extent * 0.5).expand(Q, 3)
@@ -213,7 +225,7 @@ def decoder_forward(sd, cfg: DecoderCfg, x, sp_pos, sp_pos_wo, q_in, q_pos, q2d_
             hwl = torch.sigmoid(w.mlp(queries, "ref_anchor_head", 2))
             pq_emb = sine_pe(ref_points, lo, hi, cfg.temperature, d, modulated=hwl / ref_sizes)
         else:
-            pq_emb = sine_pe(ref_points, lo, hi, cfg.temperature, d)
+            pq_emb = pe(ref_points)
         query_pos = w.mlp(pq_emb, "ref_point_head", 2)
         # ---- masked cross-attention to superpoints (:668-691)
         qc = w.lin(queries, f"ca_qcontent_proj.{i}")

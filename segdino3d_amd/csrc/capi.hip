@@ -37,6 +37,7 @@ int launch_gather_gemm_split(const GGParams&, int, int, const void*, void*, size
 size_t pair_lists_ws_bytes(int K, int64_t M);
 int launch_pair_lists(const int32_t*, int, int64_t, int64_t, int32_t*, int32_t*, int32_t*, void*, size_t, hipStream_t);
 int launch_linear_group(int, const GGParams*, hipStream_t);
+int launch_fourier_pe(const float*, int, int64_t, const float*, const float*, int, int, float*, int, hipStream_t);
 int launch_pair_lists_batch(int, const int32_t* const*, const int*, const int64_t*, const int64_t*, int32_t* const*, int32_t* const*,
                             int32_t* const*, void*, size_t, hipStream_t);
 size_t slab_conv_ws_bytes(int, int, int, int64_t, int64_t);
@@ -184,6 +185,11 @@ int sd3d_gather_gemm_split(const float* in0, int ld0, int C0, const float* in1, 
     p.ksplit = 1;
     p.ws = nullptr;
     return launch_gather_gemm_split(p, nt, terms, wt_split, ws, ws_bytes, ST);
+}
+
+int sd3d_fourier_pe(const float* xyz, int ld_xyz, int64_t n, const float* range, const float* gauss_b, int ld_b, int d_pos, float* out,
+                    int ld_out, void* stream) {
+    return launch_fourier_pe(xyz, ld_xyz, n, range, gauss_b, ld_b, d_pos, out, ld_out, ST);
 }
 
 int sd3d_linear_group(int n, const sd3d_linear_job* jobs, void* stream) {

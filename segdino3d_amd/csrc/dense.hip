@@ -109,6 +109,39 @@ int launch_sine_pe(const float* xyz, int ld_xyz, int64_t n, const float* rng, co
     return SD3D_OK;
 }
 
+// PositionEmbeddingCoordsSine.get_fourier_embeddings (utils.py:107-142, pos_type = "fourier"): the normalised coordinates
+// times 2 pi projected by the fixed Gaussian matrix gauss_B [3, d_pos / 2], then [sin | cos].  Same operation order as the
+// reference: (x_a * 2 pi) * B[a][c], summed a = 0, 1, 2.
+__global__ __launch_bounds__(256) void fourier_pe_kernel(const float* __restrict__ xyz, int ld_xyz, int64_t n, const float* __restrict__ rng,
+                                                         const float* __restrict__ gauss_b, int ld_b, int d_pos,
+                                                         float* __restrict__ out, int ld_out) {
+    const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int dh = d_pos >> 1;
+    if (t >= n * dh) return;
+    const int64_t r = t / dh;
+    const int c = (int)(t - r * dh);
+    float acc = 0.f;
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+        const float lo = rng[a], hi = rng[3 + a];
+        float p = ((xyz[r * ld_xyz + a] - lo) * 1.0f) / (hi - lo) + 0.0f;
+        p = p * 6.283185307179586f;
+        acc = fmaf(p, gauss_b[a * ld_b + c], acc);
+    }
+    out[r * ld_out + c] = sinf(acc);
+    out[r * ld_out + dh + c] = cosf(acc);
+}
+
+int launch_fourier_pe(const float* xyz, int ld_xyz, int64_t n, const float* rng, const float* gauss_b, int ld_b, int d_pos, float* out,
+                      int ld_out, hipStream_t st) {
+    if (n <= 0) return SD3D_OK;
+    if (d_pos <= 0 || (d_pos & 1)) return sd3d_set_error(SD3D_ERR_ARG, "fourier_pe: d_pos must be even");
+    hipLaunchKernelGGL(fourier_pe_kernel, dim3((unsigned)cdiv(n * (d_pos / 2), 256)), dim3(256), 0, st, xyz, ld_xyz, n, rng, gauss_b, ld_b,
+                       d_pos, out, ld_out);
+    SD3D_CHECK_LAUNCH();
+    return SD3D_OK;
+}
+
 // ---------------------------------------------------------------------------------------------
 // Fused multi-head attention, head slices of 32 channels, NSRC concatenated sources per head.
 //   score(q, key) = scale * sum_src  q_src[q, head*32 : +32] . k_src[key, head*32 : +32]

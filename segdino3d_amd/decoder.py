@@ -82,6 +82,15 @@ class _FFNHolder(nn.Module):
         self.norm = nn.LayerNorm(d_model)
 
 
+class _FourierPE(nn.Module):
+    """Buffer holder named like the reference's `position_embedding` for `pos_type="fourier"` (utils.py:45-51)."""
+
+    def __init__(self, d_pos, gauss_scale):
+        super().__init__()
+        assert d_pos % 2 == 0
+        self.register_buffer("gauss_B", torch.empty(3, d_pos // 2).normal_() * gauss_scale)
+
+
 class _EvalF:
     """The decoder's differentiable building blocks in eval mode: straight calls into the forward kernels."""
 
@@ -176,8 +185,8 @@ class ScanNetQueryDecoder(DerivedWeights):
         super().__init__()
         assert num_semantic_linears in [1, 2]
         unsupported = []
-        if add_positional_embedding and pos_type != "sine":
-            unsupported.append("pos_type='sine' is required with add_positional_embedding (fourier PE is not built)")
+        if add_positional_embedding and pos_type not in ("sine", "fourier"):
+            raise AssertionError(f"pos_type must be 'sine' or 'fourier', got {pos_type!r}")        # utils.py:41
         if not add_positional_embedding and (add_dinox_query_ca or add_box_size_pred or box_modulate_ca):
             unsupported.append("2D-query attention / box heads need add_positional_embedding=True")
         if not iter_pred or not attn_mask:
@@ -186,11 +195,10 @@ class ScanNetQueryDecoder(DerivedWeights):
             unsupported.append("learned query embeddings / objectness head are not built")
         if d_model != num_heads * 32:
             unsupported.append("attention heads must be 32 channels wide (d_model == 32 * num_heads)")
-        if dropout != 0.0:
-            unsupported.append("dropout must be 0 (the shipped configs use 0.0; dropout kernels are not built)")
         if add_dinox_query_ca and not add_dinox_query_ca_mask:
             unsupported.append("add_dinox_query_ca requires add_dinox_query_ca_mask")
         if box_modulate_ca:
+            assert pos_type == "sine", "Only implemented for sine positional embedding now."        # `:528`
             assert add_positional_embedding and add_box_size_pred, \
                 " If you want to use box to modulate cross attention, you should set add_positional_embedding and add_box_size_pred to True."
         if unsupported:
@@ -212,6 +220,9 @@ class ScanNetQueryDecoder(DerivedWeights):
         self.box_modulate_ca = box_modulate_ca
         self.normalize_box_prediction = normalize_box_prediction
         self.temperature = float(temperature)
+        self.pos_type = pos_type
+        # nn.Dropout is the identity in evaluation; the training path has no dropout kernels and refuses p > 0 when it runs
+        self.dropout = float(dropout)
         self.num_queries = 0
         # "fp32" (default, BASELINE config #2) or "bf16" (config #3: projections and both attention contractions on the bf16
         # MFMA with fp32 accumulation; LayerNorm, softmax, positional encodings, mask logits and thresholds stay fp32).  Not a
@@ -240,6 +251,8 @@ class ScanNetQueryDecoder(DerivedWeights):
             self.dinox_query_cross_attn_layers = nn.ModuleList(
                 _CrossAttentionHolder(d, num_heads, dropout, fix_attention) for _ in range(L))
         if add_positional_embedding:
+            if pos_type == "fourier":                          # checkpoint key `decoder.position_embedding.gauss_B` (utils.py:45-51)
+                self.position_embedding = _FourierPE(d, gauss_scale)
             self.ref_point_head = MLP(d, d, d, 2)
             bbox = MLP(d, d, 3, 3)
             nn.init.constant_(bbox.layers[-1].weight.data, 0)
@@ -419,7 +432,9 @@ class ScanNetQueryDecoder(DerivedWeights):
         x, sp_pos, q_in, q_pos = x.contiguous(), sp_pos.contiguous(), q_in.contiguous(), q_pos.contiguous()
         Q = q_in.shape[0]
         rng = torch.cat([lo.reshape(3), hi.reshape(3)]).float().contiguous()
-        memory_emb = ops.sine_pe(sp_pos, rng, dim_t, axis)
+        pe = (lambda xyz: ops.fourier_pe(xyz, rng, self.position_embedding.gauss_B, d)) if self.pos_type == "fourier" \
+            else (lambda xyz: ops.sine_pe(xyz, rng, dim_t, axis))
+        memory_emb = pe(sp_pos)
         if self.normalize_box_prediction:
             size_q = (1 / (hi - lo) * 0.5).float().reshape(3).contiguous()      # one row, broadcast over queries
         else:
@@ -468,7 +483,7 @@ class ScanNetQueryDecoder(DerivedWeights):
             if self.box_modulate_ca:
                 pq_emb = F.sine_pe_mod(ref_points, rng, dim_t, axis, outs2["hwl"], ref_sizes)
             else:
-                pq_emb = ops.sine_pe(ref_points, rng, dim_t, axis)
+                pq_emb = pe(ref_points)
             # ---- launch C: first layer of the positional-query MLP next to the sine projection of the cross-attention
             h, qs = F.linear_group([J(pq_emb, self.ref_point_head.layers[0], "relu"), J(pq_emb, self.ca_qpos_sine_proj[i])])
             query_pos = _lin(h, self.ref_point_head.layers[1])
@@ -531,6 +546,8 @@ class ScanNetQueryDecoder(DerivedWeights):
     @ops.bound_stream
     def forward(self, x, sp_pos=None, sp_pos_wo_elastic=None, queries=None, queries_pos=None, dinox_queries=None,
                 dinox_query_pos=None, scene_range=None):
+        if self.training and self.dropout != 0.0:
+            raise NotImplementedError("segdino3d_amd ScanNetQueryDecoder: training with dropout > 0 is not built (the shipped configs use 0.0)")
         prev = getattr(_F_TLS, "f", _EvalF)
         _F_TLS.f = _TrainF if (self.training and torch.is_grad_enabled()) else _EvalF
         try:

@@ -769,6 +769,19 @@ def sine_pe(xyz, rng, dim_t, axis, mod_num=None, mod_den=None):
     return out
 
 
+def fourier_pe(xyz, rng, gauss_b, d_pos):
+    """xyz [n,3]; rng [6] = (lo, hi); gauss_b [3, >= d_pos / 2] fp32 -> [n, d_pos] = [sin | cos] (utils.py:107-142)."""
+    lib = _lib.load()
+    px, ldx = _rows(xyz, "xyz")
+    pb, ldb = _rows(gauss_b, "gauss_b")
+    n = xyz.shape[0]
+    if gauss_b.shape[0] != 3 or gauss_b.shape[1] < d_pos // 2:
+        raise ValueError("fourier_pe: gauss_b must be [3, >= d_pos / 2]")
+    out = torch.empty(n, d_pos, dtype=torch.float32, device=xyz.device)
+    _lib.check(lib.sd3d_fourier_pe(px, ldx, n, _ptr(rng, torch.float32, "rng"), pb, ldb, d_pos, _ptr(out), d_pos, _stream()), "fourier_pe")
+    return out
+
+
 def attention(q, k, v, num_heads, scale, mask_bits=None, q2=None, k2=None):
     """q/k [L, H*32] (+ optional second source concatenated per head), v [Lk, H*32] -> [Lq, H*32]."""
     lib = _lib.load()

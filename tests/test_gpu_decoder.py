@@ -130,13 +130,14 @@ def _mask_agree(a, b, thr=0.0):
 # largest accepted fraction of query rows outside the tolerance at a layer after the first mask feedback, per fixture: the
 # measured value is 0 rows on every fixture (profiles/r02_parity_numbers.md); a fixture whose near-zero logit flips a mask bit
 # on some future kernel change would list its measured fraction here
-BAD_ROWS_MAX = {"decoder_s64_q64": 0.0, "decoder_s96_q16": 0.0, "decoder_s500_q32": 0.0, "decoder_v2_s48": 0.0}
+BAD_ROWS_MAX = {"decoder_s64_q64": 0.0, "decoder_s96_q16": 0.0, "decoder_s500_q32": 0.0, "decoder_v2_s48": 0.0, "decoder_fourier_s48": 0.0}
 
 
 @pytest.mark.parametrize("name,kw,sdkw", [
     ("decoder_s64_q64", {}, {}), ("decoder_s96_q16", {}, {}), ("decoder_s500_q32", {}, {}),
     ("decoder_v2_s48", dict(num_instance_classes=18, num_semantic_classes=20, in_channels=32, normalize_box_prediction=False),
-     dict(in_channels=32, n_inst=18, n_sem=20, size_embed_scale=0.05))])
+     dict(in_channels=32, n_inst=18, n_sem=20, size_embed_scale=0.05)),
+    ("decoder_fourier_s48", dict(pos_type="fourier", box_modulate_ca=False), dict(fourier=True))])
 def test_decoder_matches_reference_golden(name, kw, sdkw):
     d = dev()
     g = load(name)

@@ -18,7 +18,7 @@ def load(name):
     return {k: torch.from_numpy(z[k]) if z[k].dtype != object else z[k] for k in z.files}
 
 
-def decoder_state_dict(in_channels=96, n_inst=198, n_sem=200, L=6, d=256, hidden=1024, size_embed_scale=1.0):
+def decoder_state_dict(in_channels=96, n_inst=198, n_sem=200, L=6, d=256, hidden=1024, size_embed_scale=1.0, fourier=False):
     """Key names/shapes of the reference decoder state_dict; values by name."""
     shapes = {}
 
@@ -37,7 +37,10 @@ def decoder_state_dict(in_channels=96, n_inst=198, n_sem=200, L=6, d=256, hidden
     lin("ca_qpos_proj", d, d)
     for n in ("ref_point_head",):
         lin(n + ".layers.0", d, d); lin(n + ".layers.1", d, d)
-    lin("ref_anchor_head.layers.0", d, d); lin("ref_anchor_head.layers.1", 3, d)
+    if fourier:                                # pos_type="fourier": Gaussian projection buffer, no box-modulation head (:528)
+        shapes["position_embedding.gauss_B"] = (3, d // 2)
+    else:
+        lin("ref_anchor_head.layers.0", d, d); lin("ref_anchor_head.layers.1", 3, d)
     for i in range(L):
         lin(f"cross_attn_layers.{i}.out_proj", d, d)
         lin(f"self_attn_layers.{i}.out_proj", d, d)
@@ -74,6 +77,7 @@ def test_sine_pe():
     ("decoder_s96_q16", {}, {}),
     ("decoder_s500_q32", {}, {}),
     ("decoder_v2_s48", dict(in_channels=32, n_inst=18, n_sem=20, size_embed_scale=0.05), dict(normalize_box_prediction=False)),
+    ("decoder_fourier_s48", dict(fourier=True), dict(pos_type="fourier", box_modulate_ca=False)),
 ])
 def test_decoder_matches_reference(name, kw, cfgkw):
     g = load(name)
