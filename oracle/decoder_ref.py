@@ -140,6 +140,14 @@ def forward_head(w: W, queries, mask_feats, last: bool, thr: float):
     return cls, sem, logits, blocked
 
 
+def objectness_score(w: W, queries):
+    """`out_score(out_norm(queries))` (:548-550), present when the decoder was built with objectness_flag; else None."""
+    if (w.p + "out_score.0.weight") not in w.sd:
+        return None
+    nq = w.ln(queries, "out_norm")
+    return w.lin(torch.relu(w.lin(nq, "out_score.0")), "out_score.2")
+
+
 def dinox_blocked_mask(open_mask, pos_wo, q2d_pos, thr):
     """:721-726 - True = query may NOT look at 2D query m; last column (dummy key) always open."""
     dist = torch.cdist(pos_wo, q2d_pos, p=1)
@@ -174,8 +182,10 @@ def decoder_forward_plain(sd, cfg: DecoderCfg, x, q_in, prefix="decoder."):
     inst = torch.relu(w.ln(w.lin(x, "input_proj.0"), "input_proj.1"))
     mask_feats = w.lin(torch.relu(w.lin(x, "x_mask.0")), "x_mask.2")
     queries = w.lin(torch.relu(w.lin(q_in, "query_proj.0")), "query_proj.2")
+    if (prefix + "query.weight") in sd:                      # learned queries first (`_get_queries` :302-307)
+        queries = torch.cat([w("query.weight"), queries])
     cls, sem, logits, blocked = forward_head(w, queries, mask_feats, False, cfg.mask_attention_threshold)
-    aux = [dict(cls_preds=cls, masks=logits, centers=None, sizes=None)]
+    aux = [dict(cls_preds=cls, masks=logits, centers=None, sizes=None, scores=objectness_score(w, queries))]
     act = F.gelu if cfg.activation_fn == "gelu" else torch.relu
     for i in range(L):
         a = _packed_mha(w, f"cross_attn_layers.{i}.attn", queries, inst, H, blocked)
@@ -185,9 +195,9 @@ def decoder_forward_plain(sd, cfg: DecoderCfg, x, q_in, prefix="decoder."):
         h = w.lin(act(w.lin(queries, f"ffn_layers.{i}.net.0")), f"ffn_layers.{i}.net.3")
         queries = w.ln(h + queries, f"ffn_layers.{i}.norm")
         cls, sem, logits, blocked = forward_head(w, queries, mask_feats, i == L - 1, cfg.mask_attention_threshold)
-        aux.append(dict(cls_preds=cls, masks=logits, centers=None, sizes=None))
+        aux.append(dict(cls_preds=cls, masks=logits, centers=None, sizes=None, scores=objectness_score(w, queries)))
     final = aux[-1]
-    return dict(cls_preds=final["cls_preds"], sem_preds=sem, masks=final["masks"], centers=None, sizes=None,
+    return dict(cls_preds=final["cls_preds"], sem_preds=sem, masks=final["masks"], centers=None, sizes=None, scores=final["scores"],
                 hidden_states=queries, aux=aux[:-1], attn_blocked=blocked)
 
 

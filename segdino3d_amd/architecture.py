@@ -190,6 +190,8 @@ class Baseline3D(nn.Module):
         if Q * C < k:
             raise ValueError(f"topk_insts={k} needs at least {k} (query, class) pairs, got {Q * C}")
         flat, _ = ops.class_scores(cls, C)
+        if out.get("scores") is not None and out["scores"][0] is not None:        # objectness head: scores *= out['scores'][0] (:428-429)
+            flat = (flat.view(Q, C) * out["scores"][0].reshape(Q, 1)).reshape(-1).contiguous()
         order0 = _sorted_desc(flat)[:k].contiguous()                    # top-k (query, class) pairs (:434)
         top_scores = flat[order0.long()]
         labels, qidx, scores = ops.mask_scores(logits, S, order0, top_scores, C, bool(_cfg_get(cfg, "obj_normalization", None)))

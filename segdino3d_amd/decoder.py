@@ -191,8 +191,12 @@ class ScanNetQueryDecoder(DerivedWeights):
             unsupported.append("2D-query attention / box heads need add_positional_embedding=True")
         if not iter_pred or not attn_mask:
             unsupported.append("iter_pred=True and attn_mask=True are required")
-        if num_instance_queries + num_semantic_queries != 0 or objectness_flag:
-            unsupported.append("learned query embeddings / objectness head are not built")
+        if num_instance_queries != 0:
+            # the reference drops `query_proj` then (`:235-238`) while Baseline3D always passes superpoint queries (`:339-345`
+            # of baseline3d.py call `_get_queries` -> `self.query_proj`): not runnable there either
+            unsupported.append("num_instance_queries > 0 (the reference's own forward cannot run it behind Baseline3D)")
+        if num_semantic_queries != 0 and add_positional_embedding:
+            unsupported.append("learned queries with add_positional_embedding (the reference has no positions for them, :631-640)")
         if d_model != num_heads * 32:
             unsupported.append("attention heads must be 32 channels wide (d_model == 32 * num_heads)")
         if add_dinox_query_ca and not add_dinox_query_ca_mask:
@@ -220,10 +224,14 @@ class ScanNetQueryDecoder(DerivedWeights):
         self.box_modulate_ca = box_modulate_ca
         self.normalize_box_prediction = normalize_box_prediction
         self.temperature = float(temperature)
+        self.num_queries = num_instance_queries + num_semantic_queries
+        if self.num_queries > 0:
+            self.query = nn.Embedding(self.num_queries, d_model)       # learned queries, prepended to the projected ones (:302-307)
+        if objectness_flag:
+            self.out_score = nn.Sequential(nn.Linear(d_model, d_model), nn.ReLU(), nn.Linear(d_model, 1))
         self.pos_type = pos_type
         # nn.Dropout is the identity in evaluation; the training path has no dropout kernels and refuses p > 0 when it runs
         self.dropout = float(dropout)
-        self.num_queries = 0
         # "fp32" (default, BASELINE config #2) or "bf16" (config #3: projections and both attention contractions on the bf16
         # MFMA with fp32 accumulation; LayerNorm, softmax, positional encodings, mask logits and thresholds stay fp32).  Not a
         # key of the reference's config surface - there bf16 comes from autocast(cfg.amp), train_engine_3d.py:88-100.
@@ -364,7 +372,8 @@ class ScanNetQueryDecoder(DerivedWeights):
 
     # ---- prediction head (:532-577) ----------------------------------------------------------------
     def _head(self, queries, mask_feats, last_flag, defer_cls=False):
-        """-> (class logits | the normalised queries when `defer_cls`, semantic logits | None, mask logits, mask bits).  The class
+        """-> (class logits | the normalised queries when `defer_cls`, semantic logits | None, mask logits, mask bits,
+        objectness score | None).  The class
         MLP feeds nothing inside the decoder, so the positional variant runs it inside the NEXT layer's first launches."""
         S = mask_feats.shape[0]
         nq = _F().layernorm(queries, self.out_norm.weight, self.out_norm.bias)
@@ -377,7 +386,8 @@ class ScanNetQueryDecoder(DerivedWeights):
                 sem = _lin(_lin(nq, self.out_sem[0], act="relu"), self.out_sem[2])
         logits = _F().mask_logits(nq, mask_feats)
         bits = ops.mask_bits(logits.detach(), S, self.mask_attention_threshold)
-        return cls, sem, logits, bits
+        score = _lin(_lin(nq, self.out_score[0], act="relu"), self.out_score[2]) if self.objectness_flag else None   # [Q, 1] (:548-550)
+        return cls, sem, logits, bits, score
 
     def select_scores(self, x):
         """max_c softmax(out_cls(out_norm(query_proj(x))))[:-1] per superpoint (baseline3d.py:233-238)."""
@@ -395,8 +405,10 @@ class ScanNetQueryDecoder(DerivedWeights):
         inst = F.layernorm(_lin(x, self.input_proj[0]), self.input_proj[1].weight, self.input_proj[1].bias, act="relu")
         mask_feats = _lin(_lin(x, self.x_mask[0], act="relu"), self.x_mask[2])
         queries = _lin(_lin(q_in, self.query_proj[0], act="relu"), self.query_proj[2])
-        cls, sem, logits, bits = self._head(queries, mask_feats, False)
-        aux = [dict(cls_preds=cls, sem_preds=None, masks=logits, centers=None, sizes=None)]
+        if self.num_queries > 0:                               # learned queries first, then the projected ones (`_get_queries` :302-307)
+            queries = torch.cat([self.query.weight if self.training else self.query.weight.detach(), queries]).contiguous()
+        cls, sem, logits, bits, score = self._head(queries, mask_feats, False)
+        aux = [dict(cls_preds=cls, sem_preds=None, masks=logits, centers=None, sizes=None, scores=score)]
         kv_all = F.linear(inst, pk["ca_kv_all_w"], pk["ca_kv_all_b"])          # [S, 2*L*d]: k_0..k_{L-1} | v_0..v_{L-1}
         scale = (d // H) ** -0.5
         for i in range(L):
@@ -413,8 +425,8 @@ class ScanNetQueryDecoder(DerivedWeights):
             hdn = _lin(queries, ffn.net[0], act=("relu" if self.activation_fn == "relu" else "gelu"))
             hdn = _lin(hdn, ffn.net[3], res=queries)
             queries = F.layernorm(hdn, ffn.norm.weight, ffn.norm.bias)
-            cls, sem, logits, bits = self._head(queries, mask_feats, i == L - 1)
-            aux.append(dict(cls_preds=cls, sem_preds=sem, masks=logits, centers=None, sizes=None))
+            cls, sem, logits, bits, score = self._head(queries, mask_feats, i == L - 1)
+            aux.append(dict(cls_preds=cls, sem_preds=sem, masks=logits, centers=None, sizes=None, scores=score))
         final = aux.pop()
         final["hidden_states"] = queries
         final["attn_mask_bits"] = bits
@@ -446,8 +458,8 @@ class ScanNetQueryDecoder(DerivedWeights):
         # a prediction head rides with the next layer's first projections, the two box MLPs run side by side, projections that
         # share an input are batched.  Every Linear is still the same fp32 product; only the dispatch count changes.
         J = lambda x, layer, act=None, res=None, x2=None: (x, layer.weight, layer.bias, act, res, x2)  # noqa: E731
-        nq_pending, sem, logits, bits = self._head(queries, mask_feats, False, defer_cls=True)
-        aux = [dict(cls_preds=None, sem_preds=None, masks=logits, centers=None, sizes=None)]
+        nq_pending, sem, logits, bits, score = self._head(queries, mask_feats, False, defer_cls=True)
+        aux = [dict(cls_preds=None, sem_preds=None, masks=logits, centers=None, sizes=None, scores=score)]
 
         # layer-invariant key side, hoisted out of the loop (the reference recomputes it per layer, :669-671)
         kv_all = F.linear(inst, pk["kv_w"], pk["kv_b"])                  # [S, 2*L*d]: kc_0..kc_{L-1} | v_0..v_{L-1}
@@ -534,8 +546,8 @@ class ScanNetQueryDecoder(DerivedWeights):
             if self.add_box_size_pred:
                 ref_sizes = size_q = size.detach()             # `:753`
             last = i == L - 1
-            nq_pending, sem, logits, bits = self._head(queries, mask_feats, last, defer_cls=True)
-            aux.append(dict(cls_preds=None, sem_preds=sem, masks=logits, centers=center, sizes=size_metric))
+            nq_pending, sem, logits, bits, score = self._head(queries, mask_feats, last, defer_cls=True)
+            aux.append(dict(cls_preds=None, sem_preds=sem, masks=logits, centers=center, sizes=size_metric, scores=score))
         aux[-1]["cls_preds"] = _lin(_lin(nq_pending, self.out_cls[0], act="relu"), self.out_cls[2])
         final = aux.pop()
         final["hidden_states"] = queries
@@ -574,7 +586,7 @@ class ScanNetQueryDecoder(DerivedWeights):
             auxes.append(a)
         B = len(finals)
         result = dict(cls_preds=[f["cls_preds"] for f in finals], sem_preds=[f["sem_preds"] for f in finals],
-                      masks=[f["masks"] for f in finals], scores=[None] * B, centers=[f["centers"] for f in finals],
+                      masks=[f["masks"] for f in finals], scores=[f.get("scores") for f in finals], centers=[f["centers"] for f in finals],
                       sizes=[f["sizes"] for f in finals])
         if getattr(self, "return_hidden_states", True):
             result["hidden_states"] = [f["hidden_states"] for f in finals]
@@ -582,7 +594,7 @@ class ScanNetQueryDecoder(DerivedWeights):
             result["aux_outputs"] = [
                 dict(cls_preds=[a[li]["cls_preds"] for a in auxes],
                      sem_preds=None if auxes[0][li]["sem_preds"] is None else [a[li]["sem_preds"] for a in auxes],
-                     masks=[a[li]["masks"] for a in auxes], scores=[None] * B,
+                     masks=[a[li]["masks"] for a in auxes], scores=[a[li].get("scores") for a in auxes],
                      centers=[a[li]["centers"] for a in auxes], sizes=[a[li]["sizes"] for a in auxes])
                 for li in range(len(auxes[0]))]
         return result

@@ -285,6 +285,35 @@ def test_plain_decoder_matches_reference_golden():
         rows_ok(out[k][0], g[k], k, False)
 
 
+def test_plain_decoder_with_learned_queries_and_objectness():
+    """Decoder options `num_semantic_queries = 7` (learned query embeddings) and `objectness_flag=True` (`out_score` head) against
+    the REFERENCE decoder's outputs (tests/golden/make_golden_plain_obj.py)."""
+    from segdino3d_amd.decoder import ScanNetQueryDecoder
+    from test_oracle_golden import plain_decoder_state_dict
+    d = dev()
+    g = load("decoder_plain_obj_s40")
+    kw = {k: v for k, v in DEC_KW.items() if k not in ("add_box_size_pred", "add_positional_embedding", "pos_type",
+                                                         "temperature", "box_modulate_ca", "normalize_box_prediction")}
+    kw.update(add_dinox_query_ca=False, num_semantic_queries=7, objectness_flag=True)
+    dec = ScanNetQueryDecoder(**kw).eval()
+    sd = plain_decoder_state_dict(n_learned=7, objectness=True)
+    dec.load_state_dict({k[len("decoder."):]: v for k, v in sd.items()})
+    dec.to(d)
+    out = dec([g["x"].to(d)], None, None, [g["x"].to(d)], None, None, None, None)
+    assert out["masks"][0].shape == (47, 40) and out["scores"][0].shape == (47, 1)
+
+    def rows_ok(got, ref, what):
+        err = (got.cpu() - ref).abs()
+        bad = (err > 3e-4 + 3e-4 * ref.abs()).any(dim=1).float().mean().item()
+        print(f"learned queries + objectness, {what}: {bad:.1%} rows outside 3e-4, max err {err.max().item():.1e}")
+        assert bad == 0.0, f"{what}: {bad:.1%} rows outside tolerance (max err {err.max().item():.3e})"
+    for li in (0, 2, 4):
+        for k, gk in (("cls_preds", "cls"), ("masks", "masks"), ("scores", "scores")):
+            rows_ok(out["aux_outputs"][li][k][0], g[f"aux{li}_{gk}"], f"aux{li} {gk}")
+    for k in ("cls_preds", "sem_preds", "masks", "scores", "hidden_states"):
+        rows_ok(out[k][0], g[k], k)
+
+
 def test_baseline_prototype_end_to_end_matches_oracle():
     """Baseline_ScanNet200 prototype (rgb-only Res16UNet34C + non-positional decoder) through build_architecture."""
     import segdino3d_amd as seg

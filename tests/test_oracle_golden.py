@@ -97,6 +97,22 @@ def test_decoder_matches_reference(name, kw, cfgkw):
         torch.testing.assert_close(out[k], g[k], **tol)
 
 
+def test_plain_decoder_with_learned_queries_and_objectness_matches_reference():
+    """`num_semantic_queries = 7` learned queries prepended to the projected ones + the `out_score` head (objectness_flag)."""
+    g = load("decoder_plain_obj_s40")
+    sd = plain_decoder_state_dict(n_learned=7, objectness=True)
+    cfg = D.DecoderCfg(add_positional_embedding=False, add_dinox_query_ca=False, add_box_size_pred=False,
+                       box_modulate_ca=False, normalize_box_prediction=False)
+    out = D.decoder_forward(sd, cfg, g["x"], None, None, g["x"], None, None, None, None, None)
+    tol = dict(rtol=2e-4, atol=2e-4)
+    assert out["masks"].shape == (47, 40) and out["scores"].shape == (47, 1)
+    for li in (0, 2, 4):
+        for k, gk in (("cls_preds", "cls"), ("masks", "masks"), ("scores", "scores")):
+            torch.testing.assert_close(out["aux"][li][k], g[f"aux{li}_{gk}"], **tol)
+    for k in ("cls_preds", "sem_preds", "masks", "scores", "hidden_states"):
+        torch.testing.assert_close(out[k], g[k], **tol)
+
+
 def test_matrix_nms():
     g = load("matrix_nms")
     s, l, m, keep, rec = P.matrix_nms(g["masks"], g["labels"], g["scores"], kernel="linear")
@@ -133,7 +149,7 @@ def test_architecture_eval_path(name, query_num, box):
     assert torch.equal(torch.sort(res["sort_and_mask"][0])[0], torch.sort(g["topk_idx"])[0])
 
 
-def plain_decoder_state_dict(in_channels=96, n_inst=198, n_sem=200, L=6, d=256, hidden=1024):
+def plain_decoder_state_dict(in_channels=96, n_inst=198, n_sem=200, L=6, d=256, hidden=1024, n_learned=0, objectness=False):
     """state_dict of the non-positional decoder variant (Baseline_ScanNet200 prototype)."""
     shapes = {}
 
@@ -149,6 +165,10 @@ def plain_decoder_state_dict(in_channels=96, n_inst=198, n_sem=200, L=6, d=256, 
     lin("query_proj.0", d, in_channels); lin("query_proj.2", d, d)
     lin("x_mask.0", d, in_channels); lin("x_mask.2", d, d)
     ln("out_norm"); lin("out_cls.0", d, d); lin("out_cls.2", n_inst + 1, d); lin("out_sem", n_sem + 1, d)
+    if n_learned:
+        shapes["query.weight"] = (n_learned, d)          # nn.Embedding of the learned queries (:229-231)
+    if objectness:
+        lin("out_score.0", d, d); lin("out_score.2", 1, d)
     for i in range(L):
         for n in ("cross_attn_layers", "self_attn_layers"):
             shapes[f"{n}.{i}.attn.in_proj_weight"] = (3 * d, d)
