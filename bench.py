@@ -332,7 +332,9 @@ def main():
     if rank == 0:
         bf16_dec = getattr(model.decoder, "compute_dtype", "fp32") == "bf16"      # SD3D_DECODER_DTYPE=bf16: BASELINE configs[2]
         out = {
-            "metric": "scenes/sec forward (ScanNet200 ~150k pts, 200 queries)", "value": round(value, 3), "unit": "scenes/s",
+            "metric": "scenes/sec forward (ScanNet200 ~150k pts, " + ("200 queries" if args.query_num == 200 else
+                                                                       ("one query per superpoint" if args.query_num < 0 else f"{args.query_num} queries")) + ")",
+            "value": round(value, 3), "unit": "scenes/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * dt / args.steps, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32 backbone + bf16 decoder contractions" if bf16_dec else "f32", "data": "synthetic",
             "single_scene": {"scenes_per_s": round(1e3 / latency_ms, 2), "latency_ms": round(latency_ms, 3),
