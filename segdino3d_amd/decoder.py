@@ -563,7 +563,7 @@ class ScanNetQueryDecoder(DerivedWeights):
         prev = getattr(_F_TLS, "f", _EvalF)
         _F_TLS.f = _TrainF if (self.training and torch.is_grad_enabled()) else _EvalF
         try:
-            with ops.bf16_decoder_scope(self.compute_dtype == "bf16"):      # training: bf16 forward products, fp32 backward
+            with ops.bf16_decoder_scope(self.compute_dtype == "bf16"):      # training: bf16 forward and backward products of the projections
                 return self._forward(x, sp_pos, sp_pos_wo_elastic, queries, queries_pos, dinox_queries, dinox_query_pos, scene_range)
         finally:
             _F_TLS.f = prev

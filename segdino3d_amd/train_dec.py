@@ -21,6 +21,10 @@ from . import _lib, ops, train_ops
 
 _WS = ops._PerThread()
 _IDENTITY = {}
+# mixed-precision training (decoder compute_dtype "bf16"): True = bf16 operands in the Linear backward products as well
+# (what autocast does); False = fp32 backward (SD3D_BF16_BACKWARD=0)
+import os as _os
+BF16_BACKWARD = _os.environ.get("SD3D_BF16_BACKWARD", "1") != "0"
 
 
 def _identity_pairs(n_rows: int, device):
@@ -68,8 +72,8 @@ class _Linear(torch.autograd.Function):
         xd, wd = x.detach(), w.detach()
         bd = None if b is None else b.detach()
         kw = dict(x2=None if x2 is None else x2.detach(), shift=bd, res=None if res is None else res.detach())
-        # mixed precision (decoder compute_dtype "bf16"): the forward product may run with bf16 operands, every backward
-        # product stays fp32; w is a live parameter here, so no rounded copy is cached across steps
+        # mixed precision (decoder compute_dtype "bf16"): the forward product may run with bf16 operands (the backward
+        # products follow it, see ctx.bf16_bwd); w is a live parameter here, so no rounded copy is cached across steps
         exact = force_exact or not ops.bf16_decoder_active()
         ws = None if exact or xd.shape[0] < ops.BF16_MIN_ROWS or wd.shape[1] % 32 else ops.split_weights(wd.unsqueeze(0), 1)
         y = ops.gather_gemm(xd, wd, act=act, exact=True, wt_split=ws, **kw)
@@ -78,6 +82,9 @@ class _Linear(torch.autograd.Function):
             ref = ops.gather_gemm(xd, wd, act=None, exact=True, wt_split=ws, **kw)
         ctx.save_for_backward(x, w, ref if act is not None else None, x2)
         ctx.act, ctx.has_b, ctx.has_res = act, b is not None, res is not None
+        # BASELINE configs[4] (autocast(bf16) around the decoder, train_engine_3d.py:88-100): the two backward products of a
+        # Linear whose forward ran on bf16 operands run on bf16 operands too (fp32 accumulation), as autograd under autocast does
+        ctx.bf16_bwd = ws is not None and BF16_BACKWARD
         return y
 
     @staticmethod
@@ -93,7 +100,10 @@ class _Linear(torch.autograd.Function):
             else:
                 wt = torch.zeros(cin, c_pad, dtype=torch.float32, device=w.device)
                 wt[:, :cout] = w.detach().t()
-            dxa = ops.gather_gemm(g, wt, exact=True)                            # [M, cin]
+            if ctx.bf16_bwd and c_pad % 32 == 0:
+                dxa = ops.gather_gemm(g, wt, wt_split=ops.split_weights(wt.unsqueeze(0), 1))     # bf16 operands, fp32 accumulation
+            else:
+                dxa = ops.gather_gemm(g, wt, exact=True)                        # [M, cin]
             if x2 is None:
                 dx = dxa
             else:
@@ -101,6 +111,18 @@ class _Linear(torch.autograd.Function):
                 dx, dx2 = dxa[:, :c0], dxa[:, c0:]
         if ctx.needs_input_grad[1]:
             xin = x.detach() if x2 is None else torch.cat([x.detach(), x2.detach()], dim=1)
+            if ctx.bf16_bwd:
+                # dW = g^T x as a plain GEMM over the (padded) row index: [c_pad, Mp] x [cin, Mp]^T on the bf16 matrix cores
+                M = g.shape[0]
+                Mp = _round(M, 32)
+                gT = torch.zeros(c_pad, Mp, dtype=torch.float32, device=g.device)
+                gT[:, :M] = g.t()
+                xT = torch.zeros(xin.shape[1], Mp, dtype=torch.float32, device=g.device)
+                xT[:, :M] = xin.t()
+                dwp = ops.gather_gemm(gT, xT, wt_split=ops.split_weights(xT.unsqueeze(0), 1))    # [c_pad, cin]
+                dw = dwp[:cout, :cin]
+                xin = None
+        if ctx.needs_input_grad[1] and xin is not None:
             if xin.shape[1] % 4:
                 xin = torch.nn.functional.pad(xin, (0, 4 - xin.shape[1] % 4))
             dwp = train_ops.pair_wgrad(g, xin.contiguous(), _identity_pairs(g.shape[0], g.device))   # [1, c_pad, cin(+pad)]

@@ -3,7 +3,10 @@
 autograd, for the inputs and deterministic weights of the existing forward fixture decoder_s96_q16.
 Scalar objective: sum over the final and all auxiliary prediction sets of <output, R> with R = det_randn("gradw.<key><layer>").
 Stored: the objective, d/d(superpoint features), d/d(query features) in full, and for every parameter the gradient's L2
-norm plus its first 24 entries (the full set is ~8 M floats).  Runs in the build container only."""
+norm plus its first 24 entries (the full set is ~8 M floats).  Runs in the build container only.
+`--amp` writes decoder_grad_amp_s96_q16.npz instead: the same run under torch.autocast("cpu", bfloat16) around the decoder
+call (train_engine_3d.py:88-100, BASELINE configs[4]) - the yardstick for the bf16 training path's gradients."""
+import contextlib
 import os
 import sys
 
@@ -43,19 +46,28 @@ def main():
     q = x.detach()[ids].clone().requires_grad_(True)
     dec.return_hidden_states = False
     dec.return_aux_outputs = True
-    out = dec([x], [pos], [pos_wo], [q], [pos[ids]], [q2d_feat], [q2d_pos.clone()], [(lo, hi)])
+    amp = "--amp" in sys.argv
+    with (torch.autocast("cpu", dtype=torch.bfloat16) if amp else contextlib.nullcontext()):
+        out = dec([x], [pos], [pos_wo], [q], [pos[ids]], [q2d_feat], [q2d_pos.clone()], [(lo, hi)])
+
+    def as_f32(o):
+        return {k: ([as_f32(a) for a in v] if k == "aux_outputs" else
+                    v if not isinstance(v, (list, tuple)) else [t.float() if torch.is_tensor(t) else t for t in v]) for k, v in o.items()}
+
+    out = as_f32(out)
     total = objective(out)
     total.backward()
-    blob = dict(objective=total.detach().numpy(), dx=x.grad.numpy(), dq=q.grad.numpy(), masks=out["masks"][0].detach().numpy())
+    blob = dict(objective=total.detach().float().numpy(), dx=x.grad.float().numpy(), dq=q.grad.float().numpy(),
+                masks=out["masks"][0].detach().float().numpy())
     n_used = 0
     for pname, p in dec.named_parameters():
         if p.grad is None:
             continue
         n_used += 1
-        g = p.grad.reshape(-1)
+        g = p.grad.reshape(-1).float()
         blob["norm/" + pname] = np.array(float(g.norm()))
         blob["head/" + pname] = g[:24].numpy().copy()
-    path = os.path.join(HERE, "decoder_grad_s96_q16.npz")
+    path = os.path.join(HERE, "decoder_grad_amp_s96_q16.npz" if amp else "decoder_grad_s96_q16.npz")
     np.savez_compressed(path, **blob)
     print("objective", float(total), "parameters with gradient", n_used, "->", path, os.path.getsize(path))
 
