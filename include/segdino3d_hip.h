@@ -348,11 +348,15 @@ int sd3d_semantic_loss(const float* sem, int ld, int Q, int n_rows, int n_logits
  * transposed weights; the weight gradient is
  *     dw[k][co][ci] (+)= sum over pairs p of offset k of dy[out_idx[p]][co] * x[in_idx[p]][ci]
  * with in_idx / tile_k from sd3d_pair_lists and out_idx from sd3d_pair_out_rows (out_idx[pos[k][r]] = r, -1 on
- * padding).  dw is [K, Cout, Cin] like the forward weights; exact fp32 MFMA, fixed summation order. */
+ * padding).  dw is [K, Cout, Cin] like the forward weights; exact fp32 MFMA, fixed summation order.
+ * flags: bit 0 = accumulate into dw, bit 1 = round both operands to bf16 (nearest even) before multiplying - the numbers
+ * of a bf16-operand product with fp32 accumulation, for the bf16 training mode of the decoder. */
+#define SD3D_WGRAD_ACCUMULATE 1
+#define SD3D_WGRAD_BF16_OPERANDS 2
 int sd3d_pair_out_rows(const int32_t* pos, int K, int64_t M, int64_t p_cap, int32_t* out_idx, void* stream);
 size_t sd3d_pair_wgrad_ws_bytes(int K, int Cin, int Cout);
 int sd3d_pair_wgrad(const float* dy, int ld_dy, const float* x, int ld_x, const int32_t* in_idx, const int32_t* out_idx,
-                    const int32_t* tile_k, int64_t p_cap, int K, int Cin, int Cout, float* dw, int accumulate, void* ws, size_t ws_bytes,
+                    const int32_t* tile_k, int64_t p_cap, int K, int Cin, int Cout, float* dw, int flags, void* ws, size_t ws_bytes,
                     void* stream);
 
 /* ---------------------------------------------------------------------------------------------

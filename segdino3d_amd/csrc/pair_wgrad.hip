@@ -22,7 +22,14 @@ struct WGParams {
     const int32_t* in_idx; const int32_t* out_idx; const int32_t* tile_k; int n_tiles;
     int Cin, Cout;
     float* wpart; int32_t* slot_k; int n_slots;
+    int bf16;                        // round the staged operands to bf16 (nearest even): bf16-operand numerics on the fp32 matrix pipe
 };
+
+__device__ __forceinline__ float round_to_bf16(float v) {
+    uint32_t u = __float_as_uint(v);
+    u += 0x7FFFu + ((u >> 16) & 1u);
+    return __uint_as_float(u & 0xFFFF0000u);
+}
 
 __global__ __launch_bounds__(256) void pair_out_rows_kernel(const int32_t* __restrict__ pos, int K, int64_t M, int32_t* __restrict__ out_idx) {
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
@@ -93,6 +100,16 @@ __global__ __launch_bounds__(256) void pair_wgrad_kernel(const WGParams p) {
         }
     };
     auto stage = [&]() {
+        if (p.bf16) {                                          // uniform; here (not in fetch) so the loads stay in flight over the MFMA phase
+#pragma unroll
+            for (int u = 0; u < NA; ++u)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) ra[u][e] = round_to_bf16(ra[u][e]);
+#pragma unroll
+            for (int u = 0; u < NB; ++u)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) rb[u][e] = round_to_bf16(rb[u][e]);
+        }
 #pragma unroll
         for (int u = 0; u < NA; ++u) {
             const int f = u * 256 + tid;
@@ -215,7 +232,7 @@ size_t sd3d_pair_wgrad_ws_bytes(int K, int Cin, int Cout) {
 }
 
 int sd3d_pair_wgrad(const float* dy, int ld_dy, const float* x, int ld_x, const int32_t* in_idx, const int32_t* out_idx,
-                    const int32_t* tile_k, int64_t p_cap, int K, int Cin, int Cout, float* dw, int accumulate, void* ws, size_t ws_bytes,
+                    const int32_t* tile_k, int64_t p_cap, int K, int Cin, int Cout, float* dw, int flags, void* ws, size_t ws_bytes,
                     void* stream) {
     if (K <= 0 || Cin <= 0 || Cout <= 0) return SD3D_OK;
     if ((Cin & 3) || (Cout & 3) || (ld_dy & 3) || (ld_x & 3)) return sd3d_set_error(SD3D_ERR_ARG, "pair_wgrad: channel counts and row strides must be multiples of 4");
@@ -226,6 +243,8 @@ int sd3d_pair_wgrad(const float* dy, int ld_dy, const float* x, int ld_x, const 
     p.dy = dy; p.ld_dy = ld_dy; p.x = x; p.ld_x = ld_x; p.in_idx = in_idx; p.out_idx = out_idx; p.tile_k = tile_k;
     p.n_tiles = (int)(p_cap / PT); p.Cin = Cin; p.Cout = Cout;
     p.n_slots = ranges + K;
+    p.bf16 = (flags & SD3D_WGRAD_BF16_OPERANDS) ? 1 : 0;
+    const int accumulate = flags & SD3D_WGRAD_ACCUMULATE;
     p.slot_k = (int32_t*)ws;
     p.wpart = (float*)((char*)ws + align_up((size_t)p.n_slots * sizeof(int32_t), 256));
     if (hipMemsetAsync(p.slot_k, 0xFF, (size_t)p.n_slots * sizeof(int32_t), ST) != hipSuccess) return sd3d_set_error(SD3D_ERR_LAUNCH, "pair_wgrad: memset failed");

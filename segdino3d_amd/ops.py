@@ -404,6 +404,8 @@ def bf16_decoder_active() -> bool:
 def split_weights(wt, terms):
     """fp32 [K, Cout, Cin] -> bf16 [terms_per_operand, K, Cout, Cin] with wt = sum of the terms (to ~2^-17 / 2^-25)."""
     ns = {1: 1, 3: 2, 6: 3}[terms]
+    if ns == 1:                                          # plain rounding: one conversion kernel (training re-rounds live weights per step)
+        return wt.detach().to(torch.bfloat16).unsqueeze(0).contiguous()
     r = wt.detach().to(torch.float32).clone()
     parts = []
     for _ in range(ns):

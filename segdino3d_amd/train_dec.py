@@ -21,10 +21,13 @@ from . import _lib, ops, train_ops
 
 _WS = ops._PerThread()
 _IDENTITY = {}
-# mixed-precision training (decoder compute_dtype "bf16"): True = bf16 operands in the Linear backward products as well
-# (what autocast does); False = fp32 backward (SD3D_BF16_BACKWARD=0)
+# mixed-precision training (decoder compute_dtype "bf16"): True (SD3D_BF16_BACKWARD=1) = bf16 operands in the Linear backward
+# products as well - what autograd does under autocast; False (default) = fp32 backward products.  Measured at the training
+# shapes (tools/linear_dtype_quick.py, 2441 query rows): these products are launch-bound, bf16 operands buy no time (dx 16 vs
+# 14 us; the weight gradient runs on the fp32 kernel with operands rounded while they are staged), so the equally fast and more
+# precise fp32 backward is the default and the autocast-faithful one is the opt-in.
 import os as _os
-BF16_BACKWARD = _os.environ.get("SD3D_BF16_BACKWARD", "1") != "0"
+BF16_BACKWARD = _os.environ.get("SD3D_BF16_BACKWARD", "0") == "1"
 
 
 def _identity_pairs(n_rows: int, device):
@@ -111,21 +114,11 @@ class _Linear(torch.autograd.Function):
                 dx, dx2 = dxa[:, :c0], dxa[:, c0:]
         if ctx.needs_input_grad[1]:
             xin = x.detach() if x2 is None else torch.cat([x.detach(), x2.detach()], dim=1)
-            if ctx.bf16_bwd:
-                # dW = g^T x as a plain GEMM over the (padded) row index: [c_pad, Mp] x [cin, Mp]^T on the bf16 matrix cores
-                M = g.shape[0]
-                Mp = _round(M, 32)
-                gT = torch.zeros(c_pad, Mp, dtype=torch.float32, device=g.device)
-                gT[:, :M] = g.t()
-                xT = torch.zeros(xin.shape[1], Mp, dtype=torch.float32, device=g.device)
-                xT[:, :M] = xin.t()
-                dwp = ops.gather_gemm(gT, xT, wt_split=ops.split_weights(xT.unsqueeze(0), 1))    # [c_pad, cin]
-                dw = dwp[:cout, :cin]
-                xin = None
-        if ctx.needs_input_grad[1] and xin is not None:
             if xin.shape[1] % 4:
                 xin = torch.nn.functional.pad(xin, (0, 4 - xin.shape[1] % 4))
-            dwp = train_ops.pair_wgrad(g, xin.contiguous(), _identity_pairs(g.shape[0], g.device))   # [1, c_pad, cin(+pad)]
+            # bf16 mode: the same kernel with both operands rounded to bf16 as they are staged (products of bf16 values are exact in
+            # fp32, so this IS the bf16-operand / fp32-accumulate product, at the fp32 kernel's speed)
+            dwp = train_ops.pair_wgrad(g, xin.contiguous(), _identity_pairs(g.shape[0], g.device), bf16_operands=ctx.bf16_bwd)   # [1, c_pad, cin(+pad)]
             dw = dwp[0, :cout, :cin]
         if ctx.has_b and ctx.needs_input_grad[2]:
             db = col_sums(g)[:cout]

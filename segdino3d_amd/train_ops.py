@@ -33,8 +33,10 @@ def pair_out_rows(pairs: "ops.PairLists") -> torch.Tensor:
     return pairs.out_idx
 
 
-def pair_wgrad(dy: torch.Tensor, x: torch.Tensor, pairs: "ops.PairLists", dw: torch.Tensor = None, accumulate: bool = False) -> torch.Tensor:
-    """dw[k] (+)= dy[out rows of offset k]^T @ x[in rows of offset k]; dy [M, Cout], x [V_in, Cin] -> dw [K, Cout, Cin]."""
+def pair_wgrad(dy: torch.Tensor, x: torch.Tensor, pairs: "ops.PairLists", dw: torch.Tensor = None, accumulate: bool = False,
+               bf16_operands: bool = False) -> torch.Tensor:
+    """dw[k] (+)= dy[out rows of offset k]^T @ x[in rows of offset k]; dy [M, Cout], x [V_in, Cin] -> dw [K, Cout, Cin].
+    bf16_operands: both operands rounded to bf16 before the (fp32-accumulated) product."""
     lib = _lib.load()
     pdy, ldy = ops._rows(dy, "dy")
     px, ldx = ops._rows(x, "x")
@@ -49,7 +51,7 @@ def pair_wgrad(dy: torch.Tensor, x: torch.Tensor, pairs: "ops.PairLists", dw: to
     nb = lib.sd3d_pair_wgrad_ws_bytes(K, Cin, Cout)
     ws = _WS.get(nb, dy.device)
     _lib.check(lib.sd3d_pair_wgrad(pdy, ldy, px, ldx, pairs.in_idx.data_ptr(), pair_out_rows(pairs).data_ptr(), pairs.tile_k.data_ptr(),
-                                   pairs.p_cap, K, Cin, Cout, dw.data_ptr(), 1 if accumulate else 0, ws.data_ptr(), ws.numel(),
+                                   pairs.p_cap, K, Cin, Cout, dw.data_ptr(), (1 if accumulate else 0) | (2 if bf16_operands else 0), ws.data_ptr(), ws.numel(),
                                    ops._stream()), "pair_wgrad")
     return dw
 
