@@ -32,6 +32,11 @@ int sd3d_abi_version(void);
 const char* sd3d_last_error(void);
 /* Host-only self test of the Z-order key codec (runs without a GPU); returns 0 when consistent. */
 int sd3d_selftest_host(void);
+/* Scheduling hint (process-wide, default 1): how many independent scenes the caller keeps in flight on this GPU, each on its
+ * own stream (dist_eval.PipelinedRunner).  With more than one, launchers prefer kernel variants with a small LDS footprint
+ * that co-schedule with the other scenes' kernels over the ones that are fastest alone on an idle GPU (sd3d_pair_conv: the
+ * weight-stationary pass 1 for >= 96 output columns).  Results are bit-identical either way.  Returns the previous value. */
+int sd3d_set_scenes_in_flight(int n);
 
 /* ---------------------------------------------------------------------------------------------
  * Sort / scan primitives (used by voxelisation, superpoint pooling, top-k)

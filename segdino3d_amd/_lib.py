@@ -25,6 +25,7 @@ _f = C.c_float
 SIGNATURES = {
     "sd3d_abi_version": (_i, []),
     "sd3d_last_error": (C.c_char_p, []),
+    "sd3d_set_scenes_in_flight": (_i, [_i]),
     "sd3d_selftest_host": (_i, []),
     "sd3d_sort_ws_bytes": (_z, [_l]),
     "sd3d_sort_pairs_u64": (_i, [_p, _p, _p, _p, _p, _l, _i, _i, _p, _z, _p]),

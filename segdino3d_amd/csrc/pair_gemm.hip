@@ -19,6 +19,10 @@
 // product per pair, then k ascending) so results are deterministic.
 #include "gg_common.h"
 #include <stdlib.h>
+#include <atomic>
+
+static std::atomic<int> g_scenes_in_flight{1};
+extern "C" int sd3d_set_scenes_in_flight(int n) { return g_scenes_in_flight.exchange(n < 1 ? 1 : n); }
 
 #define PL_ROWS 2048            // rows per workgroup of the list-building kernels
 #define PT 128                  // pairs per tile / segment padding
@@ -693,13 +697,21 @@ int launch_pair_conv(const float* in0, int ld0, int C0, const float* in1, int ld
     if (ws_env < 0) { const char* e = getenv("SD3D_PAIR_WS"); ws_env = e ? atoi(e) : 1; }
     const size_t w_lds = (size_t)Cout * (Cin + 4) * sizeof(float);
     const size_t w_lds_cg = (size_t)(32 * nt) * (Cin + 4) * sizeof(float);       // one column group's share of W[k]
-    const bool ws_one = ws_env && cgs == 1 && Cout == 32 * nt && w_lds <= 68 * 1024;
+    static int ws_mask = -1;                                   // SD3D_PAIR_WS_MASK: bit (nt - 1) allows the weight-stationary variant for nt column tiles
+    if (ws_mask < 0) { const char* e = getenv("SD3D_PAIR_WS_MASK"); ws_mask = e ? atoi(e) : 15; }
+    // several scenes in flight: the 96 / 128-column weight-stationary variants (47-63 KB of LDS per workgroup, 2-3 per CU) leave
+    // no room for the other scenes' kernels; measured with 4 scenes in flight 107 -> 112 scenes/s without them, while alone on the
+    // GPU they are 0.3 ms per forward faster.  SD3D_PAIR_CROWD=0/1 overrides the hint.
+    static int crowd_env = -2;
+    if (crowd_env == -2) { const char* e = getenv("SD3D_PAIR_CROWD"); crowd_env = e ? atoi(e) : -1; }
+    const bool crowded = crowd_env >= 0 ? crowd_env != 0 : g_scenes_in_flight.load(std::memory_order_relaxed) > 1;
+    const bool ws_one = ws_env && ((ws_mask >> (nt - 1)) & 1) && !(crowded && nt >= 3) && cgs == 1 && Cout == 32 * nt && w_lds <= 68 * 1024;
     // wide layers (256 columns = two groups of 128): the group's half of W[k] (133 KB at Cin = 256) still fits LDS with ONE
     // workgroup per CU - no per-step barrier, no re-staging of weight chunks, like the narrow layers
     static int ws2_env = -1;
     if (ws2_env < 0) { const char* e = getenv("SD3D_PAIR_WS2"); ws2_env = e ? atoi(e) : 1; }
     // (measured: level-3 256->256, 1808 tiles: 358 -> 347 us; level-4, 472 tiles: 104 -> 113 us - too few tiles for half the workgroups)
-    const bool ws_two = ws_env && ws2_env && cgs == 2 && nt == 4 && Cout == 256 && g.n_tiles >= 1024 && w_lds_cg + WS_RANGE_TILES * PT * sizeof(int32_t) + 256 <= 160 * 1024;
+    const bool ws_two = ws_env && ws2_env && !crowded && cgs == 2 && nt == 4 && Cout == 256 && g.n_tiles >= 1024 && w_lds_cg + WS_RANGE_TILES * PT * sizeof(int32_t) + 256 <= 160 * 1024;
     if (ws_one || ws_two) {
         static bool attr_done = false;
         if (!attr_done) {

@@ -94,8 +94,14 @@ class PipelinedRunner:
         """scenes: sequence of (points, target) already on the device, or an iterator that yields them lazily
         (e.g. io_scene.ScenePrefetcher: each worker pulls its next scene when it is ready for it).  Returns the list of
         model outputs in submission order."""
+        from . import ops
         if not hasattr(scenes, "__getitem__"):
-            return self._run_stream(scenes, on_result)
+            with ops.scenes_in_flight(self.n):
+                return self._run_stream(scenes, on_result)
+        with ops.scenes_in_flight(self.n):
+            return self._run_list(scenes, on_result)
+
+    def _run_list(self, scenes, on_result=None):
         results = [None] * len(scenes)
         errors = []
 

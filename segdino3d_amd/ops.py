@@ -433,6 +433,21 @@ def _cached_split(wt, terms):
     return hit[0]
 
 
+class scenes_in_flight:
+    """Context: tell the launchers that `n` independent scenes run concurrently on this GPU (sd3d_set_scenes_in_flight)."""
+
+    def __init__(self, n):
+        self.n = int(n)
+
+    def __enter__(self):
+        self.prev = _lib.load().sd3d_set_scenes_in_flight(self.n)
+        return self
+
+    def __exit__(self, *exc):
+        _lib.load().sd3d_set_scenes_in_flight(self.prev)
+        return False
+
+
 def clear_split_cache():
     _SPLIT_CACHE.clear()
 
