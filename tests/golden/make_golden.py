@@ -244,8 +244,11 @@ def golden_nms(arch_mod):
          out_masks=m, out_keep=keep, out_record=rec)
 
 
-def golden_architecture(seg, name, query_num, n_points=4000, S=80, M=12, box_filter=True):
-    """Full eval-mode Baseline3D.forward with a stand-in backbone (stored superpoint features)."""
+def golden_architecture(seg, name, query_num, n_points=4000, S=80, M=12, box_filter=True, size_bias=0.0):
+    """Full eval-mode Baseline3D.forward with a stand-in backbone (stored superpoint features).
+    size_bias: added to the output bias of every layer's box-size head.  With the plain deterministic weights the predicted
+    boxes stay near their 0.5 m initial size and filter_outofbox_points (baseline3d.py:348-371) empties almost every mask;
+    a positive bias grows the boxes layer by layer so that the filter keeps a large part of each mask and cuts the rest."""
     from segdino3d_amd.synth import make_scene
     points, target = make_scene(scene_idx=7, n_points=n_points, n_superpoints=S, n_query2d=M)
     sp = target.extra_features["super_point_masks"]
@@ -277,6 +280,10 @@ def golden_architecture(seg, name, query_num, n_points=4000, S=80, M=12, box_fil
         add_positional_embedding=True, mode_3d_center="median", query_num=query_num,
         filter_outofbox_points_eval=box_filter)).eval()
     assign_det_weights(model.decoder, "decoder.")
+    if size_bias:
+        with torch.no_grad():
+            for head in model.decoder.bbox_size_embed:
+                head.layers[-1].bias += size_bias
     # make the synthetic scene produce non-trivial instances: bias mask logits through x_mask so
     # that a fair number of superpoints are "on" for each query (random weights alone give ~50 %).
     if query_num > 0:
@@ -293,7 +300,7 @@ def golden_architecture(seg, name, query_num, n_points=4000, S=80, M=12, box_fil
          inst_labels=pd.instance_labels, inst_scores=pd.instance_scores, inst_boxes=pd.instance_boxes,
          sem_mask=pd.pts_semantic_mask[0], pan_sem=pd.pts_semantic_mask[1], pan_inst=pd.pts_instance_mask[1],
          topk_idx=topk_idx, score_mask=score_mask, npoint_mask=npoint_mask,
-         instance_centers=res[0].instance_centers, instance_sizes=res[0].instance_sizes)
+         instance_centers=res[0].instance_centers, instance_sizes=res[0].instance_sizes, size_bias=np.float32(size_bias))
     print(f"  {name}: {inst_masks.shape[0]} instances kept, mask points {inst_masks.sum()}")
 
 
@@ -317,6 +324,8 @@ def main():
     golden_architecture(seg, "arch_qall", query_num=-1)
     golden_architecture(seg, "arch_q40", query_num=40)
     golden_architecture(seg, "arch_qall_nobox", query_num=-1, box_filter=False)
+    golden_architecture(seg, "arch_qall_widebox", query_num=-1, size_bias=0.3)
+    golden_architecture(seg, "arch_q40_widebox", query_num=40, size_bias=0.3)
 
 
 if __name__ == "__main__":

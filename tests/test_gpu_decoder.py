@@ -215,8 +215,11 @@ class _StoredBackbone(torch.nn.Module):
         return [self.f.clone()], [self.p.clone()], [self.p.clone()]
 
 
-@pytest.mark.parametrize("name,query_num,box", [("arch_qall", -1, True), ("arch_q40", 40, True), ("arch_qall_nobox", -1, False)])
+@pytest.mark.parametrize("name,query_num,box", [("arch_qall", -1, True), ("arch_q40", 40, True), ("arch_qall_nobox", -1, False),
+                                                ("arch_qall_widebox", -1, True), ("arch_q40_widebox", 40, True)])
 def test_architecture_matches_reference_golden(name, query_num, box):
+    """The *_widebox fixtures grow the predicted boxes (a bias on the size heads, make_golden.golden_architecture) so that
+    filter_outofbox_points keeps ~28 % of the mask points instead of < 1 %: the filter is exercised on real content."""
     import segdino3d_amd as seg
     from segdino3d_amd.gtypes import GD3DTarget
     d = dev()
@@ -228,6 +231,8 @@ def test_architecture_matches_reference_golden(name, query_num, box):
         decoder_cfg=dict(type="ScanNetQueryDecoder", **DEC_KW), criterion_cfg=None, query_thr=0.5, test_cfg=TEST_CFG,
         add_positional_embedding=True, mode_3d_center="median", query_num=query_num, filter_outofbox_points_eval=box)).eval()
     sd = decoder_state_dict()
+    for i in range(6):
+        sd[f"decoder.bbox_size_embed.{i}.layers.2.bias"] = sd[f"decoder.bbox_size_embed.{i}.layers.2.bias"] + float(g["size_bias"])
     model.decoder.load_state_dict({k[len("decoder."):]: v for k, v in sd.items()})
     model.to(d)
     model.backbone.f, model.backbone.p = g["sp_feat"].to(d), g["sp_pos"].to(d)
@@ -247,7 +252,16 @@ def test_architecture_matches_reference_golden(name, query_num, box):
     same_label = (pd.instance_labels == g["inst_labels"].numpy()).mean()
     assert same_label > 0.99, same_label
     agree = (got_masks == ref_masks).mean()
-    assert agree > 0.999, agree
+    # order-free check: every reference row has a twin here with the same label and the identical point mask (near-tied scores
+    # swap neighbouring rows, which the in-place comparison counts as differing bits when the two rows are different queries)
+    from collections import Counter
+    ref_rows = Counter((int(l), m.tobytes()) for l, m in zip(g["inst_labels"].numpy(), np.packbits(ref_masks, axis=1)))
+    got_rows = Counter((int(l), m.tobytes()) for l, m in zip(pd.instance_labels, np.packbits(got_masks, axis=1)))
+    twins = sum((ref_rows & got_rows).values()) / max(1, ref_masks.shape[0])
+    print(f"{name}: {int(ref_masks.sum())} mask points in the reference, {int(got_masks.sum())} here, bits equal in place {agree:.6f}, "
+          f"rows with an identical (label, mask) twin {twins:.4f}")
+    assert twins >= 0.99, twins
+    assert agree > 0.998, agree
     # near-tied scores may swap two neighbouring rows: require >= 99 % of the rows to match exactly in place
     box_ok = np.isclose(pd.instance_boxes, g["inst_boxes"].numpy(), rtol=5e-3, atol=5e-3).all(axis=1).mean()
     assert box_ok > 0.99, box_ok

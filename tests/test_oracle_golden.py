@@ -122,10 +122,13 @@ def test_matrix_nms():
 
 
 @pytest.mark.parametrize("name,query_num,box", [("arch_qall", -1, True), ("arch_q40", 40, True),
-                                                ("arch_qall_nobox", -1, False)])
+                                                ("arch_qall_nobox", -1, False), ("arch_qall_widebox", -1, True),
+                                                ("arch_q40_widebox", 40, True)])
 def test_architecture_eval_path(name, query_num, box):
     g = load(name)
     sd = decoder_state_dict()
+    for i in range(6):                                # *_widebox: grown boxes, the out-of-box filter keeps ~28 % of the mask points
+        sd[f"decoder.bbox_size_embed.{i}.layers.2.bias"] = sd[f"decoder.bbox_size_embed.{i}.layers.2.bias"] + float(g["size_bias"])
     cfg = D.DecoderCfg()
     pts = g["points"]
     lo, hi, centers, sizes = P.scene_range_and_gt_boxes(pts[:, :3], g["gt_masks"], "median")
