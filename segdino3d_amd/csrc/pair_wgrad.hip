@@ -13,6 +13,7 @@
 // of one offset are contiguous and pass 2 adds them up in a fixed order: bit-reproducible, no atomics.
 #include "common.h"
 #include "../../include/segdino3d_hip.h"
+#include <stdlib.h>
 
 #define PT 128                       // pairs per tile of the pair lists
 #define WG_STEP 64                   // pairs staged per step (32: same speed within 3 %)
@@ -209,7 +210,14 @@ __global__ __launch_bounds__(256) void pair_wgrad_reduce_kernel(const float* __r
 // the decoder has two tiles: 768 ranges would leave 766 empty slots for pass 2 to scan)
 static int wgrad_ranges(int Cin, int Cout, int64_t p_cap) {
     const int blocks = (int)(cdiv(Cout, 128) * cdiv(Cin, 128));
-    int r = 768 / blocks;
+    // workgroups in total: one per CU for the wide layers (every extra range is another Cout x Cin partial block to write and to
+    // re-read in pass 2, and counts between whole multiples of the CU count run a half-empty last round: level-3 256 -> 256
+    // 604 us with 768, 553 with 512, 533 with 256, 710 with 384), three per CU for the narrow ones (64 -> 64: 124 / 140 / 188 us
+    // with 768 / 512 / 256).  SD3D_WGRAD_WGS overrides (tuning).
+    static int total_env = -1;
+    if (total_env < 0) { const char* e = getenv("SD3D_WGRAD_WGS"); total_env = e ? atoi(e) : 0; }
+    const int total = total_env > 0 ? total_env : ((int64_t)Cin * Cout >= 96 * 96 ? 256 : 768);
+    int r = total / blocks;
     r = r < 32 ? 32 : r;
     const int64_t tiles = p_cap / PT;
     return (int)(tiles < r ? (tiles > 0 ? tiles : 1) : r);
