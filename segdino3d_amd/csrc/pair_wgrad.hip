@@ -39,18 +39,19 @@ __global__ __launch_bounds__(256) void pair_out_rows_kernel(const int32_t* __res
     if (p >= 0) out_idx[p] = (int32_t)(i % M);
 }
 
-template <int NCO, int NCI>
-__global__ __launch_bounds__(256) void pair_wgrad_kernel(const WGParams p) {
+template <int NCO, int NCI, int NW>
+__global__ __launch_bounds__(NW * 64) void pair_wgrad_kernel(const WGParams p) {
+    constexpr int NTHR = NW * 64;
     constexpr int TCO = NCO * 32, TCI = NCI * 32;
     constexpr int LDA = (TCO % 64) ? TCO : TCO + 32;           // row stride = 32 mod 64 floats: the two pair rows an MFMA reads sit in different bank halves
     constexpr int LDB = (TCI % 64) ? TCI : TCI + 32;
     constexpr int NT = NCO * NCI;                              // 32 x 32 output tiles of the block
-    constexpr int TPW = (NT + 3) / 4;                          // tiles per wave
+    constexpr int TPW = (NT + NW - 1) / NW;                    // tiles per wave
     constexpr int A4 = WG_STEP * TCO / 4, B4 = WG_STEP * TCI / 4;      // float4 pieces per step
-    constexpr int NA = (A4 + 255) / 256, NB = (B4 + 255) / 256;
+    constexpr int NA = (A4 + NTHR - 1) / NTHR, NB = (B4 + NTHR - 1) / NTHR;
     __shared__ __attribute__((aligned(16))) float As[WG_STEP * LDA];
     __shared__ __attribute__((aligned(16))) float Bs[WG_STEP * LDB];
-    __shared__ int red[4];
+    __shared__ int red[NW];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);   // wave-uniform: tile offsets live in SGPRs, no exec-masked branches
     const int n_real = p.tile_k[p.n_tiles];
@@ -60,12 +61,14 @@ __global__ __launch_bounds__(256) void pair_wgrad_kernel(const WGParams p) {
     const int co0 = blockIdx.y * TCO, ci0 = blockIdx.z * TCI;
     // slot of the first run = range index + offset changes in tiles (0, t0]
     int changes = 0;
-    for (int t = 1 + tid; t <= t0; t += 256) changes += p.tile_k[t] != p.tile_k[t - 1];
+    for (int t = 1 + tid; t <= t0; t += NTHR) changes += p.tile_k[t] != p.tile_k[t - 1];
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) changes += __shfl_xor(changes, o, 64);
     if (lane == 0) red[wv] = changes;
     __syncthreads();
-    int slot = blockIdx.x + red[0] + red[1] + red[2] + red[3];
+    int slot = blockIdx.x;
+#pragma unroll
+    for (int i = 0; i < NW; ++i) slot += red[i];
 
     f32x16 acc[TPW];
 #pragma unroll
@@ -79,7 +82,7 @@ __global__ __launch_bounds__(256) void pair_wgrad_kernel(const WGParams p) {
         const int64_t pb = (int64_t)tile * PT + sub * WG_STEP;
 #pragma unroll
         for (int u = 0; u < NA; ++u) {
-            const int f = u * 256 + tid;
+            const int f = u * NTHR + tid;
             f32x4 v = {0.f, 0.f, 0.f, 0.f};
             if (f < A4) {
                 const int row = f / (TCO / 4), c4 = f % (TCO / 4);
@@ -90,7 +93,7 @@ __global__ __launch_bounds__(256) void pair_wgrad_kernel(const WGParams p) {
         }
 #pragma unroll
         for (int u = 0; u < NB; ++u) {
-            const int f = u * 256 + tid;
+            const int f = u * NTHR + tid;
             f32x4 v = {0.f, 0.f, 0.f, 0.f};
             if (f < B4) {
                 const int row = f / (TCI / 4), c4 = f % (TCI / 4);
@@ -113,12 +116,12 @@ __global__ __launch_bounds__(256) void pair_wgrad_kernel(const WGParams p) {
         }
 #pragma unroll
         for (int u = 0; u < NA; ++u) {
-            const int f = u * 256 + tid;
+            const int f = u * NTHR + tid;
             if (f < A4) *(f32x4*)(As + (f / (TCO / 4)) * LDA + (f % (TCO / 4)) * 4) = ra[u];
         }
 #pragma unroll
         for (int u = 0; u < NB; ++u) {
-            const int f = u * 256 + tid;
+            const int f = u * NTHR + tid;
             if (f < B4) *(f32x4*)(Bs + (f / (TCI / 4)) * LDB + (f % (TCI / 4)) * 4) = rb[u];
         }
     };
@@ -126,7 +129,7 @@ __global__ __launch_bounds__(256) void pair_wgrad_kernel(const WGParams p) {
         float* dst = p.wpart + (int64_t)slot * p.Cout * p.Cin;
 #pragma unroll
         for (int i = 0; i < TPW; ++i) {
-            const int t = wv + 4 * i;
+            const int t = wv + NW * i;
             if (t < NT) {
                 const int co = co0 + (t / NCI) * 32, ci = ci0 + (t % NCI) * 32 + (lane & 31);
                 if (ci < p.Cin) {
@@ -147,7 +150,7 @@ __global__ __launch_bounds__(256) void pair_wgrad_kernel(const WGParams p) {
     bool t_ok[TPW];
 #pragma unroll
     for (int i = 0; i < TPW; ++i) {
-        const int t = wv + 4 * i;
+        const int t = wv + NW * i;
         t_ok[i] = t < NT;
         const int tt = t < NT ? t : NT - 1;
         a_off[i] = (tt / NCI) * 32; b_off[i] = (tt % NCI) * 32;
@@ -175,7 +178,7 @@ __global__ __launch_bounds__(256) void pair_wgrad_kernel(const WGParams p) {
 #pragma unroll
                 for (int i = 0; i < TPW; ++i) {
                     const float a = ar[a_off[i]];
-                    av[i] = (NT % 4 == 0 || t_ok[i]) ? a : 0.f;
+                    av[i] = (NT % NW == 0 || t_ok[i]) ? a : 0.f;
                     bv[i] = br[b_off[i]];
                 }
 #pragma unroll
@@ -256,14 +259,28 @@ int sd3d_pair_wgrad(const float* dy, int ld_dy, const float* x, int ld_x, const 
     p.slot_k = (int32_t*)ws;
     p.wpart = (float*)((char*)ws + align_up((size_t)p.n_slots * sizeof(int32_t), 256));
     if (hipMemsetAsync(p.slot_k, 0xFF, (size_t)p.n_slots * sizeof(int32_t), ST) != hipSuccess) return sd3d_set_error(SD3D_ERR_LAUNCH, "pair_wgrad: memset failed");
-    const int nco = Cout >= 128 ? 4 : (Cout + 31) / 32, nci = Cin >= 128 ? 4 : (Cin + 31) / 32;
+    // block = the channel count split evenly over its ceil(C / 128) blocks (192 channels: 2 x 96, not 128 + 64)
+    auto sub = [](int C) { const int n32 = (C + 31) / 32, nb = (n32 + 3) / 4; return (n32 + nb - 1) / nb; };
+    const int nco = sub(Cout), nci = sub(Cin);
     const dim3 grid(ranges, (unsigned)cdiv(Cout, nco * 32), (unsigned)cdiv(Cin, nci * 32));
-#define WG_CASE(a, b) if (nco == a && nci == b) pair_wgrad_kernel<a, b><<<grid, 256, 0, ST>>>(p);
+    // waves per workgroup: one 32 x 32 output tile per wave where the block has >= 8 tiles (16 waves share one staged step of the
+    // 128 x 128 block: level-3 256 -> 256 530 -> 354 us, level-2 128 -> 128 415 -> 277 us against 4 waves x 4 tiles), 4 waves otherwise.
+    // SD3D_WGRAD_NW=4 forces the 4-wave kernel (cross-check).
+    static int nw_env = -1;
+    if (nw_env < 0) { const char* e = getenv("SD3D_WGRAD_NW"); nw_env = e ? atoi(e) : 0; }
+#define WG_LAUNCH(a, b, nw) pair_wgrad_kernel<a, b, nw><<<grid, (nw) * 64, 0, ST>>>(p)
+#define WG_CASE(a, b) if (nco == a && nci == b) {                                                   \
+        if (nw_env == 4 || a * b < 8) WG_LAUNCH(a, b, 4);                                           \
+        else if (a * b == 16) WG_LAUNCH(a, b, 16);                                                  \
+        else if (a * b == 12) WG_LAUNCH(a, b, 12);                                                  \
+        else if (a * b == 9) WG_LAUNCH(a, b, 9);                                                    \
+        else WG_LAUNCH(a, b, 8); }
     WG_CASE(1, 1) WG_CASE(1, 2) WG_CASE(1, 3) WG_CASE(1, 4)
     WG_CASE(2, 1) WG_CASE(2, 2) WG_CASE(2, 3) WG_CASE(2, 4)
     WG_CASE(3, 1) WG_CASE(3, 2) WG_CASE(3, 3) WG_CASE(3, 4)
     WG_CASE(4, 1) WG_CASE(4, 2) WG_CASE(4, 3) WG_CASE(4, 4)
 #undef WG_CASE
+#undef WG_LAUNCH
     const int64_t elems = (int64_t)Cin * Cout;
     int64_t gx = cdiv(elems, 256);                           // ~2048 workgroups over all offsets: a K = 1 Linear gets as many as a 27-offset convolution
     const int64_t cap = 2048 / K > 64 ? 2048 / K : 64;
