@@ -223,23 +223,43 @@ class Baseline3D(nn.Module):
                                            boxes if self.filter_outofbox_points_eval else None)
         return dict(scores=final_scores, labels=final_labels, masks=masks_u8, count=count, boxes=boxes, topk_idx=qidx.long())
 
-    def _select(self, common, score_threshold):
+    def _select(self, common, thresholds):
+        """The data-dependent selections of predict_by_feat_instance (:470-476) for several score thresholds from ONE host read:
+        the k scores and point counts travel to the host (a few KB, polled), the row lists are made there and go back in one copy.
+        (Boolean indexing on the device costs a synchronising nonzero per selection - three per scene before.)
+        Returns [(keep int32 rows, score_mask bool[k], npoint_mask bool[n_scored])] per threshold, tensors on the device."""
         cfg = self.test_cfg
-        score_mask = common["scores"] > score_threshold
-        npoint_all = common["count"] > int(_cfg_get(cfg, "npoint_thr"))
-        npoint_mask = npoint_all[score_mask]
-        keep = (score_mask & npoint_all).nonzero().squeeze(1)
-        return keep, score_mask, npoint_mask
+        scores, count = common["scores"], common["count"]
+        k = scores.shape[0]
+        host = ops.HostRead(torch.cat([scores, count.view(torch.float32)])).wait().numpy()
+        s, c = host[:k], host[k:].view(np.int32)
+        npoint_all = c > int(_cfg_get(cfg, "npoint_thr"))
+        parts, lay = [], []
+        for thr in thresholds:
+            score_mask = s > np.float32(thr)
+            keep = np.flatnonzero(score_mask & npoint_all).astype(np.int32)
+            npoint_mask = npoint_all[score_mask]
+            pad = (-(k + npoint_mask.size)) % 4                        # keeps the next int32 block aligned
+            parts += [keep.view(np.uint8), score_mask.view(np.uint8), npoint_mask.view(np.uint8), np.zeros(pad, np.uint8)]
+            lay.append((keep.size, npoint_mask.size, pad))
+        dev = torch.from_numpy(np.concatenate(parts)).to(scores.device, non_blocking=True)
+        out, o = [], 0
+        for n_keep, n_scored, pad in lay:
+            keep = dev[o:o + 4 * n_keep].view(torch.int32); o += 4 * n_keep
+            score_mask = dev[o:o + k].view(torch.bool); o += k
+            npoint_mask = dev[o:o + n_scored].view(torch.bool); o += n_scored + pad
+            out.append((keep, score_mask, npoint_mask))
+        return out
 
     @ops.bound_stream
     def predict_by_feat(self, samples, out, superpoints):
         cfg = self.test_cfg
         ops.baton_yield()
         com = self._instances_common(samples, out, superpoints)
-        # the data-dependent selections below synchronise; wait for the scene's work by polling first so that no
-        # host thread sits inside a blocking HIP call while other scenes are being issued
-        ops.wait_event(ops.stream_event())
-        keep, score_mask, npoint_mask = self._select(com, float(_cfg_get(cfg, "inst_score_thr")))
+        # the data-dependent selections need the scores on the host: one polled read (no host thread sits inside a blocking HIP
+        # call while other scenes are being issued)
+        (keep, score_mask, npoint_mask), (pkeep, _, _) = self._select(
+            com, (float(_cfg_get(cfg, "inst_score_thr")), float(_cfg_get(cfg, "pan_score_thr"))))
         inst_masks = com["masks"][keep].view(torch.bool)
         inst_labels, inst_scores = com["labels"][keep].long(), com["scores"][keep]
         inst_boxes = com["boxes"][keep] if com["boxes"] is not None else None
@@ -252,11 +272,10 @@ class Baseline3D(nn.Module):
         stuff = list(_cfg_get(cfg, "stuff_classes"))
         cols = torch.tensor(stuff, dtype=torch.int32, device=sem.device)
         sem_stuff = ops.gather_i64(ops.row_argmax(sem, cols=cols), superpoints, use_index)
-        pkeep, _, _ = self._select(com, float(_cfg_get(cfg, "pan_score_thr")))
         if pkeep.numel() == 0:
             pan_sem, pan_inst = sem_stuff, sem_stuff
         else:
-            pan_sem, pan_inst = ops.panoptic(com["masks"], pkeep.int().contiguous(), com["labels"][pkeep].int().contiguous(),
+            pan_sem, pan_inst = ops.panoptic(com["masks"], pkeep.contiguous(), com["labels"][pkeep].int().contiguous(),
                                              len(stuff), int(_cfg_get(cfg, "npoint_thr")), sem_stuff)
         sort_and_mask = (com["topk_idx"], score_mask, npoint_mask)
         if not self.to_host:
