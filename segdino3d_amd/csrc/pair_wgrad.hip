@@ -211,7 +211,7 @@ __global__ __launch_bounds__(256) void pair_wgrad_reduce_kernel(const float* __r
 
 // tile ranges (= workgroups per output block): enough to fill the chip, never more than there are tiles (a 200-row Linear of
 // the decoder has two tiles: 768 ranges would leave 766 empty slots for pass 2 to scan)
-static int wgrad_ranges(int Cin, int Cout, int64_t p_cap) {
+static int wgrad_ranges(int K, int Cin, int Cout, int64_t p_cap) {
     const int blocks = (int)(cdiv(Cout, 128) * cdiv(Cin, 128));
     // workgroups in total: one per CU for the wide layers (every extra range is another Cout x Cin partial block to write and to
     // re-read in pass 2, and counts between whole multiples of the CU count run a half-empty last round: level-3 256 -> 256
@@ -219,7 +219,8 @@ static int wgrad_ranges(int Cin, int Cout, int64_t p_cap) {
     // with 768 / 512 / 256).  SD3D_WGRAD_WGS overrides (tuning).
     static int total_env = -1;
     if (total_env < 0) { const char* e = getenv("SD3D_WGRAD_WGS"); total_env = e ? atoi(e) : 0; }
-    const int total = total_env > 0 ? total_env : ((int64_t)Cin * Cout >= 96 * 96 ? 256 : 768);
+    // (the 5^3 stem, 288 -> 32 with 125 offsets: 868 / 517 / 659 us with 256 / 512 / 768)
+    const int total = total_env > 0 ? total_env : ((int64_t)Cin * Cout > 96 * 96 || (Cin >= 96 && Cout >= 96) ? 256 : (K > 27 ? 512 : 768));
     int r = total / blocks;
     r = r < 32 ? 32 : r;
     const int64_t tiles = p_cap / PT;
@@ -238,7 +239,7 @@ int sd3d_pair_out_rows(const int32_t* pos, int K, int64_t M, int64_t p_cap, int3
 }
 
 size_t sd3d_pair_wgrad_ws_bytes(int K, int Cin, int Cout) {
-    const size_t slots = (size_t)wgrad_ranges(Cin, Cout, (int64_t)1 << 40) + K;          // the most any p_cap can ask for
+    const size_t slots = (size_t)wgrad_ranges(K, Cin, Cout, (int64_t)1 << 40) + K;          // the most any p_cap can ask for
     return align_up(slots * sizeof(int32_t), 256) + slots * (size_t)Cin * Cout * sizeof(float);
 }
 
@@ -249,7 +250,7 @@ int sd3d_pair_wgrad(const float* dy, int ld_dy, const float* x, int ld_x, const 
     if ((Cin & 3) || (Cout & 3) || (ld_dy & 3) || (ld_x & 3)) return sd3d_set_error(SD3D_ERR_ARG, "pair_wgrad: channel counts and row strides must be multiples of 4");
     if (p_cap <= 0 || (p_cap % PT)) return sd3d_set_error(SD3D_ERR_ARG, "pair_wgrad: p_cap must be a positive multiple of 128");
     if (ws_bytes < sd3d_pair_wgrad_ws_bytes(K, Cin, Cout)) return sd3d_set_error(SD3D_ERR_WS, "pair_wgrad: workspace too small");
-    const int ranges = wgrad_ranges(Cin, Cout, p_cap);
+    const int ranges = wgrad_ranges(K, Cin, Cout, p_cap);
     WGParams p;
     p.dy = dy; p.ld_dy = ld_dy; p.x = x; p.ld_x = ld_x; p.in_idx = in_idx; p.out_idx = out_idx; p.tile_k = tile_k;
     p.n_tiles = (int)(p_cap / PT); p.Cin = Cin; p.Cout = Cout;

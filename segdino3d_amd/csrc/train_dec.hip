@@ -188,11 +188,39 @@ int sd3d_act_backward(const float* dy, int ld_dy, const float* ref, int ld_ref, 
     return SD3D_OK;
 }
 
+// few rows (the decoder's <= 8192 query / superpoint rows): one launch, one workgroup per 64-column group with 16 row lanes whose
+// fp32 partial sums meet in LDS in a fixed order (double) - the two-launch path above costs 15 us of launch latency for 2.5 MB of data
+#define CSUM_SMALL_MAX 8192
+static __global__ __launch_bounds__(1024) void col_sum_small_kernel(const float* __restrict__ x, int ld, int64_t M, int C, float* __restrict__ out) {
+    __shared__ float sm[16][64];
+    const int cl = threadIdx.x & 63, rl = threadIdx.x >> 6;
+    const int c = blockIdx.x * 64 + cl;
+    float a = 0.f;
+    if (c < C) {
+        int64_t r = rl;
+        for (; r + 48 < M; r += 64) a += (x[r * ld + c] + x[(r + 16) * ld + c]) + (x[(r + 32) * ld + c] + x[(r + 48) * ld + c]);
+        for (; r < M; r += 16) a += x[r * ld + c];
+    }
+    sm[rl][cl] = a;
+    __syncthreads();
+    if (rl == 0 && c < C) {
+        double t = 0.0;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) t += (double)sm[i][cl];
+        out[c] = (float)t;
+    }
+}
+
 size_t sd3d_col_sums_ws_bytes(int64_t M, int C) { return align_up((size_t)cdiv(M, CSUM_ROWS) * C * sizeof(float), 256); }
 
 int sd3d_col_sums(const float* x, int ld, int64_t M, int C, float* out, void* ws, size_t ws_bytes, void* stream) {
     if (M <= 0 || C <= 0) return sd3d_set_error(SD3D_ERR_ARG, "col_sums: empty input");
     if (ws_bytes < sd3d_col_sums_ws_bytes(M, C)) return sd3d_set_error(SD3D_ERR_WS, "col_sums: workspace too small");
+    if (M <= CSUM_SMALL_MAX) {
+        col_sum_small_kernel<<<(unsigned)cdiv(C, 64), 1024, 0, ST>>>(x, ld, M, C, out);
+        SD3D_CHECK_LAUNCH();
+        return SD3D_OK;
+    }
     const int nchunk = (int)cdiv(M, CSUM_ROWS);
     col_sum_partial_kernel<<<dim3((unsigned)cdiv(C, 64), nchunk), 256, 0, ST>>>(x, ld, M, C, (float*)ws);
     col_sum_final_kernel<<<(unsigned)cdiv(C, 256), 256, 0, ST>>>((const float*)ws, nchunk, C, out);

@@ -23,7 +23,7 @@ maps = SceneMaps(pts.to(d), 0.02, 5, superpoints=tgt.extra_features["super_point
 maps.prepare(same=[(0, 5)] + [(l, 3) for l in range(5)], strides=[0, 1, 2, 3])
 g = torch.Generator().manual_seed(0)
 out = []
-for key, cin, cout in [(("same", 0, 3), 96, 96), (("same", 1, 3), 96, 96), (("same", 2, 3), 128, 128), (("same", 3, 3), 256, 256),
+for key, cin, cout in [(("same", 0, 5), 288, 32), (("same", 0, 3), 96, 96), (("same", 1, 3), 96, 96), (("same", 2, 3), 128, 128), (("same", 3, 3), 256, 256),
                        (("same", 4, 3), 256, 256), (("same", 1, 3), 32, 32), (("up", 2), 256, 128), (("same", 2, 3), 64, 64), (("up", 0), 128, 96), (("same", 2, 3), 192, 128), (("same", 0, 3), 128, 96)]:
     tab = maps.conv_table(*key); nbr, pairs = tab["nbr"], tab["pairs"]
     K, M = nbr.shape
