@@ -231,3 +231,36 @@ def scannet_eval(preds, gts, options, valid_class_ids, class_labels, id_to_label
         matches[i] = {"gt": g2p, "pred": p2g}
     ap, pr_rc = evaluate_matches(matches, class_labels, options)
     return compute_averages(ap, pr_rc, options, class_labels, groups), ap, pr_rc
+
+
+def map_inst_markup(pts_semantic_mask, pts_instance_mask, valid_class_ids, num_stuff_cls):
+    """`InstanceSeg3DEvaluator.map_inst_markup` (evaluation/evaluator_3d.py:323-349): panoptic-style annotation -> the instance
+    task's ground truth.  valid_class_ids = the THING ids (the caller passes `valid_class_ids[num_stuff_cls:]`, :171);
+    numpy's negative-index wrap of `mapping[...]` is part of the behaviour (index -1 = the appended -1)."""
+    inst = np.array(pts_instance_mask, copy=True)
+    sem = np.array(pts_semantic_mask, copy=True)
+    inst -= num_stuff_cls
+    inst[inst < 0] = -1
+    sem -= num_stuff_cls
+    sem[inst == -1] = -1
+    mapping = np.array(list(valid_class_ids) + [-1])
+    return mapping[sem], inst
+
+
+def evaluator_instance_metrics(results, classes, valid_class_ids, num_stuff_cls, options=None, groups=None):
+    """The ScanNet branch of `InstanceSeg3DEvaluator.compute_metrics` (evaluator_3d.py:124-219): per scene
+    (eval_ann, pred) -> map_inst_markup -> instance_seg_eval(valid_class_ids[num_stuff:], classes[num_stuff:-1]).
+    results: [(dict(pts_semantic_mask, pts_instance_mask), dict(pts_instance_mask=[masks, ...], instance_labels, instance_scores))]."""
+    things = tuple(valid_class_ids[num_stuff_cls:])
+    labels = tuple(classes[num_stuff_cls:-1])
+    sems, insts, masks, labs, scores = [], [], [], [], []
+    for ann, pred in results:
+        s, i = map_inst_markup(ann["pts_semantic_mask"], ann["pts_instance_mask"], things, num_stuff_cls)
+        sems.append(s); insts.append(i)
+        masks.append(np.asarray(pred["pts_instance_mask"][0])); labs.append(np.asarray(pred["instance_labels"]))
+        scores.append(np.asarray(pred["instance_scores"]))
+    id_to_label = {things[i]: labels[i] for i in range(len(things))}
+    preds = aggregate_predictions(masks, labs, scores, things)
+    gts = rename_gt(sems, insts, things)
+    metrics, _, _ = scannet_eval(preds, gts, options, things, labels, id_to_label, groups)
+    return metrics, sems, insts

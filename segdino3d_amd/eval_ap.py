@@ -344,3 +344,35 @@ def instance_seg_eval(gt_semantic_masks, gt_instance_masks, pred_instance_masks,
                for m, l, s, g in zip(pred_instance_masks, pred_instance_labels, pred_instance_scores, gts)]
     ap, pr_rc = evaluate_records(records, class_labels, valid_class_ids, opts)
     return compute_averages(ap, pr_rc, opts, class_labels, groups)
+
+
+def map_inst_markup(pts_semantic_mask: torch.Tensor, pts_instance_mask: torch.Tensor, valid_class_ids, num_stuff_cls: int):
+    """`InstanceSeg3DEvaluator.map_inst_markup` (evaluation/evaluator_3d.py:323-349) on tensors (any device, not in place):
+    instance ids shifted down by the stuff classes (stuff -> -1), semantic ids of the remaining points mapped to the dataset's
+    class ids through `valid_class_ids + [-1]` (negative indices wrap as in numpy: index -1 is the appended -1)."""
+    inst = pts_instance_mask.long() - int(num_stuff_cls)
+    inst = torch.where(inst < 0, torch.full_like(inst, -1), inst)
+    sem = pts_semantic_mask.long() - int(num_stuff_cls)
+    sem = torch.where(inst == -1, torch.full_like(sem, -1), sem)
+    mapping = torch.tensor(list(valid_class_ids) + [-1], dtype=torch.long, device=sem.device)
+    return mapping[sem], inst
+
+
+def evaluator_instance_metrics(results, classes, valid_class_ids, num_stuff_cls: int, options=None, groups=None):
+    """The ScanNet branch of `InstanceSeg3DEvaluator.compute_metrics` (evaluator_3d.py:124-219) with device tensors: per scene
+    `(eval_ann, pred)` as the reference's evaluator collects them - `eval_ann` = dict(pts_semantic_mask, pts_instance_mask)
+    (panoptic-style), `pred` = this package's `PointData` fields (`pts_instance_mask[0]` [n, N] bool, `instance_labels`,
+    `instance_scores`) - through `map_inst_markup` into `instance_seg_eval(valid_class_ids[num_stuff:], classes[num_stuff:-1])`.
+    Returns the same metrics dictionary (the reference computes it and, with its last lines commented out, drops it)."""
+    things = tuple(int(v) for v in valid_class_ids[num_stuff_cls:])
+    labels = tuple(classes[num_stuff_cls:-1])
+    as_t = lambda a, dev: a if torch.is_tensor(a) else torch.as_tensor(np.asarray(a), device=dev)     # noqa: E731
+    sems, insts, masks, labs, scores = [], [], [], [], []
+    for ann, pred in results:
+        m = pred["pts_instance_mask"][0]
+        m = m if torch.is_tensor(m) else torch.as_tensor(np.asarray(m))
+        dev = m.device
+        s, i = map_inst_markup(as_t(ann["pts_semantic_mask"], dev), as_t(ann["pts_instance_mask"], dev), things, num_stuff_cls)
+        sems.append(s); insts.append(i); masks.append(m)
+        labs.append(as_t(pred["instance_labels"], dev)); scores.append(as_t(pred["instance_scores"], dev))
+    return instance_seg_eval(sems, insts, masks, labs, scores, valid_class_ids=things, class_labels=labels, options=options, groups=groups)

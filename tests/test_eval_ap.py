@@ -174,3 +174,23 @@ def test_eight_rank_exchange_with_ragged_and_empty_ranks():
         ap, pr_rc = eval_ap.evaluate_records(single, class_labels, valid, opts)
         ref = eval_ap.compute_averages(ap, pr_rc, opts, class_labels)["all_ap"]
         assert all(abs(g[2] - ref) < 1e-12 or (np.isnan(g[2]) and np.isnan(ref)) for g in got), (got, ref)
+
+
+def test_map_inst_markup_matches_reference_golden():
+    """segdino3d_amd.eval_ap.map_inst_markup (tensors, not in place) against the reference's evaluator method on the golden scenes
+    (evaluator_3d.py:323-349), plus the numpy negative-index wrap it inherits: a thing-class point whose shifted semantic id is
+    negative while its instance survives indexes the mapping from the back."""
+    from segdino3d_amd import eval_ap
+    from test_oracle_golden import _evaluator_fixture
+    z, classes, valid, n_stuff, results = _evaluator_fixture()
+    for si, (ann, _) in enumerate(results):
+        sem0, inst0 = torch.from_numpy(ann["pts_semantic_mask"]), torch.from_numpy(ann["pts_instance_mask"])
+        keep = (sem0.clone(), inst0.clone())
+        sem, inst = eval_ap.map_inst_markup(sem0, inst0, valid[n_stuff:], n_stuff)
+        assert torch.equal(sem, torch.from_numpy(z[f"s{si}_mapped_sem"])) and torch.equal(inst, torch.from_numpy(z[f"s{si}_mapped_inst"]))
+        assert torch.equal(sem0, keep[0]) and torch.equal(inst0, keep[1])                      # inputs untouched
+    from oracle import eval_ref as E
+    sem = np.array([0, 1, 5, 9, 10, 3]); inst = np.array([0, 1, 7, 2, 4, 9])                    # class 0 with a thing instance id: wraps
+    rs, ri = E.map_inst_markup(sem, inst, valid[n_stuff:], n_stuff)
+    gs, gi = eval_ap.map_inst_markup(torch.from_numpy(sem), torch.from_numpy(inst), valid[n_stuff:], n_stuff)
+    assert np.array_equal(gs.numpy(), rs) and np.array_equal(gi.numpy(), ri)

@@ -199,3 +199,25 @@ def test_end_to_end_map_of_hip_path_equals_oracle_path():
     print("mAP oracle / HIP:", {k: (round(float(m_ref[k]), 5), round(float(m_hip[k]), 5)) for k in ("all_ap", "all_ap_50%", "all_ap_25%")})
     for key in ("all_ap", "all_ap_50%", "all_ap_25%"):
         assert abs(m_hip[key] - m_ref[key]) < 1e-3, (key, m_hip[key], m_ref[key])      # north star: mAP within +-0.1 points
+
+
+def test_evaluator_level_metrics_match_reference_golden():
+    """eval_ap.evaluator_instance_metrics with device tensors against the metrics the reference's
+    InstanceSeg3DEvaluator.compute_metrics built from the same per-scene results (evaluator_3d.py:124-219)."""
+    from segdino3d_amd import eval_ap
+    from test_oracle_golden import _evaluator_fixture
+    d = dev()
+    z, classes, valid, n_stuff, results = _evaluator_fixture()
+    on_dev = [(dict(pts_semantic_mask=torch.from_numpy(a["pts_semantic_mask"]).to(d), pts_instance_mask=torch.from_numpy(a["pts_instance_mask"]).to(d)),
+               dict(pts_instance_mask=[torch.from_numpy(p["pts_instance_mask"][0]).to(d)], instance_labels=torch.from_numpy(p["instance_labels"]).to(d),
+                    instance_scores=torch.from_numpy(p["instance_scores"]).to(d))) for a, p in results]
+    metrics = eval_ap.evaluator_instance_metrics(on_dev, classes, valid, n_stuff)
+    for k, v in zip(z["keys"], z["vals"]):
+        got = metrics[str(k)]
+        assert (np.isnan(got) and np.isnan(v)) or abs(got - v) < 1e-12, (k, got, v)
+    cls = np.array([[metrics["classes"][c][f] for f in ("ap", "ap50%", "ap25%")] for c in classes[n_stuff:-1]])
+    assert np.allclose(cls, z["class_ap"], rtol=0, atol=1e-12, equal_nan=True)
+    # numpy inputs (what the reference's evaluator holds) give the same numbers
+    host = eval_ap.evaluator_instance_metrics([(a, dict(p, pts_instance_mask=[torch.from_numpy(p["pts_instance_mask"][0]).to(d)])) for a, p in results],
+                                              classes, valid, n_stuff)
+    assert all((np.isnan(host[str(k)]) and np.isnan(v)) or abs(host[str(k)] - v) < 1e-12 for k, v in zip(z["keys"], z["vals"]))

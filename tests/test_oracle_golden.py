@@ -245,3 +245,38 @@ def test_ap_protocol_oracle_matches_reference_golden(opt_name, options):
         assert (np.isnan(got) and np.isnan(v)) or abs(got - v) < 1e-12, (k, got, v)
     cls = np.array([[metrics["classes"][c][f] for f in ("ap", "ap50%", "ap25%", "prec50%", "rec50%")] for c in class_labels])
     assert np.allclose(cls, z[f"{opt_name}_class_ap"], rtol=0, atol=1e-12, equal_nan=True)
+
+
+# ------------------------------------------------------------------------------------------------
+# evaluator level (evaluation/evaluator_3d.py:124-219, 323-349): panoptic-style ground truth -> map_inst_markup -> instance AP
+# ------------------------------------------------------------------------------------------------
+def _evaluator_fixture():
+    z = np.load(os.path.join(GOLDEN, "evaluator_scannet.npz"))
+    classes = tuple(str(c) for c in z["classes"])
+    valid = tuple(int(v) for v in z["valid_class_ids"])
+    results = []
+    for si in range(4):
+        n = int(z[f"s{si}_n"])
+        masks = np.unpackbits(z[f"s{si}_masks"], axis=1)[:, :n].astype(bool)
+        results.append((dict(pts_semantic_mask=z[f"s{si}_sem"], pts_instance_mask=z[f"s{si}_inst"]),
+                        dict(pts_instance_mask=[masks], instance_labels=z[f"s{si}_labels"], instance_scores=z[f"s{si}_scores"])))
+    return z, classes, valid, int(z["num_stuff_cls"]), results
+
+
+def test_evaluator_metrics_oracle_matches_reference_golden():
+    """oracle.eval_ref.evaluator_instance_metrics against what the reference's InstanceSeg3DEvaluator.compute_metrics computed on
+    the same per-scene results (tests/golden/make_golden_evaluator.py): the mapped ground truth exactly, the metrics to 1e-12."""
+    import json
+    from oracle import eval_ref as E
+    z, classes, valid, n_stuff, results = _evaluator_fixture()
+    here = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    with open(os.path.join(here, "segdino3d_amd", "data", "scannet200_groups.json")) as f:
+        groups = json.load(f)
+    metrics, sems, insts = E.evaluator_instance_metrics(results, classes, valid, n_stuff, groups=groups)
+    for si in range(4):
+        assert np.array_equal(sems[si], z[f"s{si}_mapped_sem"]) and np.array_equal(insts[si], z[f"s{si}_mapped_inst"])
+    for k, v in zip(z["keys"], z["vals"]):
+        got = metrics[str(k)]
+        assert (np.isnan(got) and np.isnan(v)) or abs(got - v) < 1e-12, (k, got, v)
+    cls = np.array([[metrics["classes"][c][f] for f in ("ap", "ap50%", "ap25%")] for c in classes[n_stuff:-1]])
+    assert np.allclose(cls, z["class_ap"], rtol=0, atol=1e-12, equal_nan=True)
