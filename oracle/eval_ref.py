@@ -264,3 +264,17 @@ def evaluator_instance_metrics(results, classes, valid_class_ids, num_stuff_cls,
     gts = rename_gt(sems, insts, things)
     metrics, _, _ = scannet_eval(preds, gts, options, things, labels, id_to_label, groups)
     return metrics, sems, insts
+
+
+def eval_ann_from_target(masks, labels, bg_class_id):
+    """The ground-truth record the evaluation loop builds per scene (evaluation/evaluate_3d.py:49-57): masks [n, N] bool,
+    labels [n] -> (pts_instance_mask [N], pts_semantic_mask [N]).  Ids are SUMMED over the instances that cover a point
+    (overlapping masks add up, as in the reference); uncovered points get -1 / bg_class_id."""
+    masks = np.asarray(masks).astype(np.int64)
+    n = masks.shape[0]
+    covered = masks.sum(axis=0) != 0
+    inst = (masks * np.arange(n, dtype=np.int64)[:, None]).sum(axis=0)
+    inst[~covered] = -1
+    sem = (masks * np.asarray(labels, dtype=np.int64)[:, None]).sum(axis=0)
+    sem[~covered] = bg_class_id
+    return inst, sem

@@ -369,6 +369,8 @@ def evaluator_instance_metrics(results, classes, valid_class_ids, num_stuff_cls:
     as_t = lambda a, dev: a if torch.is_tensor(a) else torch.as_tensor(np.asarray(a), device=dev)     # noqa: E731
     sems, insts, masks, labs, scores = [], [], [], [], []
     for ann, pred in results:
+        if not isinstance(pred, dict):                                 # a PointData straight from the model (SegMetric.process makes it a dict)
+            pred = dict(pred.items())
         m = pred["pts_instance_mask"][0]
         m = m if torch.is_tensor(m) else torch.as_tensor(np.asarray(m))
         dev = m.device
@@ -376,3 +378,19 @@ def evaluator_instance_metrics(results, classes, valid_class_ids, num_stuff_cls:
         sems.append(s); insts.append(i); masks.append(m)
         labs.append(as_t(pred["instance_labels"], dev)); scores.append(as_t(pred["instance_scores"], dev))
     return instance_seg_eval(sems, insts, masks, labs, scores, valid_class_ids=things, class_labels=labels, options=options, groups=groups)
+
+
+def eval_ann_info(target, bg_class_id: int) -> dict:
+    """The per-scene ground-truth record of the reference's evaluation loop (evaluation/evaluate_3d.py:49-63) from a
+    `GD3DTarget` as the model returns it - tensors stay on the target's device (the reference moves them to numpy for the
+    CPU protocol; `evaluator_instance_metrics` takes either).  Instance / semantic ids are the SUM over the instance masks that
+    cover a point, uncovered points -1 / `bg_class_id`, exactly as the loop computes them."""
+    m = target["masks"].squeeze(-1).long()                                     # [n, N]
+    n = m.shape[0]
+    covered = m.sum(dim=0) != 0
+    inst = (m * torch.arange(n, device=m.device)[:, None]).sum(dim=0)
+    inst = torch.where(covered, inst, torch.full_like(inst, -1))
+    sem = (m * target["labels"].long()[:, None]).sum(dim=0)
+    sem = torch.where(covered, sem, torch.full_like(sem, int(bg_class_id)))
+    return dict(pts_instance_mask=inst, pts_semantic_mask=sem, sp_pts_mask=target["extra_features"]["super_point_masks"],
+                lidar_idx=target["scene_id"])

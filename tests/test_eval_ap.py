@@ -194,3 +194,26 @@ def test_map_inst_markup_matches_reference_golden():
     rs, ri = E.map_inst_markup(sem, inst, valid[n_stuff:], n_stuff)
     gs, gi = eval_ap.map_inst_markup(torch.from_numpy(sem), torch.from_numpy(inst), valid[n_stuff:], n_stuff)
     assert np.array_equal(gs.numpy(), rs) and np.array_equal(gi.numpy(), ri)
+
+
+def test_eval_ann_info_matches_the_reference_evaluation_loop():
+    """`eval_ap.eval_ann_info` and the oracle's restatement against the records the reference's own `evaluate_3d` loop produced from
+    the same `GD3DTarget`s (tests/golden/make_golden_eval_loop.py executes the loop of evaluation/evaluate_3d.py:44-71): the loop
+    reads `res_["masks"]`, `res_["labels"]`, `res_["extra_features"]`, `res_["scene_id"]`, `res_.pred_pts_seg` off this package's
+    target type, sums the ids of overlapping instance masks, and marks uncovered points -1 / bg_class_id."""
+    from oracle import eval_ref as E
+    from segdino3d_amd import eval_ap
+    from segdino3d_amd.gtypes import GD3DTarget
+    z = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "eval_loop.npz"))
+    bg = int(z["bg_class_id"])
+    for i in range(3):
+        n = int(z[f"s{i}_n"])
+        masks = np.unpackbits(z[f"s{i}_masks"], axis=1)[:, :n].astype(bool)
+        inst, sem = E.eval_ann_from_target(masks, z[f"s{i}_labels"], bg)
+        assert np.array_equal(inst, z[f"s{i}_inst"]) and np.array_equal(sem, z[f"s{i}_sem"])
+        t = GD3DTarget(masks=torch.from_numpy(masks)[:, :, None], labels=torch.from_numpy(z[f"s{i}_labels"]), scene_id=f"s{i}",
+                       extra_features=dict(super_point_masks=torch.from_numpy(z[f"s{i}_sp"])))
+        ann = eval_ap.eval_ann_info(t, bg)
+        assert np.array_equal(ann["pts_instance_mask"].numpy(), z[f"s{i}_inst"]) and np.array_equal(ann["pts_semantic_mask"].numpy(), z[f"s{i}_sem"])
+        assert ann["lidar_idx"] == f"s{i}" and torch.equal(ann["sp_pts_mask"], t["extra_features"]["super_point_masks"])
+    assert (z["s0_inst"] > 8).sum() == 0 and (z["s0_inst"] == 3).sum() > 0        # the overlap of instances 1 and 2 reads as id 3

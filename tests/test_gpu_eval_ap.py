@@ -221,3 +221,66 @@ def test_evaluator_level_metrics_match_reference_golden():
     host = eval_ap.evaluator_instance_metrics([(a, dict(p, pts_instance_mask=[torch.from_numpy(p["pts_instance_mask"][0]).to(d)])) for a, p in results],
                                               classes, valid, n_stuff)
     assert all((np.isnan(host[str(k)]) and np.isnan(v)) or abs(host[str(k)] - v) < 1e-12 for k, v in zip(z["keys"], z["vals"]))
+
+
+def test_evaluation_loop_chain_on_the_device_equals_the_oracle_chain():
+    """The caller chain either side of the forward, end to end: model output + ground-truth target -> the evaluation loop's record
+    (`eval_ann_info`, evaluate_3d.py:49-63) -> `map_inst_markup` -> instance AP (`evaluator_instance_metrics`, evaluator_3d.py:124-219),
+    everything on the device, against the same chain through the oracle (CPU forward, numpy records, numpy AP).  Ground truth: two
+    stuff "instances" (classes 0 / 1: they must drop out) plus up to ten objects cut from the oracle's own best predictions and
+    labelled like them, so that ground truth and predictions meet in the same classes."""
+    from oracle import eval_ref as E
+    from oracle import model_ref
+    from oracle import postprocess_ref as P
+    import segdino3d_amd as seg
+    from segdino3d_amd import eval_ap
+    from segdino3d_amd.configs import scannet200_model_cfg
+    from segdino3d_amd.synth import make_scene, sharpen_random_model, structure_scene
+    d = dev()
+    pts, tgt = make_scene(21, n_points=8000, n_superpoints=64, n_query2d=8)
+    structure_scene(pts, tgt)
+    cfg = scannet200_model_cfg(query_num=-1)
+    cfg["test_cfg"]["npoint_thr"] = 20
+    cfg["filter_outofbox_points_eval"] = False
+    torch.manual_seed(0)
+    model = sharpen_random_model(seg.build_architecture(cfg).eval())
+    sd = {k: v.detach().clone() for k, v in model.state_dict().items()}
+    ef = tgt.extra_features
+    ref = model_ref.forward_eval(sd, pts, ef["points_2dfeats"], ef["super_point_masks"], ef["query2d_feats"], ef["query2d_pos"],
+                                 tgt.masks, query_num=-1, test_cfg=P.TestCfg(npoint_thr=20), box_filter=False)
+    r_masks, r_labels, r_scores = ref["pts_instance_mask"][0].numpy().astype(bool), ref["instance_labels"].numpy(), ref["instance_scores"].numpy()
+    N = r_masks.shape[1]
+    taken = np.zeros(N, dtype=bool)
+    gt_m, gt_l = [], []
+    for i in np.argsort(-r_scores, kind="stable"):
+        m = r_masks[i] & ~taken
+        if m.sum() >= 100 and m.sum() >= 0.5 * r_masks[i].sum():
+            gt_m.append(m); gt_l.append(int(r_labels[i]) + 2)            # dataset class = thing index + the two stuff classes
+            taken |= m
+        if len(gt_m) == 10:
+            break
+    assert len(gt_m) >= 1
+    rest = np.flatnonzero(~taken)
+    stuff0, stuff1 = np.zeros(N, dtype=bool), np.zeros(N, dtype=bool)
+    stuff0[rest[: len(rest) // 3]] = True                                # "wall" and "floor" take two thirds of the uncovered points,
+    stuff1[rest[len(rest) // 3: 2 * len(rest) // 3]] = True              # the last third stays unannotated (-1 / bg_class_id)
+    gt_masks = torch.from_numpy(np.stack([stuff0, stuff1] + gt_m))[:, :, None]
+    gt_labels = torch.tensor([0, 1] + gt_l)
+    tgt.masks, tgt.labels = gt_masks.clone(), gt_labels.clone()
+    model.to(d)
+    model.to_host = False
+    with torch.no_grad():
+        out = model([pts.to(d)], [tgt.to(d)])[0]
+    classes = tuple(f"c{i}" for i in range(200)) + ("unlabeled",)
+    valid = tuple(range(1, 201))
+    opts = dict(min_region_sizes=np.array([50]))
+    m_hip = eval_ap.evaluator_instance_metrics([(eval_ap.eval_ann_info(out, 200), out.pred_pts_seg)], classes, valid, 2, options=opts, groups={})
+    inst, sem = E.eval_ann_from_target(gt_masks[:, :, 0].numpy(), gt_labels.numpy(), 200)
+    pred = dict(pts_instance_mask=[r_masks], instance_labels=r_labels, instance_scores=r_scores)
+    m_ref, sems, insts = E.evaluator_instance_metrics([(dict(pts_semantic_mask=sem, pts_instance_mask=inst), pred)], classes, valid, 2,
+                                                      options=opts, groups={})
+    assert (insts[0] >= 0).any() and (insts[0] == -1).any() and set(np.unique(sems[0][insts[0] >= 0])) <= set(valid[2:])
+    assert m_ref["all_ap_25%"] > 0.05                                      # not a trivially-zero operating point
+    print("evaluator-level mAP oracle / HIP:", {k: (round(float(m_ref[k]), 5), round(float(m_hip[k]), 5)) for k in ("all_ap", "all_ap_50%", "all_ap_25%")})
+    for key in ("all_ap", "all_ap_50%", "all_ap_25%"):
+        assert abs(m_hip[key] - m_ref[key]) < 1e-3, (key, m_hip[key], m_ref[key])
