@@ -449,3 +449,61 @@ def test_mirrored_kernel_map_equals_full_probe():
             half = ops.kernel_map(maps.keys[lvl], maps.n_vox[lvl], maps.table(lvl), offs, c2, mirrored=True)
             assert torch.equal(full, half), f"{order} level {lvl} k={ks}"
             assert int(c1.sum()) == int(c2.sum()) == int((full >= 0).sum())
+
+
+def _dense_scene(n, S, seed):
+    """Scan-like occupancy: points on three densely sampled planes (floor + two walls, ~4 points per 2 cm voxel), so that a voxel
+    has 9-17 of its 27 neighbours at level 0 - the synthetic benchmark scene has 3 - and the pair lists are long and skewed
+    (negative coordinates included: the walls cross the origin)."""
+    g = torch.Generator().manual_seed(seed)
+    per = n // 3
+    side = (per / 4.0) ** 0.5 * 0.02                                         # plane edge so that ~4 points fall into each voxel
+    u = torch.rand(n, 2, generator=g) * side - 0.3 * side
+    xyz = torch.zeros(n, 3)
+    xyz[:per, 0], xyz[:per, 1] = u[:per, 0], u[:per, 1]                       # floor z = 0
+    xyz[per:2 * per, 0], xyz[per:2 * per, 2] = u[per:2 * per, 0], u[per:2 * per, 1] + 0.3 * side   # wall y = 0
+    xyz[2 * per:, 1], xyz[2 * per:, 2] = u[2 * per:, 0], u[2 * per:, 1] + 0.3 * side               # wall x = 0
+    xyz += 0.002 * torch.randn(n, 3, generator=g)
+    pts, tgt = _scene(n=n, S=S, idx=seed)
+    pts[:, :3] = xyz
+    seeds = xyz[torch.randperm(n, generator=g)[:S]]
+    sp = torch.cdist(xyz, seeds).argmin(1)
+    sp[:S] = torch.arange(S)                                                 # every id used
+    tgt.extra_features["super_point_masks"] = sp
+    return pts, tgt
+
+
+@pytest.mark.parametrize("which", ["mink", "spconv"])
+def test_backbones_on_a_dense_surface_scene_match_oracle(which):
+    """Both U-Nets against the oracle on a scene with scan-like neighbour counts (the parity scenes above are as sparse as the
+    benchmark scene): long offset lists, many pairs per output row in pass 2, heavy voxels in the mean / pooling kernels."""
+    from oracle import sparse_ref as R
+    from segdino3d_amd.sparse import SceneMaps
+    d = dev()
+    pts, tgt = _dense_scene(24000, 120, 31)
+    if which == "mink":
+        from segdino3d_amd.backbone_mink import Res16UNet34C
+        m = Res16UNet34C(in_channels=259, out_channels=96, config=dict(dilations=[1, 1, 1, 1], conv1_kernel_size=5, bn_momentum=0.02),
+                         voxel_size=0.02, mode_fuse_2d_feat="early_fusion", add_positional_embedding=True).eval()
+        ref_fn = R.mink_forward_wrapper
+    else:
+        from segdino3d_amd.backbone_spconv import SpConvUNet
+        m = SpConvUNet(num_planes=[32 * (i + 1) for i in range(5)], return_blocks=True, voxel_size=0.02,
+                       mode_fuse_2d_feat="early_fusion", add_positional_embedding=True).eval()
+        ref_fn = R.spconv_forward_wrapper
+    sd = {k: det_param("backbone." + k, v.shape).to(v.dtype) for k, v in m.state_dict().items()}
+    m.load_state_dict(sd)
+    m.to(d)
+    maps = SceneMaps(pts.to(d), 0.02, 2, shift_to_min=(which == "spconv"))
+    nbr = maps.same(0, 3)
+    per_row = float((nbr >= 0).sum()) / nbr.shape[1]
+    f, pos, _ = m.forward_wrapper([pts.to(d)], [tgt.to(d)], return_sp_mean_pos=True)
+    tgt = tgt.to("cpu")
+    rf, rp, _ = ref_fn({"backbone." + k: v for k, v in sd.items()}, pts, tgt.extra_features["points_2dfeats"], tgt.extra_features["super_point_masks"])
+    torch.testing.assert_close(pos[0].cpu(), rp, rtol=5e-5, atol=1e-4)
+    err = (f[0].cpu() - rf).abs().max().item()
+    scale = rf.abs().max().item()
+    print(f"{which} on the dense scene: {nbr.shape[1]} voxels from {pts.shape[0]} points, {per_row:.1f} neighbours per voxel at level 0; "
+          f"features max abs err {err:.3e} at max |f| {scale:.3f} ({err / scale:.2e} relative)")
+    assert per_row > 8.0
+    assert err <= BACKBONE_REL_TOL * max(scale, 1.0), f"backbone features differ: max abs err {err} (scale {scale})"
