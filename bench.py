@@ -149,6 +149,8 @@ def main():
     ap.add_argument("--query2d", type=int, default=300)
     ap.add_argument("--query-num", type=int, default=200)
     ap.add_argument("--scene-pool", type=int, default=2, help="distinct synthetic scenes per rank (cycled)")
+    ap.add_argument("--scene-layout", choices=("benchmark", "scan"), default="benchmark",
+                    help="synth.make_scene layout: 'benchmark' = the scene of every reported number; 'scan' = mesh-like surface sampling")
     ap.add_argument("--streams", type=int, default=4,
                     help="scenes in flight per GPU (host threads x HIP streams, segdino3d_amd.dist_eval.PipelinedRunner)")
     ap.add_argument("--decoder-dtype", choices=("fp32", "bf16"), default=os.environ.get("SD3D_DECODER_DTYPE", "fp32"),
@@ -185,7 +187,7 @@ def main():
     scene_args = (args.points, args.superpoints, args.query2d)
     pool = []
     for j in range(max(1, args.scene_pool)):
-        pts, tgt = make_scene(rank * 100 + j, *scene_args)
+        pts, tgt = make_scene(rank * 100 + j, *scene_args, layout=args.scene_layout)
         pool.append((pts.to(device), tgt.to(device)))
 
     def step(i):
@@ -343,7 +345,7 @@ def main():
                                    f"{args.streams} independent scenes in flight per GPU (`value`) / one in flight (`single_scene`); "
                                    "fp32 sparse backbone (Res16UNet34C) + " + ("bf16-MFMA" if bf16_dec else "fp32") +
                                    " decoder + post-processing, device-resident in/out",
-                       "points": args.points, "superpoints": args.superpoints, "queries_2d": args.query2d,
+                       "points": args.points, "superpoints": args.superpoints, "queries_2d": args.query2d, "scene_layout": args.scene_layout,
                        "query_num": args.query_num, "voxels_per_level": maps.n_vox, "parallelism": f"scene-sharded x{world}",
                        "scenes_in_flight_per_gpu": args.streams, "single_stream_latency_ms": round(latency_ms, 3),
                        "untimed_preroll_scenes": n_pre, "host_cores_per_rank": cores_per_rank},
