@@ -219,6 +219,11 @@ int sd3d_run_layers(const sd3d_layer* layers, int n_layers, const sd3d_table* ta
  * :708-709, :82-84, :187-188).  act: 0 none, 1 ReLU (input_proj, :228-229). */
 int sd3d_layernorm(const float* x, int ld_x, const float* res, int ld_res, const float* w, const float* b, float eps,
                    int64_t M, int D, float* out, int ld_out, int act, void* stream);
+/* out = act(LayerNorm(x wt^T + bias + res) * ln_w + ln_b) in ONE launch for few rows (the 200-query tensors of the decoder): the
+ * attention out-projection / second FFN Linear with the residual add and norm that follow it (decoder :690-691, :708-709, :82-84,
+ * :187-188).  wt [Cout = 256, Cin], Cin a multiple of 16; bias / res optional; fp32 MFMA, two-pass row statistics. */
+int sd3d_linear_layernorm(const float* x, int ld_x, int64_t M, int Cin, const float* wt, int Cout, const float* bias, const float* res, int ld_res,
+                          const float* ln_w, const float* ln_b, float eps, int act, float* out, int ld_out, void* stream);
 /* PositionEmbeddingCoordsSine.get_sine_embeddings (utils.py:53-105) incl. shift_scale_points
  * (pc_util.py:48-76).  range = (lo[3], hi[3]); dim_t / axis: per output channel (host tables);
  * optional box modulation out *= mod_num / mod_den (decoder :660-663; ld_den may be 0 = broadcast). */

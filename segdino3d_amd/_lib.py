@@ -55,6 +55,7 @@ SIGNATURES = {
     "sd3d_pair_conv": (_i, [_p, _i, _i, _p, _i, _p, _p, _l, _p, _p, _i, _i, _i, _l, _p, _p, _p, _i, _p, _i, _i, _p, _z, _p]),
     "sd3d_run_layers": (_i, [_p, _i, _p, _i, _p, _i, _p, _z, _p, _z, _p]),
     "sd3d_layernorm": (_i, [_p, _i, _p, _i, _p, _p, _f, _l, _i, _p, _i, _i, _p]),
+    "sd3d_linear_layernorm": (_i, [_p, _i, _l, _i, _p, _i, _p, _p, _i, _p, _p, _f, _i, _p, _i, _p]),
     "sd3d_sine_pe": (_i, [_p, _i, _l, _p, _p, _p, _i, _p, _i, _p, _i, _p, _i, _p]),
     "sd3d_fourier_pe": (_i, [_p, _i, _l, _p, _p, _i, _i, _p, _i, _p]),
     "sd3d_attention_ws_bytes": (_z, [_i, _i]),

@@ -48,6 +48,8 @@ int launch_pair_conv(const float*, int, int, const float*, int, const int32_t*, 
                      hipStream_t);
 
 int launch_layernorm(const float*, int, const float*, int, const float*, const float*, float, int64_t, int, float*, int, int, hipStream_t);
+int launch_linear_layernorm(const float*, int, int64_t, int, const float*, int, const float*, const float*, int, const float*, const float*, float, int,
+                            float*, int, hipStream_t);
 int launch_sine_pe(const float*, int, int64_t, const float*, const float*, const int8_t*, int, const float*, int, const float*, int, float*, int, hipStream_t);
 struct AttnParams {
     const float* q[2]; int ldq[2];
@@ -233,6 +235,10 @@ int sd3d_slab_conv(const float* in0, int ld0, int C0, const float* in1, int ld1,
 int sd3d_layernorm(const float* x, int ld_x, const float* res, int ld_res, const float* w, const float* b, float eps, int64_t M,
                    int D, float* out, int ld_out, int act, void* stream) {
     return launch_layernorm(x, ld_x, res, ld_res, w, b, eps, M, D, out, ld_out, act, ST);
+}
+int sd3d_linear_layernorm(const float* x, int ld_x, int64_t M, int Cin, const float* wt, int Cout, const float* bias, const float* res, int ld_res,
+                          const float* ln_w, const float* ln_b, float eps, int act, float* out, int ld_out, void* stream) {
+    return launch_linear_layernorm(x, ld_x, M, Cin, wt, Cout, bias, res, ld_res, ln_w, ln_b, eps, act, out, ld_out, ST);
 }
 int sd3d_sine_pe(const float* xyz, int ld_xyz, int64_t n, const float* range, const float* dim_t, const int8_t* axis, int d_pos,
                  const float* mod_num, int ld_num, const float* mod_den, int ld_den, float* out, int ld_out, void* stream) {

@@ -75,6 +75,110 @@ int launch_layernorm(const float* x, int ld_x, const float* res, int ld_res, con
 }
 
 // ---------------------------------------------------------------------------------------------
+// Projection + residual + LayerNorm in one launch for the decoder's few-hundred-row tensors (200 queries):
+//     out = act(LayerNorm(x W^T + bias + res) * g + b),   W [256, Cin]
+// (attention out-projection / second FFN Linear followed by the residual add and the norm: decoder :690-691, :708-709, :82-84,
+// :187-188).  One workgroup owns 16 rows x all 256 columns - the whole LayerNorm row - as four waves of 64 columns on
+// v_mfma_f32_16x16x4_f32 (A = 16 rows x 4 channels, B = 4 channels x 16 columns); the row statistics meet in LDS (two-pass mean /
+// variance like layernorm_kernel).  Both operands are read as dwordx4 along the channel axis: lane (i, kq) holds channels
+// 16 g + 4 kq .. + 3 of its row / column, and MFMA e of the group contracts {16 g + 4 kq + e}.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void linear_layernorm_kernel(const float* __restrict__ x, int ld_x, const float* __restrict__ wt, int Cin,
+                                                               const float* __restrict__ bias, const float* __restrict__ res, int ld_res,
+                                                               const float* __restrict__ g, const float* __restrict__ b, float eps, int64_t M,
+                                                               float* __restrict__ out, int ld_out, int act) {
+    __shared__ float red[2][4][16];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int c16 = lane & 15, kq = lane >> 4;
+    const int64_t row0 = (int64_t)blockIdx.x * 16;
+    const int64_t arow = row0 + c16 < M ? row0 + c16 : M - 1;
+    const float* __restrict__ xa = x + arow * ld_x + 4 * kq;
+    const float* __restrict__ wb = wt + (int64_t)(wv * 64 + c16) * Cin + 4 * kq;
+    f32x4 acc[4];
+#pragma unroll
+    for (int cb = 0; cb < 4; ++cb) acc[cb] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const int ngroups = Cin >> 4;
+#pragma unroll 4
+    for (int gi = 0; gi < ngroups; ++gi) {
+        const f32x4 a = *(const f32x4*)(xa + 16 * gi);
+        f32x4 w4[4];
+#pragma unroll
+        for (int cb = 0; cb < 4; ++cb) w4[cb] = *(const f32x4*)(wb + (int64_t)cb * 16 * Cin + 16 * gi);
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+#pragma unroll
+            for (int cb = 0; cb < 4; ++cb) acc[cb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[e], w4[cb][e], acc[cb], 0, 0, 0);
+    }
+    // acc[cb][i] = (x W^T)[row0 + 4 kq + i][wv * 64 + cb * 16 + c16]
+    float s[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int cb = 0; cb < 4; ++cb) {
+        const int col = wv * 64 + cb * 16 + c16;
+        const float bv = bias ? bias[col] : 0.f;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int64_t r = row0 + 4 * kq + i;
+            float t = acc[cb][i] + bv;
+            if (res && r < M) t += res[r * ld_res + col];
+            acc[cb][i] = t;
+            s[i] += t;
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+#pragma unroll
+        for (int o = 8; o > 0; o >>= 1) s[i] += __shfl_xor(s[i], o, 64);         // the 16 lanes that share kq: this wave's 64 columns
+    }
+    if (c16 == 0) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) red[0][wv][4 * kq + i] = s[i];
+    }
+    __syncthreads();
+    float mean[4], q[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int rr = 4 * kq + i;
+        mean[i] = ((red[0][0][rr] + red[0][1][rr]) + (red[0][2][rr] + red[0][3][rr])) * (1.0f / 256.0f);
+#pragma unroll
+        for (int cb = 0; cb < 4; ++cb) { const float d = acc[cb][i] - mean[i]; q[i] += d * d; }
+#pragma unroll
+        for (int o = 8; o > 0; o >>= 1) q[i] += __shfl_xor(q[i], o, 64);
+    }
+    if (c16 == 0) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) red[1][wv][4 * kq + i] = q[i];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int rr = 4 * kq + i;
+        const int64_t r = row0 + rr;
+        const float var = ((red[1][0][rr] + red[1][1][rr]) + (red[1][2][rr] + red[1][3][rr])) * (1.0f / 256.0f);
+        const float rstd = 1.0f / sqrtf(var + eps);
+        if (r < M) {
+#pragma unroll
+            for (int cb = 0; cb < 4; ++cb) {
+                const int col = wv * 64 + cb * 16 + c16;
+                float y = (acc[cb][i] - mean[i]) * rstd * g[col] + b[col];
+                if (act == 1) y = fmaxf(y, 0.f);
+                out[r * ld_out + col] = y;
+            }
+        }
+    }
+}
+
+int launch_linear_layernorm(const float* x, int ld_x, int64_t M, int Cin, const float* wt, int Cout, const float* bias, const float* res,
+                            int ld_res, const float* g, const float* b, float eps, int act, float* out, int ld_out, hipStream_t st) {
+    if (M <= 0) return SD3D_OK;
+    if (Cout != 256 || Cin <= 0 || (Cin & 15) || (ld_x & 3) || act < 0 || act > 1)
+        return sd3d_set_error(SD3D_ERR_ARG, "linear_layernorm: Cout must be 256, Cin a multiple of 16, ld_x a multiple of 4, act 0 / 1");
+    hipLaunchKernelGGL(linear_layernorm_kernel, dim3((unsigned)cdiv(M, 16)), dim3(256), 0, st, x, ld_x, wt, Cin, bias, res, ld_res, g, b, eps, M,
+                       out, ld_out, act);
+    SD3D_CHECK_LAUNCH();
+    return SD3D_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
 // sine positional encoding (utils.py:53-105).  Per output channel c the host supplies axis[c] in
 // {0,1,2} and dim_t[c]; even channels are sin, odd cos.  rng = (lo[3], hi[3]) device.
 //   pos = ((x - lo) * 1 / (hi - lo) + 0) * 2pi / dim_t        (same operation order as the reference)

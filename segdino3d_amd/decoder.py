@@ -103,6 +103,11 @@ class _EvalF:
         return ops.linear_group(jobs)
 
     layernorm = staticmethod(ops.layernorm)
+
+    @staticmethod
+    def linear_ln(x, w, b, ln_w, ln_b, res=None):               # projection + residual + LayerNorm: one launch for few rows
+        return ops.linear_layernorm(x, w, b, ln_w, ln_b, res=res)
+
     attention = staticmethod(ops.attention)
     box_refine = staticmethod(ops.box_refine)
 
@@ -132,6 +137,11 @@ class _TrainF:
     def layernorm(x, w, b, res=None, act=None, eps=1e-5):
         from . import train_dec
         return train_dec.layernorm(x, w, b, res=res, act=act, eps=eps)
+
+    @staticmethod
+    def linear_ln(x, w, b, ln_w, ln_b, res=None):               # training: two autograd nodes
+        from . import train_dec
+        return train_dec.layernorm(train_dec.linear(x, w, b), ln_w, ln_b, res=res)
 
     @staticmethod
     def attention(q, k, v, num_heads, scale, mask_bits=None, q2=None, k2=None):
@@ -509,13 +519,13 @@ class ScanNetQueryDecoder(DerivedWeights):
             else:
                 qc = outs["qc"]
             a = F.attention(qc, kc, v, H, (2 * d // H) ** -0.5, mask_bits=bits, q2=qs, k2=kp)
-            a = _lin(a, self.cross_attn_layers[i].out_proj)
-            queries = F.layernorm(a, self.norm1[i].weight, self.norm1[i].bias, res=queries)
+            op = self.cross_attn_layers[i].out_proj
+            queries = F.linear_ln(a, op.weight, op.bias, self.norm1[i].weight, self.norm1[i].bias, res=queries)
             # ---- self-attention (:695-709)
             qkv = F.linear(queries, pk["sa_qkv_w"][i], pk["sa_qkv_b"][i], x2=query_pos)     # [Q, 3d]
             a = F.attention(qkv[:, :d], qkv[:, d:2 * d], qkv[:, 2 * d:], H, (d // H) ** -0.5)
-            a = _lin(a, self.self_attn_layers[i].out_proj)
-            queries = F.layernorm(a, self.norm2[i].weight, self.norm2[i].bias, res=queries)
+            op = self.self_attn_layers[i].out_proj
+            queries = F.linear_ln(a, op.weight, op.bias, self.norm2[i].weight, self.norm2[i].bias, res=queries)
             # ---- cross-attention to the cached DINO-X 2D object queries (:713-731, :60-86)
             if self.add_dinox_query_ca:
                 layer = self.dinox_query_cross_attn_layers[i]
@@ -524,15 +534,14 @@ class ScanNetQueryDecoder(DerivedWeights):
                 a = F.attention(q, kv2d_all[:, i * d:(i + 1) * d], kv2d_all[:, (L + i) * d:(L + i + 1) * d], H,
                                   (d // H) ** -0.5, mask_bits=bits2d)
                 if layer.fix:
-                    a = _lin(a, layer.attn.out_proj)
-                    queries = F.layernorm(a, layer.norm.weight, layer.norm.bias, res=queries)
+                    op = layer.attn.out_proj
+                    queries = F.linear_ln(a, op.weight, op.bias, layer.norm.weight, layer.norm.bias, res=queries)
                 else:
                     queries = _lin(a, layer.attn.out_proj, res=queries)
             # ---- FFN (:173-190)
             ffn = self.ffn_layers[i]
             hdn = _lin(queries, ffn.net[0], act=("relu" if self.activation_fn == "relu" else "gelu"))
-            hdn = _lin(hdn, ffn.net[3], res=queries)
-            queries = F.layernorm(hdn, ffn.norm.weight, ffn.norm.bias)
+            queries = F.linear_ln(hdn, ffn.net[3].weight, ffn.net[3].bias, ffn.norm.weight, ffn.norm.bias, res=queries)
             # ---- iterative box refinement (:735-759): the centre and the size MLP side by side, three launches for six Linears
             if self.add_box_size_pred:
                 be, se = self.bbox_embed[i].layers, self.bbox_size_embed[i].layers

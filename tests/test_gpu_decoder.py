@@ -355,3 +355,40 @@ def test_baseline_prototype_end_to_end_matches_oracle():
     assert bad <= 0.02, f"{bad:.1%} of query rows differ (max err {err.max().item():.3e})"
     pd = res[0].pred_pts_seg
     assert pd.pts_instance_mask[0].shape[1] == pts.shape[0] and pd.instance_boxes is None
+
+
+@pytest.mark.parametrize("M,Cin,with_res,act", [(200, 256, True, None), (200, 1024, True, None), (37, 256, False, None), (512, 256, True, "relu"),
+                                                (1, 256, True, None), (16, 1024, False, None)])
+def test_fused_projection_residual_layernorm(M, Cin, with_res, act):
+    """sd3d_linear_layernorm (one launch for <= 512 rows) against float64 LayerNorm(x W^T + b + res), and against the two-launch path it
+    replaces (gather_gemm + layernorm kernel) - same formula, different fp32 summation order: 2e-6 of the row scale."""
+    from segdino3d_amd import _lib, ops
+    d = dev()
+    x = det_randn(f"fl.x{M}{Cin}", (M, Cin)); w = det_randn(f"fl.w{Cin}", (256, Cin), Cin ** -0.5); b = det_randn("fl.b", (256,), 0.1)
+    res = det_randn(f"fl.r{M}", (M, 256)) if with_res else None
+    g = 1 + det_randn("fl.g", (256,), 0.1); beta = det_randn("fl.beta", (256,), 0.1)
+    # the C entry itself (ops.linear_layernorm sends contractions longer than 512 to the two-launch path: faster there)
+    xd, wd, bd, gd, betad = x.to(d), w.to(d), b.to(d), g.to(d), beta.to(d)
+    rd = None if res is None else res.to(d)
+    got = torch.empty(M, 256, device=d)
+    _lib.check(_lib.load().sd3d_linear_layernorm(xd.data_ptr(), Cin, M, Cin, wd.data_ptr(), 256, bd.data_ptr(), None if rd is None else rd.data_ptr(), 256,
+                                                 gd.data_ptr(), betad.data_ptr(), 1e-5, ops.ACT[act], got.data_ptr(), 256, ops._stream()), "linear_layernorm")
+    if Cin <= 512:
+        assert torch.equal(got, ops.linear_layernorm(xd, wd, bd, gd, betad, res=rd, act=act))
+    pre = x.double() @ w.double().T + b.double() + (0 if res is None else res.double())
+    ref = torch.nn.functional.layer_norm(pre, (256,), g.double(), beta.double(), 1e-5)
+    if act == "relu":
+        ref = torch.relu(ref)
+    err = (got.cpu().double() - ref).abs().max().item()
+    assert err <= 2e-6 * max(1.0, ref.abs().max().item()) * 4, err
+    keep = ops.LINEAR_LN_MAX_ROWS
+    ops.LINEAR_LN_MAX_ROWS = 0                                    # the two-launch path
+    try:
+        two = ops.linear_layernorm(x.to(d), w.to(d), b.to(d), g.to(d), beta.to(d), res=None if res is None else res.to(d), act=act)
+    finally:
+        ops.LINEAR_LN_MAX_ROWS = keep
+    assert (two.cpu().double() - ref).abs().max().item() <= 2e-6 * max(1.0, ref.abs().max().item()) * 4
+    assert (got - two).abs().max().item() <= 1e-5
+    # rows beyond the limit take the two-launch path by themselves
+    big = ops.linear_layernorm(torch.cat([x] * (600 // M + 1)).to(d)[:600] if M < 600 else x.to(d), w.to(d), b.to(d), g.to(d), beta.to(d))
+    assert big.shape[1] == 256
