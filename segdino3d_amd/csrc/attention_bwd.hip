@@ -16,6 +16,7 @@
 #include "common.h"
 #include "../../include/segdino3d_hip.h"
 #include <math.h>
+#include <stdlib.h>
 
 struct AttnBwdParams {
     const float* q[2]; int ldq[2];
@@ -123,7 +124,7 @@ __global__ __launch_bounds__(256) void attn_bwd_q_kernel(const AttnBwdParams p) 
 }
 
 template <int NSRC>
-__global__ __launch_bounds__(256) void attn_bwd_kv_kernel(const AttnBwdParams p) {
+__global__ __launch_bounds__(512) void attn_bwd_kv_kernel(const AttnBwdParams p) {
     extern __shared__ __attribute__((aligned(16))) float smem[];      // [nw][NSRC + 1][32 ch][32 keys]
     const int nw = blockDim.x >> 6;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -246,8 +247,18 @@ int sd3d_attention_backward(const float* q0, int ldq0, const float* q1, int ldq1
     p.dv = dv; p.ld_dv = ld_dv; p.Lq = Lq; p.Lk = Lk; p.H = H; p.scale = scale;
     const int nsrc = q1 ? 2 : 1;
     const int kt = (Lk + 31) / 32, qt = (Lq + 31) / 32;
-    const int nwq = kt >= 8 ? 4 : (kt >= 2 ? 2 : 1), nwk = qt >= 8 ? 4 : (qt >= 2 ? 2 : 1);
+    // kv kernel: 8 waves per workgroup when there are >= 32 query tiles and a 128-register budget (launch bounds 512): at the
+    // training shapes (2441 queries x 3000 keys) 752 workgroups x 4 waves at two per SIMD ran two rounds of 19 query tiles each,
+    // 611 us; 8 waves x 4 per SIMD: 396 us (4 waves at the same budget: 439).  The q kernel keeps 4 waves and its 256-register
+    // budget (302 us; 324 / 362 with the kv kernel's settings).
+    const int nwq = kt >= 8 ? 4 : (kt >= 2 ? 2 : 1), nwk = qt >= 32 ? 8 : (qt >= 8 ? 4 : (qt >= 2 ? 2 : 1));
     const dim3 gq((unsigned)qt, (unsigned)H), gk((unsigned)kt, (unsigned)H);
+    static bool attr_done = false;
+    if (!attr_done) {
+        (void)hipFuncSetAttribute((const void*)attn_bwd_kv_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 8 * 2 * 4096);
+        (void)hipFuncSetAttribute((const void*)attn_bwd_kv_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, 8 * 3 * 4096);
+        attr_done = true;
+    }
     if (nsrc == 1) {
         attn_bwd_q_kernel<1><<<gq, 64 * nwq, (size_t)nwq * 1 * 4096, ST>>>(p);
         attn_bwd_kv_kernel<1><<<gk, 64 * nwk, (size_t)nwk * 2 * 4096, ST>>>(p);
