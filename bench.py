@@ -10,9 +10,12 @@ fp32) whose inputs are already resident in HBM; outputs stay on the device.  Sce
 units, so ranks shard them with no data-path collective (weak scaling); one all-gather of per-scene
 records (scene id, points, voxels, ms) closes the run, as in the north-star's metric exchange.
 Inside a rank the K timed steps are issued by `--streams` host threads, each on its own HIP stream
-(segdino3d_amd.dist_eval.PipelinedRunner): a forward is ~800 dependent launches, many too small to
-fill 256 CUs, so 3 scenes in flight raise scenes/s by ~45 % over back-to-back forwards; the
-single-stream latency is reported next to it (`config.single_stream_latency_ms`).
+(segdino3d_amd.dist_eval.PipelinedRunner): a forward is ~500 dependent launches, many too small to
+fill 256 CUs, so several scenes in flight raise scenes/s over back-to-back forwards; the
+single-stream latency is reported next to it (`single_scene`).
+`--gpus N` with N > 1 and no RANK in the environment starts the N ranks itself (one child process per GPU,
+segdino3d_amd.dist_eval.rank_commands - the parent never touches the GPU), relays rank 0's JSON line and
+exits non-zero if any rank fails; under an external launcher (torch.distributed.run) it is one of the ranks.
 
 Prints ONE JSON line (rank 0) with the contract fields plus
   roofline     : the dominant kernel = the pair-major sparse convolution (sd3d_pair_conv: pair_gemm_* + pair_reduce_kernel,
@@ -120,23 +123,69 @@ def cpu_baseline(model, scene_args, n_timed=4):
                       f"torch CPU fp32 with {threads} threads (oracle/model_ref.forward_eval)"}
 
 
-def pin_rank_to_cores(local_rank: int, local_world: int, threads_per_rank: int):
-    """One process per GPU drives `threads_per_rank` issuing threads; with 8 ranks on a node they must not migrate across each
-    other's cores (or NUMA nodes): rank r takes the r-th slice of the cores this process may run on.  Returns the slice size."""
+def pin_rank_to_cores(local_rank: int, local_world: int, threads_per_rank: int, share_gpu: bool = False):
+    """One process per GPU drives `threads_per_rank` issuing threads; with 8 ranks on a node they must stay on the cores of
+    the NUMA node their GPU hangs off (`/sys/bus/pci/devices/<bdf>/numa_node`) and off each other's cores: ranks whose GPUs
+    share a node split that node's cores evenly (segdino3d_amd.dist_eval.cores_for_rank; an even slice of the allowed cores
+    when the platform reports no node).  Returns (cores in the slice, NUMA node or -1)."""
+    from segdino3d_amd.dist_eval import cores_for_rank, gpu_numa_node
     try:
-        cores = sorted(os.sched_getaffinity(0))
+        allowed = sorted(os.sched_getaffinity(0))
     except (AttributeError, OSError):
-        return 0
-    per = len(cores) // max(1, local_world)
-    if local_world <= 1 or per < 1:
-        return len(cores)
-    mine = cores[local_rank * per:(local_rank + 1) * per]
+        return 0, -1
+    if local_world <= 1:
+        return len(allowed), -1
+    nodes = []
+    for r in range(local_world):
+        node = -1
+        try:                                                   # properties only: no context is created on the other ranks' GPUs
+            pr = torch.cuda.get_device_properties(0 if share_gpu else r)
+            bdf = f"{pr.pci_domain_id:04x}:{pr.pci_bus_id:02x}:{pr.pci_device_id:02x}.0"
+            node = gpu_numa_node(bdf)
+        except Exception:  # noqa: BLE001 - placement is best effort
+            node = -1
+        nodes.append(node)
+    mine = cores_for_rank(local_rank, nodes, allowed)
     try:
         os.sched_setaffinity(0, mine)
     except OSError:
-        return len(cores)
-    torch.set_num_threads(max(1, min(per, threads_per_rank)))
-    return per
+        return len(allowed), nodes[local_rank]
+    torch.set_num_threads(max(1, min(len(mine), threads_per_rank)))
+    return len(mine), nodes[local_rank]
+
+
+def launch_ranks(n_ranks: int, argv):
+    """Parent of a self-launched multi-GPU run: starts one child per GPU, relays rank 0's stdout (the JSON line), waits for
+    all of them and returns the exit code (non-zero if any rank failed; the others are then terminated by PID)."""
+    import socket
+    import subprocess
+    from segdino3d_amd.dist_eval import rank_commands
+    share = os.environ.get("SD3D_SHARE_GPU") == "1"
+    n_dev = torch.cuda.device_count()                            # does not initialise the GPU
+    if n_dev < n_ranks and not share:
+        print(f"bench.py: --gpus {n_ranks} but only {n_dev} GPU(s) are visible (SD3D_SHARE_GPU=1 + SD3D_DIST_BACKEND=gloo "
+              f"rehearses the multi-rank flow on one GPU)", file=sys.stderr)
+        return 2
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    procs = []
+    for rank, (cmd, env) in enumerate(rank_commands(os.path.abspath(__file__), argv, n_ranks, port)):
+        procs.append(subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE if rank == 0 else sys.stderr))
+    out0, _ = procs[0].communicate()
+    rc = procs[0].returncode
+    for p in procs[1:]:
+        if rc != 0 and p.poll() is None:
+            p.terminate()
+        try:
+            p.wait(timeout=120)
+        except subprocess.TimeoutExpired:
+            p.kill()
+            p.wait()
+        rc = rc or p.returncode
+    sys.stdout.write(out0.decode())
+    sys.stdout.flush()
+    return rc
 
 
 def main():
@@ -159,16 +208,19 @@ def main():
     ap.add_argument("--preroll-seconds", type=float, default=2.0, help="untimed pipelined pre-roll before the timed K steps")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "RANK" not in os.environ:            # started without a launcher: be the launcher
+        raise SystemExit(launch_ranks(args.gpus, sys.argv[1:]))
     rank = int(os.environ.get("RANK", 0))
     local_rank = int(os.environ.get("LOCAL_RANK", 0))
     world = int(os.environ.get("WORLD_SIZE", 1))
-    if world != args.gpus and world > 1:
+    if world != args.gpus:                                     # never print a line whose n_gpus differs from --gpus
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     # SD3D_DIST_BACKEND=gloo + SD3D_SHARE_GPU=1: rehearsal of the multi-rank flow on ONE GPU (ranks share device 0,
     # collectives on CPU tensors); the real runs use "nccl" (= RCCL over xGMI), one GPU per rank.
     backend = os.environ.get("SD3D_DIST_BACKEND", "nccl")
-    dev_index = 0 if os.environ.get("SD3D_SHARE_GPU") == "1" else local_rank
-    cores_per_rank = pin_rank_to_cores(local_rank, int(os.environ.get("LOCAL_WORLD_SIZE", world)), args.streams)
+    share_gpu = os.environ.get("SD3D_SHARE_GPU") == "1"
+    dev_index = 0 if share_gpu else local_rank
+    cores_per_rank, numa_node = pin_rank_to_cores(local_rank, int(os.environ.get("LOCAL_WORLD_SIZE", world)), args.streams, share_gpu)
     torch.cuda.set_device(dev_index)
     device = torch.device("cuda", dev_index)
     comm_device = device if backend == "nccl" else torch.device("cpu")
@@ -348,7 +400,7 @@ def main():
                        "points": args.points, "superpoints": args.superpoints, "queries_2d": args.query2d, "scene_layout": args.scene_layout,
                        "query_num": args.query_num, "voxels_per_level": maps.n_vox, "parallelism": f"scene-sharded x{world}",
                        "scenes_in_flight_per_gpu": args.streams, "single_stream_latency_ms": round(latency_ms, 3),
-                       "untimed_preroll_scenes": n_pre, "host_cores_per_rank": cores_per_rank},
+                       "untimed_preroll_scenes": n_pre, "host_cores_per_rank": cores_per_rank, "gpu_numa_node": numa_node},
             "roofline": roofline, "cpu_baseline": cpu,
             "per_rank_records": records,
         }

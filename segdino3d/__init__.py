@@ -25,5 +25,6 @@ if len(__path__) > 1:
         from .datasets.dataset import *  # noqa: E402,F401,F403
         from .datasets.preparer import *  # noqa: E402,F401,F403
         from .datasets.transform import *  # noqa: E402,F401,F403
-    except ImportError as _e:  # pragma: no cover - depends on the host's Python environment
+    except Exception as _e:  # noqa: BLE001  # pragma: no cover - depends on the host's Python environment (any failure of the
+        # reference's dataset side - missing wheels, registry clashes, version mismatches - must not break model-only use)
         datasets_import_error = _e

@@ -15,9 +15,13 @@ _TLS = threading.local()
 
 
 class capture:
-    def __init__(self):
+    def __init__(self, keep_all: bool = False):
+        """keep_all=False (default): `maps` holds the voxel maps of the MOST RECENT forward only (a scene's neighbour tables and
+        pair lists are > 100 MB at 150 k points; a scope around an evaluation loop must not accumulate them).  keep_all=True keeps
+        every forward's maps for the lifetime of the scope."""
+        self.keep_all = bool(keep_all)
         self.outputs = None          # decoder output dict of the most recent forward in the scope
-        self.maps = []               # sparse.SceneMaps, one per scene run in the scope
+        self.maps = []               # sparse.SceneMaps of the most recent forward (all forwards with keep_all)
         self.sp_feats = None         # backbone output: per-scene superpoint features / positions
         self.sp_pos = None
 
@@ -29,6 +33,13 @@ class capture:
     def __exit__(self, *exc):
         _TLS.cap = self._prev
         return False
+
+    def record_maps(self, maps):
+        """Called by the backbones' forward_wrapper with the maps of the scenes of ONE forward."""
+        if self.keep_all:
+            self.maps.extend(maps)
+        else:
+            self.maps = list(maps)
 
 
 def active():

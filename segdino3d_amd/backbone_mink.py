@@ -264,7 +264,7 @@ class Res16UNetBase(DerivedWeights):
         scenes = [self._scene_inputs(p, t) for p, t in zip(samples, targets)]
         cap = _trace.active()
         if cap is not None:
-            cap.maps.extend(s[0] for s in scenes)
+            cap.record_maps([s[0] for s in scenes])
         if self.training and len(scenes) > 1:
             # one block-diagonal tensor for the whole batch, as ME's batch_sparse_collate builds (:624-627): convolutions stay
             # within their scene, every BatchNorm sees the voxels of all scenes

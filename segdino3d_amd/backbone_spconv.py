@@ -212,7 +212,7 @@ class SpConvUNet(DerivedWeights):
             scenes.append((maps, vf, pts, sp, el))
         cap = _trace.active()
         if cap is not None:
-            cap.maps.extend(s[0] for s in scenes)
+            cap.record_maps([s[0] for s in scenes])
         if self.training and len(scenes) > 1:
             # the batch as one block-diagonal tensor (spconv's batched SparseConvTensor, :378-379): BatchNorm over all scenes
             from .sparse import BatchedMaps

@@ -190,12 +190,17 @@ __global__ __launch_bounds__(256) void pair_fill_batch_kernel(const PLBatch b) {
             if ((int64_t)(seg / PT + t) * PT < T.p_cap) T.tile_k[seg / PT + t] = k;
         for (int e = tot_k + tid; e < seg_len; e += 256)       // the segment's padding
             if ((int64_t)seg + e < T.p_cap) T.in_idx[seg + e] = -1;
-        if (k == T.K - 1) {                                    // past the last segment: unused capacity reads as "no pair"
+        if (k == T.K - 1 && tid == 0) {                        // number of real tiles, after the last slot
             const int64_t end = (int64_t)seg + seg_len < T.p_cap ? (int64_t)seg + seg_len : T.p_cap;
-            for (int64_t e = end + tid; e < T.p_cap; e += 256) T.in_idx[e] = -1;
-            for (int64_t t = end / PT + tid; t < T.p_cap / PT; t += 256) T.tile_k[t] = -1;
-            if (tid == 0) T.tile_k[T.p_cap / PT] = (int)(end / PT);
+            T.tile_k[T.p_cap / PT] = (int)(end / PT);
         }
+    }
+    if (k == T.K - 1) {
+        // past the last segment: unused capacity reads as "no pair".  Every row block of the last offset fills its slice
+        // (with worst-case sized lists, SD3D_EXACT_PAIRS=0, the tail is tens of MB: one workgroup would sit on the critical path)
+        const int64_t end = (int64_t)seg + seg_len < T.p_cap ? (int64_t)seg + seg_len : T.p_cap;
+        for (int64_t e = end + (int64_t)blk * 256 + tid; e < T.p_cap; e += (int64_t)T.nblk * 256) T.in_idx[e] = -1;
+        for (int64_t t = end / PT + (int64_t)blk * 256 + tid; t < T.p_cap / PT; t += (int64_t)T.nblk * 256) T.tile_k[t] = -1;
     }
     int base = seg + T.blk_cnt[(int64_t)k * T.nblk + blk];
     const uint64_t lt = (1ull << lane) - 1ull;
@@ -644,7 +649,11 @@ int launch_pair_lists_batch(int n, const int32_t* const* nbr, const int* K, cons
     size_t off = 0;
     int wg = 0, kk = 0;
     for (int i = 0; i < n; ++i) {
-        if (K[i] <= 0 || M[i] <= 0) continue;
+        if (K[i] <= 0 || M[i] <= 0) {                          // no rows: a later pair_conv on this table must see "0 real tiles"
+            if (tile_k[i] && p_cap[i] > 0 && hipMemsetAsync(tile_k[i] + p_cap[i] / PT, 0, sizeof(int32_t), st) != hipSuccess)
+                return sd3d_set_error(SD3D_ERR_LAUNCH, "pair_lists_batch: memset failed");
+            continue;
+        }
         if (p_cap[i] <= 0 || (p_cap[i] % PT)) return sd3d_set_error(SD3D_ERR_ARG, "pair_lists_batch: p_cap must be a positive multiple of 128");
         PLTable& T = b.t[b.n++];
         T.nbr = nbr[i]; T.pos = pos[i]; T.in_idx = in_idx[i]; T.tile_k = tile_k[i]; T.M = M[i]; T.p_cap = p_cap[i]; T.K = K[i];

@@ -70,12 +70,87 @@ def run_sharded(n_scenes: int, process_scene: Callable[[int], Sequence[float]], 
     return merge_by_scene(all_gather_records(local))
 
 
+# ---- one process per GPU: launch line and host-core placement ------------------------------------------------------------
+def rank_commands(script: str, argv: Sequence[str], n_ranks: int, port: int, python: str = None, base_env=None):
+    """The N child processes of a self-launched run: [(command, environment)] for rank 0..N-1, one per GPU of ONE node - what
+    `python -m torch.distributed.launch --nproc_per_node N` of the reference's launch lines (`scripts/eval.sh:12-19`,
+    `scripts/train.sh:21-28`) sets up, without the launcher in between: RANK / LOCAL_RANK / WORLD_SIZE / LOCAL_WORLD_SIZE,
+    rendezvous on 127.0.0.1 (the container's hostname may not resolve).  The PARENT that calls this must not have touched
+    the GPU (the children are fresh processes, never an exec of an initialised one)."""
+    import sys
+    python = python or sys.executable
+    base = dict(os.environ if base_env is None else base_env)
+    base.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")         # dmabuf IPC: RCCL across processes needs it on this driver
+    out = []
+    for r in range(int(n_ranks)):
+        env = dict(base)
+        env.update(RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n_ranks), LOCAL_WORLD_SIZE=str(n_ranks),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        out.append(([python, script] + list(argv), env))
+    return out
+
+
+def parse_cpulist(text: str) -> List[int]:
+    """'0-3,8,10-11' (sysfs cpulist) -> [0, 1, 2, 3, 8, 10, 11]."""
+    cores = []
+    for part in text.strip().split(","):
+        if not part:
+            continue
+        lo, _, hi = part.partition("-")
+        cores += list(range(int(lo), int(hi or lo) + 1))
+    return cores
+
+
+def gpu_numa_node(pci_bus_id: str, sysfs_root: str = "/sys") -> int:
+    """NUMA node a GPU hangs off, from `<sysfs>/bus/pci/devices/<domain:bus:dev.fn>/numa_node` (the same file the DRM node
+    `/sys/class/drm/card*/device/numa_node` links to); -1 when the platform does not say."""
+    for name in (pci_bus_id.lower(), pci_bus_id.upper()):
+        path = os.path.join(sysfs_root, "bus", "pci", "devices", name, "numa_node")
+        try:
+            with open(path) as f:
+                return int(f.read().strip())
+        except (OSError, ValueError):
+            continue
+    return -1
+
+
+def cores_for_rank(local_rank: int, gpu_nodes: Sequence[int], allowed: Sequence[int], sysfs_root: str = "/sys") -> List[int]:
+    """Host cores for the issuing threads of `local_rank`: the cores of ITS GPU's NUMA node (gpu_nodes[r] = node of the GPU of
+    local rank r) that this process may run on, divided evenly among the ranks whose GPUs share that node; ranks whose node is
+    unknown (-1) - or whose node has no allowed core - share an even slice of whatever the NUMA-placed ranks leave."""
+    allowed = sorted(allowed)
+    n = len(gpu_nodes)
+    node_cores = {}
+    for node in set(gpu_nodes):
+        if node < 0:
+            continue
+        try:
+            with open(os.path.join(sysfs_root, "devices", "system", "node", f"node{node}", "cpulist")) as f:
+                cs = [c for c in parse_cpulist(f.read()) if c in set(allowed)]
+        except (OSError, ValueError):
+            cs = []
+        node_cores[node] = cs
+    placed = [r for r in range(n) if node_cores.get(gpu_nodes[r])]
+    mine = gpu_nodes[local_rank]
+    if local_rank in placed:
+        peers = [r for r in placed if gpu_nodes[r] == mine]
+        cs = node_cores[mine]
+        per = max(1, len(cs) // len(peers))
+        i = peers.index(local_rank)
+        return cs[i * per:(i + 1) * per] or cs
+    taken = set(c for r in placed for c in node_cores[gpu_nodes[r]])
+    rest = [c for c in allowed if c not in taken] or allowed
+    loose = [r for r in range(n) if r not in placed]
+    per = max(1, len(rest) // len(loose))
+    i = loose.index(local_rank)
+    return rest[i * per:(i + 1) * per] or rest
+
+
 class PipelinedRunner:
     """Keeps `n_streams` scenes in flight on ONE GPU: each worker thread owns a HIP stream and runs whole
-    eval forwards on it.  A single forward is a chain of ~800 dependent launches, many of them far too
+    eval forwards on it.  A single forward is a chain of ~500 dependent launches, many of them far too
     small to fill 256 CUs (decoder Linears on 200 queries, the stride-16 U-Net level, radix-sort passes),
-    plus two host synchronisations; a second scene's kernels fill those holes (+30 % scenes/s measured
-    with two streams).  ctypes and torch release the GIL while they launch / wait, so two Python threads
+    plus host synchronisations; another scene's kernels fill those holes.  ctypes and torch release the GIL while they launch / wait, so two Python threads
     are enough to keep both streams fed.  Results keep their submission order.
     """
 

@@ -7,6 +7,7 @@ there is deliberately no CPU path (the CPU restatement is oracle/, test infrastr
 from __future__ import annotations
 
 import threading
+from collections import OrderedDict as _collections_od
 from typing import Optional
 
 import torch
@@ -371,7 +372,7 @@ GEMM_MODE = _os.environ.get("SD3D_GEMM_MODE") or None
 if GEMM_MODE not in (None, "bf16x3", "bf16x6"):
     raise ValueError(f"SD3D_GEMM_MODE must be bf16x3 or bf16x6, got {GEMM_MODE!r}")
 SPLIT_MIN_ROWS = 2048          # below this the launch is latency-bound and stays on the fp32 kernel
-_SPLIT_CACHE = {}
+_SPLIT_CACHE = _collections_od()
 _BF16_TLS = threading.local()
 # projections of fewer rows are launch-latency bound and measured FASTER on the exact fp32 small-M kernel (200-query decoder:
 # 2.6 ms fp32, 3.5 ms with every Linear on the bf16 kernel); exact fp32 is never less precise than the bf16 the mode allows
@@ -415,21 +416,28 @@ def split_weights(wt, terms):
     return torch.stack(parts).contiguous()
 
 
-_SPLIT_CACHE_MAX = 64
+_SPLIT_CACHE_MAX = 1024          # a decoder forward touches ~110 distinct Linear weights in the bf16 mode (17 per layer + heads); owners clear on change
+_SPLIT_LOCK = threading.Lock()   # the scene threads of dist_eval.PipelinedRunner share the cache
 
 
 def _cached_split(wt, terms):
     """bf16 rounding(s) of a weight tensor, cached.  An entry keeps its SOURCE tensor alive, so the address in the key
     cannot be handed to another tensor while the entry exists (the caching allocator reuses addresses of freed blocks: a
     rebuilt set of packed weights lands where the old one was); in-place updates move `_version`.  Least-recently-used
-    entries are dropped beyond _SPLIT_CACHE_MAX; owners drop everything with clear_split_cache() when their weights change."""
+    entries are dropped beyond _SPLIT_CACHE_MAX; owners drop everything with clear_split_cache() when their weights change.
+    Lookups, insertions and evictions happen under one lock (a hit moves the entry to the end, nothing is popped on the way)."""
     key = (wt.data_ptr(), tuple(wt.shape), tuple(wt.stride()), terms, wt._version)
-    hit = _SPLIT_CACHE.pop(key, None)
-    if hit is None:
-        hit = (split_weights(wt, terms), wt)
-        while len(_SPLIT_CACHE) >= _SPLIT_CACHE_MAX:
-            _SPLIT_CACHE.pop(next(iter(_SPLIT_CACHE)), None)
-    _SPLIT_CACHE[key] = hit                          # re-inserted last = most recently used
+    with _SPLIT_LOCK:
+        hit = _SPLIT_CACHE.get(key)
+        if hit is not None:
+            _SPLIT_CACHE.move_to_end(key)
+            return hit[0]
+    made = (split_weights(wt, terms), wt)                 # outside the lock: a conversion launch; a racing thread makes an equal copy
+    with _SPLIT_LOCK:
+        hit = _SPLIT_CACHE.setdefault(key, made)
+        _SPLIT_CACHE.move_to_end(key)
+        while len(_SPLIT_CACHE) > _SPLIT_CACHE_MAX:
+            _SPLIT_CACHE.popitem(last=False)
     return hit[0]
 
 
@@ -449,7 +457,8 @@ class scenes_in_flight:
 
 
 def clear_split_cache():
-    _SPLIT_CACHE.clear()
+    with _SPLIT_LOCK:
+        _SPLIT_CACHE.clear()
 
 
 class PairLists:
