@@ -202,6 +202,9 @@ def main():
                     help="synth.make_scene layout: 'benchmark' = the scene of every reported number; 'scan' = mesh-like surface sampling")
     ap.add_argument("--streams", type=int, default=4,
                     help="scenes in flight per GPU (host threads x HIP streams, segdino3d_amd.dist_eval.PipelinedRunner)")
+    ap.add_argument("--batch", type=int, default=int(os.environ.get("SD3D_BENCH_BATCH", "1")),
+                    help="scenes per forward: > 1 runs them as ONE block-diagonal sparse tensor (sparse.BatchSceneMaps, every scene's "
+                         "outputs bit-identical to its single-scene forward); each stream then keeps a whole batch in flight")
     ap.add_argument("--decoder-dtype", choices=("fp32", "bf16"), default=os.environ.get("SD3D_DECODER_DTYPE", "fp32"),
                     help="bf16 = BASELINE configs[2]: bf16-MFMA attention contractions and projections, fp32 accumulation")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -247,7 +250,7 @@ def main():
         return model([pts], [tgt])
 
     from segdino3d_amd.dist_eval import PipelinedRunner
-    runner = PipelinedRunner(model, args.streams, device)
+    runner = PipelinedRunner(model, args.streams, device, batch=args.batch)
     # every step gets its own target object (the forward attaches its outputs to it)
     import copy
     def scene_list(n):
@@ -256,7 +259,7 @@ def main():
     with torch.no_grad():
         for i in range(args.warmup):
             step(i)
-        runner.run(scene_list(max(args.streams, 2)))           # warm the worker streams' allocator pools
+        runner.run(scene_list(max(args.streams, 2) * args.batch))   # warm the worker streams' allocator pools
         torch.cuda.synchronize()
         # single-scene latency (one stream, back to back) for reference
         t0 = time.perf_counter()
@@ -269,8 +272,8 @@ def main():
         # real workload to settle (a cold node measured 85 -> 93 -> 98 scenes/s over three back-to-back processes without it)
         t_pre, n_pre = time.perf_counter(), 0
         while time.perf_counter() - t_pre < args.preroll_seconds:
-            runner.run(scene_list(2 * args.streams))
-            n_pre += 2 * args.streams
+            runner.run(scene_list(2 * args.streams * args.batch))
+            n_pre += 2 * args.streams * args.batch
         torch.cuda.synchronize()
         if dist is not None:
             dist.barrier()
@@ -290,8 +293,13 @@ def main():
         timer.enabled = True
         import segdino3d_amd as seg
         with seg.capture() as cap:
-            for i in range(args.steps):
-                step(i)
+            if args.batch > 1:                                    # the same K scenes, in the batches the timed region ran them in
+                for g in range(0, args.steps, args.batch):
+                    grp = scene_list(min(args.steps, g + args.batch))[g:]
+                    model([p for p, _ in grp], [t for _, t in grp])
+            else:
+                for i in range(args.steps):
+                    step(i)
         torch.cuda.synchronize()
         timer.enabled = False
         ops.GG_HOOK = None
@@ -394,12 +402,14 @@ def main():
             "single_scene": {"scenes_per_s": round(1e3 / latency_ms, 2), "latency_ms": round(latency_ms, 3),
                              "note": "ONE scene in flight per GPU (SURVEY 8(d) batch = 1), same forward, same process"},
             "config": {"workload": ("configs[2]" if bf16_dec else "configs[1]") + ": ScanNet-val-like scenes, one scene per forward (step), "
-                                   f"{args.streams} independent scenes in flight per GPU (`value`) / one in flight (`single_scene`); "
+                                   f"{args.streams * args.batch} independent scenes in flight per GPU (`value`: {args.streams} stream(s) x {args.batch} scene(s) per forward) "
+                                   "/ one in flight (`single_scene`); "
                                    "fp32 sparse backbone (Res16UNet34C) + " + ("bf16-MFMA" if bf16_dec else "fp32") +
                                    " decoder + post-processing, device-resident in/out",
                        "points": args.points, "superpoints": args.superpoints, "queries_2d": args.query2d, "scene_layout": args.scene_layout,
                        "query_num": args.query_num, "voxels_per_level": maps.n_vox, "parallelism": f"scene-sharded x{world}",
-                       "scenes_in_flight_per_gpu": args.streams, "single_stream_latency_ms": round(latency_ms, 3),
+                       "scenes_in_flight_per_gpu": args.streams * args.batch, "streams": args.streams, "scenes_per_forward": args.batch,
+                       "single_stream_latency_ms": round(latency_ms, 3),
                        "untimed_preroll_scenes": n_pre, "host_cores_per_rank": cores_per_rank, "gpu_numa_node": numa_node},
             "roofline": roofline, "cpu_baseline": cpu,
             "per_rank_records": records,

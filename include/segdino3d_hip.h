@@ -102,6 +102,30 @@ int sd3d_voxel_mean(const float* points, int ld_points, const float* feats2d, in
                     int ld_out, void* stream);
 /* start[s] = first position of superpoint id s in the sorted id array, start[S] = n. */
 int sd3d_segment_starts(const uint64_t* sorted_ids, int64_t n, int64_t S, int32_t* start, void* stream);
+
+/* ---- several scenes as ONE block-diagonal sparse tensor (the collation of `utils/dataset_utils.py:215-230` collate_fn_3D +
+ * ME.utils.batch_sparse_collate, minkunet.py:624-627): the scene index sits in the key bits above the 48-bit Z-order code
+ * (sd3d_voxel_keys batch_index), so ONE sort / unique / hash / kernel-map pass serves every scene of the batch and rows of
+ * different scenes never become neighbours.  Per voxel / superpoint the arithmetic is the single-scene kernels'. ---- */
+#define SD3D_MAX_BATCH 16
+typedef struct sd3d_scene_src {
+    const float* points;     /* [n_points, ld_points] xyz rgb of this scene */
+    const float* feats2d;    /* [n_points, F] or NULL (mode 1) */
+    const float* stats;      /* the scene's sd3d_scene_stats row */
+    int64_t point_off;       /* index of the scene's first point in the batch-global point numbering */
+    int64_t n_points;
+    int32_t ld_points, pad_;
+} sd3d_scene_src;
+/* sd3d_voxel_mean over the voxels of all scenes: voxel v belongs to scene (ukeys[v] >> 48) & 0xFF; sorted_idx holds
+ * batch-global point numbers.  `scenes` is a HOST array (copied into the launch). */
+int sd3d_voxel_mean_batch(const sd3d_scene_src* scenes, int n_scenes, int F, int mode, const uint64_t* ukeys,
+                          const uint32_t* sorted_idx, const int32_t* seg_start, int64_t n_vox, float* out, int ld_out, void* stream);
+/* keys[i] = x[i] + add: superpoint ids of scene b become (b << 32) | id before the batch-wide sort. */
+int sd3d_keys_from_i64_offset(const int64_t* x, int64_t n, int64_t add, uint64_t* keys, void* stream);
+/* sd3d_segment_starts for sorted (scene << 32 | id) keys: dense id = id_off[scene] + id, S = number of dense ids of the batch.
+ * `id_off` is a HOST array of n_scenes entries. */
+int sd3d_segment_starts_batch(const uint64_t* sorted_ids, int64_t n, int64_t S, const int32_t* id_off, int n_scenes, int32_t* start,
+                              void* stream);
 /* Fused `x.slice(field)` + torch_scatter.scatter_mean of features [S,C] and of the floor-quantised
  * coordinates * voxel_size [S,3]  (minkunet.py:631-656; spconvunet.py:390). */
 int sd3d_pool_superpoints(const float* feat, int ld_feat, int C, const int32_t* inverse, const int32_t* icoords,
@@ -171,6 +195,33 @@ int sd3d_pair_conv(const float* in0, int ld0, int C0, const float* in1, int ld1,
                    int64_t M, const float* scale, const float* shift, const float* res, int ld_res, float* out,
                    int ld_out, int act, float* part, size_t part_bytes, void* stream);
 
+/* Round-3 products of the list builder, all optional, and the convolution entry that uses them (same contract as sd3d_pair_conv,
+ * same fixed per-row summation order for a given table description, results reproducible bit for bit):
+ *   rlist [M, rl_stride]   per output row {count, list positions of its pairs in offset order}; rl_stride a multiple of 4,
+ *                          >= K + 4.  Pass 2 walks a row's own partial products instead of the K slots of pos[k][r].
+ *   center                 offset whose pairs are (in = r, out = r) for EVERY row (a stride-1 table of a voxel set onto itself,
+ *                          minkunet.py:135-162 `conv` with stride 1; K / 2 for the centred odd kernels), or -1.  rlist then
+ *                          leaves that offset out, tile_k receives the offset's run of tiles in two extra slots (meta = 1:
+ *                          tile_k has p_cap / 128 + 3 entries), pass 1 skips the run, and ONE dense kernel makes the centre
+ *                          product, adds the other offsets' partial products (k ascending) and applies the epilogue: no partial
+ *                          product is written or read back for the centre, each output row is written once.
+ *   out_idx [p_cap]        output row of every list entry (-1 on padding).  Handing it to the convolution promises ONE pair per
+ *                          output row - the transposed k2s2 convolutions (minkunet.py:165-192 `conv_tr`: every fine voxel has one
+ *                          parent) - and pass 1 writes act(scale * product + shift + res) to the row directly: no pass 2. */
+typedef struct sd3d_pair_table_desc {
+    const int32_t* nbr;                  /* [K, M] */
+    int32_t *pos, *in_idx, *tile_k;      /* as sd3d_pair_lists */
+    int32_t *rlist, *out_idx;            /* optional (NULL) */
+    int64_t M, p_cap;
+    int32_t K, center, rl_stride, meta;
+} sd3d_pair_table_desc;
+int sd3d_pair_lists_desc(int n, const sd3d_pair_table_desc* tables, void* ws, size_t ws_bytes, void* stream);
+int sd3d_pair_conv_ex(const float* in0, int ld0, int C0, const float* in1, int ld1, const int32_t* in_idx,
+                      const int32_t* tile_k, int64_t p_cap, const int32_t* pos, const int32_t* rlist, int rl_stride, int center,
+                      const int32_t* out_idx, const float* wt, int K, int Cin, int Cout, int64_t M, const float* scale,
+                      const float* shift, const float* res, int ld_res, float* out, int ld_out, int act, float* part,
+                      size_t part_bytes, void* stream);
+
 /* Output-stationary sparse convolution (csrc/slab_conv.hip) - the same contract again (MinkowskiConvolution /
  * SubMConv3d / their transposes + folded BN + residual + activation; minkunet.py:135-192, spconvunet.py:21-99), straight
  * from the neighbour table nbr [K, M]: a workgroup owns a slab of consecutive output rows, keeps their fp32 sums in LDS
@@ -202,6 +253,8 @@ typedef struct sd3d_table {
     const int32_t *in_idx, *tile_k, *pos;   /* from sd3d_pair_lists */
     int64_t p_cap, M;                        /* M = output rows of the table */
     int32_t K, pad_;
+    const int32_t *rlist, *out_idx;          /* optional products of sd3d_pair_lists_desc (NULL) */
+    int32_t rl_stride, center;               /* center = -1 when the table has no all-rows centre offset */
 } sd3d_table;
 typedef struct sd3d_buf {
     float* ptr;

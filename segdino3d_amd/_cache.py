@@ -70,5 +70,5 @@ class DerivedWeights(nn.Module):
         if self.__dict__.get("_dw_stamp") == stamp:
             return True
         self._derived_reset()
-        self.__dict__["_dw_stamp"] = stamp
+        self.__dict__["_dw_stamp"] = self._sources_stamp()    # the reset dropped the enumeration: stamp of the fresh one
         return False

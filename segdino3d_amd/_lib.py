@@ -43,6 +43,9 @@ SIGNATURES = {
     "sd3d_stride_maps": (_i, [_p, _p, _l, _l, _p, _p, _p, _p]),
     "sd3d_voxel_mean": (_i, [_p, _i, _p, _i, _i, _p, _l, _p, _p, _l, _p, _i, _p]),
     "sd3d_segment_starts": (_i, [_p, _l, _l, _p, _p]),
+    "sd3d_voxel_mean_batch": (_i, [_p, _i, _i, _i, _p, _p, _p, _l, _p, _i, _p]),
+    "sd3d_keys_from_i64_offset": (_i, [_p, _l, _l, _p, _p]),
+    "sd3d_segment_starts_batch": (_i, [_p, _l, _l, _p, _i, _p, _p]),
     "sd3d_pool_superpoints": (_i, [_p, _i, _i, _p, _p, _f, _p, _p, _l, _p, _p, _p]),
     "sd3d_gather_gemm": (_i, [_p, _i, _i, _p, _i, _p, _p, _i, _i, _i, _l, _p, _p, _p, _i, _p, _i, _i, _i, _p, _z, _p]),
     "sd3d_linear_group": (_i, [_i, _p, _p]),
@@ -53,6 +56,8 @@ SIGNATURES = {
     "sd3d_slab_conv_ws_bytes": (_z, [_i, _i, _i, _l, _l]),
     "sd3d_slab_conv": (_i, [_p, _i, _i, _p, _i, _p, _l, _p, _i, _i, _i, _l, _p, _p, _p, _i, _p, _i, _i, _p, _z, _p]),
     "sd3d_pair_conv": (_i, [_p, _i, _i, _p, _i, _p, _p, _l, _p, _p, _i, _i, _i, _l, _p, _p, _p, _i, _p, _i, _i, _p, _z, _p]),
+    "sd3d_pair_lists_desc": (_i, [_i, _p, _p, _z, _p]),
+    "sd3d_pair_conv_ex": (_i, [_p, _i, _i, _p, _i, _p, _p, _l, _p, _p, _i, _i, _p, _p, _i, _i, _i, _l, _p, _p, _p, _i, _p, _i, _i, _p, _z, _p]),
     "sd3d_run_layers": (_i, [_p, _i, _p, _i, _p, _i, _p, _z, _p, _z, _p]),
     "sd3d_layernorm": (_i, [_p, _i, _p, _i, _p, _p, _f, _l, _i, _p, _i, _i, _p]),
     "sd3d_linear_layernorm": (_i, [_p, _i, _l, _i, _p, _i, _p, _p, _i, _p, _p, _f, _i, _p, _i, _p]),

@@ -43,6 +43,13 @@ except Exception:  # noqa: BLE001
 
 from . import criterion as _criterion  # noqa: E402,F401 - registers ScanNetUnifiedCriterion
 
+import os as _os  # noqa: E402
+# SD3D_FAN_OUT=1: the scenes of a batched evaluation forward run their decoders / post-processing side by side on one side
+# stream each.  Bit-identical, but MEASURED SLOWER than one after the other on the forward's stream (3 streams x batch 4:
+# 91.8 vs 109.1 scenes/s; more hardware queues make it worse): many concurrent chains of tiny launches take workgroup slots away
+# from the persistent convolution kernels of the other batches, whose static tile partition then waits for its slowest workgroup.
+FAN_OUT = _os.environ.get("SD3D_FAN_OUT", "0") == "1"
+
 
 def _cfg_get(cfg, key, default=None):
     if cfg is None:
@@ -85,6 +92,7 @@ class Baseline3D(nn.Module):
             assert self.decoder.add_box_size_pred, \
                 "When filter_outofbox_points_eval is True, decoder must have add_box_size_pred set to True."
         self.to_host = True          # False: keep post-processed outputs on the device (bench.py forward timing)
+        self._stuff_cols = {}        # stuff-class column list per device (predict_by_feat panoptic branch)
 
     # ---- get_extra_instance_data (:266-306) ------------------------------------------------------
     def get_extra_instance_data(self, samples, targets, add_instance_centers=False, add_instance_axis_aligned_box=False):
@@ -166,32 +174,72 @@ class Baseline3D(nn.Module):
         queries, queries_pos, targets = self._select_queries(sp_features_3d, sp_pos, targets)
         self.decoder.return_hidden_states = not self.training
         self.decoder.return_aux_outputs = True
+        if not self.training and len(samples) > 1 and FAN_OUT:
+            return self._forward_eval_fanned(samples, targets, sp_features_3d, sp_pos, sp_pos_wo_elastic, queries, queries_pos, scene_range)
         outputs = self.forward_decoder(sp_features_3d, sp_pos, sp_pos_wo_elastic, queries, queries_pos, targets, scene_range)
         cap = _trace.active()
         if cap is not None:                                      # per-call, per-thread (segdino3d_amd/_trace.py)
             cap.outputs, cap.sp_feats, cap.sp_pos = outputs, sp_features_3d, sp_pos
         if self.training:                                        # {"seg_loss", "inst_loss"}, gradients attached (:346)
             return self.criterion(outputs, targets)
-        pred = self.predict_by_feat(samples, outputs, targets[0]["extra_features"]["super_point_masks"])  # bs = 1 (:335)
-        targets[0].pred_pts_seg = pred[0]
+        # the reference evaluates one scene per forward (:335-338, bs = 1); here a list of B scenes is B independent evaluations
+        # whose backbone ran as one block-diagonal tensor: every target receives its own `pred_pts_seg`
+        for b in range(len(targets)):
+            pred = self.predict_by_feat(samples, outputs, targets[b]["extra_features"]["super_point_masks"], b)
+            targets[b].pred_pts_seg = pred[0]
+        return targets
+
+    def _forward_eval_fanned(self, samples, targets, sp_feats, sp_pos, sp_pos_wo, queries, queries_pos, scene_range):
+        """Decoder + post-processing of the B scenes of a batched evaluation forward, each scene on its own side stream: per
+        scene these are ~300 dependent launches of a few microseconds that fill a handful of CUs, so B of them side by side
+        take about as long as one.  Issue order: all decoders, then all threshold-independent post-processing (ending in each
+        scene's host read), then the data-dependent selections as their reads arrive.  Same kernels, same per-scene launch
+        sequence as the single-scene forward: results are bit-identical to it."""
+        B = len(samples)
+        main = torch.cuda.current_stream()
+        sides = ops.side_streams(B, samples[0].device)
+        outs, coms, reads = [None] * B, [None] * B, [None] * B
+        pick = lambda lst, b: None if lst is None else [lst[b]]      # noqa: E731
+        for b, st in enumerate(sides):
+            st.wait_stream(main)
+            with ops.use_stream(st):
+                outs[b] = self.forward_decoder([sp_feats[b]], pick(sp_pos, b), pick(sp_pos_wo, b), [queries[b]], pick(queries_pos, b),
+                                               [targets[b]], pick(scene_range, b))
+        ops.baton_yield()
+        for b, st in enumerate(sides):
+            with ops.use_stream(st):
+                coms[b] = self._instances_common([samples[b]], outs[b], targets[b]["extra_features"]["super_point_masks"])
+                reads[b] = self._select_begin(coms[b])
+        for b, st in enumerate(sides):
+            with ops.use_stream(st):
+                pred = self._predict_finish([samples[b]], outs[b], targets[b]["extra_features"]["super_point_masks"], coms[b], reads[b])
+            targets[b].pred_pts_seg = pred[0]
+            main.wait_stream(st)
+        cap = _trace.active()
+        if cap is not None:                                      # the per-scene dicts merged back into the decoder's list-of-scenes form
+            merged = {k: [o[k][0] for o in outs] for k in outs[0] if k != "aux_outputs"}
+            if "aux_outputs" in outs[0]:
+                merged["aux_outputs"] = [{k: (None if a[0][k] is None else [x[k][0] for x in a]) for k in a[0]}
+                                         for a in zip(*[o["aux_outputs"] for o in outs])]
+            cap.outputs, cap.sp_feats, cap.sp_pos = merged, sp_feats, sp_pos
         return targets
 
     # ---- post-processing -------------------------------------------------------------------------------------
-    def _instances_common(self, samples, out, superpoints):
+    def _instances_common(self, samples, out, superpoints, b=0):
         """Everything of predict_by_feat_instance (:406-486) that does not depend on the score threshold;
-        the reference runs it twice (inst_score_thr and pan_score_thr), here it runs once."""
+        the reference runs it twice (inst_score_thr and pan_score_thr), here it runs once.  `b`: scene of the batch."""
         cfg = self.test_cfg
-        cls = out["cls_preds"][0]
-        logits = out["masks"][0]
-        pts = samples[0]
+        cls = out["cls_preds"][b]
+        logits = out["masks"][b]
+        pts = samples[b]
         C = self.num_classes
         Q, S = cls.shape[0], logits.shape[1]
         k = int(_cfg_get(cfg, "topk_insts"))
         if Q * C < k:
             raise ValueError(f"topk_insts={k} needs at least {k} (query, class) pairs, got {Q * C}")
         flat, _ = ops.class_scores(cls, C)
-        if out.get("scores") is not None and out["scores"][0] is not None:        # objectness head: scores *= out['scores'][0] (:428-429)
-            flat = (flat.view(Q, C) * out["scores"][0].reshape(Q, 1)).reshape(-1).contiguous()
+        if out.get("scores") is not None and out["scores"][b] is not None:        # objectness head: scores *= out['scores'][0] (:428-429)
+            flat = (flat.view(Q, C) * out["scores"][b].reshape(Q, 1)).reshape(-1).contiguous()
         order0 = _sorted_desc(flat)[:k].contiguous()                    # top-k (query, class) pairs (:434)
         top_scores = flat[order0.long()]
         labels, qidx, scores = ops.mask_scores(logits, S, order0, top_scores, C, bool(_cfg_get(cfg, "obj_normalization", None)))
@@ -213,8 +261,8 @@ class Baseline3D(nn.Module):
             ident = torch.arange(k, dtype=torch.int32, device=cls.device)
             sig, area = ops.gather_sigmoid(logits, S, qidx, ident, S_pad)
             final_scores, final_labels, record, src_row = scores, labels, ident.long(), ident
-        centers = out["centers"][0] if "centers" in out else None
-        sizes = out["sizes"][0] if "sizes" in out else None
+        centers = out["centers"][b] if "centers" in out else None
+        sizes = out["sizes"][b] if "sizes" in out else None
         boxes = None
         if centers is not None and sizes is not None:
             q_rec = qidx.long()[record]
@@ -228,10 +276,17 @@ class Baseline3D(nn.Module):
         the k scores and point counts travel to the host (a few KB, polled), the row lists are made there and go back in one copy.
         (Boolean indexing on the device costs a synchronising nonzero per selection - three per scene before.)
         Returns [(keep int32 rows, score_mask bool[k], npoint_mask bool[n_scored])] per threshold, tensors on the device."""
+        return self._select_finish(common, thresholds, self._select_begin(common))
+
+    def _select_begin(self, common):
+        """Start the host read of the k scores and point counts (asynchronous copy + event on the current stream)."""
+        return ops.HostRead(torch.cat([common["scores"], common["count"].view(torch.float32)]))
+
+    def _select_finish(self, common, thresholds, read):
         cfg = self.test_cfg
-        scores, count = common["scores"], common["count"]
+        scores = common["scores"]
         k = scores.shape[0]
-        host = ops.HostRead(torch.cat([scores, count.view(torch.float32)])).wait().numpy()
+        host = read.wait().numpy()
         s, c = host[:k], host[k:].view(np.int32)
         npoint_all = c > int(_cfg_get(cfg, "npoint_thr"))
         parts, lay = [], []
@@ -252,25 +307,34 @@ class Baseline3D(nn.Module):
         return out
 
     @ops.bound_stream
-    def predict_by_feat(self, samples, out, superpoints):
+    def predict_by_feat(self, samples, out, superpoints, b=0):
         cfg = self.test_cfg
         ops.baton_yield()
-        com = self._instances_common(samples, out, superpoints)
+        com = self._instances_common(samples, out, superpoints, b)
+        return self._predict_finish(samples, out, superpoints, com, self._select_begin(com), b)
+
+    def _predict_finish(self, samples, out, superpoints, com, read, b=0):
+        """The part of predict_by_feat behind the host read of the scores (data-dependent selections, semantic, panoptic)."""
+        cfg = self.test_cfg
         # the data-dependent selections need the scores on the host: one polled read (no host thread sits inside a blocking HIP
         # call while other scenes are being issued)
-        (keep, score_mask, npoint_mask), (pkeep, _, _) = self._select(
-            com, (float(_cfg_get(cfg, "inst_score_thr")), float(_cfg_get(cfg, "pan_score_thr"))))
+        (keep, score_mask, npoint_mask), (pkeep, _, _) = self._select_finish(
+            com, (float(_cfg_get(cfg, "inst_score_thr")), float(_cfg_get(cfg, "pan_score_thr"))), read)
         inst_masks = com["masks"][keep].view(torch.bool)
         inst_labels, inst_scores = com["labels"][keep].long(), com["scores"][keep]
         inst_boxes = com["boxes"][keep] if com["boxes"] is not None else None
         # semantic (:488-507)
-        sem = out["sem_preds"][0]
+        sem = out["sem_preds"][b]
         n_sem = sem.shape[1] - 1
         use_index = self.query_num == -1
         sem_res = ops.gather_i64(ops.row_argmax(sem, ncols=n_sem), superpoints, use_index)
         # panoptic (:509-556)
         stuff = list(_cfg_get(cfg, "stuff_classes"))
-        cols = torch.tensor(stuff, dtype=torch.int32, device=sem.device)
+        cols = self._stuff_cols.get(str(sem.device)) if tuple(stuff) == self._stuff_cols.get("classes") else None
+        if cols is None:                                         # one H2D copy per device, not one per scene
+            if tuple(stuff) != self._stuff_cols.get("classes"):
+                self._stuff_cols = {"classes": tuple(stuff)}
+            cols = self._stuff_cols[str(sem.device)] = torch.tensor(stuff, dtype=torch.int32, device=sem.device)
         sem_stuff = ops.gather_i64(ops.row_argmax(sem, cols=cols), superpoints, use_index)
         if pkeep.numel() == 0:
             pan_sem, pan_inst = sem_stuff, sem_stuff

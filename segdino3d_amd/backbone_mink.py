@@ -29,6 +29,10 @@ from .builder import BACKBONES
 from .sparse import SceneMaps
 
 BN_EPS = 1e-5      # MinkowskiBatchNorm wraps nn.BatchNorm1d with the default eps
+# SD3D_BATCH_EVAL=0: an evaluation forward of several scenes runs them one after the other (A/B switch; default = one
+# block-diagonal sparse tensor, sparse.BatchSceneMaps)
+import os as _os
+BATCH_EVAL = _os.environ.get("SD3D_BATCH_EVAL", "1") != "0"
 
 
 class MinkConv(nn.Module):
@@ -258,8 +262,36 @@ class Res16UNetBase(DerivedWeights):
         plain = SceneMaps(pts, self.voxel_size, 1, shift_to_min=False, order=self.KERNEL_ORDER, superpoints=sp)
         return plain.pool(x.new_zeros((plain.n_vox[0], 4)), 4)[1]
 
+    def _forward_wrapper_batched(self, samples, targets, return_sp_mean_pos):
+        """Evaluation forward of several scenes as ONE block-diagonal sparse tensor (sparse.BatchSceneMaps): one voxelisation,
+        one set of neighbour tables, every convolution one launch over all scenes' pairs, one pooling launch.  Each scene's
+        outputs are bit-identical to its single-scene forward."""
+        from .sparse import BatchSceneMaps
+        pts = [p.float().contiguous() for p in samples]
+        sps = [t["extra_features"]["super_point_masks"].contiguous() for t in targets]
+        if self.mode_fuse_2d_feat == "early_fusion":
+            f2d, mode = [t["extra_features"]["points_2dfeats"].float().contiguous() for t in targets], 0
+        else:
+            f2d, mode = None, 1
+        maps = BatchSceneMaps(pts, self.voxel_size, 5, shift_to_min=False, order=self.KERNEL_ORDER, superpoints=sps)
+        cap = _trace.active()
+        if cap is not None:
+            cap.record_maps([maps])
+        vf = maps.voxel_features(pts, f2d, mode, _round32(self.in_channels))
+        x = self.forward_sparse(maps, vf)
+        f_all, p_all = maps.pool(x, self.out_planes)
+        cuts = list(zip(maps.sp_off[:-1], maps.sp_off[1:]))
+        feats = [f_all[a:b] for a, b in cuts]
+        pos = [p_all[a:b] for a, b in cuts]
+        pos_wo = [p.clone() for p in pos]
+        sp_pos = pos if self.add_positional_embedding else None
+        return (feats, sp_pos, pos_wo) if return_sp_mean_pos else (feats, sp_pos, None)
+
     @ops.bound_stream
     def forward_wrapper(self, samples: List[torch.Tensor], targets, return_sp_mean_pos=False):
+        if (not self.training and 1 < len(samples) <= 16 and BATCH_EVAL
+                and not any("elastic_coords" in t for t in targets)):
+            return self._forward_wrapper_batched(samples, targets, return_sp_mean_pos)
         feats, pos, pos_wo = [], [], []
         scenes = [self._scene_inputs(p, t) for p, t in zip(samples, targets)]
         cap = _trace.active()

@@ -28,6 +28,10 @@ int launch_stride_maps(const uint64_t*, const int32_t*, int64_t, int64_t, const 
 int launch_voxel_mean(const float*, int, const float*, int, int, const float*, int64_t, const uint32_t*, const int32_t*, int64_t,
                       float*, int, hipStream_t);
 int launch_segment_starts(const uint64_t*, int64_t, int64_t, int32_t*, hipStream_t);
+int launch_segment_starts_batch(const uint64_t*, int64_t, int64_t, const int32_t*, int, int32_t*, hipStream_t);
+int launch_voxel_mean_batch(const sd3d_scene_src*, int, int, int, const uint64_t*, const uint32_t*, const int32_t*, int64_t, float*, int,
+                            hipStream_t);
+int launch_i64_to_sortkey_add(const int64_t*, int64_t, uint64_t, uint64_t*, hipStream_t);
 int launch_pool_superpoints(const float*, int, int, const int32_t*, const int32_t*, float, const uint32_t*, const int32_t*,
                             int64_t, float*, float*, hipStream_t);
 int launch_voxel_keys(const float*, int, int64_t, float, const float*, int, int, int32_t*, uint64_t*, int32_t*, int32_t*, hipStream_t);
@@ -43,9 +47,10 @@ int launch_pair_lists_batch(int, const int32_t* const*, const int*, const int64_
 size_t slab_conv_ws_bytes(int, int, int, int64_t, int64_t);
 int launch_slab_conv(const float*, int, int, const float*, int, const int32_t*, int64_t, const float*, int, int, int, int64_t, const float*,
                      const float*, const float*, int, float*, int, int, void*, size_t, hipStream_t);
-int launch_pair_conv(const float*, int, int, const float*, int, const int32_t*, const int32_t*, int64_t, const int32_t*, const float*,
-                     int, int, int, int64_t, const float*, const float*, const float*, int, float*, int, int, float*, size_t,
-                     hipStream_t);
+int launch_pair_conv(const float*, int, int, const float*, int, const int32_t*, const int32_t*, int64_t, const int32_t*, const int32_t*, int,
+                     int, const int32_t*, const float*, int, int, int, int64_t, const float*, const float*, const float*, int, float*, int,
+                     int, float*, size_t, hipStream_t);
+int launch_pair_lists_desc(int, const sd3d_pair_table_desc*, void*, size_t, hipStream_t);
 
 int launch_layernorm(const float*, int, const float*, int, const float*, const float*, float, int64_t, int, float*, int, int, hipStream_t);
 int launch_linear_layernorm(const float*, int, int64_t, int, const float*, int, const float*, const float*, int, const float*, const float*, float, int,
@@ -158,6 +163,19 @@ int sd3d_voxel_mean(const float* points, int ld_points, const float* feats2d, in
 int sd3d_segment_starts(const uint64_t* sorted_ids, int64_t n, int64_t S, int32_t* start, void* stream) {
     return launch_segment_starts(sorted_ids, n, S, start, ST);
 }
+int sd3d_segment_starts_batch(const uint64_t* sorted_ids, int64_t n, int64_t S, const int32_t* id_off, int n_scenes, int32_t* start,
+                              void* stream) {
+    if (!id_off) return sd3d_set_error(SD3D_ERR_ARG, "segment_starts_batch: id_off is NULL");
+    return launch_segment_starts_batch(sorted_ids, n, S, id_off, n_scenes, start, ST);
+}
+int sd3d_voxel_mean_batch(const sd3d_scene_src* scenes, int n_scenes, int F, int mode, const uint64_t* ukeys,
+                          const uint32_t* sorted_idx, const int32_t* seg_start, int64_t n_vox, float* out, int ld_out, void* stream) {
+    if (!scenes) return sd3d_set_error(SD3D_ERR_ARG, "voxel_mean_batch: scenes is NULL");
+    return launch_voxel_mean_batch(scenes, n_scenes, F, mode, ukeys, sorted_idx, seg_start, n_vox, out, ld_out, ST);
+}
+int sd3d_keys_from_i64_offset(const int64_t* x, int64_t n, int64_t add, uint64_t* keys, void* stream) {
+    return launch_i64_to_sortkey_add(x, n, (uint64_t)add, keys, ST);
+}
 int sd3d_pool_superpoints(const float* feat, int ld_feat, int C, const int32_t* inverse, const int32_t* icoords,
                           float voxel_size, const uint32_t* sorted_idx, const int32_t* start, int64_t S, float* out_feat,
                           float* out_pos, void* stream) {
@@ -220,8 +238,19 @@ int sd3d_pair_conv(const float* in0, int ld0, int C0, const float* in1, int ld1,
                    int64_t p_cap, const int32_t* pos, const float* wt, int K, int Cin, int Cout, int64_t M, const float* scale,
                    const float* shift, const float* res, int ld_res, float* out, int ld_out, int act, float* part,
                    size_t part_bytes, void* stream) {
-    return launch_pair_conv(in0, ld0, C0, in1, ld1, in_idx, tile_k, p_cap, pos, wt, K, Cin, Cout, M, scale, shift, res, ld_res, out,
-                            ld_out, act, part, part_bytes, ST);
+    return launch_pair_conv(in0, ld0, C0, in1, ld1, in_idx, tile_k, p_cap, pos, nullptr, 0, -1, nullptr, wt, K, Cin, Cout, M, scale, shift,
+                            res, ld_res, out, ld_out, act, part, part_bytes, ST);
+}
+int sd3d_pair_lists_desc(int n, const sd3d_pair_table_desc* tables, void* ws, size_t ws_bytes, void* stream) {
+    if (n > 0 && !tables) return sd3d_set_error(SD3D_ERR_ARG, "pair_lists_desc: tables is NULL");
+    return launch_pair_lists_desc(n, tables, ws, ws_bytes, ST);
+}
+int sd3d_pair_conv_ex(const float* in0, int ld0, int C0, const float* in1, int ld1, const int32_t* in_idx, const int32_t* tile_k,
+                      int64_t p_cap, const int32_t* pos, const int32_t* rlist, int rl_stride, int center, const int32_t* out_idx,
+                      const float* wt, int K, int Cin, int Cout, int64_t M, const float* scale, const float* shift, const float* res,
+                      int ld_res, float* out, int ld_out, int act, float* part, size_t part_bytes, void* stream) {
+    return launch_pair_conv(in0, ld0, C0, in1, ld1, in_idx, tile_k, p_cap, pos, rlist, rl_stride, center, out_idx, wt, K, Cin, Cout, M,
+                            scale, shift, res, ld_res, out, ld_out, act, part, part_bytes, ST);
 }
 
 size_t sd3d_slab_conv_ws_bytes(int K, int Cin, int Cout, int64_t M, int64_t n_pairs) { return slab_conv_ws_bytes(K, Cin, Cout, M, n_pairs); }

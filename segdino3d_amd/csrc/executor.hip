@@ -8,9 +8,9 @@
 #include "../../include/segdino3d_hip.h"
 
 int launch_gather_gemm(const GGParams&, int, void*, size_t, hipStream_t);
-int launch_pair_conv(const float*, int, int, const float*, int, const int32_t*, const int32_t*, int64_t, const int32_t*, const float*,
-                     int, int, int, int64_t, const float*, const float*, const float*, int, float*, int, int, float*, size_t,
-                     hipStream_t);
+int launch_pair_conv(const float*, int, int, const float*, int, const int32_t*, const int32_t*, int64_t, const int32_t*, const int32_t*, int,
+                     int, const int32_t*, const float*, int, int, int, int64_t, const float*, const float*, const float*, int, float*, int,
+                     int, float*, size_t, hipStream_t);
 int launch_scale_shift_act(const float*, int, int, const float*, int, const float*, const float*, int, int64_t, int, float*, int,
                            hipStream_t);
 
@@ -31,7 +31,8 @@ extern "C" int sd3d_run_layers(const sd3d_layer* layers, int n_layers, const sd3
             const sd3d_table& T = tables[L.table];
             if (T.K != L.K) return sd3d_set_error(SD3D_ERR_ARG, "run_layers: table / weight offset count mismatch");
             if (o.rows != T.M) return sd3d_set_error(SD3D_ERR_ARG, "run_layers: output buffer rows != table rows");
-            rc = launch_pair_conv(a.ptr, a.ld, L.C0, b ? b->ptr : nullptr, b ? b->ld : 0, T.in_idx, T.tile_k, T.p_cap, T.pos, L.wt, L.K,
+            rc = launch_pair_conv(a.ptr, a.ld, L.C0, b ? b->ptr : nullptr, b ? b->ld : 0, T.in_idx, T.tile_k, T.p_cap, T.pos, T.rlist,
+                                  T.rl_stride, T.center, T.out_idx, L.wt, L.K,
                                   L.Cin, L.Cout, T.M, L.scale, L.shift, r ? r->ptr : nullptr, r ? r->ld : 0, o.ptr, o.ld, L.act, part,
                                   part_bytes, st);
         } else if (L.kind == SD3D_LAYER_DENSE) {

@@ -18,6 +18,7 @@
 // fp32 matrix rate (>= 16 flop per byte moved at Cin = 96).  The sum order is fixed (full Cin dot
 // product per pair, then k ascending) so results are deterministic.
 #include "gg_common.h"
+#include "../../include/segdino3d_hip.h"
 #include <stdlib.h>
 #include <atomic>
 
@@ -125,22 +126,27 @@ __global__ __launch_bounds__(256) void pair_fill_kernel(const int32_t* __restric
 // covers all tables: a workgroup finds its (table, offset, row block) from the tables' cumulative block counts, and the fill
 // kernel writes the -1 padding itself (segment tails, the unused end of in_idx / tile_k) instead of two memsets per table.
 #define PL_MAX_TABLES 16
+#define RL_ROWS 256             // rows per workgroup of the row-list kernel
 struct PLTable {
     const int32_t* nbr; int32_t* pos; int32_t* in_idx; int32_t* tile_k; int32_t* blk_cnt; int32_t* totals;
+    int32_t* rlist;                // [M][rl_stride]: per output row {count, list positions of its pairs in offset order} (NULL: not built)
+    int32_t* out_idx;              // [p_cap]: output row of every list entry, -1 on padding (NULL: not built)
     int64_t M, p_cap;
     int K, nblk, wg0, k0;          // wg0: first workgroup of this table in the (K * nblk)-flattened grid; k0: first of the K-flattened grid
+    int center;                    // offset whose pairs are (in = r, out = r) for EVERY row r (stride-1 table of a voxel set onto itself), or -1
+    int rl_stride, rb0, meta;      // rb0: first workgroup of the table in the row-list grid; meta: tile_k carries the two centre slots
 };
 struct PLBatch { int n; PLTable t[PL_MAX_TABLES]; };
 
-__device__ __forceinline__ int pl_find_table(const PLBatch& b, int wg, bool by_k) {
+__device__ __forceinline__ int pl_find_table(const PLBatch& b, int wg, int by) {           // by: 0 = wg0, 1 = k0, 2 = rb0
     int ti = 0;
-    for (int i = 1; i < b.n; ++i) if (wg >= (by_k ? b.t[i].k0 : b.t[i].wg0)) ti = i;
+    for (int i = 1; i < b.n; ++i) if (wg >= (by == 1 ? b.t[i].k0 : (by == 2 ? b.t[i].rb0 : b.t[i].wg0))) ti = i;
     return ti;
 }
 
 __global__ __launch_bounds__(256) void pair_count_batch_kernel(const PLBatch b) {
     __shared__ int sm[4];
-    const int ti = pl_find_table(b, blockIdx.x, false);
+    const int ti = pl_find_table(b, blockIdx.x, 0);
     const PLTable& T = b.t[ti];
     const int local = blockIdx.x - T.wg0, k = local / T.nblk, blk = local - k * T.nblk, tid = threadIdx.x;
     int c = 0;
@@ -157,7 +163,7 @@ __global__ __launch_bounds__(256) void pair_count_batch_kernel(const PLBatch b) 
 
 __global__ __launch_bounds__(256) void pair_scan_batch_kernel(const PLBatch b) {
     __shared__ int sm[4];
-    const int ti = pl_find_table(b, blockIdx.x, true);
+    const int ti = pl_find_table(b, blockIdx.x, 1);
     const PLTable& T = b.t[ti];
     const int k = blockIdx.x - T.k0, tid = threadIdx.x;
     int running = 0;
@@ -175,7 +181,7 @@ __global__ __launch_bounds__(256) void pair_scan_batch_kernel(const PLBatch b) {
 __global__ __launch_bounds__(256) void pair_fill_batch_kernel(const PLBatch b) {
     __shared__ int sm[4];
     __shared__ int wcnt[4];
-    const int ti = pl_find_table(b, blockIdx.x, false);
+    const int ti = pl_find_table(b, blockIdx.x, 0);
     const PLTable& T = b.t[ti];
     const int local = blockIdx.x - T.wg0, k = local / T.nblk, blk = local - k * T.nblk;
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
@@ -189,17 +195,28 @@ __global__ __launch_bounds__(256) void pair_fill_batch_kernel(const PLBatch b) {
         for (int t = tid; t < seg_len / PT; t += 256)
             if ((int64_t)(seg / PT + t) * PT < T.p_cap) T.tile_k[seg / PT + t] = k;
         for (int e = tot_k + tid; e < seg_len; e += 256)       // the segment's padding
-            if ((int64_t)seg + e < T.p_cap) T.in_idx[seg + e] = -1;
+            if ((int64_t)seg + e < T.p_cap) {
+                T.in_idx[seg + e] = -1;
+                if (T.out_idx) T.out_idx[seg + e] = -1;
+            }
         if (k == T.K - 1 && tid == 0) {                        // number of real tiles, after the last slot
             const int64_t end = (int64_t)seg + seg_len < T.p_cap ? (int64_t)seg + seg_len : T.p_cap;
             T.tile_k[T.p_cap / PT] = (int)(end / PT);
+            if (T.meta && T.center < 0) { T.tile_k[T.p_cap / PT + 1] = 0; T.tile_k[T.p_cap / PT + 2] = 0; }
+        }
+        if (T.meta && k == T.center && tid == 0) {             // the centre offset's run of tiles (pass 1 may skip it, pair_center_kernel owns it)
+            T.tile_k[T.p_cap / PT + 1] = seg / PT;
+            T.tile_k[T.p_cap / PT + 2] = (int64_t)seg + seg_len <= T.p_cap ? seg_len / PT : 0;
         }
     }
     if (k == T.K - 1) {
         // past the last segment: unused capacity reads as "no pair".  Every row block of the last offset fills its slice
         // (with worst-case sized lists, SD3D_EXACT_PAIRS=0, the tail is tens of MB: one workgroup would sit on the critical path)
         const int64_t end = (int64_t)seg + seg_len < T.p_cap ? (int64_t)seg + seg_len : T.p_cap;
-        for (int64_t e = end + (int64_t)blk * 256 + tid; e < T.p_cap; e += (int64_t)T.nblk * 256) T.in_idx[e] = -1;
+        for (int64_t e = end + (int64_t)blk * 256 + tid; e < T.p_cap; e += (int64_t)T.nblk * 256) {
+            T.in_idx[e] = -1;
+            if (T.out_idx) T.out_idx[e] = -1;
+        }
         for (int64_t t = end / PT + (int64_t)blk * 256 + tid; t < T.p_cap / PT; t += (int64_t)T.nblk * 256) T.tile_k[t] = -1;
     }
     int base = seg + T.blk_cnt[(int64_t)k * T.nblk + blk];
@@ -217,9 +234,35 @@ __global__ __launch_bounds__(256) void pair_fill_batch_kernel(const PLBatch b) {
         __syncthreads();
         const int p = base + before + __popcll(bal & lt);
         if (row < T.M) T.pos[(int64_t)k * T.M + row] = (id >= 0 && p < T.p_cap) ? p : -1;
-        if (id >= 0 && p < T.p_cap) T.in_idx[p] = id;
+        if (id >= 0 && p < T.p_cap) {
+            T.in_idx[p] = id;
+            if (T.out_idx) T.out_idx[p] = (int32_t)row;
+        }
         base += all;
     }
+}
+
+// Per output row: how many partial products pass 2 has to add up and where they are - {count, positions in offset order} in
+// rl_stride ints per row (the count and the first three positions arrive with ONE 16-byte load; a level-0 row has ~2 partners, so
+// walking all K slots of pos[k][r] was 27 loads for 3 hits).  The centre offset of a stride-1 table is left out: its product
+// is made inside pair_center_kernel and never stored.  One thread per row; pos is read offset-major (coalesced over rows).
+__global__ __launch_bounds__(RL_ROWS) void pair_rowlist_batch_kernel(const PLBatch b) {
+    const int ti = pl_find_table(b, blockIdx.x, 2);
+    const PLTable& T = b.t[ti];
+    if (!T.rlist) return;
+    const int64_t row = (int64_t)(blockIdx.x - T.rb0) * RL_ROWS + threadIdx.x;
+    if (row >= T.M) return;
+    int32_t* rl = T.rlist + row * T.rl_stride;
+    int cnt = 0;
+    for (int k0 = 0; k0 < T.K; k0 += 8) {
+        int v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v[u] = (k0 + u < T.K && k0 + u != T.center) ? T.pos[(int64_t)(k0 + u) * T.M + row] : -1;
+#pragma unroll
+        for (int u = 0; u < 8; ++u)
+            if (v[u] >= 0) rl[1 + cnt++] = v[u];
+    }
+    rl[0] = cnt;
 }
 
 // ---- pass 1: dense tiles over the pair list --------------------------------------------------
@@ -232,7 +275,24 @@ struct PGParams {
     int Cin, Cout;
     float* part;                              // [n_tiles * 128][Cout]
     int n_tiles;                              // capacity; the real count is tile_k[n_tiles]
+    int skip_center;                          // 1: leave out the tiles tile_k[n_tiles + 1] .. + tile_k[n_tiles + 2] (pair_center_kernel makes them)
+    // direct epilogue (out_idx != NULL): every output row has exactly ONE pair (transposed k2s2 convolution), so the tile's
+    // products ARE the output rows: out[out_idx[p]] = act(scale * acc + shift + res) straight from pass 1, no partial products
+    const int32_t* out_idx;
+    const float* scale; const float* shift; const float* res; int ld_res;
+    float* out; int ld_out; int act;
 };
+
+// scale * x + shift as ONE fused multiply-add in every epilogue of this file, so that the paths agree bit for bit
+__device__ __forceinline__ float pg_affine(float x, const float* scale, const float* shift, int n) {
+    return __builtin_fmaf(x, scale ? scale[n] : 1.f, shift ? shift[n] : 0.f);
+}
+__device__ __forceinline__ float pg_act(float t, int act) {
+    if (act == 1) t = fmaxf(t, 0.f);
+    else if (act == 2) t = 0.5f * t * (1.f + erff(t * 0.70710678118654752440f));
+    else if (act == 3) t = 1.f / (1.f + expf(-t));
+    return t;
+}
 
 // A workgroup walks its range of consecutive 128-pair tiles as ONE flat stream of (tile, 32-channel
 // chunk) steps: the weight chunk of step s+1 is staged global -> registers -> LDS while step s runs on
@@ -240,14 +300,18 @@ struct PGParams {
 // stages), across tile boundaries, so the dependent in_idx -> row gather latency of a new tile never
 // stalls the MFMA pipe.  The four waves share the weight chunk (lock-step, one barrier per step); each
 // owns 32 pairs x (32*NT) output columns.
-template <int NT>
+template <int NT, bool DIRECT>
 __device__ __forceinline__ void pair_gemm_body(const PGParams& p, float (*Bs)[NT * 32 * PBS_LD]) {
     const int tid = threadIdx.x, lane = tid & 63;
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);   // wave-uniform values must live in SGPRs (scalar branches)
     const int j = lane & 31, h = lane >> 5;
     // balanced contiguous tile ranges over a grid sized to the resident workgroup slots: no wave-quantisation
     // tail (a fixed tiles-per-workgroup grid of 2.1 rounds costs 3 rounds of time)
-    const int n_real = p.tile_k[p.n_tiles];
+    // tiles are numbered WITHOUT the centre offset's run when pass 1 skips it; PHYS() maps back to list positions
+    const int skip0 = p.skip_center ? p.tile_k[p.n_tiles + 1] : 0;
+    const int skipn = p.skip_center ? p.tile_k[p.n_tiles + 2] : 0;
+    const int n_real = p.tile_k[p.n_tiles] - skipn;
+#define PHYS(e) ((e) < skip0 ? (e) : (e) + skipn)
     const int tile0 = (int)((int64_t)blockIdx.x * n_real / gridDim.x);
     const int ntl = (int)((int64_t)(blockIdx.x + 1) * n_real / gridDim.x) - tile0;
     if (ntl <= 0) return;                                      // uniform over the workgroup
@@ -256,8 +320,8 @@ __device__ __forceinline__ void pair_gemm_body(const PGParams& p, float (*Bs)[NT
     const int nsteps = ntl * nchunks;
     const int64_t wstride = (int64_t)p.Cout * p.Cin;
 
-#define LOAD_IDX(lt) ((lt) < ntl ? p.in_idx[(int64_t)(tile0 + (lt)) * PT + wv * 32 + j] : -1)
-#define LOAD_K(lt) ((lt) < ntl ? p.tile_k[tile0 + (lt)] : 0)
+#define LOAD_IDX(lt) ((lt) < ntl ? p.in_idx[(int64_t)PHYS(tile0 + (lt)) * PT + wv * 32 + j] : -1)
+#define LOAD_K(lt) ((lt) < ntl ? p.tile_k[PHYS(tile0 + (lt))] : 0)
     int q0 = LOAD_IDX(0), q1 = LOAD_IDX(1), q2 = LOAD_IDX(2);  // gather rows of the current tile and the next two
     int k_cur = LOAD_K(0), k_nxt = LOAD_K(1);
 
@@ -337,9 +401,23 @@ __device__ __forceinline__ void pair_gemm_body(const PGParams& p, float (*Bs)[NT
                 __builtin_amdgcn_sched_barrier(0);                                                                    \
             }                                                                                                         \
         }                                                                                                             \
-        if (last_chunk) { /* tile complete: write its partial products */                                             \
-            {                                                                                                         \
-                const int64_t prow0 = (int64_t)(tile0 + cur_lt) * PT + wv * 32;                                       \
+        if (last_chunk) { /* tile complete: write its partial products (or, one pair per output row, the rows themselves) */ \
+            const int64_t prow0 = (int64_t)PHYS(tile0 + cur_lt) * PT + wv * 32;                                       \
+            if (DIRECT) {                                                                                             \
+                _Pragma("unroll") for (int r = 0; r < 16; ++r) {                                                      \
+                    const int64_t o = p.out_idx[prow0 + (r & 3) + 8 * (r >> 2) + 4 * h];   /* uniform over the 32 lanes j */ \
+                    if (o >= 0) {                                                                                     \
+                        _Pragma("unroll") for (int t = 0; t < NT; ++t) {                                              \
+                            const int n = ncol0 + t * 32 + j;                                                         \
+                            if (n < p.Cout) {                                                                         \
+                                float y = pg_affine(acc[t][r], p.scale, p.shift, n);                                  \
+                                if (p.res) y += p.res[o * p.ld_res + n];                                              \
+                                p.out[o * p.ld_out + n] = pg_act(y, p.act);                                           \
+                            }                                                                                         \
+                        }                                                                                             \
+                    }                                                                                                 \
+                }                                                                                                     \
+            } else {                                                                                                  \
                 _Pragma("unroll") for (int t = 0; t < NT; ++t) {                                                      \
                     const int n = ncol0 + t * 32 + j;                                                                 \
                     _Pragma("unroll") for (int r = 0; r < 16; ++r) {                                                  \
@@ -370,21 +448,29 @@ __device__ __forceinline__ void pair_gemm_body(const PGParams& p, float (*Bs)[NT
         PAIR_STEP(a2, a1)
     }
 #undef PAIR_STEP
+#undef LOAD_IDX
+#undef LOAD_K
+#undef PF_IDX
+#undef PF_ADVANCE
 }
 
 // One entry per column-tile count: the register budget (waves per SIMD) is pinned per variant, which
 // also stops the compiler from splitting the file into VGPR + AGPR halves with separate alignment
 // (272 registers and one wave per SIMD for NT = 4 otherwise).
-#define PAIR_GEMM_ENTRY(NT, WAVES)                                                                              \
-    __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WAVES, WAVES))) void pair_gemm_kernel_##NT( \
-        const PGParams p) {                                                                                     \
+#define PAIR_GEMM_ENTRY(NAME, NT, WAVES, DIRECT)                                                                 \
+    __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WAVES, WAVES))) void NAME(const PGParams p) { \
         __shared__ __attribute__((aligned(16))) float Bs[2][NT * 32 * PBS_LD];                                  \
-        pair_gemm_body<NT>(p, Bs);                                                                              \
+        pair_gemm_body<NT, DIRECT>(p, Bs);                                                                      \
     }
-PAIR_GEMM_ENTRY(1, 3)
-PAIR_GEMM_ENTRY(2, 2)
-PAIR_GEMM_ENTRY(3, 2)
-PAIR_GEMM_ENTRY(4, 2)
+PAIR_GEMM_ENTRY(pair_gemm_kernel_1, 1, 3, false)
+PAIR_GEMM_ENTRY(pair_gemm_kernel_2, 2, 2, false)
+PAIR_GEMM_ENTRY(pair_gemm_kernel_3, 3, 2, false)
+PAIR_GEMM_ENTRY(pair_gemm_kernel_4, 4, 2, false)
+// one pair per output row (transposed k2s2 convolutions): the epilogue writes the output rows themselves
+PAIR_GEMM_ENTRY(pair_gemm_direct_kernel_1, 1, 3, true)
+PAIR_GEMM_ENTRY(pair_gemm_direct_kernel_2, 2, 2, true)
+PAIR_GEMM_ENTRY(pair_gemm_direct_kernel_3, 3, 2, true)
+PAIR_GEMM_ENTRY(pair_gemm_direct_kernel_4, 4, 2, true)
 
 // ---- pass 1, weight-stationary variant ----------------------------------------------------------
 // For layers whose whole W[k] (Cout x Cin fp32, Cout = 32*NT <= 128) fits in LDS next to a second
@@ -406,13 +492,15 @@ PAIR_GEMM_ENTRY(4, 2)
 // measured SLOWER than RT = 1 (stem 296 -> 333 us, 32->32 62 -> 72, 64->64 108 -> 121): those layers are
 // bound by the gathers and partial stores per flop, not by the matrix pipe, and RT costs them half their
 // resident waves.  All variants therefore run RT = 1.
-template <int NT, int RT, int ST>
+template <int NT, int RT, int ST, bool DIRECT>
 __device__ __forceinline__ void pair_gemm_ws_body(const PGParams& p, float* Ws) {   // no __restrict__: LDS shared across waves
     constexpr int UPT = 4 / RT;                                // wave units (RT x 32 pairs) per 128-pair tile
     const int tid = threadIdx.x, lane = tid & 63;
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);   // wave-uniform values must live in SGPRs (scalar branches)
     const int j = lane & 31, h = lane >> 5;
-    const int n_real = p.tile_k[p.n_tiles];
+    const int skip0 = p.skip_center ? p.tile_k[p.n_tiles + 1] : 0;
+    const int skipn = p.skip_center ? p.tile_k[p.n_tiles + 2] : 0;
+    const int n_real = p.tile_k[p.n_tiles] - skipn;            // PHYS(): tile number without the centre run -> list position
     const int range0 = (int)((int64_t)blockIdx.x * n_real / gridDim.x);
     const int range1 = (int)((int64_t)(blockIdx.x + 1) * n_real / gridDim.x);
     if (range1 <= range0) return;
@@ -437,14 +525,14 @@ __device__ __forceinline__ void pair_gemm_ws_body(const PGParams& p, float* Ws) 
     const int ntl = range1 - tile0 < WS_RANGE_TILES ? range1 - tile0 : WS_RANGE_TILES;
     __syncthreads();                                           // nobody still reads the previous piece's indices
     for (int f = tid; f < ntl * PT; f += 256) {
-        const int v = p.in_idx[(int64_t)tile0 * PT + f];
+        const int v = p.in_idx[(int64_t)PHYS(tile0 + (f >> 7)) * PT + (f & (PT - 1))];
         Ix[f] = v < 0 ? 0 : v;                                 // their partial products are never read back
     }
     int run_start = 0;
     while (run_start < ntl) {                                  // runs of tiles with the same offset (uniform)
-        const int k = p.tile_k[tile0 + run_start];
+        const int k = p.tile_k[PHYS(tile0 + run_start)];
         int run_end = run_start + 1;
-        while (run_end < ntl && p.tile_k[tile0 + run_end] == k) ++run_end;
+        while (run_end < ntl && p.tile_k[PHYS(tile0 + run_end)] == k) ++run_end;
         __syncthreads();                                       // everyone is done reading the previous W (and Ix is written)
         {
             const float* __restrict__ W = p.wt + ((int64_t)k * p.Cout + ncol0) * p.Cin;
@@ -520,11 +608,27 @@ __device__ __forceinline__ void pair_gemm_ws_body(const PGParams& p, float* Ws) 
         }                                                                                                             \
         if (last_chunk) { /* unit complete: lane = pair row, register group g = columns 8g + 4h .. +3 */              \
             _Pragma("unroll") for (int rt = 0; rt < RT; ++rt) {                                                       \
-                float* dst = p.part + (((int64_t)tile0 * UPT + u0 + 4 * cur_i) * RT * 32 + rt * 32 + j) * p.Cout + ncol0 + 4 * h; \
+                const int ue = (u0 + 4 * cur_i) * RT + rt;          /* 32-pair unit of the piece: tile ue / 4, quarter ue % 4 */ \
+                const int64_t prow = (int64_t)PHYS(tile0 + (ue >> 2)) * PT + (ue & 3) * 32 + j;                       \
+                if (DIRECT) {                                       /* one pair per output row: write the row itself */ \
+                    const int64_t o = p.out_idx[prow];                                                                \
+                    if (o >= 0) {                                                                                     \
+                        _Pragma("unroll") for (int t = 0; t < NT; ++t)                                                \
+                            _Pragma("unroll") for (int g = 0; g < 4; ++g) {                                           \
+                                const int c = ncol0 + 4 * h + t * 32 + 8 * g;                                         \
+                                f32x4 y;                                                                              \
+                                _Pragma("unroll") for (int i = 0; i < 4; ++i) y[i] = pg_affine(acc[rt][t][4 * g + i], p.scale, p.shift, c + i); \
+                                if (p.res) y += *(const f32x4*)(p.res + o * p.ld_res + c);                            \
+                                *(f32x4*)(p.out + o * p.ld_out + c) = f32x4{pg_act(y[0], p.act), pg_act(y[1], p.act), pg_act(y[2], p.act), pg_act(y[3], p.act)}; \
+                            }                                                                                         \
+                    }                                                                                                 \
+                } else {                                                                                              \
+                float* dst = p.part + prow * p.Cout + ncol0 + 4 * h;                                                  \
                 _Pragma("unroll") for (int t = 0; t < NT; ++t)                                                        \
                     _Pragma("unroll") for (int g = 0; g < 4; ++g)                                                     \
                         *(f32x4*)(dst + t * 32 + 8 * g) = f32x4{acc[rt][t][4 * g], acc[rt][t][4 * g + 1],             \
                                                                 acc[rt][t][4 * g + 2], acc[rt][t][4 * g + 3]};        \
+                }                                                                                                     \
                 _Pragma("unroll") for (int t = 0; t < NT; ++t)                                                        \
                     _Pragma("unroll") for (int r = 0; r < 16; ++r) acc[rt][t][r] = 0.f;                               \
             }                                                                                                         \
@@ -560,16 +664,19 @@ __device__ __forceinline__ void pair_gemm_ws_body(const PGParams& p, float* Ws) 
   }
 }
 
-#define PAIR_GEMM_WS_ENTRY(NT, RT, ST, WAVES)                                                                          \
-    __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WAVES, WAVES))) void pair_gemm_ws_kernel_##NT( \
-        const PGParams p) {                                                                                        \
+#define PAIR_GEMM_WS_ENTRY(NAME, NT, RT, ST, WAVES, DIRECT)                                                        \
+    __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WAVES, WAVES))) void NAME(const PGParams p) { \
         extern __shared__ __attribute__((aligned(16))) float ws_smem[];                                            \
-        pair_gemm_ws_body<NT, RT, ST>(p, ws_smem);                                                                     \
+        pair_gemm_ws_body<NT, RT, ST, DIRECT>(p, ws_smem);                                                         \
     }
-PAIR_GEMM_WS_ENTRY(1, 1, 3, 4)
-PAIR_GEMM_WS_ENTRY(2, 1, 3, 2)
-PAIR_GEMM_WS_ENTRY(3, 1, 2, 3)
-PAIR_GEMM_WS_ENTRY(4, 1, 2, 2)
+PAIR_GEMM_WS_ENTRY(pair_gemm_ws_kernel_1, 1, 1, 3, 4, false)
+PAIR_GEMM_WS_ENTRY(pair_gemm_ws_kernel_2, 2, 1, 3, 2, false)
+PAIR_GEMM_WS_ENTRY(pair_gemm_ws_kernel_3, 3, 1, 2, 3, false)
+PAIR_GEMM_WS_ENTRY(pair_gemm_ws_kernel_4, 4, 1, 2, 2, false)
+PAIR_GEMM_WS_ENTRY(pair_gemm_ws_direct_kernel_1, 1, 1, 3, 4, true)
+PAIR_GEMM_WS_ENTRY(pair_gemm_ws_direct_kernel_2, 2, 1, 3, 2, true)
+PAIR_GEMM_WS_ENTRY(pair_gemm_ws_direct_kernel_3, 3, 1, 2, 3, true)
+PAIR_GEMM_WS_ENTRY(pair_gemm_ws_direct_kernel_4, 4, 1, 2, 2, true)
 
 // ---- pass 2: fixed-order reduction over the offsets + epilogue --------------------------------
 struct PRParams {
@@ -603,15 +710,224 @@ __global__ __launch_bounds__(256) void pair_reduce_kernel(const PRParams p) {
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         const int n = q + i;
-        float t = a[i] * (p.scale ? p.scale[n] : 1.f) + (p.shift ? p.shift[n] : 0.f);
+        float t = pg_affine(a[i], p.scale, p.shift, n);
         if (p.res) t += p.res[r * p.ld_res + n];
-        if (p.act == 1) t = fmaxf(t, 0.f);
-        else if (p.act == 2) t = 0.5f * t * (1.f + erff(t * 0.70710678118654752440f));
-        else if (p.act == 3) t = 1.f / (1.f + expf(-t));
-        y[i] = t;
+        y[i] = pg_act(t, p.act);
     }
     *(f32x4*)(p.out + r * p.ld_out + q) = f32x4{y[0], y[1], y[2], y[3]};
 }
+
+// ---- pass 2 over the per-row lists ---------------------------------------------------------------
+// The same fixed-order sum, but a row walks ITS OWN partial products {count, positions...} (pair_rowlist_batch_kernel) instead of
+// all K slots of pos[k][r]: one 16-byte load brings the count and the first three positions.
+struct PRLParams {
+    const int32_t* rlist; int rl_stride; int64_t M;
+    const float* part; int Cout;
+    const float* scale; const float* shift;
+    const float* res; int ld_res;
+    float* out; int ld_out; int act;
+};
+
+__global__ __launch_bounds__(256) void pair_reduce_rl_kernel(const PRLParams p) {
+    const int c4 = p.Cout >> 2;
+    const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int64_t r = e / c4;
+    if (r >= p.M) return;
+    const int q = (int)(e - r * c4) * 4;
+    const int32_t* rl = p.rlist + r * p.rl_stride;
+    const int4 head = *(const int4*)rl;
+    const int cnt = head.x;
+    f32x4 a = {0.f, 0.f, 0.f, 0.f};
+    {
+        f32x4 v0 = {0.f, 0.f, 0.f, 0.f}, v1 = v0, v2 = v0;
+        if (cnt > 0) v0 = *(const f32x4*)(p.part + (int64_t)head.y * p.Cout + q);
+        if (cnt > 1) v1 = *(const f32x4*)(p.part + (int64_t)head.z * p.Cout + q);
+        if (cnt > 2) v2 = *(const f32x4*)(p.part + (int64_t)head.w * p.Cout + q);
+        if (cnt > 0) a += v0;
+        if (cnt > 1) a += v1;
+        if (cnt > 2) a += v2;
+    }
+    for (int i0 = 3; i0 < cnt; i0 += 4) {                       // list entries 3.., four at a time (16-byte aligned: rl + 4, rl + 8, ...)
+        const int4 ids = *(const int4*)(rl + 1 + i0);
+        f32x4 v[4];
+        const int idv[4] = {ids.x, ids.y, ids.z, ids.w};
+#pragma unroll
+        for (int u = 0; u < 4; ++u) v[u] = i0 + u < cnt ? *(const f32x4*)(p.part + (int64_t)idv[u] * p.Cout + q) : f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int u = 0; u < 4; ++u) if (i0 + u < cnt) a += v[u];
+    }
+    float y[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int n = q + i;
+        float t = pg_affine(a[i], p.scale, p.shift, n);
+        if (p.res) t += p.res[r * p.ld_res + n];
+        y[i] = pg_act(t, p.act);
+    }
+    *(f32x4*)(p.out + r * p.ld_out + q) = f32x4{y[0], y[1], y[2], y[3]};
+}
+
+// ---- centre offset + pass 2 in one kernel ----------------------------------------------------------------------
+// Stride-1 tables of a voxel set onto itself: the centre offset pairs every row with itself (in = out = r).  Its product is a
+// DENSE GEMM over consecutive rows - no gather indirection, perfectly balanced - and needs no partial product: this kernel makes
+// it in registers for a tile of 128 rows (weight-stationary: W[centre] sits in LDS for the whole launch, a wave owns 32 rows,
+// MFMA issued transposed so a lane owns a row), then streams the OTHER offsets' partial products of its rows in through the
+// per-row lists (k ascending), applies scale / shift / residual / activation and writes each output row once.  Versus pass 1
+// over all K offsets + pair_reduce_kernel this removes the write and the read-back of one partial row per output row (a third of
+// the partial traffic at level 0, where a voxel has ~2 neighbours) and the pass-2 stream runs under the matrix work of the other
+// waves on the CU.  Summation order per row: centre product, then the offsets ascending - fixed, so results are reproducible.
+struct PCParams {
+    const float* in0; int ld0; int C0;
+    const float* in1; int ld1;
+    const float* wt;                          // W[centre]: [Cout][Cin]
+    int Cin, Cout;
+    int64_t M;
+    const int32_t* rlist; int rl_stride;
+    const float* part;
+    const float* scale; const float* shift; const float* res; int ld_res;
+    float* out; int ld_out; int act;
+};
+
+template <int NT, int ST>
+__device__ __forceinline__ void pair_center_body(const PCParams& p, float* Ws) {
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int j = lane & 31, h = lane >> 5;
+    const int n_tiles = (int)((p.M + PT - 1) / PT);
+    const int tile0 = (int)((int64_t)blockIdx.x * n_tiles / gridDim.x);
+    const int tile1 = (int)((int64_t)(blockIdx.x + 1) * n_tiles / gridDim.x);
+    if (tile1 <= tile0) return;
+    const int nchunks = p.Cin >> 5;
+    const int ldw = p.Cin + 4;                                 // conflict-free b128 rows, as in pair_gemm_ws_body
+    const int c4 = p.Cin >> 2;
+    const int npieces = 32 * NT * c4;
+    const int ncol0 = blockIdx.y * NT * 32;
+    {                                                          // W[centre] rows ncol0 .. ncol0 + 32 NT: once per launch
+        const float* __restrict__ W = p.wt + (int64_t)ncol0 * p.Cin;
+        for (int f0 = 0; f0 < npieces; f0 += 256 * 4) {
+            f32x4 v[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int f = f0 + u * 256 + tid;
+                if (f < npieces) v[u] = *(const f32x4*)(W + (int64_t)f * 4);
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int f = f0 + u * 256 + tid;
+                if (f < npieces) {
+                    const int row = f / c4, col = f - row * c4;
+                    *(f32x4*)(Ws + row * ldw + col * 4) = v[u];
+                }
+            }
+        }
+    }
+    __syncthreads();
+
+    f32x16 acc[NT];
+#pragma unroll 1
+    for (int tile = tile0; tile < tile1; ++tile) {
+        const int64_t r = (int64_t)tile * PT + wv * 32 + j;
+        const bool ok = r < p.M;
+        const int64_t row = ok ? r : p.M - 1;                   // rows past the end load the last row and store nothing
+        const int32_t* rl = p.rlist + row * p.rl_stride;
+        const int4 head = *(const int4*)rl;                     // {count, first three list positions}: ready long before the epilogue
+#pragma unroll
+        for (int t = 0; t < NT; ++t)
+#pragma unroll
+            for (int q = 0; q < 16; ++q) acc[t][q] = 0.f;
+        auto load_step = [&](f32x4 (&A)[4], int c) {
+            const int cc = (c < nchunks ? c : 0) * 32;         // wave-uniform
+            const bool first = cc < p.C0;
+            const float* base = first ? p.in0 : p.in1;
+            const int ld = first ? p.ld0 : p.ld1;
+            const float* q = base + row * ld + (first ? cc : cc - p.C0) + h * 16;
+            LOAD_A4(A, q);
+        };
+        f32x4 a0[4], a1[4], a2[4];
+        load_step(a0, 0);
+        if (ST >= 3) load_step(a1, 1);
+        int cur_c = 0;
+#define PC_STEP(CUR, PF)                                                                                              \
+    {                                                                                                                 \
+        load_step(PF, cur_c + ST - 1);                                                                                \
+        {                                                                                                             \
+            const float* wb = Ws + j * ldw + cur_c * 32 + h * 16;                                                     \
+            f32x4 wq[2][NT];                                                                                          \
+            _Pragma("unroll") for (int t = 0; t < NT; ++t) wq[0][t] = *(const f32x4*)(wb + t * 32 * ldw);             \
+            _Pragma("unroll") for (int q = 0; q < 4; ++q) {                                                           \
+                if (q < 3) {                                                                                          \
+                    _Pragma("unroll") for (int t = 0; t < NT; ++t)                                                    \
+                        wq[(q + 1) & 1][t] = *(const f32x4*)(wb + t * 32 * ldw + (q + 1) * 4);                        \
+                }                                                                                                     \
+                _Pragma("unroll") for (int e = 0; e < 4; ++e)                                                         \
+                    _Pragma("unroll") for (int t = 0; t < NT; ++t)                                                    \
+                        acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(wq[q & 1][t][e], CUR[q][e], acc[t], 0, 0, 0);   \
+                __builtin_amdgcn_sched_barrier(0);                                                                    \
+            }                                                                                                         \
+        }                                                                                                             \
+        if (++cur_c == nchunks) break;                                                                                \
+    }
+        if (ST == 2) {
+            for (;;) {
+                PC_STEP(a0, a1)
+                PC_STEP(a1, a0)
+            }
+        } else {
+            for (;;) {
+                PC_STEP(a0, a2)
+                PC_STEP(a1, a0)
+                PC_STEP(a2, a1)
+            }
+        }
+#undef PC_STEP
+        // ---- the other offsets' partial products of this lane's row, k ascending ----
+        const int cnt = ok ? head.x : 0;
+        const float* pbase = p.part + ncol0 + 4 * h;
+        for (int i = 0; __ballot(i < cnt) != 0ull; ++i) {
+            int id = i == 0 ? head.y : (i == 1 ? head.z : head.w);
+            if (i >= 3 && i < cnt) id = rl[1 + i];
+            if (i < cnt) {
+                const float* pp = pbase + (int64_t)id * p.Cout;
+                f32x4 v[NT][4];
+#pragma unroll
+                for (int t = 0; t < NT; ++t)
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) v[t][g] = *(const f32x4*)(pp + t * 32 + 8 * g);
+#pragma unroll
+                for (int t = 0; t < NT; ++t)
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) {
+                        acc[t][4 * g] += v[t][g][0]; acc[t][4 * g + 1] += v[t][g][1];
+                        acc[t][4 * g + 2] += v[t][g][2]; acc[t][4 * g + 3] += v[t][g][3];
+                    }
+            }
+        }
+        if (ok) {
+#pragma unroll
+            for (int t = 0; t < NT; ++t)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const int c = ncol0 + 4 * h + t * 32 + 8 * g;
+                    f32x4 y;
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) y[i] = pg_affine(acc[t][4 * g + i], p.scale, p.shift, c + i);
+                    if (p.res) y += *(const f32x4*)(p.res + r * p.ld_res + c);
+                    *(f32x4*)(p.out + r * p.ld_out + c) = f32x4{pg_act(y[0], p.act), pg_act(y[1], p.act), pg_act(y[2], p.act), pg_act(y[3], p.act)};
+                }
+        }
+    }
+}
+
+#define PAIR_CENTER_ENTRY(NT, ST, WAVES)                                                                            \
+    __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WAVES, WAVES))) void pair_center_kernel_##NT( \
+        const PCParams p) {                                                                                         \
+        extern __shared__ __attribute__((aligned(16))) float pc_smem[];                                             \
+        pair_center_body<NT, ST>(p, pc_smem);                                                                       \
+    }
+PAIR_CENTER_ENTRY(1, 3, 4)
+PAIR_CENTER_ENTRY(2, 3, 2)
+PAIR_CENTER_ENTRY(3, 2, 3)
+PAIR_CENTER_ENTRY(4, 2, 2)
 
 // ---- launchers --------------------------------------------------------------------------------
 size_t pair_lists_ws_bytes(int K, int64_t M) {
@@ -639,42 +955,65 @@ int launch_pair_lists(const int32_t* nbr, int K, int64_t M, int64_t p_cap, int32
     return SD3D_OK;
 }
 
-// n tables at once (n <= PL_MAX_TABLES); ws of table i starts at ws_off[i] (pair_lists_ws_bytes(K_i, M_i) bytes each)
-int launch_pair_lists_batch(int n, const int32_t* const* nbr, const int* K, const int64_t* M, const int64_t* p_cap, int32_t* const* pos,
-                            int32_t* const* in_idx, int32_t* const* tile_k, void* ws, size_t ws_bytes, hipStream_t st) {
+// n tables at once (n <= PL_MAX_TABLES); the tables' scratch sits back to back in ws (pair_lists_ws_bytes(K_i, M_i) bytes each,
+// rounded up to 256).  rlist / out_idx / the two centre slots of tile_k are optional products (see sd3d_pair_table_desc).
+int launch_pair_lists_desc(int n, const sd3d_pair_table_desc* d, void* ws, size_t ws_bytes, hipStream_t st) {
     if (n <= 0) return SD3D_OK;
     if (n > PL_MAX_TABLES) return sd3d_set_error(SD3D_ERR_ARG, "pair_lists_batch: at most 16 tables per call");
     PLBatch b;
     b.n = 0;
     size_t off = 0;
-    int wg = 0, kk = 0;
+    int wg = 0, kk = 0, rb = 0;
     for (int i = 0; i < n; ++i) {
-        if (K[i] <= 0 || M[i] <= 0) {                          // no rows: a later pair_conv on this table must see "0 real tiles"
-            if (tile_k[i] && p_cap[i] > 0 && hipMemsetAsync(tile_k[i] + p_cap[i] / PT, 0, sizeof(int32_t), st) != hipSuccess)
+        const int K = d[i].K;
+        const int64_t M = d[i].M, p_cap = d[i].p_cap;
+        if (K <= 0 || M <= 0) {                                // no rows: a later pair_conv on this table must see "0 real tiles"
+            if (d[i].tile_k && p_cap > 0 && hipMemsetAsync(d[i].tile_k + p_cap / PT, 0, (d[i].meta ? 3 : 1) * sizeof(int32_t), st) != hipSuccess)
                 return sd3d_set_error(SD3D_ERR_LAUNCH, "pair_lists_batch: memset failed");
             continue;
         }
-        if (p_cap[i] <= 0 || (p_cap[i] % PT)) return sd3d_set_error(SD3D_ERR_ARG, "pair_lists_batch: p_cap must be a positive multiple of 128");
+        if (p_cap <= 0 || (p_cap % PT)) return sd3d_set_error(SD3D_ERR_ARG, "pair_lists_batch: p_cap must be a positive multiple of 128");
+        if (d[i].rlist && (d[i].rl_stride < K + 4 || (d[i].rl_stride & 3))) return sd3d_set_error(SD3D_ERR_ARG, "pair_lists_batch: rl_stride must be a multiple of 4, >= K + 4");
+        if (d[i].center >= K) return sd3d_set_error(SD3D_ERR_ARG, "pair_lists_batch: centre offset out of range");
         PLTable& T = b.t[b.n++];
-        T.nbr = nbr[i]; T.pos = pos[i]; T.in_idx = in_idx[i]; T.tile_k = tile_k[i]; T.M = M[i]; T.p_cap = p_cap[i]; T.K = K[i];
-        T.nblk = (int)cdiv(M[i], PL_ROWS);
+        T.nbr = d[i].nbr; T.pos = d[i].pos; T.in_idx = d[i].in_idx; T.tile_k = d[i].tile_k; T.M = M; T.p_cap = p_cap; T.K = K;
+        T.rlist = d[i].rlist; T.out_idx = d[i].out_idx; T.center = d[i].center; T.rl_stride = d[i].rl_stride; T.meta = d[i].meta;
+        T.nblk = (int)cdiv(M, PL_ROWS);
         T.blk_cnt = (int32_t*)((char*)ws + off);
         T.totals = T.blk_cnt + (int64_t)T.K * T.nblk;
-        off += align_up(pair_lists_ws_bytes(K[i], M[i]), 256);
-        T.wg0 = wg; T.k0 = kk;
+        off += align_up(pair_lists_ws_bytes(K, M), 256);
+        T.wg0 = wg; T.k0 = kk; T.rb0 = rb;
         wg += T.K * T.nblk; kk += T.K;
+        rb += T.rlist ? (int)cdiv(M, RL_ROWS) : 0;
     }
     if (off > ws_bytes) return sd3d_set_error(SD3D_ERR_ARG, "pair_lists_batch: workspace too small");
     if (b.n == 0) return SD3D_OK;
     hipLaunchKernelGGL(pair_count_batch_kernel, dim3(wg), dim3(256), 0, st, b);
     hipLaunchKernelGGL(pair_scan_batch_kernel, dim3(kk), dim3(256), 0, st, b);
     hipLaunchKernelGGL(pair_fill_batch_kernel, dim3(wg), dim3(256), 0, st, b);
+    if (rb > 0) hipLaunchKernelGGL(pair_rowlist_batch_kernel, dim3(rb), dim3(RL_ROWS), 0, st, b);
     SD3D_CHECK_LAUNCH();
     return SD3D_OK;
 }
 
+int launch_pair_lists_batch(int n, const int32_t* const* nbr, const int* K, const int64_t* M, const int64_t* p_cap, int32_t* const* pos,
+                            int32_t* const* in_idx, int32_t* const* tile_k, void* ws, size_t ws_bytes, hipStream_t st) {
+    if (n > PL_MAX_TABLES) return sd3d_set_error(SD3D_ERR_ARG, "pair_lists_batch: at most 16 tables per call");
+    sd3d_pair_table_desc d[PL_MAX_TABLES];
+    for (int i = 0; i < n; ++i) {
+        d[i].nbr = nbr[i]; d[i].pos = pos[i]; d[i].in_idx = in_idx[i]; d[i].tile_k = tile_k[i]; d[i].rlist = nullptr; d[i].out_idx = nullptr;
+        d[i].M = M[i]; d[i].p_cap = p_cap[i]; d[i].K = K[i]; d[i].center = -1; d[i].rl_stride = 0; d[i].meta = 0;
+    }
+    return launch_pair_lists_desc(n, d, ws, ws_bytes, st);
+}
+
+static int env_flag(const char* name, int dflt) { const char* e = getenv(name); return e ? atoi(e) : dflt; }
+
+// rlist / rl_stride / center / out_idx: optional products of launch_pair_lists_desc (NULL / -1: the round-1 path, pass 1 over all
+// offsets + pair_reduce_kernel over pos).  out_idx != NULL promises ONE pair per output row (transposed k2s2 convolution).
 int launch_pair_conv(const float* in0, int ld0, int C0, const float* in1, int ld1, const int32_t* in_idx, const int32_t* tile_k,
-                     int64_t p_cap, const int32_t* pos, const float* wt, int K, int Cin, int Cout, int64_t M, const float* scale,
+                     int64_t p_cap, const int32_t* pos, const int32_t* rlist, int rl_stride, int center, const int32_t* out_idx,
+                     const float* wt, int K, int Cin, int Cout, int64_t M, const float* scale,
                      const float* shift, const float* res, int ld_res, float* out, int ld_out, int act, float* part,
                      size_t part_bytes, hipStream_t st) {
     if (M <= 0 || Cout <= 0) return SD3D_OK;
@@ -685,9 +1024,35 @@ int launch_pair_conv(const float* in0, int ld0, int C0, const float* in1, int ld
     if ((ld0 & 3) || (in1 && (ld1 & 3)) || (ld_out & 3)) return sd3d_set_error(SD3D_ERR_ARG, "pair_conv: row strides must be multiples of 4 floats");
     if (p_cap <= 0 || (p_cap % PT)) return sd3d_set_error(SD3D_ERR_ARG, "pair_conv: p_cap must be a positive multiple of 128");
     if (part_bytes < (size_t)p_cap * Cout * sizeof(float)) return sd3d_set_error(SD3D_ERR_ARG, "pair_conv: partial-product buffer too small");
+    static int n_cu = 0;
+    if (!n_cu) {
+        int dev = 0; hipDeviceProp_t prop;
+        if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return sd3d_set_error(SD3D_ERR_LAUNCH, "pair_conv: no device");
+        n_cu = prop.multiProcessorCount;
+    }
+    // SD3D_PAIR_CENTER / SD3D_PAIR_DIRECT / SD3D_PAIR_RL = 0 switch the round-3 paths off one by one (A/B, cross-checks in the tests)
+    static const int center_env = env_flag("SD3D_PAIR_CENTER", 1), direct_env = env_flag("SD3D_PAIR_DIRECT", 1), rl_env = env_flag("SD3D_PAIR_RL", 1);
+    if ((ld_res & 3) && res) return sd3d_set_error(SD3D_ERR_ARG, "pair_conv: residual row stride must be a multiple of 4 floats");
+    const bool direct = out_idx != nullptr && direct_env;
+    // centre kernel configuration: NT column tiles of 32 per workgroup, W[centre] rows of the column group in LDS
+    int nt_c = 0, cgs_c = 0;
+    size_t lds_c = 0;
+    if (!direct && rlist && center_env && rl_env && center >= 0 && center < K && (Cout & 31) == 0) {
+        const int subc = Cout / 32;
+        for (int c = subc >= 4 ? 4 : subc; c >= 1; --c) {
+            if (subc % c) continue;
+            const size_t l = (size_t)(32 * c) * (Cin + 4) * sizeof(float);
+            if (l <= 150 * 1024) { nt_c = c; cgs_c = subc / c; lds_c = l; break; }
+        }
+    }
+    const bool fused = nt_c > 0;
     PGParams g;
     g.in0 = in0; g.ld0 = ld0; g.C0 = C0; g.in1 = in1; g.ld1 = ld1; g.in_idx = in_idx; g.tile_k = tile_k; g.wt = wt;
     g.Cin = Cin; g.Cout = Cout; g.part = part;
+    g.skip_center = fused ? 1 : 0;
+    g.out_idx = direct ? out_idx : nullptr;
+    g.scale = scale; g.shift = shift; g.res = res; g.ld_res = ld_res; g.out = out; g.ld_out = ld_out; g.act = act;
+    const bool pass1 = !(fused && K == 1);                     // a K = 1 table is its own centre: the dense kernel is the whole convolution
     const int sub = (Cout + 31) / 32;
     int nt = sub >= 4 ? 4 : sub;
     if (sub > 4 && sub % 4) { for (int c = 4; c >= 1; --c) if (sub % c == 0) { nt = c; break; } }
@@ -695,12 +1060,6 @@ int launch_pair_conv(const float* in0, int ld0, int C0, const float* in1, int ld
     g.n_tiles = (int)(p_cap / PT);
     static int slots_env = -1;                                 // SD3D_PAIR_SLOTS: workgroups per CU override (tuning)
     if (slots_env < 0) { const char* e = getenv("SD3D_PAIR_SLOTS"); slots_env = e ? atoi(e) : 0; }
-    static int n_cu = 0;
-    if (!n_cu) {
-        int dev = 0; hipDeviceProp_t prop;
-        if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return sd3d_set_error(SD3D_ERR_LAUNCH, "pair_conv: no device");
-        n_cu = prop.multiProcessorCount;
-    }
     // weight-stationary variant: Cout = 32 * nt <= 128 and W[k] (padded rows) <= 68 KB of LDS
     static int ws_env = -1;
     if (ws_env < 0) { const char* e = getenv("SD3D_PAIR_WS"); ws_env = e ? atoi(e) : 1; }
@@ -721,13 +1080,18 @@ int launch_pair_conv(const float* in0, int ld0, int C0, const float* in1, int ld
     if (ws2_env < 0) { const char* e = getenv("SD3D_PAIR_WS2"); ws2_env = e ? atoi(e) : 1; }
     // (measured: level-3 256->256, 1808 tiles: 358 -> 347 us; level-4, 472 tiles: 104 -> 113 us - too few tiles for half the workgroups)
     const bool ws_two = ws_env && ws2_env && !crowded && cgs == 2 && nt == 4 && Cout == 256 && g.n_tiles >= 1024 && w_lds_cg + WS_RANGE_TILES * PT * sizeof(int32_t) + 256 <= 160 * 1024;
-    if (ws_one || ws_two) {
+    if (!pass1) {
+    } else if (ws_one || ws_two) {
         static bool attr_done = false;
         if (!attr_done) {
             (void)hipFuncSetAttribute((const void*)pair_gemm_ws_kernel_1, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
             (void)hipFuncSetAttribute((const void*)pair_gemm_ws_kernel_2, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
             (void)hipFuncSetAttribute((const void*)pair_gemm_ws_kernel_3, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
             (void)hipFuncSetAttribute((const void*)pair_gemm_ws_kernel_4, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            (void)hipFuncSetAttribute((const void*)pair_gemm_ws_direct_kernel_1, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
+            (void)hipFuncSetAttribute((const void*)pair_gemm_ws_direct_kernel_2, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
+            (void)hipFuncSetAttribute((const void*)pair_gemm_ws_direct_kernel_3, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
+            (void)hipFuncSetAttribute((const void*)pair_gemm_ws_direct_kernel_4, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
             attr_done = true;
         }
         // resident workgroups per CU: the pinned register budgets allow 4 / 3 / 3 / 2; LDS (160 KB) may allow fewer
@@ -741,11 +1105,20 @@ int launch_pair_conv(const float* in0, int ld0, int C0, const float* in1, int ld
         { static int gx_env = -1; if (gx_env < 0) { const char* e = getenv("SD3D_PAIR_GX"); gx_env = e ? atoi(e) : 0; } if (gx_env > 0) gx = gx_env; }
         const dim3 wgrid((unsigned)gx, ws_two ? 2u : 1u);
         const size_t lds = w_need + (size_t)WS_RANGE_TILES * PT * sizeof(int32_t);
-        switch (nt) {
-            case 1: hipLaunchKernelGGL(pair_gemm_ws_kernel_1, wgrid, dim3(256), lds, st, g); break;
-            case 2: hipLaunchKernelGGL(pair_gemm_ws_kernel_2, wgrid, dim3(256), lds, st, g); break;
-            case 3: hipLaunchKernelGGL(pair_gemm_ws_kernel_3, wgrid, dim3(256), lds, st, g); break;
-            default: hipLaunchKernelGGL(pair_gemm_ws_kernel_4, wgrid, dim3(256), lds, st, g); break;
+        if (direct) {
+            switch (nt) {
+                case 1: hipLaunchKernelGGL(pair_gemm_ws_direct_kernel_1, wgrid, dim3(256), lds, st, g); break;
+                case 2: hipLaunchKernelGGL(pair_gemm_ws_direct_kernel_2, wgrid, dim3(256), lds, st, g); break;
+                case 3: hipLaunchKernelGGL(pair_gemm_ws_direct_kernel_3, wgrid, dim3(256), lds, st, g); break;
+                default: hipLaunchKernelGGL(pair_gemm_ws_direct_kernel_4, wgrid, dim3(256), lds, st, g); break;
+            }
+        } else {
+            switch (nt) {
+                case 1: hipLaunchKernelGGL(pair_gemm_ws_kernel_1, wgrid, dim3(256), lds, st, g); break;
+                case 2: hipLaunchKernelGGL(pair_gemm_ws_kernel_2, wgrid, dim3(256), lds, st, g); break;
+                case 3: hipLaunchKernelGGL(pair_gemm_ws_kernel_3, wgrid, dim3(256), lds, st, g); break;
+                default: hipLaunchKernelGGL(pair_gemm_ws_kernel_4, wgrid, dim3(256), lds, st, g); break;
+            }
         }
     } else {
         int per_cu = nt == 1 ? 3 : 2;
@@ -753,17 +1126,63 @@ int launch_pair_conv(const float* in0, int ld0, int C0, const float* in1, int ld
         int gx = n_cu * per_cu / cgs;
         gx = gx < 1 ? 1 : (gx < g.n_tiles ? gx : g.n_tiles);
         const dim3 grid((unsigned)gx, (unsigned)cgs);
-        switch (nt) {
-            case 1: hipLaunchKernelGGL(pair_gemm_kernel_1, grid, dim3(256), 0, st, g); break;
-            case 2: hipLaunchKernelGGL(pair_gemm_kernel_2, grid, dim3(256), 0, st, g); break;
-            case 3: hipLaunchKernelGGL(pair_gemm_kernel_3, grid, dim3(256), 0, st, g); break;
-            default: hipLaunchKernelGGL(pair_gemm_kernel_4, grid, dim3(256), 0, st, g); break;
+        if (direct) {
+            switch (nt) {
+                case 1: hipLaunchKernelGGL(pair_gemm_direct_kernel_1, grid, dim3(256), 0, st, g); break;
+                case 2: hipLaunchKernelGGL(pair_gemm_direct_kernel_2, grid, dim3(256), 0, st, g); break;
+                case 3: hipLaunchKernelGGL(pair_gemm_direct_kernel_3, grid, dim3(256), 0, st, g); break;
+                default: hipLaunchKernelGGL(pair_gemm_direct_kernel_4, grid, dim3(256), 0, st, g); break;
+            }
+        } else {
+            switch (nt) {
+                case 1: hipLaunchKernelGGL(pair_gemm_kernel_1, grid, dim3(256), 0, st, g); break;
+                case 2: hipLaunchKernelGGL(pair_gemm_kernel_2, grid, dim3(256), 0, st, g); break;
+                case 3: hipLaunchKernelGGL(pair_gemm_kernel_3, grid, dim3(256), 0, st, g); break;
+                default: hipLaunchKernelGGL(pair_gemm_kernel_4, grid, dim3(256), 0, st, g); break;
+            }
         }
     }
-    PRParams r;
-    r.pos = pos; r.K = K; r.M = M; r.part = part; r.Cout = Cout; r.scale = scale; r.shift = shift; r.res = res; r.ld_res = ld_res;
-    r.out = out; r.ld_out = ld_out; r.act = act;
-    hipLaunchKernelGGL(pair_reduce_kernel, dim3((unsigned)cdiv(M * (Cout / 4), 256)), dim3(256), 0, st, r);
+    if (direct) {                                              // pass 1 wrote the output rows
+    } else if (fused) {
+        static bool cattr_done = false;
+        if (!cattr_done) {
+            (void)hipFuncSetAttribute((const void*)pair_center_kernel_1, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            (void)hipFuncSetAttribute((const void*)pair_center_kernel_2, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            (void)hipFuncSetAttribute((const void*)pair_center_kernel_3, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            (void)hipFuncSetAttribute((const void*)pair_center_kernel_4, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            cattr_done = true;
+        }
+        PCParams c;
+        c.in0 = in0; c.ld0 = ld0; c.C0 = C0; c.in1 = in1; c.ld1 = ld1; c.wt = wt + (int64_t)center * Cout * Cin; c.Cin = Cin; c.Cout = Cout;
+        c.M = M; c.rlist = rlist; c.rl_stride = rl_stride; c.part = part; c.scale = scale; c.shift = shift; c.res = res; c.ld_res = ld_res;
+        c.out = out; c.ld_out = ld_out; c.act = act;
+        int per_cu = nt_c == 1 ? 4 : (nt_c == 3 ? 3 : 2);       // the pinned register budgets
+        const int by_lds = (int)((160 * 1024) / (lds_c + 256));
+        per_cu = per_cu < by_lds ? per_cu : by_lds;
+        per_cu = per_cu < 1 ? 1 : per_cu;
+        static const int cslots = env_flag("SD3D_PAIR_CENTER_SLOTS", 0);
+        if (cslots > 0) per_cu = cslots;
+        const int n_tiles_c = (int)cdiv(M, PT);
+        int gx = n_cu * per_cu / cgs_c;
+        gx = gx < 1 ? 1 : (gx < n_tiles_c ? gx : n_tiles_c);
+        const dim3 cgrid((unsigned)gx, (unsigned)cgs_c);
+        switch (nt_c) {
+            case 1: hipLaunchKernelGGL(pair_center_kernel_1, cgrid, dim3(256), lds_c, st, c); break;
+            case 2: hipLaunchKernelGGL(pair_center_kernel_2, cgrid, dim3(256), lds_c, st, c); break;
+            case 3: hipLaunchKernelGGL(pair_center_kernel_3, cgrid, dim3(256), lds_c, st, c); break;
+            default: hipLaunchKernelGGL(pair_center_kernel_4, cgrid, dim3(256), lds_c, st, c); break;
+        }
+    } else if (rlist && rl_env && center < 0) {                 // (a list that leaves the centre out is only complete with the centre kernel)
+        PRLParams r;
+        r.rlist = rlist; r.rl_stride = rl_stride; r.M = M; r.part = part; r.Cout = Cout; r.scale = scale; r.shift = shift; r.res = res;
+        r.ld_res = ld_res; r.out = out; r.ld_out = ld_out; r.act = act;
+        hipLaunchKernelGGL(pair_reduce_rl_kernel, dim3((unsigned)cdiv(M * (Cout / 4), 256)), dim3(256), 0, st, r);
+    } else {
+        PRParams r;
+        r.pos = pos; r.K = K; r.M = M; r.part = part; r.Cout = Cout; r.scale = scale; r.shift = shift; r.res = res; r.ld_res = ld_res;
+        r.out = out; r.ld_out = ld_out; r.act = act;
+        hipLaunchKernelGGL(pair_reduce_kernel, dim3((unsigned)cdiv(M * (Cout / 4), 256)), dim3(256), 0, st, r);
+    }
     SD3D_CHECK_LAUNCH();
     return SD3D_OK;
 }

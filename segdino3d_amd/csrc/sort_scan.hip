@@ -349,6 +349,16 @@ int launch_f32_to_sortkey(const float* x, int64_t n, int desc, uint64_t* keys, h
     SD3D_CHECK_LAUNCH();
     return SD3D_OK;
 }
+__global__ void i64_to_sortkey_add(const int64_t* __restrict__ x, int64_t n, uint64_t add, uint64_t* __restrict__ keys) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) keys[i] = (uint64_t)x[i] + add;
+}
+int launch_i64_to_sortkey_add(const int64_t* x, int64_t n, uint64_t add, uint64_t* keys, hipStream_t st) {
+    if (n <= 0) return SD3D_OK;
+    hipLaunchKernelGGL(i64_to_sortkey_add, dim3((unsigned)cdiv(n, 256)), dim3(256), 0, st, x, n, add, keys);
+    SD3D_CHECK_LAUNCH();
+    return SD3D_OK;
+}
 int launch_i64_to_sortkey(const int64_t* x, int64_t n, uint64_t* keys, hipStream_t st) {
     if (n <= 0) return SD3D_OK;
     hipLaunchKernelGGL(i64_to_sortkey, dim3((unsigned)cdiv(n, 256)), dim3(256), 0, st, x, n, keys);

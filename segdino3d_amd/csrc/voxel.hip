@@ -11,6 +11,7 @@
 //   voxel_mean    : per-voxel unweighted mean of point features (wave per voxel, ascending point order)
 //   pool          : fused devoxelise + superpoint mean of features and quantised positions
 #include "common.h"
+#include "../../include/segdino3d_hip.h"
 
 // ---------------------------------------------------------------------------------------------
 // scene statistics: stats[0:3]=min xyz, [3:6]=max xyz, [6:9]=sum xyz (fp32)
@@ -152,9 +153,10 @@ __device__ static inline bool parent_valid(uint64_t pkey, const ExtentClip& c) {
     uint32_t x[3];
     morton_decode(pkey & SD3D_MORTON_MASK, x[0], x[1], x[2]);
     const int off = 32 >> c.level;                       // key origin is -32 voxels of level 0
+    const float* st = c.stats + 9 * (int)((pkey >> SD3D_MORTON_BITS) & 0xFF);   // stats row of the key's scene (batch bits)
 #pragma unroll
     for (int a = 0; a < 3; ++a) {
-        int D = (int)floorf((c.stats[3 + a] - c.stats[a]) * c.inv_voxel) + 1;
+        int D = (int)floorf((st[3 + a] - st[a]) * c.inv_voxel) + 1;
         D = D > c.min_shape ? D : c.min_shape;
         for (int i = 0; i < c.level; ++i) D = (D - 2) / 2 + 1;
         if ((int)x[a] - off >= D) return false;
@@ -409,14 +411,12 @@ int launch_stride_maps(const uint64_t* fkeys, const int32_t* parent, int64_t n_f
 // Members of a voxel are visited in ascending point index (stable sort) => deterministic sum.
 // Columns C..ld_out-1 are written as zero (K padding for the first convolution).
 // ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void voxel_mean_kernel(const float* __restrict__ pts, int ld_pts,
-                                                         const float* __restrict__ f2d, int F, int mode,
-                                                         const float* __restrict__ stats, float inv_n,
-                                                         const uint32_t* __restrict__ sidx, const int32_t* __restrict__ seg_start,
-                                                         int64_t n_vox, float* __restrict__ out, int ld_out) {
+// `poff` = index of the scene's first point in the batch-global point numbering of sidx (0 for a single scene)
+__device__ __forceinline__ void voxel_mean_body(const float* __restrict__ pts, int ld_pts, const float* __restrict__ f2d, int F, int mode,
+                                                const float* __restrict__ stats, float inv_n, int64_t poff,
+                                                const uint32_t* __restrict__ sidx, const int32_t* __restrict__ seg_start, int64_t v,
+                                                float* __restrict__ out, int ld_out) {
     const int lane = threadIdx.x & 63;
-    const int64_t v = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (v >= n_vox) return;
     const int j0 = seg_start[v], j1 = seg_start[v + 1];
     const int C = (mode == 0) ? 3 + F : (mode == 1 ? 3 : 6 + F);
     const float cnt = (float)(j1 - j0);
@@ -427,7 +427,7 @@ __global__ __launch_bounds__(256) void voxel_mean_kernel(const float* __restrict
         for (int jb = j0; jb < j1; jb += 4) {
             int64_t pp[4];
 #pragma unroll
-            for (int u = 0; u < 4; ++u) pp[u] = jb + u < j1 ? (int64_t)sidx[jb + u] : -1;
+            for (int u = 0; u < 4; ++u) pp[u] = jb + u < j1 ? (int64_t)sidx[jb + u] - poff : -1;
             float x[4][5];
 #pragma unroll
             for (int u = 0; u < 4; ++u)
@@ -460,7 +460,7 @@ __global__ __launch_bounds__(256) void voxel_mean_kernel(const float* __restrict
         float s = 0.f;
         if (c < C) {
             for (int j = j0; j < j1; ++j) {
-                const int64_t p = sidx[j];
+                const int64_t p = (int64_t)sidx[j] - poff;
                 float x;
                 if (c < 3) x = pts[p * ld_pts + 3 + c];
                 else if (mode == 2 && c < 6) x = pts[p * ld_pts + (c - 3)] - stats[6 + (c - 3)] * inv_n;
@@ -473,12 +473,54 @@ __global__ __launch_bounds__(256) void voxel_mean_kernel(const float* __restrict
     }
 }
 
+__global__ __launch_bounds__(256) void voxel_mean_kernel(const float* __restrict__ pts, int ld_pts,
+                                                         const float* __restrict__ f2d, int F, int mode,
+                                                         const float* __restrict__ stats, float inv_n,
+                                                         const uint32_t* __restrict__ sidx, const int32_t* __restrict__ seg_start,
+                                                         int64_t n_vox, float* __restrict__ out, int ld_out) {
+    const int64_t v = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (v >= n_vox) return;
+    voxel_mean_body(pts, ld_pts, f2d, F, mode, stats, inv_n, 0, sidx, seg_start, v, out, ld_out);
+}
+
+// Several scenes voxelised as ONE block-diagonal tensor (batch index in the key bits above the Z-order code): a voxel finds its
+// scene's source arrays from its key.  Per voxel the arithmetic is the single-scene kernel's (same point order, same sums).
+struct VMBatch { int n; sd3d_scene_src s[SD3D_MAX_BATCH]; };
+__global__ __launch_bounds__(256) void voxel_mean_batch_kernel(const VMBatch b, int F, int mode, const uint64_t* __restrict__ ukeys,
+                                                               const uint32_t* __restrict__ sidx, const int32_t* __restrict__ seg_start,
+                                                               int64_t n_vox, float* __restrict__ out, int ld_out) {
+    const int64_t v = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (v >= n_vox) return;
+    int bi = (int)((ukeys[v] >> SD3D_MORTON_BITS) & 0xFF);
+    bi = __builtin_amdgcn_readfirstlane(bi < b.n ? bi : 0);
+    const sd3d_scene_src& sc = b.s[bi];
+    voxel_mean_body(sc.points, sc.ld_points, sc.feats2d, F, mode, sc.stats, 1.0f / (float)sc.n_points, sc.point_off, sidx, seg_start, v,
+                    out, ld_out);
+}
+
 int launch_voxel_mean(const float* pts, int ld_pts, const float* f2d, int F, int mode, const float* stats, int64_t n_points,
                       const uint32_t* sidx, const int32_t* seg_start, int64_t n_vox, float* out, int ld_out, hipStream_t st) {
     if (n_vox <= 0) return SD3D_OK;
     if (mode != 1 && !f2d) return sd3d_set_error(SD3D_ERR_ARG, "voxel_mean: 2D features missing");
     hipLaunchKernelGGL(voxel_mean_kernel, dim3((unsigned)cdiv(n_vox, 4)), dim3(256), 0, st, pts, ld_pts, f2d, F, mode, stats,
                        1.0f / (float)n_points, sidx, seg_start, n_vox, out, ld_out);
+    SD3D_CHECK_LAUNCH();
+    return SD3D_OK;
+}
+
+int launch_voxel_mean_batch(const sd3d_scene_src* scenes, int n_scenes, int F, int mode, const uint64_t* ukeys, const uint32_t* sidx,
+                            const int32_t* seg_start, int64_t n_vox, float* out, int ld_out, hipStream_t st) {
+    if (n_vox <= 0) return SD3D_OK;
+    if (n_scenes <= 0 || n_scenes > SD3D_MAX_BATCH) return sd3d_set_error(SD3D_ERR_ARG, "voxel_mean_batch: 1..16 scenes per call");
+    VMBatch b;
+    b.n = n_scenes;
+    for (int i = 0; i < n_scenes; ++i) {
+        b.s[i] = scenes[i];
+        if (!scenes[i].points || scenes[i].n_points <= 0 || !scenes[i].stats) return sd3d_set_error(SD3D_ERR_ARG, "voxel_mean_batch: scene without points / stats");
+        if (mode != 1 && !scenes[i].feats2d) return sd3d_set_error(SD3D_ERR_ARG, "voxel_mean_batch: 2D features missing");
+    }
+    hipLaunchKernelGGL(voxel_mean_batch_kernel, dim3((unsigned)cdiv(n_vox, 4)), dim3(256), 0, st, b, F, mode, ukeys, sidx, seg_start, n_vox,
+                       out, ld_out);
     SD3D_CHECK_LAUNCH();
     return SD3D_OK;
 }
@@ -557,6 +599,34 @@ __global__ __launch_bounds__(256) void pool_superpoints_kernel(const float* __re
             out_pos[s * 3 + (li - nvec)] = pacc / den;
         }
     }
+}
+
+// sorted ids = (scene << 32) | superpoint id of the scene; dense id = off[scene] + id (scenes one after the other)
+struct SegOff { int n; int32_t off[SD3D_MAX_BATCH]; };
+__global__ __launch_bounds__(256) void segment_starts_batch_kernel(const uint64_t* __restrict__ sorted_ids, int64_t n, int64_t S,
+                                                                   const SegOff so, int32_t* __restrict__ start /*[S+1]*/) {
+    const int64_t j = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (j > n) return;
+    auto dense = [&](uint64_t key) -> int64_t {
+        int b = (int)(key >> 32);
+        b = b < so.n ? b : so.n - 1;
+        return (int64_t)so.off[b] + (int64_t)(key & 0xFFFFFFFFull);
+    };
+    const int64_t prev = (j == 0) ? -1 : dense(sorted_ids[j - 1]);
+    int64_t cur = (j == n) ? S : dense(sorted_ids[j]);
+    if (cur > S) cur = S;
+    for (int64_t s = prev + 1; s <= cur; ++s) start[s] = (int32_t)j;
+}
+
+int launch_segment_starts_batch(const uint64_t* sorted_ids, int64_t n, int64_t S, const int32_t* off_host, int n_scenes, int32_t* start,
+                                hipStream_t st) {
+    if (n_scenes <= 0 || n_scenes > SD3D_MAX_BATCH) return sd3d_set_error(SD3D_ERR_ARG, "segment_starts_batch: 1..16 scenes per call");
+    SegOff so;
+    so.n = n_scenes;
+    for (int i = 0; i < n_scenes; ++i) so.off[i] = off_host[i];
+    hipLaunchKernelGGL(segment_starts_batch_kernel, dim3((unsigned)cdiv(n + 1, 256)), dim3(256), 0, st, sorted_ids, n, S, so, start);
+    SD3D_CHECK_LAUNCH();
+    return SD3D_OK;
 }
 
 int launch_segment_starts(const uint64_t* sorted_ids, int64_t n, int64_t S, int32_t* start, hipStream_t st) {

@@ -154,10 +154,13 @@ class PipelinedRunner:
     are enough to keep both streams fed.  Results keep their submission order.
     """
 
-    def __init__(self, model, n_streams: int = 2, device=None):
+    def __init__(self, model, n_streams: int = 2, device=None, batch: int = 1):
+        """batch > 1: every forward takes `batch` consecutive scenes as ONE block-diagonal sparse tensor
+        (sparse.BatchSceneMaps; evaluation only) - each stream then keeps a whole batch in flight."""
         import threading
         self.model = model
         self.n = max(1, int(n_streams))
+        self.batch = max(1, int(batch))
         self.device = device if device is not None else torch.device("cuda", torch.cuda.current_device())
         self.streams = [torch.cuda.Stream(device=self.device) for _ in range(self.n)]
         self._threading = threading
@@ -190,11 +193,14 @@ class PipelinedRunner:
                     baton.acquire()
                     ops.set_baton(baton)
                 with torch.cuda.stream(self.streams[wid]), torch.no_grad():
-                    for i in range(wid, len(scenes), self.n):
-                        pts, tgt = scenes[i]
-                        results[i] = self.model([pts], [tgt])
-                        if on_result is not None:
-                            on_result(i, results[i])
+                    B = self.batch
+                    for g in range(wid, (len(scenes) + B - 1) // B, self.n):
+                        ids = range(g * B, min(len(scenes), (g + 1) * B))
+                        out = self.model([scenes[i][0] for i in ids], [scenes[i][1] for i in ids])
+                        for j, i in enumerate(ids):
+                            results[i] = [out[j]]
+                            if on_result is not None:
+                                on_result(i, results[i])
                     ops.wait_event(ops.stream_event())
             except BaseException as e:  # noqa: BLE001 - re-raised in the caller's thread
                 errors.append(e)
@@ -272,16 +278,22 @@ def _pipelined_run_stream(self, it, on_result=None):
                 ops.set_baton(baton)
             with torch.cuda.stream(self.streams[wid]), torch.no_grad():
                 while True:
+                    group = []
                     with take:
-                        try:
-                            pts, tgt = next(it)
-                        except StopIteration:
-                            break
-                        i = counter[0]
-                        counter[0] += 1
-                    results[i] = self.model([pts], [tgt])
-                    if on_result is not None:
-                        on_result(i, results[i])
+                        for _ in range(self.batch):
+                            try:
+                                pts, tgt = next(it)
+                            except StopIteration:
+                                break
+                            group.append((counter[0], pts, tgt))
+                            counter[0] += 1
+                    if not group:
+                        break
+                    out = self.model([g[1] for g in group], [g[2] for g in group])
+                    for j, (i, _, _) in enumerate(group):
+                        results[i] = [out[j]]
+                        if on_result is not None:
+                            on_result(i, results[i])
                 ops.wait_event(ops.stream_event())
         except BaseException as e:  # noqa: BLE001 - re-raised in the caller's thread
             errors.append(e)

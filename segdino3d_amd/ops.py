@@ -50,6 +50,38 @@ class stream_scope:
         return False
 
 
+class use_stream:
+    """Issue on `stream` (a torch.cuda.Stream) inside the scope: torch's current stream AND the bound handle of this thread's
+    ops move together.  The caller orders the streams (`stream.wait_stream(...)` before, `....wait_stream(stream)` after)."""
+
+    def __init__(self, stream):
+        self.stream = stream
+        self.ctx = torch.cuda.stream(stream)
+
+    def __enter__(self):
+        self.prev = getattr(_STREAM_TLS, "handle", None)
+        self.ctx.__enter__()
+        _STREAM_TLS.handle = self.stream.cuda_stream
+        return self
+
+    def __exit__(self, *exc):
+        _STREAM_TLS.handle = self.prev
+        return self.ctx.__exit__(*exc)
+
+
+_SIDE_TLS = threading.local()
+
+
+def side_streams(n: int, device=None):
+    """`n` side streams owned by the calling host thread (created once, reused by every forward of the thread)."""
+    pool = getattr(_SIDE_TLS, "pool", None)
+    if pool is None:
+        pool = _SIDE_TLS.pool = []
+    while len(pool) < n:
+        pool.append(torch.cuda.Stream(device=device))
+    return pool[:n]
+
+
 def bound_stream(fn):
     """Decorator form of stream_scope for the public forward entry points."""
     import functools
@@ -179,16 +211,21 @@ class Workspace:
 
 
 class _PerThread:
-    """One scratch buffer per host thread: each worker thread of the pipelined runner drives its own HIP
-    stream, and scratch must never be shared between streams."""
+    """One scratch buffer per (host thread, HIP stream): each worker thread of the pipelined runner drives its own stream, a
+    batched forward additionally fans its scenes' decoders out over side streams (`use_stream`), and scratch must never be
+    shared between streams."""
 
     def __init__(self):
         self._tls = threading.local()
 
     def get(self, nbytes: int, device):
-        ws = getattr(self._tls, "ws", None)
+        by_stream = getattr(self._tls, "ws", None)
+        if by_stream is None:
+            by_stream = self._tls.ws = {}
+        key = _stream()
+        ws = by_stream.get(key)
         if ws is None:
-            ws = self._tls.ws = Workspace()
+            ws = by_stream[key] = Workspace()
         return ws.get(nbytes, device)
 
 
@@ -249,26 +286,31 @@ def keys_from_i64(x: torch.Tensor):
 # --------------------------------------------------------------------------------------------
 # voxelisation / coordinate maps
 # --------------------------------------------------------------------------------------------
-def scene_stats(points: torch.Tensor):
-    """points [N, >=3] fp32 -> stats[9] = (min xyz, max xyz, sum xyz)."""
+def scene_stats(points: torch.Tensor, out: Optional[torch.Tensor] = None):
+    """points [N, >=3] fp32 -> stats[9] = (min xyz, max xyz, sum xyz); `out`: a contiguous fp32 [9] row to write into."""
     lib = _lib.load()
     p, ld = _rows(points, "points")
-    stats = torch.empty(9, dtype=torch.float32, device=points.device)
+    stats = torch.empty(9, dtype=torch.float32, device=points.device) if out is None else out
     ws = _WS.get(lib.sd3d_scene_stats_ws_bytes(), points.device)
     _lib.check(lib.sd3d_scene_stats(p, ld, points.shape[0], _ptr(stats), ws.data_ptr(), ws.numel(), _stream()),
                "scene_stats")
     return stats
 
 
-def voxel_keys(points, inv_voxel: float, stats, shift_to_min=False, batch_index=0, want_icoords=True):
+def voxel_keys(points, inv_voxel: float, stats, shift_to_min=False, batch_index=0, want_icoords=True, out=None):
+    """`out` = (keys [n] int64, icoords [n, 3] int32 | None, err [1] int32): slices of batch-wide buffers to write into
+    (the error flag is OR-ed, so several scenes may share it)."""
     lib = _lib.load()
     p, ld = _rows(points, "points")
     n = points.shape[0]
     dev = points.device
-    keys = torch.empty(n, dtype=torch.int64, device=dev)
-    icoords = torch.empty(n, 3, dtype=torch.int32, device=dev) if want_icoords else None
+    if out is not None:
+        keys, icoords, err = out
+    else:
+        keys = torch.empty(n, dtype=torch.int64, device=dev)
+        icoords = torch.empty(n, 3, dtype=torch.int32, device=dev) if want_icoords else None
+        err = torch.zeros(1, dtype=torch.int32, device=dev)
     origin = torch.empty(3, dtype=torch.int32, device=dev)
-    err = torch.zeros(1, dtype=torch.int32, device=dev)
     _lib.check(lib.sd3d_voxel_keys(p, ld, n, float(inv_voxel), _ptr(stats, torch.float32, "stats"), int(shift_to_min),
                                    int(batch_index), _ptr(origin), _ptr(keys), _ptr(icoords), _ptr(err), _stream()),
                "voxel_keys")
@@ -340,6 +382,53 @@ def voxel_mean(points, feats2d, mode, stats, sorted_idx, seg_start, n_vox, ld_ou
                                    _ptr(sorted_idx, torch.int32, "sorted_idx"), _ptr(seg_start, torch.int32, "seg_start"),
                                    n_vox, _ptr(out), ld_out, _stream()), "voxel_mean")
     return out
+
+
+def voxel_mean_batch(scenes, mode, ukeys, sorted_idx, seg_start, n_vox, ld_out):
+    """scenes: [(points [N_i, >=6], feats2d [N_i, F] | None, stats [9], point_off)] of one batch (sparse.BatchSceneMaps);
+    one launch over the voxels of all scenes."""
+    import numpy as np
+    lib = _lib.load()
+    dt = np.dtype([("points", "<u8"), ("feats2d", "<u8"), ("stats", "<u8"), ("point_off", "<i8"), ("n_points", "<i8"),
+                   ("ld_points", "<i4"), ("pad_", "<i4")], align=True)
+    assert dt.itemsize == 48
+    tab = np.zeros(len(scenes), dtype=dt)
+    F = 0
+    for i, (pts, f2d, stats, off) in enumerate(scenes):
+        p, ld = _rows(pts, "points")
+        if f2d is not None:
+            if F and f2d.shape[1] != F:
+                raise ValueError("voxel_mean_batch: every scene must carry the same number of 2D feature channels")
+            F = f2d.shape[1]
+        tab[i] = (p, 0 if f2d is None else _ptr(f2d, torch.float32, "feats2d"), _ptr(stats, torch.float32, "stats"), int(off),
+                  pts.shape[0], ld, 0)
+    dev = scenes[0][0].device
+    out = torch.empty(n_vox, ld_out, dtype=torch.float32, device=dev)
+    _lib.check(lib.sd3d_voxel_mean_batch(tab.ctypes.data, len(scenes), F, mode, _ptr(ukeys, torch.int64, "ukeys"),
+                                         _ptr(sorted_idx, torch.int32, "sorted_idx"), _ptr(seg_start, torch.int32, "seg_start"),
+                                         n_vox, _ptr(out), ld_out, _stream()), "voxel_mean_batch")
+    return out
+
+
+def keys_from_i64_offset(x: torch.Tensor, add: int, out: torch.Tensor):
+    """out[i] = x[i] + add (out: a contiguous int64 slice of the batch-wide key buffer)."""
+    lib = _lib.load()
+    if out.numel() != x.numel():
+        raise ValueError("keys_from_i64_offset: output slice has another length")
+    _lib.check(lib.sd3d_keys_from_i64_offset(_ptr(x, torch.int64, "x"), x.numel(), int(add), _ptr(out, torch.int64, "out"), _stream()),
+               "keys_from_i64_offset")
+    return out
+
+
+def segment_starts_batch(sorted_ids, n, S, id_off):
+    """sorted (scene << 32 | id) keys -> start[S + 1] over the dense ids id_off[scene] + id."""
+    import ctypes as C
+    lib = _lib.load()
+    start = torch.empty(S + 1, dtype=torch.int32, device=sorted_ids.device)
+    offs = (C.c_int32 * len(id_off))(*[int(v) for v in id_off])
+    _lib.check(lib.sd3d_segment_starts_batch(_ptr(sorted_ids, torch.int64, "sorted_ids"), n, S, offs, len(id_off), _ptr(start),
+                                             _stream()), "segment_starts_batch")
+    return start
 
 
 def segment_starts(sorted_ids, n, S):
@@ -462,58 +551,67 @@ def clear_split_cache():
 
 
 class PairLists:
-    """Offset-major layout of one neighbour table (csrc/pair_gemm.hip): shared by every convolution that uses it."""
-    __slots__ = ("pos", "in_idx", "tile_k", "p_cap", "K", "M", "out_idx")
+    """Offset-major layout of one neighbour table (csrc/pair_gemm.hip): shared by every convolution that uses it.
+    Optional round-3 products (sd3d_pair_lists_desc): `rlist` [M, rl_stride] per-row partial-product lists, `center` = the
+    offset that pairs every row with itself (its product is made by the dense centre kernel, never stored), `direct` = every
+    output row has exactly one pair (`out_idx` is then built and pass 1 writes the output rows itself)."""
+    __slots__ = ("pos", "in_idx", "tile_k", "p_cap", "K", "M", "out_idx", "rlist", "rl_stride", "center", "direct")
 
-    def __init__(self, pos, in_idx, tile_k, p_cap, K, M):
+    def __init__(self, pos, in_idx, tile_k, p_cap, K, M, rlist=None, rl_stride=0, center=-1, out_idx=None, direct=False):
         self.pos, self.in_idx, self.tile_k, self.p_cap, self.K, self.M = pos, in_idx, tile_k, p_cap, K, M
-        self.out_idx = None                               # output row of every pair; built on demand (train_ops.pair_out_rows)
+        self.out_idx = out_idx                            # output row of every pair; built on demand otherwise (train_ops.pair_out_rows)
+        self.rlist, self.rl_stride, self.center, self.direct = rlist, rl_stride, center, direct
 
 
-def pair_lists(nbr, n_pairs):
-    """nbr int32 [K, M]; n_pairs = number of entries >= 0 (host int, e.g. from kernel_map's pair counter)."""
-    lib = _lib.load()
-    K, M = nbr.shape
-    p_cap = (int(n_pairs) + 127 * K + 127) // 128 * 128
-    pos = torch.empty(K, M, dtype=torch.int32, device=nbr.device)
-    in_idx = torch.empty(p_cap, dtype=torch.int32, device=nbr.device)
-    tile_k = torch.empty(p_cap // 128 + 1, dtype=torch.int32, device=nbr.device)     # last entry: number of real tiles
-    nb = lib.sd3d_pair_lists_ws_bytes(K, M)
-    ws = _WS4.get(nb, nbr.device)
-    _lib.check(lib.sd3d_pair_lists(_ptr(nbr, torch.int32, "nbr"), K, M, p_cap, pos.data_ptr(), in_idx.data_ptr(),
-                                   tile_k.data_ptr(), ws.data_ptr(), ws.numel(), _stream()), "pair_lists")
-    return PairLists(pos, in_idx, tile_k, p_cap, K, M)
+def pair_lists(nbr, n_pairs, center=-1, direct=False):
+    """nbr int32 [K, M]; n_pairs = number of entries >= 0 (host int, e.g. from kernel_map's pair counter).  `center` / `direct`:
+    see PairLists (the caller vouches for them: a stride-1 table of a voxel set onto itself / a one-pair-per-row table)."""
+    return pair_lists_batch([(nbr, n_pairs, center, direct)])[0]
 
 
 # Sparse convolutions run pair-major (pair_conv) whenever the caller hands over the table's PairLists;
 # SD3D_PAIR_CONV=0 keeps the output-stationary gather_gemm kernels (tuning / ablation).
 PAIR_CONV = _os.environ.get("SD3D_PAIR_CONV", "1") != "0"
+_PAIR_DESC_DT = None
 
 
 def pair_lists_batch(tables):
-    """tables: list of (nbr int32 [K, M], n_pairs) -> list of PairLists, built by ONE launch set (csrc/pair_gemm.hip)."""
-    import ctypes as C
+    """tables: list of (nbr int32 [K, M], n_pairs[, center[, direct]]) -> list of PairLists, built by ONE launch set
+    (csrc/pair_gemm.hip: count, scan, fill, per-row lists)."""
+    global _PAIR_DESC_DT
+    import numpy as np
+    if _PAIR_DESC_DT is None:
+        _PAIR_DESC_DT = np.dtype([("nbr", "<u8"), ("pos", "<u8"), ("in_idx", "<u8"), ("tile_k", "<u8"), ("rlist", "<u8"), ("out_idx", "<u8"),
+                                  ("M", "<i8"), ("p_cap", "<i8"), ("K", "<i4"), ("center", "<i4"), ("rl_stride", "<i4"), ("meta", "<i4")],
+                                 align=True)
+        assert _PAIR_DESC_DT.itemsize == 80
     lib = _lib.load()
     out = []
     for start in range(0, len(tables), 16):
         chunk = tables[start:start + 16]
-        n = len(chunk)
         dev = chunk[0][0].device
-        Ks = (C.c_int * n)(); Ms = (C.c_int64 * n)(); caps = (C.c_int64 * n)()
-        nbrs = (C.c_void_p * n)(); poss = (C.c_void_p * n)(); idxs = (C.c_void_p * n)(); tks = (C.c_void_p * n)()
+        desc = np.zeros(len(chunk), dtype=_PAIR_DESC_DT)
         res, nb = [], 0
-        for i, (nbr, n_pairs) in enumerate(chunk):
+        for i, t in enumerate(chunk):
+            nbr, n_pairs = t[0], t[1]
+            center = int(t[2]) if len(t) > 2 else -1
+            direct = bool(t[3]) if len(t) > 3 else False
             K, M = nbr.shape
             p_cap = (int(n_pairs) + 127 * K + 127) // 128 * 128
             pos = torch.empty(K, M, dtype=torch.int32, device=dev)
             in_idx = torch.empty(p_cap, dtype=torch.int32, device=dev)
-            tile_k = torch.empty(p_cap // 128 + 1, dtype=torch.int32, device=dev)
-            Ks[i], Ms[i], caps[i] = K, M, p_cap
-            nbrs[i], poss[i], idxs[i], tks[i] = _ptr(nbr, torch.int32, "nbr"), pos.data_ptr(), in_idx.data_ptr(), tile_k.data_ptr()
+            tile_k = torch.empty(p_cap // 128 + 3, dtype=torch.int32, device=dev)     # [p_cap / 128]: number of real tiles, then the centre run
+            rl_stride = (K + 4 + 3) // 4 * 4
+            rlist = None if direct else torch.empty(M, rl_stride, dtype=torch.int32, device=dev)
+            out_idx = torch.empty(p_cap, dtype=torch.int32, device=dev) if direct else None
+            desc[i] = (_ptr(nbr, torch.int32, "nbr"), pos.data_ptr(), in_idx.data_ptr(), tile_k.data_ptr(),
+                       0 if rlist is None else rlist.data_ptr(), 0 if out_idx is None else out_idx.data_ptr(), M, p_cap, K, center,
+                       rl_stride, 1)
             nb += (lib.sd3d_pair_lists_ws_bytes(K, M) + 255) // 256 * 256
-            res.append(PairLists(pos, in_idx, tile_k, p_cap, K, M))
+            res.append(PairLists(pos, in_idx, tile_k, p_cap, K, M, rlist=rlist, rl_stride=rl_stride, center=center, out_idx=out_idx,
+                                 direct=direct))
         ws = _WS4.get(nb, dev)
-        _lib.check(lib.sd3d_pair_lists_batch(n, nbrs, Ks, Ms, caps, poss, idxs, tks, ws.data_ptr(), ws.numel(), _stream()), "pair_lists_batch")
+        _lib.check(lib.sd3d_pair_lists_desc(len(chunk), desc.ctypes.data, ws.data_ptr(), ws.numel(), _stream()), "pair_lists_desc")
         out += res
     return out
 
@@ -544,10 +642,12 @@ def pair_conv(x, wt, pairs, x2=None, scale=None, shift=None, res=None, act=None,
     hook = GG_HOOK
     if hook is not None:
         hook.before(dict(K=K, Cin=Cin, Cout=Cout, M=M, nbr=None, pairs=pairs))
-    _lib.check(lib.sd3d_pair_conv(p0, ld0, C0, p1, ld1, pairs.in_idx.data_ptr(), pairs.tile_k.data_ptr(), pairs.p_cap,
-                                  pairs.pos.data_ptr(), _ptr(wt, torch.float32, "wt"), K, Cin, Cout, M,
-                                  _ptr(scale, torch.float32, "scale"), _ptr(shift, torch.float32, "shift"), pr, ldr, po, ldo,
-                                  ACT[act], part.data_ptr(), part.numel(), _stream()), "pair_conv")
+    _lib.check(lib.sd3d_pair_conv_ex(p0, ld0, C0, p1, ld1, pairs.in_idx.data_ptr(), pairs.tile_k.data_ptr(), pairs.p_cap,
+                                     pairs.pos.data_ptr(), None if pairs.rlist is None else pairs.rlist.data_ptr(), pairs.rl_stride,
+                                     pairs.center, pairs.out_idx.data_ptr() if pairs.direct else None,
+                                     _ptr(wt, torch.float32, "wt"), K, Cin, Cout, M,
+                                     _ptr(scale, torch.float32, "scale"), _ptr(shift, torch.float32, "shift"), pr, ldr, po, ldo,
+                                     ACT[act], part.data_ptr(), part.numel(), _stream()), "pair_conv")
     if hook is not None:
         hook.after()
     return out

@@ -27,9 +27,9 @@ LAYER_DT = np.dtype([("kind", "<i4"), ("table", "<i4"), ("src0", "<i4"), ("src1"
                      ("K", "<i4"), ("Cin", "<i4"), ("C0", "<i4"), ("Cout", "<i4"), ("act", "<i4"), ("pad_", "<i4"),
                      ("wt", "<u8"), ("scale", "<u8"), ("shift", "<u8")], align=True)
 TABLE_DT = np.dtype([("in_idx", "<u8"), ("tile_k", "<u8"), ("pos", "<u8"), ("p_cap", "<i8"), ("M", "<i8"), ("K", "<i4"),
-                     ("pad_", "<i4")], align=True)
+                     ("pad_", "<i4"), ("rlist", "<u8"), ("out_idx", "<u8"), ("rl_stride", "<i4"), ("center", "<i4")], align=True)
 BUF_DT = np.dtype([("ptr", "<u8"), ("rows", "<i8"), ("ld", "<i4"), ("pad_", "<i4")], align=True)
-assert LAYER_DT.itemsize == 72 and TABLE_DT.itemsize == 48 and BUF_DT.itemsize == 24
+assert LAYER_DT.itemsize == 72 and TABLE_DT.itemsize == 72 and BUF_DT.itemsize == 24
 
 
 def table_level(key: Tuple) -> int:
@@ -158,7 +158,8 @@ class LayerPlan:
             pl = maps.pairs.get(key)
             if pl is None:
                 raise RuntimeError(f"neighbour table {key} has no pair lists (SceneMaps.prepare not called for it)")
-            tabs[i] = (pl.in_idx.data_ptr(), pl.tile_k.data_ptr(), pl.pos.data_ptr(), pl.p_cap, pl.M, pl.K, 0)
+            tabs[i] = (pl.in_idx.data_ptr(), pl.tile_k.data_ptr(), pl.pos.data_ptr(), pl.p_cap, pl.M, pl.K, 0,
+                       0 if pl.rlist is None else pl.rlist.data_ptr(), pl.out_idx.data_ptr() if pl.direct else 0, pl.rl_stride, pl.center)
             part_floats = max(part_floats, pl.p_cap * int(self.table_cout[i]))
         part = ops._WS3.get(part_floats * 4, x.device)
         ws = ops._WS2.get(256, x.device)

@@ -72,6 +72,12 @@ EXACT_PAIR_CAPACITY = os.environ.get("SD3D_EXACT_PAIRS", "1") == "1"
 # needs only half its hash probes.  SD3D_MIRRORED_MAPS=0 probes every offset (cross-check).
 MIRRORED_MAPS = os.environ.get("SD3D_MIRRORED_MAPS", "1") != "0"
 
+# SD3D_PAIR_CENTER=1: stride-1 tables hand their centre offset to the dense centre kernel (csrc/pair_gemm.hip pair_center_kernel:
+# no partial product stored for the centre, pass 2 fused behind the dense GEMM).  Parity-green and bit-reproducible, but measured
+# SLOWER than pass 1 over all offsets + the row-list pass 2 everywhere except the level-0 3^3 layers (137 vs 140 us; level 1
+# 96 -> 96: 293 vs 246 us, level 3 256 -> 256: 379 vs 340, level 4: 164 vs 105; profiles/r03_pair_paths.md), so it is opt-in.
+CENTER_KERNEL = os.environ.get("SD3D_PAIR_CENTER", "0") == "1"
+
 
 class SceneMaps:
     """Voxelisation + coordinate levels + neighbour tables of ONE scene, all on the HIP device."""
@@ -85,6 +91,7 @@ class SceneMaps:
         self.order = order
         self.device = points.device
         self.voxel_size = float(voxel_size)
+        self.clipped = clip_min_shape > 0
         N = points.shape[0]
         self.n_points = N
         inv = float(np.float32(1.0) / np.float32(voxel_size))
@@ -146,19 +153,21 @@ class SceneMaps:
         todo = []                                               # (key, nbr, pairs): all rulebooks of the scene in one launch set
         for (lvl, k), c in zip(same, host):
             self.density[("same", lvl, k)] = (c / max(1, k ** 3 * self.n_vox[lvl])) if exact else None
-            if ops.PAIR_CONV:
-                todo.append((("same", lvl, k), self._same[(lvl, k)], c))
+            if ops.PAIR_CONV:                                   # stride-1 table of the level onto itself: offset k^3 // 2 pairs every row with itself
+                todo.append((("same", lvl, k), self._same[(lvl, k)], c, (k ** 3) // 2 if (k % 2 and CENTER_KERNEL) else -1, False))
         for lvl in strides:
             # every fine voxel has exactly one parent: P = V_fine pairs in both directions
             self.density[("down", lvl)] = self.n_vox[lvl] / max(1, 8 * self.n_vox[lvl + 1])
             self.density[("up", lvl)] = 1.0 / 8.0
             if ops.PAIR_CONV and ("down", lvl) not in self.pairs:
                 dn, up = self._stride_maps(lvl)
-                todo.append((("down", lvl), dn, self.n_vox[lvl]))
-                todo.append((("up", lvl), up, self.n_vox[lvl]))
+                todo.append((("down", lvl), dn, self.n_vox[lvl], -1, False))
+                # transposed convolution: every fine voxel has exactly one parent - one pair per output row.  (Not with spconv's
+                # output-extent clip: fine voxels whose parent was dropped have NO pair and must still receive shift / activation.)
+                todo.append((("up", lvl), up, self.n_vox[lvl], -1, not self.clipped))
         if todo:
-            for (key, _, _), pl in zip(todo, ops.pair_lists_batch([(t[1], t[2]) for t in todo])):
-                self.pairs[key] = pl
+            for t, pl in zip(todo, ops.pair_lists_batch([t[1:] for t in todo])):
+                self.pairs[t[0]] = pl
 
     # ------------------------------------------------------------------------------------------
     def table(self, level: int):
@@ -220,6 +229,93 @@ class SceneMaps:
             out[("down", lvl)] = int((d >= 0).sum())
             out[("up", lvl)] = int((u >= 0).sum())
         return out
+
+
+class BatchSceneMaps(SceneMaps):
+    """B scenes voxelised as ONE block-diagonal sparse tensor for the evaluation forward - what ME.utils.batch_sparse_collate
+    builds for a batch (`minkunet.py:624-627`, collated by `utils/dataset_utils.py:215-230`): the scene index rides in the key
+    bits above the Z-order code, so ONE radix sort, ONE run-length unique per level, ONE hash table and ONE kernel-map launch per
+    level serve every scene, the rows of level l are the scenes' rows one after the other (each scene in its own Z-order, the
+    order a single-scene SceneMaps gives it), neighbour tables never cross scenes, and every convolution of the U-Net is one
+    launch over B times the pairs.  Evaluation BatchNorm is an affine map and every kernel on this path computes an output row
+    from that row's own pairs in a fixed order, so each scene's rows come out bit-identical to its single-scene forward
+    (tests/test_gpu_batch_eval.py).  Point / voxel / superpoint numbers are batch-global; `sp_off` splits the pooled rows."""
+
+    def __init__(self, points: Sequence[torch.Tensor], voxel_size: float, n_levels: int, shift_to_min: bool = False,
+                 order: str = "x_fastest", superpoints: Optional[Sequence[torch.Tensor]] = None, clip_min_shape: int = 0):
+        B = len(points)
+        if not 1 <= B <= 16:
+            raise ValueError("BatchSceneMaps: 1..16 scenes per batch (SD3D_MAX_BATCH)")
+        if not all(p.is_cuda for p in points):
+            raise RuntimeError("BatchSceneMaps needs device-resident points (no CPU fallback in the product path)")
+        self.order = order
+        self.device = dev = points[0].device
+        self.voxel_size = float(voxel_size)
+        self.clipped = clip_min_shape > 0
+        self.n_scenes = B
+        self.point_off = [0]
+        for p in points:
+            self.point_off.append(self.point_off[-1] + int(p.shape[0]))
+        N = self.point_off[-1]
+        self.n_points = N
+        inv = float(np.float32(1.0) / np.float32(voxel_size))
+        self.stats = torch.empty(B, 9, dtype=torch.float32, device=dev)
+        keys = torch.empty(N, dtype=torch.int64, device=dev)
+        self.icoords = torch.empty(N, 3, dtype=torch.int32, device=dev)
+        err = torch.zeros(1, dtype=torch.int32, device=dev)
+        for i, p in enumerate(points):
+            a, b = self.point_off[i], self.point_off[i + 1]
+            ops.scene_stats(p, out=self.stats[i])
+            ops.voxel_keys(p, inv, self.stats[i], shift_to_min, batch_index=i, out=(keys[a:b], self.icoords[a:b], err))
+        skeys, self.sidx = ops.sort_pairs(keys, None, 0, 56)
+        ukeys, self.seg_start, self.inverse, n0 = ops.unique_sorted(
+            skeys, self.sidx, N, None, 0, want_seg_start=True, want_map=True, map_size=N)
+        keys_l, counts, parents = [ukeys], [n0], []
+        for lvl in range(1, n_levels):
+            clip = (self.stats, inv, lvl, clip_min_shape) if clip_min_shape > 0 else None
+            uk, _, parent, nl = ops.unique_sorted(keys_l[-1], None, N, counts[-1], 3, want_seg_start=False, want_map=True, clip=clip)
+            keys_l.append(uk)
+            counts.append(nl)
+            parents.append(parent)
+        extra = [err]
+        self.superpoints = superpoints
+        if superpoints is not None:
+            sp_keys = torch.empty(N, dtype=torch.int64, device=dev)
+            for i, sp in enumerate(superpoints):
+                ops.keys_from_i64_offset(sp.contiguous(), i << 32, sp_keys[self.point_off[i]:self.point_off[i + 1]])
+            self.sp_sorted, self.sp_sidx = ops.sort_pairs(sp_keys, None, 0, 32 + max(1, (B - 1).bit_length()))
+            # largest id of scene i = low word of the last key of its run (the scenes' runs have the known lengths N_i)
+            extra += [self.sp_sorted[c - 1:c].view(torch.int32)[:1] for c in self.point_off[1:]]
+        host = ops.HostRead(torch.cat(counts + extra)).wait().tolist()   # synchronisation 1 of the batch (polled)
+        self.n_vox = [int(v) for v in host[:n_levels]]
+        if host[n_levels] != 0:
+            raise RuntimeError("scene exceeds the 16-bit-per-axis voxel key range (extent > ~1.3 km at 2 cm)")
+        self.sp_off = [0]
+        if superpoints is not None:
+            for v in host[n_levels + 1:n_levels + 1 + B]:
+                self.sp_off.append(self.sp_off[-1] + int(v) + 1)
+        self.n_superpoints = self.sp_off[-1]
+        self.keys = [k[: self.n_vox[l]] for l, k in enumerate(keys_l)]
+        self.parents = [p[: self.n_vox[l]] for l, p in enumerate(parents)]
+        self.seg_start = self.seg_start[: self.n_vox[0] + 1]
+        self._hash, self._same, self._stride = {}, {}, {}
+        self._perm8 = torch.from_numpy(child_perm(order)).to(self.device)
+        self._sp_start = None
+        self.density, self.pairs = {}, {}
+
+    def voxel_features(self, points: Sequence[torch.Tensor], feats2d, mode: int, ld_out: int, stats=None) -> torch.Tensor:
+        """points / feats2d: the scenes' tensors in batch order (feats2d None or a list)."""
+        if stats is not None:
+            raise NotImplementedError("BatchSceneMaps.voxel_features: per-scene override statistics are a training feature")
+        scenes = [(points[i], None if feats2d is None else feats2d[i], self.stats[i], self.point_off[i]) for i in range(self.n_scenes)]
+        return ops.voxel_mean_batch(scenes, mode, self.keys[0], self.sidx, self.seg_start, self.n_vox[0], ld_out)
+
+    def pool(self, feat: torch.Tensor, C: int):
+        """-> ([S_total, C], [S_total, 3]) over the batch-global superpoint numbering; scene i owns rows sp_off[i]:sp_off[i + 1]."""
+        if self._sp_start is None:
+            self._sp_start = ops.segment_starts_batch(self.sp_sorted, self.n_points, self.n_superpoints, self.sp_off[:-1])
+        return ops.pool_superpoints(feat, C, self.inverse, self.icoords, self.voxel_size, self.sp_sidx, self._sp_start,
+                                    self.n_superpoints)
 
 
 class BatchedMaps:

@@ -93,8 +93,12 @@ def test_pair_lists_cover_the_rulebook_exactly(scene):
         assert torch.equal(torch.sort(p)[0], torch.nonzero(pl.in_idx >= 0).squeeze(1))   # a bijection onto the real entries
         assert torch.equal(pl.in_idx.long()[p], nbr[valid].long())
         tk = pl.tile_k.long()
-        n_real = int(tk[-1])
-        assert bool((tk[:n_real] >= 0).all()) and bool((tk[n_real:-1] == -1).all())
+        n_real, c0, cn = (int(v) for v in tk[-3:])              # number of real tiles, then the centre offset's run of tiles
+        assert bool((tk[:n_real] >= 0).all()) and bool((tk[n_real:-3] == -1).all())
+        if pl.center >= 0:
+            assert cn == (M + 127) // 128 and bool((tk[c0:c0 + cn] == pl.center).all()) and (c0 == 0 or int(tk[c0 - 1]) == pl.center - 1)
+        else:
+            assert (c0, cn) == (0, 0)
         kk = torch.arange(K, device=nbr.device).unsqueeze(1).expand(K, M)[valid]
         assert torch.equal(tk[p // 128], kk)                                    # every pair sits in a tile of its offset
 

@@ -1,0 +1,199 @@
+"""The round-3 paths of the pair-major sparse convolution (csrc/pair_gemm.hip, entry sd3d_pair_conv_ex) against each other and
+against a float64 model of `ME.MinkowskiConvolution(Transpose) + BN + ReLU + residual` (`minkunet.py:135-192, 234-250`):
+  * centre kernel: a stride-1 table's centre offset as a dense GEMM whose epilogue adds the other offsets' partial products
+    (pass 1 skips the centre run; no partial product stored for it),
+  * per-row partial-product lists in pass 2 (down convolutions),
+  * direct epilogue: one pair per output row (transposed k2s2 convolutions) - pass 1 writes the output rows, no pass 2.
+The three older combinations (pos-based pass 2 over all offsets) stay reachable by stripping the optional products from a
+PairLists object, so every path is compared in ONE process on the same rulebook.  fp32 tolerance 2e-6 of the row magnitude
+(the paths differ in summation order only); each path must be bit-reproducible run to run."""
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def dev():
+    if not torch.cuda.is_available():
+        pytest.skip("needs a HIP device")
+    return torch.device("cuda:0")
+
+
+@pytest.fixture(scope="module")
+def scene_maps():
+    from segdino3d_amd.sparse import SceneMaps
+    from segdino3d_amd.synth import make_scene
+    d = dev()
+    pts, tgt = make_scene(3, 60_000, 800, 40)
+    maps = SceneMaps(pts.to(d), 0.02, 5, superpoints=tgt.extra_features["super_point_masks"].to(d))
+    maps.prepare(same=[(0, 5)] + [(l, 3) for l in range(5)], strides=[0, 1, 2, 3])
+    return maps
+
+
+def _variant(pl, **kw):
+    """A PairLists over the SAME device arrays with some optional products switched off."""
+    from segdino3d_amd.ops import PairLists
+    v = PairLists(pl.pos, pl.in_idx, pl.tile_k, pl.p_cap, pl.K, pl.M, rlist=pl.rlist, rl_stride=pl.rl_stride, center=pl.center,
+                  out_idx=pl.out_idx, direct=pl.direct)
+    for k, val in kw.items():
+        setattr(v, k, val)
+    return v
+
+
+def _ref64(x, w, nbr, scale, shift, res, act):
+    """float64 model: out[r] = act(scale * sum_k x[nbr[k][r]] . w[k]^T + shift + res[r])"""
+    K, M = nbr.shape
+    out = torch.zeros(M, w.shape[1], dtype=torch.float64, device=x.device)
+    xd, wd = x.double(), w.double()
+    for k in range(K):
+        rows = (nbr[k] >= 0).nonzero().squeeze(1)
+        if rows.numel():
+            out[rows] += xd[nbr[k][rows].long()] @ wd[k].t()
+    if scale is not None:
+        out = out * scale.double()
+    if shift is not None:
+        out = out + shift.double()
+    if res is not None:
+        out = out + res.double()
+    return torch.relu(out) if act == "relu" else out
+
+
+def _case(maps, key, cin, cout, split=0, use_res=True, act="relu", seed=0, center=False):
+    from segdino3d_amd import ops
+    d = maps.device
+    tab = maps.conv_table(*key)
+    nbr, pl = tab["nbr"], tab["pairs"]
+    K, M = nbr.shape
+    if center:                                                   # the same table with its centre offset handed to the dense kernel
+        pl = ops.pair_lists(nbr, int((nbr >= 0).sum()), center=K // 2)
+    n_in = int(nbr.max().item()) + 1
+    g = torch.Generator().manual_seed(seed)
+    x = torch.randn(n_in, cin, generator=g).to(d)
+    w = (torch.randn(K, cout, cin, generator=g) * (K * cin) ** -0.5 * 3).to(d)
+    scale = (0.5 + torch.rand(cout, generator=g)).to(d)
+    shift = (0.1 * torch.randn(cout, generator=g)).to(d)
+    res = torch.randn(M, cout, generator=g).to(d) if use_res else None
+    x1 = x2 = None
+    if split:
+        x1, x2 = x[:, :split].contiguous(), x[:, split:].contiguous()
+    return dict(nbr=nbr, pl=pl, x=x, x1=x1, x2=x2, w=w, scale=scale, shift=shift, res=res, act=act)
+
+
+def _run(c, pl):
+    from segdino3d_amd import ops
+    if c["x1"] is not None:
+        return ops.pair_conv(c["x1"], c["w"], pl, x2=c["x2"], scale=c["scale"], shift=c["shift"], res=c["res"], act=c["act"])
+    return ops.pair_conv(c["x"], c["w"], pl, scale=c["scale"], shift=c["shift"], res=c["res"], act=c["act"])
+
+
+def _close(a, ref, tol=2e-6):
+    mag = ref.abs().amax(dim=1, keepdim=True).clamp(min=1.0)
+    err = ((a.double() - ref).abs() / mag).max().item()
+    return err
+
+
+@pytest.mark.parametrize("key,cin,cout,split", [
+    (("same", 0, 3), 96, 96, 0), (("same", 0, 3), 128, 96, 96), (("same", 1, 3), 32, 32, 0), (("same", 2, 3), 64, 64, 0),
+    (("same", 2, 3), 192, 128, 128), (("same", 3, 3), 256, 256, 0), (("same", 3, 3), 384, 256, 256), (("same", 4, 3), 256, 256, 0),
+    (("same", 0, 5), 288, 32, 0), (("same", 1, 3), 160, 96, 96)])
+def test_centre_kernel_matches_the_all_offsets_path(scene_maps, key, cin, cout, split):
+    c = _case(scene_maps, key, cin, cout, split, center=True)
+    pl = c["pl"]
+    assert pl.center == pl.K // 2 and pl.rlist is not None
+    # the centre offset really pairs every row with itself, and the centre run recorded in tile_k covers exactly those pairs
+    assert torch.equal(c["nbr"][pl.center], torch.arange(pl.M, dtype=torch.int32, device=pl.pos.device))
+    meta = pl.tile_k[pl.p_cap // 128: pl.p_cap // 128 + 3].tolist()
+    assert meta[2] == (pl.M + 127) // 128 and bool((pl.tile_k[meta[1]:meta[1] + meta[2]] == pl.center).all())
+    assert int(pl.pos[pl.center][0]) == meta[1] * 128
+    # per-row lists: count = neighbours without the centre, entries = pos[k][r] in offset order
+    cnt_ref = (c["nbr"] >= 0).sum(dim=0) - 1
+    assert torch.equal(pl.rlist[:, 0].long(), cnt_ref)
+    r = int(cnt_ref.argmax())
+    ks = [k for k in range(pl.K) if k != pl.center and int(c["nbr"][k][r]) >= 0]
+    assert pl.rlist[r, 1:1 + len(ks)].tolist() == [int(pl.pos[k][r]) for k in ks]
+    fused = _run(c, pl)
+    again = _run(c, pl)
+    assert torch.equal(fused, again), "the centre path must be bit-reproducible"
+    old = _run(c, _variant(pl, rlist=None, center=-1))                     # round-1/2 path: pass 1 over all offsets + pos-based pass 2
+    plain = scene_maps.conv_table(*key)["pairs"]                            # the product path: all offsets + row-list pass 2
+    assert plain.center == -1 and plain.rlist is not None
+    rl = _run(c, plain)
+    assert torch.equal(rl, old), "same offsets in the same order: the row-list pass 2 must equal the pos-based one bit for bit"
+    ref = _ref64(c["x"], c["w"], c["nbr"], c["scale"], c["shift"], c["res"], c["act"])
+    e_f, e_o = _close(fused, ref), _close(old, ref)
+    print(f"{key} {cin}->{cout}: centre path err {e_f:.2e}, all-offsets path err {e_o:.2e} (of the row magnitude)")
+    assert e_f < 2e-6 and e_o < 2e-6
+
+
+def test_identity_table_runs_on_the_centre_kernel_alone():
+    """K = 1 (a 1x1 convolution as a pair table, train_ops identity lists): the centre kernel is the whole convolution."""
+    from segdino3d_amd import ops
+    d = dev()
+    M = 5000
+    nbr = torch.arange(M, dtype=torch.int32, device=d).view(1, M)
+    pl = ops.pair_lists(nbr, M, center=0)
+    g = torch.Generator().manual_seed(1)
+    x, w = torch.randn(M, 64, generator=g).to(d), (torch.randn(1, 96, 64, generator=g) * 0.1).to(d)
+    res = torch.randn(M, 96, generator=g).to(d)
+    y = ops.pair_conv(x, w, pl, res=res, act="relu")
+    ref = torch.relu(x.double() @ w[0].double().t() + res.double())
+    assert _close(y, ref) < 2e-6
+    assert bool((pl.rlist[:, 0] == 0).all())
+
+
+@pytest.mark.parametrize("lvl,cin,cout", [(0, 32, 32), (1, 32, 64), (2, 64, 128), (3, 128, 256)])
+def test_down_convolution_row_lists_match_pos_based_pass2(scene_maps, lvl, cin, cout):
+    c = _case(scene_maps, ("down", lvl), cin, cout, use_res=False)
+    pl = c["pl"]
+    assert pl.center == -1 and pl.rlist is not None and not pl.direct
+    a = _run(c, pl)
+    b = _run(c, _variant(pl, rlist=None))
+    assert torch.equal(a, b), "same offsets in the same order: the row-list pass 2 must equal the pos-based one bit for bit"
+    ref = _ref64(c["x"], c["w"], c["nbr"], c["scale"], c["shift"], None, c["act"])
+    assert _close(a, ref) < 2e-6
+
+
+@pytest.mark.parametrize("lvl,cin,cout,use_res", [(0, 96, 96, False), (1, 128, 96, True), (2, 256, 128, False), (3, 256, 256, True),
+                                                   (0, 64, 32, False), (1, 96, 64, False)])
+def test_transposed_convolution_direct_epilogue(scene_maps, lvl, cin, cout, use_res):
+    c = _case(scene_maps, ("up", lvl), cin, cout, use_res=use_res)
+    pl = c["pl"]
+    assert pl.direct and pl.out_idx is not None and pl.rlist is None
+    assert bool(((c["nbr"] >= 0).sum(dim=0) == 1).all()), "every fine voxel has exactly one parent"
+    # out_idx[pos[k][r]] == r, -1 on the padding
+    hit = pl.pos >= 0
+    rows = torch.arange(pl.M, device=pl.pos.device).expand_as(pl.pos)
+    assert torch.equal(pl.out_idx[pl.pos[hit].long()].long(), rows[hit])
+    assert int((pl.out_idx >= 0).sum()) == pl.M
+    from segdino3d_amd import ops
+    direct = _run(c, pl)
+    with ops.scenes_in_flight(4):                               # the lock-step kernels (the pipelined runner's choice)
+        direct_ls = _run(c, pl)
+    two_pass = _run(c, _variant(pl, direct=False))              # pass 1 -> partial products -> pos-based pass 2
+    ref = _ref64(c["x"], c["w"], c["nbr"], c["scale"], c["shift"], c["res"], c["act"])
+    print(f"up {lvl} {cin}->{cout}: direct == two-pass bitwise: {torch.equal(direct, two_pass)}, lock-step == weight-stationary: {torch.equal(direct, direct_ls)}")
+    assert _close(direct, ref) < 2e-6 and _close(two_pass, ref) < 2e-6
+    assert torch.equal(direct, direct_ls), "the two pass-1 variants must write the same bits"
+
+
+def test_plan_and_eager_agree_with_the_new_paths():
+    """The whole Res16UNet34C forward through sd3d_run_layers (tables carry rlist / centre / out_idx) equals the layer-by-layer path."""
+    import segdino3d_amd as seg
+    from segdino3d_amd import plan
+    from segdino3d_amd.configs import scannet200_model_cfg
+    from segdino3d_amd.synth import make_scene
+    d = dev()
+    torch.manual_seed(0)
+    model = seg.build_architecture(scannet200_model_cfg(query_num=-1)).eval().to(d)
+    pts, tgt = make_scene(2, 30_000, 400, 20)
+    pts, tgt = pts.to(d), tgt.to(d)
+    with torch.no_grad():
+        a = model.backbone.forward_wrapper([pts], [tgt], return_sp_mean_pos=True)[0][0]
+        old = plan.USE_PLAN
+        plan.USE_PLAN = False
+        try:
+            b = model.backbone.forward_wrapper([pts], [tgt], return_sp_mean_pos=True)[0][0]
+        finally:
+            plan.USE_PLAN = old
+    assert torch.equal(a, b)

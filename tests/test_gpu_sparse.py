@@ -300,7 +300,7 @@ def test_pair_lists_are_exact():
         off = 0
         exp_pos = np.full((K, M), -1, np.int32)
         exp_idx = np.full(pl.p_cap, -1, np.int32)
-        exp_tk = np.full(pl.p_cap // 128 + 1, -1, np.int32)
+        exp_tk = np.full(pl.p_cap // 128 + 3, -1, np.int32)   # [p_cap / 128] = number of real tiles, then the centre run (start, length)
         for k in range(K):
             rows = np.nonzero(h[k] >= 0)[0]
             exp_pos[k, rows] = off + np.arange(len(rows))
@@ -308,8 +308,13 @@ def test_pair_lists_are_exact():
             seg = (len(rows) + 127) // 128 * 128
             exp_tk[off // 128:(off + seg) // 128] = k
             off += seg
-        exp_tk[-1] = off // 128
+        exp_tk[-3:] = (off // 128, 0, 0)                      # built without a centre offset
         assert np.array_equal(pos, exp_pos) and np.array_equal(in_idx, exp_idx) and np.array_equal(tile_k, exp_tk)
+        # per-row lists: {count, positions of the row's pairs in offset order}
+        rl = pl.rlist.cpu().numpy()
+        assert np.array_equal(rl[:, 0], (h >= 0).sum(axis=0))
+        for r in (0, M // 2, M - 1):
+            assert rl[r, 1:1 + rl[r, 0]].tolist() == [int(exp_pos[k, r]) for k in range(K) if exp_pos[k, r] >= 0]
         singles.append((nbr, P, pl))
     # all tables in ONE launch set (what SceneMaps.prepare uses): identical arrays, incl. the -1 padding the batch kernels
     # write themselves, and a capacity larger than needed (unused tail reads as "no pair")
@@ -318,8 +323,8 @@ def test_pair_lists_are_exact():
         assert torch.equal(bl.pos, pl.pos) and bl.K == pl.K and bl.M == pl.M
         n = min(bl.p_cap, pl.p_cap)
         assert torch.equal(bl.in_idx[:n], pl.in_idx[:n]) and bool((bl.in_idx[n:] == -1).all())
-        assert torch.equal(bl.tile_k[: n // 128], pl.tile_k[: n // 128]) and bool((bl.tile_k[n // 128:-1] == -1).all())
-        assert int(bl.tile_k[-1]) == int(pl.tile_k[-1])
+        assert torch.equal(bl.tile_k[: n // 128], pl.tile_k[: n // 128]) and bool((bl.tile_k[n // 128:-3] == -1).all())
+        assert bl.tile_k[-3:].tolist() == pl.tile_k[-3:].tolist()
 
 
 def test_pair_conv_matches_gather_gemm_and_fp64():

@@ -36,4 +36,13 @@ for key, cin, cout in cases:
     x = torch.randn(n_in, cin, generator=g).to(d); w = (torch.randn(K, cout, cin, generator=g) * (K * cin) ** -0.5).to(d)
     P = int((pairs.in_idx >= 0).sum())
     t = timeit(lambda: ops.pair_conv(x, w, pairs), 5)
-    print(key, cin, cout, f"M={M} P={P} tiles={pairs.p_cap // 128} | {t:.0f} us | {2.0 * P * cin * cout / t / 1e6:.1f} TF/s active")
+    line = f"M={M} P={P} tiles={pairs.p_cap // 128} | {t:.0f} us | {2.0 * P * cin * cout / t / 1e6:.1f} TF/s active"
+    if os.environ.get("PAIR_MODES") == "1":      # the same convolution on the other paths: per-row lists over ALL offsets, pos-based pass 2
+        from segdino3d_amd.ops import PairLists
+        plain = ops.pair_lists(nbr, P)                                                     # no centre offset, not direct
+        old = PairLists(plain.pos, plain.in_idx, plain.tile_k, plain.p_cap, plain.K, plain.M)   # rlist = None: round-2 path
+        t_rl = timeit(lambda: ops.pair_conv(x, w, plain), 5)
+        t_old = timeit(lambda: ops.pair_conv(x, w, old), 5)
+        what = "direct" if pairs.direct else ("centre kernel" if pairs.center >= 0 else "row lists")
+        line += f" ({what}) | all offsets + row-list pass 2: {t_rl:.0f} us | all offsets + pos pass 2 (round 2): {t_old:.0f} us"
+    print(key, cin, cout, line)
