@@ -123,6 +123,73 @@ def cpu_baseline(model, scene_args, n_timed=4):
                       f"torch CPU fp32 with {threads} threads (oracle/model_ref.forward_eval)"}
 
 
+def end_to_end(model, device, args, n_scenes=32):
+    """SURVEY 8(d) "report end-to-end separately": the same forward fed from packed scene FILES (disk / page cache -> pinned host ->
+    H2D on a copy stream, segdino3d_amd.io_scene.ScenePrefetcher) with the post-processed PointData copied back to host numpy arrays
+    (`model.to_host = True`: what evaluation/evaluate_3d.py:49-63 consumes).  Bounded: 4 packed scenes cycled, `n_scenes` forwards."""
+    import copy
+    import shutil
+    import tempfile
+    from segdino3d_amd import io_scene
+    from segdino3d_amd.dist_eval import PipelinedRunner
+    from segdino3d_amd.synth import make_scene
+    tmp = tempfile.mkdtemp(prefix="sd3d_e2e_")
+    try:
+        paths, nbytes = [], 0
+        for j in range(4):
+            pts, tgt = make_scene(500 + j, args.points, args.superpoints, args.query2d, layout=args.scene_layout)
+            ef = tgt.extra_features
+            path = os.path.join(tmp, f"s{j}.sd3d")
+            nbytes = io_scene.pack_scene(path, dict(points=pts, super_points=ef["super_point_masks"], points_2dfeats=ef["points_2dfeats"],
+                                                    query2d_feats=ef["query2d_feats"], query2d_pos=ef["query2d_pos"]))
+            paths.append(path)
+        runner = PipelinedRunner(model, args.streams, device)
+        out_bytes = [0]
+
+        def count(i, res):
+            pd = res[0].pred_pts_seg
+            out_bytes[0] += sum(a.nbytes for a in (pd.pts_instance_mask[0], pd.pts_instance_mask[1], pd.pts_semantic_mask[0],
+                                                   pd.pts_semantic_mask[1], pd.instance_labels, pd.instance_scores))
+        prev = model.to_host
+        model.to_host = True
+        try:
+            with torch.no_grad():
+                runner.run(io_scene.ScenePrefetcher(paths, device, depth=2))                      # warm: files in the page cache, pools sized
+                torch.cuda.synchronize()
+                files = [paths[i % 4] for i in range(n_scenes)]
+                t0 = time.perf_counter()
+                runner.run(io_scene.ScenePrefetcher(files, device, depth=4, readers=2), on_result=count)
+                torch.cuda.synchronize()
+                dt = time.perf_counter() - t0
+        finally:
+            model.to_host = prev
+        return {"value": round(n_scenes / dt, 2), "unit": "scenes/s", "scenes": n_scenes, "input_bytes_per_scene": int(nbytes),
+                "output_bytes_per_scene": int(out_bytes[0] // max(1, n_scenes)),
+                "what": f"packed scene files (page cache) -> pinned host -> H2D (copy stream) -> forward, {args.streams} scenes in flight -> "
+                        "post-processed masks / labels / scores copied to host numpy arrays; PCIe-inclusive, never `value`"}
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+
+
+def load_pmc_traffic(key):
+    """HBM-side bytes per forward of the dominant kernel from the committed PMC passes (rocprofv3 cannot run inside this process) -
+    ONLY if they were collected on the workload this run measures (`key`: scene shape, layout, query mode, scenes per forward).
+    Returns (bytes per forward | None, source | reason)."""
+    for name in ("r03_pmc_traffic.json", "r02_pmc_traffic.json"):
+        path = os.path.join(ROOT, "profiles", name)
+        if not os.path.exists(path):
+            continue
+        with open(path) as f:
+            pmc = json.load(f)
+        have = pmc.get("workload")
+        if have is None:
+            return None, f"profiles/{name} carries no workload key (collected before the traffic was keyed): not reported"
+        if any(have.get(k) != v for k, v in key.items()):
+            return None, f"profiles/{name} was collected on {have}, this run is {key}: not reported"
+        return int(pmc.get("conv_bytes_per_forward", pmc.get("bytes_per_forward"))), pmc["source"]
+    return None, "no PMC passes committed"
+
+
 def pin_rank_to_cores(local_rank: int, local_world: int, threads_per_rank: int, share_gpu: bool = False):
     """One process per GPU drives `threads_per_rank` issuing threads; with 8 ranks on a node they must stay on the cores of
     the NUMA node their GPU hangs off (`/sys/bus/pci/devices/<bdf>/numa_node`) and off each other's cores: ranks whose GPUs
@@ -208,6 +275,7 @@ def main():
     ap.add_argument("--decoder-dtype", choices=("fp32", "bf16"), default=os.environ.get("SD3D_DECODER_DTYPE", "fp32"),
                     help="bf16 = BASELINE configs[2]: bf16-MFMA attention contractions and projections, fp32 accumulation")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-end-to-end", action="store_true", help="skip the packed-files -> host-numpy-outputs measurement (`end_to_end`)")
     ap.add_argument("--preroll-seconds", type=float, default=2.0, help="untimed pipelined pre-roll before the timed K steps")
     args = ap.parse_args()
 
@@ -341,40 +409,33 @@ def main():
     conv_sec = conv_ms * 1e-3
     conv_tf = conv_flops / conv_sec / 1e12 if conv_sec > 0 else 0.0
     conv_gbs = conv_bytes / conv_sec / 1e9 if conv_sec > 0 else 0.0
-    conv_per_step = max(1, conv_n // steps)
-    # HBM-side bytes of the dominant kernel from the committed PMC passes of THIS tree (rocprofv3 cannot run inside this
-    # process): FETCH_SIZE x 2 (the guide's gfx950 correction) + WRITE_SIZE of pair_gemm_* + pair_reduce_kernel per forward.
-    # They exceed the algorithmic bytes by design: the partial products are written by pass 1 and re-read by pass 2.
-    traffic = traffic_fwd = traffic_src = None
-    for name in ("r02_pmc_traffic.json", "r01_pmc_traffic.json"):
-        pmc_path = os.path.join(ROOT, "profiles", name)
-        if os.path.exists(pmc_path):
-            with open(pmc_path) as f:
-                pmc = json.load(f)
-            traffic_fwd = int(pmc.get("conv_bytes_per_forward", pmc.get("bytes_per_forward")))
-            traffic = traffic_fwd // conv_per_step
-            traffic_src = pmc["source"]
-            break
+    n_fwd = max(1, (steps + args.batch - 1) // args.batch)      # forwards of the instrumented replay (batches of --batch scenes)
+    conv_per_step = max(1, conv_n // n_fwd)
+    # HBM-side bytes of the dominant kernel per forward: FETCH_SIZE x 2 (the guide's gfx950 correction) + WRITE_SIZE of pair_gemm_* +
+    # pair_reduce_* from the committed PMC passes, reported only when they were collected on THIS workload.  They exceed the
+    # algorithmic bytes by design: the partial products are written by pass 1 and re-read by pass 2.
+    workload_key = {"points": args.points, "superpoints": args.superpoints, "queries_2d": args.query2d, "scene_layout": args.scene_layout,
+                    "scenes_per_forward": args.batch}
+    traffic_fwd, traffic_src = load_pmc_traffic(workload_key)
     roofline = {"bound": "mfma",
-                "kernel": "sd3d_pair_conv = pair_gemm_* (pass 1, fp32 MFMA over the offset-major rulebook) + pair_reduce_kernel (pass 2): "
-                          "the sparse convolutions of Res16UNet34C",
+                "kernel": "sd3d_pair_conv_ex = pair_gemm_* (pass 1, fp32 MFMA over the offset-major rulebook) + pair_reduce_rl_kernel (pass 2 over per-row lists; "
+                          "none for the transposed convolutions): the 55 sparse convolutions of Res16UNet34C",
                 "achieved": round(conv_tf, 2), "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                 "frac": round(conv_tf / FP32_MFMA_PEAK_TFLOPS, 4),
-                "launches_per_step": conv_per_step, "avg_launch_us": round(1e3 * conv_ms / max(1, conv_n), 2),
-                "ms_per_forward": round(conv_ms / steps, 3),
-                "algorithmic_flops_per_launch": conv_flops // max(1, conv_n), "algorithmic_bytes_per_launch": conv_bytes // max(1, conv_n),
-                "traffic": traffic, "traffic_unit": "HBM-side bytes per launch, average over the launches of one forward (PMC)",
-                "traffic_per_forward": traffic_fwd, "algorithmic_bytes_per_forward": conv_bytes // steps,
+                "launches_per_forward": conv_per_step, "ms_per_forward": round(conv_ms / steps, 3),
+                "algorithmic_flops_per_forward": conv_flops // steps, "algorithmic_bytes_per_forward": conv_bytes // steps,
+                "traffic": traffic_fwd, "traffic_unit": "HBM-side bytes per forward of the 55 convolutions (PMC: FETCH_SIZE x 2 + WRITE_SIZE)",
                 "traffic_over_algorithmic": round(traffic_fwd / max(1, conv_bytes // steps), 2) if traffic_fwd else None,
                 "traffic_source": traffic_src,
                 "hbm_achieved_gbs": round(conv_gbs, 1), "hbm_peak_gbs": HBM_PEAK_GBS, "hbm_frac": round(conv_gbs / HBM_PEAK_GBS, 4),
-                "share_of_single_stream_forward": round(conv_ms / steps / latency_ms, 3),
-                "measured": "HIP events around every launch on the launching stream, single-stream instrumented replay of the timed steps",
+                "share_of_single_stream_forward": round(conv_ms / steps / latency_ms, 3) if args.batch == 1 else None,
+                "measured": "HIP events around every launch on the launching stream, single-stream instrumented replay of the timed steps"
+                            + (f" in batches of {args.batch} scenes (per-forward figures are per SCENE)" if args.batch > 1 else ""),
                 # every sparse convolution AND every Linear of the decoder / heads (the ~155 extra launches are 10 us each for 26 MFLOP)
-                "gemm_family": {"launches_per_step": n_launch // steps, "ms_per_forward": round(gemm_ms / steps, 3),
+                "gemm_family": {"launches_per_forward": n_launch // n_fwd, "ms_per_forward": round(gemm_ms / steps, 3),
                                 "achieved": round(fam_tf, 2), "unit": "TFLOP/s", "frac": round(fam_tf / FP32_MFMA_PEAK_TFLOPS, 4),
-                                "hbm_achieved_gbs": round(fam_gbs, 1), "algorithmic_bytes_per_step": tot_bytes // steps,
-                                "algorithmic_flops_per_step": tot_flops // steps}}
+                                "hbm_achieved_gbs": round(fam_gbs, 1), "algorithmic_bytes_per_forward": tot_bytes // steps,
+                                "algorithmic_flops_per_forward": tot_flops // steps}}
 
     # ---- closing all-gather of per-scene records over RCCL/xGMI -----------------------
     maps = cap.maps[-1]
@@ -387,7 +448,9 @@ def main():
     else:
         records = [rec.cpu().tolist()]
 
-    cpu = None
+    cpu = e2e = None
+    if rank == 0 and world == 1 and not args.no_end_to_end:
+        e2e = end_to_end(model, device, args)
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         cpu = cpu_baseline(model, scene_args)
 
@@ -411,7 +474,7 @@ def main():
                        "scenes_in_flight_per_gpu": args.streams * args.batch, "streams": args.streams, "scenes_per_forward": args.batch,
                        "single_stream_latency_ms": round(latency_ms, 3),
                        "untimed_preroll_scenes": n_pre, "host_cores_per_rank": cores_per_rank, "gpu_numa_node": numa_node},
-            "roofline": roofline, "cpu_baseline": cpu,
+            "roofline": roofline, "cpu_baseline": cpu, "end_to_end": e2e,
             "per_rank_records": records,
         }
         print(json.dumps(out))

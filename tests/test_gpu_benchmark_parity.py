@@ -143,8 +143,10 @@ def _compare_forward(cfg, backbone, scene_args, query_num, n_cls, bounds, oracle
     assert sem_agree >= bounds["semantic"]
 
 
-# bounds: measured on MI355X (see the printed numbers in profiles/r02_parity_numbers.md) times a safety factor
-FULL = dict(feat_atol=2e-4, feat_rtol=2e-4, logit_atol=2e-3, logit_rtol=2e-3, bad_rows=0.02, sign=0.9995, twins=0.97, semantic=0.995)
+# bounds: <= 3x what is measured on MI355X (printed numbers: profiles/r03_parity_numbers.md - worst case over the three
+# configurations: 0.133 % rows outside tolerance after a thresholded mask bit flips (query_num = -1), sign agreement 0.99994,
+# 597 / 600 twins, semantic labels equal on every point, superpoint features 2.7e-7)
+FULL = dict(feat_atol=2e-6, feat_rtol=2e-6, logit_atol=2e-3, logit_rtol=2e-3, bad_rows=0.004, sign=0.9998, twins=0.99, semantic=0.9999)
 
 
 @pytest.mark.parametrize("query_num", [200, -1])
@@ -152,6 +154,99 @@ def test_benchmark_size_forward_matches_oracle(query_num):
     """configs[1] / the headline shape: 150 k points, 3000 superpoints, 300 2D queries."""
     from segdino3d_amd.configs import scannet200_model_cfg
     _compare_forward(scannet200_model_cfg(query_num=query_num), "mink", (150_000, 3000, 300), query_num, 198, FULL, {})
+
+
+def test_bf16_decoder_mode_through_the_whole_forward_at_benchmark_size():
+    """BASELINE configs[2] where the benchmark runs: the 150 k-point / 3000-superpoint / 300-2D-query forward with
+    `decoder.compute_dtype = "bf16"` (bf16-MFMA contractions and >= 1024-row projections, fp32 accumulation; the sparse backbone stays
+    fp32) against the fp32 mode on the SAME weights and scene, `query_num = -1` (3000 queries: every projection takes the bf16 path).
+    The yardstick is the reference's own bf16 behaviour AT THIS SIZE AND ON THESE WEIGHTS: the oracle decoder (pinned to the reference
+    in fp32 and, at the fixture size, under autocast: `tests/golden/decoder_bf16_s500_q32.npz`) is run on the same superpoint features
+    in fp32 and under `torch.autocast("cpu", bfloat16)` - what `train_engine_3d.py:88-100` does to the reference with `cfg.amp`.  With
+    the sharpened random weights of this test the mask feedback amplifies rounding noise (autocast moves the reference's own
+    logits by tens of percent), so absolute bounds would say nothing; asserted instead: the HIP bf16 mode deviates from ITS fp32 mode
+    no more than 1.3x what autocast does to the reference (relative L2 of the mask logits, flipped mask bits, changed semantic labels),
+    and its mAP is not below the autocast reference's by more than 0.15 (both collapse on this operating point: printed)."""
+    import segdino3d_amd as seg
+    from oracle import decoder_ref as D
+    from oracle import postprocess_ref as P
+    from segdino3d_amd import eval_ap
+    from segdino3d_amd.configs import scannet200_model_cfg
+    from segdino3d_amd.synth import make_scene, structure_scene
+    d = dev()
+    pts_c, tgt_c = make_scene(21, 150_000, 3000, 300)
+    structure_scene(pts_c, tgt_c)
+    ef = tgt_c.extra_features
+    sp_c, q2d_feat_c, q2d_pos_c = ef["super_point_masks"].clone(), ef["query2d_feats"].clone(), ef["query2d_pos"].clone()
+    pts, tgt = pts_c.to(d), copy.copy(tgt_c).to(d)
+    model, sd = _build(scannet200_model_cfg(query_num=-1), d)
+    res = {}
+    for mode in ("fp32", "bf16"):
+        model.decoder.compute_dtype = mode
+        with torch.no_grad(), seg.capture() as cap:
+            pd = model([pts], [copy.copy(tgt)])[0].pred_pts_seg
+        res[mode] = (pd, cap.outputs["masks"][0], cap.sp_feats[0], cap.sp_pos[0])
+    model.decoder.compute_dtype = "fp32"
+    torch.cuda.synchronize()
+    (pf, lf, ff, pos), (pb, lb, fb, _) = res["fp32"], res["bf16"]
+    assert torch.equal(ff, fb), "the sparse backbone must not change with the decoder's compute dtype"
+    assert not torch.equal(lf, lb), "the bf16 mode must really run"
+
+    # ---- the reference's behaviour on the same features: oracle decoder + post-processing, fp32 and under autocast(bf16)
+    torch.set_num_threads(min(32, os.cpu_count() or 8))
+    xyz = pts_c[:, :3]
+    lo, hi = xyz.min(0)[0], xyz.max(0)[0]
+    sp_feat, sp_pos = ff.cpu(), pos.cpu()
+    oracle = {}
+    with torch.no_grad():
+        for mode in ("fp32", "bf16"):
+            with torch.autocast("cpu", dtype=torch.bfloat16, enabled=(mode == "bf16")):
+                out = D.decoder_forward(sd, D.DecoderCfg(), sp_feat, sp_pos, sp_pos, sp_feat, sp_pos, q2d_feat_c, q2d_pos_c, lo, hi)
+            out = {k: (v.float() if torch.is_tensor(v) else v) for k, v in out.items()}
+            oracle[mode] = (P.predict_by_feat(out, sp_c, xyz, 198, P.TestCfg(), True, -1), out["masks"])
+    e_hip = (lf.cpu() - oracle["fp32"][1]).abs().max().item()
+    print(f"[bf16 decoder] fp32 mode vs oracle fp32 on the same features: mask-logit max err {e_hip:.3e}")
+
+    def deviation(l_b, l_f, sem_b, sem_f):
+        return (((l_b - l_f).norm() / l_f.norm()).item(), 1.0 - ((l_b > 0) == (l_f > 0)).float().mean().item(),
+                1.0 - (sem_b == sem_f).float().mean().item())
+    dev_hip = deviation(lb, lf, pb.pts_semantic_mask[0], pf.pts_semantic_mask[0])
+    dev_ref = deviation(oracle["bf16"][1], oracle["fp32"][1], oracle["bf16"][0]["pts_semantic_mask"][0], oracle["fp32"][0]["pts_semantic_mask"][0])
+
+    # ---- mAP of all four predictions against ONE ground truth labelled from the fp32 HIP predictions
+    masks, labels, scores = pf.pts_instance_mask[0].cpu().numpy().astype(bool), pf.instance_labels.cpu().numpy(), pf.instance_scores.cpu().numpy()
+    valid = tuple(range(2, 2 + 198))
+    N = masks.shape[1]
+    inst, semgt, taken, k = np.zeros(N, dtype=np.int64), np.zeros(N, dtype=np.int64), np.zeros(N, dtype=bool), 0
+    for i in np.argsort(-scores, kind="stable"):
+        m = masks[i] & ~taken
+        if m.sum() >= 100 and m.sum() >= 0.5 * masks[i].sum():
+            k += 1
+            inst[m], semgt[m] = k, valid[int(labels[i])]
+            taken |= m
+        if k == 40:
+            break
+    assert k >= 3
+
+    def ev(m, lab, sc):
+        return eval_ap.instance_seg_eval([torch.from_numpy(semgt).to(d)], [torch.from_numpy(inst).to(d)], [m], [lab], [sc], valid,
+                                         tuple(f"c{i}" for i in valid), options=dict(min_region_sizes=np.array([50])), groups={})
+    m_hf = ev(pf.pts_instance_mask[0], pf.instance_labels, pf.instance_scores)
+    m_hb = ev(pb.pts_instance_mask[0], pb.instance_labels, pb.instance_scores)
+    o = lambda r: ev(r["pts_instance_mask"][0].to(d), r["instance_labels"].to(d), r["instance_scores"].to(d))  # noqa: E731
+    m_of, m_ob = o(oracle["fp32"][0]), o(oracle["bf16"][0])
+    keys = ("all_ap", "all_ap_50%", "all_ap_25%")
+    fmt = lambda m: " / ".join(f"{float(m[k_]):.4f}" for k_ in keys)  # noqa: E731
+    print(f"[bf16 decoder, N=150000 S=3000 query_num=-1] bf16 vs fp32 (relative L2 of the mask logits, flipped mask bits, changed semantic labels): "
+          f"HIP {dev_hip[0]:.4f} / {dev_hip[1]:.4f} / {dev_hip[2]:.4f}; reference under autocast {dev_ref[0]:.4f} / {dev_ref[1]:.4f} / {dev_ref[2]:.4f}")
+    print(f"[bf16 decoder] mAP / AP50 / AP25 on {k} objects labelled from the fp32 predictions: HIP fp32 {fmt(m_hf)}, HIP bf16 {fmt(m_hb)}, "
+          f"oracle fp32 {fmt(m_of)}, oracle under autocast {fmt(m_ob)}")
+    for a, b, what in zip(dev_hip, dev_ref, ("relative L2 of the mask logits", "flipped mask bits", "changed semantic labels")):
+        assert a <= 1.3 * b + 1e-3, f"{what}: HIP bf16 mode {a:.4f} vs the reference's autocast noise {b:.4f}"
+    # On these sharpened weights bf16 costs the REFERENCE most of its mAP too (autocast: 0.42 -> 0.03 AP, 0.55 -> 0.10 AP50 measured): the
+    # operating point is chaotic in bf16, so the mAP check is a floor against the reference's autocast result, not a closeness claim
+    for key in keys:
+        assert float(m_hb[key]) >= float(m_ob[key]) - 0.15, (key, m_hf[key], m_hb[key], m_of[key], m_ob[key])
 
 
 def test_configs0_scannetv2_forward_matches_oracle():

@@ -90,7 +90,8 @@ def test_bf16_attention(Lq, Lk, nsrc, masked):
 
 
 def test_bf16_decoder_stays_close_to_fp32_decoder():
-    """Whole decoder at the benchmark shape in both modes on the same weights: class logits, mask logits and boxes of the
+    """Whole decoder at S = 1000 superpoints / 200 queries / 150 2D queries (a third of the benchmark's 3000 superpoints; the benchmark-size
+    forward in this mode is `test_gpu_benchmark_parity.py::test_bf16_decoder_mode_through_the_whole_forward_at_benchmark_size`) in both modes on the same weights: class logits, mask logits and boxes of the
     bf16 mode within 10 % (logits) / 5 % (boxes) relative L2 of the fp32 mode (thresholded attention masks make single rows diverge, so the
     distance is taken over the whole tensor), >= 98 % of the final mask bits equal, the same top class on >= 85 % of the queries."""
     d = dev()

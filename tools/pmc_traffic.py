@@ -1,7 +1,9 @@
 #!/usr/bin/env python3
 """Condense the two PMC passes (FETCH_SIZE, WRITE_SIZE: separate rocprofv3 runs of bench.py --streams 1, summarised by
 tools/prof_summary.py) into profiles/<round>_pmc_traffic.json: HBM-side bytes per forward of the dominant kernel (pair_gemm_* +
-pair_reduce_kernel) and of the whole GEMM family.   usage: pmc_traffic.py <fetch.md> <write.md> <out.json>
+pair_reduce_kernel) and of the whole GEMM family.   usage: pmc_traffic.py <fetch.md> <write.md> <out.json> [<bench.json of one of the passes>]
+The bench line of the profiled run (tools/pmc_run.sh keeps it next to the summary) supplies the WORKLOAD KEY - scene shape, layout,
+scenes per forward - that bench.py compares with its own run before it reports these bytes.
 
 Corrections as MI355X_MICROARCH.md prescribes: FETCH_SIZE (KB) x 2 on gfx950 (128-B requests tallied at 64 B; calibrated for
 16 B/lane streaming reads, which is what the gathers and the pass-2 reads are), WRITE_SIZE (KB) as reported."""
@@ -30,7 +32,7 @@ def main():
     fetch, nf = table(sys.argv[1])
     write, nw = table(sys.argv[2])
     assert nf and nf == nw, (nf, nw)
-    conv = lambda n: n.startswith("pair_gemm") or n.startswith("pair_reduce")  # noqa: E731
+    conv = lambda n: n.startswith("pair_gemm") or n.startswith("pair_reduce") or n.startswith("pair_center")  # noqa: E731
     fam = lambda n: conv(n) or "gather_gemm" in n  # noqa: E731
     out = {"source": f"{sys.argv[1]} + {sys.argv[2]} (rocprofv3 --kernel-trace --pmc FETCH_SIZE | WRITE_SIZE, separate passes, bench.py --streams 1)",
            "forwards": nf,
@@ -42,7 +44,13 @@ def main():
         out[f"{key}_fetch_kb_sum"], out[f"{key}_write_kb_sum"] = f_kb, w_kb
         out[f"{key}_bytes_per_forward"] = int((2.0 * f_kb + w_kb) * 1024 / nf)
     out["bytes_per_forward"] = out["family_bytes_per_forward"]
-    out["conv_launches_per_forward"] = sum(v[0] for n, v in fetch.items() if n.startswith("pair_reduce")) // nf
+    out["conv_launches_per_forward"] = sum(v[0] for n, v in fetch.items() if n.startswith("pair_gemm")) // nf
+    if len(sys.argv) > 4:
+        for line in open(sys.argv[4]):
+            if line.startswith("{"):
+                cfg = json.loads(line)["config"]
+                out["workload"] = {"points": cfg["points"], "superpoints": cfg["superpoints"], "queries_2d": cfg["queries_2d"],
+                                   "scene_layout": cfg["scene_layout"], "scenes_per_forward": cfg.get("scenes_per_forward", 1)}
     json.dump(out, open(sys.argv[3], "w"), indent=1)
     print(json.dumps(out, indent=1))
 
