@@ -279,6 +279,13 @@ typedef __bf16 abf16x8 __attribute__((ext_vector_type(8)));
 // indices per lane instead of 1: 2 * NSRC + 2 MFMAs per key tile instead of 16 * NSRC + 16); scores, softmax and the
 // accumulators stay fp32.  The (lane half, register) -> (channel | key) assignment is the fp32 kernel's, which both
 // operands of each product share, so only the grouping of the contraction changes.
+// Softmax in the log2 domain: the queries are pre-scaled by scale * log2(e), so a probability is ONE v_exp_f32
+// (`__builtin_amdgcn_exp2f`) of score - max instead of a library expf (~10 VALU instructions x 16 scores per lane and key tile:
+// the VALU, not the matrix pipe, bounded the kernel at one query per superpoint - 42 % pipe busy).  M / lse leave the kernel
+// converted back to natural units.  The next tile's keys and mask word are requested while the current tile multiplies, and a
+// key tile whose 32 x 32 mask block is all "blocked" is skipped before its keys are touched (wave-uniform).
+#define SD3D_LOG2E 1.4426950408889634f
+#define SD3D_LN2 0.6931471805599453f
 template <int NSRC, bool BF16>
 __global__ __launch_bounds__(512) void attention_kernel(const AttnParams p) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -298,7 +305,7 @@ __global__ __launch_bounds__(512) void attention_kernel(const AttnParams p) {
         for (int e = 0; e < 4; ++e) {
             const f32x4 t = *(const f32x4*)(src + e * 4);
 #pragma unroll
-            for (int c = 0; c < 4; ++c) qreg[s][e * 4 + c] = t[c] * p.scale;
+            for (int c = 0; c < 4; ++c) qreg[s][e * 4 + c] = t[c] * (p.scale * SD3D_LOG2E);
         }
     }
     abf16x8 qb[NSRC][2];
@@ -313,15 +320,38 @@ __global__ __launch_bounds__(512) void attention_kernel(const AttnParams p) {
     f32x16 O;
 #pragma unroll
     for (int r = 0; r < 16; ++r) O[r] = 0.f;
-    float m = -INFINITY, l = 0.f;
+    float m = -INFINITY, l = 0.f;                       // running max (log2 units) and sum
 
     const int ntiles = (p.Lk + 31) >> 5;
-    for (int t = blockIdx.z * nw + wave; t < ntiles; t += nw * p.ksplit) {
-        const int kt0 = t * 32;
-        const int kr = min(kt0 + i, p.Lk - 1);          // A-operand row = key
-        f32x16 S;
+    const int tstep = nw * p.ksplit;
+    const uint32_t tail = (p.Lk & 31) ? ~0u << (p.Lk & 31) : 0u;          // key slots of the last tile that lie past Lk
+    // bit (slot + 4 * h) of the word belongs to this lane's register r with slot = (r & 3) + 8 * (r >> 2): shift once per tile
+    auto load_word = [&](int t) -> uint32_t {
+        uint32_t w = (p.bits && t < ntiles) ? p.bits[(int64_t)qi * p.nwords + t] : 0u;
+        if (t == ntiles - 1) w |= tail;
+        return w;
+    };
+    auto load_k = [&](f32x4 (&kk)[NSRC][4], int t) {
+        const int kr = min(t * 32 + i, p.Lk - 1);      // A-operand row = key (tiles past the end reload the last key: harmless)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) S[r] = 0.f;
+        for (int s = 0; s < NSRC; ++s) {
+            const float* src = p.k[s] + (int64_t)kr * p.ldk[s] + hc;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) kk[s][e] = *(const f32x4*)(src + e * 4);
+        }
+    };
+    constexpr bool KPF = !BF16;                         // next tile's keys in flight while this one multiplies: fp32 187 vs 198 us at Q = S = 3000;
+                                                        // the bf16 kernel is better off with the registers (4 waves per SIMD: 91 vs 105 us)
+    int t = blockIdx.z * nw + wave;
+    uint32_t word = load_word(t);
+    f32x4 kcur[NSRC][4], knxt[NSRC][4];
+    if (KPF && t < ntiles) load_k(kcur, t);
+    for (; t < ntiles; t += tstep) {
+        const int kt0 = t * 32;
+        const uint32_t word_nxt = load_word(t + tstep);
+        if (KPF) load_k(knxt, t + tstep);
+        if (__ballot(word != ~0u) != 0ull) {                              // some query of the tile sees some key of it
+        if (!KPF) load_k(kcur, t);
         // the value rows of this tile are requested before the score MFMAs: their latency hides behind QK^T + softmax
         float vreg[16];
         {
@@ -332,18 +362,17 @@ __global__ __launch_bounds__(512) void attention_kernel(const AttnParams p) {
                 vreg[r] = vsrc[(int64_t)key * p.ldv];
             }
         }
+        f32x16 S;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) S[r] = 0.f;
 #pragma unroll
         for (int s = 0; s < NSRC; ++s) {
-            const float* src = p.k[s] + (int64_t)kr * p.ldk[s] + hc;
-            f32x4 kk[4];
-#pragma unroll
-            for (int e = 0; e < 4; ++e) kk[e] = *(const f32x4*)(src + e * 4);
             if (BF16) {
 #pragma unroll
                 for (int g = 0; g < 2; ++g) {
                     abf16x8 kb;
 #pragma unroll
-                    for (int c = 0; c < 8; ++c) kb[c] = (__bf16)kk[2 * g + (c >> 2)][c & 3];
+                    for (int c = 0; c < 8; ++c) kb[c] = (__bf16)kcur[s][2 * g + (c >> 2)][c & 3];
                     S = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kb, qb[s][g], S, 0, 0, 0);
                 }
             } else {
@@ -351,17 +380,15 @@ __global__ __launch_bounds__(512) void attention_kernel(const AttnParams p) {
                 for (int e = 0; e < 4; ++e)
 #pragma unroll
                     for (int c = 0; c < 4; ++c)
-                        S = __builtin_amdgcn_mfma_f32_32x32x2f32(kk[e][c], qreg[s][e * 4 + c], S, 0, 0, 0);
+                        S = __builtin_amdgcn_mfma_f32_32x32x2f32(kcur[s][e][c], qreg[s][e * 4 + c], S, 0, 0, 0);
             }
         }
-        // S[r] = score(key = kt0 + (r&3) + 8*(r>>2) + 4*h, query = q0 + i)
-        const uint32_t word = p.bits ? p.bits[(int64_t)qi * p.nwords + t] : 0u;
+        // S[r] = log2-score(key = kt0 + (r&3) + 8*(r>>2) + 4*h, query = q0 + i)
+        const uint32_t wh = word >> (4 * h);
         float tmax = -INFINITY;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-            const int kb = (r & 3) + 8 * (r >> 2) + 4 * h;
-            const bool blocked = ((word >> kb) & 1u) || (kt0 + kb >= p.Lk);
-            S[r] = blocked ? -INFINITY : S[r];
+            S[r] = ((wh >> ((r & 3) + 8 * (r >> 2))) & 1u) ? -INFINITY : S[r];
             tmax = fmaxf(tmax, S[r]);
         }
         tmax = fmaxf(tmax, __shfl_xor(tmax, 32));
@@ -372,15 +399,17 @@ __global__ __launch_bounds__(512) void attention_kernel(const AttnParams p) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) pr[r] = 0.f;
         } else {
-            alpha = expf(m - mn);                       // m = -inf -> 0
+            alpha = __builtin_amdgcn_exp2f(m - mn);     // m = -inf -> 0
             float ls = 0.f;
 #pragma unroll
-            for (int r = 0; r < 16; ++r) { pr[r] = expf(S[r] - mn); ls += pr[r]; }
+            for (int r = 0; r < 16; ++r) { pr[r] = __builtin_amdgcn_exp2f(S[r] - mn); ls += pr[r]; }
             l = l * alpha + ls;
             m = mn;
         }
+        if (__ballot(alpha != 1.f) != 0ull) {           // the running maxima settle after a few tiles: no rescale, no dependency on O
 #pragma unroll
-        for (int r = 0; r < 16; ++r) O[r] *= alpha;
+            for (int r = 0; r < 16; ++r) O[r] *= alpha;
+        }
         // O^T[dv][query] += sum_key V[key][dv] * P[query][key];  A = V^T (row = dv = i), B = P^T
         if (BF16) {
 #pragma unroll
@@ -393,6 +422,14 @@ __global__ __launch_bounds__(512) void attention_kernel(const AttnParams p) {
         } else {
 #pragma unroll
             for (int r = 0; r < 16; ++r) O = __builtin_amdgcn_mfma_f32_32x32x2f32(vreg[r], pr[r], O, 0, 0, 0);
+        }
+        }
+        word = word_nxt;
+        if (KPF) {
+#pragma unroll
+            for (int s = 0; s < NSRC; ++s)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) kcur[s][e] = knxt[s][e];
         }
     }
     l += __shfl_xor(l, 32);
@@ -413,7 +450,7 @@ __global__ __launch_bounds__(512) void attention_kernel(const AttnParams p) {
         for (int w = 0; w < nw; ++w) {
             const float* base = smem + w * (64 + 1024);
             const float mw = base[qq];
-            const float f = (mw == -INFINITY) ? 0.f : expf(mw - M);
+            const float f = (mw == -INFINITY) ? 0.f : __builtin_amdgcn_exp2f(mw - M);
             L += base[32 + qq] * f;
             acc += base[64 + dv * 32 + qq] * f;
         }
@@ -423,7 +460,7 @@ __global__ __launch_bounds__(512) void attention_kernel(const AttnParams p) {
             dst[64 + dv * 32 + qq] = acc;
         } else if (q0 + qq < p.Lq) {
             p.out[(int64_t)(q0 + qq) * p.ldo + head * 32 + dv] = acc / L;
-            if (p.lse && dv == 0) p.lse[(int64_t)head * p.Lq + q0 + qq] = M + logf(L);
+            if (p.lse && dv == 0) p.lse[(int64_t)head * p.Lq + q0 + qq] = M * SD3D_LN2 + logf(L);      // back to natural units
         }
     }
 }
@@ -440,13 +477,13 @@ __global__ __launch_bounds__(256) void attention_merge_kernel(const AttnParams p
         for (int z = 0; z < p.ksplit; ++z) {
             const float* b = base + z * (64 + 1024);
             const float mz = b[qq];
-            const float f = (mz == -INFINITY) ? 0.f : expf(mz - M);
+            const float f = (mz == -INFINITY) ? 0.f : __builtin_amdgcn_exp2f(mz - M);
             L += b[32 + qq] * f;
             acc += b[64 + dv * 32 + qq] * f;
         }
         if (q0 + qq < p.Lq) {
             p.out[(int64_t)(q0 + qq) * p.ldo + head * 32 + dv] = acc / L;
-            if (p.lse && dv == 0) p.lse[(int64_t)head * p.Lq + q0 + qq] = M + logf(L);
+            if (p.lse && dv == 0) p.lse[(int64_t)head * p.Lq + q0 + qq] = M * SD3D_LN2 + logf(L);
         }
     }
 }
