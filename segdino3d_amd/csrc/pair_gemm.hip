@@ -735,19 +735,31 @@ __global__ __launch_bounds__(256) void pair_reduce_rl_kernel(const PRLParams p) 
     if (r >= p.M) return;
     const int q = (int)(e - r * c4) * 4;
     const int32_t* rl = p.rlist + r * p.rl_stride;
-    const int4 head = *(const int4*)rl;
-    const int cnt = head.x;
+    // the row's whole list in registers first (7 x 16 bytes cover count + 27 positions: every 3^3 table), then the partial
+    // products eight at a time: two short dependent steps instead of a position -> product chain per group of four
+    int4 hv[7];
+    hv[0] = *(const int4*)rl;
+    const int cnt = hv[0].x;
+#pragma unroll
+    for (int g = 1; g < 7; ++g) hv[g] = (4 * g <= cnt) ? *(const int4*)(rl + 4 * g) : int4{0, 0, 0, 0};
+    auto id_at = [&](int i) -> int {                            // list entry i (< 27) = int 1 + i of the row; compile-time i after unrolling
+        const int4& v = hv[(1 + i) >> 2];
+        const int c = (1 + i) & 3;
+        return c == 0 ? v.x : (c == 1 ? v.y : (c == 2 ? v.z : v.w));
+    };
     f32x4 a = {0.f, 0.f, 0.f, 0.f};
-    {
-        f32x4 v0 = {0.f, 0.f, 0.f, 0.f}, v1 = v0, v2 = v0;
-        if (cnt > 0) v0 = *(const f32x4*)(p.part + (int64_t)head.y * p.Cout + q);
-        if (cnt > 1) v1 = *(const f32x4*)(p.part + (int64_t)head.z * p.Cout + q);
-        if (cnt > 2) v2 = *(const f32x4*)(p.part + (int64_t)head.w * p.Cout + q);
-        if (cnt > 0) a += v0;
-        if (cnt > 1) a += v1;
-        if (cnt > 2) a += v2;
+#pragma unroll
+    for (int i0 = 0; i0 < 27; i0 += 9) {
+        if (i0 < cnt) {
+            f32x4 v[9];
+#pragma unroll
+            for (int u = 0; u < 9; ++u)
+                v[u] = i0 + u < cnt ? *(const f32x4*)(p.part + (int64_t)id_at(i0 + u) * p.Cout + q) : f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int u = 0; u < 9; ++u) if (i0 + u < cnt) a += v[u];
+        }
     }
-    for (int i0 = 3; i0 < cnt; i0 += 4) {                       // list entries 3.., four at a time (16-byte aligned: rl + 4, rl + 8, ...)
+    for (int i0 = 27; i0 < cnt; i0 += 4) {                      // longer lists (the 5^3 stem): four at a time from memory (int 1 + 27 = 28: 16-byte aligned)
         const int4 ids = *(const int4*)(rl + 1 + i0);
         f32x4 v[4];
         const int idv[4] = {ids.x, ids.y, ids.z, ids.w};
