@@ -347,9 +347,17 @@ class Baseline3D(nn.Module):
                               instance_labels=inst_labels, instance_scores=inst_scores, sort_and_mask=sort_and_mask,
                               instance_boxes=inst_boxes)]
         n = inst_scores.shape[0]
+        # D2H of the post-processed outputs (the [n, N] boolean masks are up to 90 MB): asynchronous copies into pinned host
+        # tensors (torch's caching host allocator hands the blocks out again once the copies have completed) and ONE polled
+        # wait, instead of six blocking pageable `.cpu()` calls - other scenes' streams keep the GPU busy meanwhile
+        dev = [sem_res, pan_sem, inst_masks, pan_inst, inst_labels, inst_scores] + ([inst_boxes] if inst_boxes is not None else [])
+        host = []
+        for t in dev:
+            h = torch.empty(t.shape, dtype=t.dtype, pin_memory=True)
+            h.copy_(t, non_blocking=True)
+            host.append(h)
+        ops.wait_event(ops.stream_event())
+        arr = [h.numpy() for h in host]
         return [PointData(
-            pts_semantic_mask=[sem_res.cpu().numpy(), pan_sem.cpu().numpy()],
-            pts_instance_mask=[inst_masks.cpu().numpy(), pan_inst.cpu().numpy()],
-            instance_labels=inst_labels.cpu().numpy(), instance_scores=inst_scores.cpu().numpy(),
-            sort_and_mask=sort_and_mask,
-            instance_boxes=inst_boxes.cpu().numpy() if inst_boxes is not None else np.zeros((n, 6)))]
+            pts_semantic_mask=[arr[0], arr[1]], pts_instance_mask=[arr[2], arr[3]], instance_labels=arr[4], instance_scores=arr[5],
+            sort_and_mask=sort_and_mask, instance_boxes=arr[6] if inst_boxes is not None else np.zeros((n, 6)))]

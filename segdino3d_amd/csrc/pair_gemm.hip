@@ -800,7 +800,12 @@ struct PCParams {
     float* out; int ld_out; int act;
 };
 
-template <int NT, int ST>
+// GLOBALW: the weight fragments come straight from global memory (W[centre] is 36-260 KB and L2-resident; the four waves of a
+// workgroup read the same fragments, so most hits are L1) instead of an LDS copy staged per workgroup.  That frees the kernel from
+// LDS and from a persistent grid: one workgroup per 128-row tile, dispatched by the hardware as slots free up - no tile
+// quantisation (level 0: 1084 tiles on 768 persistent slots were two rounds), no 38-133 KB of staging for one or two tiles, and
+// 12 waves per CU stream the partial products of their rows.
+template <int NT, int ST, bool GLOBALW>
 __device__ __forceinline__ void pair_center_body(const PCParams& p, float* Ws) {
     const int tid = threadIdx.x, lane = tid & 63;
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -810,11 +815,12 @@ __device__ __forceinline__ void pair_center_body(const PCParams& p, float* Ws) {
     const int tile1 = (int)((int64_t)(blockIdx.x + 1) * n_tiles / gridDim.x);
     if (tile1 <= tile0) return;
     const int nchunks = p.Cin >> 5;
-    const int ldw = p.Cin + 4;                                 // conflict-free b128 rows, as in pair_gemm_ws_body
+    const int ldw = GLOBALW ? p.Cin : p.Cin + 4;               // LDS copy: conflict-free b128 rows, as in pair_gemm_ws_body
     const int c4 = p.Cin >> 2;
     const int npieces = 32 * NT * c4;
     const int ncol0 = blockIdx.y * NT * 32;
-    {                                                          // W[centre] rows ncol0 .. ncol0 + 32 NT: once per launch
+    const float* wrows = GLOBALW ? p.wt + (int64_t)ncol0 * p.Cin : Ws;
+    if (!GLOBALW) {                                            // W[centre] rows ncol0 .. ncol0 + 32 NT: once per launch
         const float* __restrict__ W = p.wt + (int64_t)ncol0 * p.Cin;
         for (int f0 = 0; f0 < npieces; f0 += 256 * 4) {
             f32x4 v[4];
@@ -832,8 +838,8 @@ __device__ __forceinline__ void pair_center_body(const PCParams& p, float* Ws) {
                 }
             }
         }
+        __syncthreads();
     }
-    __syncthreads();
 
     f32x16 acc[NT];
 #pragma unroll 1
@@ -863,7 +869,7 @@ __device__ __forceinline__ void pair_center_body(const PCParams& p, float* Ws) {
     {                                                                                                                 \
         load_step(PF, cur_c + ST - 1);                                                                                \
         {                                                                                                             \
-            const float* wb = Ws + j * ldw + cur_c * 32 + h * 16;                                                     \
+            const float* wb = wrows + j * ldw + cur_c * 32 + h * 16;                                                  \
             f32x4 wq[2][NT];                                                                                          \
             _Pragma("unroll") for (int t = 0; t < NT; ++t) wq[0][t] = *(const f32x4*)(wb + t * 32 * ldw);             \
             _Pragma("unroll") for (int q = 0; q < 4; ++q) {                                                           \
@@ -874,7 +880,7 @@ __device__ __forceinline__ void pair_center_body(const PCParams& p, float* Ws) {
                 _Pragma("unroll") for (int e = 0; e < 4; ++e)                                                         \
                     _Pragma("unroll") for (int t = 0; t < NT; ++t)                                                    \
                         acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(wq[q & 1][t][e], CUR[q][e], acc[t], 0, 0, 0);   \
-                __builtin_amdgcn_sched_barrier(0);                                                                    \
+                if (!GLOBALW) __builtin_amdgcn_sched_barrier(0);                                                      \
             }                                                                                                         \
         }                                                                                                             \
         if (++cur_c == nchunks) break;                                                                                \
@@ -930,16 +936,19 @@ __device__ __forceinline__ void pair_center_body(const PCParams& p, float* Ws) {
     }
 }
 
-#define PAIR_CENTER_ENTRY(NT, ST, WAVES)                                                                            \
-    __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WAVES, WAVES))) void pair_center_kernel_##NT( \
-        const PCParams p) {                                                                                         \
+#define PAIR_CENTER_ENTRY(NAME, NT, ST, WAVES, GLOBALW)                                                             \
+    __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WAVES, WAVES))) void NAME(const PCParams p) { \
         extern __shared__ __attribute__((aligned(16))) float pc_smem[];                                             \
-        pair_center_body<NT, ST>(p, pc_smem);                                                                       \
+        pair_center_body<NT, ST, GLOBALW>(p, pc_smem);                                                              \
     }
-PAIR_CENTER_ENTRY(1, 3, 4)
-PAIR_CENTER_ENTRY(2, 3, 2)
-PAIR_CENTER_ENTRY(3, 2, 3)
-PAIR_CENTER_ENTRY(4, 2, 2)
+PAIR_CENTER_ENTRY(pair_center_kernel_1, 1, 3, 4, false)
+PAIR_CENTER_ENTRY(pair_center_kernel_2, 2, 3, 2, false)
+PAIR_CENTER_ENTRY(pair_center_kernel_3, 3, 2, 3, false)
+PAIR_CENTER_ENTRY(pair_center_kernel_4, 4, 2, 2, false)
+PAIR_CENTER_ENTRY(pair_center_g_kernel_1, 1, 3, 4, true)
+PAIR_CENTER_ENTRY(pair_center_g_kernel_2, 2, 2, 3, true)
+PAIR_CENTER_ENTRY(pair_center_g_kernel_3, 3, 2, 3, true)
+PAIR_CENTER_ENTRY(pair_center_g_kernel_4, 4, 2, 2, true)
 
 // ---- launchers --------------------------------------------------------------------------------
 size_t pair_lists_ws_bytes(int K, int64_t M) {
@@ -1175,6 +1184,16 @@ int launch_pair_conv(const float* in0, int ld0, int C0, const float* in1, int ld
         static const int cslots = env_flag("SD3D_PAIR_CENTER_SLOTS", 0);
         if (cslots > 0) per_cu = cslots;
         const int n_tiles_c = (int)cdiv(M, PT);
+        static const int cglobal = env_flag("SD3D_PAIR_CENTER_GLOBALW", 1);
+        if (cglobal) {                                          // one workgroup per row tile, weights from L2 / L1, no LDS
+            const dim3 cgrid((unsigned)n_tiles_c, (unsigned)cgs_c);
+            switch (nt_c) {
+                case 1: hipLaunchKernelGGL(pair_center_g_kernel_1, cgrid, dim3(256), 0, st, c); break;
+                case 2: hipLaunchKernelGGL(pair_center_g_kernel_2, cgrid, dim3(256), 0, st, c); break;
+                case 3: hipLaunchKernelGGL(pair_center_g_kernel_3, cgrid, dim3(256), 0, st, c); break;
+                default: hipLaunchKernelGGL(pair_center_g_kernel_4, cgrid, dim3(256), 0, st, c); break;
+            }
+        } else {
         int gx = n_cu * per_cu / cgs_c;
         gx = gx < 1 ? 1 : (gx < n_tiles_c ? gx : n_tiles_c);
         const dim3 cgrid((unsigned)gx, (unsigned)cgs_c);
@@ -1183,6 +1202,7 @@ int launch_pair_conv(const float* in0, int ld0, int C0, const float* in1, int ld
             case 2: hipLaunchKernelGGL(pair_center_kernel_2, cgrid, dim3(256), lds_c, st, c); break;
             case 3: hipLaunchKernelGGL(pair_center_kernel_3, cgrid, dim3(256), lds_c, st, c); break;
             default: hipLaunchKernelGGL(pair_center_kernel_4, cgrid, dim3(256), lds_c, st, c); break;
+        }
         }
     } else if (rlist && rl_env && center < 0) {                 // (a list that leaves the centre out is only complete with the centre kernel)
         PRLParams r;
