@@ -4,9 +4,10 @@
     python bench.py --gpus N --steps K --warmup W
 
 One process per GPU (N > 1: launched by torch.distributed.run, backend "nccl" = RCCL).  A *step* is one
-eval-mode `Baseline3D.forward` (backbone + superpoint pooling + 6-layer decoder + post-processing) over
-one synthetic ScanNet200-like scene (150 k points, 3000 superpoints, 300 2D queries, `query_num=200`,
-fp32) whose inputs are already resident in HBM; outputs stay on the device.  Scenes are independent
+SCENE through the eval-mode `Baseline3D.forward` (backbone + superpoint pooling + 6-layer decoder + post-processing):
+a synthetic ScanNet200-like scene (150 k points, 3000 superpoints, 300 2D queries, `query_num=200`,
+fp32) whose inputs are already resident in HBM; outputs stay on the device.  `--batch` scenes share a forward
+(one block-diagonal sparse tensor, bit-identical per scene; default 4), `--streams` forwards are in flight.  Scenes are independent
 units, so ranks shard them with no data-path collective (weak scaling); one all-gather of per-scene
 records (scene id, points, voxels, ms) closes the run, as in the north-star's metric exchange.
 Inside a rank the K timed steps are issued by `--streams` host threads, each on its own HIP stream
@@ -269,9 +270,10 @@ def main():
                     help="synth.make_scene layout: 'benchmark' = the scene of every reported number; 'scan' = mesh-like surface sampling")
     ap.add_argument("--streams", type=int, default=4,
                     help="scenes in flight per GPU (host threads x HIP streams, segdino3d_amd.dist_eval.PipelinedRunner)")
-    ap.add_argument("--batch", type=int, default=int(os.environ.get("SD3D_BENCH_BATCH", "1")),
-                    help="scenes per forward: > 1 runs them as ONE block-diagonal sparse tensor (sparse.BatchSceneMaps, every scene's "
-                         "outputs bit-identical to its single-scene forward); each stream then keeps a whole batch in flight")
+    ap.add_argument("--batch", type=int, default=int(os.environ.get("SD3D_BENCH_BATCH", "4")),
+                    help="scenes per forward: > 1 runs them as ONE block-diagonal sparse tensor (sparse.BatchSceneMaps + the batched decoder, every "
+                         "scene's outputs bit-identical to its single-scene forward); each stream then keeps a whole batch in flight.  Default 4: "
+                         "same scenes/s as 1 within 1-2 %, convolutions 7 % faster (4 x the tiles per launch); `single_scene` is always one scene per forward")
     ap.add_argument("--decoder-dtype", choices=("fp32", "bf16"), default=os.environ.get("SD3D_DECODER_DTYPE", "fp32"),
                     help="bf16 = BASELINE configs[2]: bf16-MFMA attention contractions and projections, fp32 accumulation")
     ap.add_argument("--no-cpu-baseline", action="store_true")

@@ -287,6 +287,16 @@ int sd3d_sine_pe(const float* xyz, int ld_xyz, int64_t n, const float* range, co
  * out[:, d/2:] = cos(p), p = (2 pi * shift_scale(xyz)) @ gauss_b[:, :d/2]; gauss_b [3, >= d/2] is the module's buffer. */
 int sd3d_fourier_pe(const float* xyz, int ld_xyz, int64_t n, const float* range, const float* gauss_b, int ld_b, int d_pos,
                     float* out, int ld_out, void* stream);
+/* The same two encodings and sd3d_box_refine over the rows of SEVERAL scenes at once (the decoder of a batched evaluation forward):
+ * ranges [n_scenes, 6], row_scene [n] = scene of every row; row r uses ranges[row_scene[r]].  Per row the arithmetic is unchanged. */
+int sd3d_sine_pe_rows(const float* xyz, int ld_xyz, int64_t n, const float* ranges, const int32_t* row_scene, const float* dim_t,
+                      const int8_t* axis, int d_pos, const float* mod_num, int ld_num, const float* mod_den, int ld_den, float* out,
+                      int ld_out, void* stream);
+int sd3d_fourier_pe_rows(const float* xyz, int ld_xyz, int64_t n, const float* ranges, const int32_t* row_scene, const float* gauss_b,
+                         int ld_b, int d_pos, float* out, int ld_out, void* stream);
+int sd3d_box_refine_rows(const float* ref_points, const float* d_center, const float* size_prev, int ld_size_prev,
+                         const float* d_size, const float* ranges, const int32_t* row_scene, int normalize, int64_t Q, float* center,
+                         float* size, float* size_metric, void* stream);
 /* Fused multi-head attention (replaces bmm + masked_fill + softmax + bmm of attention.py:361-385 and
  * nn.MultiheadAttention's SDPA at decoder :79).  Heads are 32-channel slices; nsrc = 2 concatenates
  * [q0|q1] . [k0|k1] per head (decoder :681-687).  mask_bits [Lq, ceil(Lk/32)]: bit = 1 -> blocked.

@@ -41,7 +41,7 @@ int launch_gather_gemm_split(const GGParams&, int, int, const void*, void*, size
 size_t pair_lists_ws_bytes(int K, int64_t M);
 int launch_pair_lists(const int32_t*, int, int64_t, int64_t, int32_t*, int32_t*, int32_t*, void*, size_t, hipStream_t);
 int launch_linear_group(int, const GGParams*, hipStream_t);
-int launch_fourier_pe(const float*, int, int64_t, const float*, const float*, int, int, float*, int, hipStream_t);
+int launch_fourier_pe(const float*, int, int64_t, const float*, const float*, int, int, float*, int, const int32_t*, hipStream_t);
 int launch_pair_lists_batch(int, const int32_t* const*, const int*, const int64_t*, const int64_t*, int32_t* const*, int32_t* const*,
                             int32_t* const*, void*, size_t, hipStream_t);
 size_t slab_conv_ws_bytes(int, int, int, int64_t, int64_t);
@@ -55,7 +55,7 @@ int launch_pair_lists_desc(int, const sd3d_pair_table_desc*, void*, size_t, hipS
 int launch_layernorm(const float*, int, const float*, int, const float*, const float*, float, int64_t, int, float*, int, int, hipStream_t);
 int launch_linear_layernorm(const float*, int, int64_t, int, const float*, int, const float*, const float*, int, const float*, const float*, float, int,
                             float*, int, hipStream_t);
-int launch_sine_pe(const float*, int, int64_t, const float*, const float*, const int8_t*, int, const float*, int, const float*, int, float*, int, hipStream_t);
+int launch_sine_pe(const float*, int, int64_t, const float*, const float*, const int8_t*, int, const float*, int, const float*, int, float*, int, const int32_t*, hipStream_t);
 struct AttnParams {
     const float* q[2]; int ldq[2];
     const float* k[2]; int ldk[2];
@@ -74,7 +74,7 @@ int launch_attention(const AttnParams&, int, void*, size_t, hipStream_t);
 int launch_mask_bits(const float*, int, int64_t, int, float, uint32_t*, int, hipStream_t);
 int launch_near_bits(const float*, int64_t, const float*, int64_t, float, uint32_t*, int, hipStream_t);
 int launch_dinox_mask_bits(const uint32_t*, const uint32_t*, int, int64_t, int64_t, uint32_t*, int, hipStream_t);
-int launch_box_refine(const float*, const float*, const float*, int, const float*, const float*, int, int64_t, float*, float*, float*, hipStream_t);
+int launch_box_refine(const float*, const float*, const float*, int, const float*, const float*, int, int64_t, float*, float*, float*, const int32_t*, hipStream_t);
 int launch_class_scores(const float*, int, int64_t, int, float*, float*, hipStream_t);
 int launch_mask_scores(const float*, int, int, const uint32_t*, const float*, int, int, int, int32_t*, int32_t*, float*, hipStream_t);
 int launch_gather_sigmoid(const float*, int, int, const int32_t*, const uint32_t*, int, float*, int, float*, hipStream_t);
@@ -209,7 +209,11 @@ int sd3d_gather_gemm_split(const float* in0, int ld0, int C0, const float* in1, 
 
 int sd3d_fourier_pe(const float* xyz, int ld_xyz, int64_t n, const float* range, const float* gauss_b, int ld_b, int d_pos, float* out,
                     int ld_out, void* stream) {
-    return launch_fourier_pe(xyz, ld_xyz, n, range, gauss_b, ld_b, d_pos, out, ld_out, ST);
+    return launch_fourier_pe(xyz, ld_xyz, n, range, gauss_b, ld_b, d_pos, out, ld_out, nullptr, ST);
+}
+int sd3d_fourier_pe_rows(const float* xyz, int ld_xyz, int64_t n, const float* ranges, const int32_t* row_scene, const float* gauss_b, int ld_b,
+                         int d_pos, float* out, int ld_out, void* stream) {
+    return launch_fourier_pe(xyz, ld_xyz, n, ranges, gauss_b, ld_b, d_pos, out, ld_out, row_scene, ST);
 }
 
 int sd3d_linear_group(int n, const sd3d_linear_job* jobs, void* stream) {
@@ -272,7 +276,13 @@ int sd3d_linear_layernorm(const float* x, int ld_x, int64_t M, int Cin, const fl
 int sd3d_sine_pe(const float* xyz, int ld_xyz, int64_t n, const float* range, const float* dim_t, const int8_t* axis, int d_pos,
                  const float* mod_num, int ld_num, const float* mod_den, int ld_den, float* out, int ld_out, void* stream) {
     if (mod_num && !mod_den) return sd3d_set_error(SD3D_ERR_ARG, "sine_pe: mod_den missing");
-    return launch_sine_pe(xyz, ld_xyz, n, range, dim_t, axis, d_pos, mod_num, ld_num, mod_den, ld_den, out, ld_out, ST);
+    return launch_sine_pe(xyz, ld_xyz, n, range, dim_t, axis, d_pos, mod_num, ld_num, mod_den, ld_den, out, ld_out, nullptr, ST);
+}
+int sd3d_sine_pe_rows(const float* xyz, int ld_xyz, int64_t n, const float* ranges, const int32_t* row_scene, const float* dim_t,
+                      const int8_t* axis, int d_pos, const float* mod_num, int ld_num, const float* mod_den, int ld_den, float* out,
+                      int ld_out, void* stream) {
+    if (mod_num && !mod_den) return sd3d_set_error(SD3D_ERR_ARG, "sine_pe_rows: mod_den missing");
+    return launch_sine_pe(xyz, ld_xyz, n, ranges, dim_t, axis, d_pos, mod_num, ld_num, mod_den, ld_den, out, ld_out, row_scene, ST);
 }
 size_t sd3d_attention_ws_bytes(int Lq, int H) { return attention_ws_bytes(Lq, H); }
 int sd3d_attention(const float* q0, int ldq0, const float* q1, int ldq1, const float* k0, int ldk0, const float* k1, int ldk1,
@@ -331,7 +341,12 @@ int sd3d_dinox_mask_bits(const uint32_t* blocked, const uint32_t* near, int nwor
 }
 int sd3d_box_refine(const float* ref_points, const float* d_center, const float* size_prev, int ld_size_prev, const float* d_size,
                     const float* range, int normalize, int64_t Q, float* center, float* size, float* size_metric, void* stream) {
-    return launch_box_refine(ref_points, d_center, size_prev, ld_size_prev, d_size, range, normalize, Q, center, size, size_metric, ST);
+    return launch_box_refine(ref_points, d_center, size_prev, ld_size_prev, d_size, range, normalize, Q, center, size, size_metric, nullptr, ST);
+}
+int sd3d_box_refine_rows(const float* ref_points, const float* d_center, const float* size_prev, int ld_size_prev, const float* d_size,
+                         const float* ranges, const int32_t* row_scene, int normalize, int64_t Q, float* center, float* size,
+                         float* size_metric, void* stream) {
+    return launch_box_refine(ref_points, d_center, size_prev, ld_size_prev, d_size, ranges, normalize, Q, center, size, size_metric, row_scene, ST);
 }
 int sd3d_class_scores(const float* cls, int ld, int64_t Q, int C, float* scores, float* rowmax, void* stream) {
     return launch_class_scores(cls, ld, Q, C, scores, rowmax, ST);

@@ -189,12 +189,13 @@ __global__ __launch_bounds__(256) void sine_pe_kernel(const float* __restrict__ 
                                                       const int8_t* __restrict__ axis, int d_pos,
                                                       const float* __restrict__ mod_num, int ld_num,
                                                       const float* __restrict__ mod_den, int ld_den,
-                                                      float* __restrict__ out, int ld_out) {
+                                                      float* __restrict__ out, int ld_out, const int32_t* __restrict__ row_scene) {
     const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (t >= n * d_pos) return;
     const int64_t r = t / d_pos;
     const int c = (int)(t - r * d_pos);
     const int a = axis[c];
+    if (row_scene) rng += 6 * row_scene[r];                   // rows of several scenes: each row normalises by ITS scene's range
     const float lo = rng[a], hi = rng[3 + a];
     float p = ((xyz[r * ld_xyz + a] - lo) * 1.0f) / (hi - lo) + 0.0f;
     p = p * 6.283185307179586f;
@@ -205,10 +206,11 @@ __global__ __launch_bounds__(256) void sine_pe_kernel(const float* __restrict__ 
 }
 
 int launch_sine_pe(const float* xyz, int ld_xyz, int64_t n, const float* rng, const float* dim_t, const int8_t* axis, int d_pos,
-                   const float* mod_num, int ld_num, const float* mod_den, int ld_den, float* out, int ld_out, hipStream_t st) {
+                   const float* mod_num, int ld_num, const float* mod_den, int ld_den, float* out, int ld_out, const int32_t* row_scene,
+                   hipStream_t st) {
     if (n <= 0) return SD3D_OK;
     hipLaunchKernelGGL(sine_pe_kernel, dim3((unsigned)cdiv(n * d_pos, 256)), dim3(256), 0, st, xyz, ld_xyz, n, rng, dim_t, axis,
-                       d_pos, mod_num, ld_num, mod_den, ld_den, out, ld_out);
+                       d_pos, mod_num, ld_num, mod_den, ld_den, out, ld_out, row_scene);
     SD3D_CHECK_LAUNCH();
     return SD3D_OK;
 }
@@ -218,12 +220,13 @@ int launch_sine_pe(const float* xyz, int ld_xyz, int64_t n, const float* rng, co
 // reference: (x_a * 2 pi) * B[a][c], summed a = 0, 1, 2.
 __global__ __launch_bounds__(256) void fourier_pe_kernel(const float* __restrict__ xyz, int ld_xyz, int64_t n, const float* __restrict__ rng,
                                                          const float* __restrict__ gauss_b, int ld_b, int d_pos,
-                                                         float* __restrict__ out, int ld_out) {
+                                                         float* __restrict__ out, int ld_out, const int32_t* __restrict__ row_scene) {
     const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
     const int dh = d_pos >> 1;
     if (t >= n * dh) return;
     const int64_t r = t / dh;
     const int c = (int)(t - r * dh);
+    if (row_scene) rng += 6 * row_scene[r];
     float acc = 0.f;
 #pragma unroll
     for (int a = 0; a < 3; ++a) {
@@ -237,11 +240,11 @@ __global__ __launch_bounds__(256) void fourier_pe_kernel(const float* __restrict
 }
 
 int launch_fourier_pe(const float* xyz, int ld_xyz, int64_t n, const float* rng, const float* gauss_b, int ld_b, int d_pos, float* out,
-                      int ld_out, hipStream_t st) {
+                      int ld_out, const int32_t* row_scene, hipStream_t st) {
     if (n <= 0) return SD3D_OK;
     if (d_pos <= 0 || (d_pos & 1)) return sd3d_set_error(SD3D_ERR_ARG, "fourier_pe: d_pos must be even");
     hipLaunchKernelGGL(fourier_pe_kernel, dim3((unsigned)cdiv(n * (d_pos / 2), 256)), dim3(256), 0, st, xyz, ld_xyz, n, rng, gauss_b, ld_b,
-                       d_pos, out, ld_out);
+                       d_pos, out, ld_out, row_scene);
     SD3D_CHECK_LAUNCH();
     return SD3D_OK;
 }
@@ -651,11 +654,13 @@ int launch_dinox_mask_bits(const uint32_t* blocked, const uint32_t* near, int nw
 // ---------------------------------------------------------------------------------------------
 __global__ void box_refine_kernel(const float* __restrict__ ref, const float* __restrict__ dc, const float* __restrict__ sprev,
                                   int ld_sprev, const float* __restrict__ ds, const float* __restrict__ rng, int normalize,
-                                  int64_t Q, float* __restrict__ center, float* __restrict__ size, float* __restrict__ size_out) {
+                                  int64_t Q, float* __restrict__ center, float* __restrict__ size, float* __restrict__ size_out,
+                                  const int32_t* __restrict__ row_scene) {
     const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (t >= Q * 3) return;
     const int64_t q = t / 3;
     const int a = (int)(t - q * 3);
+    if (row_scene) rng += 6 * row_scene[q];
     center[t] = ref[t] + dc[t];
     if (!ds) return;
     const float sp = sprev[q * ld_sprev + a];
@@ -675,10 +680,10 @@ __global__ void box_refine_kernel(const float* __restrict__ ref, const float* __
 }
 
 int launch_box_refine(const float* ref, const float* dc, const float* sprev, int ld_sprev, const float* ds, const float* rng,
-                      int normalize, int64_t Q, float* center, float* size, float* size_out, hipStream_t st) {
+                      int normalize, int64_t Q, float* center, float* size, float* size_out, const int32_t* row_scene, hipStream_t st) {
     if (Q <= 0) return SD3D_OK;
     hipLaunchKernelGGL(box_refine_kernel, dim3((unsigned)cdiv(Q * 3, 256)), dim3(256), 0, st, ref, dc, sprev, ld_sprev, ds, rng,
-                       normalize, Q, center, size, size_out);
+                       normalize, Q, center, size, size_out, row_scene);
     SD3D_CHECK_LAUNCH();
     return SD3D_OK;
 }

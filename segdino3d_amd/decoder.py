@@ -165,6 +165,9 @@ class _TrainF:
 
 
 _F_TLS = threading.local()
+# SD3D_BATCH_DECODER=0: the decoder of a multi-scene evaluation forward runs scene by scene (A/B switch; default: the row-wise work of
+# all scenes in one pass, `ScanNetQueryDecoder._forward_batch`)
+BATCH_DECODER = os.environ.get("SD3D_BATCH_DECODER", "1") != "0"
 
 
 def _F():
@@ -563,6 +566,212 @@ class ScanNetQueryDecoder(DerivedWeights):
         final["attn_mask_bits"] = bits
         return final, aux
 
+    # ---- several scenes at once (evaluation, positional variant) ---------------------------------------------------------
+    def _row_shapes(self):
+        """(Cin, Cout) of every plain Linear of the positional decoder, by the rows it runs on: queries / superpoints / 2D keys."""
+        d, L, c = self.d_model, self.num_layers, self.in_channels
+        q = [(c, d), (d, d), (2 * d, d), (2 * d, 3 * d), (d, self.ffn_layers[0].net[0].out_features), (self.ffn_layers[0].net[0].out_features, d),
+             (d, self.num_instance_classes + 1), (d, self.num_semantic_classes + 1), (d, 3), (d, 1)]
+        s = [(c, d), (d, d), (d, 2 * L * d), (d, L * d)]
+        return q, s, [(d, 2 * L * d)]
+
+    def _batchable(self, x, queries, dinox_queries):
+        """The batched path keeps every row on the kernel its scene's own forward would use (bit-identical outputs): it is taken when
+        every scene gets the same tiling code (ops.dense_code) for every Linear of its three row families, the query tensors have few
+        hundred rows (grouped launches, fused Linear + LayerNorm) and no instrumentation / opt-in arithmetic mode is active;
+        anything else runs scene by scene."""
+        if self.training or not self.add_positional_embedding or len(x) < 2 or not BATCH_DECODER or ops.GG_HOOK is not None:
+            return False
+        lim = ops.LINEAR_LN_MAX_ROWS
+        if lim <= 0 or ops.GEMM_MODE is not None or ops.GG_FORCE_NT is not None:
+            return False
+        if not all(0 < q.shape[0] <= min(512, lim) for q in queries):
+            return False
+        if ops.bf16_decoder_active() and not (all(t.shape[0] >= ops.BF16_MIN_ROWS for t in x) or all(t.shape[0] < ops.BF16_MIN_ROWS for t in x)):
+            return False
+        fams = [[q.shape[0] for q in queries], [t.shape[0] for t in x]]
+        if self.add_dinox_query_ca:
+            fams.append([t.shape[0] + 1 for t in dinox_queries])
+        for rows, shapes in zip(fams, self._row_shapes()):
+            for cin, cout in shapes:
+                codes = {ops.dense_code(r, cin, cout) for r in rows}
+                if len(codes) != 1 or None in codes:
+                    return False
+        return True
+
+    def _forward_batch(self, xs, sp_pos, sp_pos_wo, q_in, q_pos, q2d_feat, q2d_pos, ranges):
+        """`_forward_scene` for B scenes in one pass: everything row-wise (every Linear, LayerNorm, positional encoding, box
+        refinement) runs ONCE over the scenes' rows back to back - B x fewer launches per scene - with the tiling codes one scene's
+        rows would get; what couples the rows of a scene (the three attentions, mask bits, the 2D-query masks) runs per scene on
+        row slices; the B mask-logit products are one grouped launch.  Returns [(final, aux)] per scene, the tensors being row
+        slices of the batch tensors; bit-identical to B calls of `_forward_scene`."""
+        dev = xs[0].device
+        d, H, L = self.d_model, self.num_heads, self.num_layers
+        B = len(xs)
+        pk = self.packed()
+        dim_t, axis = self.pe_tables(dev)
+        s_off, q_off = [0], [0]
+        for b in range(B):
+            s_off.append(s_off[-1] + xs[b].shape[0])
+            q_off.append(q_off[-1] + q_in[b].shape[0])
+        S_tot, Q_tot = s_off[-1], q_off[-1]
+        X = torch.cat([t.contiguous() for t in xs]).contiguous()
+        SP = torch.cat([t.float() for t in sp_pos]).contiguous()
+        Qin = torch.cat(list(q_in)).contiguous()
+        rng = torch.stack([torch.cat([lo.reshape(3), hi.reshape(3)]).float() for lo, hi in ranges]).contiguous()      # [B, 6]
+        # scene index of every row, made ON the device from host-known sizes (B fills + a concatenation): no host -> device copy and no
+        # synchronising op here - a blocking call inside the issue baton stalls the other scenes' threads (measured: 114 -> 96 scenes/s)
+        scene_of = lambda offs: torch.cat([torch.full((offs[b + 1] - offs[b],), b, dtype=torch.int32, device=dev) for b in range(B)])  # noqa: E731
+        rs_s, rs_q = scene_of(s_off), scene_of(q_off)
+        # every Linear with the tiling code ONE scene's rows get (`_batchable` made sure all scenes agree on it); superpoint-side rows
+        # may take the bf16 kernel in the bf16 mode exactly when one scene's rows would (>= BF16_MIN_ROWS), query-side rows never do
+        rows_q, rows_s = q_in[0].shape[0], xs[0].shape[0]
+        s_exact = rows_s < ops.BF16_MIN_ROWS
+
+        def lin_rows(rows, exact):
+            def f(x, w, b=None, act=None, res=None, x2=None):
+                return ops.gather_gemm(x, w, x2=x2, shift=b, act=act, res=res, nt=ops.dense_code(rows, w.shape[-1], w.shape[0]), exact=exact)
+            return f
+        qlin, slin = lin_rows(rows_q, True), lin_rows(rows_s, s_exact)
+        QL = lambda x, layer, act=None, res=None: qlin(x, layer.weight, layer.bias, act, res)  # noqa: E731
+        SL = lambda x, layer, act=None, res=None: slin(x, layer.weight, layer.bias, act, res)  # noqa: E731
+        J = lambda x, layer, act=None, res=None, x2=None: (x, layer.weight, layer.bias, act, res, x2)  # noqa: E731
+        group = lambda jobs: ops.linear_group(jobs, force_small=True)  # noqa: E731
+        lin_ln = lambda x, w, b, ln_w, ln_b, res: ops.linear_layernorm(x, w, b, ln_w, ln_b, res=res, max_rows=Q_tot)  # noqa: E731
+        if self.pos_type == "fourier":
+            pe = lambda xyz, rs: ops.fourier_pe(xyz, rng, self.position_embedding.gauss_B, d, row_scene=rs)  # noqa: E731
+        else:
+            pe = lambda xyz, rs: ops.sine_pe(xyz, rng, dim_t, axis, row_scene=rs)  # noqa: E731
+
+        memory_emb = pe(SP, rs_s)
+        if self.normalize_box_prediction:
+            size_q = torch.cat([(1 / (hi - lo) * 0.5).float().reshape(1, 3).expand(q_off[b + 1] - q_off[b], 3)
+                                for b, (lo, hi) in enumerate(ranges)]).contiguous()
+        else:
+            size_q = torch.full((Q_tot, 3), 0.5, dtype=torch.float32, device=dev)
+        inst = ops.layernorm(SL(X, self.input_proj[0]), self.input_proj[1].weight, self.input_proj[1].bias, act="relu")
+        mask_feats = SL(SL(X, self.x_mask[0], act="relu"), self.x_mask[2])
+        queries = QL(QL(Qin, self.query_proj[0], act="relu"), self.query_proj[2])
+
+        def head(queries, last):
+            nq = ops.layernorm(queries, self.out_norm.weight, self.out_norm.bias)
+            sem = None
+            if last:
+                sem = QL(nq, self.out_sem) if isinstance(self.out_sem, nn.Linear) else QL(QL(nq, self.out_sem[0], act="relu"), self.out_sem[2])
+            # the B mask-logit products nq_b . mask_feats_b^T: one grouped launch (exact fp32 in every mode: they feed thresholds)
+            logits = group([(nq[q_off[b]:q_off[b + 1]], mask_feats[s_off[b]:s_off[b + 1]], None, None, None, None) for b in range(B)])
+            bits = [ops.mask_bits(logits[b], s_off[b + 1] - s_off[b], self.mask_attention_threshold) for b in range(B)]
+            score = QL(QL(nq, self.out_score[0], act="relu"), self.out_score[2]) if self.objectness_flag else None
+            return nq, sem, logits, bits, score
+
+        nq_pending, sem, logits, bits, score = head(queries, False)
+        aux = [dict(cls_preds=None, sem_preds=None, masks=logits, centers=None, sizes=None, scores=score)]
+        kv_all = slin(inst, pk["kv_w"], pk["kv_b"])                      # [S_tot, 2*L*d]
+        kp_all = slin(memory_emb, pk["kp_w"], pk["kp_b"])                # [S_tot, L*d]
+        if self.add_dinox_query_ca:
+            m_off, keys2d, near = [0], [], []
+            for b in range(B):
+                qp = q2d_pos[b]
+                if not isinstance(qp, torch.Tensor):
+                    qp = qp.tensor.type(sp_pos_wo[b].dtype).to(dev)
+                f = q2d_feat[b]
+                keys2d.append(torch.cat([f.float(), f.new_ones(1, f.shape[1], dtype=torch.float32)]))
+                m_off.append(m_off[-1] + f.shape[0] + 1)
+                near.append(ops.near_bits(sp_pos_wo[b].float().contiguous(), qp.float().contiguous(), self.dinox_query_ca_mask_threshold))
+            rows_m = q2d_feat[0].shape[0] + 1
+            kv2d_all = lin_rows(rows_m, rows_m < ops.BF16_MIN_ROWS)(torch.cat(keys2d).contiguous(), pk["kv2d_w"], pk["kv2d_b"])    # [sum(M_b + 1), 2*L*d]
+
+        ref_points = torch.cat([t.float() for t in q_pos]).contiguous()
+        ref_sizes = size_q
+        for i in range(L):
+            ops.baton_yield()
+            jobs, what = [], []
+            if self.box_modulate_ca:
+                jobs.append(J(queries, self.ref_anchor_head.layers[0], "relu")); what.append("anchor")
+            if i > 0:
+                jobs.append(J(queries, self.ca_qcontent_proj[i])); what.append("qc")
+            jobs.append(J(nq_pending, self.out_cls[0], "relu")); what.append("cls")
+            outs = dict(zip(what, group(jobs)))
+            jobs, what = [J(outs["cls"], self.out_cls[2])], ["cls"]
+            if self.box_modulate_ca:
+                jobs.append(J(outs["anchor"], self.ref_anchor_head.layers[1], "sigmoid")); what.append("hwl")
+            outs2 = dict(zip(what, group(jobs)))
+            aux[-1]["cls_preds"] = outs2["cls"]
+            if self.box_modulate_ca:
+                pq_emb = ops.sine_pe(ref_points, rng, dim_t, axis, mod_num=outs2["hwl"], mod_den=ref_sizes, row_scene=rs_q)
+            else:
+                pq_emb = pe(ref_points, rs_q)
+            h, qs = group([J(pq_emb, self.ref_point_head.layers[0], "relu"), J(pq_emb, self.ca_qpos_sine_proj[i])])
+            query_pos = QL(h, self.ref_point_head.layers[1])
+            kc = kv_all[:, i * d:(i + 1) * d]
+            v = kv_all[:, (L + i) * d:(L + i + 1) * d]
+            kp = kp_all[:, i * d:(i + 1) * d]
+            if i == 0:
+                qc = qlin(queries, pk["ca_q0_w"], pk["ca_q0_b"], x2=query_pos)
+                kc = SL(inst, self.ca_kcontent_proj[0], res=kp)
+            else:
+                qc = outs["qc"]
+            a = torch.empty(Q_tot, d, dtype=torch.float32, device=dev)
+            for b in range(B):
+                q0, q1, k0, k1 = q_off[b], q_off[b + 1], s_off[b], s_off[b + 1]
+                ops.attention(qc[q0:q1], kc[k0:k1], v[k0:k1], H, (2 * d // H) ** -0.5, mask_bits=bits[b], q2=qs[q0:q1], k2=kp[k0:k1], out=a[q0:q1])
+            op = self.cross_attn_layers[i].out_proj
+            queries = lin_ln(a, op.weight, op.bias, self.norm1[i].weight, self.norm1[i].bias, queries)
+            qkv = qlin(queries, pk["sa_qkv_w"][i], pk["sa_qkv_b"][i], x2=query_pos)
+            a = torch.empty(Q_tot, d, dtype=torch.float32, device=dev)
+            for b in range(B):
+                q0, q1 = q_off[b], q_off[b + 1]
+                ops.attention(qkv[q0:q1, :d], qkv[q0:q1, d:2 * d], qkv[q0:q1, 2 * d:], H, (d // H) ** -0.5, out=a[q0:q1])
+            op = self.self_attn_layers[i].out_proj
+            queries = lin_ln(a, op.weight, op.bias, self.norm2[i].weight, self.norm2[i].bias, queries)
+            if self.add_dinox_query_ca:
+                layer = self.dinox_query_cross_attn_layers[i]
+                q = qlin(queries, pk["q2d_w"][i], pk["q2d_b"][i])
+                a = torch.empty(Q_tot, d, dtype=torch.float32, device=dev)
+                for b in range(B):
+                    q0, q1, k0, k1 = q_off[b], q_off[b + 1], m_off[b], m_off[b + 1]
+                    ops.attention(q[q0:q1], kv2d_all[k0:k1, i * d:(i + 1) * d], kv2d_all[k0:k1, (L + i) * d:(L + i + 1) * d], H,
+                                  (d // H) ** -0.5, mask_bits=ops.dinox_mask_bits(bits[b], near[b]), out=a[q0:q1])
+                op = layer.attn.out_proj
+                if layer.fix:
+                    queries = lin_ln(a, op.weight, op.bias, layer.norm.weight, layer.norm.bias, queries)
+                else:
+                    queries = qlin(a, op.weight, op.bias, res=queries)
+            ffn = self.ffn_layers[i]
+            hdn = QL(queries, ffn.net[0], act=("relu" if self.activation_fn == "relu" else "gelu"))
+            queries = ops.layernorm(qlin(hdn, ffn.net[3].weight, ffn.net[3].bias, res=queries), ffn.norm.weight, ffn.norm.bias)
+            if self.add_box_size_pred:
+                be, se = self.bbox_embed[i].layers, self.bbox_size_embed[i].layers
+                c1, s1 = group([J(queries, be[0], "relu"), J(queries, se[0], "relu")])
+                c2, s2 = group([J(c1, be[1], "relu"), J(s1, se[1], "relu")])
+                dc, ds = group([J(c2, be[2]), J(s2, se[2])])
+            else:
+                dc, ds = queries, None
+                for li, layer_ in enumerate(self.bbox_embed[i].layers):
+                    dc = QL(dc, layer_, act=None if li == len(self.bbox_embed[i].layers) - 1 else "relu")
+            center, size, size_metric = ops.box_refine(ref_points, dc, size_q, ds, rng, self.normalize_box_prediction, row_scene=rs_q)
+            ref_points = center
+            if self.add_box_size_pred:
+                ref_sizes = size_q = size
+            last = i == L - 1
+            nq_pending, sem, logits, bits, score = head(queries, last)
+            aux.append(dict(cls_preds=None, sem_preds=sem, masks=logits, centers=center, sizes=size_metric, scores=score))
+        aux[-1]["cls_preds"] = QL(QL(nq_pending, self.out_cls[0], act="relu"), self.out_cls[2])
+
+        def scene_view(entry, b):
+            q0, q1 = q_off[b], q_off[b + 1]
+            row = lambda t: None if t is None else t[q0:q1]  # noqa: E731
+            return dict(cls_preds=row(entry["cls_preds"]), sem_preds=row(entry["sem_preds"]), masks=entry["masks"][b],
+                        centers=row(entry["centers"]), sizes=row(entry["sizes"]), scores=row(entry["scores"]))
+        results = []
+        for b in range(B):
+            views = [scene_view(e, b) for e in aux]
+            final = views.pop()
+            final["hidden_states"] = queries[q_off[b]:q_off[b + 1]]
+            final["attn_mask_bits"] = bits[b]
+            results.append((final, views))
+        return results
+
     # ---- reference-shaped entry point (:417-435) --------------------------------------------------
     @ops.bound_stream
     def forward(self, x, sp_pos=None, sp_pos_wo_elastic=None, queries=None, queries_pos=None, dinox_queries=None,
@@ -586,7 +795,13 @@ class ScanNetQueryDecoder(DerivedWeights):
                 auxes.append(a)
         else:
             assert (sp_pos is not None) and (queries_pos is not None) and (scene_range is not None)
-        for j in range(len(x) if self.add_positional_embedding else 0):
+        batched = self.add_positional_embedding and self._batchable(x, queries, dinox_queries)
+        if batched:
+            for f, a in self._forward_batch(x, sp_pos, sp_pos_wo_elastic if sp_pos_wo_elastic is not None else sp_pos, queries, queries_pos,
+                                            dinox_queries, dinox_query_pos, scene_range):
+                finals.append(f)
+                auxes.append(a)
+        for j in range(len(x) if (self.add_positional_embedding and not batched) else 0):
             f, a = self._forward_scene(
                 x[j], sp_pos[j], sp_pos_wo_elastic[j] if sp_pos_wo_elastic is not None else sp_pos[j], queries[j],
                 queries_pos[j], dinox_queries[j] if dinox_queries is not None else None,

@@ -168,6 +168,19 @@ class PipelinedRunner:
         # one issuing thread at a time, handed over while a thread waits for the GPU (ops.wait_event)
         self.use_baton = os.environ.get("SD3D_BATON", "1") != "0"
 
+    def plan_batches(self, n_scenes: int):
+        """Which scenes each stream runs, in which forwards: scene i goes to stream i mod n (every stream gets the same number of
+        scenes +- 1, whatever the batch size), and a stream cuts ITS scenes into ceil(share / batch) forwards of near-equal size -
+        so a short list (the driver's 20 steps on 4 streams x batches of 4: five scenes per stream, forwards of 3 + 2) keeps all
+        streams busy to the end instead of leaving one stream a whole extra batch.  -> [[scene ids of a forward, ...] per stream]"""
+        plan = []
+        for w in range(self.n):
+            mine = list(range(w, n_scenes, self.n))
+            nb = (len(mine) + self.batch - 1) // self.batch
+            cuts = [len(mine) * k // nb for k in range(nb + 1)] if nb else [0]
+            plan.append([mine[cuts[k]:cuts[k + 1]] for k in range(nb)])
+        return plan
+
     def run(self, scenes, on_result=None):
         """scenes: sequence of (points, target) already on the device, or an iterator that yields them lazily
         (e.g. io_scene.ScenePrefetcher: each worker pulls its next scene when it is ready for it).  Returns the list of
@@ -193,9 +206,7 @@ class PipelinedRunner:
                     baton.acquire()
                     ops.set_baton(baton)
                 with torch.cuda.stream(self.streams[wid]), torch.no_grad():
-                    B = self.batch
-                    for g in range(wid, (len(scenes) + B - 1) // B, self.n):
-                        ids = range(g * B, min(len(scenes), (g + 1) * B))
+                    for ids in self.plan_batches(len(scenes))[wid]:
                         out = self.model([scenes[i][0] for i in ids], [scenes[i][1] for i in ids])
                         for j, i in enumerate(ids):
                             results[i] = [out[j]]

@@ -656,16 +656,49 @@ def pair_conv(x, wt, pairs, x2=None, scale=None, shift=None, res=None, act=None,
 _LINEAR_JOB_DT = None
 
 
-def linear_group(jobs):
+def dense_code(rows: int, cin: int, cout: int) -> int:
+    """The tiling code of sd3d_gather_gemm that reproduces, for ANY number of rows, the kernel its heuristic picks for a plain Linear
+    on `rows` rows (csrc/gather_gemm.hip launch_gather_gemm, identity rows): the batched decoder passes it so that the rows of several
+    scenes run on the SAME kernel - same summation order - as one scene's rows.  0 = the lock-step kernel (>= 64 row tiles: its order
+    does not depend on the row count, the heuristic may choose freely), -1 = one 32-column tile per wave with the contraction split over
+    the four waves of a workgroup, n > 0 = n column tiles per wave, no split."""
+    sub, tiles, steps = (cout + 31) // 32, (rows + 31) // 32, cin // 32
+    if tiles >= 64 and steps >= 2:
+        return 0
+    cdiv = lambda a, b: (a + b - 1) // b  # noqa: E731
+    nt = 4 if sub >= 4 else sub
+    while nt > 1 and tiles * cdiv(sub, nt) < 2048:
+        nt -= 1
+    if sub % nt:
+        nt = max(c for c in range(1, nt + 1) if sub % c == 0)
+    if tiles * cdiv(sub, nt) < 1024 and steps >= 8:
+        return -1 if nt <= 2 else None                         # split-K runs with one tile per wave (nt > 2 cannot occur with < 1024 units)
+    return nt
+
+
+def small_rows_code(cin: int) -> int:
+    """dense_code for <= 512 rows and <= 1024 output columns (the decoder's query tensors)."""
+    return -1 if cin // 32 >= 8 else 1
+
+
+def linear_group(jobs, force_small=False):
     """jobs: list of (x, weight [Cout, Cin], bias | None, act | None, res | None, x2 | None) - INDEPENDENT plain Linears on a few
     hundred rows each; returns their outputs.  Up to 8 per launch (csrc/gather_gemm.hip gather_gemm_group_kernel); jobs that do
-    not fit the small-row path (>= 2048 rows, bf16 decoder scope on >= BF16_MIN_ROWS rows, instrumentation hook) run one by one."""
+    not fit the small-row path (>= 2048 rows, bf16 decoder scope on >= BF16_MIN_ROWS rows, instrumentation hook) run one by one.
+    force_small: the rows are several scenes' few-hundred-row tensors back to back - always the group kernel."""
     global _LINEAR_JOB_DT
     import numpy as np
-    if len(jobs) == 1 or GG_HOOK is not None or GEMM_MODE is not None or GG_FORCE_NT is not None:
+    if GG_HOOK is not None or GEMM_MODE is not None or GG_FORCE_NT is not None:
+        if force_small:
+            return [gather_gemm(x, w, x2=x2, shift=b, act=act, res=res, nt=-1, exact=True) for (x, w, b, act, res, x2) in jobs]
         return [gather_gemm(x, w, x2=x2, shift=b, act=act, res=res) for (x, w, b, act, res, x2) in jobs]
+    if len(jobs) == 1:
+        x, w, b, act, res, x2 = jobs[0]
+        if force_small:                                         # the kernel the heuristic picks for ONE scene's rows
+            return [gather_gemm(x, w, x2=x2, shift=b, act=act, res=res, nt=small_rows_code(w.shape[-1]), exact=True)]
+        return [gather_gemm(x, w, x2=x2, shift=b, act=act, res=res)]
     bf16 = getattr(_BF16_TLS, "on", False)
-    small = [x.shape[0] < 2048 and not (bf16 and x.shape[0] >= BF16_MIN_ROWS) and x.shape[0] > 0 for (x, *_r) in jobs]
+    small = [force_small or (x.shape[0] < 2048 and not (bf16 and x.shape[0] >= BF16_MIN_ROWS) and x.shape[0] > 0) for (x, *_r) in jobs]
     if not all(small):
         return [gather_gemm(x, w, x2=x2, shift=b, act=act, res=res) for (x, w, b, act, res, x2) in jobs]
     if _LINEAR_JOB_DT is None:
@@ -880,14 +913,16 @@ def layernorm(x, weight, bias, res=None, act=None, eps=1e-5, out=None):
 LINEAR_LN_MAX_ROWS = int(_os.environ.get("SD3D_LINEAR_LN_MAX_ROWS", "512"))      # 0 switches the fused launch off
 
 
-def linear_layernorm(x, weight, bias, ln_weight, ln_bias, res=None, act=None, eps=1e-5):
+def linear_layernorm(x, weight, bias, ln_weight, ln_bias, res=None, act=None, eps=1e-5, max_rows=None):
     """act(LayerNorm(x @ weight^T + bias + res) * ln_weight + ln_bias).  Few rows and a 256-wide output (the decoder's query tensors):
     one fused launch (sd3d_linear_layernorm); anything else - or an instrumented / split-precision run - is the projection followed
     by the LayerNorm kernel."""
     M, Cin = x.shape
     # (measured at 200 rows: Cin = 256 14.5 us fused vs 21.9 us in two launches; Cin = 1024 39.9 vs 22.2 - a 16-row workgroup walks
     # the whole contraction alone - so long contractions keep the two launches)
-    if (M > LINEAR_LN_MAX_ROWS or Cin > 512 or weight.shape[0] != 256 or Cin % 16 or GG_HOOK is not None or GEMM_MODE is not None or GG_FORCE_NT is not None
+    # max_rows: the rows of several scenes of <= LINEAR_LN_MAX_ROWS rows each take the fused launch too (16-row workgroups:
+    # per row the same arithmetic whatever M is - the batched decoder must not switch kernels with the batch size)
+    if (M > (LINEAR_LN_MAX_ROWS if max_rows is None else max_rows) or Cin > 512 or weight.shape[0] != 256 or Cin % 16 or GG_HOOK is not None or GEMM_MODE is not None or GG_FORCE_NT is not None
             or not weight.is_contiguous() or (res is not None and res.stride(1) != 1)):
         return layernorm(gather_gemm(x, weight, shift=bias, res=res), ln_weight, ln_bias, act=act, eps=eps)
     lib = _lib.load()
@@ -901,8 +936,9 @@ def linear_layernorm(x, weight, bias, ln_weight, ln_bias, res=None, act=None, ep
     return out
 
 
-def sine_pe(xyz, rng, dim_t, axis, mod_num=None, mod_den=None):
-    """xyz [n,3]; rng [6] = (lo, hi); dim_t [d] fp32, axis [d] int8 -> [n, d]."""
+def sine_pe(xyz, rng, dim_t, axis, mod_num=None, mod_den=None, row_scene=None):
+    """xyz [n,3]; rng [6] = (lo, hi); dim_t [d] fp32, axis [d] int8 -> [n, d].  row_scene int32 [n]: rows of several scenes,
+    rng is then [n_scenes, 6] and row r uses rng[row_scene[r]] (sd3d_sine_pe_rows)."""
     lib = _lib.load()
     px, ldx = _rows(xyz, "xyz")
     n, d = xyz.shape[0], dim_t.numel()
@@ -914,12 +950,17 @@ def sine_pe(xyz, rng, dim_t, axis, mod_num=None, mod_den=None):
             pd, ldd = _ptr(mod_den, torch.float32, "mod_den"), 0
         else:
             pd, ldd = _rows(mod_den, "mod_den")
+    if row_scene is not None:
+        _lib.check(lib.sd3d_sine_pe_rows(px, ldx, n, _ptr(rng, torch.float32, "rng"), _ptr(row_scene, torch.int32, "row_scene"),
+                                         _ptr(dim_t, torch.float32, "dim_t"), _ptr(axis, torch.int8, "axis"), d, pn, ldn, pd, ldd,
+                                         _ptr(out), d, _stream()), "sine_pe_rows")
+        return out
     _lib.check(lib.sd3d_sine_pe(px, ldx, n, _ptr(rng, torch.float32, "rng"), _ptr(dim_t, torch.float32, "dim_t"),
                                 _ptr(axis, torch.int8, "axis"), d, pn, ldn, pd, ldd, _ptr(out), d, _stream()), "sine_pe")
     return out
 
 
-def fourier_pe(xyz, rng, gauss_b, d_pos):
+def fourier_pe(xyz, rng, gauss_b, d_pos, row_scene=None):
     """xyz [n,3]; rng [6] = (lo, hi); gauss_b [3, >= d_pos / 2] fp32 -> [n, d_pos] = [sin | cos] (utils.py:107-142)."""
     lib = _lib.load()
     px, ldx = _rows(xyz, "xyz")
@@ -928,12 +969,16 @@ def fourier_pe(xyz, rng, gauss_b, d_pos):
     if gauss_b.shape[0] != 3 or gauss_b.shape[1] < d_pos // 2:
         raise ValueError("fourier_pe: gauss_b must be [3, >= d_pos / 2]")
     out = torch.empty(n, d_pos, dtype=torch.float32, device=xyz.device)
+    if row_scene is not None:
+        _lib.check(lib.sd3d_fourier_pe_rows(px, ldx, n, _ptr(rng, torch.float32, "rng"), _ptr(row_scene, torch.int32, "row_scene"), pb, ldb,
+                                            d_pos, _ptr(out), d_pos, _stream()), "fourier_pe_rows")
+        return out
     _lib.check(lib.sd3d_fourier_pe(px, ldx, n, _ptr(rng, torch.float32, "rng"), pb, ldb, d_pos, _ptr(out), d_pos, _stream()), "fourier_pe")
     return out
 
 
-def attention(q, k, v, num_heads, scale, mask_bits=None, q2=None, k2=None):
-    """q/k [L, H*32] (+ optional second source concatenated per head), v [Lk, H*32] -> [Lq, H*32]."""
+def attention(q, k, v, num_heads, scale, mask_bits=None, q2=None, k2=None, out=None):
+    """q/k [L, H*32] (+ optional second source concatenated per head), v [Lk, H*32] -> [Lq, H*32] (`out`: rows to write into)."""
     lib = _lib.load()
     pq, ldq = _rows(q, "q")
     pk, ldk = _rows(k, "k")
@@ -947,7 +992,10 @@ def attention(q, k, v, num_heads, scale, mask_bits=None, q2=None, k2=None):
         raise ValueError("attention: head slices must be 32 channels wide")
     if mask_bits is not None and tuple(mask_bits.shape) != (Lq, (Lk + 31) // 32):
         raise ValueError(f"attention: mask bits shape {tuple(mask_bits.shape)} != ({Lq}, {(Lk + 31) // 32})")
-    out = torch.empty(Lq, num_heads * 32, dtype=torch.float32, device=q.device)
+    if out is None:
+        out = torch.empty(Lq, num_heads * 32, dtype=torch.float32, device=q.device)
+    elif tuple(out.shape) != (Lq, num_heads * 32) or not out.is_contiguous() or out.dtype != torch.float32:
+        raise ValueError("attention: `out` must be a contiguous fp32 [Lq, H * 32] tensor")
     ws = _WS6.get(lib.sd3d_attention_ws_bytes(Lq, num_heads), q.device)
     fn = lib.sd3d_attention_bf16 if bf16_decoder_active() else lib.sd3d_attention
     _lib.check(fn(pq, ldq, pq2, ldq2, pk, ldk, pk2, ldk2, pv, ldv, _ptr(mask_bits, torch.int32, "mask_bits"),
@@ -986,7 +1034,8 @@ def dinox_mask_bits(blocked, near):
     return out
 
 
-def box_refine(ref_points, d_center, size_prev, d_size, rng, normalize):
+def box_refine(ref_points, d_center, size_prev, d_size, rng, normalize, row_scene=None):
+    """row_scene int32 [Q]: rows of several scenes, rng [n_scenes, 6] (sd3d_box_refine_rows)."""
     lib = _lib.load()
     Q = ref_points.shape[0]
     dev = ref_points.device
@@ -998,6 +1047,12 @@ def box_refine(ref_points, d_center, size_prev, d_size, rng, normalize):
         size_metric = torch.empty(Q, 3, dtype=torch.float32, device=dev)
         ps = _ptr(size_prev, torch.float32, "size_prev")
         lds = 0 if size_prev.dim() == 1 else 3
+    if row_scene is not None:
+        _lib.check(lib.sd3d_box_refine_rows(_ptr(ref_points, torch.float32, "ref_points"), _ptr(d_center, torch.float32, "d_center"),
+                                            ps, lds, _ptr(d_size, torch.float32, "d_size"), _ptr(rng, torch.float32, "rng"),
+                                            _ptr(row_scene, torch.int32, "row_scene"), int(normalize), Q, _ptr(center), _ptr(size),
+                                            _ptr(size_metric), _stream()), "box_refine_rows")
+        return center, size, size_metric
     _lib.check(lib.sd3d_box_refine(_ptr(ref_points, torch.float32, "ref_points"), _ptr(d_center, torch.float32, "d_center"),
                                    ps, lds, _ptr(d_size, torch.float32, "d_size"), _ptr(rng, torch.float32, "rng"),
                                    int(normalize), Q, _ptr(center), _ptr(size), _ptr(size_metric), _stream()), "box_refine")

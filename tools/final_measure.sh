@@ -8,7 +8,7 @@ python bench.py > gpurun_out/${P}_bench.json 2> gpurun_out/${P}_bench.err
 python bench.py --no-cpu-baseline --no-end-to-end --decoder-dtype bf16 > gpurun_out/${P}_bench_bf16.json 2>> gpurun_out/${P}_bench.err
 python bench.py --no-cpu-baseline --no-end-to-end --query-num -1 > gpurun_out/${P}_bench_qall.json 2>> gpurun_out/${P}_bench.err
 python bench.py --no-cpu-baseline --no-end-to-end --query-num -1 --decoder-dtype bf16 > gpurun_out/${P}_bench_qall_bf16.json 2>> gpurun_out/${P}_bench.err
-python bench.py --no-cpu-baseline --no-end-to-end --batch 4 > gpurun_out/${P}_bench_batch4.json 2>> gpurun_out/${P}_bench.err
+python bench.py --no-cpu-baseline --no-end-to-end --batch 1 > gpurun_out/${P}_bench_batch1.json 2>> gpurun_out/${P}_bench.err
 python bench.py --no-cpu-baseline --no-end-to-end --scene-layout scan > gpurun_out/${P}_bench_scan_layout.json 2>> gpurun_out/${P}_bench.err
 SD3D_DIST_BACKEND=gloo SD3D_SHARE_GPU=1 python bench.py --gpus 2 --no-cpu-baseline --no-end-to-end --steps 24 > gpurun_out/${P}_bench_2ranks_shared_gpu.json 2>> gpurun_out/${P}_bench.err
 bash tools/profile_run.sh ${P}_kernel_trace_1stream --steps 8 --warmup 2 --streams 1 --preroll-seconds 0.2 --no-end-to-end
