@@ -146,6 +146,10 @@ int sd3d_pool_superpoints(const float* feat, int ld_feat, int C, const int32_t* 
 int sd3d_gather_gemm(const float* in0, int ld0, int C0, const float* in1, int ld1, const int32_t* nbr, const float* wt,
                      int K, int Cin, int Cout, int64_t M, const float* scale, const float* shift, const float* res,
                      int ld_res, float* out, int ld_out, int act, int nt, void* ws, size_t ws_bytes, void* stream);
+/* Host-only helper: the value of `nt` that makes sd3d_gather_gemm run a plain Linear (nbr = NULL, K = 1) on ANY number of rows with the
+ * kernel - hence the summation order and the bits - it picks by itself for `rows` rows (0 = the lock-step kernel, whose order does
+ * not depend on the row count).  The batched evaluation forward runs the rows of several scenes in one launch this way. */
+int sd3d_dense_plan_code(int64_t rows, int Cin, int Cout);
 /* n <= 8 INDEPENDENT plain Linears in one launch: out_i = act_i([in0_i | in1_i] wt_i^T + shift_i + res_i), wt_i [Cout, Cin]
  * (nn.Linear layout).  For the decoder's chains of few-hundred-row Linears (instance_seg_3d_decoder.py:656-772: the two box MLPs
  * of a layer, projections that share an input) - the same kernel as sd3d_gather_gemm's small-M path, one dispatch. */

@@ -48,6 +48,7 @@ SIGNATURES = {
     "sd3d_segment_starts_batch": (_i, [_p, _l, _l, _p, _i, _p, _p]),
     "sd3d_pool_superpoints": (_i, [_p, _i, _i, _p, _p, _f, _p, _p, _l, _p, _p, _p]),
     "sd3d_gather_gemm": (_i, [_p, _i, _i, _p, _i, _p, _p, _i, _i, _i, _l, _p, _p, _p, _i, _p, _i, _i, _i, _p, _z, _p]),
+    "sd3d_dense_plan_code": (_i, [_l, _i, _i]),
     "sd3d_linear_group": (_i, [_i, _p, _p]),
     "sd3d_gather_gemm_split": (_i, [_p, _i, _i, _p, _i, _p, _p, _i, _i, _i, _i, _l, _p, _p, _p, _i, _p, _i, _i, _i, _p, _z, _p]),
     "sd3d_pair_lists_ws_bytes": (_z, [_i, _l]),

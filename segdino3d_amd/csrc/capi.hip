@@ -37,6 +37,7 @@ int launch_pool_superpoints(const float*, int, int, const int32_t*, const int32_
 int launch_voxel_keys(const float*, int, int64_t, float, const float*, int, int, int32_t*, uint64_t*, int32_t*, int32_t*, hipStream_t);
 
 int launch_gather_gemm(const GGParams&, int, void*, size_t, hipStream_t);
+int dense_plan_code(int64_t, int, int);
 int launch_gather_gemm_split(const GGParams&, int, int, const void*, void*, size_t, hipStream_t);
 size_t pair_lists_ws_bytes(int K, int64_t M);
 int launch_pair_lists(const int32_t*, int, int64_t, int64_t, int32_t*, int32_t*, int32_t*, void*, size_t, hipStream_t);
@@ -215,6 +216,8 @@ int sd3d_fourier_pe_rows(const float* xyz, int ld_xyz, int64_t n, const float* r
                          int d_pos, float* out, int ld_out, void* stream) {
     return launch_fourier_pe(xyz, ld_xyz, n, ranges, gauss_b, ld_b, d_pos, out, ld_out, row_scene, ST);
 }
+
+int sd3d_dense_plan_code(int64_t rows, int Cin, int Cout) { return dense_plan_code(rows, Cin, Cout); }
 
 int sd3d_linear_group(int n, const sd3d_linear_job* jobs, void* stream) {
     GGParams g[8];

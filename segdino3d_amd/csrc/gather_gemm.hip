@@ -381,6 +381,23 @@ void launch_splitk_epilogue(const GGParams& p, hipStream_t st) {
     hipLaunchKernelGGL(splitk_epilogue_kernel, dim3((unsigned)cdiv(p.M * p.Cout, 256)), dim3(256), 0, st, p);
 }
 
+// The tiling code that makes launch_gather_gemm pick, for ANY number of rows, the kernel its heuristic picks for a plain Linear
+// (identity rows, K = 1) on `rows` rows: 0 = lock-step kernel (>= 64 row tiles; its summation order does not depend on the
+// row count, so the heuristic stays free), -1 = one column tile per wave with the contraction split over the four waves,
+// n > 0 = n column tiles per wave without split.  The batched decoder passes it so that the rows of several scenes run on the
+// same kernel - same summation order, same bits - as one scene's rows.  Mirrors the heuristic below; keep them together.
+int dense_plan_code(int64_t rows, int Cin, int Cout) {
+    const int sub = (Cout + 31) / 32;
+    const int64_t tiles = cdiv(rows, 32);
+    const int64_t steps = Cin / 32;
+    if (tiles >= 64 && steps >= 2) return 0;
+    int nt = sub >= 4 ? 4 : sub;
+    while (nt > 1 && tiles * cdiv(sub, nt) < 2048) --nt;
+    if (sub % nt) { for (int c = nt; c >= 1; --c) if (sub % c == 0) { nt = c; break; } }
+    if (tiles * cdiv(sub, nt) < 1024 && steps >= 8) return -1;        // (split-K then runs with one tile per wave when nt > 2; nt <= 2 here)
+    return nt;
+}
+
 int launch_gather_gemm(const GGParams& p_in, int nt, void* ws, size_t ws_bytes, hipStream_t st) {
     GGParams p = p_in;
     p.ksplit = 1;

@@ -657,23 +657,12 @@ _LINEAR_JOB_DT = None
 
 
 def dense_code(rows: int, cin: int, cout: int) -> int:
-    """The tiling code of sd3d_gather_gemm that reproduces, for ANY number of rows, the kernel its heuristic picks for a plain Linear
-    on `rows` rows (csrc/gather_gemm.hip launch_gather_gemm, identity rows): the batched decoder passes it so that the rows of several
+    """Tiling code of sd3d_gather_gemm that reproduces, for ANY number of rows, the kernel its heuristic picks for a plain Linear
+    on `rows` rows (sd3d_dense_plan_code - the C library's own answer): the batched decoder passes it so that the rows of several
     scenes run on the SAME kernel - same summation order - as one scene's rows.  0 = the lock-step kernel (>= 64 row tiles: its order
-    does not depend on the row count, the heuristic may choose freely), -1 = one 32-column tile per wave with the contraction split over
-    the four waves of a workgroup, n > 0 = n column tiles per wave, no split."""
-    sub, tiles, steps = (cout + 31) // 32, (rows + 31) // 32, cin // 32
-    if tiles >= 64 and steps >= 2:
-        return 0
-    cdiv = lambda a, b: (a + b - 1) // b  # noqa: E731
-    nt = 4 if sub >= 4 else sub
-    while nt > 1 and tiles * cdiv(sub, nt) < 2048:
-        nt -= 1
-    if sub % nt:
-        nt = max(c for c in range(1, nt + 1) if sub % c == 0)
-    if tiles * cdiv(sub, nt) < 1024 and steps >= 8:
-        return -1 if nt <= 2 else None                         # split-K runs with one tile per wave (nt > 2 cannot occur with < 1024 units)
-    return nt
+    does not depend on the row count), -1 = one 32-column tile per wave with the contraction split over the four waves of a
+    workgroup, n > 0 = n column tiles per wave, no split."""
+    return _lib.load().sd3d_dense_plan_code(int(rows), int(cin), int(cout))
 
 
 def small_rows_code(cin: int) -> int:

@@ -1,6 +1,6 @@
 """Batched evaluation forward: B scenes as ONE block-diagonal sparse tensor (sparse.BatchSceneMaps - the collation of the
-reference's `utils/dataset_utils.py:215-230` collate_fn_3D + `minkunet.py:624-627`), decoders / post-processing fanned out
-over side streams.  Evaluation BatchNorm is an affine map and every kernel on the path computes an output row from that row's
+reference's `utils/dataset_utils.py:215-230` collate_fn_3D + `minkunet.py:624-627`), the decoder's row-wise work for all scenes
+in one pass (`ScanNetQueryDecoder._forward_batch`), post-processing per scene.  Evaluation BatchNorm is an affine map and every kernel on the path computes an output row from that row's
 own pairs in a fixed order, so EVERY output of every scene must be bit-identical (`torch.equal`) to its single-scene forward
 (`baseline3d.py:308-346` runs one scene per forward, `:335-338`).  Integer work (maps, pair lists) is compared exactly."""
 import copy
@@ -198,3 +198,38 @@ def test_pipelined_runner_with_batches_is_bit_identical_to_sequential():
             got = _fields(par[slot][0].pred_pts_seg)
             for k, v in seq[i].items():
                 assert got[k].shape == v.shape and torch.equal(got[k], v), f"run {rep}, slot {slot} (scene {i}): `{k}` differs"
+
+
+@pytest.mark.parametrize("rows,cin,cout", [(90, 256, 3072), (200, 96, 256), (200, 256, 256), (200, 512, 768), (200, 256, 1024), (200, 1024, 256),
+                                            (200, 256, 199), (301, 256, 3072), (340, 256, 3072), (512, 256, 1536), (700, 256, 3072), (1500, 96, 256),
+                                            (3000, 256, 3072), (3000, 96, 256)])
+def test_dense_plan_code_reproduces_the_single_scene_kernel(rows, cin, cout):
+    """sd3d_dense_plan_code(rows, Cin, Cout) must make sd3d_gather_gemm compute each of MANY rows exactly as its own heuristic computes
+    them when it is given `rows` rows: the batched decoder's bit-identity rests on it (csrc/gather_gemm.hip keeps the two together)."""
+    from segdino3d_amd import ops
+    d = dev()
+    g = torch.Generator().manual_seed(rows + cin)
+    big = 4 * rows + 37
+    x = torch.randn(big, cin, generator=g).to(d)
+    w = (torch.randn(cout, cin, generator=g) * cin ** -0.5).to(d)
+    b = torch.randn(cout, generator=g).to(d)
+    ref = torch.cat([ops.gather_gemm(x[i:i + rows].contiguous(), w, shift=b, act="relu") for i in range(0, big - rows + 1, rows)])
+    code = ops.dense_code(rows, cin, cout)
+    got = ops.gather_gemm(x, w, shift=b, act="relu", nt=code, exact=True)
+    assert torch.equal(got[:ref.shape[0]], ref), f"rows={rows} {cin}->{cout}: code {code} does not reproduce the heuristic's kernel"
+
+
+def test_batched_forward_in_the_bf16_decoder_mode_and_for_configs0():
+    """The batched path in the two other configurations: configs[2] (`compute_dtype = "bf16"`: superpoint-side projections and the
+    attention contractions on bf16 operands) and configs[0] (SpConvUNet backbone scene by scene + additive box refinement,
+    `SegDINO3D_ScanNetv2`) - bit-identical to single-scene forwards in both."""
+    from segdino3d_amd.configs import scannet200_model_cfg, scannetv2_model_cfg
+    d = dev()
+    cfg = scannet200_model_cfg(query_num=200)
+    cfg["decoder_cfg"]["compute_dtype"] = "bf16"
+    model = _build(cfg, d)
+    _compare(model, _scenes(d, [(90_000, 2500, 200), (84_000, 2300, 180)]), "bf16 decoder")
+    cfg0 = scannetv2_model_cfg(query_num=-1)
+    cfg0["test_cfg"]["npoint_thr"] = 20
+    model0 = _build(cfg0, d)
+    _compare(model0, _scenes(d, [(10_000, 300, 50), (8_000, 250, 40), (9_000, 280, 50)], seed=31), "configs[0]")

@@ -84,3 +84,32 @@ def test_bench_rank_refuses_world_size_mismatch():
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1"], env=env,
                        capture_output=True, text=True, timeout=300)
     assert r.returncode != 0 and "WORLD_SIZE=1" in r.stderr and "n_gpus" not in r.stdout
+
+
+def test_runner_plans_equal_shares_per_stream():
+    """`PipelinedRunner.plan_batches`: every scene exactly once, streams within one scene of each other, forwards of near-equal size
+    no larger than the batch - the driver's 20 steps on 4 streams x batches of 4 become five scenes per stream as 2 + 3."""
+    from segdino3d_amd.dist_eval import PipelinedRunner
+
+    class Plan(PipelinedRunner):
+        def __init__(self, n, batch):                      # planning only: no device, no streams
+            self.n, self.batch = n, batch
+    for n, b, k in [(4, 4, 20), (4, 4, 48), (4, 1, 5), (2, 2, 11), (3, 4, 2), (1, 4, 9), (4, 4, 0)]:
+        plan = Plan(n, b).plan_batches(k)
+        assert len(plan) == n
+        assert sorted(i for st in plan for fwd in st for i in fwd) == list(range(k))
+        shares = [sum(len(f) for f in st) for st in plan]
+        assert max(shares) - min(shares) <= 1
+        for st in plan:
+            sizes = [len(f) for f in st]
+            assert all(1 <= z <= b for z in sizes) and (not sizes or max(sizes) - min(sizes) <= 1)
+    assert [[len(f) for f in st] for st in Plan(4, 4).plan_batches(20)] == [[2, 3]] * 4
+
+
+def test_dense_plan_code_is_a_host_function():
+    """sd3d_dense_plan_code needs no GPU: lock-step kernel from 64 row tiles on, split contraction for few tiles and >= 8 chunks."""
+    from segdino3d_amd import ops
+    assert ops.dense_code(3000, 256, 3072) == 0 and ops.dense_code(2048, 96, 256) == 0
+    assert ops.dense_code(200, 256, 256) == -1 and ops.dense_code(200, 1024, 256) == -1
+    assert ops.dense_code(200, 96, 256) == 1                      # 3 chunks of 32: no split
+    assert ops.dense_code(340, 256, 3072) == 1 and ops.dense_code(301, 256, 3072) == -1
