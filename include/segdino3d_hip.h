@@ -315,6 +315,18 @@ int sd3d_attention(const float* q0, int ldq0, const float* q1, int ldq1, const f
 int sd3d_attention_bf16(const float* q0, int ldq0, const float* q1, int ldq1, const float* k0, int ldk0, const float* k1,
                         int ldk1, const float* v, int ldv, const uint32_t* mask_bits, int Lq, int Lk, int H, float scale,
                         float* out, int ldo, void* ws, size_t ws_bytes, void* stream);
+/* n <= SD3D_MAX_BATCH independent attentions of the same kind (heads, scale, one or two sources, fp32 / bf16 contractions) in ONE launch:
+ * the decoder of a batched evaluation forward runs the scenes' cross- / self- / 2D-query attentions this way.  blockIdx.x runs over
+ * the query tiles of all scenes; each scene keeps the waves per workgroup and the key split its own launch would have, so its rows are
+ * the bits of sd3d_attention on that scene alone (scenes whose workgroup shapes differ are launched one by one inside the call).
+ * ws: split workspace, scene i's sd3d_attention_ws_bytes(Lq_i, H) bytes back to back. */
+typedef struct sd3d_attn_job {
+    const float *q0, *q1, *k0, *k1, *v;      /* q1 / k1 NULL for one source (all jobs alike) */
+    const uint32_t* mask_bits;               /* [Lq, ceil(Lk / 32)] or NULL */
+    float* out;
+    int32_t ldq0, ldq1, ldk0, ldk1, ldv, ldo, Lq, Lk;
+} sd3d_attn_job;
+int sd3d_attention_batch(int n, const sd3d_attn_job* jobs, int H, float scale, int bf16, void* ws, size_t ws_bytes, void* stream);
 /* _forward_head mask part (:567-572): bits = sigmoid(logits) < thr, dead rows reset to open. */
 int sd3d_mask_bits(const float* logits, int ld, int64_t Q, int S, float thr, uint32_t* bits, int nwords, void* stream);
 /* (dist < thr) of torch.cdist(p=1) (:721) as bits near[M, ceil(S/32)]. */
@@ -323,6 +335,11 @@ int sd3d_near_bits(const float* sp_pos, int64_t S, const float* centers, int64_t
 /* mask_ = ((~attn_mask).float() @ near.float()) == 0, plus the always-open dummy key (:722-726). */
 int sd3d_dinox_mask_bits(const uint32_t* blocked, const uint32_t* near, int nwords, int64_t Q, int64_t M, uint32_t* out,
                          int nwords_out, void* stream);
+/* sd3d_mask_bits / sd3d_dinox_mask_bits for the matrices of n <= SD3D_MAX_BATCH scenes in one launch each (host arrays of n entries). */
+int sd3d_mask_bits_batch(int n, const float* const* logits, const int* ld, const int64_t* Q, const int* S, uint32_t* const* bits,
+                         const int* nwords, float thr, void* stream);
+int sd3d_dinox_mask_bits_batch(int n, const uint32_t* const* blocked, const uint32_t* const* near, const int* nwords, const int64_t* Q,
+                               const int64_t* Mq, uint32_t* const* out, const int* nwords_out, void* stream);
 /* centre / size refinement (:735-759, :768-772). d_size may be NULL (no size head). */
 int sd3d_box_refine(const float* ref_points, const float* d_center, const float* size_prev, int ld_size_prev,
                     const float* d_size, const float* range, int normalize, int64_t Q, float* center, float* size,

@@ -67,6 +67,9 @@ SIGNATURES = {
     "sd3d_sine_pe_rows": (_i, [_p, _i, _l, _p, _p, _p, _p, _i, _p, _i, _p, _i, _p, _i, _p]),
     "sd3d_fourier_pe_rows": (_i, [_p, _i, _l, _p, _p, _p, _i, _i, _p, _i, _p]),
     "sd3d_box_refine_rows": (_i, [_p, _p, _p, _i, _p, _p, _p, _i, _l, _p, _p, _p, _p]),
+    "sd3d_attention_batch": (_i, [_i, _p, _i, _f, _i, _p, _z, _p]),
+    "sd3d_mask_bits_batch": (_i, [_i, _p, _p, _p, _p, _p, _p, _f, _p]),
+    "sd3d_dinox_mask_bits_batch": (_i, [_i, _p, _p, _p, _p, _p, _p, _p, _p]),
     "sd3d_attention_ws_bytes": (_z, [_i, _i]),
     "sd3d_attention": (_i, [_p, _i, _p, _i, _p, _i, _p, _i, _p, _i, _p, _i, _i, _i, _f, _p, _i, _p, _z, _p]),
     "sd3d_attention_bf16": (_i, [_p, _i, _p, _i, _p, _i, _p, _i, _p, _i, _p, _i, _i, _i, _f, _p, _i, _p, _z, _p]),

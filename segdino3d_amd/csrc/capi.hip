@@ -71,6 +71,10 @@ struct AttnParams {
     float* lse;
 };
 size_t attention_ws_bytes(int Lq, int H);
+int launch_attention_batch(int, const AttnParams*, int, void*, size_t, hipStream_t);
+int launch_mask_bits_batch(int, const float* const*, const int*, const int64_t*, const int*, uint32_t* const*, const int*, float, hipStream_t);
+int launch_dinox_mask_bits_batch(int, const uint32_t* const*, const uint32_t* const*, const int*, const int64_t*, const int64_t*,
+                                 uint32_t* const*, const int*, hipStream_t);
 int launch_attention(const AttnParams&, int, void*, size_t, hipStream_t);
 int launch_mask_bits(const float*, int, int64_t, int, float, uint32_t*, int, hipStream_t);
 int launch_near_bits(const float*, int64_t, const float*, int64_t, float, uint32_t*, int, hipStream_t);
@@ -286,6 +290,29 @@ int sd3d_sine_pe_rows(const float* xyz, int ld_xyz, int64_t n, const float* rang
                       int ld_out, void* stream) {
     if (mod_num && !mod_den) return sd3d_set_error(SD3D_ERR_ARG, "sine_pe_rows: mod_den missing");
     return launch_sine_pe(xyz, ld_xyz, n, ranges, dim_t, axis, d_pos, mod_num, ld_num, mod_den, ld_den, out, ld_out, row_scene, ST);
+}
+int sd3d_attention_batch(int n, const sd3d_attn_job* jobs, int H, float scale, int bf16, void* ws, size_t ws_bytes, void* stream) {
+    if (n <= 0) return SD3D_OK;
+    if (n > SD3D_MAX_BATCH || !jobs) return sd3d_set_error(SD3D_ERR_ARG, "attention_batch: 1..16 jobs");
+    AttnParams p[SD3D_MAX_BATCH];
+    const bool two = jobs[0].q1 != nullptr;
+    for (int i = 0; i < n; ++i) {
+        const sd3d_attn_job& j = jobs[i];
+        if ((j.q1 == nullptr) != (j.k1 == nullptr) || (j.q1 != nullptr) != two) return sd3d_set_error(SD3D_ERR_ARG, "attention_batch: all jobs need the same sources");
+        p[i].q[0] = j.q0; p[i].ldq[0] = j.ldq0; p[i].q[1] = j.q1; p[i].ldq[1] = j.ldq1;
+        p[i].k[0] = j.k0; p[i].ldk[0] = j.ldk0; p[i].k[1] = j.k1; p[i].ldk[1] = j.ldk1;
+        p[i].v = j.v; p[i].ldv = j.ldv; p[i].bits = j.mask_bits; p[i].nwords = (j.Lk + 31) / 32; p[i].out = j.out; p[i].ldo = j.ldo;
+        p[i].Lq = j.Lq; p[i].Lk = j.Lk; p[i].H = H; p[i].scale = scale; p[i].ksplit = 1; p[i].part = nullptr; p[i].bf16 = bf16 ? 1 : 0; p[i].lse = nullptr;
+    }
+    return launch_attention_batch(n, p, two ? 2 : 1, ws, ws_bytes, ST);
+}
+int sd3d_mask_bits_batch(int n, const float* const* logits, const int* ld, const int64_t* Q, const int* S, uint32_t* const* bits,
+                         const int* nwords, float thr, void* stream) {
+    return launch_mask_bits_batch(n, logits, ld, Q, S, bits, nwords, thr, ST);
+}
+int sd3d_dinox_mask_bits_batch(int n, const uint32_t* const* blocked, const uint32_t* const* near, const int* nwords, const int64_t* Q,
+                               const int64_t* Mq, uint32_t* const* out, const int* nwords_out, void* stream) {
+    return launch_dinox_mask_bits_batch(n, blocked, near, nwords, Q, Mq, out, nwords_out, ST);
 }
 size_t sd3d_attention_ws_bytes(int Lq, int H) { return attention_ws_bytes(Lq, H); }
 int sd3d_attention(const float* q0, int ldq0, const float* q1, int ldq1, const float* k0, int ldk0, const float* k1, int ldk1,

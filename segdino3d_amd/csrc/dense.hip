@@ -8,6 +8,7 @@
 //   near_bits / dinox_mask_bits : boolean (mask . distance) product as AND/any over bit words (K19)
 //   box_refine       : iterative centre / size refinement (:735-759)
 #include "common.h"
+#include "../../include/segdino3d_hip.h"
 
 __device__ static inline float wsum(float v) {
 #pragma unroll
@@ -290,13 +291,13 @@ typedef __bf16 abf16x8 __attribute__((ext_vector_type(8)));
 #define SD3D_LOG2E 1.4426950408889634f
 #define SD3D_LN2 0.6931471805599453f
 template <int NSRC, bool BF16>
-__global__ __launch_bounds__(512) void attention_kernel(const AttnParams p) {
-    extern __shared__ __attribute__((aligned(16))) float smem[];
+__device__ __forceinline__ void attention_body(const AttnParams& p, const int bx, float* smem) {
+    if ((int)blockIdx.z >= p.ksplit) return;                   // (a batched launch: this scene splits its keys fewer ways than the widest)
     const int nw = blockDim.x >> 6;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int i = lane & 31, h = lane >> 5;
     const int head = blockIdx.y;
-    const int q0 = blockIdx.x * 32;
+    const int q0 = bx * 32;
     const int qi = min(q0 + i, p.Lq - 1);
     const int hc = head * 32 + h * 16;
 
@@ -458,7 +459,7 @@ __global__ __launch_bounds__(512) void attention_kernel(const AttnParams p) {
             acc += base[64 + dv * 32 + qq] * f;
         }
         if (p.ksplit > 1) {                             // this workgroup's share of the keys: leave (M, L, sum) for the merge pass
-            float* dst = p.part + (((int64_t)blockIdx.x * p.H + head) * p.ksplit + blockIdx.z) * (64 + 1024);
+            float* dst = p.part + (((int64_t)bx * p.H + head) * p.ksplit + blockIdx.z) * (64 + 1024);
             if (dv == 0) { dst[qq] = M; dst[32 + qq] = L; }
             dst[64 + dv * 32 + qq] = acc;
         } else if (q0 + qq < p.Lq) {
@@ -468,10 +469,29 @@ __global__ __launch_bounds__(512) void attention_kernel(const AttnParams p) {
     }
 }
 
+template <int NSRC, bool BF16>
+__global__ __launch_bounds__(512) void attention_kernel(const AttnParams p) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    attention_body<NSRC, BF16>(p, blockIdx.x, smem);
+}
+
+// Several scenes' attentions in ONE launch (the decoder of a batched evaluation forward): blockIdx.x runs over the query tiles of all
+// scenes, a workgroup finds its scene from the tiles' prefix sums and then IS that scene's workgroup - same code, same waves per
+// workgroup, same key split, so every scene's rows are the bits of its own launch.
+struct AttnBatch { int n; int tile0[SD3D_MAX_BATCH + 1]; AttnParams s[SD3D_MAX_BATCH]; };
+template <int NSRC, bool BF16>
+__global__ __launch_bounds__(512) void attention_batch_kernel(const AttnBatch b) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    int si = 0;
+    for (int k = 1; k < b.n; ++k) if ((int)blockIdx.x >= b.tile0[k]) si = k;
+    attention_body<NSRC, BF16>(b.s[si], blockIdx.x - b.tile0[si], smem);
+}
+
 // second pass of the key-split attention: combine the ksplit partial softmax states of one (query tile, head)
-__global__ __launch_bounds__(256) void attention_merge_kernel(const AttnParams p) {
-    const int head = blockIdx.y, q0 = blockIdx.x * 32;
-    const float* base = p.part + ((int64_t)blockIdx.x * p.H + head) * p.ksplit * (64 + 1024);
+__device__ __forceinline__ void attention_merge_body(const AttnParams& p, const int bx) {
+    if (p.ksplit <= 1) return;
+    const int head = blockIdx.y, q0 = bx * 32;
+    const float* base = p.part + ((int64_t)bx * p.H + head) * p.ksplit * (64 + 1024);
     for (int e = threadIdx.x; e < 1024; e += 256) {
         const int qq = e >> 5, dv = e & 31;
         float M = -INFINITY;
@@ -490,23 +510,25 @@ __global__ __launch_bounds__(256) void attention_merge_kernel(const AttnParams p
         }
     }
 }
+__global__ __launch_bounds__(256) void attention_merge_kernel(const AttnParams p) { attention_merge_body(p, blockIdx.x); }
+__global__ __launch_bounds__(256) void attention_merge_batch_kernel(const AttnBatch b) {
+    int si = 0;
+    for (int k = 1; k < b.n; ++k) if ((int)blockIdx.x >= b.tile0[k]) si = k;
+    attention_merge_body(b.s[si], blockIdx.x - b.tile0[si]);
+}
 
 size_t attention_ws_bytes(int Lq, int H) { return (size_t)cdiv(Lq, 32) * H * 8 * (64 + 1024) * sizeof(float); }
 
-int launch_attention(const AttnParams& p_in, int nsrc, void* ws, size_t ws_bytes, hipStream_t st) {
-    AttnParams p = p_in;
-    if (p.Lq <= 0 || p.Lk <= 0) return sd3d_set_error(SD3D_ERR_ARG, "attention: empty query or key set");
-    for (int s = 0; s < nsrc; ++s)
-        if ((p.ldq[s] & 3) || (p.ldk[s] & 3)) return sd3d_set_error(SD3D_ERR_ARG, "attention: q/k strides must be multiples of 4");
-    const int ntiles = (p.Lk + 31) / 32;
+// waves per workgroup and key split of one attention (Lq queries, Lk keys, H heads) given `ws_bytes` of split workspace
+static void attention_config(int Lq, int Lk, int H, bool have_ws, size_t ws_bytes, int* nw_out, int* ks_out) {
+    const int ntiles = (Lk + 31) / 32;
     int nw = ntiles >= 32 ? 8 : (ntiles >= 8 ? 4 : (ntiles >= 2 ? 2 : 1));
-
     // few query tiles x heads (200 queries: 56 workgroups on 256 CUs) and many key tiles: deal the key tiles to several
     // workgroups and merge their softmax states in a second, tiny pass (each wave walks its tiles serially, so the
     // single-pass kernel is bound by ~12 dependent load -> MFMA round trips per wave)
-    const int64_t wgs = cdiv(p.Lq, 32) * p.H;
+    const int64_t wgs = cdiv(Lq, 32) * H;
     int ks = 1;
-    if (ws && wgs < 128 && ntiles >= 4 * nw) {
+    if (have_ws && wgs < 128 && ntiles >= 4 * nw) {
         nw = nw > 4 ? 4 : nw;                                  // 4 waves x more key splits: 200 queries x 3000 keys 44.4 -> 37.7 us (8 waves merge through LDS longer than they multiply)
         ks = (int)(512 / wgs);
         const int most = ntiles / (2 * nw);
@@ -514,6 +536,16 @@ int launch_attention(const AttnParams& p_in, int nsrc, void* ws, size_t ws_bytes
         ks = ks > 8 ? 8 : ks;
         if (ks < 2 || ws_bytes < (size_t)wgs * ks * (64 + 1024) * sizeof(float)) ks = 1;
     }
+    *nw_out = nw; *ks_out = ks;
+}
+
+int launch_attention(const AttnParams& p_in, int nsrc, void* ws, size_t ws_bytes, hipStream_t st) {
+    AttnParams p = p_in;
+    if (p.Lq <= 0 || p.Lk <= 0) return sd3d_set_error(SD3D_ERR_ARG, "attention: empty query or key set");
+    for (int s = 0; s < nsrc; ++s)
+        if ((p.ldq[s] & 3) || (p.ldk[s] & 3)) return sd3d_set_error(SD3D_ERR_ARG, "attention: q/k strides must be multiples of 4");
+    int nw, ks;
+    attention_config(p.Lq, p.Lk, p.H, ws != nullptr, ws_bytes, &nw, &ks);
     p.ksplit = ks;
     p.part = (float*)ws;
     const dim3 grid((unsigned)cdiv(p.Lq, 32), (unsigned)p.H, (unsigned)ks), block(64 * nw);
@@ -528,6 +560,57 @@ int launch_attention(const AttnParams& p_in, int nsrc, void* ws, size_t ws_bytes
     return SD3D_OK;
 }
 
+// n <= SD3D_MAX_BATCH independent attentions (same heads, scale, sources, arithmetic type) in one launch - when every scene's own launch
+// would use the same number of waves per workgroup; otherwise one launch per scene.  Scene i's split workspace is
+// attention_ws_bytes(Lq_i, H) bytes, back to back in ws.
+int launch_attention_batch(int n, const AttnParams* jobs, int nsrc, void* ws, size_t ws_bytes, hipStream_t st) {
+    if (n <= 0) return SD3D_OK;
+    if (n > SD3D_MAX_BATCH) return sd3d_set_error(SD3D_ERR_ARG, "attention_batch: at most 16 scenes per call");
+    AttnBatch b;
+    b.n = n;
+    int nw0 = 0, ks_max = 1, tiles = 0;
+    bool same = true;
+    size_t off = 0;
+    for (int i = 0; i < n; ++i) {
+        AttnParams p = jobs[i];
+        if (p.Lq <= 0 || p.Lk <= 0) return sd3d_set_error(SD3D_ERR_ARG, "attention_batch: empty query or key set");
+        for (int s = 0; s < nsrc; ++s)
+            if ((p.ldq[s] & 3) || (p.ldk[s] & 3)) return sd3d_set_error(SD3D_ERR_ARG, "attention_batch: q/k strides must be multiples of 4");
+        const size_t need = attention_ws_bytes(p.Lq, p.H);
+        const bool have = ws != nullptr && off + need <= ws_bytes;
+        int nw, ks;
+        attention_config(p.Lq, p.Lk, p.H, have, need, &nw, &ks);
+        p.ksplit = ks;
+        p.part = have ? (float*)((char*)ws + off) : nullptr;
+        off += need;
+        if (i == 0) nw0 = nw;
+        same = same && nw == nw0;
+        ks_max = ks > ks_max ? ks : ks_max;
+        b.tile0[i] = tiles;
+        tiles += (int)cdiv(p.Lq, 32);
+        b.s[i] = p;
+    }
+    b.tile0[n] = tiles;
+    if (!same) {                                               // different workgroup shapes: each scene its own launch (same results)
+        for (int i = 0; i < n; ++i) {
+            const int rc = launch_attention(jobs[i], nsrc, b.s[i].part, b.s[i].part ? attention_ws_bytes(jobs[i].Lq, jobs[i].H) : 0, st);
+            if (rc != SD3D_OK) return rc;
+        }
+        return SD3D_OK;
+    }
+    const bool bf16 = b.s[0].bf16 != 0;
+    const dim3 grid((unsigned)tiles, (unsigned)b.s[0].H, (unsigned)ks_max), block(64 * nw0);
+    const size_t sm = (size_t)nw0 * (64 + 1024) * sizeof(float);
+    if (nsrc == 1 && !bf16) hipLaunchKernelGGL((attention_batch_kernel<1, false>), grid, block, sm, st, b);
+    else if (nsrc == 2 && !bf16) hipLaunchKernelGGL((attention_batch_kernel<2, false>), grid, block, sm, st, b);
+    else if (nsrc == 1) hipLaunchKernelGGL((attention_batch_kernel<1, true>), grid, block, sm, st, b);
+    else if (nsrc == 2) hipLaunchKernelGGL((attention_batch_kernel<2, true>), grid, block, sm, st, b);
+    else return sd3d_set_error(SD3D_ERR_ARG, "attention_batch: nsrc must be 1 or 2");
+    if (ks_max > 1) hipLaunchKernelGGL(attention_merge_batch_kernel, dim3((unsigned)tiles, (unsigned)b.s[0].H), dim3(256), 0, st, b);
+    SD3D_CHECK_LAUNCH();
+    return SD3D_OK;
+}
+
 // ---------------------------------------------------------------------------------------------
 // mask head bits (_forward_head :567-572): blocked = sigmoid(logit) < thr; a row with every real
 // column blocked is reset to all-open.  Bits beyond S are always 1 (blocked).  One wave per row.
@@ -535,11 +618,9 @@ int launch_attention(const AttnParams& p_in, int nsrc, void* ws, size_t ws_bytes
 // One WORKGROUP per row: the four waves read the row coalesced (lane = column), a ballot turns 64 verdicts into two words;
 // the row-wide "any column open" meets in LDS.  (The first version gave every lane a 32-bit word and walked its 32 columns
 // one dependent, uncoalesced load at a time: 15.7 us for 200 x 3000 logits; this one is bound by the launch.)
-__global__ __launch_bounds__(256) void mask_bits_kernel(const float* __restrict__ logits, int ld, int64_t Q, int S, float thr,
-                                                        uint32_t* __restrict__ bits, int nwords) {
-    __shared__ int open_s[4];
+__device__ __forceinline__ void mask_bits_body(const float* __restrict__ logits, int ld, int S, float thr, uint32_t* __restrict__ bits,
+                                               int nwords, const int64_t q, int* open_s) {
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    const int64_t q = blockIdx.x;
     const float* row = logits + q * ld;
     uint32_t* out = bits + q * nwords;
     bool any_open = false;
@@ -567,6 +648,38 @@ __global__ __launch_bounds__(256) void mask_bits_kernel(const float* __restrict_
             out[w] = rem >= 32 ? 0u : (0xFFFFFFFFu << rem);
         }
     }
+}
+__global__ __launch_bounds__(256) void mask_bits_kernel(const float* __restrict__ logits, int ld, int64_t Q, int S, float thr,
+                                                        uint32_t* __restrict__ bits, int nwords) {
+    __shared__ int open_s[4];
+    mask_bits_body(logits, ld, S, thr, bits, nwords, blockIdx.x, open_s);
+}
+// the same for the logit matrices of several scenes (one workgroup per query row of any scene)
+struct MaskBitsBatch { int n; int row0[SD3D_MAX_BATCH + 1]; const float* logits[SD3D_MAX_BATCH]; uint32_t* bits[SD3D_MAX_BATCH];
+                       int ld[SD3D_MAX_BATCH], S[SD3D_MAX_BATCH], nwords[SD3D_MAX_BATCH]; };
+__global__ __launch_bounds__(256) void mask_bits_batch_kernel(const MaskBitsBatch b, float thr) {
+    __shared__ int open_s[4];
+    int si = 0;
+    for (int k = 1; k < b.n; ++k) if ((int)blockIdx.x >= b.row0[k]) si = k;
+    mask_bits_body(b.logits[si], b.ld[si], b.S[si], thr, b.bits[si], b.nwords[si], blockIdx.x - b.row0[si], open_s);
+}
+int launch_mask_bits_batch(int n, const float* const* logits, const int* ld, const int64_t* Q, const int* S, uint32_t* const* bits,
+                           const int* nwords, float thr, hipStream_t st) {
+    if (n <= 0) return SD3D_OK;
+    if (n > SD3D_MAX_BATCH) return sd3d_set_error(SD3D_ERR_ARG, "mask_bits_batch: at most 16 scenes per call");
+    MaskBitsBatch b;
+    b.n = n;
+    int rows = 0;
+    for (int i = 0; i < n; ++i) {
+        if (nwords[i] != (S[i] + 31) / 32) return sd3d_set_error(SD3D_ERR_ARG, "mask_bits_batch: nwords != ceil(S/32)");
+        b.row0[i] = rows; rows += (int)Q[i];
+        b.logits[i] = logits[i]; b.bits[i] = bits[i]; b.ld[i] = ld[i]; b.S[i] = S[i]; b.nwords[i] = nwords[i];
+    }
+    b.row0[n] = rows;
+    if (rows <= 0) return SD3D_OK;
+    hipLaunchKernelGGL(mask_bits_batch_kernel, dim3((unsigned)rows), dim3(256), 0, st, b, thr);
+    SD3D_CHECK_LAUNCH();
+    return SD3D_OK;
 }
 
 int launch_mask_bits(const float* logits, int ld, int64_t Q, int S, float thr, uint32_t* bits, int nwords, hipStream_t st) {
@@ -598,12 +711,10 @@ __global__ __launch_bounds__(256) void near_bits_kernel(const float* __restrict_
 
 // blocked2d[q] bit m = 1 <=> no superpoint is both open for query q and near 2D query m  (:722-726);
 // key Mq is the appended dummy key (always open); bits beyond Mq are blocked.
-__global__ __launch_bounds__(256) void dinox_mask_bits_kernel(const uint32_t* __restrict__ blocked, const uint32_t* __restrict__ near,
-                                                              int nwords, int64_t Q, int64_t Mq, uint32_t* __restrict__ out,
-                                                              int nwords_out) {
-    extern __shared__ uint32_t open_w[];                       // ~blocked[q][:], read by every lane
+__device__ __forceinline__ void dinox_mask_bits_body(const uint32_t* __restrict__ blocked, const uint32_t* __restrict__ near, int nwords,
+                                                     int64_t Mq, uint32_t* __restrict__ out, int nwords_out, const int64_t q,
+                                                     uint32_t* open_w) {
     const int lane = threadIdx.x & 63;
-    const int64_t q = blockIdx.x;
     for (int w = threadIdx.x; w < nwords; w += 256) open_w[w] = ~blocked[q * nwords + w];
     __syncthreads();
     for (int64_t m0 = (threadIdx.x >> 6) * 64; m0 <= Mq; m0 += 256) {      // one wave per 64 keys (incl. the dummy key Mq)
@@ -627,6 +738,39 @@ __global__ __launch_bounds__(256) void dinox_mask_bits_kernel(const uint32_t* __
             if (w + 1 < nwords_out) out[q * nwords_out + w + 1] = (uint32_t)(bal >> 32);
         }
     }
+}
+__global__ __launch_bounds__(256) void dinox_mask_bits_kernel(const uint32_t* __restrict__ blocked, const uint32_t* __restrict__ near,
+                                                              int nwords, int64_t Q, int64_t Mq, uint32_t* __restrict__ out,
+                                                              int nwords_out) {
+    extern __shared__ uint32_t open_w[];                       // ~blocked[q][:], read by every lane
+    dinox_mask_bits_body(blocked, near, nwords, Mq, out, nwords_out, blockIdx.x, open_w);
+}
+struct DinoxBitsBatch { int n; int row0[SD3D_MAX_BATCH + 1]; const uint32_t* blocked[SD3D_MAX_BATCH]; const uint32_t* near[SD3D_MAX_BATCH];
+                        uint32_t* out[SD3D_MAX_BATCH]; int nwords[SD3D_MAX_BATCH], Mq[SD3D_MAX_BATCH], nwords_out[SD3D_MAX_BATCH]; };
+__global__ __launch_bounds__(256) void dinox_mask_bits_batch_kernel(const DinoxBitsBatch b) {
+    extern __shared__ uint32_t open_w[];
+    int si = 0;
+    for (int k = 1; k < b.n; ++k) if ((int)blockIdx.x >= b.row0[k]) si = k;
+    dinox_mask_bits_body(b.blocked[si], b.near[si], b.nwords[si], b.Mq[si], b.out[si], b.nwords_out[si], blockIdx.x - b.row0[si], open_w);
+}
+int launch_dinox_mask_bits_batch(int n, const uint32_t* const* blocked, const uint32_t* const* near, const int* nwords, const int64_t* Q,
+                                 const int64_t* Mq, uint32_t* const* out, const int* nwords_out, hipStream_t st) {
+    if (n <= 0) return SD3D_OK;
+    if (n > SD3D_MAX_BATCH) return sd3d_set_error(SD3D_ERR_ARG, "dinox_mask_bits_batch: at most 16 scenes per call");
+    DinoxBitsBatch b;
+    b.n = n;
+    int rows = 0, wmax = 0;
+    for (int i = 0; i < n; ++i) {
+        if (nwords_out[i] != (int)((Mq[i] + 1 + 31) / 32)) return sd3d_set_error(SD3D_ERR_ARG, "dinox_mask_bits_batch: nwords_out != ceil((M+1)/32)");
+        b.row0[i] = rows; rows += (int)Q[i];
+        b.blocked[i] = blocked[i]; b.near[i] = near[i]; b.out[i] = out[i]; b.nwords[i] = nwords[i]; b.Mq[i] = (int)Mq[i]; b.nwords_out[i] = nwords_out[i];
+        wmax = nwords[i] > wmax ? nwords[i] : wmax;
+    }
+    b.row0[n] = rows;
+    if (rows <= 0) return SD3D_OK;
+    hipLaunchKernelGGL(dinox_mask_bits_batch_kernel, dim3((unsigned)rows), dim3(256), (size_t)wmax * sizeof(uint32_t), st, b);
+    SD3D_CHECK_LAUNCH();
+    return SD3D_OK;
 }
 
 int launch_near_bits(const float* pos, int64_t S, const float* ctr, int64_t Mq, float thr, uint32_t* near, int nwords, hipStream_t st) {

@@ -660,7 +660,7 @@ class ScanNetQueryDecoder(DerivedWeights):
                 sem = QL(nq, self.out_sem) if isinstance(self.out_sem, nn.Linear) else QL(QL(nq, self.out_sem[0], act="relu"), self.out_sem[2])
             # the B mask-logit products nq_b . mask_feats_b^T: one grouped launch (exact fp32 in every mode: they feed thresholds)
             logits = group([(nq[q_off[b]:q_off[b + 1]], mask_feats[s_off[b]:s_off[b + 1]], None, None, None, None) for b in range(B)])
-            bits = [ops.mask_bits(logits[b], s_off[b + 1] - s_off[b], self.mask_attention_threshold) for b in range(B)]
+            bits = ops.mask_bits_batch(logits, [s_off[b + 1] - s_off[b] for b in range(B)], self.mask_attention_threshold)
             score = QL(QL(nq, self.out_score[0], act="relu"), self.out_score[2]) if self.objectness_flag else None
             return nq, sem, logits, bits, score
 
@@ -712,26 +712,25 @@ class ScanNetQueryDecoder(DerivedWeights):
             else:
                 qc = outs["qc"]
             a = torch.empty(Q_tot, d, dtype=torch.float32, device=dev)
-            for b in range(B):
-                q0, q1, k0, k1 = q_off[b], q_off[b + 1], s_off[b], s_off[b + 1]
-                ops.attention(qc[q0:q1], kc[k0:k1], v[k0:k1], H, (2 * d // H) ** -0.5, mask_bits=bits[b], q2=qs[q0:q1], k2=kp[k0:k1], out=a[q0:q1])
+            QS = [(q_off[b], q_off[b + 1], s_off[b], s_off[b + 1]) for b in range(B)]
+            ops.attention_batch([(qc[q0:q1], kc[k0:k1], v[k0:k1], bits[b], qs[q0:q1], kp[k0:k1], a[q0:q1]) for b, (q0, q1, k0, k1) in enumerate(QS)],
+                                H, (2 * d // H) ** -0.5)
             op = self.cross_attn_layers[i].out_proj
             queries = lin_ln(a, op.weight, op.bias, self.norm1[i].weight, self.norm1[i].bias, queries)
             qkv = qlin(queries, pk["sa_qkv_w"][i], pk["sa_qkv_b"][i], x2=query_pos)
             a = torch.empty(Q_tot, d, dtype=torch.float32, device=dev)
-            for b in range(B):
-                q0, q1 = q_off[b], q_off[b + 1]
-                ops.attention(qkv[q0:q1, :d], qkv[q0:q1, d:2 * d], qkv[q0:q1, 2 * d:], H, (d // H) ** -0.5, out=a[q0:q1])
+            ops.attention_batch([(qkv[q0:q1, :d], qkv[q0:q1, d:2 * d], qkv[q0:q1, 2 * d:], None, None, None, a[q0:q1]) for (q0, q1, _, _) in QS],
+                                H, (d // H) ** -0.5)
             op = self.self_attn_layers[i].out_proj
             queries = lin_ln(a, op.weight, op.bias, self.norm2[i].weight, self.norm2[i].bias, queries)
             if self.add_dinox_query_ca:
                 layer = self.dinox_query_cross_attn_layers[i]
                 q = qlin(queries, pk["q2d_w"][i], pk["q2d_b"][i])
                 a = torch.empty(Q_tot, d, dtype=torch.float32, device=dev)
-                for b in range(B):
-                    q0, q1, k0, k1 = q_off[b], q_off[b + 1], m_off[b], m_off[b + 1]
-                    ops.attention(q[q0:q1], kv2d_all[k0:k1, i * d:(i + 1) * d], kv2d_all[k0:k1, (L + i) * d:(L + i + 1) * d], H,
-                                  (d // H) ** -0.5, mask_bits=ops.dinox_mask_bits(bits[b], near[b]), out=a[q0:q1])
+                bits2d = ops.dinox_mask_bits_batch(bits, near)
+                ops.attention_batch([(q[q_off[b]:q_off[b + 1]], kv2d_all[m_off[b]:m_off[b + 1], i * d:(i + 1) * d],
+                                      kv2d_all[m_off[b]:m_off[b + 1], (L + i) * d:(L + i + 1) * d], bits2d[b], None, None, a[q_off[b]:q_off[b + 1]])
+                                     for b in range(B)], H, (d // H) ** -0.5)
                 op = layer.attn.out_proj
                 if layer.fix:
                     queries = lin_ln(a, op.weight, op.bias, layer.norm.weight, layer.norm.bias, queries)

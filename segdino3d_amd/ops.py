@@ -992,6 +992,84 @@ def attention(q, k, v, num_heads, scale, mask_bits=None, q2=None, k2=None, out=N
     return out
 
 
+_ATTN_JOB_DT = None
+
+
+def attention_batch(jobs, num_heads, scale):
+    """jobs: list of (q, k, v, mask_bits | None, q2 | None, k2 | None, out) - the same attention for several scenes in ONE launch
+    (sd3d_attention_batch): per scene the rows are the bits of `attention` on that scene alone."""
+    global _ATTN_JOB_DT
+    import numpy as np
+    lib = _lib.load()
+    if _ATTN_JOB_DT is None:
+        _ATTN_JOB_DT = np.dtype([("q0", "<u8"), ("q1", "<u8"), ("k0", "<u8"), ("k1", "<u8"), ("v", "<u8"), ("bits", "<u8"), ("out", "<u8"),
+                                 ("ldq0", "<i4"), ("ldq1", "<i4"), ("ldk0", "<i4"), ("ldk1", "<i4"), ("ldv", "<i4"), ("ldo", "<i4"),
+                                 ("Lq", "<i4"), ("Lk", "<i4")], align=True)
+        assert _ATTN_JOB_DT.itemsize == 88
+    tab = np.zeros(len(jobs), dtype=_ATTN_JOB_DT)
+    nb = 0
+    for i, (q, k, v, bits, q2, k2, out) in enumerate(jobs):
+        pq, ldq = _rows(q, "q")
+        pk, ldk = _rows(k, "k")
+        pv, ldv = _rows(v, "v")
+        pq2 = pk2 = ldq2 = ldk2 = 0
+        if q2 is not None:
+            pq2, ldq2 = _rows(q2, "q2")
+            pk2, ldk2 = _rows(k2, "k2")
+        Lq, Lk = q.shape[0], k.shape[0]
+        if q.shape[1] != num_heads * 32 or v.shape[1] != num_heads * 32:
+            raise ValueError("attention_batch: head slices must be 32 channels wide")
+        if bits is not None and tuple(bits.shape) != (Lq, (Lk + 31) // 32):
+            raise ValueError("attention_batch: mask bits shape mismatch")
+        if tuple(out.shape) != (Lq, num_heads * 32) or not out.is_contiguous() or out.dtype != torch.float32:
+            raise ValueError("attention_batch: `out` must be a contiguous fp32 [Lq, H * 32] tensor")
+        tab[i] = (pq, pq2, pk, pk2, pv, 0 if bits is None else _ptr(bits, torch.int32, "mask_bits"), out.data_ptr(), ldq, ldq2, ldk, ldk2, ldv,
+                  out.stride(0), Lq, Lk)
+        nb += lib.sd3d_attention_ws_bytes(Lq, num_heads)
+    ws = _WS6.get(nb, jobs[0][0].device)
+    _lib.check(lib.sd3d_attention_batch(len(jobs), tab.ctypes.data, num_heads, float(scale), 1 if bf16_decoder_active() else 0,
+                                        ws.data_ptr(), ws.numel(), _stream()), "attention_batch")
+
+
+def mask_bits_batch(logits_list, S_list, thr):
+    """mask_bits for several scenes' logit matrices in one launch -> list of bit tensors."""
+    import ctypes as C
+    lib = _lib.load()
+    n = len(logits_list)
+    out = []
+    P, I, L = (C.c_void_p * n), (C.c_int * n), (C.c_int64 * n)
+    lp, ld, Q, S, bp, nw = P(), I(), L(), I(), P(), I()
+    for i, (lg, s) in enumerate(zip(logits_list, S_list)):
+        lp[i], ld[i] = _rows(lg, "logits")
+        Q[i], S[i] = lg.shape[0], int(s)
+        nw[i] = (int(s) + 31) // 32
+        bits = torch.empty(lg.shape[0], nw[i], dtype=torch.int32, device=lg.device)
+        bp[i] = bits.data_ptr()
+        out.append(bits)
+    _lib.check(lib.sd3d_mask_bits_batch(n, lp, ld, Q, S, bp, nw, float(thr), _stream()), "mask_bits_batch")
+    return out
+
+
+def dinox_mask_bits_batch(blocked_list, near_list):
+    """dinox_mask_bits for several scenes in one launch -> list of bit tensors."""
+    import ctypes as C
+    lib = _lib.load()
+    n = len(blocked_list)
+    P, I, L = (C.c_void_p * n), (C.c_int * n), (C.c_int64 * n)
+    bl, nr, nw, Q, Mq, op, nwo = P(), P(), I(), L(), L(), P(), I()
+    out = []
+    for i, (b, nearb) in enumerate(zip(blocked_list, near_list)):
+        bl[i], nr[i] = _ptr(b, torch.int32, "blocked"), _ptr(nearb, torch.int32, "near")
+        Q[i], nw[i] = b.shape
+        Mq[i] = nearb.shape[0]
+        nwo[i] = (nearb.shape[0] + 1 + 31) // 32
+        o = torch.empty(b.shape[0], nwo[i], dtype=torch.int32, device=b.device)
+        op[i] = o.data_ptr()
+        out.append(o)
+    _lib.check(lib.sd3d_dinox_mask_bits_batch(n, bl, nr, nw, Q, Mq, op, nwo, _stream()), "dinox_mask_bits_batch")
+    return out
+
+
 def mask_bits(logits, S, thr):
     lib = _lib.load()
     pl, ld = _rows(logits, "logits")
