@@ -23,28 +23,29 @@ def table(path):
         if in_pmc and m:
             vals = [v.strip() for v in m.group(3).split("|")]
             rows[m.group(1)] = (int(m.group(2)), float(vals[0]) if vals[0] else 0.0)
-        elif not in_pmc and m and m.group(1).startswith("voxel_mean_kernel"):
-            forwards = int(m.group(2))
+        ms = re.match(r"scenes in the run: (\d+)", line)
+        if ms:
+            forwards = int(ms.group(1))              # SCENES of the run (tools/prof_summary.py), one scene or several per forward
     return rows, forwards
 
 
 def main():
     fetch, nf = table(sys.argv[1])
     write, nw = table(sys.argv[2])
-    assert nf and nf == nw, (nf, nw)
+    assert nf and nw, (nf, nw)                      # scenes of the two passes (the time-based pre-roll may give them different counts)
     conv = lambda n: n.startswith("pair_gemm") or n.startswith("pair_reduce") or n.startswith("pair_center")  # noqa: E731
     fam = lambda n: conv(n) or "gather_gemm" in n  # noqa: E731
     out = {"source": f"{sys.argv[1]} + {sys.argv[2]} (rocprofv3 --kernel-trace --pmc FETCH_SIZE | WRITE_SIZE, separate passes, bench.py --streams 1)",
-           "forwards": nf,
+           "forwards": nf, "forwards_write_pass": nw, "forwards_note": "scenes of the profiled runs (bytes_per_forward = bytes per scene)",
            "fetch_correction": "x2 (MI355X_MICROARCH.md: gfx950 FETCH_SIZE reports half the bytes of 16 B/lane reads)",
            "write_correction": "none (uncalibrated)"}
     for key, sel in (("conv", conv), ("family", fam)):
         f_kb = sum(v[1] for n, v in fetch.items() if sel(n))
         w_kb = sum(v[1] for n, v in write.items() if sel(n))
         out[f"{key}_fetch_kb_sum"], out[f"{key}_write_kb_sum"] = f_kb, w_kb
-        out[f"{key}_bytes_per_forward"] = int((2.0 * f_kb + w_kb) * 1024 / nf)
+        out[f"{key}_bytes_per_forward"] = int((2.0 * f_kb / nf + w_kb / nw) * 1024)
     out["bytes_per_forward"] = out["family_bytes_per_forward"]
-    out["conv_launches_per_forward"] = sum(v[0] for n, v in fetch.items() if n.startswith("pair_gemm")) // nf
+    out["conv_launches_per_forward"] = round(sum(v[0] for n, v in fetch.items() if n.startswith("pair_gemm")) / nf, 2)
     if len(sys.argv) > 4:
         for line in open(sys.argv[4]):
             if line.startswith("{"):

@@ -29,6 +29,9 @@ def main():
               "| kernel | calls | total ms | avg us | % |", "|---|---:|---:|---:|---:|"]
     for name, calls, tot, avg, pct in rows[:45]:
         lines.append(f"| `{name[:90]}` | {calls} | {tot / 1e3:.3f} | {avg:.1f} | {pct:.2f} |")
+    n_stats = cur.execute("select count(*) from kernels where name like 'scene_stats_final%'").fetchone()[0]
+    lines += ["", f"scenes in the run: {n_stats // 2} (scene_stats_final launches / 2: one for the scene range, one for the voxel keys, per scene - "
+                  "whether a forward takes one scene or several)"]
     lines += ["", "## GEMM family by launch shape", "", "| variant | workgroups | launches | avg us | total ms | vgpr | lds |",
               "|---|---:|---:|---:|---:|---:|---:|"]
     q = ("select name, grid_x / workgroup_x, count(*), avg(duration), sum(duration), vgpr_count, lds_size, grid_y from kernels "
