@@ -155,11 +155,11 @@ def end_to_end(model, device, args, n_scenes=32):
         model.to_host = True
         try:
             with torch.no_grad():
-                runner.run(io_scene.ScenePrefetcher(paths, device, depth=2))                      # warm: files in the page cache, pools sized
+                runner.run(io_scene.ScenePrefetcher(paths + paths, device, depth=2), keep=False)  # warm: files in the page cache, pinned pools sized
                 torch.cuda.synchronize()
                 files = [paths[i % 4] for i in range(n_scenes)]
                 t0 = time.perf_counter()
-                runner.run(io_scene.ScenePrefetcher(files, device, depth=4, readers=2), on_result=count)
+                runner.run(io_scene.ScenePrefetcher(files, device, depth=4, readers=2), on_result=count, keep=False)
                 torch.cuda.synchronize()
                 dt = time.perf_counter() - t0
         finally:

@@ -167,6 +167,7 @@ class PipelinedRunner:
         self.switch_interval = float(os.environ.get("SD3D_SWITCH_INTERVAL", "2e-4"))
         # one issuing thread at a time, handed over while a thread waits for the GPU (ops.wait_event)
         self.use_baton = os.environ.get("SD3D_BATON", "1") != "0"
+        self._keep = True
 
     def plan_batches(self, n_scenes: int):
         """Which scenes each stream runs, in which forwards: scene i goes to stream i mod n (every stream gets the same number of
@@ -181,11 +182,13 @@ class PipelinedRunner:
             plan.append([mine[cuts[k]:cuts[k + 1]] for k in range(nb)])
         return plan
 
-    def run(self, scenes, on_result=None):
+    def run(self, scenes, on_result=None, keep=True):
         """scenes: sequence of (points, target) already on the device, or an iterator that yields them lazily
         (e.g. io_scene.ScenePrefetcher: each worker pulls its next scene when it is ready for it).  Returns the list of
-        model outputs in submission order."""
+        model outputs in submission order.  keep=False: an output is dropped as soon as `on_result` has seen it (a long
+        evaluation with host-resident outputs would otherwise pin ~100 MB per scene until the run returns)."""
         from . import ops
+        self._keep = bool(keep)
         if not hasattr(scenes, "__getitem__"):
             with ops.scenes_in_flight(self.n):
                 return self._run_stream(scenes, on_result)
@@ -212,6 +215,9 @@ class PipelinedRunner:
                             results[i] = [out[j]]
                             if on_result is not None:
                                 on_result(i, results[i])
+                            if not self._keep:
+                                results[i] = None
+                        del out
                     ops.wait_event(ops.stream_event())
             except BaseException as e:  # noqa: BLE001 - re-raised in the caller's thread
                 errors.append(e)
@@ -305,6 +311,9 @@ def _pipelined_run_stream(self, it, on_result=None):
                         results[i] = [out[j]]
                         if on_result is not None:
                             on_result(i, results[i])
+                        if not self._keep:
+                            results[i] = None
+                    del out, group
                 ops.wait_event(ops.stream_event())
         except BaseException as e:  # noqa: BLE001 - re-raised in the caller's thread
             errors.append(e)
