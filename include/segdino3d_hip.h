@@ -244,7 +244,8 @@ int sd3d_slab_conv(const float* in0, int ld0, int C0, const float* in1, int ld1,
  * neighbour tables and the activation buffers (one arena, carved by the caller); the call only enqueues.
  *   SD3D_LAYER_PAIR_CONV        out = act(scale * conv(cat[src0, src1]; table) + shift + res)   (sd3d_pair_conv)
  *   SD3D_LAYER_DENSE            the same with identity rows, K = 1                                 (sd3d_gather_gemm)
- *   SD3D_LAYER_SCALE_SHIFT_ACT  out = act(cat[src0, src1] * scale + shift), Cin = total channels  (sd3d_scale_shift_act) */
+ *   SD3D_LAYER_SCALE_SHIFT_ACT  out = act(cat[src0, src1] * scale + shift) + res, Cin = total channels; res (optional) is
+ *                               added AFTER the activation here                                  (sd3d_scale_shift_act_add) */
 enum { SD3D_LAYER_PAIR_CONV = 0, SD3D_LAYER_DENSE = 1, SD3D_LAYER_SCALE_SHIFT_ACT = 2 };
 typedef struct sd3d_layer {
     int32_t kind, table;               /* table: index into tables[] (PAIR_CONV) */
@@ -348,6 +349,11 @@ int sd3d_box_refine(const float* ref_points, const float* d_center, const float*
  * spconv residual blocks (spconvunet.py:48-51, 154-156, 184-187, 227-229).  x1 may be NULL. */
 int sd3d_scale_shift_act(const float* x0, int ld0, int C0, const float* x1, int ld1, const float* scale,
                          const float* shift, int act, int64_t M, int C, float* out, int ld_out, void* stream);
+/* out = act(x * scale + shift) + add : the tail of a normalize_before=False residual block - conv -> BatchNorm1d -> ReLU,
+ * then the identity branch summed in AFTER the activation (spconvunet.py:66-81, 95-97).  add may be NULL. */
+int sd3d_scale_shift_act_add(const float* x0, int ld0, int C0, const float* x1, int ld1, const float* scale,
+                             const float* shift, int act, int64_t M, int C, const float* add, int ld_add, float* out,
+                             int ld_out, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Post-processing (segdino3d/models/architecture/baseline3d.py)

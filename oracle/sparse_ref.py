@@ -327,13 +327,20 @@ class SpLevels:
         return self._same[key]
 
 
-def _sp_resblock(x, sd, p, pairs):
-    """ResidualBlock, normalize_before=True (spconvunet.py:48-64, 82-99)."""
+def _sp_resblock(x, sd, p, pairs, normalize_before=True):
+    """ResidualBlock (spconvunet.py:48-81, 82-99): BN, ReLU, conv, BN, ReLU, conv when normalising before; conv, BN, ReLU,
+    conv, BN, ReLU otherwise - either way `conv_branch(x) + i_branch(x)`, so the second form adds the identity AFTER its ReLU."""
     n = x.shape[0]
     if (p + ".i_branch.0.weight") in sd:
         ident = x @ _spw(sd[p + ".i_branch.0.weight"])[0]
     else:
         ident = x
+    if not normalize_before:
+        h = sparse_conv(x, pairs, _spw(sd[p + ".conv_branch.0.weight"]), n)
+        h = torch.relu(bn_eval(h, sd, p + ".conv_branch.1", SPCONV_EPS))
+        h = sparse_conv(h, pairs, _spw(sd[p + ".conv_branch.3.weight"]), n)
+        h = torch.relu(bn_eval(h, sd, p + ".conv_branch.4", SPCONV_EPS))
+        return h + ident
     h = torch.relu(bn_eval(x, sd, p + ".conv_branch.0", SPCONV_EPS))
     h = sparse_conv(h, pairs, _spw(sd[p + ".conv_branch.2.weight"]), n)
     h = torch.relu(bn_eval(h, sd, p + ".conv_branch.3", SPCONV_EPS))
@@ -341,27 +348,37 @@ def _sp_resblock(x, sd, p, pairs):
     return h + ident
 
 
-def _sp_unet(x, sd, p, lv: SpLevels, level, n_levels, block_reps=2):
-    """SpConvUNet.forward (spconvunet.py:233-268), recursive."""
+def _sp_unet(x, sd, p, lv: SpLevels, level, n_levels, block_reps=2, normalize_before=True):
+    """SpConvUNet.forward (spconvunet.py:233-268), recursive; `conv` / `deconv` are BN, ReLU, conv or conv, BN, ReLU (:154-201)."""
     pairs = lv.same(level)
+    nb = normalize_before
     for r in range(block_reps):
-        x = _sp_resblock(x, sd, f"{p}blocks.block{r}", pairs)
+        x = _sp_resblock(x, sd, f"{p}blocks.block{r}", pairs, nb)
     if level < n_levels - 1:
         ident = x
-        h = torch.relu(bn_eval(x, sd, p + "conv.0", SPCONV_EPS))
         down = lv.pairs_down[level]
-        h = sparse_conv(h, down, _spw(sd[p + "conv.2.weight"]), len(lv.coords[level + 1]))
-        h = _sp_unet(h, sd, p + "u.", lv, level + 1, n_levels, block_reps)
-        h = torch.relu(bn_eval(h, sd, p + "deconv.0", SPCONV_EPS))
-        h = sparse_conv(h, [(o, i) for (i, o) in down], _spw(sd[p + "deconv.2.weight"]), x.shape[0])
+        up = [(o, i) for (i, o) in down]
+        if nb:
+            h = torch.relu(bn_eval(x, sd, p + "conv.0", SPCONV_EPS))
+            h = sparse_conv(h, down, _spw(sd[p + "conv.2.weight"]), len(lv.coords[level + 1]))
+            h = _sp_unet(h, sd, p + "u.", lv, level + 1, n_levels, block_reps, nb)
+            h = torch.relu(bn_eval(h, sd, p + "deconv.0", SPCONV_EPS))
+            h = sparse_conv(h, up, _spw(sd[p + "deconv.2.weight"]), x.shape[0])
+        else:
+            h = sparse_conv(x, down, _spw(sd[p + "conv.0.weight"]), len(lv.coords[level + 1]))
+            h = torch.relu(bn_eval(h, sd, p + "conv.1", SPCONV_EPS))
+            h = _sp_unet(h, sd, p + "u.", lv, level + 1, n_levels, block_reps, nb)
+            h = sparse_conv(h, up, _spw(sd[p + "deconv.0.weight"]), x.shape[0])
+            h = torch.relu(bn_eval(h, sd, p + "deconv.1", SPCONV_EPS))
         x = torch.cat([ident, h], dim=1)
         for r in range(block_reps):
-            x = _sp_resblock(x, sd, f"{p}blocks_tail.block{r}", pairs)
+            x = _sp_resblock(x, sd, f"{p}blocks_tail.block{r}", pairs, nb)
     return x
 
 
-def spconv_state_dict_shapes(num_planes=(32, 64, 96, 128, 160), in_channels=262, block_reps=2):
+def spconv_state_dict_shapes(num_planes=(32, 64, 96, 128, 160), in_channels=262, block_reps=2, normalize_before=True):
     shapes = {}
+    nb = normalize_before
 
     def bn(name, c):
         for leaf, shp in (("weight", (c,)), ("bias", (c,)), ("running_mean", (c,)), ("running_var", (c,)),
@@ -371,20 +388,34 @@ def spconv_state_dict_shapes(num_planes=(32, 64, 96, 128, 160), in_channels=262,
     def resblock(name, cin, cout):
         if cin != cout:
             shapes[name + ".i_branch.0.weight"] = (cout, 1, 1, 1, cin)
-        bn(name + ".conv_branch.0", cin)
-        shapes[name + ".conv_branch.2.weight"] = (cout, 3, 3, 3, cin)
-        bn(name + ".conv_branch.3", cout)
-        shapes[name + ".conv_branch.5.weight"] = (cout, 3, 3, 3, cout)
+        if nb:
+            bn(name + ".conv_branch.0", cin)
+            shapes[name + ".conv_branch.2.weight"] = (cout, 3, 3, 3, cin)
+            bn(name + ".conv_branch.3", cout)
+            shapes[name + ".conv_branch.5.weight"] = (cout, 3, 3, 3, cout)
+        else:
+            shapes[name + ".conv_branch.0.weight"] = (cout, 3, 3, 3, cin)
+            bn(name + ".conv_branch.1", cout)
+            shapes[name + ".conv_branch.3.weight"] = (cout, 3, 3, 3, cout)
+            bn(name + ".conv_branch.4", cout)
 
     def unet(p, planes):
         for r in range(block_reps):
             resblock(f"{p}blocks.block{r}", planes[0], planes[0])
         if len(planes) > 1:
-            bn(p + "conv.0", planes[0])
-            shapes[p + "conv.2.weight"] = (planes[1], 2, 2, 2, planes[0])
+            if nb:
+                bn(p + "conv.0", planes[0])
+                shapes[p + "conv.2.weight"] = (planes[1], 2, 2, 2, planes[0])
+            else:
+                shapes[p + "conv.0.weight"] = (planes[1], 2, 2, 2, planes[0])
+                bn(p + "conv.1", planes[1])
             unet(p + "u.", planes[1:])
-            bn(p + "deconv.0", planes[1])
-            shapes[p + "deconv.2.weight"] = (planes[0], 2, 2, 2, planes[1])
+            if nb:
+                bn(p + "deconv.0", planes[1])
+                shapes[p + "deconv.2.weight"] = (planes[0], 2, 2, 2, planes[1])
+            else:
+                shapes[p + "deconv.0.weight"] = (planes[0], 2, 2, 2, planes[1])
+                bn(p + "deconv.1", planes[0])
             for r in range(block_reps):
                 resblock(f"{p}blocks_tail.block{r}", planes[0] * (2 - r), planes[0])
 
@@ -395,7 +426,7 @@ def spconv_state_dict_shapes(num_planes=(32, 64, 96, 128, 160), in_channels=262,
 
 
 def spconv_forward_wrapper(sd, points, feats2d, superpoints, voxel_size=0.02, num_planes=(32, 64, 96, 128, 160),
-                           prefix="backbone.", min_spatial_shape=128, elastic=None):
+                           prefix="backbone.", min_spatial_shape=128, elastic=None, normalize_before=True):
     """forward_wrapper + collate (spconvunet.py:364-399, 270-362), eval, early_fusion, ONE scene."""
     sd = {k[len(prefix):]: v for k, v in sd.items() if k.startswith(prefix)}
     xyz = points[:, :3]
@@ -409,7 +440,7 @@ def spconv_forward_wrapper(sd, points, feats2d, superpoints, voxel_size=0.02, nu
     vf = segment_mean(f, inv, len(uc))
     lv = SpLevels(uc, len(num_planes), min_spatial_shape)
     x = sparse_conv(vf, lv.same(0), _spw(sd["input_conv.0.weight"]), len(uc))
-    x = _sp_unet(x, sd, "", lv, 0, len(num_planes))
+    x = _sp_unet(x, sd, "", lv, 0, len(num_planes), normalize_before=normalize_before)
     x = torch.relu(bn_eval(x, sd, "output_layer.0", SPCONV_EPS))
     S = int(superpoints.max()) + 1
     sp_feats = segment_mean(x[torch.from_numpy(inv)], superpoints.numpy(), S)

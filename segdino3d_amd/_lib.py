@@ -78,6 +78,7 @@ SIGNATURES = {
     "sd3d_dinox_mask_bits": (_i, [_p, _p, _i, _l, _l, _p, _i, _p]),
     "sd3d_box_refine": (_i, [_p, _p, _p, _i, _p, _p, _i, _l, _p, _p, _p, _p]),
     "sd3d_scale_shift_act": (_i, [_p, _i, _i, _p, _i, _p, _p, _i, _l, _i, _p, _i, _p]),
+    "sd3d_scale_shift_act_add": (_i, [_p, _i, _i, _p, _i, _p, _p, _i, _l, _i, _p, _i, _p, _i, _p]),
     "sd3d_class_scores": (_i, [_p, _i, _l, _i, _p, _p, _p]),
     "sd3d_mask_scores": (_i, [_p, _i, _i, _p, _p, _i, _i, _i, _p, _p, _p, _p]),
     "sd3d_gather_sigmoid": (_i, [_p, _i, _i, _p, _p, _i, _p, _i, _p, _p]),

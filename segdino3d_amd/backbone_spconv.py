@@ -49,10 +49,17 @@ def _bn(c):
 
 
 class ResidualBlock(nn.Module):
-    def __init__(self, cin, cout):
+    """Parameter holder with the reference's Sequential indices (`spconvunet.py:41-81`): normalize_before=True is
+    BN, ReLU, conv, BN, ReLU, conv (BatchNorms at 0 / 3, convolutions at 2 / 5); False is conv, BN, ReLU, conv, BN, ReLU
+    (convolutions at 0 / 3, BatchNorms at 1 / 4)."""
+
+    def __init__(self, cin, cout, normalize_before=True):
         super().__init__()
         self.i_branch = nn.Sequential(nn.Identity() if cin == cout else SpConv(cin, cout, 1))
-        self.conv_branch = nn.Sequential(_bn(cin), nn.ReLU(), SpConv(cin, cout, 3), _bn(cout), nn.ReLU(), SpConv(cout, cout, 3))
+        if normalize_before:
+            self.conv_branch = nn.Sequential(_bn(cin), nn.ReLU(), SpConv(cin, cout, 3), _bn(cout), nn.ReLU(), SpConv(cout, cout, 3))
+        else:
+            self.conv_branch = nn.Sequential(SpConv(cin, cout, 3), _bn(cout), nn.ReLU(), SpConv(cout, cout, 3), _bn(cout), nn.ReLU())
 
 
 def _pack(conv: SpConv) -> torch.Tensor:
@@ -79,19 +86,24 @@ class SpConvUNet(DerivedWeights):
                  return_blocks=False, voxel_size=0.02, mode_fuse_2d_feat="early_fusion", main_model=True,
                  min_spatial_shape=128, add_positional_embedding=False):
         super().__init__()
-        if not normalize_before:
-            raise NotImplementedError("segdino3d_amd SpConvUNet: only the pre-activation (normalize_before=True) variant is built")
+        if block not in (None, "residual") and getattr(block, "__name__", "") != "ResidualBlock":
+            raise NotImplementedError(f"segdino3d_amd SpConvUNet: block {block!r} is not built (the reference ships 'residual' only)")
+        self.normalize_before = bool(normalize_before)
+        nb = self.normalize_before
         self.return_blocks = return_blocks
         self.num_planes = list(num_planes)
         self.block_reps = block_reps
         p = self.num_planes
-        self.blocks = nn.ModuleDict({f"block{i}": ResidualBlock(p[0], p[0]) for i in range(block_reps)})
+        self.blocks = nn.ModuleDict({f"block{i}": ResidualBlock(p[0], p[0], nb) for i in range(block_reps)})
         if len(p) > 1:
-            self.conv = nn.Sequential(_bn(p[0]), nn.ReLU(), SpConv(p[0], p[1], 2))
-            self.u = SpConvUNet(p[1:], block_reps=block_reps, indice_key_id=indice_key_id + 1,
+            # spconvunet.py:154-201: BN, ReLU, conv when normalising before; conv, BN, ReLU otherwise
+            self.conv = (nn.Sequential(_bn(p[0]), nn.ReLU(), SpConv(p[0], p[1], 2)) if nb else
+                         nn.Sequential(SpConv(p[0], p[1], 2), _bn(p[1]), nn.ReLU()))
+            self.u = SpConvUNet(p[1:], block_reps=block_reps, indice_key_id=indice_key_id + 1, normalize_before=nb,
                                 return_blocks=return_blocks, main_model=False)
-            self.deconv = nn.Sequential(_bn(p[1]), nn.ReLU(), SpConv(p[1], p[0], 2))
-            self.blocks_tail = nn.ModuleDict({f"block{i}": ResidualBlock(p[0] * (2 - i), p[0]) for i in range(block_reps)})
+            self.deconv = (nn.Sequential(_bn(p[1]), nn.ReLU(), SpConv(p[1], p[0], 2)) if nb else
+                           nn.Sequential(SpConv(p[1], p[0], 2), _bn(p[0]), nn.ReLU()))
+            self.blocks_tail = nn.ModuleDict({f"block{i}": ResidualBlock(p[0] * (2 - i), p[0], nb) for i in range(block_reps)})
         self.mode_fuse_2d_feat = mode_fuse_2d_feat
         self.voxel_size = voxel_size
         self.min_spatial_shape = min_spatial_shape
@@ -143,6 +155,14 @@ class SpConvUNet(DerivedWeights):
     # ---- network -----------------------------------------------------------------------------------
     def _resblock(self, be, pk, p, x, key, x2=None):
         """ResidualBlock.forward (:82-99): conv_branch(x) + i_branch(x); x may be the concat [x | x2]."""
+        if not self.normalize_before:
+            # conv, BN, ReLU, conv, BN, ReLU (:66-81): the first BN + ReLU rides in its convolution's epilogue; the second
+            # ReLU comes BEFORE the identity add, so that BN + ReLU + add is one elementwise pass over the raw convolution
+            h = be.conv(x, pk[p + ".conv_branch.0"], pk[p + ".conv_branch.1"], key, x2=x2, act="relu")
+            h = be.conv(h, pk[p + ".conv_branch.3"], None, key)
+            ident = be.dense(x, pk[p + ".i_branch.0"], None, x2=x2) if (p + ".i_branch.0") in pk else x
+            assert (p + ".i_branch.0") in pk or x2 is None
+            return be.affine(h, pk[p + ".conv_branch.4"], act="relu", add=ident)
         h = be.affine(x, pk[p + ".conv_branch.0"], x2=x2, act="relu")
         h = be.conv(h, pk[p + ".conv_branch.2"], pk[p + ".conv_branch.3"], key, act="relu")
         if (p + ".i_branch.0") in pk:
@@ -158,11 +178,16 @@ class SpConvUNet(DerivedWeights):
             x = self._resblock(be, pk, f"{prefix}blocks.block{r}", x, key)
         if level < n_levels - 1:
             ident = x
-            h = be.affine(x, pk[prefix + "conv.0"], act="relu")
-            h = be.conv(h, pk[prefix + "conv.2"], None, ("down", level))
-            h = self._unet(be, pk, prefix + "u.", n_levels, level + 1, h)
-            h = be.affine(h, pk[prefix + "deconv.0"], act="relu")
-            h = be.conv(h, pk[prefix + "deconv.2"], None, ("up", level))
+            if self.normalize_before:
+                h = be.affine(x, pk[prefix + "conv.0"], act="relu")
+                h = be.conv(h, pk[prefix + "conv.2"], None, ("down", level))
+                h = self._unet(be, pk, prefix + "u.", n_levels, level + 1, h)
+                h = be.affine(h, pk[prefix + "deconv.0"], act="relu")
+                h = be.conv(h, pk[prefix + "deconv.2"], None, ("up", level))
+            else:                                                # conv, BN, ReLU (:166-174, 194-201): all epilogue
+                h = be.conv(x, pk[prefix + "conv.0"], pk[prefix + "conv.1"], ("down", level), act="relu")
+                h = self._unet(be, pk, prefix + "u.", n_levels, level + 1, h)
+                h = be.conv(h, pk[prefix + "deconv.0"], pk[prefix + "deconv.1"], ("up", level), act="relu")
             x = self._resblock(be, pk, f"{prefix}blocks_tail.block0", ident, key, x2=h)
             for r in range(1, self.block_reps):
                 x = self._resblock(be, pk, f"{prefix}blocks_tail.block{r}", x, key)

@@ -91,7 +91,8 @@ int launch_row_argmax(const float*, int, int64_t, const int32_t*, int, int64_t*,
 int launch_gather_i64(const int64_t*, const int64_t*, int64_t, int, int64_t*, hipStream_t);
 int launch_panoptic(const uint8_t*, int64_t, const int32_t*, const int32_t*, int, int, int, const int64_t*, int32_t*, int32_t*, int64_t*, int64_t*, hipStream_t);
 int launch_instance_boxes(const float*, int, int64_t, const uint8_t*, int64_t, int, int, float*, float*, void*, size_t, hipStream_t);
-int launch_scale_shift_act(const float*, int, int, const float*, int, const float*, const float*, int, int64_t, int, float*, int, hipStream_t);
+int launch_scale_shift_act(const float*, int, int, const float*, int, const float*, const float*, int, int64_t, int, const float*, int, float*, int,
+                           hipStream_t);
 
 #define ST ((hipStream_t)stream)
 
@@ -418,7 +419,11 @@ int sd3d_instance_boxes(const float* points, int ld, int64_t N, const uint8_t* m
 }
 int sd3d_scale_shift_act(const float* x0, int ld0, int C0, const float* x1, int ld1, const float* scale, const float* shift, int act,
                          int64_t M, int C, float* out, int ld_out, void* stream) {
-    return launch_scale_shift_act(x0, ld0, C0, x1, ld1, scale, shift, act, M, C, out, ld_out, ST);
+    return launch_scale_shift_act(x0, ld0, C0, x1, ld1, scale, shift, act, M, C, nullptr, 0, out, ld_out, ST);
+}
+int sd3d_scale_shift_act_add(const float* x0, int ld0, int C0, const float* x1, int ld1, const float* scale, const float* shift, int act,
+                             int64_t M, int C, const float* add, int ld_add, float* out, int ld_out, void* stream) {
+    return launch_scale_shift_act(x0, ld0, C0, x1, ld1, scale, shift, act, M, C, add, ld_add, out, ld_out, ST);
 }
 
 int sd3d_mask_overlaps(const uint8_t* masks, int64_t mask_stride, int n, const int32_t* gt_index, int64_t N, int n_cols,

@@ -835,11 +835,14 @@ int launch_box_refine(const float* ref, const float* dc, const float* sprev, int
 // ---------------------------------------------------------------------------------------------
 // y = act(x * scale + shift) over [M, C] where x may be the concatenation [x0 (C0 ch) | x1 (C - C0 ch)]:
 // the pre-activation BatchNorm + ReLU of the spconv residual blocks (spconvunet.py:48-51, 154-156,
-// 184-187, 227-229).  HBM-bound elementwise pass, float4 per thread.
+// 184-187, 227-229).  With `add` the identity branch is summed in AFTER the activation - the tail of a
+// normalize_before=False block, conv -> BN -> ReLU, then + i_branch (spconvunet.py:66-81, 95-97).
+// HBM-bound elementwise pass, float4 per thread.
 // ---------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void scale_shift_act_kernel(const float* __restrict__ x0, int ld0, int C0,
                                                               const float* __restrict__ x1, int ld1, const float* __restrict__ scale,
                                                               const float* __restrict__ shift, int act, int64_t M, int C,
+                                                              const float* __restrict__ add, int ld_add,
                                                               float* __restrict__ out, int ld_out) {
     const int cv = C >> 2;
     const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
@@ -854,17 +857,18 @@ __global__ __launch_bounds__(256) void scale_shift_act_kernel(const float* __res
         y[e] = v[e] * s[e] + b[e];
         if (act == 1) y[e] = fmaxf(y[e], 0.f);
     }
+    if (add) y += *(const f32x4*)(add + r * ld_add + c);      // AFTER the activation: the post-activation residual blocks
     *(f32x4*)(out + r * ld_out + c) = y;
 }
 
 int launch_scale_shift_act(const float* x0, int ld0, int C0, const float* x1, int ld1, const float* scale, const float* shift,
-                           int act, int64_t M, int C, float* out, int ld_out, hipStream_t st) {
+                           int act, int64_t M, int C, const float* add, int ld_add, float* out, int ld_out, hipStream_t st) {
     if (M <= 0) return SD3D_OK;
-    if ((C & 3) || (C0 & 3) || (ld0 & 3) || (ld_out & 3) || (x1 && (ld1 & 3)))
+    if ((C & 3) || (C0 & 3) || (ld0 & 3) || (ld_out & 3) || (x1 && (ld1 & 3)) || (add && (ld_add & 3)))
         return sd3d_set_error(SD3D_ERR_ARG, "scale_shift_act: channels and strides must be multiples of 4");
     if (!x1) C0 = C;
     hipLaunchKernelGGL(scale_shift_act_kernel, dim3((unsigned)cdiv(M * (C >> 2), 256)), dim3(256), 0, st, x0, ld0, C0, x1, ld1, scale,
-                       shift, act, M, C, out, ld_out);
+                       shift, act, M, C, add, ld_add, out, ld_out);
     SD3D_CHECK_LAUNCH();
     return SD3D_OK;
 }

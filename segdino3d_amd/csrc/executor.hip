@@ -11,8 +11,8 @@ int launch_gather_gemm(const GGParams&, int, void*, size_t, hipStream_t);
 int launch_pair_conv(const float*, int, int, const float*, int, const int32_t*, const int32_t*, int64_t, const int32_t*, const int32_t*, int,
                      int, const int32_t*, const float*, int, int, int, int64_t, const float*, const float*, const float*, int, float*, int,
                      int, float*, size_t, hipStream_t);
-int launch_scale_shift_act(const float*, int, int, const float*, int, const float*, const float*, int, int64_t, int, float*, int,
-                           hipStream_t);
+int launch_scale_shift_act(const float*, int, int, const float*, int, const float*, const float*, int, int64_t, int, const float*, int,
+                           float*, int, hipStream_t);
 
 extern "C" int sd3d_run_layers(const sd3d_layer* layers, int n_layers, const sd3d_table* tables, int n_tables, const sd3d_buf* bufs,
                                int n_bufs, float* part, size_t part_bytes, void* ws, size_t ws_bytes, void* stream) {
@@ -42,8 +42,8 @@ extern "C" int sd3d_run_layers(const sd3d_layer* layers, int n_layers, const sd3
             p.ld_res = r ? r->ld : 0; p.out = o.ptr; p.ld_out = o.ld; p.act = L.act; p.col_groups = 1; p.ksplit = 1; p.ws = nullptr;
             rc = launch_gather_gemm(p, 0, ws, ws_bytes, st);
         } else if (L.kind == SD3D_LAYER_SCALE_SHIFT_ACT) {
-            rc = launch_scale_shift_act(a.ptr, a.ld, L.C0, b ? b->ptr : nullptr, b ? b->ld : 0, L.scale, L.shift, L.act, o.rows, L.Cin, o.ptr,
-                                        o.ld, st);
+            rc = launch_scale_shift_act(a.ptr, a.ld, L.C0, b ? b->ptr : nullptr, b ? b->ld : 0, L.scale, L.shift, L.act, o.rows, L.Cin,
+                                        r ? r->ptr : nullptr, r ? r->ld : 0, o.ptr, o.ld, st);
         } else {
             return sd3d_set_error(SD3D_ERR_ARG, "run_layers: unknown layer kind");
         }

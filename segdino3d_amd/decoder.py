@@ -112,6 +112,10 @@ class _EvalF:
     box_refine = staticmethod(ops.box_refine)
 
     @staticmethod
+    def dropout(x):                                             # nn.Dropout is the identity in evaluation
+        return x
+
+    @staticmethod
     def sine_pe_mod(xyz, rng, dim_t, axis, num, den):
         return ops.sine_pe(xyz, rng, dim_t, axis, mod_num=num, mod_den=den)
 
@@ -139,13 +143,23 @@ class _TrainF:
         return train_dec.layernorm(x, w, b, res=res, act=act, eps=eps)
 
     @staticmethod
-    def linear_ln(x, w, b, ln_w, ln_b, res=None):               # training: two autograd nodes
+    def dropout(x):
+        """nn.Dropout(p) of the reference's layers (`instance_seg_3d_decoder.py:51, 131, 168-170, 499, 515`); the rate of the
+        running forward is thread-local (set by ScanNetQueryDecoder.forward), 0.0 in every shipped config."""
+        p = getattr(_F_TLS, "p", 0.0)
+        return torch.nn.functional.dropout(x, p, training=True) if p > 0.0 else x
+
+    @staticmethod
+    def linear_ln(x, w, b, ln_w, ln_b, res=None):               # training: two autograd nodes, the layer's Dropout between them
         from . import train_dec
-        return train_dec.layernorm(train_dec.linear(x, w, b), ln_w, ln_b, res=res)
+        return train_dec.layernorm(_TrainF.dropout(train_dec.linear(x, w, b)), ln_w, ln_b, res=res)
 
     @staticmethod
     def attention(q, k, v, num_heads, scale, mask_bits=None, q2=None, k2=None):
         from . import train_dec
+        p = getattr(_F_TLS, "p", 0.0)
+        if p > 0.0:                                             # nn.MultiheadAttention(dropout=p): dropout on the probabilities
+            return train_dec.attention_dropout(q, k, v, num_heads, scale, mask_bits=mask_bits, q2=q2, k2=k2, p=p)
         return train_dec.attention(q, k, v, num_heads, scale, mask_bits=mask_bits, q2=q2, k2=k2)
 
     @staticmethod
@@ -243,7 +257,8 @@ class ScanNetQueryDecoder(DerivedWeights):
         if objectness_flag:
             self.out_score = nn.Sequential(nn.Linear(d_model, d_model), nn.ReLU(), nn.Linear(d_model, 1))
         self.pos_type = pos_type
-        # nn.Dropout is the identity in evaluation; the training path has no dropout kernels and refuses p > 0 when it runs
+        # nn.Dropout is the identity in evaluation; training with p > 0 (no shipped config) drops between the autograd nodes with
+        # torch's generator and forms the attention probabilities explicitly (train_dec.attention_dropout)
         self.dropout = float(dropout)
         # "fp32" (default, BASELINE config #2) or "bf16" (config #3: projections and both attention contractions on the bf16
         # MFMA with fp32 accumulation; LayerNorm, softmax, positional encodings, mask logits and thresholds stay fp32).  Not a
@@ -424,20 +439,24 @@ class ScanNetQueryDecoder(DerivedWeights):
         aux = [dict(cls_preds=cls, sem_preds=None, masks=logits, centers=None, sizes=None, scores=score)]
         kv_all = F.linear(inst, pk["ca_kv_all_w"], pk["ca_kv_all_b"])          # [S, 2*L*d]: k_0..k_{L-1} | v_0..v_{L-1}
         scale = (d // H) ** -0.5
+        dropping = self.training and self.dropout > 0.0
         for i in range(L):
             ca, sa, ffn = self.cross_attn_layers[i], self.self_attn_layers[i], self.ffn_layers[i]
             q = F.linear(queries, pk["ca_q_w"][i], pk["ca_q_b"][i])
             a = F.attention(q, kv_all[:, i * d:(i + 1) * d], kv_all[:, (L + i) * d:(L + i + 1) * d], H, scale, mask_bits=bits)
-            if ca.fix:
-                queries = F.layernorm(_lin(a, ca.attn.out_proj), ca.norm.weight, ca.norm.bias, res=queries)
+            if ca.fix:                                          # dropout only on the `fix` path (:80-84)
+                queries = F.layernorm(F.dropout(_lin(a, ca.attn.out_proj)), ca.norm.weight, ca.norm.bias, res=queries)
             else:
                 queries = _lin(a, ca.attn.out_proj, res=queries)
             qkv = F.linear(queries, sa.attn.in_proj_weight, sa.attn.in_proj_bias)      # [Q, 3d]
             a = F.attention(qkv[:, :d], qkv[:, d:2 * d], qkv[:, 2 * d:], H, scale)
-            queries = F.layernorm(_lin(a, sa.attn.out_proj), sa.norm.weight, sa.norm.bias, res=queries)
-            hdn = _lin(queries, ffn.net[0], act=("relu" if self.activation_fn == "relu" else "gelu"))
-            hdn = _lin(hdn, ffn.net[3], res=queries)
-            queries = F.layernorm(hdn, ffn.norm.weight, ffn.norm.bias)
+            queries = F.layernorm(F.dropout(_lin(a, sa.attn.out_proj)), sa.norm.weight, sa.norm.bias, res=queries)
+            hdn = F.dropout(_lin(queries, ffn.net[0], act=("relu" if self.activation_fn == "relu" else "gelu")))
+            if dropping:                                        # net(y) ends in a Dropout, then + y, then the norm (:166-190)
+                queries = F.layernorm(F.dropout(_lin(hdn, ffn.net[3])), ffn.norm.weight, ffn.norm.bias, res=queries)
+            else:
+                hdn = _lin(hdn, ffn.net[3], res=queries)
+                queries = F.layernorm(hdn, ffn.norm.weight, ffn.norm.bias)
             cls, sem, logits, bits, score = self._head(queries, mask_feats, i == L - 1)
             aux.append(dict(cls_preds=cls, sem_preds=sem, masks=logits, centers=None, sizes=None, scores=score))
         final = aux.pop()
@@ -543,7 +562,7 @@ class ScanNetQueryDecoder(DerivedWeights):
                     queries = _lin(a, layer.attn.out_proj, res=queries)
             # ---- FFN (:173-190)
             ffn = self.ffn_layers[i]
-            hdn = _lin(queries, ffn.net[0], act=("relu" if self.activation_fn == "relu" else "gelu"))
+            hdn = F.dropout(_lin(queries, ffn.net[0], act=("relu" if self.activation_fn == "relu" else "gelu")))
             queries = F.linear_ln(hdn, ffn.net[3].weight, ffn.net[3].bias, ffn.norm.weight, ffn.norm.bias, res=queries)
             # ---- iterative box refinement (:735-759): the centre and the size MLP side by side, three launches for six Linears
             if self.add_box_size_pred:
@@ -775,15 +794,15 @@ class ScanNetQueryDecoder(DerivedWeights):
     @ops.bound_stream
     def forward(self, x, sp_pos=None, sp_pos_wo_elastic=None, queries=None, queries_pos=None, dinox_queries=None,
                 dinox_query_pos=None, scene_range=None):
-        if self.training and self.dropout != 0.0:
-            raise NotImplementedError("segdino3d_amd ScanNetQueryDecoder: training with dropout > 0 is not built (the shipped configs use 0.0)")
-        prev = getattr(_F_TLS, "f", _EvalF)
-        _F_TLS.f = _TrainF if (self.training and torch.is_grad_enabled()) else _EvalF
+        prev, prev_p = getattr(_F_TLS, "f", _EvalF), getattr(_F_TLS, "p", 0.0)
+        # train mode drops under no_grad too (nn.Dropout looks at .training only): the autograd nodes run fine without a graph
+        _F_TLS.f = _TrainF if (self.training and (torch.is_grad_enabled() or self.dropout > 0.0)) else _EvalF
+        _F_TLS.p = self.dropout if _F_TLS.f is _TrainF else 0.0
         try:
             with ops.bf16_decoder_scope(self.compute_dtype == "bf16"):      # training: bf16 forward and backward products of the projections
                 return self._forward(x, sp_pos, sp_pos_wo_elastic, queries, queries_pos, dinox_queries, dinox_query_pos, scene_range)
         finally:
-            _F_TLS.f = prev
+            _F_TLS.f, _F_TLS.p = prev, prev_p
 
     def _forward(self, x, sp_pos, sp_pos_wo_elastic, queries, queries_pos, dinox_queries, dinox_query_pos, scene_range):
         finals, auxes = [], []

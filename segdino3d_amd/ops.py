@@ -1240,8 +1240,8 @@ def instance_boxes(points, masks_bool, mode):
     return centers, sizes
 
 
-def scale_shift_act(x, scale, shift, act=None, x2=None):
-    """act(cat[x, x2] * scale + shift) -> new contiguous [M, C] tensor."""
+def scale_shift_act(x, scale, shift, act=None, x2=None, add=None):
+    """act(cat[x, x2] * scale + shift) (+ add, AFTER the activation) -> new contiguous [M, C] tensor."""
     lib = _lib.load()
     p0, ld0 = _rows(x, "x")
     C0 = x.shape[1]
@@ -1249,8 +1249,11 @@ def scale_shift_act(x, scale, shift, act=None, x2=None):
     if x2 is not None:
         p1, ld1 = _rows(x2, "x2")
         C = C0 + x2.shape[1]
+    pa, lda = (None, 0) if add is None else _rows(add, "add")
+    if add is not None and tuple(add.shape) != (x.shape[0], C):
+        raise ValueError(f"scale_shift_act: add must be [{x.shape[0]}, {C}], got {tuple(add.shape)}")
     out = torch.empty(x.shape[0], C, dtype=torch.float32, device=x.device)
-    _lib.check(lib.sd3d_scale_shift_act(p0, ld0, C0, p1, ld1, _ptr(scale, torch.float32, "scale"),
-                                        _ptr(shift, torch.float32, "shift"), ACT[act], x.shape[0], C, _ptr(out), C,
-                                        _stream()), "scale_shift_act")
+    _lib.check(lib.sd3d_scale_shift_act_add(p0, ld0, C0, p1, ld1, _ptr(scale, torch.float32, "scale"),
+                                            _ptr(shift, torch.float32, "shift"), ACT[act], x.shape[0], C, pa, lda, _ptr(out), C,
+                                            _stream()), "scale_shift_act")
     return out

@@ -51,8 +51,8 @@ class EagerBackend:
         s, b = affine if affine is not None else (None, None)
         return ops.gather_gemm(x, wt, x2=x2, scale=s, shift=b, res=res, act=act)
 
-    def affine(self, x, affine, x2=None, act=None):
-        return ops.scale_shift_act(x, affine[0], affine[1], act=act, x2=x2)
+    def affine(self, x, affine, x2=None, act=None, add=None):
+        return ops.scale_shift_act(x, affine[0], affine[1], act=act, x2=x2, add=add)
 
 
 class _Sym:
@@ -109,9 +109,12 @@ class Recorder:
         out = self._new(x.level, wt.shape[1])
         return self._layer(KIND_DENSE, x, x2, res, out, wt, affine, act)
 
-    def affine(self, x, affine, x2=None, act=None):
+    def affine(self, x, affine, x2=None, act=None, add=None):
+        """out = act(cat[x, x2] * scale + shift) + add: for THIS layer kind the `res` slot is summed in after the activation."""
         out = self._new(x.level, x.ch + (x2.ch if x2 is not None else 0))
-        return self._layer(KIND_AFFINE, x, x2, None, out, None, affine, act)
+        if add is not None and (add.level != out.level or add.ch != out.ch):
+            raise ValueError("plan: affine add operand does not match the output rows / channels")
+        return self._layer(KIND_AFFINE, x, x2, add, out, None, affine, act)
 
     def finish(self, output: _Sym) -> "LayerPlan":
         return LayerPlan(self, output)

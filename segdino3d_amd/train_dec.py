@@ -243,6 +243,26 @@ def attention(q, k, v, num_heads, scale, mask_bits=None, q2=None, k2=None):
     return _Attention.apply(q, k, v, num_heads, scale, mask_bits, q2, k2)
 
 
+def attention_dropout(q, k, v, num_heads, scale, mask_bits=None, q2=None, k2=None, p=0.0):
+    """Attention with dropout on the softmax probabilities - what `nn.MultiheadAttention(dropout=p)` does in training
+    (`instance_seg_3d_decoder.py:48-49, 128-129`).  The fused kernel has no random stream, so for p > 0 - no shipped config,
+    `configs/models/base_3d.py:30` is 0.0 - the probabilities are formed explicitly on the device ([H, Lq, Lk] fp32: 19 MB at
+    200 x 3000, 288 MB at 3000 x 3000) and torch's dropout and autograd carry the rest.  Same arguments as `attention`;
+    bit = 1 in mask_bits blocks a key."""
+    Lq, Lk, H = q.shape[0], k.shape[0], num_heads
+    heads = lambda t, L: t.reshape(L, H, -1).transpose(0, 1)  # noqa: E731   [H, L, width / H]
+    s = heads(q, Lq) @ heads(k, Lk).transpose(1, 2)
+    if q2 is not None:
+        s = s + heads(q2, Lq) @ heads(k2, Lk).transpose(1, 2)
+    s = s * scale
+    if mask_bits is not None:
+        cols = torch.arange(Lk, device=q.device)
+        blocked = (mask_bits[:, cols >> 5] >> (cols & 31)) & 1             # [Lq, Lk]
+        s = s.masked_fill(blocked.bool().unsqueeze(0), float("-inf"))
+    prob = torch.nn.functional.dropout(torch.softmax(s, dim=-1), p, training=True)
+    return (prob @ heads(v, Lk)).transpose(0, 1).reshape(Lq, -1)
+
+
 class _BoxRefine(torch.autograd.Function):
     """`ops.box_refine`: (center, size, size_metric); gradients reach d_center and d_size through center / size_metric only
     (the refined points and sizes that feed the next layer are detached in the reference, `:740, :753`)."""

@@ -229,7 +229,9 @@ class TrainBackend:
         y = SparseConv.apply(xin, wt, pairs, pairs, True, None)                 # K = 1: its own mirror
         return batch_norm_act(y, affine, res=res, act=act)
 
-    def affine(self, x, affine, x2=None, act=None):
-        """Pre-activation BatchNorm (+ ReLU) of the spconv residual blocks (`spconv_unet.py:82-99`)."""
+    def affine(self, x, affine, x2=None, act=None, add=None):
+        """Pre-activation BatchNorm (+ ReLU) of the spconv residual blocks (`spconvunet.py:48-64`); `add` = the identity branch
+        of a normalize_before=False block, summed in after the activation (`spconvunet.py:66-81, 95-97`)."""
         act = None if self.IGNORE_ACT else act
-        return batch_norm_act(self._cat(x, x2), affine, act=act)
+        y = batch_norm_act(self._cat(x, x2), affine, act=act)
+        return y if add is None else y + add

@@ -220,6 +220,59 @@ def test_spconvunet_forward_wrapper_matches_oracle():
     assert err <= BACKBONE_REL_TOL * max(scale, 1.0), f"spconv backbone features differ: max abs err {err} (scale {scale})"
 
 
+def test_spconvunet_post_activation_variant_matches_oracle():
+    """normalize_before=False (spconvunet.py:66-81, 166-174, 194-201): convolution -> BatchNorm -> ReLU everywhere, the identity
+    branch of a block added AFTER its last ReLU (sd3d_scale_shift_act_add / the `res` slot of SD3D_LAYER_SCALE_SHIFT_ACT).
+    The reference's state_dict keys for this variant load; the layer plan and the layer-by-layer path agree bit for bit and
+    match the oracle (training mode: tests/test_gpu_train_ops.py)."""
+    from oracle import sparse_ref as R
+    from segdino3d_amd import plan
+    from segdino3d_amd.backbone_spconv import SpConvUNet
+    d = dev()
+    pts, tgt = _scene(n=10000, S=100, idx=16)
+    m = SpConvUNet(num_planes=[32 * (i + 1) for i in range(5)], return_blocks=True, voxel_size=0.02, normalize_before=False,
+                   mode_fuse_2d_feat="early_fusion", add_positional_embedding=True).eval()
+    shapes = R.spconv_state_dict_shapes(normalize_before=False)
+    assert {k: tuple(v.shape) for k, v in m.state_dict().items()} == shapes, "state_dict keys / shapes of the reference module"
+    sd = {k: det_param("backbone." + k, v.shape).to(v.dtype) for k, v in m.state_dict().items()}
+    m.load_state_dict(sd)
+    m.to(d)
+    with torch.no_grad():
+        f, pos, _ = m.forward_wrapper([pts.to(d)], [tgt.to(d)], return_sp_mean_pos=True)
+        old = plan.USE_PLAN
+        plan.USE_PLAN = False
+        try:
+            f_eager, _, _ = m.forward_wrapper([pts.to(d)], [tgt.to(d)], return_sp_mean_pos=True)
+        finally:
+            plan.USE_PLAN = old
+    assert torch.equal(f[0], f_eager[0]), "sd3d_run_layers and the layer-by-layer path run the same kernels"
+    tgt = tgt.to("cpu")
+    rf, rp, _ = R.spconv_forward_wrapper({"backbone." + k: v for k, v in sd.items()}, pts, tgt.extra_features["points_2dfeats"],
+                                         tgt.extra_features["super_point_masks"], normalize_before=False)
+    torch.testing.assert_close(pos[0].cpu(), rp, rtol=5e-5, atol=1e-4)
+    err, scale = (f[0].cpu() - rf).abs().max().item(), rf.abs().max().item()
+    print(f"SpConvUNet (normalize_before=False) superpoint features vs oracle: max abs err {err:.3e} at max |f| {scale:.3f}")
+    assert err <= BACKBONE_REL_TOL * max(scale, 1.0)
+    # the pre-activation network on the same numbers is a different function
+    rf_pre, _, _ = R.spconv_forward_wrapper({"backbone." + k: det_param("backbone." + k, s) for k, s in R.spconv_state_dict_shapes().items()},
+                                            pts, tgt.extra_features["points_2dfeats"], tgt.extra_features["super_point_masks"])
+    assert (rf_pre - rf).abs().max().item() > 100 * err
+
+
+def test_scale_shift_act_add_is_post_activation():
+    from segdino3d_amd import ops
+    d = dev()
+    g = torch.Generator().manual_seed(3)
+    x, x2, add = torch.randn(777, 32, generator=g).to(d), torch.randn(777, 64, generator=g).to(d), torch.randn(777, 96, generator=g).to(d)
+    sc, sh = torch.randn(96, generator=g).to(d), torch.randn(96, generator=g).to(d)
+    y = ops.scale_shift_act(x, sc, sh, act="relu", x2=x2, add=add)
+    ref = torch.relu(torch.cat([x, x2], 1) * sc + sh) + add
+    torch.testing.assert_close(y, ref, rtol=1e-6, atol=1e-6)
+    assert bool((y < 0).any()), "the add comes after the ReLU"
+    with pytest.raises(ValueError):
+        ops.scale_shift_act(x, sc[:32], sh[:32], add=add)
+
+
 # ------------------------------------------------------------------------------------------------
 @pytest.mark.parametrize("terms,tol", [(3, 3e-5), (6, 2e-6)])
 def test_split_bf16_gather_gemm_accuracy(terms, tol):

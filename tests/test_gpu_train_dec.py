@@ -158,6 +158,90 @@ def test_attention_gradients(Lq, Lk, nsrc, masked):
     assert torch.equal(pq2.grad, pq.grad) and torch.equal(pk2.grad, pk.grad)
 
 
+@pytest.mark.parametrize("Lq,Lk,nsrc,masked", [(200, 3000, 2, True), (200, 301, 1, True), (64, 77, 1, False)])
+def test_attention_dropout_path_equals_the_fused_attention_at_rate_zero(Lq, Lk, nsrc, masked):
+    """`train_dec.attention_dropout` (explicit probabilities + torch dropout, the p > 0 training path) at p = 0 against the fused
+    attention node: same mask-bit convention, scaling, two score sources, strided inputs - outputs and gradients within 2e-5."""
+    from segdino3d_amd import train_dec as T
+    d = dev()
+    H = 8
+    pack_q, pack_k, dy = det_randn(f"ta.q{Lq}", (Lq, 512)), det_randn(f"ta.k{Lk}", (Lk, 768)), det_randn(f"ta.dy{Lq}", (Lq, 256)).to(d)
+    bits = None
+    if masked:
+        blocked = det_randn(f"ta.m{Lq}{Lk}", (Lq, Lk)) > 0.3
+        blocked[torch.arange(Lq), torch.arange(Lq) % Lk] = False
+        nw = (Lk + 31) // 32
+        pad = torch.ones(Lq, nw * 32, dtype=torch.bool); pad[:, :Lk] = blocked
+        words = (pad.view(Lq, nw, 32).long() << torch.arange(32)).sum(-1)
+        bits = torch.where(words >= 2 ** 31, words - 2 ** 32, words).to(torch.int32).to(d)
+    scale = (32 * nsrc) ** -0.5
+    res = []
+    for fn in (T.attention, lambda *a, **k: T.attention_dropout(*a, p=0.0, **k)):
+        pq, pk = pack_q.to(d).requires_grad_(True), pack_k.to(d).requires_grad_(True)
+        out = fn(pq[:, :256], pk[:, :256], pk[:, 512:], H, scale, mask_bits=bits, q2=pq[:, 256:] if nsrc == 2 else None,
+                 k2=pk[:, 256:512] if nsrc == 2 else None)
+        out.backward(dy)
+        res.append((out.detach(), pq.grad, pk.grad))
+    for a, b, name in zip(res[0], res[1], ("out", "dq", "dk / dv")):
+        close(b, a.double(), name, 2e-5)
+
+
+def test_decoder_trains_with_dropout():
+    """dropout > 0 in training (no shipped config: configs/models/base_3d.py:30 is 0.0): nn.Dropout after every attention /
+    FFN projection and on the attention probabilities (instance_seg_3d_decoder.py:48-51, 128-131, 166-170, 499, 515, 690, 708).
+    The random stream is torch's on the device, so the check is behavioural: same seed -> same bits, other seed -> other
+    outputs, finite gradients for every parameter, mean over seeds close to the rate-0 forward, evaluation untouched."""
+    from test_gpu_decoder import _build_decoder
+    from test_oracle_golden import load
+    d = dev()
+    g = load("decoder_s96_q16")
+    dec0, _ = _build_decoder()
+    dec, _ = _build_decoder(dict(dropout=0.1))
+    dec.load_state_dict(dec0.state_dict())
+    dec0.to(d).train(); dec.to(d).train()
+    ids = g["query_ids"].long()
+    t = lambda a: a.to(d)
+    x, q = t(g["x"].detach()), t(g["x"].detach()[ids])
+
+    def run(m, seed, grad=False):
+        torch.manual_seed(seed)
+        xx, qq = x.clone().requires_grad_(grad), q.clone().requires_grad_(grad)
+        out = m([xx], [t(g["pos"])], [t(g["pos_wo"])], [qq], [t(g["pos"][ids])], [t(g["q2d_feat"])], [t(g["q2d_pos"])], [(t(g["lo"]), t(g["hi"]))])
+        return out, xx
+    base, _ = run(dec0, 0)
+    a, xa = run(dec, 1, grad=True)
+    b, _ = run(dec, 1)
+    c, _ = run(dec, 2)
+    assert torch.equal(a["cls_preds"][0], b["cls_preds"][0]) and torch.equal(a["masks"][0], b["masks"][0])
+    assert not torch.equal(a["cls_preds"][0], c["cls_preds"][0])
+    assert not torch.allclose(a["cls_preds"][0], base["cls_preds"][0], atol=1e-4), "dropout must change the training forward"
+    from decoder_grad_case import objective
+    pick = lambda o: {k: (None if o.get(k) is None or o[k][0] is None else o[k][0]) for k in ("cls_preds", "masks", "centers", "sizes", "sem_preds")}
+
+    def grads(m, out):
+        objective([pick(z) for z in out["aux_outputs"]] + [pick(out)]).backward()
+        return {n: p.grad for n, p in m.named_parameters()}
+    ga = grads(dec, a)
+    g0 = grads(dec0, run(dec0, 0, grad=True)[0])
+    assert xa.grad is not None and torch.isfinite(xa.grad).all()
+    assert {n for n, v in ga.items() if v is None} == {n for n, v in g0.items() if v is None}, "the same parameters take part"
+    assert all(torch.isfinite(v).all() for v in ga.values() if v is not None)
+    assert sum(v is not None for v in ga.values()) > 150
+    # under no_grad the module still drops (nn.Dropout looks at .training only)
+    with torch.no_grad():
+        e, _ = run(dec, 1)
+    assert torch.equal(e["cls_preds"][0], a["cls_preds"][0].detach())
+    # inverted dropout is unbiased: the first layer's class logits averaged over seeds approach the rate-0 ones
+    first = torch.stack([run(dec, 100 + s)[0]["aux_outputs"][1]["cls_preds"][0].detach() for s in range(48)]).mean(0)
+    ref = base["aux_outputs"][1]["cls_preds"][0].detach()
+    one = run(dec, 100)[0]["aux_outputs"][1]["cls_preds"][0].detach()
+    assert (first - ref).abs().mean().item() < 0.5 * (one - ref).abs().mean().item()
+    # evaluation: dropout is the identity
+    dec.eval(); dec0.eval()
+    with torch.no_grad():
+        assert torch.equal(run(dec, 5)[0]["masks"][0], run(dec0, 6)[0]["masks"][0])
+
+
 def test_decoder_training_gradients_match_reference():
     """The whole query decoder in training mode on the device (autograd nodes over HIP kernels) against the gradients of the
     REFERENCE decoder itself (tests/golden/decoder_grad_s96_q16.npz: reference autograd, train mode, same weights / inputs):

@@ -216,8 +216,10 @@ def test_res16unet34c_training_step_matches_float64_oracle():
     assert med(0) <= max(4.0 * med(1), 1e-3), f"median gradient error {med(0)} vs float32 oracle {med(1)}"
 
 
-def test_spconvunet_backward_without_relu_matches_float64_oracle():
-    """SpConvUNet (ScanNetv2 prototype) in training mode, ReLUs dropped on both sides: pre-activation BatchNorms,
+@pytest.mark.parametrize("normalize_before", [True, False])
+def test_spconvunet_backward_without_relu_matches_float64_oracle(normalize_before):
+    """SpConvUNet (ScanNetv2 prototype) in training mode, ReLUs dropped on both sides: pre-activation BatchNorms
+    (or, normalize_before=False, BatchNorm after each convolution and the identity added after the block - spconvunet.py:66-81),
     1x1 identity branches, stride-2 / transposed convolutions, skip concatenations - gradients of every parameter
     against the float64 oracle (relative L2 <= 2e-4)."""
     import os, sys
@@ -230,7 +232,7 @@ def test_spconvunet_backward_without_relu_matches_float64_oracle():
     d = dev()
     pts, tgt = make_scene(15, n_points=10000, n_superpoints=100, n_query2d=20)
     m = SpConvUNet(num_planes=[32 * (i + 1) for i in range(5)], return_blocks=True, voxel_size=0.02,
-                   mode_fuse_2d_feat="early_fusion", add_positional_embedding=True)
+                   mode_fuse_2d_feat="early_fusion", add_positional_embedding=True, normalize_before=normalize_before)
     sd = {k: det_param("backbone." + k, v.shape).to(v.dtype) for k, v in m.state_dict().items()}
     m.load_state_dict(sd)
     m.to(d).train()
@@ -250,7 +252,7 @@ def test_spconvunet_backward_without_relu_matches_float64_oracle():
     R.floor_voxel = lambda xyz, vs: floor_voxel(xyz.float(), vs)              # voxelise exactly as the fp32 pipeline does
     try:
         rf, _, _ = R.spconv_forward_wrapper(rsd, pts.double(), tgt.extra_features["points_2dfeats"].double(),
-                                            tgt.extra_features["super_point_masks"])
+                                            tgt.extra_features["super_point_masks"], normalize_before=normalize_before)
         (rf * R_w.double()).sum().backward()
     finally:
         R.BN_TRAIN = False

@@ -111,3 +111,22 @@ def test_spconvunet_runs():
     f, pos, _ = R.spconv_forward_wrapper(sd, pts, tgt.extra_features["points_2dfeats"],
                                          tgt.extra_features["super_point_masks"])
     assert f.shape == (40, 32) and torch.isfinite(f).all() and pos.shape == (40, 3)
+
+
+def test_spconvunet_post_activation_variant():
+    """normalize_before=False (spconvunet.py:66-81, 166-174, 194-201): convolution first, BatchNorm + ReLU after it, the identity
+    branch added after the block's last ReLU.  Same 49 convolutions; with every BatchNorm an identity and the second convolution
+    of every block zeroed, a block reduces to `relu(0) + x = x` - the skip path alone - which pins the order of ReLU and add."""
+    from segdino3d_amd.synth import make_scene
+    pts, tgt = make_scene(4, n_points=3000, n_superpoints=40, n_query2d=5)
+    shapes = R.spconv_state_dict_shapes(normalize_before=False)
+    assert sum(1 for s in shapes.values() if len(s) == 5) == 49
+    assert "blocks.block0.conv_branch.0.weight" in shapes and "blocks.block0.conv_branch.1.running_var" in shapes
+    assert "conv.0.weight" in shapes and "conv.1.weight" in shapes and "deconv.1.bias" in shapes and "conv.2.weight" not in shapes
+    assert shapes["u.deconv.1.weight"] == (64,) and shapes["conv.1.weight"] == (64,)       # BN after the (de)convolution: its OUTPUT width
+    sd = _sd(shapes, "backbone.")
+    ef = tgt.extra_features
+    f, pos, _ = R.spconv_forward_wrapper(sd, pts, ef["points_2dfeats"], ef["super_point_masks"], normalize_before=False)
+    g, _, _ = R.spconv_forward_wrapper(_sd(R.spconv_state_dict_shapes(), "backbone."), pts, ef["points_2dfeats"], ef["super_point_masks"])
+    assert f.shape == (40, 32) and torch.isfinite(f).all() and not torch.allclose(f, g)
+    assert (f >= 0).all()                    # output_layer ends in a ReLU either way
