@@ -450,9 +450,12 @@ int sd3d_semantic_loss(const float* sem, int ld, int Q, int n_rows, int n_logits
  * with in_idx / tile_k from sd3d_pair_lists and out_idx from sd3d_pair_out_rows (out_idx[pos[k][r]] = r, -1 on
  * padding).  dw is [K, Cout, Cin] like the forward weights; exact fp32 MFMA, fixed summation order.
  * flags: bit 0 = accumulate into dw, bit 1 = round both operands to bf16 (nearest even) before multiplying - the numbers
- * of a bf16-operand product with fp32 accumulation, for the bf16 training mode of the decoder. */
+ * of a bf16-operand product with fp32 accumulation, for the bf16 training mode of the decoder; bit 2 (K = 1: a Linear) =
+ * dw has Cout more floats after the [Cout, Cin] block and receives the bias gradient there (column sums of dy over the
+ * listed rows), formed from the dy rows the kernel has staged anyway. */
 #define SD3D_WGRAD_ACCUMULATE 1
 #define SD3D_WGRAD_BF16_OPERANDS 2
+#define SD3D_WGRAD_BIAS 4
 int sd3d_pair_out_rows(const int32_t* pos, int K, int64_t M, int64_t p_cap, int32_t* out_idx, void* stream);
 size_t sd3d_pair_wgrad_ws_bytes(int K, int Cin, int Cout);
 int sd3d_pair_wgrad(const float* dy, int ld_dy, const float* x, int ld_x, const int32_t* in_idx, const int32_t* out_idx,

@@ -24,6 +24,7 @@ struct WGParams {
     int Cin, Cout;
     float* wpart; int32_t* slot_k; int n_slots;
     int bf16;                        // round the staged operands to bf16 (nearest even): bf16-operand numerics on the fp32 matrix pipe
+    int bias;                        // 1 (K = 1 only): a slot is Cout*Cin + Cout floats, the tail = column sums of dY over the slot's pairs
 };
 
 __device__ __forceinline__ float round_to_bf16(float v) {
@@ -75,6 +76,11 @@ __global__ __launch_bounds__(NW * 64) void pair_wgrad_kernel(const WGParams p) {
     for (int i = 0; i < TPW; ++i)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+    // bias gradient of a Linear (K = 1): the column sums of dY ride along - the dY rows are in LDS anyway; thread c of the
+    // first input-channel block adds column c of every staged step in row order (fixed order: bit-reproducible)
+    const bool do_bias = p.bias && blockIdx.z == 0 && tid < TCO;
+    const int64_t slab = (int64_t)p.Cout * p.Cin + (p.bias ? p.Cout : 0);
+    float bsum = 0.f;
 
     // float4 piece f of a step: pair row f / (T/4), column piece f % (T/4)
     f32x4 ra[NA], rb[NB];
@@ -126,7 +132,7 @@ __global__ __launch_bounds__(NW * 64) void pair_wgrad_kernel(const WGParams p) {
         }
     };
     auto flush = [&](int k) {
-        float* dst = p.wpart + (int64_t)slot * p.Cout * p.Cin;
+        float* dst = p.wpart + (int64_t)slot * slab;
 #pragma unroll
         for (int i = 0; i < TPW; ++i) {
             const int t = wv + NW * i;
@@ -141,6 +147,10 @@ __global__ __launch_bounds__(NW * 64) void pair_wgrad_kernel(const WGParams p) {
                     }
                 }
             }
+        }
+        if (do_bias) {
+            if (co0 + tid < p.Cout) dst[(int64_t)p.Cout * p.Cin + co0 + tid] = bsum;
+            bsum = 0.f;
         }
         if (tid == 0 && blockIdx.y == 0 && blockIdx.z == 0) p.slot_k[slot] = k;
         ++slot;
@@ -183,6 +193,10 @@ __global__ __launch_bounds__(NW * 64) void pair_wgrad_kernel(const WGParams p) {
                 }
 #pragma unroll
                 for (int i = 0; i < TPW; ++i) acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i], bv[i], acc[i], 0, 0, 0);
+            }
+            if (do_bias) {
+#pragma unroll 16
+                for (int r = 0; r < WG_STEP; ++r) bsum += As[r * LDA + tid];
             }
         }
     }
@@ -240,7 +254,7 @@ int sd3d_pair_out_rows(const int32_t* pos, int K, int64_t M, int64_t p_cap, int3
 
 size_t sd3d_pair_wgrad_ws_bytes(int K, int Cin, int Cout) {
     const size_t slots = (size_t)wgrad_ranges(K, Cin, Cout, (int64_t)1 << 40) + K;          // the most any p_cap can ask for
-    return align_up(slots * sizeof(int32_t), 256) + slots * (size_t)Cin * Cout * sizeof(float);
+    return align_up(slots * sizeof(int32_t), 256) + slots * ((size_t)Cin * Cout + Cout) * sizeof(float);   // + Cout: SD3D_WGRAD_BIAS
 }
 
 int sd3d_pair_wgrad(const float* dy, int ld_dy, const float* x, int ld_x, const int32_t* in_idx, const int32_t* out_idx,
@@ -256,6 +270,8 @@ int sd3d_pair_wgrad(const float* dy, int ld_dy, const float* x, int ld_x, const 
     p.n_tiles = (int)(p_cap / PT); p.Cin = Cin; p.Cout = Cout;
     p.n_slots = ranges + K;
     p.bf16 = (flags & SD3D_WGRAD_BF16_OPERANDS) ? 1 : 0;
+    p.bias = (flags & SD3D_WGRAD_BIAS) ? 1 : 0;
+    if (p.bias && K != 1) return sd3d_set_error(SD3D_ERR_ARG, "pair_wgrad: SD3D_WGRAD_BIAS is for K = 1 (a Linear's identity pair list)");
     const int accumulate = flags & SD3D_WGRAD_ACCUMULATE;
     p.slot_k = (int32_t*)ws;
     p.wpart = (float*)((char*)ws + align_up((size_t)p.n_slots * sizeof(int32_t), 256));
@@ -282,7 +298,7 @@ int sd3d_pair_wgrad(const float* dy, int ld_dy, const float* x, int ld_x, const 
     WG_CASE(4, 1) WG_CASE(4, 2) WG_CASE(4, 3) WG_CASE(4, 4)
 #undef WG_CASE
 #undef WG_LAUNCH
-    const int64_t elems = (int64_t)Cin * Cout;
+    const int64_t elems = (int64_t)Cin * Cout + (p.bias ? Cout : 0);
     int64_t gx = cdiv(elems, 256);                           // ~2048 workgroups over all offsets: a K = 1 Linear gets as many as a 27-offset convolution
     const int64_t cap = 2048 / K > 64 ? 2048 / K : 64;
     gx = gx < cap ? gx : cap;

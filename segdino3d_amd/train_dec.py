@@ -51,6 +51,8 @@ def _round(n, m):
 def act_backward(dy, ref, act, c_pad):
     lib = _lib.load()
     M, C = dy.shape
+    if act is None and c_pad == C and dy.is_contiguous():        # nothing to apply, nothing to pad: g IS dy
+        return dy
     g = torch.empty(M, c_pad, dtype=torch.float32, device=dy.device)
     pd, ldd = ops._rows(dy, "dy")
     pr, ldr = (None, 0) if ref is None else ops._rows(ref, "ref")
@@ -118,9 +120,16 @@ class _Linear(torch.autograd.Function):
                 xin = torch.nn.functional.pad(xin, (0, 4 - xin.shape[1] % 4))
             # bf16 mode: the same kernel with both operands rounded to bf16 as they are staged (products of bf16 values are exact in
             # fp32, so this IS the bf16-operand / fp32-accumulate product, at the fp32 kernel's speed)
-            dwp = train_ops.pair_wgrad(g, xin.contiguous(), _identity_pairs(g.shape[0], g.device), bf16_operands=ctx.bf16_bwd)   # [1, c_pad, cin(+pad)]
+            # the bias gradient (column sums of g) comes out of the same launch; in the bf16 mode the kernel stages ROUNDED
+            # operands, so there the sums keep their own fp32 pass
+            want_b = ctx.has_b and ctx.needs_input_grad[2]
+            fuse_b = want_b and not ctx.bf16_bwd
+            dwp = train_ops.pair_wgrad(g, xin.contiguous(), _identity_pairs(g.shape[0], g.device), bf16_operands=ctx.bf16_bwd, bias=fuse_b)   # [1, c_pad, cin(+pad)]
+            if fuse_b:
+                dwp, dbp = dwp
+                db = dbp[:cout]
             dw = dwp[0, :cout, :cin]
-        if ctx.has_b and ctx.needs_input_grad[2]:
+        if db is None and ctx.has_b and ctx.needs_input_grad[2]:
             db = col_sums(g)[:cout]
         if ctx.has_res and ctx.needs_input_grad[4]:
             dres = g[:, :cout]

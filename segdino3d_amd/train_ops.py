@@ -34,25 +34,33 @@ def pair_out_rows(pairs: "ops.PairLists") -> torch.Tensor:
 
 
 def pair_wgrad(dy: torch.Tensor, x: torch.Tensor, pairs: "ops.PairLists", dw: torch.Tensor = None, accumulate: bool = False,
-               bf16_operands: bool = False) -> torch.Tensor:
+               bf16_operands: bool = False, bias: bool = False):
     """dw[k] (+)= dy[out rows of offset k]^T @ x[in rows of offset k]; dy [M, Cout], x [V_in, Cin] -> dw [K, Cout, Cin].
-    bf16_operands: both operands rounded to bf16 before the (fp32-accumulated) product."""
+    bf16_operands: both operands rounded to bf16 before the (fp32-accumulated) product.
+    bias (K = 1, a Linear): returns (dw, db) with db [Cout] = column sums of dy, out of the same launch (SD3D_WGRAD_BIAS)."""
     lib = _lib.load()
     pdy, ldy = ops._rows(dy, "dy")
     px, ldx = ops._rows(x, "x")
     Cout, Cin, K = dy.shape[1], x.shape[1], pairs.K
     if dy.shape[0] != pairs.M:
         raise ValueError(f"dy has {dy.shape[0]} rows, the rulebook {pairs.M} outputs")
-    if dw is None:
+    if bias:
+        if K != 1 or dw is not None:
+            raise ValueError("pair_wgrad: bias=True is for K = 1 and a fresh output")
+        flat = torch.empty(Cout * Cin + Cout, dtype=torch.float32, device=dy.device)
+        dw, accumulate = flat, False
+    elif dw is None:
         dw = torch.empty(K, Cout, Cin, dtype=torch.float32, device=dy.device)
         accumulate = False
     elif dw.shape != (K, Cout, Cin) or not dw.is_contiguous():
         raise ValueError("dw must be a contiguous [K, Cout, Cin] tensor")
     nb = lib.sd3d_pair_wgrad_ws_bytes(K, Cin, Cout)
     ws = _WS.get(nb, dy.device)
+    flags = (1 if accumulate else 0) | (2 if bf16_operands else 0) | (4 if bias else 0)
     _lib.check(lib.sd3d_pair_wgrad(pdy, ldy, px, ldx, pairs.in_idx.data_ptr(), pair_out_rows(pairs).data_ptr(), pairs.tile_k.data_ptr(),
-                                   pairs.p_cap, K, Cin, Cout, dw.data_ptr(), (1 if accumulate else 0) | (2 if bf16_operands else 0), ws.data_ptr(), ws.numel(),
-                                   ops._stream()), "pair_wgrad")
+                                   pairs.p_cap, K, Cin, Cout, dw.data_ptr(), flags, ws.data_ptr(), ws.numel(), ops._stream()), "pair_wgrad")
+    if bias:
+        return dw[:Cout * Cin].view(1, Cout, Cin), dw[Cout * Cin:]
     return dw
 
 

@@ -258,7 +258,16 @@ def test_spconvunet_backward_without_relu_matches_float64_oracle(normalize_befor
         R.BN_TRAIN = False
         torch.relu, R.floor_voxel = relu, floor_voxel
     assert (f[0].detach().cpu().double() - rf.detach()).abs().max().item() <= 2e-4 * max(rf.abs().max().item(), 1.0)
-    worst = sorted(((_rel(p.grad.cpu(), rsd["backbone." + n].grad), n) for n, p in m.named_parameters()), reverse=True)
+    grads = {n: (p.grad.cpu(), rsd["backbone." + n].grad) for n, p in m.named_parameters()}
+    # normalize_before=False with the ReLUs dropped: the last block's BatchNorm bias is a per-channel constant in front of
+    # output_layer's batch-statistics BatchNorm - its gradient is zero in exact arithmetic (1e-20 in float64, rounding noise in
+    # fp32), so it is held to an absolute bound relative to the other bias gradients instead of a relative one
+    scale = max(g64.norm().item() for n, (_, g64) in grads.items() if n.endswith(".bias"))
+    null = [n for n, (_, g64) in grads.items() if g64.norm().item() < 1e-9 * scale]
+    assert null == ([] if normalize_before else ["blocks_tail.block1.conv_branch.4.bias"]), null
+    for n in null:
+        assert grads[n][0].norm().item() < 1e-5 * scale, (n, grads[n][0].norm().item(), scale)
+    worst = sorted(((_rel(g, g64), n) for n, (g, g64) in grads.items() if n not in null), reverse=True)
     assert worst[0][0] <= 2e-4, f"parameter gradients differ: {worst[:5]}"
 
 
