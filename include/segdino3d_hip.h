@@ -474,6 +474,12 @@ int sd3d_pair_wgrad(const float* dy, int ld_dy, const float* x, int ld_x, const 
 size_t sd3d_bn_ws_bytes(int64_t M, int C);
 int sd3d_bn_stats(const float* x, int ld, int64_t M, int C, float eps, float* mean, float* var, float* rstd, void* ws, size_t ws_bytes,
                   void* stream);
+/* sd3d_bn_stats that also advances nn.BatchNorm1d's buffers in place (any of the three may be NULL):
+ * running_mean = (1 - momentum) running_mean + momentum mean, running_var likewise with the UNBIASED batch variance
+ * (var * M / (M - 1)), num_batches_tracked += 1 (torch/nn/modules/batchnorm.py semantics behind minkunet.py:302-304). */
+int sd3d_bn_stats_running(const float* x, int ld, int64_t M, int C, float eps, float* mean, float* var, float* rstd,
+                          float* running_mean, float* running_var, int64_t* num_batches_tracked, float momentum, void* ws,
+                          size_t ws_bytes, void* stream);
 int sd3d_bn_apply(const float* x, int ld_x, const float* mean, const float* rstd, const float* gamma, const float* beta, const float* res,
                   int ld_res, int64_t M, int C, int act, float* y, int ld_y, void* stream);
 int sd3d_bn_backward(const float* dy, int ld_dy, const float* y, int ld_y, const float* x, int ld_x, const float* mean, const float* rstd,

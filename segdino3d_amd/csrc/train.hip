@@ -66,7 +66,9 @@ __global__ __launch_bounds__(256) void col_partial_kernel(const ColParams p) {
 template <int MODE>
 __global__ __launch_bounds__(256) void col_final_kernel(const float* __restrict__ partial, int nblk, int C, int64_t M, float eps,
                                                         const float* __restrict__ x_first, float* __restrict__ o0, float* __restrict__ o1,
-                                                        float* __restrict__ o2) {
+                                                        float* __restrict__ o2, float* __restrict__ run_mean = nullptr,
+                                                        float* __restrict__ run_var = nullptr, long long* __restrict__ n_tracked = nullptr,
+                                                        float momentum = 0.f) {
     __shared__ double sa[16][16], sb[16][16];
     const int cl = threadIdx.x & 15, part = threadIdx.x >> 4;
     const int c = blockIdx.x * 16 + cl;
@@ -83,6 +85,11 @@ __global__ __launch_bounds__(256) void col_final_kernel(const float* __restrict_
         o0[c] = (float)((double)x_first[c] + m1);
         o1[c] = (float)(var > 0.0 ? var : 0.0);
         o2[c] = (float)(1.0 / sqrt((var > 0.0 ? var : 0.0) + (double)eps));
+        // nn.BatchNorm1d's running statistics (momentum form, unbiased variance), in the launch that makes the batch statistics:
+        // six elementwise launches per BatchNorm otherwise
+        if (run_mean) run_mean[c] = __builtin_fmaf(momentum, o0[c], run_mean[c] * (1.f - momentum));
+        if (run_var) run_var[c] = __builtin_fmaf(momentum, o1[c] * ((float)M / (float)(M > 1 ? M - 1 : 1)), run_var[c] * (1.f - momentum));
+        if (n_tracked && c == 0) *n_tracked += 1;
     } else {
         o0[c] = (float)a;                                      // dbeta
         o1[c] = (float)b;                                      // dgamma
@@ -161,16 +168,22 @@ extern "C" {
 
 size_t sd3d_bn_ws_bytes(int64_t M, int C) { return align_up((size_t)col_blocks(M) * 2 * C * sizeof(float), 256); }
 
-int sd3d_bn_stats(const float* x, int ld, int64_t M, int C, float eps, float* mean, float* var, float* rstd, void* ws, size_t ws_bytes,
-                  void* stream) {
+int sd3d_bn_stats_running(const float* x, int ld, int64_t M, int C, float eps, float* mean, float* var, float* rstd, float* running_mean,
+                          float* running_var, int64_t* num_batches_tracked, float momentum, void* ws, size_t ws_bytes, void* stream) {
     if (M <= 0 || C <= 0 || (C & 3) || C > 1024 || (ld & 3)) return sd3d_set_error(SD3D_ERR_ARG, "bn_stats: C must be a multiple of 4, <= 1024");
     if (ws_bytes < sd3d_bn_ws_bytes(M, C)) return sd3d_set_error(SD3D_ERR_WS, "bn_stats: workspace too small");
     ColParams p{}; p.a = x; p.ld_a = ld; p.M = M; p.C = C; p.partial = (float*)ws;
     const int nblk = col_blocks(M), rpi = 256 / (C >> 2);
     col_partial_kernel<0><<<nblk, 256, (size_t)rpi * 2 * C * sizeof(float), ST>>>(p);
-    col_final_kernel<0><<<(unsigned)cdiv(C, 16), 256, 0, ST>>>(p.partial, nblk, C, M, eps, x, mean, var, rstd);
+    col_final_kernel<0><<<(unsigned)cdiv(C, 16), 256, 0, ST>>>(p.partial, nblk, C, M, eps, x, mean, var, rstd, running_mean, running_var,
+                                                               (long long*)num_batches_tracked, momentum);
     SD3D_CHECK_LAUNCH();
     return SD3D_OK;
+}
+
+int sd3d_bn_stats(const float* x, int ld, int64_t M, int C, float eps, float* mean, float* var, float* rstd, void* ws, size_t ws_bytes,
+                  void* stream) {
+    return sd3d_bn_stats_running(x, ld, M, C, eps, mean, var, rstd, nullptr, nullptr, nullptr, 0.f, ws, ws_bytes, stream);
 }
 
 int sd3d_bn_apply(const float* x, int ld_x, const float* mean, const float* rstd, const float* gamma, const float* beta, const float* res,

@@ -116,6 +116,10 @@ class _EvalF:
         return x
 
     @staticmethod
+    def split_cols(t, width):                                   # equal column blocks of a packed projection's output (views)
+        return [t[:, c:c + width] for c in range(0, t.shape[1], width)]
+
+    @staticmethod
     def sine_pe_mod(xyz, rng, dim_t, axis, num, den):
         return ops.sine_pe(xyz, rng, dim_t, axis, mod_num=num, mod_den=den)
 
@@ -141,6 +145,11 @@ class _TrainF:
     def layernorm(x, w, b, res=None, act=None, eps=1e-5):
         from . import train_dec
         return train_dec.layernorm(x, w, b, res=res, act=act, eps=eps)
+
+    @staticmethod
+    def split_cols(t, width):
+        from . import train_dec
+        return train_dec.split_cols(t, width)
 
     @staticmethod
     def dropout(x):
@@ -437,19 +446,19 @@ class ScanNetQueryDecoder(DerivedWeights):
             queries = torch.cat([self.query.weight if self.training else self.query.weight.detach(), queries]).contiguous()
         cls, sem, logits, bits, score = self._head(queries, mask_feats, False)
         aux = [dict(cls_preds=cls, sem_preds=None, masks=logits, centers=None, sizes=None, scores=score)]
-        kv_all = F.linear(inst, pk["ca_kv_all_w"], pk["ca_kv_all_b"])          # [S, 2*L*d]: k_0..k_{L-1} | v_0..v_{L-1}
+        kv = F.split_cols(F.linear(inst, pk["ca_kv_all_w"], pk["ca_kv_all_b"]), d)     # [S, 2*L*d]: k_0..k_{L-1} | v_0..v_{L-1}
         scale = (d // H) ** -0.5
         dropping = self.training and self.dropout > 0.0
         for i in range(L):
             ca, sa, ffn = self.cross_attn_layers[i], self.self_attn_layers[i], self.ffn_layers[i]
             q = F.linear(queries, pk["ca_q_w"][i], pk["ca_q_b"][i])
-            a = F.attention(q, kv_all[:, i * d:(i + 1) * d], kv_all[:, (L + i) * d:(L + i + 1) * d], H, scale, mask_bits=bits)
+            a = F.attention(q, kv[i], kv[L + i], H, scale, mask_bits=bits)
             if ca.fix:                                          # dropout only on the `fix` path (:80-84)
                 queries = F.layernorm(F.dropout(_lin(a, ca.attn.out_proj)), ca.norm.weight, ca.norm.bias, res=queries)
             else:
                 queries = _lin(a, ca.attn.out_proj, res=queries)
-            qkv = F.linear(queries, sa.attn.in_proj_weight, sa.attn.in_proj_bias)      # [Q, 3d]
-            a = F.attention(qkv[:, :d], qkv[:, d:2 * d], qkv[:, 2 * d:], H, scale)
+            qkv = F.split_cols(F.linear(queries, sa.attn.in_proj_weight, sa.attn.in_proj_bias), d)      # [Q, 3d]
+            a = F.attention(qkv[0], qkv[1], qkv[2], H, scale)
             queries = F.layernorm(F.dropout(_lin(a, sa.attn.out_proj)), sa.norm.weight, sa.norm.bias, res=queries)
             hdn = F.dropout(_lin(queries, ffn.net[0], act=("relu" if self.activation_fn == "relu" else "gelu")))
             if dropping:                                        # net(y) ends in a Dropout, then + y, then the norm (:166-190)
@@ -494,13 +503,13 @@ class ScanNetQueryDecoder(DerivedWeights):
         aux = [dict(cls_preds=None, sem_preds=None, masks=logits, centers=None, sizes=None, scores=score)]
 
         # layer-invariant key side, hoisted out of the loop (the reference recomputes it per layer, :669-671)
-        kv_all = F.linear(inst, pk["kv_w"], pk["kv_b"])                  # [S, 2*L*d]: kc_0..kc_{L-1} | v_0..v_{L-1}
-        kp_all = F.linear(memory_emb, pk["kp_w"], pk["kp_b"])            # [S, L*d]
+        kv_all = F.split_cols(F.linear(inst, pk["kv_w"], pk["kv_b"]), d)             # [S, 2*L*d]: kc_0..kc_{L-1} | v_0..v_{L-1}
+        kp_all = F.split_cols(F.linear(memory_emb, pk["kp_w"], pk["kp_b"]), d)       # [S, L*d]
         if self.add_dinox_query_ca:
             if not isinstance(q2d_pos, torch.Tensor):
                 q2d_pos = q2d_pos.tensor.type(sp_pos_wo.dtype).to(dev)
             keys2d = torch.cat([q2d_feat.float(), q2d_feat.new_ones(1, q2d_feat.shape[1], dtype=torch.float32)]).contiguous()
-            kv2d_all = F.linear(keys2d, pk["kv2d_w"], pk["kv2d_b"])      # [M+1, 2*L*d]
+            kv2d_all = F.split_cols(F.linear(keys2d, pk["kv2d_w"], pk["kv2d_b"]), d)     # [M+1, 2*L*d]
             near = ops.near_bits(sp_pos_wo.float().contiguous(), q2d_pos.float().contiguous(),
                                  self.dinox_query_ca_mask_threshold)
 
@@ -532,9 +541,7 @@ class ScanNetQueryDecoder(DerivedWeights):
             h, qs = F.linear_group([J(pq_emb, self.ref_point_head.layers[0], "relu"), J(pq_emb, self.ca_qpos_sine_proj[i])])
             query_pos = _lin(h, self.ref_point_head.layers[1])
             # ---- masked cross-attention to the superpoints (:668-691)
-            kc = kv_all[:, i * d:(i + 1) * d]
-            v = kv_all[:, (L + i) * d:(L + i + 1) * d]
-            kp = kp_all[:, i * d:(i + 1) * d]
+            kc, v, kp = kv_all[i], kv_all[L + i], kp_all[i]
             if i == 0:
                 qc = F.linear(queries, pk["ca_q0_w"], pk["ca_q0_b"], x2=query_pos)
                 kc = _lin(inst, self.ca_kcontent_proj[0], res=kp)
@@ -544,8 +551,8 @@ class ScanNetQueryDecoder(DerivedWeights):
             op = self.cross_attn_layers[i].out_proj
             queries = F.linear_ln(a, op.weight, op.bias, self.norm1[i].weight, self.norm1[i].bias, res=queries)
             # ---- self-attention (:695-709)
-            qkv = F.linear(queries, pk["sa_qkv_w"][i], pk["sa_qkv_b"][i], x2=query_pos)     # [Q, 3d]
-            a = F.attention(qkv[:, :d], qkv[:, d:2 * d], qkv[:, 2 * d:], H, (d // H) ** -0.5)
+            qkv = F.split_cols(F.linear(queries, pk["sa_qkv_w"][i], pk["sa_qkv_b"][i], x2=query_pos), d)     # [Q, 3d]
+            a = F.attention(qkv[0], qkv[1], qkv[2], H, (d // H) ** -0.5)
             op = self.self_attn_layers[i].out_proj
             queries = F.linear_ln(a, op.weight, op.bias, self.norm2[i].weight, self.norm2[i].bias, res=queries)
             # ---- cross-attention to the cached DINO-X 2D object queries (:713-731, :60-86)
@@ -553,7 +560,7 @@ class ScanNetQueryDecoder(DerivedWeights):
                 layer = self.dinox_query_cross_attn_layers[i]
                 bits2d = ops.dinox_mask_bits(bits, near)
                 q = F.linear(queries, pk["q2d_w"][i], pk["q2d_b"][i])
-                a = F.attention(q, kv2d_all[:, i * d:(i + 1) * d], kv2d_all[:, (L + i) * d:(L + i + 1) * d], H,
+                a = F.attention(q, kv2d_all[i], kv2d_all[L + i], H,
                                   (d // H) ** -0.5, mask_bits=bits2d)
                 if layer.fix:
                     op = layer.attn.out_proj

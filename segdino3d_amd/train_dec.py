@@ -252,6 +252,34 @@ def attention(q, k, v, num_heads, scale, mask_bits=None, q2=None, k2=None):
     return _Attention.apply(q, k, v, num_heads, scale, mask_bits, q2, k2)
 
 
+class _SplitCols(torch.autograd.Function):
+    """Equal column blocks of a packed projection's output as views.  Plain slicing gives every block its own SliceBackward:
+    a zero-filled full-width tensor per block and a chain of full-width adds (12 x 30 MB fills + 11 adds for the packed key /
+    value projection); here the blocks' gradients are concatenated once."""
+
+    @staticmethod
+    def forward(ctx, t, width):
+        ctx.width, ctx.shape = width, t.shape
+        ctx.set_materialize_grads(False)
+        return tuple(t[:, c:c + width] for c in range(0, t.shape[1], width))
+
+    @staticmethod
+    def backward(ctx, *grads):
+        if all(g is not None for g in grads):
+            return torch.cat(grads, dim=1), None
+        out = torch.zeros(ctx.shape, dtype=torch.float32, device=next(g for g in grads if g is not None).device)
+        for i, g in enumerate(grads):
+            if g is not None:
+                out[:, i * ctx.width:(i + 1) * ctx.width] = g
+        return out, None
+
+
+def split_cols(t, width):
+    if t.shape[1] % width:
+        raise ValueError("split_cols: the width must divide the column count")
+    return list(_SplitCols.apply(t, width))
+
+
 def attention_dropout(q, k, v, num_heads, scale, mask_bits=None, q2=None, k2=None, p=0.0):
     """Attention with dropout on the softmax probabilities - what `nn.MultiheadAttention(dropout=p)` does in training
     (`instance_seg_3d_decoder.py:48-49, 128-129`).  The fused kernel has no random stream, so for p > 0 - no shipped config,
@@ -282,6 +310,7 @@ class _BoxRefine(torch.autograd.Function):
                                                    None if d_size is None else d_size.detach().contiguous(), rng, normalize)
         ctx.save_for_backward(size, rng)
         ctx.normalize, ctx.has_size, ctx.Q = normalize, d_size is not None, ref_points.shape[0]
+        ctx.set_materialize_grads(False)                        # backward takes None for the outputs nothing differentiates
         if size is None:
             return center, None, None
         ctx.mark_non_differentiable(size)

@@ -113,7 +113,9 @@ class _BatchNormAct(torch.autograd.Function):
     """y = act(BN_batch(x) + res) for x [M, C] (`minkunet.py:234-250, 302-304`); returns (y, mean, biased var)."""
 
     @staticmethod
-    def forward(ctx, x, gamma, beta, res, act, eps):
+    def forward(ctx, x, gamma, beta, res, act, eps, running=None):
+        """running = (running_mean, running_var, num_batches_tracked, momentum) or None: the module's buffers, advanced in place by
+        the launch that makes the batch statistics."""
         lib = _lib.load()
         px, ldx = ops._rows(x, "x")
         M, C = x.shape
@@ -121,8 +123,12 @@ class _BatchNormAct(torch.autograd.Function):
         mean, var, rstd = (torch.empty(C, dtype=torch.float32, device=dev) for _ in range(3))
         nb = lib.sd3d_bn_ws_bytes(M, C)
         ws = _WS_BN.get(nb, dev)
-        _lib.check(lib.sd3d_bn_stats(px, ldx, M, C, float(eps), mean.data_ptr(), var.data_ptr(), rstd.data_ptr(), ws.data_ptr(), ws.numel(),
-                                     ops._stream()), "bn_stats")
+        rm, rv, nt, mom = running if running is not None else (None, None, None, 0.0)
+        _lib.check(lib.sd3d_bn_stats_running(px, ldx, M, C, float(eps), mean.data_ptr(), var.data_ptr(), rstd.data_ptr(),
+                                             ops._ptr(rm, torch.float32, "running_mean"), ops._ptr(rv, torch.float32, "running_var"),
+                                             ops._ptr(nt, torch.int64, "num_batches_tracked"), float(mom), ws.data_ptr(), ws.numel(),
+                                             ops._stream()), "bn_stats")
+        ctx.set_materialize_grads(False)                        # no zero tensors for the two statistics outputs in backward
         y = torch.empty(M, C, dtype=torch.float32, device=dev)
         pr, ldr = ops._rows(res, "res") if res is not None else (None, 0)
         g, b = gamma.detach().float().contiguous(), beta.detach().float().contiguous()
@@ -149,14 +155,18 @@ class _BatchNormAct(torch.autograd.Function):
         _lib.check(lib.sd3d_bn_backward(dy.data_ptr(), C, y.data_ptr(), C, px, ldx, mean.data_ptr(), rstd.data_ptr(), g.data_ptr(), M, C,
                                         ops.ACT[ctx.act], dx.data_ptr(), C, None if dres is None else dres.data_ptr(), C, dgamma.data_ptr(),
                                         dbeta.data_ptr(), ws.data_ptr(), ws.numel(), ops._stream()), "bn_backward")
-        return dx, dgamma, dbeta, dres, None, None
+        return dx, dgamma, dbeta, dres, None, None, None
 
 
 def batch_norm_act(x, bn: "torch.nn.BatchNorm1d", res=None, act=None):
     """Training-mode BatchNorm1d over the rows of x with the residual add and activation folded in; updates the
     module's running statistics like nn.BatchNorm1d (momentum, unbiased variance)."""
+    tracked = bn.track_running_stats and bn.running_mean is not None
+    if tracked and bn.momentum is not None and bn.running_mean.is_contiguous() and bn.running_var.is_contiguous():
+        running = (bn.running_mean, bn.running_var, bn.num_batches_tracked, bn.momentum)
+        return _BatchNormAct.apply(x, bn.weight, bn.bias, res, act, bn.eps, running)[0]
     y, mean, var = _BatchNormAct.apply(x, bn.weight, bn.bias, res, act, bn.eps)
-    if bn.track_running_stats and bn.running_mean is not None:
+    if tracked:                                                  # momentum=None: cumulative average, needs the step count on the host
         with torch.no_grad():
             m = x.shape[0]
             mom = bn.momentum if bn.momentum is not None else 1.0 / float(bn.num_batches_tracked + 1)
@@ -174,6 +184,7 @@ class _PoolSuperpoints(torch.autograd.Function):
         f, pos = maps.pool(feat.detach(), C)
         ctx.maps, ctx.C, ctx.V = maps, C, feat.shape[0]
         ctx.mark_non_differentiable(pos)
+        ctx.set_materialize_grads(False)
         return f, pos
 
     @staticmethod
