@@ -52,24 +52,35 @@ __global__ __launch_bounds__(NW * 64) void pair_wgrad_kernel(const WGParams p) {
     constexpr int NA = (A4 + NTHR - 1) / NTHR, NB = (B4 + NTHR - 1) / NTHR;
     __shared__ __attribute__((aligned(16))) float As[WG_STEP * LDA];
     __shared__ __attribute__((aligned(16))) float Bs[WG_STEP * LDB];
-    __shared__ int red[NW];
+    __shared__ int red[NW], red2[NW];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);   // wave-uniform: tile offsets live in SGPRs, no exec-masked branches
     const int n_real = p.tile_k[p.n_tiles];
     const int t0 = (int)((int64_t)blockIdx.x * n_real / gridDim.x);
     const int t1 = (int)((int64_t)(blockIdx.x + 1) * n_real / gridDim.x);
-    if (t1 <= t0) return;
+    const bool owner = blockIdx.y == 0 && blockIdx.z == 0;     // the workgroup of the range that keeps the slot table
+    if (t1 <= t0 && !owner) return;
     const int co0 = blockIdx.y * TCO, ci0 = blockIdx.z * TCI;
-    // slot of the first run = range index + offset changes in tiles (0, t0]
-    int changes = 0;
-    for (int t = 1 + tid; t <= t0; t += NTHR) changes += p.tile_k[t] != p.tile_k[t - 1];
+    // slot of the first run = range index + offset changes in tiles (0, t0]; `more` = changes in (t0, t1] (a tile index past the
+    // last real tile is no change).  Range r owns the slots [slot_r, slot_{r+1}) with slot_{r+1} = r + 1 + changes in (0, t1]: the
+    // ones its runs do not fill are marked empty by its owner workgroup, so the table needs no memset before the launch.
+    int changes = 0, more = 0;
+    for (int t = 1 + tid; t <= t1 && t < n_real; t += NTHR) {
+        const int c = p.tile_k[t] != p.tile_k[t - 1];
+        if (t <= t0) changes += c; else more += c;
+    }
 #pragma unroll
-    for (int o = 32; o > 0; o >>= 1) changes += __shfl_xor(changes, o, 64);
-    if (lane == 0) red[wv] = changes;
+    for (int o = 32; o > 0; o >>= 1) { changes += __shfl_xor(changes, o, 64); more += __shfl_xor(more, o, 64); }
+    if (lane == 0) { red[wv] = changes; red2[wv] = more; }
     __syncthreads();
-    int slot = blockIdx.x;
+    int slot = blockIdx.x, slot_end = blockIdx.x + 1;
 #pragma unroll
-    for (int i = 0; i < NW; ++i) slot += red[i];
+    for (int i = 0; i < NW; ++i) { slot += red[i]; slot_end += red[i] + red2[i]; }
+    if (blockIdx.x + 1 == gridDim.x) slot_end = p.n_slots;
+    if (t1 <= t0) {                                            // empty range (fewer tiles than ranges): its slots are empty
+        for (int s2 = slot + tid; s2 < slot_end; s2 += NTHR) p.slot_k[s2] = -1;
+        return;
+    }
 
     f32x16 acc[TPW];
 #pragma unroll
@@ -201,6 +212,8 @@ __global__ __launch_bounds__(NW * 64) void pair_wgrad_kernel(const WGParams p) {
         }
     }
     flush(cur_k);
+    if (owner)
+        for (int s2 = slot + tid; s2 < slot_end; s2 += NTHR) p.slot_k[s2] = -1;
 }
 
 // pass 2: dW[k] (+)= sum of the slots of offset k, in slot order
@@ -275,7 +288,6 @@ int sd3d_pair_wgrad(const float* dy, int ld_dy, const float* x, int ld_x, const 
     const int accumulate = flags & SD3D_WGRAD_ACCUMULATE;
     p.slot_k = (int32_t*)ws;
     p.wpart = (float*)((char*)ws + align_up((size_t)p.n_slots * sizeof(int32_t), 256));
-    if (hipMemsetAsync(p.slot_k, 0xFF, (size_t)p.n_slots * sizeof(int32_t), ST) != hipSuccess) return sd3d_set_error(SD3D_ERR_LAUNCH, "pair_wgrad: memset failed");
     // block = the channel count split evenly over its ceil(C / 128) blocks (192 channels: 2 x 96, not 128 + 64)
     auto sub = [](int C) { const int n32 = (C + 31) / 32, nb = (n32 + 3) / 4; return (n32 + nb - 1) / nb; };
     const int nco = sub(Cout), nci = sub(Cin);
