@@ -516,6 +516,14 @@ int sd3d_elastic_displace(float* coords, int64_t n, const float* noise, int D0, 
  *   sd3d_layernorm_backward: for y = act(LayerNorm(x + res) * w + b): dxin = d/d(x + res) [M, D], dw, db (act 0 / 1 = relu).
  *   sd3d_sine_pe_mod_backward: gradient of sd3d_sine_pe's box modulation w.r.t. mod_num [n, 3] (positions and mod_den are
  *                            detached in the reference, :740, :753). */
+/* dst_i [cols_i, ld_dst_i] = src_i [rows_i, cols_i]^T, columns rows_i .. ld_dst_i - 1 zero, for n matrices in as few launches as
+ * their descriptors fit (112 per launch): all the W^T the Linear input gradients of one backward pass need
+ * (`x.grad = dy @ W` of every nn.Linear in instance_seg_3d_decoder.py), made at once instead of one copy kernel per weight. */
+typedef struct sd3d_transpose_job {
+    const float* src; float* dst;
+    int32_t rows, cols, ld_dst, pad_;
+} sd3d_transpose_job;
+int sd3d_transpose_batch(int n, const sd3d_transpose_job* jobs, void* stream);
 int sd3d_act_backward(const float* dy, int ld_dy, const float* ref, int ld_ref, int act, int64_t M, int C, int C_pad, float* g, int ld_g,
                       void* stream);
 size_t sd3d_col_sums_ws_bytes(int64_t M, int C);

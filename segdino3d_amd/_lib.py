@@ -102,6 +102,7 @@ SIGNATURES = {
     "sd3d_pair_wgrad": (_i, [_p, _i, _p, _i, _p, _p, _p, _l, _i, _i, _i, _p, _i, _p, _z, _p]),
     "sd3d_bn_ws_bytes": (_z, [_l, _i]),
     "sd3d_bn_stats": (_i, [_p, _i, _l, _i, _f, _p, _p, _p, _p, _z, _p]),
+    "sd3d_transpose_batch": (_i, [_i, _p, _p]),
     "sd3d_bn_stats_running": (_i, [_p, _i, _l, _i, _f, _p, _p, _p, _p, _p, _p, _f, _p, _z, _p]),
     "sd3d_bn_apply": (_i, [_p, _i, _p, _p, _p, _p, _p, _i, _l, _i, _i, _p, _i, _p]),
     "sd3d_bn_backward": (_i, [_p, _i, _p, _i, _p, _i, _p, _p, _p, _l, _i, _i, _p, _i, _p, _i, _p, _p, _p, _z, _p]),

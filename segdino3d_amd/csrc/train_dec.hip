@@ -167,8 +167,56 @@ __global__ __launch_bounds__(256) void box_refine_bwd_kernel(const float* __rest
     }
 }
 
+// W [rows, cols] -> W^T [cols, ld_dst] (columns rows..ld_dst-1 zero) for MANY matrices in one launch: the input gradient of a
+// Linear is a product with W^T, and autograd used to transpose every weight with its own copy kernel (145 launches per step).
+// A workgroup = one 32 x 32 tile of one destination, found by its tile number in the jobs' prefix sums.
+#define TB_MAX 112
+struct TBatch { int n; int32_t tile0[TB_MAX + 1]; sd3d_transpose_job job[TB_MAX]; };
+static __global__ __launch_bounds__(256) void transpose_batch_kernel(const TBatch b) {
+    __shared__ float tile[32][33];
+    int lo = 0, hi = b.n - 1;
+    const int wg = blockIdx.x;
+    while (lo < hi) { const int mid = (lo + hi + 1) >> 1; if (b.tile0[mid] <= wg) lo = mid; else hi = mid - 1; }
+    const sd3d_transpose_job& J = b.job[lo];
+    const int tx = (J.ld_dst + 31) / 32;                       // tiles along the destination's columns (= source rows, padded)
+    const int t = wg - b.tile0[lo];
+    const int r0 = (t % tx) * 32, c0 = (t / tx) * 32;          // source row / column of the tile's corner
+    const int x = threadIdx.x & 31, y = threadIdx.x >> 5;
+#pragma unroll
+    for (int i = 0; i < 32; i += 8) {
+        const int r = r0 + y + i, c = c0 + x;
+        tile[y + i][x] = (r < J.rows && c < J.cols) ? J.src[(int64_t)r * J.cols + c] : 0.f;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 32; i += 8) {
+        const int c = c0 + y + i, r = r0 + x;                  // destination row c, destination column r
+        if (c < J.cols && r < J.ld_dst) J.dst[(int64_t)c * J.ld_dst + r] = tile[x][y + i];
+    }
+}
+
 #define ST ((hipStream_t)stream)
 extern "C" {
+
+int sd3d_transpose_batch(int n, const sd3d_transpose_job* jobs, void* stream) {
+    for (int i0 = 0; i0 < n; i0 += TB_MAX) {
+        TBatch b;
+        b.n = n - i0 < TB_MAX ? n - i0 : TB_MAX;
+        int tiles = 0;
+        for (int i = 0; i < b.n; ++i) {
+            const sd3d_transpose_job& J = jobs[i0 + i];
+            if (!J.src || !J.dst || J.rows <= 0 || J.cols <= 0 || J.ld_dst < J.rows)
+                return sd3d_set_error(SD3D_ERR_ARG, "transpose_batch: bad job");
+            b.job[i] = J;
+            b.tile0[i] = tiles;
+            tiles += ((J.ld_dst + 31) / 32) * ((J.cols + 31) / 32);
+        }
+        b.tile0[b.n] = tiles;
+        transpose_batch_kernel<<<tiles, 256, 0, ST>>>(b);
+        SD3D_CHECK_LAUNCH();
+    }
+    return SD3D_OK;
+}
 
 int sd3d_box_refine_backward(const float* d_center, const float* d_size_out, const float* size, const float* range, int normalize, int64_t Q,
                              float* d_dc, float* d_ds, void* stream) {

@@ -15,6 +15,8 @@ gradients is done by torch.  No CPU fallback.
 """
 from __future__ import annotations
 
+import threading
+
 import torch
 
 from . import _lib, ops, train_ops
@@ -28,6 +30,7 @@ _IDENTITY = {}
 # precise fp32 backward is the default and the autocast-faithful one is the opt-in.
 import os as _os
 BF16_BACKWARD = _os.environ.get("SD3D_BF16_BACKWARD", "0") == "1"
+BATCH_WT = _os.environ.get("SD3D_BATCH_WT", "1") != "0"
 
 
 def _identity_pairs(n_rows: int, device):
@@ -46,6 +49,70 @@ def _identity_pairs(n_rows: int, device):
 
 def _round(n, m):
     return (n + m - 1) // m * m
+
+
+class _TransposedWeights(threading.local):
+    """W^T of every Linear weight of the running training step, made by ONE launch.  The input gradient of a Linear is a
+    product with W^T ([Cin, Cout padded to 32]); transposing each weight inside its own backward cost one copy kernel and a
+    handful of host-side tensor ops per Linear (145 per step).  Forward passes register their weights; the first backward
+    that needs a transposed weight transposes all registered ones (sd3d_transpose_batch) and the following ones look theirs
+    up.  The next registration after a backward starts a new step.  Keyed by (storage pointer, shape): packed weights
+    (torch.cat views rebuilt every step) are fresh tensors each time and simply register again."""
+
+    def __init__(self):
+        self.pending, self.done, self.closed = [], {}, False
+
+    @staticmethod
+    def _key(w):
+        return (w.data_ptr(), tuple(w.shape), w._version)
+
+    def register(self, w):
+        if self.closed:
+            self.pending, self.done, self.closed = [], {}, False
+        self.pending.append(w)
+
+    def get(self, w):
+        key = self._key(w)
+        hit = self.done.get(key)
+        if hit is None:
+            todo = [t for t in self.pending if self._key(t) not in self.done]
+            if not any(self._key(t) == key for t in todo):
+                todo.append(w)
+            self._run(todo)
+            self.pending, self.closed = [], True
+            hit = self.done[key]
+        return hit
+
+    def _run(self, ws):
+        import ctypes as C
+        import numpy as np
+        lib = _lib.load()
+        seen, jobs = set(), []
+        for w in ws:
+            k = self._key(w)
+            if k in seen or w.dim() != 2 or not w.is_cuda or w.dtype != torch.float32:
+                continue
+            seen.add(k)
+            src = w.detach()
+            if not src.is_contiguous():
+                src = src.contiguous()
+            cout, cin = src.shape
+            dst = torch.empty(cin, _round(cout, 32), dtype=torch.float32, device=w.device)
+            self.done[k] = dst
+            jobs.append((src, dst, cout, cin))
+        if not jobs:
+            return
+        arr = np.zeros(len(jobs), dtype=_TJOB_DT)
+        for i, (src, dst, cout, cin) in enumerate(jobs):
+            arr[i] = (src.data_ptr(), dst.data_ptr(), cout, cin, dst.shape[1], 0)
+        _lib.check(lib.sd3d_transpose_batch(len(jobs), arr.ctypes.data, ops._stream()), "transpose_batch")
+        self._keep = jobs                                        # sources stay alive until the launch has been issued
+
+
+import numpy as _np
+_TJOB_DT = _np.dtype([("src", "<u8"), ("dst", "<u8"), ("rows", "<i4"), ("cols", "<i4"), ("ld_dst", "<i4"), ("pad_", "<i4")], align=True)
+assert _TJOB_DT.itemsize == 32
+_WT = _TransposedWeights()
 
 
 def act_backward(dy, ref, act, c_pad):
@@ -87,6 +154,8 @@ class _Linear(torch.autograd.Function):
             ref = ops.gather_gemm(xd, wd, act=None, exact=True, wt_split=ws, **kw)
         ctx.save_for_backward(x, w, ref if act is not None else None, x2)
         ctx.act, ctx.has_b, ctx.has_res = act, b is not None, res is not None
+        if ctx.needs_input_grad[0] or (x2 is not None and ctx.needs_input_grad[5]):
+            _WT.register(w)                                     # its transpose is made with all the others at the first backward
         # BASELINE configs[4] (autocast(bf16) around the decoder, train_engine_3d.py:88-100): the two backward products of a
         # Linear whose forward ran on bf16 operands run on bf16 operands too (fp32 accumulation), as autograd under autocast does
         ctx.bf16_bwd = ws is not None and BF16_BACKWARD
@@ -100,7 +169,9 @@ class _Linear(torch.autograd.Function):
         g = act_backward(dy.contiguous(), ref, ctx.act, c_pad)                  # [M, c_pad], zero beyond cout
         dx = dx2 = dw = db = dres = None
         if ctx.needs_input_grad[0] or (x2 is not None and ctx.needs_input_grad[5]):
-            if c_pad == cout:
+            if BATCH_WT:
+                wt = _WT.get(w)                                 # [cin, c_pad], zero beyond cout
+            elif c_pad == cout:
                 wt = w.detach().t().contiguous()
             else:
                 wt = torch.zeros(cin, c_pad, dtype=torch.float32, device=w.device)
