@@ -711,64 +711,94 @@ __global__ __launch_bounds__(256) void near_bits_kernel(const float* __restrict_
 
 // blocked2d[q] bit m = 1 <=> no superpoint is both open for query q and near 2D query m  (:722-726);
 // key Mq is the appended dummy key (always open); bits beyond Mq are blocked.
+// A workgroup takes QB consecutive queries (their open words ~blocked[q][:] in LDS) and its waves take the output words: for
+// each of a word's 32 keys m the wave reads near[m][:] with lane = superpoint word (coalesced rows of the 113 KB table), ANDs it
+// with the QB open rows and reduces with a ballot.  One query per workgroup and lane = m (the first version) re-read the whole
+// table per query through 64 cache lines per load: 150 us at 3000 queries x 300 keys, the whole table 3000 times.
+#define DINOX_QB_MAX 8
+template <int QB>
 __device__ __forceinline__ void dinox_mask_bits_body(const uint32_t* __restrict__ blocked, const uint32_t* __restrict__ near, int nwords,
-                                                     int64_t Mq, uint32_t* __restrict__ out, int nwords_out, const int64_t q,
+                                                     int64_t Q, int64_t Mq, uint32_t* __restrict__ out, int nwords_out, const int64_t q0,
                                                      uint32_t* open_w) {
-    const int lane = threadIdx.x & 63;
-    for (int w = threadIdx.x; w < nwords; w += 256) open_w[w] = ~blocked[q * nwords + w];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
+    for (int e = threadIdx.x; e < QB * nwords; e += blockDim.x) {
+        const int qq = e / nwords, w = e - qq * nwords;
+        open_w[e] = q0 + qq < Q ? ~blocked[(q0 + qq) * nwords + w] : 0u;
+    }
     __syncthreads();
-    for (int64_t m0 = (threadIdx.x >> 6) * 64; m0 <= Mq; m0 += 256) {      // one wave per 64 keys (incl. the dummy key Mq)
-        const int64_t m = m0 + lane;
-        bool blk = true;
-        if (m < Mq) {
-            const uint32_t* b = near + m * nwords;
-            uint32_t hit = 0u;
-            int w = 0;
-            for (; w + 4 <= nwords; w += 4)                      // four independent loads in flight per lane
-                hit |= (open_w[w] & b[w]) | (open_w[w + 1] & b[w + 1]) | (open_w[w + 2] & b[w + 2]) | (open_w[w + 3] & b[w + 3]);
-            for (; w < nwords; ++w) hit |= open_w[w] & b[w];
-            blk = hit == 0u;
-        } else if (m == Mq) {
-            blk = false;
+    for (int chunk = wave; chunk < nwords_out; chunk += nw) {
+        uint32_t word[QB];
+#pragma unroll
+        for (int qq = 0; qq < QB; ++qq) word[qq] = 0u;
+#pragma unroll 4
+        for (int jb = 0; jb < 32; ++jb) {
+            const int64_t m = (int64_t)chunk * 32 + jb;                         // wave-uniform
+            const int64_t mc = m < Mq ? m : (Mq > 0 ? Mq - 1 : 0);
+            uint32_t acc[QB];
+#pragma unroll
+            for (int qq = 0; qq < QB; ++qq) acc[qq] = 0u;
+            if (Mq > 0)
+                for (int w = lane; w < nwords; w += 64) {
+                    const uint32_t nb = near[mc * nwords + w];
+#pragma unroll
+                    for (int qq = 0; qq < QB; ++qq) acc[qq] |= open_w[qq * nwords + w] & nb;
+                }
+#pragma unroll
+            for (int qq = 0; qq < QB; ++qq) {
+                const bool hit = __ballot(acc[qq] != 0u) != 0ull;
+                const uint32_t blk = m < Mq ? (hit ? 0u : 1u) : (m == Mq ? 0u : 1u);
+                word[qq] |= blk << jb;
+            }
         }
-        const uint64_t bal = __ballot(blk);
         if (lane == 0) {
-            const int w = (int)(m0 >> 5);
-            if (w < nwords_out) out[q * nwords_out + w] = (uint32_t)bal;
-            if (w + 1 < nwords_out) out[q * nwords_out + w + 1] = (uint32_t)(bal >> 32);
+#pragma unroll
+            for (int qq = 0; qq < QB; ++qq)
+                if (q0 + qq < Q) out[(q0 + qq) * nwords_out + chunk] = word[qq];
         }
     }
 }
+template <int QB>
 __global__ __launch_bounds__(256) void dinox_mask_bits_kernel(const uint32_t* __restrict__ blocked, const uint32_t* __restrict__ near,
                                                               int nwords, int64_t Q, int64_t Mq, uint32_t* __restrict__ out,
                                                               int nwords_out) {
-    extern __shared__ uint32_t open_w[];                       // ~blocked[q][:], read by every lane
-    dinox_mask_bits_body(blocked, near, nwords, Mq, out, nwords_out, blockIdx.x, open_w);
+    extern __shared__ uint32_t open_w[];                       // ~blocked[q0 .. q0 + QB)[:]
+    dinox_mask_bits_body<QB>(blocked, near, nwords, Q, Mq, out, nwords_out, (int64_t)blockIdx.x * QB, open_w);
 }
-struct DinoxBitsBatch { int n; int row0[SD3D_MAX_BATCH + 1]; const uint32_t* blocked[SD3D_MAX_BATCH]; const uint32_t* near[SD3D_MAX_BATCH];
-                        uint32_t* out[SD3D_MAX_BATCH]; int nwords[SD3D_MAX_BATCH], Mq[SD3D_MAX_BATCH], nwords_out[SD3D_MAX_BATCH]; };
+struct DinoxBitsBatch { int n; int wg0[SD3D_MAX_BATCH + 1]; const uint32_t* blocked[SD3D_MAX_BATCH]; const uint32_t* near[SD3D_MAX_BATCH];
+                        uint32_t* out[SD3D_MAX_BATCH]; int nwords[SD3D_MAX_BATCH], Q[SD3D_MAX_BATCH], Mq[SD3D_MAX_BATCH], nwords_out[SD3D_MAX_BATCH]; };
+template <int QB>
 __global__ __launch_bounds__(256) void dinox_mask_bits_batch_kernel(const DinoxBitsBatch b) {
     extern __shared__ uint32_t open_w[];
     int si = 0;
-    for (int k = 1; k < b.n; ++k) if ((int)blockIdx.x >= b.row0[k]) si = k;
-    dinox_mask_bits_body(b.blocked[si], b.near[si], b.nwords[si], b.Mq[si], b.out[si], b.nwords_out[si], blockIdx.x - b.row0[si], open_w);
+    for (int k = 1; k < b.n; ++k) if ((int)blockIdx.x >= b.wg0[k]) si = k;
+    dinox_mask_bits_body<QB>(b.blocked[si], b.near[si], b.nwords[si], b.Q[si], b.Mq[si], b.out[si], b.nwords_out[si],
+                             (int64_t)(blockIdx.x - b.wg0[si]) * QB, open_w);
 }
+// queries per workgroup: 8 where that still leaves >= 256 workgroups, 2 for the few hundred queries of the default mode
+static int dinox_qb(int64_t rows) { return rows >= 2048 ? 8 : 2; }
 int launch_dinox_mask_bits_batch(int n, const uint32_t* const* blocked, const uint32_t* const* near, const int* nwords, const int64_t* Q,
                                  const int64_t* Mq, uint32_t* const* out, const int* nwords_out, hipStream_t st) {
     if (n <= 0) return SD3D_OK;
     if (n > SD3D_MAX_BATCH) return sd3d_set_error(SD3D_ERR_ARG, "dinox_mask_bits_batch: at most 16 scenes per call");
     DinoxBitsBatch b;
     b.n = n;
-    int rows = 0, wmax = 0;
+    int64_t rows = 0;
+    int wmax = 0;
+    for (int i = 0; i < n; ++i) rows += Q[i];
+    const int qb = dinox_qb(rows);
+    int wgs = 0;
     for (int i = 0; i < n; ++i) {
         if (nwords_out[i] != (int)((Mq[i] + 1 + 31) / 32)) return sd3d_set_error(SD3D_ERR_ARG, "dinox_mask_bits_batch: nwords_out != ceil((M+1)/32)");
-        b.row0[i] = rows; rows += (int)Q[i];
-        b.blocked[i] = blocked[i]; b.near[i] = near[i]; b.out[i] = out[i]; b.nwords[i] = nwords[i]; b.Mq[i] = (int)Mq[i]; b.nwords_out[i] = nwords_out[i];
+        b.wg0[i] = wgs; wgs += (int)cdiv(Q[i], qb);
+        b.blocked[i] = blocked[i]; b.near[i] = near[i]; b.out[i] = out[i]; b.nwords[i] = nwords[i]; b.Q[i] = (int)Q[i]; b.Mq[i] = (int)Mq[i];
+        b.nwords_out[i] = nwords_out[i];
         wmax = nwords[i] > wmax ? nwords[i] : wmax;
     }
-    b.row0[n] = rows;
-    if (rows <= 0) return SD3D_OK;
-    hipLaunchKernelGGL(dinox_mask_bits_batch_kernel, dim3((unsigned)rows), dim3(256), (size_t)wmax * sizeof(uint32_t), st, b);
+    b.wg0[n] = wgs;
+    if (wgs <= 0) return SD3D_OK;
+    const size_t sm = (size_t)qb * wmax * sizeof(uint32_t);
+    if (qb == 8) hipLaunchKernelGGL(dinox_mask_bits_batch_kernel<8>, dim3((unsigned)wgs), dim3(256), sm, st, b);
+    else hipLaunchKernelGGL(dinox_mask_bits_batch_kernel<2>, dim3((unsigned)wgs), dim3(256), sm, st, b);
     SD3D_CHECK_LAUNCH();
     return SD3D_OK;
 }
@@ -783,8 +813,11 @@ int launch_dinox_mask_bits(const uint32_t* blocked, const uint32_t* near, int nw
                            int nwords_out, hipStream_t st) {
     if (Q <= 0) return SD3D_OK;
     if (nwords_out != (int)((Mq + 1 + 31) / 32)) return sd3d_set_error(SD3D_ERR_ARG, "dinox_mask_bits: nwords_out != ceil((M+1)/32)");
-    hipLaunchKernelGGL(dinox_mask_bits_kernel, dim3((unsigned)Q), dim3(256), (size_t)nwords * sizeof(uint32_t), st, blocked, near, nwords,
-                       Q, Mq, out, nwords_out);
+    const int qb = dinox_qb(Q);
+    const size_t sm = (size_t)qb * nwords * sizeof(uint32_t);
+    if (sm > 64 * 1024) return sd3d_set_error(SD3D_ERR_ARG, "dinox_mask_bits: more than 65536 superpoints");
+    if (qb == 8) hipLaunchKernelGGL(dinox_mask_bits_kernel<8>, dim3((unsigned)cdiv(Q, 8)), dim3(256), sm, st, blocked, near, nwords, Q, Mq, out, nwords_out);
+    else hipLaunchKernelGGL(dinox_mask_bits_kernel<2>, dim3((unsigned)cdiv(Q, 2)), dim3(256), sm, st, blocked, near, nwords, Q, Mq, out, nwords_out);
     SD3D_CHECK_LAUNCH();
     return SD3D_OK;
 }

@@ -114,6 +114,34 @@ def test_mask_and_distance_bits_match_oracle():
     assert unpack(b2, ((M + 1 + 31) // 32) * 32)[:, M + 1:].all()
 
 
+@pytest.mark.parametrize("Q,S,M", [(2501, 3000, 300), (2048, 333, 45), (3, 70, 1), (201, 4100, 95), (9, 64, 64)])
+def test_dinox_mask_bits_sizes(Q, S, M):
+    """sd3d_dinox_mask_bits at one query per superpoint (eight queries per workgroup) and at odd sizes (two per workgroup, ragged last
+    workgroup, keys filling whole output words, more than 4096 superpoints), single call and the batched entry, against the boolean
+    product of instance_seg_3d_decoder.py:721-726."""
+    from segdino3d_amd import ops
+    d = dev()
+    g = torch.Generator().manual_seed(Q + S)
+    open_ = torch.rand(Q, S, generator=g) < 0.03
+    open_[0] = False                                           # a query with nothing open: every real key blocked, the dummy key open
+    near_b = torch.rand(M, S, generator=g) < 0.02
+    W = (S + 31) // 32
+
+    def pack(m, fill):                                          # bool [R, S] -> int32 words [R, W], padding bits = fill
+        full = torch.full((m.shape[0], W * 32), fill, dtype=torch.bool)
+        full[:, :S] = m
+        w = (full.view(m.shape[0], W, 32).long() << torch.arange(32)).sum(-1)
+        return torch.where(w >= 2 ** 31, w - 2 ** 32, w).to(torch.int32)
+    blocked_bits, near_bits = pack(~open_, True).to(d), pack(near_b, False).to(d)
+    ref = torch.cat([(open_.float() @ near_b.float().t()) == 0, torch.zeros(Q, 1, dtype=torch.bool)], dim=1)
+    got = ops.dinox_mask_bits(blocked_bits, near_bits)
+    assert torch.equal(unpack(got, M + 1), ref)
+    assert unpack(got, got.shape[1] * 32)[:, M + 1:].all()
+    half = Q // 2 + 1
+    two = ops.dinox_mask_bits_batch([blocked_bits[:half].contiguous(), blocked_bits[half:].contiguous()], [near_bits, near_bits])
+    assert torch.equal(torch.cat(two), got)
+
+
 def _build_decoder(kw_over=None, sd_kw=None):
     from segdino3d_amd.decoder import ScanNetQueryDecoder
     kw = dict(DEC_KW); kw.update(kw_over or {})
