@@ -198,14 +198,12 @@ __global__ __launch_bounds__(256) void gather_gemm_group_kernel(const GGGroup g)
 // ---------------------------------------------------------------------------------------------
 #define BS_LD 36
 template <int NT>
-__global__ __launch_bounds__(256) void gather_gemm_lds_kernel(const GGParams p) {
-    __shared__ __attribute__((aligned(16))) float Bs[2][NT * 32 * BS_LD];
-    __shared__ unsigned long long wmask[4][2];
+__device__ __forceinline__ void gather_gemm_lds_body(const GGParams& p, const int bx, const int cg, const int bz, float (*Bs)[NT * 32 * BS_LD],
+                                                     unsigned long long (*wmask)[2]) {
     const int tid = threadIdx.x;
     const int lane = tid & 63, wv = tid >> 6;
     const int j = lane & 31, h = lane >> 5;
-    const int64_t row_tile = (int64_t)blockIdx.x * 4 + wv;
-    const int cg = blockIdx.y;
+    const int64_t row_tile = (int64_t)bx * 4 + wv;
     const int64_t row0 = row_tile * 32;
     const int64_t row = row0 + j;
     const bool row_ok = row < p.M;
@@ -228,7 +226,7 @@ __global__ __launch_bounds__(256) void gather_gemm_lds_kernel(const GGParams p) 
     uint64_t b1 = wmask[0][1] | wmask[1][1] | wmask[2][1] | wmask[3][1];
     if (p.ksplit > 1) {            // this workgroup only walks the offsets k with k % ksplit == blockIdx.z
         uint64_t s0 = 0, s1 = 0;
-        for (int k = blockIdx.z; k < p.K; k += p.ksplit) { if (k < 64) s0 |= 1ull << k; else s1 |= 1ull << (k - 64); }
+        for (int k = bz; k < p.K; k += p.ksplit) { if (k < 64) s0 |= 1ull << k; else s1 |= 1ull << (k - 64); }
         b0 &= s0; b1 &= s1;
     }
 
@@ -320,7 +318,7 @@ __global__ __launch_bounds__(256) void gather_gemm_lds_kernel(const GGParams p) 
     }
     if (row0 >= p.M) return;
     if (p.ksplit > 1) {            // raw partial sums; splitk_epilogue_kernel reduces them in slice order
-        float* wsz = p.ws + (int64_t)blockIdx.z * p.M * p.Cout;
+        float* wsz = p.ws + (int64_t)bz * p.M * p.Cout;
 #pragma unroll
         for (int t = 0; t < NT; ++t) {
             const int n = ncol0 + t * 32 + j;
@@ -351,6 +349,24 @@ __global__ __launch_bounds__(256) void gather_gemm_lds_kernel(const GGParams p) 
             p.out[rr * p.ld_out + n] = y;
         }
     }
+}
+
+template <int NT>
+__global__ __launch_bounds__(256) void gather_gemm_lds_kernel(const GGParams p) {
+    __shared__ __attribute__((aligned(16))) float Bs[2][NT * 32 * BS_LD];
+    __shared__ unsigned long long wmask[4][2];
+    gather_gemm_lds_body<NT>(p, blockIdx.x, blockIdx.y, blockIdx.z, Bs, wmask);
+}
+// Several INDEPENDENT plain Linears on a few thousand rows each in one launch (blockIdx.z = job): the decoder with one query per
+// superpoint runs ~100 Linears of 3000 x 256 -> 256 per scene, each 192 workgroups for 256 CUs and ~13 us of dependent steps;
+// the ones that do not depend on each other share a launch.  Same body, same tiling per job as the single launch: same bits.
+template <int NT>
+__global__ __launch_bounds__(256) void gather_gemm_lds_group_kernel(const GGGroup g) {
+    __shared__ __attribute__((aligned(16))) float Bs[2][NT * 32 * BS_LD];
+    __shared__ unsigned long long wmask[4][2];
+    const GGParams& p = g.job[blockIdx.z];
+    if ((int64_t)blockIdx.x * 128 >= p.M || (int)blockIdx.y >= p.col_groups) return;      // uniform per workgroup
+    gather_gemm_lds_body<NT>(p, blockIdx.x, blockIdx.y, 0, Bs, wmask);
 }
 
 // out = act(scale * sum_z ws[z] + shift + res): fixed-order reduction of the split-K partials.
@@ -398,6 +414,18 @@ int dense_plan_code(int64_t rows, int Cin, int Cout) {
     return nt;
 }
 
+// column tiles per workgroup of the lock-step kernel
+static int lds_column_tiles(int sub, int64_t tiles, bool gathered) {
+    int nt = sub >= 4 ? 4 : sub;
+    while (nt > 2 && cdiv(tiles, 4) * cdiv(sub, nt) < 256) --nt;
+    if (nt == 2 && cdiv(tiles, 4) * cdiv(sub, 2) < 192) nt = 1;
+    if (sub % nt) { for (int c = nt; c >= 1; --c) if (sub % c == 0) { nt = c; break; } }
+    // plain Linears on a few thousand rows (the decoder with one query per superpoint, the superpoint-side projections):
+    // measured on M = 3000, 256 -> 1024 / 3072 columns: 1-2 column tiles per workgroup beat 3-4 (24 vs 30 us, 61 vs 88 us)
+    if (!gathered && tiles < 1024) nt = (sub % 2 == 0 && cdiv(tiles, 4) * (sub / 2) >= 512) ? 2 : 1;
+    return nt;
+}
+
 int launch_gather_gemm(const GGParams& p_in, int nt, void* ws, size_t ws_bytes, hipStream_t st) {
     GGParams p = p_in;
     p.ksplit = 1;
@@ -423,13 +451,7 @@ int launch_gather_gemm(const GGParams& p_in, int nt, void* ws, size_t ws_bytes, 
         if (!force_split && tiles >= 64 && steps >= 2) {
             // enough rows for 4-tile workgroups: share the weights through LDS
             lds = true;
-            nt = sub >= 4 ? 4 : sub;
-            while (nt > 2 && cdiv(tiles, 4) * cdiv(sub, nt) < 256) --nt;
-            if (nt == 2 && cdiv(tiles, 4) * cdiv(sub, 2) < 192) nt = 1;
-            if (sub % nt) { for (int c = nt; c >= 1; --c) if (sub % c == 0) { nt = c; break; } }
-            // plain Linears on a few thousand rows (the decoder with one query per superpoint, the superpoint-side projections):
-            // measured on M = 3000, 256 -> 1024 / 3072 columns: 1-2 column tiles per workgroup beat 3-4 (24 vs 30 us, 61 vs 88 us)
-            if (!p.nbr && tiles < 1024) nt = (sub % 2 == 0 && cdiv(tiles, 4) * (sub / 2) >= 512) ? 2 : 1;
+            nt = lds_column_tiles(sub, tiles, p.nbr != nullptr);
         } else {
             nt = sub >= 4 ? 4 : sub;
             while (nt > 1 && tiles * cdiv(sub, nt) < 2048) --nt;
@@ -488,6 +510,42 @@ int launch_gather_gemm(const GGParams& p_in, int nt, void* ws, size_t ws_bytes, 
 int launch_linear_group(int n, const GGParams* jobs, hipStream_t st) {
     if (n <= 0) return SD3D_OK;
     if (n > GG_GROUP_MAX) return sd3d_set_error(SD3D_ERR_ARG, "linear_group: at most 8 jobs per launch");
+    // every job on enough rows for the lock-step kernel (dense_plan_code 0): one launch per column-tile count, each job on the
+    // tiling its own launch would get
+    bool all_lds = true;
+    for (int i = 0; i < n; ++i) all_lds = all_lds && jobs[i].Cin > 0 && !(jobs[i].Cin & 31) && dense_plan_code(jobs[i].M, jobs[i].Cin, jobs[i].Cout) == 0;
+    if (all_lds) {
+        for (int want = 1; want <= 4; ++want) {
+            GGGroup g;
+            g.n = 0;
+            unsigned gx = 0, gy = 0;
+            for (int i = 0; i < n; ++i) {
+                GGParams p = jobs[i];
+                if (p.M <= 0 || p.Cout <= 0) return sd3d_set_error(SD3D_ERR_ARG, "linear_group: empty job");
+                if (p.in1 && ((p.C0 & 31) || p.C0 > p.Cin)) return sd3d_set_error(SD3D_ERR_ARG, "linear_group: concat split must be a multiple of 32");
+                if (!p.in1) p.C0 = p.Cin;
+                if ((p.ld0 & 3) || (p.in1 && (p.ld1 & 3))) return sd3d_set_error(SD3D_ERR_ARG, "linear_group: input row stride must be a multiple of 4 floats");
+                const int sub = (p.Cout + 31) / 32;
+                const int64_t tiles = cdiv(p.M, 32);
+                if (lds_column_tiles(sub, tiles, false) != want) continue;
+                p.nbr = nullptr; p.K = 1; p.ksplit = 1; p.ws = nullptr;
+                p.col_groups = (int)cdiv(p.Cout, 32 * want);
+                gx = (unsigned)cdiv(tiles, 4) > gx ? (unsigned)cdiv(tiles, 4) : gx;
+                gy = (unsigned)p.col_groups > gy ? (unsigned)p.col_groups : gy;
+                g.job[g.n++] = p;
+            }
+            if (!g.n) continue;
+            const dim3 grid(gx, gy, (unsigned)g.n);
+            switch (want) {
+                case 1: hipLaunchKernelGGL(gather_gemm_lds_group_kernel<1>, grid, dim3(256), 0, st, g); break;
+                case 2: hipLaunchKernelGGL(gather_gemm_lds_group_kernel<2>, grid, dim3(256), 0, st, g); break;
+                case 3: hipLaunchKernelGGL(gather_gemm_lds_group_kernel<3>, grid, dim3(256), 0, st, g); break;
+                default: hipLaunchKernelGGL(gather_gemm_lds_group_kernel<4>, grid, dim3(256), 0, st, g); break;
+            }
+        }
+        SD3D_CHECK_LAUNCH();
+        return SD3D_OK;
+    }
     GGGroup g;
     g.n = n;
     int64_t max_units = 0;

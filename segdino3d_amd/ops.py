@@ -672,8 +672,10 @@ def small_rows_code(cin: int) -> int:
 
 def linear_group(jobs, force_small=False):
     """jobs: list of (x, weight [Cout, Cin], bias | None, act | None, res | None, x2 | None) - INDEPENDENT plain Linears on a few
-    hundred rows each; returns their outputs.  Up to 8 per launch (csrc/gather_gemm.hip gather_gemm_group_kernel); jobs that do
-    not fit the small-row path (>= 2048 rows, bf16 decoder scope on >= BF16_MIN_ROWS rows, instrumentation hook) run one by one.
+    hundred rows each; returns their outputs.  Up to 8 per launch (csrc/gather_gemm.hip gather_gemm_group_kernel).  Jobs on
+    >= 2017 rows each go out together as well, every one on the lock-step tiling its own launch would use
+    (gather_gemm_lds_group_kernel: same bits).  Mixed sizes, the bf16 decoder scope on >= BF16_MIN_ROWS rows and the
+    instrumentation hook run one by one.
     force_small: the rows are several scenes' few-hundred-row tensors back to back - always the group kernel."""
     global _LINEAR_JOB_DT
     import numpy as np
@@ -688,7 +690,10 @@ def linear_group(jobs, force_small=False):
         return [gather_gemm(x, w, x2=x2, shift=b, act=act, res=res)]
     bf16 = getattr(_BF16_TLS, "on", False)
     small = [force_small or (x.shape[0] < 2048 and not (bf16 and x.shape[0] >= BF16_MIN_ROWS) and x.shape[0] > 0) for (x, *_r) in jobs]
-    if not all(small):
+    # a few thousand rows each (one query per superpoint): the lock-step kernel of the single launch, several jobs per launch
+    large = not bf16 and not force_small and all(w.dim() == 2 and w.shape[1] % 32 == 0 and dense_code(x.shape[0], w.shape[1], w.shape[0]) == 0
+                                                   for (x, w, *_r) in jobs)
+    if not all(small) and not large:
         return [gather_gemm(x, w, x2=x2, shift=b, act=act, res=res) for (x, w, b, act, res, x2) in jobs]
     if _LINEAR_JOB_DT is None:
         _LINEAR_JOB_DT = np.dtype([("in0", "<u8"), ("in1", "<u8"), ("wt", "<u8"), ("shift", "<u8"), ("res", "<u8"), ("out", "<u8"),

@@ -420,3 +420,35 @@ def test_fused_projection_residual_layernorm(M, Cin, with_res, act):
     # rows beyond the limit take the two-launch path by themselves
     big = ops.linear_layernorm(torch.cat([x] * (600 // M + 1)).to(d)[:600] if M < 600 else x.to(d), w.to(d), b.to(d), g.to(d), beta.to(d))
     assert big.shape[1] == 256
+
+
+@pytest.mark.parametrize("rows", [200, 2441, 3000])
+def test_linear_group_equals_single_launches(rows):
+    """ops.linear_group (independent Linears sharing launches) against one ops.gather_gemm per job, bit for bit: the few-hundred-row
+    group kernel and, from 2017 rows on, the grouped lock-step kernel (jobs of different widths, two inputs, residual, activations,
+    a 3072-column job that takes two column tiles per workgroup)."""
+    from segdino3d_amd import ops
+    d = dev()
+    g = torch.Generator().manual_seed(rows)
+    rnd = lambda *s: torch.randn(*s, generator=g).to(d)  # noqa: E731
+    x, x2, res = rnd(rows, 256), rnd(rows, 256), rnd(rows, 256)
+    jobs = [(x, rnd(256, 256) * 0.06, rnd(256), "relu", None, None),
+            (x, rnd(199, 256) * 0.06, rnd(199), None, None, None),
+            (x, rnd(256, 512) * 0.04, None, None, res, x2),
+            (x2, rnd(1024, 256) * 0.06, rnd(1024), "gelu", None, None),
+            (x, rnd(32, 256) * 0.06, rnd(32), "sigmoid", None, None),
+            (x2, rnd(3072, 256) * 0.06, rnd(3072), None, None, None)]
+    got = ops.linear_group(jobs)
+    for (xx, w, b, act, r, xx2), y in zip(jobs, got):
+        if rows < 2048:                                          # the group kernel = the split-contraction kernel of a single small launch
+            ref = ops.gather_gemm(xx, w, x2=xx2, shift=b, act=act, res=r, nt=-1, exact=True)
+        else:
+            ref = ops.gather_gemm(xx, w, x2=xx2, shift=b, act=act, res=r)
+        assert torch.equal(y, ref), (rows, tuple(w.shape), act)
+        ref64 = torch.cat([xx, xx2], 1).double() @ w.double().t() if xx2 is not None else xx.double() @ w.double().t()
+        if b is not None:
+            ref64 = ref64 + b.double()
+        if r is not None:
+            ref64 = ref64 + r.double()
+        ref64 = {None: lambda t: t, "relu": torch.relu, "gelu": torch.nn.functional.gelu, "sigmoid": torch.sigmoid}[act](ref64)
+        assert (y.double() - ref64).abs().max().item() < 2e-5 * max(1.0, ref64.abs().max().item())
