@@ -721,18 +721,67 @@ __device__ __forceinline__ void dinox_mask_bits_body(const uint32_t* __restrict_
                                                      int64_t Q, int64_t Mq, uint32_t* __restrict__ out, int nwords_out, const int64_t q0,
                                                      uint32_t* open_w) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
+    uint16_t* out16 = (uint16_t*)out;                           // a wave produces 16 keys = half an output word at a time
+    const int nhalf = nwords_out * 2;
+    if (nwords <= 128) {
+        // up to 4096 superpoints: a lane keeps its two words of every open row in registers; the near rows of EIGHT keys are
+        // requested before the first is used (one key at a time the loop ran at the latency of one load per key)
+        uint32_t o[QB][2];
+#pragma unroll
+        for (int qq = 0; qq < QB; ++qq)
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const int w = lane + 64 * i;
+                o[qq][i] = (q0 + qq < Q && w < nwords) ? ~blocked[(q0 + qq) * nwords + w] : 0u;
+            }
+        for (int unit = wave; unit < nhalf; unit += nw) {
+            uint32_t word[QB];
+#pragma unroll
+            for (int qq = 0; qq < QB; ++qq) word[qq] = 0u;
+#pragma unroll
+            for (int g = 0; g < 2; ++g) {
+                uint32_t nb[8][2];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const int64_t m = (int64_t)unit * 16 + g * 8 + u;
+                    const int64_t mc = m < Mq ? m : (Mq > 0 ? Mq - 1 : 0);
+#pragma unroll
+                    for (int i = 0; i < 2; ++i) {
+                        const int w = lane + 64 * i;
+                        nb[u][i] = (Mq > 0 && w < nwords) ? near[mc * nwords + w] : 0u;
+                    }
+                }
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const int64_t m = (int64_t)unit * 16 + g * 8 + u;
+#pragma unroll
+                    for (int qq = 0; qq < QB; ++qq) {
+                        const bool hit = __ballot(((o[qq][0] & nb[u][0]) | (o[qq][1] & nb[u][1])) != 0u) != 0ull;
+                        const uint32_t blk = m < Mq ? (hit ? 0u : 1u) : (m == Mq ? 0u : 1u);
+                        word[qq] |= blk << (g * 8 + u);
+                    }
+                }
+            }
+            if (lane == 0) {
+#pragma unroll
+                for (int qq = 0; qq < QB; ++qq)
+                    if (q0 + qq < Q) out16[(q0 + qq) * nhalf + unit] = (uint16_t)word[qq];
+            }
+        }
+        return;
+    }
+    // more superpoints than two words per lane: open rows in LDS, one key at a time
     for (int e = threadIdx.x; e < QB * nwords; e += blockDim.x) {
         const int qq = e / nwords, w = e - qq * nwords;
         open_w[e] = q0 + qq < Q ? ~blocked[(q0 + qq) * nwords + w] : 0u;
     }
     __syncthreads();
-    for (int chunk = wave; chunk < nwords_out; chunk += nw) {
+    for (int unit = wave; unit < nhalf; unit += nw) {
         uint32_t word[QB];
 #pragma unroll
         for (int qq = 0; qq < QB; ++qq) word[qq] = 0u;
-#pragma unroll 4
-        for (int jb = 0; jb < 32; ++jb) {
-            const int64_t m = (int64_t)chunk * 32 + jb;                         // wave-uniform
+        for (int jb = 0; jb < 16; ++jb) {
+            const int64_t m = (int64_t)unit * 16 + jb;                          // wave-uniform
             const int64_t mc = m < Mq ? m : (Mq > 0 ? Mq - 1 : 0);
             uint32_t acc[QB];
 #pragma unroll
@@ -753,7 +802,7 @@ __device__ __forceinline__ void dinox_mask_bits_body(const uint32_t* __restrict_
         if (lane == 0) {
 #pragma unroll
             for (int qq = 0; qq < QB; ++qq)
-                if (q0 + qq < Q) out[(q0 + qq) * nwords_out + chunk] = word[qq];
+                if (q0 + qq < Q) out16[(q0 + qq) * nhalf + unit] = (uint16_t)word[qq];
         }
     }
 }
