@@ -35,6 +35,10 @@ struct AttnBwdParams {
 };
 
 __device__ __forceinline__ int tile_row(int r, int h) { return (r & 3) + 8 * (r >> 2) + 4 * h; }
+// P = exp(S - lse) as v_exp_f32 of (S - lse) * log2(e): one fused multiply-add and the hardware exponential instead of the library
+// expf's range handling (the forward kernel forms its probabilities the same way)
+#define ABW_LOG2E 1.4426950408889634f
+__device__ __forceinline__ float prob_of(float s, float lse_log2) { return __builtin_amdgcn_exp2f(__builtin_fmaf(s, ABW_LOG2E, -lse_log2)); }
 
 template <int NSRC>
 __global__ __launch_bounds__(256) void attn_bwd_q_kernel(const AttnBwdParams p) {
@@ -63,7 +67,7 @@ __global__ __launch_bounds__(256) void attn_bwd_q_kernel(const AttnBwdParams p) 
     }
     dsum += __shfl_xor(dsum, 32);
     if (wave == 0 && h == 0 && q0 + i < p.Lq) p.dsum[(int64_t)head * p.Lq + q0 + i] = dsum;
-    const float lse = p.lse[(int64_t)head * p.Lq + qi];
+    const float lse = p.lse[(int64_t)head * p.Lq + qi] * ABW_LOG2E;
 
     f32x16 dQ[NSRC];
 #pragma unroll
@@ -95,7 +99,7 @@ __global__ __launch_bounds__(256) void attn_bwd_q_kernel(const AttnBwdParams p) 
         for (int r = 0; r < 16; ++r) {
             const int kb = tile_row(r, h);
             const bool blocked = ((word >> kb) & 1u) || (kt0 + kb >= p.Lk);
-            const float pr = blocked ? 0.f : expf(S[r] - lse);
+            const float pr = blocked ? 0.f : prob_of(S[r], lse);
             ds[r] = pr * (dP[r] - dsum);
         }
         // dQ^T[c][query] += sum_key K[key][c] dS[query][key];  A = K^T (row = channel i), B = dS^T
@@ -174,16 +178,24 @@ __global__ __launch_bounds__(512) void attn_bwd_kv_kernel(const AttnBwdParams p)
 #pragma unroll
             for (int e = 0; e < 16; ++e) dP = __builtin_amdgcn_mfma_f32_32x32x2f32(src[e], vreg[e], dP, 0, 0, 0);
         }
-        // S[r], dP[r]: (query = qt0 + tile_row(r, h), key = k0 + j)
+        // S[r], dP[r]: (query = qt0 + tile_row(r, h), key = k0 + j).  The per-query values (mask word, lse, D) are loaded once per
+        // tile by the lane whose index is the query's row in the tile and handed round with readlane - not 48 loads per lane and tile
+        const uint32_t my_word = p.bits ? p.bits[(int64_t)qr * p.nwords + ktile] : 0u;
+        const float my_lse = p.lse[(int64_t)head * p.Lq + qr] * ABW_LOG2E, my_dsum = p.dsum[(int64_t)head * p.Lq + qr];
         float pr[16], ds[16];
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-            const int qq = qt0 + tile_row(r, h);
-            const int qc = min(qq, p.Lq - 1);
-            bool blocked = !key_ok || qq >= p.Lq;
-            if (p.bits && !blocked) blocked = (p.bits[(int64_t)qc * p.nwords + ktile] >> j) & 1u;
-            const float lse = p.lse[(int64_t)head * p.Lq + qc], dsum = p.dsum[(int64_t)head * p.Lq + qc];
-            pr[r] = blocked ? 0.f : expf(S[r] - lse);
+            const int row0 = tile_row(r, 0), row1 = tile_row(r, 1);             // compile-time lane numbers
+            const uint32_t w0 = (uint32_t)__builtin_amdgcn_readlane((int)my_word, row0), w1 = (uint32_t)__builtin_amdgcn_readlane((int)my_word, row1);
+            const float l0 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(my_lse), row0));
+            const float l1 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(my_lse), row1));
+            const float d0 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(my_dsum), row0));
+            const float d1 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(my_dsum), row1));
+            const uint32_t word = h ? w1 : w0;
+            const float lse = h ? l1 : l0, dsum = h ? d1 : d0;
+            const int qq = qt0 + (h ? row1 : row0);
+            const bool blocked = !key_ok || qq >= p.Lq || ((word >> j) & 1u);
+            pr[r] = blocked ? 0.f : prob_of(S[r], lse);
             ds[r] = pr[r] * (dP[r] - dsum);
         }
         // dV^T[dv][key] += sum_q dO[q][dv] P[q][key];  A = dO^T (row = dv = j), B = P
