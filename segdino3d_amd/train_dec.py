@@ -69,6 +69,8 @@ class _TransposedWeights(threading.local):
     def register(self, w):
         if self.closed:
             self.pending, self.done, self.closed = [], {}, False
+        if len(self.pending) >= 4096:                            # forwards without a backward: do not hold their weights for ever
+            del self.pending[:2048]
         self.pending.append(w)
 
     def get(self, w):
