@@ -51,39 +51,45 @@ def _round(n, m):
     return (n + m - 1) // m * m
 
 
-class _TransposedWeights(threading.local):
+class _TransposedWeights:
     """W^T of every Linear weight of the running training step, made by ONE launch.  The input gradient of a Linear is a
     product with W^T ([Cin, Cout padded to 32]); transposing each weight inside its own backward cost one copy kernel and a
     handful of host-side tensor ops per Linear (145 per step).  Forward passes register their weights; the first backward
     that needs a transposed weight transposes all registered ones (sd3d_transpose_batch) and the following ones look theirs
-    up.  The next registration after a backward starts a new step.  Keyed by (storage pointer, shape): packed weights
-    (torch.cat views rebuilt every step) are fresh tensors each time and simply register again."""
+    up.  The next registration after a backward starts a new step.  Keyed by (storage pointer, shape, version): packed weights
+    (torch.cat views rebuilt every step) are fresh tensors each time and simply register again.
+    ONE instance per process, behind a lock: forward passes register from the calling thread, the backward of device tensors runs
+    on the autograd engine's device thread (a thread-local registry never saw a registered weight there, transposed them one by
+    one, and kept stale entries whose addresses later parameters reused)."""
 
     def __init__(self):
         self.pending, self.done, self.closed = [], {}, False
+        self.lock = threading.Lock()
 
     @staticmethod
     def _key(w):
         return (w.data_ptr(), tuple(w.shape), w._version)
 
     def register(self, w):
-        if self.closed:
-            self.pending, self.done, self.closed = [], {}, False
-        if len(self.pending) >= 4096:                            # forwards without a backward: do not hold their weights for ever
-            del self.pending[:2048]
-        self.pending.append(w)
+        with self.lock:
+            if self.closed:
+                self.pending, self.done, self.closed = [], {}, False
+            if len(self.pending) >= 4096:                        # forwards without a backward: do not hold their weights for ever
+                del self.pending[:2048]
+            self.pending.append(w)
 
     def get(self, w):
         key = self._key(w)
-        hit = self.done.get(key)
-        if hit is None:
-            todo = [t for t in self.pending if self._key(t) not in self.done]
-            if not any(self._key(t) == key for t in todo):
-                todo.append(w)
-            self._run(todo)
-            self.pending, self.closed = [], True
-            hit = self.done[key]
-        return hit
+        with self.lock:
+            hit = self.done.get(key)
+            if hit is None:
+                todo = [t for t in self.pending if self._key(t) not in self.done]
+                if not any(self._key(t) == key for t in todo):
+                    todo.append(w)
+                self._run(todo)
+                self.pending, self.closed = [], True
+                hit = self.done[key]
+            return hit
 
     def _run(self, ws):
         import ctypes as C

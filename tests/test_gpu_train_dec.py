@@ -242,6 +242,44 @@ def test_decoder_trains_with_dropout():
         assert torch.equal(run(dec, 5)[0]["masks"][0], run(dec0, 6)[0]["masks"][0])
 
 
+def test_transposed_weights_are_batched_across_threads():
+    """The W^T of all Linears of a step come from ONE `_TransposedWeights._run` (sd3d_transpose_batch) although the forward registers
+    from the calling thread and the backward asks from the autograd engine's device thread; a second model whose parameters may land
+    on the addresses of the first (freed) one gets its own transposes, not the cached ones."""
+    import gc
+    from segdino3d_amd import train_dec as T
+    d = dev()
+    calls = []
+    orig = T._TransposedWeights._run
+
+    def counted(self, ws):
+        calls.append(len(ws))
+        return orig(self, ws)
+    T._TransposedWeights._run = counted
+    try:
+        for seed in (1, 2, 3):
+            torch.manual_seed(seed)
+            lins = [torch.nn.Linear(256, 256).to(d) for _ in range(5)] + [torch.nn.Linear(256, 199).to(d)]
+            x = torch.randn(300, 256, device=d, requires_grad=True)
+            h = x
+            for m in lins[:5]:
+                h = T.linear(h, m.weight, m.bias, act="relu")
+            y = T.linear(h, lins[5].weight, lins[5].bias)
+            n0 = len(calls)
+            y.square().mean().backward()
+            assert len(calls) == n0 + 1 and calls[-1] >= 6, calls          # one batched run for the six weights (plus leftovers)
+            x2 = x.detach().clone().requires_grad_(True)
+            h = x2
+            for m in lins[:5]:
+                h = torch.relu(torch.nn.functional.linear(h, m.weight, m.bias))
+            torch.nn.functional.linear(h, lins[5].weight, lins[5].bias).square().mean().backward()
+            close(x.grad, x2.grad.double(), f"dx, model {seed}", 2e-5)
+            del lins, x, x2, h, y
+            gc.collect(); torch.cuda.empty_cache()
+    finally:
+        T._TransposedWeights._run = orig
+
+
 def test_decoder_training_gradients_match_reference():
     """The whole query decoder in training mode on the device (autograd nodes over HIP kernels) against the gradients of the
     REFERENCE decoder itself (tests/golden/decoder_grad_s96_q16.npz: reference autograd, train mode, same weights / inputs):
