@@ -362,7 +362,8 @@ __device__ __forceinline__ void attention_body(const AttnParams& p, const int bx
             const float* vsrc = p.v + head * 32 + i;
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                vreg[r] = vsrc[(int64_t)(kt0 + h) * p.ldv + r];   /* EXPERIMENT: one row per half, consecutive channels (wrong results) */
+                const int key = min(kt0 + (r & 3) + 8 * (r >> 2) + 4 * h, p.Lk - 1);
+                vreg[r] = vsrc[(int64_t)key * p.ldv];
             }
         }
         f32x16 S;
