@@ -152,22 +152,32 @@ def end_to_end(model, device, args, n_scenes=32):
             out_bytes[0] += sum(a.nbytes for a in (pd.pts_instance_mask[0], pd.pts_instance_mask[1], pd.pts_semantic_mask[0],
                                                    pd.pts_semantic_mask[1], pd.instance_labels, pd.instance_scores))
         prev = model.to_host
-        model.to_host = True
+
+        def timed(mode, n):
+            model.to_host = mode
+            out_bytes[0] = 0
+            files = [paths[i % 4] for i in range(n)]
+            t0 = time.perf_counter()
+            runner.run(io_scene.ScenePrefetcher(files, device, depth=4, readers=2), on_result=count, keep=False)
+            torch.cuda.synchronize()
+            return n / (time.perf_counter() - t0), out_bytes[0] // max(1, n)
         try:
             with torch.no_grad():
-                runner.run(io_scene.ScenePrefetcher(paths + paths, device, depth=2), keep=False)  # warm: files in the page cache, pinned pools sized
+                model.to_host = "packed"
+                runner.run(io_scene.ScenePrefetcher(paths + paths, device, depth=2), keep=False)  # warm: files in the page cache, staging sized
                 torch.cuda.synchronize()
-                files = [paths[i % 4] for i in range(n_scenes)]
-                t0 = time.perf_counter()
-                runner.run(io_scene.ScenePrefetcher(files, device, depth=4, readers=2), on_result=count, keep=False)
-                torch.cuda.synchronize()
-                dt = time.perf_counter() - t0
+                rate, nbytes_out = timed("packed", n_scenes)
+                rate_bool, nbytes_bool = timed(True, max(8, n_scenes // 2))
         finally:
             model.to_host = prev
-        return {"value": round(n_scenes / dt, 2), "unit": "scenes/s", "scenes": n_scenes, "input_bytes_per_scene": int(nbytes),
-                "output_bytes_per_scene": int(out_bytes[0] // max(1, n_scenes)),
+        return {"value": round(rate, 2), "unit": "scenes/s", "scenes": n_scenes, "input_bytes_per_scene": int(nbytes),
+                "output_bytes_per_scene": int(nbytes_out),
+                "unpacked_masks": {"value": round(rate_bool, 2), "output_bytes_per_scene": int(nbytes_bool),
+                                   "what": "`to_host=True`: the [n, N] instance masks expanded to the bool array of the reference's evaluator "
+                                           "(evaluator_3d.py:178) on the host, pageable"},
                 "what": f"packed scene files (page cache) -> pinned host -> H2D (copy stream) -> forward, {args.streams} scenes in flight -> "
-                        "post-processed masks / labels / scores copied to host numpy arrays; PCIe-inclusive, never `value`"}
+                        "post-processed masks (bit-packed on the device, `to_host=\"packed\"`) / labels / scores copied to pageable host arrays; "
+                        "PCIe-inclusive, never `value`"}
     finally:
         shutil.rmtree(tmp, ignore_errors=True)
 
@@ -176,7 +186,7 @@ def load_pmc_traffic(key):
     """HBM-side bytes per forward of the dominant kernel from the committed PMC passes (rocprofv3 cannot run inside this process) -
     ONLY if they were collected on the workload this run measures (`key`: scene shape, layout, query mode, scenes per forward).
     Returns (bytes per forward | None, source | reason)."""
-    for name in ("r03_pmc_traffic.json", "r02_pmc_traffic.json"):
+    for name in ("r04_pmc_traffic.json", "r03_pmc_traffic.json", "r02_pmc_traffic.json"):
         path = os.path.join(ROOT, "profiles", name)
         if not os.path.exists(path):
             continue
@@ -195,24 +205,20 @@ def pin_rank_to_cores(local_rank: int, local_world: int, threads_per_rank: int, 
     """One process per GPU drives `threads_per_rank` issuing threads; with 8 ranks on a node they must stay on the cores of
     the NUMA node their GPU hangs off (`/sys/bus/pci/devices/<bdf>/numa_node`) and off each other's cores: ranks whose GPUs
     share a node split that node's cores evenly (segdino3d_amd.dist_eval.cores_for_rank; an even slice of the allowed cores
-    when the platform reports no node).  Returns (cores in the slice, NUMA node or -1)."""
-    from segdino3d_amd.dist_eval import cores_for_rank, gpu_numa_node
+    when the platform reports no node).  The GPUs' PCI addresses come from the KFD topology in sysfs
+    (dist_eval.visible_gpu_bdfs): no HIP call touches the OTHER ranks' GPUs.  Returns (cores in the slice, NUMA node or -1)."""
+    from segdino3d_amd.dist_eval import cores_for_rank, gpu_numa_node, visible_gpu_bdfs
     try:
         allowed = sorted(os.sched_getaffinity(0))
     except (AttributeError, OSError):
         return 0, -1
     if local_world <= 1:
         return len(allowed), -1
+    bdfs = visible_gpu_bdfs()
     nodes = []
     for r in range(local_world):
-        node = -1
-        try:                                                   # properties only: no context is created on the other ranks' GPUs
-            pr = torch.cuda.get_device_properties(0 if share_gpu else r)
-            bdf = f"{pr.pci_domain_id:04x}:{pr.pci_bus_id:02x}:{pr.pci_device_id:02x}.0"
-            node = gpu_numa_node(bdf)
-        except Exception:  # noqa: BLE001 - placement is best effort
-            node = -1
-        nodes.append(node)
+        g = 0 if share_gpu else r
+        nodes.append(gpu_numa_node(bdfs[g]) if g < len(bdfs) else -1)
     mine = cores_for_rank(local_rank, nodes, allowed)
     try:
         os.sched_setaffinity(0, mine)
@@ -223,13 +229,13 @@ def pin_rank_to_cores(local_rank: int, local_world: int, threads_per_rank: int, 
 
 
 def launch_ranks(n_ranks: int, argv):
-    """Parent of a self-launched multi-GPU run: starts one child per GPU, relays rank 0's stdout (the JSON line), waits for
-    all of them and returns the exit code (non-zero if any rank failed; the others are then terminated by PID)."""
+    """Parent of a self-launched multi-GPU run: starts one child per GPU and supervises all of them
+    (segdino3d_amd.dist_eval.launch_ranks: rank 0's stdout - the JSON line - is relayed, the first rank that fails takes the
+    others down at once).  The parent never touches the GPU: the devices are counted from the KFD topology in sysfs."""
     import socket
-    import subprocess
-    from segdino3d_amd.dist_eval import rank_commands
+    from segdino3d_amd import dist_eval
     share = os.environ.get("SD3D_SHARE_GPU") == "1"
-    n_dev = torch.cuda.device_count()                            # does not initialise the GPU
+    n_dev = len(dist_eval.visible_gpu_bdfs())
     if n_dev < n_ranks and not share:
         print(f"bench.py: --gpus {n_ranks} but only {n_dev} GPU(s) are visible (SD3D_SHARE_GPU=1 + SD3D_DIST_BACKEND=gloo "
               f"rehearses the multi-rank flow on one GPU)", file=sys.stderr)
@@ -237,21 +243,9 @@ def launch_ranks(n_ranks: int, argv):
     with socket.socket() as sk:
         sk.bind(("127.0.0.1", 0))
         port = sk.getsockname()[1]
-    procs = []
-    for rank, (cmd, env) in enumerate(rank_commands(os.path.abspath(__file__), argv, n_ranks, port)):
-        procs.append(subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE if rank == 0 else sys.stderr))
-    out0, _ = procs[0].communicate()
-    rc = procs[0].returncode
-    for p in procs[1:]:
-        if rc != 0 and p.poll() is None:
-            p.terminate()
-        try:
-            p.wait(timeout=120)
-        except subprocess.TimeoutExpired:
-            p.kill()
-            p.wait()
-        rc = rc or p.returncode
-    sys.stdout.write(out0.decode())
+    out0 = []
+    rc = dist_eval.launch_ranks(dist_eval.rank_commands(os.path.abspath(__file__), argv, n_ranks, port), out0)
+    sys.stdout.write(b"".join(out0).decode())
     sys.stdout.flush()
     return rc
 
@@ -279,6 +273,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-end-to-end", action="store_true", help="skip the packed-files -> host-numpy-outputs measurement (`end_to_end`)")
     ap.add_argument("--preroll-seconds", type=float, default=2.0, help="untimed pipelined pre-roll before the timed K steps")
+    ap.add_argument("--sustain-seconds", type=float, default=1.0,
+                    help="after the timed K steps the same K-step list is repeated for this long: `sustained` (never `value`)")
     args = ap.parse_args()
 
     if args.gpus > 1 and "RANK" not in os.environ:            # started without a launcher: be the launcher
@@ -348,28 +344,38 @@ def main():
         if dist is not None:
             dist.barrier()
         work = scene_list(args.steps)
+        plan = runner.plan_batches(args.steps)                    # [[scene ids of a forward, ...] per stream]: what the timed region runs
         torch.cuda.synchronize()
         t0 = time.perf_counter()
-        runner.run(work)                                          # EXACTLY K steps, args.streams scenes in flight
+        runner.run(work)                                          # EXACTLY K steps, args.streams forwards in flight
         torch.cuda.synchronize()
         if dist is not None:
             dist.barrier()
         dt = time.perf_counter() - t0
+        # sustained rate: the same K-step list repeated until >= 1 s has been timed (the K = 20 region of the driver is 0.2 s, a
+        # sixth of it pipeline ramp and drain); reported next to `value`, never instead of it
+        sus_n, t1 = 0, time.perf_counter()
+        while time.perf_counter() - t1 < args.sustain_seconds:
+            runner.run(scene_list(args.steps))
+            sus_n += args.steps
+        torch.cuda.synchronize()
+        sus_dt = time.perf_counter() - t1
+        # one scene per forward, for the per-scene voxel counts of the line
+        import segdino3d_amd as seg
+        with seg.capture() as cap1:
+            step(0)
         # Instrumented replay of the same K steps for the roofline of the dominant kernel: a HIP-event
         # pair around every gather_gemm launch costs ~2 x 237 event records per step (+15-20 % wall),
-        # so it is kept out of the region that produces `value`.
+        # so it is kept out of the region that produces `value`.  It runs the forwards of `plan` - the same scenes grouped
+        # into the same forwards as the timed region - one after the other on one stream.
         timer = GemmTimer()
         ops.GG_HOOK = timer
         timer.enabled = True
-        import segdino3d_amd as seg
-        with seg.capture() as cap:
-            if args.batch > 1:                                    # the same K scenes, in the batches the timed region ran them in
-                for g in range(0, args.steps, args.batch):
-                    grp = scene_list(min(args.steps, g + args.batch))[g:]
-                    model([p for p, _ in grp], [t for _, t in grp])
-            else:
-                for i in range(args.steps):
-                    step(i)
+        n_fwd = 0
+        for st_plan in plan:
+            for ids in st_plan:
+                model([work[i][0] for i in ids], [copy.copy(work[i][1]) for i in ids])
+                n_fwd += 1
         torch.cuda.synchronize()
         timer.enabled = False
         ops.GG_HOOK = None
@@ -411,13 +417,13 @@ def main():
     conv_sec = conv_ms * 1e-3
     conv_tf = conv_flops / conv_sec / 1e12 if conv_sec > 0 else 0.0
     conv_gbs = conv_bytes / conv_sec / 1e9 if conv_sec > 0 else 0.0
-    n_fwd = max(1, (steps + args.batch - 1) // args.batch)      # forwards of the instrumented replay (batches of --batch scenes)
+    n_fwd = max(1, n_fwd)                                       # forwards of the instrumented replay = forwards of the timed region
     conv_per_step = max(1, conv_n // n_fwd)
     # HBM-side bytes of the dominant kernel per forward: FETCH_SIZE x 2 (the guide's gfx950 correction) + WRITE_SIZE of pair_gemm_* +
     # pair_reduce_* from the committed PMC passes, reported only when they were collected on THIS workload.  They exceed the
     # algorithmic bytes by design: the partial products are written by pass 1 and re-read by pass 2.
     workload_key = {"points": args.points, "superpoints": args.superpoints, "queries_2d": args.query2d, "scene_layout": args.scene_layout,
-                    "scenes_per_forward": args.batch}
+                    "scenes_per_forward": args.batch}           # (the PMC passes run whole batches: --steps a multiple of streams x batch)
     traffic_fwd, traffic_src = load_pmc_traffic(workload_key)
     roofline = {"bound": "mfma",
                 "kernel": "sd3d_pair_conv_ex = pair_gemm_* (pass 1, fp32 MFMA over the offset-major rulebook) + pair_reduce_rl_kernel (pass 2 over per-row lists; "
@@ -430,9 +436,13 @@ def main():
                 "traffic_over_algorithmic": round(traffic_fwd / max(1, conv_bytes // steps), 2) if traffic_fwd else None,
                 "traffic_source": traffic_src,
                 "hbm_achieved_gbs": round(conv_gbs, 1), "hbm_peak_gbs": HBM_PEAK_GBS, "hbm_frac": round(conv_gbs / HBM_PEAK_GBS, 4),
+                # the same with the MEASURED HBM-side bytes (partial products written by pass 1 and re-read by pass 2 included)
+                "hbm_traffic_gbs": round(traffic_fwd / (conv_ms / steps) / 1e6, 1) if (traffic_fwd and conv_ms > 0) else None,
+                "hbm_traffic_frac": round(traffic_fwd / (conv_ms / steps) / 1e6 / HBM_PEAK_GBS, 4) if (traffic_fwd and conv_ms > 0) else None,
                 "share_of_single_stream_forward": round(conv_ms / steps / latency_ms, 3) if args.batch == 1 else None,
                 "measured": "HIP events around every launch on the launching stream, single-stream instrumented replay of the timed steps"
-                            + (f" in batches of {args.batch} scenes (per-forward figures are per SCENE)" if args.batch > 1 else ""),
+                            + (" in the forwards of `config.forward_sizes` (`*_per_forward` figures are per SCENE, `launches_per_forward` per forward call)"
+                               if args.batch > 1 else ""),
                 # every sparse convolution AND every Linear of the decoder / heads (the ~155 extra launches are 10 us each for 26 MFLOP)
                 "gemm_family": {"launches_per_forward": n_launch // n_fwd, "ms_per_forward": round(gemm_ms / steps, 3),
                                 "achieved": round(fam_tf, 2), "unit": "TFLOP/s", "frac": round(fam_tf / FP32_MFMA_PEAK_TFLOPS, 4),
@@ -440,7 +450,8 @@ def main():
                                 "algorithmic_flops_per_forward": tot_flops // steps}}
 
     # ---- closing all-gather of per-scene records over RCCL/xGMI -----------------------
-    maps = cap.maps[-1]
+    maps = cap1.maps[-1]                                      # ONE scene's maps: per-scene voxel counts
+    fwd_sizes = [[len(f) for f in st] for st in plan]
     rec = torch.tensor([float(rank), float(args.points), float(maps.n_vox[0]), 1e3 * dt / args.steps],
                        dtype=torch.float64, device=comm_device)
     if dist is not None:
@@ -467,15 +478,20 @@ def main():
             "single_scene": {"scenes_per_s": round(1e3 / latency_ms, 2), "latency_ms": round(latency_ms, 3),
                              "note": "ONE scene in flight per GPU (SURVEY 8(d) batch = 1), same forward, same process"},
             "config": {"workload": ("configs[2]" if bf16_dec else "configs[1]") + ": ScanNet-val-like scenes, one scene per forward (step), "
-                                   f"{args.streams * args.batch} independent scenes in flight per GPU (`value`: {args.streams} stream(s) x {args.batch} scene(s) per forward) "
-                                   "/ one in flight (`single_scene`); "
+                                   f"{args.streams} forward(s) in flight per GPU of <= {args.batch} scene(s) each (`value`; the K steps of THIS run as `forward_sizes`: "
+                                   f"<= {sum(max(st) if st else 0 for st in fwd_sizes)} scenes in flight) / one in flight (`single_scene`); "
                                    "fp32 sparse backbone (Res16UNet34C) + " + ("bf16-MFMA" if bf16_dec else "fp32") +
                                    " decoder + post-processing, device-resident in/out",
                        "points": args.points, "superpoints": args.superpoints, "queries_2d": args.query2d, "scene_layout": args.scene_layout,
                        "query_num": args.query_num, "voxels_per_level": maps.n_vox, "parallelism": f"scene-sharded x{world}",
-                       "scenes_in_flight_per_gpu": args.streams * args.batch, "streams": args.streams, "scenes_per_forward": args.batch,
+                       "streams": args.streams, "max_scenes_per_forward": args.batch,
+                       "forward_sizes": fwd_sizes,             # per stream: scenes of each forward of the timed region (PipelinedRunner.plan_batches)
+                       "scenes_in_flight_per_gpu": sum(max(st) if st else 0 for st in fwd_sizes),
+                       "scenes_per_forward": round(args.steps / max(1, sum(len(st) for st in fwd_sizes)), 2),
                        "single_stream_latency_ms": round(latency_ms, 3),
                        "untimed_preroll_scenes": n_pre, "host_cores_per_rank": cores_per_rank, "gpu_numa_node": numa_node},
+            "sustained": {"scenes_per_s": round(world * sus_n / sus_dt, 3) if sus_n else None, "timed_scenes": sus_n, "seconds": round(sus_dt, 3),
+                          "note": "the same K-step list repeated back to back after the K timed steps (rank 0's clock); not `value`"},
             "roofline": roofline, "cpu_baseline": cpu, "end_to_end": e2e,
             "per_rank_records": records,
         }

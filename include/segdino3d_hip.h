@@ -376,6 +376,12 @@ size_t sd3d_expand_masks_ws_bytes(int n, int ld_sig);
 int sd3d_expand_masks(const float* sig, int ld_sig, const uint32_t* src_row, int n, const int64_t* superpoints,
                       const float* points, int ld_points, int64_t N, float sp_thr, const float* boxes, float loose_ratio,
                       uint8_t* out, int32_t* count, void* ws, size_t ws_bytes, void* stream);
+/* Bit-packed copy of selected rows of the [n, N] byte masks of sd3d_expand_masks, for the device -> host copy of
+ * `pts_instance_mask[0]` (baseline3d.py:453-454; evaluator_3d.py:178 reads it on the host): out [n_rows, nb = ceil(N/8)] bytes,
+ * bit j of byte b = masks[rows[i]][8 b + j] != 0 (numpy bitorder "little"); rows NULL = rows 0..n_rows-1. */
+int sd3d_pack_mask_rows(const uint8_t* masks, int64_t N, const int32_t* rows, int n_rows, uint8_t* out, int64_t nb, void* stream);
+/* HOST function (no GPU): packed_host [n_rows, nb] -> out_host [n_rows, N] bytes 0 / 1, the torch.bool / numpy bool layout. */
+int sd3d_unpack_bits_host(const uint8_t* packed_host, int64_t n_rows, int64_t N, int64_t nb, uint8_t* out_host);
 /* argmax over selected columns (:504) and table gather (:504-507). */
 int sd3d_row_argmax(const float* x, int ld, int64_t Q, const int32_t* cols, int ncols, int64_t* out, void* stream);
 int sd3d_gather_i64(const int64_t* table, const int64_t* idx, int64_t N, int use_index, int64_t* out, void* stream);

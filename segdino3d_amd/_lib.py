@@ -83,6 +83,8 @@ SIGNATURES = {
     "sd3d_mask_scores": (_i, [_p, _i, _i, _p, _p, _i, _i, _i, _p, _p, _p, _p]),
     "sd3d_gather_sigmoid": (_i, [_p, _i, _i, _p, _p, _i, _p, _i, _p, _p]),
     "sd3d_nms_decay": (_i, [_p, _i, _p, _p, _i, _i, _f, _p, _p, _p, _p]),
+    "sd3d_pack_mask_rows": (_i, [_p, _l, _p, _i, _p, _l, _p]),
+    "sd3d_unpack_bits_host": (_i, [_p, _l, _l, _l, _p]),
     "sd3d_expand_masks_ws_bytes": (_z, [_i, _i]),
     "sd3d_expand_masks": (_i, [_p, _i, _p, _i, _p, _p, _i, _l, _f, _p, _f, _p, _p, _p, _z, _p]),
     "sd3d_row_argmax": (_i, [_p, _i, _l, _p, _i, _p, _p]),
@@ -167,7 +169,7 @@ def load_nogil():
     if _lib_nogil is None:
         load()
         lib = C.CDLL(LIB_PATH)
-        for name in ("sd3d_run_layers",):
+        for name in ("sd3d_run_layers", "sd3d_unpack_bits_host"):
             fn = getattr(lib, name)
             fn.restype, fn.argtypes = SIGNATURES[name]
         _lib_nogil = lib

@@ -19,6 +19,7 @@ int scan_exclusive_i32(const int*, int*, int64_t, const int*, int*, void*, size_
 int launch_f32_to_sortkey(const float*, int64_t, int, uint64_t*, hipStream_t);
 int launch_i64_to_sortkey(const int64_t*, int64_t, uint64_t*, hipStream_t);
 int launch_scene_stats(const float*, int, int64_t, float*, void*, size_t, hipStream_t);
+int launch_pack_mask_rows(const uint8_t*, int64_t, const int32_t*, int, uint8_t*, int64_t, hipStream_t);
 size_t unique_ws_bytes(int64_t);
 int launch_unique_sorted(const uint64_t*, const uint32_t*, int64_t, const int*, int, uint64_t*, int32_t*, int32_t*, int32_t*,
                          void*, size_t, const float*, float, int, int, hipStream_t);
@@ -400,6 +401,32 @@ int sd3d_expand_masks(const float* sig, int ld_sig, const uint32_t* src_row, int
                       void* ws, size_t ws_bytes, void* stream) {
     return launch_expand_masks(sig, ld_sig, src_row, n, superpoints, points, ld_points, N, sp_thr, boxes, loose_ratio, out, count, ws,
                                ws_bytes, ST);
+}
+int sd3d_pack_mask_rows(const uint8_t* masks, int64_t N, const int32_t* rows, int n_rows, uint8_t* out, int64_t nb, void* stream) {
+    return launch_pack_mask_rows(masks, N, rows, n_rows, out, nb, ST);
+}
+// Host side of sd3d_pack_mask_rows: packed_host [n_rows, nb] bits -> out_host [n_rows, N] bytes (0 / 1).  One table lookup per
+// input byte (8 output bytes at a time); plain C, no GPU, no threads - the caller's thread does it with the GIL released.
+int sd3d_unpack_bits_host(const uint8_t* packed_host, int64_t n_rows, int64_t N, int64_t nb, uint8_t* out_host) {
+    if (n_rows < 0 || N < 0 || nb != (N + 7) / 8) return sd3d_set_error(SD3D_ERR_ARG, "unpack_bits_host: nb != ceil(N / 8)");
+    static uint64_t lut[256];
+    static bool ready = false;
+    if (!ready) {                                              // idempotent: racing callers write the same values
+        for (int v = 0; v < 256; ++v) {
+            uint64_t w = 0;
+            for (int j = 0; j < 8; ++j) if (v >> j & 1) w |= 1ull << (8 * j);
+            lut[v] = w;
+        }
+        __atomic_store_n(&ready, true, __ATOMIC_RELEASE);
+    }
+    const int64_t full = N / 8;
+    for (int64_t r = 0; r < n_rows; ++r) {
+        const uint8_t* src = packed_host + r * nb;
+        uint8_t* dst = out_host + r * N;
+        for (int64_t b = 0; b < full; ++b) { const uint64_t w = lut[src[b]]; __builtin_memcpy(dst + 8 * b, &w, 8); }
+        for (int64_t p = full * 8; p < N; ++p) dst[p] = (src[full] >> (p - full * 8)) & 1;
+    }
+    return SD3D_OK;
 }
 int sd3d_row_argmax(const float* x, int ld, int64_t Q, const int32_t* cols, int ncols, int64_t* out, void* stream) {
     return launch_row_argmax(x, ld, Q, cols, ncols, out, ST);

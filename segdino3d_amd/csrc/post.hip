@@ -246,6 +246,35 @@ __global__ __launch_bounds__(256) void em_expand_kernel(const uint32_t* __restri
     }
 }
 
+// Bit-packed copy of selected rows of the [n, N] byte masks for the host (baseline3d.py:453-454 hands the evaluator an [n, N] bool
+// array: 90 MB per scene over PCIe as bytes, 11 MB as bits): out[i][b] bit j = masks[rows[i]][8 b + j] != 0 (little-endian bit
+// order, numpy's `unpackbits(bitorder="little")`); bits past N are 0.  A thread makes one output byte from 8 consecutive mask
+// bytes - one 8-byte load where the row base allows it.
+__global__ __launch_bounds__(256) void pack_mask_rows_kernel(const uint8_t* __restrict__ masks, int64_t N, const int32_t* __restrict__ rows,
+                                                             int n_rows, uint8_t* __restrict__ out, int64_t nb) {
+    const int64_t b = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int i = blockIdx.y;
+    if (b >= nb || i >= n_rows) return;
+    const int64_t r = rows ? rows[i] : i;
+    const uint8_t* src = masks + r * N + 8 * b;
+    uint32_t v = 0;
+    if (8 * b + 8 <= N && ((r * N) & 7) == 0) {
+        const uint64_t w = *(const uint64_t*)src;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v |= ((w >> (8 * j)) & 0xFFull) ? (1u << j) : 0u;
+    } else {
+        for (int j = 0; j < 8 && 8 * b + j < N; ++j) v |= src[j] ? (1u << j) : 0u;
+    }
+    out[(int64_t)i * nb + b] = (uint8_t)v;
+}
+int launch_pack_mask_rows(const uint8_t* masks, int64_t N, const int32_t* rows, int n_rows, uint8_t* out, int64_t nb, hipStream_t st) {
+    if (n_rows <= 0 || N <= 0) return SD3D_OK;
+    if (nb != (N + 7) / 8) return sd3d_set_error(SD3D_ERR_ARG, "pack_mask_rows: nb != ceil(N / 8)");
+    hipLaunchKernelGGL(pack_mask_rows_kernel, dim3((unsigned)cdiv(nb, 256), (unsigned)n_rows), dim3(256), 0, st, masks, N, rows, n_rows, out, nb);
+    SD3D_CHECK_LAUNCH();
+    return SD3D_OK;
+}
+
 // sem_q[q] = argmax_c sem[q, classes...]: classes = first n_cls columns (n_cls = C) or an explicit list.
 __global__ __launch_bounds__(256) void row_argmax_kernel(const float* __restrict__ x, int ld, int64_t Q, const int32_t* __restrict__ cols,
                                                          int ncols, int64_t* __restrict__ out) {

@@ -90,6 +90,118 @@ def rank_commands(script: str, argv: Sequence[str], n_ranks: int, port: int, pyt
     return out
 
 
+def kfd_gpu_bdfs(sysfs_root: str = "/sys") -> List[str]:
+    """PCI addresses ('dddd:bb:dd.f') of the GPU agents of this node in KFD order, read from
+    `<sysfs>/class/kfd/kfd/topology/nodes/<i>/properties` - no HIP / HSA call, so a launcher parent that uses it stays
+    provably GPU-free (`torch.cuda.device_count()` may open /dev/kfd on a ROCm build without amdsmi).  A node is a GPU when its
+    `simd_count` is non-zero (CPU agents report 0); `location_id` = bus << 8 | device << 3 | function, `domain` the PCI domain."""
+    base = os.path.join(sysfs_root, "class", "kfd", "kfd", "topology", "nodes")
+    try:
+        ids = sorted((int(n) for n in os.listdir(base) if n.isdigit()))
+    except OSError:
+        return []
+    out = []
+    for i in ids:
+        props = {}
+        try:
+            with open(os.path.join(base, str(i), "properties")) as f:
+                for line in f:
+                    k, _, v = line.strip().partition(" ")
+                    if v.strip().lstrip("-").isdigit():
+                        props[k] = int(v)
+        except OSError:
+            continue
+        if props.get("simd_count", 0) <= 0:
+            continue
+        loc, dom = props.get("location_id", 0), props.get("domain", 0)
+        out.append(f"{dom:04x}:{(loc >> 8) & 0xff:02x}:{(loc >> 3) & 0x1f:02x}.{loc & 7}")
+    return out
+
+
+def visible_gpu_bdfs(sysfs_root: str = "/sys", env=None) -> List[str]:
+    """`kfd_gpu_bdfs` filtered the way the runtime will filter the devices of a child process: ROCR_VISIBLE_DEVICES first (it
+    renumbers the agents), then HIP_VISIBLE_DEVICES / CUDA_VISIBLE_DEVICES on the renumbered list.  Only integer lists are
+    interpreted (UUID entries leave the list as it is); an empty string hides every GPU, as in the runtime."""
+    env = os.environ if env is None else env
+    gpus = kfd_gpu_bdfs(sysfs_root)
+    for var in ("ROCR_VISIBLE_DEVICES", "HIP_VISIBLE_DEVICES"):
+        val = env.get(var)
+        if val is None and var == "HIP_VISIBLE_DEVICES":
+            val = env.get("CUDA_VISIBLE_DEVICES")
+        if val is None:
+            continue
+        parts = [p.strip() for p in val.split(",") if p.strip() != ""]
+        if val.strip() == "":
+            return []
+        if not all(p.lstrip("-").isdigit() for p in parts):
+            continue
+        picked = []
+        for p in parts:
+            j = int(p)
+            if j < 0 or j >= len(gpus):
+                break                                          # the runtime stops at the first invalid index
+            picked.append(gpus[j])
+        gpus = picked
+    return gpus
+
+
+def launch_ranks(commands, rank0_stdout_sink, poll_s: float = 0.2, grace_s: float = 600.0, popen=None):
+    """Run the per-rank (command, environment) list of `rank_commands` as child processes and supervise ALL of them: rank 0's
+    stdout is drained by a reader thread into `rank0_stdout_sink` (a list of byte chunks; the JSON line), every child is polled, and the
+    FIRST non-zero exit of ANY rank terminates the others at once (a rank that dies early would otherwise leave its peers in
+    `init_process_group` / a barrier until the collective timeout).  After rank 0 has finished cleanly the others get `grace_s`
+    more seconds (they only have the closing barrier and teardown left).  Returns the exit code: 0, the first failing rank's
+    code, or 124 for a rank killed after the grace period."""
+    import subprocess
+    import sys
+    import threading
+    import time
+    popen = popen or subprocess.Popen
+    procs = []
+    for rank, (cmd, env) in enumerate(commands):
+        procs.append(popen(cmd, env=env, stdout=subprocess.PIPE if rank == 0 else sys.stderr))
+
+    def drain():
+        while True:
+            chunk = procs[0].stdout.read(65536)
+            if not chunk:
+                break
+            rank0_stdout_sink.append(chunk)
+    reader = threading.Thread(target=drain, daemon=True)
+    reader.start()
+    rc, t_rank0_done = 0, None
+    try:
+        while True:
+            codes = [p.poll() for p in procs]
+            bad = [(r, c) for r, c in enumerate(codes) if c not in (None, 0)]
+            if bad:
+                rc = bad[0][1]
+                print(f"launch_ranks: rank {bad[0][0]} exited with code {rc}; terminating the other ranks", file=sys.stderr)
+                break
+            if all(c == 0 for c in codes):
+                break
+            if codes[0] == 0:
+                t_rank0_done = t_rank0_done or time.monotonic()
+                if time.monotonic() - t_rank0_done > grace_s:
+                    rc = 124
+                    print(f"launch_ranks: ranks {[r for r, c in enumerate(codes) if c is None]} still running {grace_s:.0f} s after rank 0 "
+                          "finished; killing them", file=sys.stderr)
+                    break
+            time.sleep(poll_s)
+    finally:
+        for p in procs:
+            if p.poll() is None:
+                p.terminate()
+        for p in procs:
+            try:
+                p.wait(timeout=10)
+            except subprocess.TimeoutExpired:
+                p.kill()
+                p.wait()
+        reader.join(timeout=10)
+    return rc
+
+
 def parse_cpulist(text: str) -> List[int]:
     """'0-3,8,10-11' (sysfs cpulist) -> [0, 1, 2, 3, 8, 10, 11]."""
     cores = []

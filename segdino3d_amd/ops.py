@@ -1196,6 +1196,71 @@ def expand_masks(sig, src_row, superpoints, points, sp_thr, boxes=None, loose_ra
     return out, count
 
 
+def pack_mask_rows(masks_u8, rows=None):
+    """masks_u8 [n, N] uint8 (0 / 1) -> bit-packed uint8 [len(rows) | n, ceil(N / 8)] of the selected rows (int32 `rows`, or all):
+    bit j of byte b = masks[row][8 b + j] (numpy bitorder "little").  The device half of the host-output path."""
+    lib = _lib.load()
+    n, N = masks_u8.shape
+    n_rows = n if rows is None else rows.numel()
+    nb = (N + 7) // 8
+    out = torch.empty(n_rows, nb, dtype=torch.uint8, device=masks_u8.device)
+    _lib.check(lib.sd3d_pack_mask_rows(_ptr(masks_u8, torch.uint8, "masks"), N, _ptr(rows, torch.int32, "rows"), n_rows, _ptr(out), nb,
+                                       _stream()), "pack_mask_rows")
+    return out
+
+
+def unpack_bits_host(packed, n_points: int):
+    """HOST arrays: packed uint8 [n, ceil(N / 8)] (numpy) -> bool [n, N] (a fresh pageable array).  Runs in the C library with the
+    GIL released (sd3d_unpack_bits_host): the other scene threads keep issuing while this one expands its masks."""
+    import numpy as np
+    packed = np.ascontiguousarray(packed, dtype=np.uint8)
+    n, nb = packed.shape
+    if nb != (n_points + 7) // 8:
+        raise ValueError(f"unpack_bits_host: {nb} bytes per row cannot hold {n_points} points")
+    out = np.empty((n, n_points), dtype=np.bool_)
+    _lib.check(_lib.load_nogil().sd3d_unpack_bits_host(packed.ctypes.data, n, n_points, nb, out.ctypes.data), "unpack_bits_host")
+    return out
+
+
+class PinnedStaging:
+    """One grow-only pinned host buffer per (host thread): the staging area of a forward's device -> host copies.  The outputs
+    handed to the caller are pageable copies made from it, so nothing page-locked outlives the forward (a long evaluation keeps
+    every scene's outputs until `evaluate()`: ~100 MB of pinned memory per scene otherwise)."""
+
+    def __init__(self):
+        self._tls = threading.local()
+
+    def get(self, nbytes: int):
+        buf = getattr(self._tls, "buf", None)
+        if buf is None or buf.numel() < nbytes:
+            buf = self._tls.buf = torch.empty(max(int(nbytes), 1 << 20), dtype=torch.uint8, pin_memory=True)
+        return buf
+
+
+_STAGING = PinnedStaging()
+
+
+def to_host_arrays(tensors):
+    """Device tensors -> pageable numpy arrays through ONE pinned staging buffer: asynchronous copies, one polled wait (the issue
+    baton goes to another scene's thread meanwhile), then host copies out of the staging area."""
+    import numpy as np
+    offs, total = [], 0
+    for t in tensors:
+        total = (total + 63) // 64 * 64
+        offs.append(total)
+        total += t.numel() * t.element_size()
+    stage = _STAGING.get(total)
+    views = []
+    for t, o in zip(tensors, offs):
+        nb = t.numel() * t.element_size()
+        v = stage[o:o + nb].view(t.dtype).view(t.shape) if nb else torch.empty(t.shape, dtype=t.dtype)
+        if nb:
+            v.copy_(t.contiguous(), non_blocking=True)
+        views.append(v)
+    wait_event(stream_event())
+    return [np.array(v.numpy(), copy=True) for v in views]
+
+
 def row_argmax(x, ncols=None, cols=None):
     lib = _lib.load()
     px, ld = _rows(x, "x")

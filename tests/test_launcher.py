@@ -113,3 +113,70 @@ def test_dense_plan_code_is_a_host_function():
     assert ops.dense_code(200, 256, 256) == -1 and ops.dense_code(200, 1024, 256) == -1
     assert ops.dense_code(200, 96, 256) == 1                      # 3 chunks of 32: no split
     assert ops.dense_code(340, 256, 3072) == 1 and ops.dense_code(301, 256, 3072) == -1
+
+
+def _fake_kfd(tmp_path, nodes):
+    """nodes: list of (simd_count, domain, location_id)."""
+    for i, (simd, dom, loc) in enumerate(nodes):
+        d = tmp_path / "class" / "kfd" / "kfd" / "topology" / "nodes" / str(i)
+        d.mkdir(parents=True)
+        (d / "properties").write_text(f"cpu_cores_count {0 if simd else 64}\nsimd_count {simd}\ndomain {dom}\nlocation_id {loc}\nname x\n")
+    return str(tmp_path)
+
+
+def test_gpus_are_counted_from_sysfs_without_hip(tmp_path):
+    """The launcher parent counts GPUs from the KFD topology: CPU agents (simd_count 0) are skipped, the PCI
+    address is decoded from location_id, and the *_VISIBLE_DEVICES filters apply in the runtime's order."""
+    from segdino3d_amd.dist_eval import kfd_gpu_bdfs, visible_gpu_bdfs
+    root = _fake_kfd(tmp_path, [(0, 0, 0), (0, 0, 0), (1024, 0, 0x0500), (1024, 0, 0x1500), (1024, 1, 0x8508), (1024, 0, 0xa500)])
+    assert kfd_gpu_bdfs(root) == ["0000:05:00.0", "0000:15:00.0", "0001:85:01.0", "0000:a5:00.0"]
+    assert visible_gpu_bdfs(root, env={}) == kfd_gpu_bdfs(root)
+    assert visible_gpu_bdfs(root, env={"HIP_VISIBLE_DEVICES": "2,0"}) == ["0001:85:01.0", "0000:05:00.0"]
+    assert visible_gpu_bdfs(root, env={"ROCR_VISIBLE_DEVICES": "1,2,3", "HIP_VISIBLE_DEVICES": "0,2"}) == ["0000:15:00.0", "0000:a5:00.0"]
+    assert visible_gpu_bdfs(root, env={"CUDA_VISIBLE_DEVICES": "1"}) == ["0000:15:00.0"]
+    assert visible_gpu_bdfs(root, env={"HIP_VISIBLE_DEVICES": ""}) == []
+    assert visible_gpu_bdfs(root, env={"HIP_VISIBLE_DEVICES": "0,9,1"}) == ["0000:05:00.0"]          # stops at the first invalid index
+    assert visible_gpu_bdfs(root, env={"ROCR_VISIBLE_DEVICES": "GPU-abcdef"}) == kfd_gpu_bdfs(root)   # UUIDs are not interpreted
+    assert kfd_gpu_bdfs(str(tmp_path / "nothing")) == []
+
+
+def test_bench_parent_does_not_import_a_gpu_count_from_torch():
+    """`launch_ranks` / `pin_rank_to_cores` in bench.py must not call torch.cuda.* (the parent stays GPU-free; a rank only touches ITS GPU)."""
+    import ast
+    src = open(os.path.join(ROOT, "bench.py")).read()
+    tree = ast.parse(src)
+    for fn in tree.body:
+        if isinstance(fn, ast.FunctionDef) and fn.name in ("launch_ranks", "pin_rank_to_cores"):
+            body = ast.get_source_segment(src, fn)
+            assert "torch.cuda" not in body.split('"""')[2], fn.name
+
+
+def test_launch_ranks_takes_every_rank_down_when_one_fails():
+    """Rank 3 of 8 exits non-zero while the others sit in a (simulated) collective: the parent notices within a poll interval,
+    terminates the other seven, relays what rank 0 printed, and returns rank 3's code (bench.py:243)."""
+    import time
+    from segdino3d_amd.dist_eval import launch_ranks
+    sleeper = "import sys, time; print('rank0 line', flush=True); time.sleep(120)"
+    cmds = []
+    for r in range(8):
+        code = "import sys, time; time.sleep(0.5); sys.exit(7)" if r == 3 else sleeper
+        cmds.append(([sys.executable, "-c", code], dict(os.environ)))
+    sink, t0 = [], time.monotonic()
+    rc = launch_ranks(cmds, sink, poll_s=0.05)
+    dt = time.monotonic() - t0
+    assert rc == 7
+    assert dt < 30, dt                                            # not the sleepers' 120 s
+    assert b"rank0 line" in b"".join(sink)
+
+
+def test_launch_ranks_success_and_grace_period():
+    import time
+    from segdino3d_amd.dist_eval import launch_ranks
+    ok = [([sys.executable, "-c", f"print('{{\"n_gpus\": 2}}') if {r} == 0 else None"], dict(os.environ)) for r in range(2)]
+    sink = []
+    assert launch_ranks(ok, sink, poll_s=0.05) == 0 and b"n_gpus" in b"".join(sink)
+    # rank 1 hangs after rank 0 finished: killed after the grace period, reported as 124
+    hang = [([sys.executable, "-c", "pass"], dict(os.environ)), ([sys.executable, "-c", "import time; time.sleep(120)"], dict(os.environ))]
+    t0 = time.monotonic()
+    assert launch_ranks(hang, [], poll_s=0.05, grace_s=1.0) == 124
+    assert time.monotonic() - t0 < 30
