@@ -273,6 +273,60 @@ int sd3d_run_layers(const sd3d_layer* layers, int n_layers, const sd3d_table* ta
  * Decoder kernels (segdino3d/models/decoder/instance_seg_3d_decoder.py:606-799,
  * segdino3d/models/module/attention.py:186-395, segdino3d/models/module/utils.py:53-105)
  * ------------------------------------------------------------------------------------------- */
+/* ---- Row-chain executor (csrc/rowchain.hip): the row-local part of a decoder layer as ONE launch ------------------------------
+ * Replaces the per-op launches of instance_seg_3d_decoder.py:606-799 between the superpoint cross-attention and the mask-logit
+ * product: a workgroup owns 16 consecutive query rows of one scene, keeps their activations in LDS slots ([16][260] fp32 each; a
+ * buffer wider than 256 columns has row stride width + 4 and spills into the following slots) and interprets `ops` over them.
+ * All pointers are device pointers; global tensors hold the query rows of ALL scenes of the call back to back (row = scene.q0 +
+ * row in scene).  Slot 0xFF = "none".  Per row the arithmetic does not depend on the other rows of the launch. */
+#define SD3D_RC_MAX_OPS 44
+#define SD3D_RC_MAX_PROGRAMS 4
+enum { SD3D_RC_LOAD = 1,   /* slot dst[:, :cout] = p0[row, :cout] (row stride ld) */
+       SD3D_RC_STORE = 2,  /* p0[row, :cout] = slot src0 */
+       SD3D_RC_LINEAR = 3, /* dst = act([src0 (k0 ch) | src1 (k1 ch)] . W^T + bias (+ res)); p0 = W [cout, k0 + k1], p1 = bias | NULL,
+                            * p2 = optional global copy (row stride ld); flag NO_LDS_DST: only the global copy */
+       SD3D_RC_LN = 4,     /* dst = act(LayerNorm_256(src0 (+ res)) * p0 + p1), eps = f0; p2 = optional global copy (ld) */
+       SD3D_RC_PE = 5,     /* dst = sine PE (utils.py:53-105) of p0[row, 0:3] in the scene's range; p1 = dim_t [256], p2 = axis int8 [256];
+                            * src0 != none: times slot src0[:, a] / p3[row, a] (box modulation, :659-666) */
+       SD3D_RC_BOX = 6,    /* box refinement (:735-759): p2[row] = p0[row] + src0[:, 0:3]; with src1: size p3 / metric size p4 from p1 (previous
+                            * size) and src1[:, 0:3]; flag NORMALIZE */
+       SD3D_RC_MERGE = 7,  /* dst = rows of the superpoint cross-attention: p1 (its output, stride ld) where the scene's key split is 1, else
+                            * the combination of its partial states p0 + scene.part_off (sd3d_attention_parts) */
+       SD3D_RC_BITS2D = 8, /* LDS bit rows: blocked2d = no superpoint open for the query (p0 + scene.bits_off: blocked bits [nq, nw]) and near
+                            * the 2D query (p1 + scene.near_off: [nm - 1, nw]) (:722-726) */
+       SD3D_RC_ATTN = 9    /* dst = 8-head attention (32 channels per head) of slot src0 over the scene's keys: K = p0, V = p1 (row stride ld),
+                            * key rows scene.q0.. (nq) or, flag KEYS_2D, scene.m0.. (nm); flag MASK_BITS2D: the LDS bit rows; scale f0;
+                            * aux = first of two scratch slots */ };
+#define SD3D_RC_F_NO_LDS_DST 1
+#define SD3D_RC_F_NORMALIZE 2
+#define SD3D_RC_F_KEYS_2D 4
+#define SD3D_RC_F_MASK_BITS2D 8
+typedef struct sd3d_rc_op {
+    uint8_t type, act, src0, src1, dst, res, flag, aux;
+    uint16_t k0, k1, cout, pad_;
+    int32_t ld;
+    float f0;
+    const void *p0, *p1, *p2, *p3, *p4;
+} sd3d_rc_op;                                                  /* 64 bytes */
+typedef struct sd3d_rc_scene {
+    int32_t q0, nq;                                            /* first query row, number of query rows */
+    int32_t m0, nm;                                            /* 2D keys: first row, count (incl. the appended dummy key) */
+    int32_t bits_off, nw;                                      /* blocked bits of the scene: offset in words, words per row */
+    int32_t near_off, ksplit;                                  /* near table offset in words; key split of the cross-attention */
+    int64_t part_off;                                          /* offset (floats) of the scene's partial attention states */
+} sd3d_rc_scene;                                               /* 40 bytes */
+typedef struct sd3d_rc_program {
+    int32_t n_scenes, n_programs, n_slots, nw_max, nw2_max, pad_;
+    const float* rng;                                          /* [n_scenes][6] scene ranges (lo, hi) for PE / BOX */
+    int32_t tile0[SD3D_MAX_BATCH + 1];                         /* prefix sums of ceil(nq / 16) */
+    int32_t prog_begin[SD3D_RC_MAX_PROGRAMS + 1];              /* op ranges of the programs (gridDim.y) */
+    sd3d_rc_scene scenes[SD3D_MAX_BATCH];
+    sd3d_rc_op ops[SD3D_RC_MAX_OPS];
+} sd3d_rc_program;
+/* program_host: HOST pointer to the program (passed to the kernel by value). */
+int sd3d_row_chain(const sd3d_rc_program* program_host, void* stream);
+size_t sd3d_row_chain_program_bytes(void);                     /* sizeof(sd3d_rc_program): bindings check their layout against it */
+
 /* out = act(LayerNorm(x + res) * w + b); nn.LayerNorm (+ the residual adds at decoder :690-691,
  * :708-709, :82-84, :187-188).  act: 0 none, 1 ReLU (input_proj, :228-229). */
 int sd3d_layernorm(const float* x, int ld_x, const float* res, int ld_res, const float* w, const float* b, float eps,
@@ -328,6 +382,11 @@ typedef struct sd3d_attn_job {
     int32_t ldq0, ldq1, ldk0, ldk1, ldv, ldo, Lq, Lk;
 } sd3d_attn_job;
 int sd3d_attention_batch(int n, const sd3d_attn_job* jobs, int H, float scale, int bf16, void* ws, size_t ws_bytes, void* stream);
+/* The same launch WITHOUT the pass that combines the key splits (its consumer does: sd3d_row_chain MERGE): on return scene i's rows
+ * are final in its `out` where ksplit_out_host[i] == 1, and otherwise wait as partial softmax states [ceil(Lq/32)][H][ksplit][64 + 1024]
+ * (m[32], l[32], O[32 dv][32 q], log2 domain) at ws + part_off_out_host[i] floats. */
+int sd3d_attention_batch_parts(int n, const sd3d_attn_job* jobs, int H, float scale, int bf16, void* ws, size_t ws_bytes,
+                               int32_t* ksplit_out_host, int64_t* part_off_out_host, void* stream);
 /* _forward_head mask part (:567-572): bits = sigmoid(logits) < thr, dead rows reset to open. */
 int sd3d_mask_bits(const float* logits, int ld, int64_t Q, int S, float thr, uint32_t* bits, int nwords, void* stream);
 /* (dist < thr) of torch.cdist(p=1) (:721) as bits near[M, ceil(S/32)]. */

@@ -83,6 +83,9 @@ SIGNATURES = {
     "sd3d_mask_scores": (_i, [_p, _i, _i, _p, _p, _i, _i, _i, _p, _p, _p, _p]),
     "sd3d_gather_sigmoid": (_i, [_p, _i, _i, _p, _p, _i, _p, _i, _p, _p]),
     "sd3d_nms_decay": (_i, [_p, _i, _p, _p, _i, _i, _f, _p, _p, _p, _p]),
+    "sd3d_row_chain": (_i, [_p, _p]),
+    "sd3d_row_chain_program_bytes": (_z, []),
+    "sd3d_attention_batch_parts": (_i, [_i, _p, _i, _f, _i, _p, _z, _p, _p, _p]),
     "sd3d_pack_mask_rows": (_i, [_p, _l, _p, _i, _p, _l, _p]),
     "sd3d_unpack_bits_host": (_i, [_p, _l, _l, _l, _p]),
     "sd3d_expand_masks_ws_bytes": (_z, [_i, _i]),

@@ -20,6 +20,7 @@ int launch_f32_to_sortkey(const float*, int64_t, int, uint64_t*, hipStream_t);
 int launch_i64_to_sortkey(const int64_t*, int64_t, uint64_t*, hipStream_t);
 int launch_scene_stats(const float*, int, int64_t, float*, void*, size_t, hipStream_t);
 int launch_pack_mask_rows(const uint8_t*, int64_t, const int32_t*, int, uint8_t*, int64_t, hipStream_t);
+int launch_row_chain(const sd3d_rc_program*, hipStream_t);
 size_t unique_ws_bytes(int64_t);
 int launch_unique_sorted(const uint64_t*, const uint32_t*, int64_t, const int*, int, uint64_t*, int32_t*, int32_t*, int32_t*,
                          void*, size_t, const float*, float, int, int, hipStream_t);
@@ -72,11 +73,11 @@ struct AttnParams {
     float* lse;
 };
 size_t attention_ws_bytes(int Lq, int H);
-int launch_attention_batch(int, const AttnParams*, int, void*, size_t, hipStream_t);
+int launch_attention_batch(int, const AttnParams*, int, void*, size_t, hipStream_t, int32_t* = nullptr, int64_t* = nullptr);
 int launch_mask_bits_batch(int, const float* const*, const int*, const int64_t*, const int*, uint32_t* const*, const int*, float, hipStream_t);
 int launch_dinox_mask_bits_batch(int, const uint32_t* const*, const uint32_t* const*, const int*, const int64_t*, const int64_t*,
                                  uint32_t* const*, const int*, hipStream_t);
-int launch_attention(const AttnParams&, int, void*, size_t, hipStream_t);
+int launch_attention(const AttnParams&, int, void*, size_t, hipStream_t, bool = true);
 int launch_mask_bits(const float*, int, int64_t, int, float, uint32_t*, int, hipStream_t);
 int launch_near_bits(const float*, int64_t, const float*, int64_t, float, uint32_t*, int, hipStream_t);
 int launch_dinox_mask_bits(const uint32_t*, const uint32_t*, int, int64_t, int64_t, uint32_t*, int, hipStream_t);
@@ -293,7 +294,18 @@ int sd3d_sine_pe_rows(const float* xyz, int ld_xyz, int64_t n, const float* rang
     if (mod_num && !mod_den) return sd3d_set_error(SD3D_ERR_ARG, "sine_pe_rows: mod_den missing");
     return launch_sine_pe(xyz, ld_xyz, n, ranges, dim_t, axis, d_pos, mod_num, ld_num, mod_den, ld_den, out, ld_out, row_scene, ST);
 }
+static int attention_batch_impl(int n, const sd3d_attn_job* jobs, int H, float scale, int bf16, void* ws, size_t ws_bytes, void* stream,
+                                int32_t* ksplit_out, int64_t* part_off_out);
 int sd3d_attention_batch(int n, const sd3d_attn_job* jobs, int H, float scale, int bf16, void* ws, size_t ws_bytes, void* stream) {
+    return attention_batch_impl(n, jobs, H, scale, bf16, ws, ws_bytes, stream, nullptr, nullptr);
+}
+int sd3d_attention_batch_parts(int n, const sd3d_attn_job* jobs, int H, float scale, int bf16, void* ws, size_t ws_bytes,
+                               int32_t* ksplit_out_host, int64_t* part_off_out_host, void* stream) {
+    if (!ksplit_out_host || !part_off_out_host) return sd3d_set_error(SD3D_ERR_ARG, "attention_batch_parts: output arrays missing");
+    return attention_batch_impl(n, jobs, H, scale, bf16, ws, ws_bytes, stream, ksplit_out_host, part_off_out_host);
+}
+static int attention_batch_impl(int n, const sd3d_attn_job* jobs, int H, float scale, int bf16, void* ws, size_t ws_bytes, void* stream,
+                                int32_t* ksplit_out, int64_t* part_off_out) {
     if (n <= 0) return SD3D_OK;
     if (n > SD3D_MAX_BATCH || !jobs) return sd3d_set_error(SD3D_ERR_ARG, "attention_batch: 1..16 jobs");
     AttnParams p[SD3D_MAX_BATCH];
@@ -306,7 +318,7 @@ int sd3d_attention_batch(int n, const sd3d_attn_job* jobs, int H, float scale, i
         p[i].v = j.v; p[i].ldv = j.ldv; p[i].bits = j.mask_bits; p[i].nwords = (j.Lk + 31) / 32; p[i].out = j.out; p[i].ldo = j.ldo;
         p[i].Lq = j.Lq; p[i].Lk = j.Lk; p[i].H = H; p[i].scale = scale; p[i].ksplit = 1; p[i].part = nullptr; p[i].bf16 = bf16 ? 1 : 0; p[i].lse = nullptr;
     }
-    return launch_attention_batch(n, p, two ? 2 : 1, ws, ws_bytes, ST);
+    return launch_attention_batch(n, p, two ? 2 : 1, ws, ws_bytes, ST, ksplit_out, part_off_out);
 }
 int sd3d_mask_bits_batch(int n, const float* const* logits, const int* ld, const int64_t* Q, const int* S, uint32_t* const* bits,
                          const int* nwords, float thr, void* stream) {
@@ -402,6 +414,8 @@ int sd3d_expand_masks(const float* sig, int ld_sig, const uint32_t* src_row, int
     return launch_expand_masks(sig, ld_sig, src_row, n, superpoints, points, ld_points, N, sp_thr, boxes, loose_ratio, out, count, ws,
                                ws_bytes, ST);
 }
+int sd3d_row_chain(const sd3d_rc_program* program_host, void* stream) { return launch_row_chain(program_host, ST); }
+size_t sd3d_row_chain_program_bytes(void) { return sizeof(sd3d_rc_program); }
 int sd3d_pack_mask_rows(const uint8_t* masks, int64_t N, const int32_t* rows, int n_rows, uint8_t* out, int64_t nb, void* stream) {
     return launch_pack_mask_rows(masks, N, rows, n_rows, out, nb, ST);
 }

@@ -539,7 +539,7 @@ static void attention_config(int Lq, int Lk, int H, bool have_ws, size_t ws_byte
     *nw_out = nw; *ks_out = ks;
 }
 
-int launch_attention(const AttnParams& p_in, int nsrc, void* ws, size_t ws_bytes, hipStream_t st) {
+int launch_attention(const AttnParams& p_in, int nsrc, void* ws, size_t ws_bytes, hipStream_t st, bool merge = true) {
     AttnParams p = p_in;
     if (p.Lq <= 0 || p.Lk <= 0) return sd3d_set_error(SD3D_ERR_ARG, "attention: empty query or key set");
     for (int s = 0; s < nsrc; ++s)
@@ -555,7 +555,7 @@ int launch_attention(const AttnParams& p_in, int nsrc, void* ws, size_t ws_bytes
     else if (nsrc == 1) hipLaunchKernelGGL((attention_kernel<1, true>), grid, block, sm, st, p);
     else if (nsrc == 2) hipLaunchKernelGGL((attention_kernel<2, true>), grid, block, sm, st, p);
     else return sd3d_set_error(SD3D_ERR_ARG, "attention: nsrc must be 1 or 2");
-    if (ks > 1) hipLaunchKernelGGL(attention_merge_kernel, dim3((unsigned)cdiv(p.Lq, 32), (unsigned)p.H), dim3(256), 0, st, p);
+    if (ks > 1 && merge) hipLaunchKernelGGL(attention_merge_kernel, dim3((unsigned)cdiv(p.Lq, 32), (unsigned)p.H), dim3(256), 0, st, p);
     SD3D_CHECK_LAUNCH();
     return SD3D_OK;
 }
@@ -563,8 +563,13 @@ int launch_attention(const AttnParams& p_in, int nsrc, void* ws, size_t ws_bytes
 // n <= SD3D_MAX_BATCH independent attentions (same heads, scale, sources, arithmetic type) in one launch - when every scene's own launch
 // would use the same number of waves per workgroup; otherwise one launch per scene.  Scene i's split workspace is
 // attention_ws_bytes(Lq_i, H) bytes, back to back in ws.
-int launch_attention_batch(int n, const AttnParams* jobs, int nsrc, void* ws, size_t ws_bytes, hipStream_t st) {
+// ksplit_out / part_off_out (host arrays of n entries, optional): the launch then STOPS after the key-split pass - scene i's rows are
+// final in its `out` where ksplit_out[i] == 1 and otherwise wait as partial softmax states at ws + part_off_out[i] floats for the
+// consumer that combines them (rowchain.hip MERGE: the expression of attention_merge_body).
+int launch_attention_batch(int n, const AttnParams* jobs, int nsrc, void* ws, size_t ws_bytes, hipStream_t st, int32_t* ksplit_out = nullptr,
+                           int64_t* part_off_out = nullptr) {
     if (n <= 0) return SD3D_OK;
+    const bool merge = ksplit_out == nullptr;
     if (n > SD3D_MAX_BATCH) return sd3d_set_error(SD3D_ERR_ARG, "attention_batch: at most 16 scenes per call");
     AttnBatch b;
     b.n = n;
@@ -589,11 +594,15 @@ int launch_attention_batch(int n, const AttnParams* jobs, int nsrc, void* ws, si
         b.tile0[i] = tiles;
         tiles += (int)cdiv(p.Lq, 32);
         b.s[i] = p;
+        if (!merge) {
+            ksplit_out[i] = ks;
+            if (part_off_out) part_off_out[i] = have ? (int64_t)((off - need) / sizeof(float)) : 0;
+        }
     }
     b.tile0[n] = tiles;
     if (!same) {                                               // different workgroup shapes: each scene its own launch (same results)
         for (int i = 0; i < n; ++i) {
-            const int rc = launch_attention(jobs[i], nsrc, b.s[i].part, b.s[i].part ? attention_ws_bytes(jobs[i].Lq, jobs[i].H) : 0, st);
+            const int rc = launch_attention(jobs[i], nsrc, b.s[i].part, b.s[i].part ? attention_ws_bytes(jobs[i].Lq, jobs[i].H) : 0, st, merge);
             if (rc != SD3D_OK) return rc;
         }
         return SD3D_OK;
@@ -606,7 +615,7 @@ int launch_attention_batch(int n, const AttnParams* jobs, int nsrc, void* ws, si
     else if (nsrc == 1) hipLaunchKernelGGL((attention_batch_kernel<1, true>), grid, block, sm, st, b);
     else if (nsrc == 2) hipLaunchKernelGGL((attention_batch_kernel<2, true>), grid, block, sm, st, b);
     else return sd3d_set_error(SD3D_ERR_ARG, "attention_batch: nsrc must be 1 or 2");
-    if (ks_max > 1) hipLaunchKernelGGL(attention_merge_batch_kernel, dim3((unsigned)tiles, (unsigned)b.s[0].H), dim3(256), 0, st, b);
+    if (ks_max > 1 && merge) hipLaunchKernelGGL(attention_merge_batch_kernel, dim3((unsigned)tiles, (unsigned)b.s[0].H), dim3(256), 0, st, b);
     SD3D_CHECK_LAUNCH();
     return SD3D_OK;
 }

@@ -1,0 +1,576 @@
+// Row-chain executor: the decoder's row-local work as a few fat launches instead of ~25 thin ones per layer
+// (reference: segdino3d/models/decoder/instance_seg_3d_decoder.py:606-799 - per layer {positional query, masked cross-attention,
+//  self-attention, 2D-query cross-attention, FFN, box refinement, head}; VERDICT r1-r3 "one persistent kernel per decoder layer").
+//
+// Everything in a decoder layer except (a) the superpoint cross-attention and (b) the mask-logit product couples only the
+// channels of ONE query row (Linear, LayerNorm, positional encoding, box refinement) or one query row with a few hundred
+// layer-invariant keys (self-attention over the scene's queries, attention over the 2D object queries, the boolean
+// mask x distance product).  A workgroup of 16 waves therefore OWNS 16 consecutive query rows of one scene, keeps their
+// activations in LDS "slots" ([16][260] fp32, row stride padded by 4 floats: conflict-free ds_read_b128) and interprets a
+// small program (RCOp list, passed by value in the kernel arguments) over them:
+//
+//   LOAD / STORE   slot <-> global rows
+//   LINEAR         dst = act(src . W^T + b (+ res)), src = one or two slots (concatenated channels), W straight from L2:
+//                  wave w owns the 16-column tiles {w, w + 16, ...}; v_mfma_f32_16x16x4_f32, A = the 16 rows (LDS), B = W rows
+//                  (global, requested a 16-MFMA block ahead); exact fp32, fixed summation order (channel ascending)
+//   LN             dst = act(LayerNorm(src (+ res)) * g + b), wave w = row w, two-pass statistics
+//   PE             (box-modulated) sine positional encoding of the rows' reference points (utils.py:53-105)
+//   BOX            iterative box refinement (:735-759)
+//   MERGE          gathers the rows of the key-split superpoint cross-attention (dense.hip attention_body partial states)
+//   BITS2D         blocked2d[q][m] = no superpoint both open for q and near 2D query m (:722-726), into LDS bit rows
+//   ATTN           multi-head attention of the 16 rows over <= a few thousand keys of their scene (K / V from global, L2-resident):
+//                  wave = (head, key half); S^T = K Q^T per 16-key tile puts a query in a lane column, online softmax in the
+//                  log2 domain, O^T += V^T P^T with the probability registers as B operand; the two key halves meet in LDS
+//
+// One barrier after every op.  A row's arithmetic never depends on which other rows share its tile or its launch, so the
+// rows of several scenes in one launch (a batched evaluation forward) get the bits of their own single-scene launch.
+// gridDim.y selects one of up to 4 independent programs over the same rows (e.g. the class head of the previous layer next
+// to the positional-query chain of this one): they run on different CUs at the same time.
+#include "common.h"
+#include "../../include/segdino3d_hip.h"
+
+#define RC_R 16
+#define RC_LDW 260
+#define RC_SLOT (RC_R * RC_LDW)
+#define RC_LOG2E 1.4426950408889634f
+
+typedef sd3d_rc_op RCOp;
+typedef sd3d_rc_scene RCScene;
+typedef sd3d_rc_program RCProgram;
+
+__device__ __forceinline__ int rc_ld(int width) { return width <= 256 ? RC_LDW : width + 4; }
+
+__device__ __forceinline__ float rc_wsum(float v) {
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) v += __shfl_xor(v, d);
+    return v;
+}
+
+__device__ __forceinline__ float rc_act(float y, int act) {
+    if (act == 1) return fmaxf(y, 0.f);
+    if (act == 2) return 0.5f * y * (1.f + erff(y * 0.70710678118654752440f));
+    if (act == 3) return 1.f / (1.f + expf(-y));
+    return y;
+}
+
+struct RCCtx {
+    float* lds;            // slots
+    uint32_t* bits2d;      // [16][nw2_max]
+    uint32_t* open_w;      // [16][nw_max]
+    int nw2_max, nw_max;
+    int row0;              // first global query row of this tile
+    int nrows;             // valid rows of the tile (1..16)
+    int scene;             // scene index
+};
+
+// ------------------------------------------------------------------------------------------------ LINEAR
+// acc[t][i] = out[row 4 kq + i][col (wave + 16 t) * 16 + c16]
+template <int NT, int GB>
+__device__ __forceinline__ void rc_linear_body(const RCOp& op, const RCCtx& cx, f32x4 (&acc)[NT]) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int c16 = lane & 15, kq = lane >> 4;
+    const int K0 = op.k0, K = op.k0 + op.k1, Cout = op.cout;
+    const float* __restrict__ W = (const float*)op.p0;
+    const float* a0 = cx.lds + op.src0 * RC_SLOT + c16 * rc_ld(op.k0) + 4 * kq;
+    const float* a1 = cx.lds + op.src1 * RC_SLOT + c16 * rc_ld(op.k1) + 4 * kq - K0;     // indexed by the global channel
+    const float* wrow[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+        int col = (wave + 16 * t) * 16 + c16;
+        col = col < Cout ? col : Cout - 1;
+        wrow[t] = W + (int64_t)col * K + 4 * kq;
+        acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+    const int nb = (K >> 4) / GB;
+    f32x4 cur[GB][NT], nxt[GB][NT];
+#pragma unroll
+    for (int g = 0; g < GB; ++g)
+#pragma unroll
+        for (int t = 0; t < NT; ++t) cur[g][t] = *(const f32x4*)(wrow[t] + 16 * g);
+    for (int b = 0; b < nb; ++b) {
+        const int ch0 = b * GB * 16;
+        if (b + 1 < nb) {
+#pragma unroll
+            for (int g = 0; g < GB; ++g)
+#pragma unroll
+                for (int t = 0; t < NT; ++t) nxt[g][t] = *(const f32x4*)(wrow[t] + ch0 + 16 * (GB + g));
+        }
+        f32x4 a[GB];
+#pragma unroll
+        for (int g = 0; g < GB; ++g) {
+            const int ch = ch0 + 16 * g;
+            a[g] = *(const f32x4*)((ch < K0 ? a0 : a1) + ch);
+        }
+#pragma unroll
+        for (int g = 0; g < GB; ++g)
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+#pragma unroll
+                for (int t = 0; t < NT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[g][e], cur[g][t][e], acc[t], 0, 0, 0);
+#pragma unroll
+        for (int g = 0; g < GB; ++g)
+#pragma unroll
+            for (int t = 0; t < NT; ++t) cur[g][t] = nxt[g][t];
+    }
+}
+
+template <int NT, int GB>
+__device__ __forceinline__ void rc_linear(const RCOp& op, const RCCtx& cx) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int c16 = lane & 15, kq = lane >> 4;
+    f32x4 acc[NT];
+    rc_linear_body<NT, GB>(op, cx, acc);
+    __syncthreads();                                          // every wave has read its inputs: dst may alias a source
+    const int Cout = op.cout;
+    const float* __restrict__ bias = (const float*)op.p1;
+    const int ldd = rc_ld(Cout);
+    float* dst = cx.lds + op.dst * RC_SLOT;
+    const float* res = op.res != 0xFF ? cx.lds + op.res * RC_SLOT : nullptr;
+    float* gout = (float*)op.p2;                              // optional global copy of the result (rows of this tile)
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+        const int col = (wave + 16 * t) * 16 + c16;
+        if (col >= Cout) continue;
+        const float bv = bias ? bias[col] : 0.f;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int r = 4 * kq + i;
+            float y = acc[t][i] + bv;
+            if (res) y += res[r * ldd + col];
+            y = rc_act(y, op.act);
+            if (!(op.flag & SD3D_RC_F_NO_LDS_DST)) dst[r * ldd + col] = y;
+            if (gout && r < cx.nrows) gout[(int64_t)(cx.row0 + r) * op.ld + col] = y;
+        }
+    }
+}
+
+__device__ __forceinline__ void rc_linear_dispatch(const RCOp& op, const RCCtx& cx) {
+    const int ct = (op.cout + 15) >> 4;
+    const int nt = (ct + 15) >> 4;
+    const int ng = (op.k0 + op.k1) >> 4;
+    if (nt <= 1) { if ((ng & 3) == 0) rc_linear<1, 4>(op, cx); else if ((ng & 1) == 0) rc_linear<1, 2>(op, cx); else rc_linear<1, 1>(op, cx); }
+    else if (nt == 2) { if ((ng & 1) == 0) rc_linear<2, 2>(op, cx); else rc_linear<2, 1>(op, cx); }
+    else if (nt == 3) rc_linear<3, 1>(op, cx);
+    else rc_linear<4, 1>(op, cx);
+}
+
+// ------------------------------------------------------------------------------------------------ LN (D = 256)
+__device__ __forceinline__ void rc_layernorm(const RCOp& op, const RCCtx& cx) {
+    const int lane = threadIdx.x & 63, r = threadIdx.x >> 6;
+    const float* src = cx.lds + op.src0 * RC_SLOT + r * RC_LDW + 4 * lane;
+    f32x4 v = *(const f32x4*)src;
+    if (op.res != 0xFF) v += *(const f32x4*)(cx.lds + op.res * RC_SLOT + r * RC_LDW + 4 * lane);
+    const float mean = rc_wsum(v[0] + v[1] + v[2] + v[3]) / 256.0f;
+    float q = 0.f;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { const float d = v[e] - mean; q += d * d; }
+    const float rstd = 1.0f / sqrtf(rc_wsum(q) / 256.0f + op.f0);
+    const f32x4 g = *(const f32x4*)((const float*)op.p0 + 4 * lane), b = *(const f32x4*)((const float*)op.p1 + 4 * lane);
+    f32x4 y;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        y[e] = (v[e] - mean) * rstd * g[e] + b[e];
+        if (op.act == 1) y[e] = fmaxf(y[e], 0.f);
+    }
+    *(f32x4*)(cx.lds + op.dst * RC_SLOT + r * RC_LDW + 4 * lane) = y;
+    float* gout = (float*)op.p2;
+    if (gout && r < cx.nrows) *(f32x4*)(gout + (int64_t)(cx.row0 + r) * op.ld + 4 * lane) = y;
+}
+
+// ------------------------------------------------------------------------------------------------ LOAD / STORE
+__device__ __forceinline__ void rc_load(const RCOp& op, const RCCtx& cx) {
+    const int C = op.cout, cv = C >> 2, ldw = rc_ld(C);
+    const float* __restrict__ src = (const float*)op.p0;
+    float* dst = cx.lds + op.dst * RC_SLOT;
+    for (int e = threadIdx.x; e < RC_R * cv; e += blockDim.x) {
+        const int r = e / cv, c = (e - r * cv) * 4;
+        const int rr = r < cx.nrows ? r : cx.nrows - 1;       // rows past the scene's end repeat its last row (never stored)
+        *(f32x4*)(dst + r * ldw + c) = *(const f32x4*)(src + (int64_t)(cx.row0 + rr) * op.ld + c);
+    }
+}
+__device__ __forceinline__ void rc_store(const RCOp& op, const RCCtx& cx) {
+    const int C = op.cout, ldw = rc_ld(C);
+    float* __restrict__ out = (float*)op.p0;
+    const float* src = cx.lds + op.src0 * RC_SLOT;
+    if ((C & 3) == 0) {
+        const int cv = C >> 2;
+        for (int e = threadIdx.x; e < cx.nrows * cv; e += blockDim.x) {
+            const int r = e / cv, c = (e - r * cv) * 4;
+            *(f32x4*)(out + (int64_t)(cx.row0 + r) * op.ld + c) = *(const f32x4*)(src + r * ldw + c);
+        }
+    } else {
+        for (int e = threadIdx.x; e < cx.nrows * C; e += blockDim.x) {
+            const int r = e / C, c = e - r * C;
+            out[(int64_t)(cx.row0 + r) * op.ld + c] = src[r * ldw + c];
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ PE (d = 256)
+// the arithmetic of dense.hip sine_pe_kernel, operation for operation
+__device__ __forceinline__ void rc_pe(const RCOp& op, const RCCtx& cx, const RCProgram& P) {
+    const int r = threadIdx.x >> 6, c4 = (threadIdx.x & 63) * 4;
+    const int rr = r < cx.nrows ? r : cx.nrows - 1;
+    const float* xyz = (const float*)op.p0 + (int64_t)(cx.row0 + rr) * 3;
+    const float* __restrict__ dim_t = (const float*)op.p1;
+    const int8_t* __restrict__ axis = (const int8_t*)op.p2;
+    const float* den = op.p3 ? (const float*)op.p3 + (int64_t)(cx.row0 + rr) * 3 : nullptr;
+    const float* num = op.src0 != 0xFF ? cx.lds + op.src0 * RC_SLOT + r * RC_LDW : nullptr;
+    const float* rng = P.rng + 6 * cx.scene;
+    f32x4 y;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const int c = c4 + e;
+        const int a = axis[c];
+        const float lo = rng[a], hi = rng[3 + a];
+        float p = ((xyz[a] - lo) * 1.0f) / (hi - lo) + 0.0f;
+        p = p * 6.283185307179586f;
+        p = p / dim_t[c];
+        float v = (c & 1) ? cosf(p) : sinf(p);
+        if (num) v *= num[a] / den[a];
+        y[e] = v;
+    }
+    *(f32x4*)(cx.lds + op.dst * RC_SLOT + r * RC_LDW + c4) = y;
+}
+
+// ------------------------------------------------------------------------------------------------ BOX (dense.hip box_refine_kernel)
+__device__ __forceinline__ void rc_box(const RCOp& op, const RCCtx& cx, const RCProgram& P) {
+    const int t = threadIdx.x;
+    if (t >= cx.nrows * 3) return;
+    const int r = t / 3, a = t - r * 3;
+    const int64_t g = (int64_t)(cx.row0 + r) * 3 + a;
+    const float* rng = P.rng + 6 * cx.scene;
+    const float dc = cx.lds[op.src0 * RC_SLOT + r * RC_LDW + a];
+    ((float*)op.p2)[g] = ((const float*)op.p0)[g] + dc;
+    if (op.src1 == 0xFF) return;
+    const float ds = cx.lds[op.src1 * RC_SLOT + r * RC_LDW + a];
+    const float sp = ((const float*)op.p1)[g];
+    float s, so;
+    if (op.flag & SD3D_RC_F_NORMALIZE) {
+        const float eps = 1e-5f;
+        const float x = fminf(fmaxf(sp, 0.f), 1.f);
+        const float x1 = fmaxf(x, eps), x2 = fmaxf(1.f - x, eps);
+        const float z = logf(x1 / x2) + ds;
+        s = 1.0f / (1.0f + expf(-z));
+        so = s * (rng[3 + a] - rng[a]);
+    } else {
+        s = sp + ds;
+        so = s;
+    }
+    ((float*)op.p3)[g] = s;
+    ((float*)op.p4)[g] = so;
+}
+
+// ------------------------------------------------------------------------------------------------ MERGE
+// rows of the superpoint cross-attention: either its finished output (key split 1) or the combination of its partial softmax
+// states (dense.hip attention_merge_body: the same expression, the same order over the splits)
+__device__ __forceinline__ void rc_merge(const RCOp& op, const RCCtx& cx, const RCScene& sc) {
+    float* dst = cx.lds + op.dst * RC_SLOT;
+    const int H = 8;
+    if (sc.ksplit <= 1) {
+        const float* src = (const float*)op.p1;
+        for (int e = threadIdx.x; e < RC_R * 64; e += blockDim.x) {
+            const int r = e >> 6, c = (e & 63) * 4;
+            const int rr = r < cx.nrows ? r : cx.nrows - 1;
+            *(f32x4*)(dst + r * RC_LDW + c) = *(const f32x4*)(src + (int64_t)(cx.row0 + rr) * op.ld + c);
+        }
+        return;
+    }
+    const float* part = (const float*)op.p0 + sc.part_off;
+    const int lrow0 = cx.row0 - sc.q0;                        // row inside the scene
+    for (int e = threadIdx.x; e < RC_R * 256; e += blockDim.x) {
+        const int r = e >> 8, col = e & 255;
+        const int head = col >> 5, dv = col & 31;
+        const int lr = lrow0 + (r < cx.nrows ? r : cx.nrows - 1);
+        const int bx = lr >> 5, qq = lr & 31;
+        const float* base = part + ((int64_t)bx * H + head) * sc.ksplit * (64 + 1024);
+        float M = -INFINITY;
+        for (int z = 0; z < sc.ksplit; ++z) M = fmaxf(M, base[z * (64 + 1024) + qq]);
+        float L = 0.f, acc = 0.f;
+        for (int z = 0; z < sc.ksplit; ++z) {
+            const float* b = base + z * (64 + 1024);
+            const float mz = b[qq];
+            const float f = (mz == -INFINITY) ? 0.f : __builtin_amdgcn_exp2f(mz - M);
+            L += b[32 + qq] * f;
+            acc += b[64 + dv * 32 + qq] * f;
+        }
+        dst[r * RC_LDW + col] = acc / L;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ BITS2D
+// blocked2d[q] bit m = 1 <=> no superpoint is both open for query q and near 2D query m; key Mq (the appended dummy key) is
+// always open; bits beyond it are blocked (dense.hip dinox_mask_bits_body).  Wave w makes the 16-key units w, w + 16, ...
+__device__ __forceinline__ void rc_bits2d(const RCOp& op, const RCCtx& cx, const RCScene& sc) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int nw = sc.nw, Mq = sc.nm - 1;
+    const uint32_t* __restrict__ blocked = (const uint32_t*)op.p0 + sc.bits_off;
+    const uint32_t* __restrict__ near = (const uint32_t*)op.p1 + sc.near_off;
+    const int lrow0 = cx.row0 - sc.q0;
+    for (int e = threadIdx.x; e < RC_R * nw; e += blockDim.x) {
+        const int r = e / nw, w = e - r * nw;
+        cx.open_w[r * cx.nw_max + w] = r < cx.nrows ? ~blocked[(int64_t)(lrow0 + r) * nw + w] : 0u;
+    }
+    __syncthreads();
+    const int nw2 = (sc.nm + 31) >> 5, nhalf = nw2 * 2;
+    uint16_t* out16 = (uint16_t*)cx.bits2d;
+    for (int unit = wave; unit < nhalf; unit += 16) {
+        uint32_t word[RC_R];
+#pragma unroll
+        for (int q = 0; q < RC_R; ++q) word[q] = 0u;
+        for (int jb = 0; jb < 16; ++jb) {
+            const int m = unit * 16 + jb;                      // wave-uniform
+            uint32_t acc[RC_R];
+#pragma unroll
+            for (int q = 0; q < RC_R; ++q) acc[q] = 0u;
+            if (m < Mq) {
+                for (int w = lane; w < nw; w += 64) {
+                    const uint32_t nb = near[(int64_t)m * nw + w];
+#pragma unroll
+                    for (int q = 0; q < RC_R; ++q) acc[q] |= cx.open_w[q * cx.nw_max + w] & nb;
+                }
+            }
+#pragma unroll
+            for (int q = 0; q < RC_R; ++q) {
+                const bool hit = __ballot(acc[q] != 0u) != 0ull;
+                const uint32_t blk = m < Mq ? (hit ? 0u : 1u) : (m == Mq ? 0u : 1u);
+                word[q] |= blk << jb;
+            }
+        }
+        if (lane < RC_R) {
+            uint32_t mine = 0u;
+#pragma unroll
+            for (int q = 0; q < RC_R; ++q) mine = (lane == q) ? word[q] : mine;
+            out16[lane * (cx.nw2_max * 2) + unit] = (uint16_t)mine;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ ATTN
+// 16 query rows x Lk keys x 8 heads of 32 channels.  wave = (head = wave & 7, key half = wave >> 3).
+// lane (c16, kq):  S tile: S[key 4 kq + v][query c16];  O: O[dv 4 kq + v (+ 16 dt)][query c16]
+__device__ __forceinline__ void rc_attn(const RCOp& op, const RCCtx& cx, const RCScene& sc) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int c16 = lane & 15, kq = lane >> 4;
+    const int head = wave & 7, half = wave >> 3;
+    const bool keys_2d = (op.flag & SD3D_RC_F_KEYS_2D) != 0;
+    const int key0 = keys_2d ? sc.m0 : sc.q0, Lk = keys_2d ? sc.nm : sc.nq;
+    const float* __restrict__ Kp = (const float*)op.p0;
+    const float* __restrict__ Vp = (const float*)op.p1;
+    const int ldk = op.ld;
+    const bool masked = (op.flag & SD3D_RC_F_MASK_BITS2D) != 0;
+    // queries, pre-scaled into the log2 domain: B operand of S^T = K Q^T:  B[k = channel][j = query c16]
+    f32x4 qf[2];
+    {
+        const float* q = cx.lds + op.src0 * RC_SLOT + c16 * RC_LDW + head * 32 + 4 * kq;
+#pragma unroll
+        for (int g = 0; g < 2; ++g) {
+            qf[g] = *(const f32x4*)(q + 16 * g);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) qf[g][e] *= op.f0 * RC_LOG2E;
+        }
+    }
+    f32x4 O[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
+    float m = -INFINITY, l = 0.f;
+    const int ntiles = (Lk + 15) >> 4;
+    const int t_mid = (ntiles + 1) >> 1;
+    const int t_begin = half ? t_mid : 0, t_end = half ? ntiles : t_mid;
+    for (int t = t_begin; t < t_end; ++t) {
+        const int kt0 = t * 16;
+        // K rows: A[i = key c16][k = channel]
+        const int krow = key0 + min(kt0 + c16, Lk - 1);
+        const float* ks = Kp + (int64_t)krow * ldk + head * 32 + 4 * kq;
+        const f32x4 k0 = *(const f32x4*)ks, k1 = *(const f32x4*)(ks + 16);
+        // V: A[i = dv c16 (+16)][k = key 4 kq + e]
+        float v0[4], v1[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int vrow = key0 + min(kt0 + 4 * kq + e, Lk - 1);
+            const float* vs = Vp + (int64_t)vrow * ldk + head * 32 + c16;
+            v0[e] = vs[0];
+            v1[e] = vs[16];
+        }
+        f32x4 S = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int e = 0; e < 4; ++e) S = __builtin_amdgcn_mfma_f32_16x16x4f32(k0[e], qf[0][e], S, 0, 0, 0);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) S = __builtin_amdgcn_mfma_f32_16x16x4f32(k1[e], qf[1][e], S, 0, 0, 0);
+        // S[v] = log2-score(key kt0 + 4 kq + v, query c16)
+        uint32_t wbits = 0u;
+        if (masked) {
+            const uint32_t w = cx.bits2d[c16 * cx.nw2_max + (t >> 1)];
+            wbits = (w >> ((t & 1) * 16 + 4 * kq)) & 0xFu;
+        }
+        float tmax = -INFINITY;
+#pragma unroll
+        for (int v = 0; v < 4; ++v) {
+            const bool off = ((wbits >> v) & 1u) || (kt0 + 4 * kq + v >= Lk);
+            S[v] = off ? -INFINITY : S[v];
+            tmax = fmaxf(tmax, S[v]);
+        }
+        tmax = fmaxf(tmax, __shfl_xor(tmax, 16));
+        tmax = fmaxf(tmax, __shfl_xor(tmax, 32));
+        const float mn = fmaxf(m, tmax);
+        f32x4 pr = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (mn != -INFINITY) {
+            const float alpha = __builtin_amdgcn_exp2f(m - mn);
+            float ls = 0.f;
+#pragma unroll
+            for (int v = 0; v < 4; ++v) { pr[v] = __builtin_amdgcn_exp2f(S[v] - mn); ls += pr[v]; }
+            l = l * alpha + ls;
+            m = mn;
+#pragma unroll
+            for (int v = 0; v < 4; ++v) { O[0][v] *= alpha; O[1][v] *= alpha; }
+        }
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            O[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(v0[e], pr[e], O[0], 0, 0, 0);
+            O[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(v1[e], pr[e], O[1], 0, 0, 0);
+        }
+    }
+    l += __shfl_xor(l, 16);
+    l += __shfl_xor(l, 32);
+    // the second key half hands (m, l, O) over through the scratch slots; the first combines (fixed order: half 0, half 1)
+    float* scratch = cx.lds + op.aux * RC_SLOT + head * (64 * 10);
+    if (half == 1) {
+        float* s = scratch + lane * 10;
+        s[0] = m; s[1] = l;
+#pragma unroll
+        for (int v = 0; v < 4; ++v) { s[2 + v] = O[0][v]; s[6 + v] = O[1][v]; }
+    }
+    __syncthreads();
+    if (half == 0) {
+        const float* s = scratch + lane * 10;
+        const float m1 = s[0], l1 = s[1];
+        const float M = fmaxf(m, m1);
+        const float f0 = (m == -INFINITY) ? 0.f : __builtin_amdgcn_exp2f(m - M);
+        const float f1 = (m1 == -INFINITY) ? 0.f : __builtin_amdgcn_exp2f(m1 - M);
+        const float L = l * f0 + l1 * f1;
+        float* dst = cx.lds + op.dst * RC_SLOT + c16 * RC_LDW + head * 32 + 4 * kq;
+        f32x4 o0, o1;
+#pragma unroll
+        for (int v = 0; v < 4; ++v) {
+            o0[v] = (O[0][v] * f0 + s[2 + v] * f1) / L;
+            o1[v] = (O[1][v] * f0 + s[6 + v] * f1) / L;
+        }
+        *(f32x4*)dst = o0;
+        *(f32x4*)(dst + 16) = o1;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ the interpreter
+__global__ __launch_bounds__(1024) void row_chain_kernel(const RCProgram P) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    int si = 0;
+    for (int k = 1; k < P.n_scenes; ++k) if ((int)blockIdx.x >= P.tile0[k]) si = k;
+    const RCScene& sc = P.scenes[si];
+    RCCtx cx;
+    cx.lds = smem;
+    cx.bits2d = (uint32_t*)(smem + P.n_slots * RC_SLOT);
+    cx.nw2_max = P.nw2_max;
+    cx.nw_max = P.nw_max;
+    cx.open_w = cx.bits2d + RC_R * P.nw2_max;
+    const int tile = blockIdx.x - P.tile0[si];
+    cx.row0 = sc.q0 + tile * RC_R;
+    cx.nrows = min(RC_R, sc.nq - tile * RC_R);
+    cx.scene = si;
+    const int o_begin = P.prog_begin[blockIdx.y], o_end = P.prog_begin[blockIdx.y + 1];
+    for (int o = o_begin; o < o_end; ++o) {
+        const RCOp& op = P.ops[o];
+        switch (op.type) {
+            case SD3D_RC_LOAD: rc_load(op, cx); break;
+            case SD3D_RC_STORE: rc_store(op, cx); break;
+            case SD3D_RC_LINEAR: rc_linear_dispatch(op, cx); break;
+            case SD3D_RC_LN: rc_layernorm(op, cx); break;
+            case SD3D_RC_PE: rc_pe(op, cx, P); break;
+            case SD3D_RC_BOX: rc_box(op, cx, P); break;
+            case SD3D_RC_MERGE: rc_merge(op, cx, sc); break;
+            case SD3D_RC_BITS2D: rc_bits2d(op, cx, sc); break;
+            case SD3D_RC_ATTN: rc_attn(op, cx, sc); break;
+            default: break;
+        }
+        __syncthreads();
+    }
+}
+
+static const char* rc_check(const RCProgram& P) {
+    if (P.n_scenes < 1 || P.n_scenes > SD3D_MAX_BATCH) return "row_chain: 1..16 scenes";
+    if (P.n_programs < 1 || P.n_programs > SD3D_RC_MAX_PROGRAMS) return "row_chain: 1..4 programs";
+    if (P.n_slots < 1 || P.n_slots > 9) return "row_chain: 1..9 LDS slots";
+    if (P.prog_begin[0] != 0) return "row_chain: programs start at op 0";
+    for (int i = 0; i < P.n_programs; ++i)
+        if (P.prog_begin[i + 1] < P.prog_begin[i] || P.prog_begin[i + 1] > SD3D_RC_MAX_OPS) return "row_chain: bad program bounds";
+    int tiles = 0;
+    for (int s = 0; s < P.n_scenes; ++s) {
+        if (P.tile0[s] != tiles) return "row_chain: tile0 must be the prefix sums of ceil(nq / 16)";
+        if (P.scenes[s].nq <= 0) return "row_chain: a scene without query rows";
+        tiles += (P.scenes[s].nq + RC_R - 1) / RC_R;
+    }
+    if (P.tile0[P.n_scenes] != tiles) return "row_chain: tile0[n_scenes] != number of tiles";
+    auto slot_ok = [&](int slot, int width) { return slot >= 0 && slot * RC_SLOT + RC_R * (width <= 256 ? RC_LDW : width + 4) <= P.n_slots * RC_SLOT; };
+    bool needs_rng = false;
+    for (int o = 0; o < P.prog_begin[P.n_programs]; ++o) {
+        const RCOp& op = P.ops[o];
+        switch (op.type) {
+            case SD3D_RC_LOAD:
+                if (!op.p0 || (op.cout & 3) || (op.ld & 3) || op.cout < 4 || !slot_ok(op.dst, op.cout)) return "row_chain: bad LOAD";
+                break;
+            case SD3D_RC_STORE:
+                if (!op.p0 || op.cout < 1 || !slot_ok(op.src0, op.cout)) return "row_chain: bad STORE";
+                break;
+            case SD3D_RC_LINEAR:
+                if (!op.p0 || op.k0 < 16 || (op.k0 & 15) || (op.k1 & 15) || op.cout < 1 || op.cout > 1024 || !slot_ok(op.src0, op.k0) ||
+                    (op.k1 && !slot_ok(op.src1, op.k1)) || (!(op.flag & SD3D_RC_F_NO_LDS_DST) && !slot_ok(op.dst, op.cout)) ||
+                    (op.res != 0xFF && !slot_ok(op.res, op.cout)) || ((op.flag & SD3D_RC_F_NO_LDS_DST) && !op.p2))
+                    return "row_chain: bad LINEAR";
+                break;
+            case SD3D_RC_LN:
+                if (!op.p0 || !op.p1 || !slot_ok(op.src0, 256) || !slot_ok(op.dst, 256) || (op.res != 0xFF && !slot_ok(op.res, 256)) || (op.p2 && (op.ld & 3)))
+                    return "row_chain: bad LN";
+                break;
+            case SD3D_RC_PE:
+                needs_rng = true;
+                if (!op.p0 || !op.p1 || !op.p2 || !slot_ok(op.dst, 256) || (op.src0 != 0xFF && (!slot_ok(op.src0, 256) || !op.p3))) return "row_chain: bad PE";
+                break;
+            case SD3D_RC_BOX:
+                needs_rng = true;
+                if (!op.p0 || !op.p2 || !slot_ok(op.src0, 256) || (op.src1 != 0xFF && (!slot_ok(op.src1, 256) || !op.p1 || !op.p3 || !op.p4))) return "row_chain: bad BOX";
+                break;
+            case SD3D_RC_MERGE:
+                if (!slot_ok(op.dst, 256)) return "row_chain: bad MERGE";
+                for (int s = 0; s < P.n_scenes; ++s)
+                    if ((P.scenes[s].ksplit > 1 && !op.p0) || (P.scenes[s].ksplit <= 1 && (!op.p1 || (op.ld & 3)))) return "row_chain: MERGE without its source";
+                break;
+            case SD3D_RC_BITS2D:
+                if (!op.p0 || !op.p1) return "row_chain: bad BITS2D";
+                for (int s = 0; s < P.n_scenes; ++s)
+                    if (P.scenes[s].nw > P.nw_max || (P.scenes[s].nm + 31) / 32 > P.nw2_max || P.scenes[s].nm < 1) return "row_chain: BITS2D sizes exceed the LDS areas";
+                break;
+            case SD3D_RC_ATTN:
+                if (!op.p0 || !op.p1 || (op.ld & 3) || !slot_ok(op.src0, 256) || !slot_ok(op.dst, 256) || op.aux * RC_SLOT + 8 * 640 > P.n_slots * RC_SLOT)
+                    return "row_chain: bad ATTN";
+                break;
+            default: return "row_chain: unknown op";
+        }
+    }
+    if (needs_rng && !P.rng) return "row_chain: PE / BOX need the scene ranges";
+    return nullptr;
+}
+
+size_t row_chain_lds_bytes(const RCProgram& P) {
+    return ((size_t)P.n_slots * RC_SLOT + (size_t)RC_R * (P.nw2_max + P.nw_max)) * sizeof(float);
+}
+
+int launch_row_chain(const RCProgram* P, hipStream_t st) {
+    if (!P) return sd3d_set_error(SD3D_ERR_ARG, "row_chain: null program");
+    const char* err = rc_check(*P);
+    if (err) return sd3d_set_error(SD3D_ERR_ARG, err);
+    const size_t sm = row_chain_lds_bytes(*P);
+    if (sm > 160 * 1024) return sd3d_set_error(SD3D_ERR_ARG, "row_chain: more than 160 KB of LDS");
+    static bool attr = false;
+    if (!attr) { (void)hipFuncSetAttribute((const void*)row_chain_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr = true; }
+    const int tiles = P->tile0[P->n_scenes];
+    hipLaunchKernelGGL(row_chain_kernel, dim3((unsigned)tiles, (unsigned)P->n_programs), dim3(1024), sm, st, *P);
+    SD3D_CHECK_LAUNCH();
+    return SD3D_OK;
+}

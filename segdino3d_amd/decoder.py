@@ -191,6 +191,9 @@ _F_TLS = threading.local()
 # SD3D_BATCH_DECODER=0: the decoder of a multi-scene evaluation forward runs scene by scene (A/B switch; default: the row-wise work of
 # all scenes in one pass, `ScanNetQueryDecoder._forward_batch`)
 BATCH_DECODER = os.environ.get("SD3D_BATCH_DECODER", "1") != "0"
+# SD3D_FUSED_DECODER=0: evaluation runs the op-by-op decoder of rounds 1-3 (`_forward_scene` / `_forward_batch`) instead of the
+# row-chain launches (`_forward_fused`); training always runs op by op (autograd nodes)
+FUSED_DECODER = os.environ.get("SD3D_FUSED_DECODER", "1") != "0"
 
 
 def _F():
@@ -618,6 +621,10 @@ class ScanNetQueryDecoder(DerivedWeights):
         fams = [[q.shape[0] for q in queries], [t.shape[0] for t in x]]
         if self.add_dinox_query_ca:
             fams.append([t.shape[0] + 1 for t in dinox_queries])
+        # the mask-logit products nq_b . mask_feats_b^T run grouped on the split-contraction kernel: only where ONE scene's own launch
+        # would take it too (ops.gather_gemm(nq, mask_feats, exact=True) -> dense_code(Q_b, d, S_b); ~320 < Q <= 512 at S ~ 3000 does not)
+        if any(ops.dense_code(q.shape[0], self.d_model, t.shape[0]) != -1 for q, t in zip(queries, x)):
+            return False
         for rows, shapes in zip(fams, self._row_shapes()):
             for cin, cout in shapes:
                 codes = {ops.dense_code(r, cin, cout) for r in rows}
@@ -797,6 +804,273 @@ class ScanNetQueryDecoder(DerivedWeights):
             results.append((final, views))
         return results
 
+    # ---- evaluation, positional variant: the row-local work of a layer as row-chain launches (csrc/rowchain.hip) ----------------
+    def _fusable(self):
+        """The fused path covers the SegDINO3D prototypes in evaluation: sine positional embedding, 256 channels in 8 heads."""
+        return (FUSED_DECODER and not self.training and self.add_positional_embedding and self.pos_type == "sine" and self.d_model == 256
+                and self.num_heads == 8 and self.num_queries == 0 and ops.GEMM_MODE is None and ops.GG_FORCE_NT is None
+                and self.in_channels % 16 == 0 and self.ffn_layers[0].net[0].out_features <= 1024
+                and self.ffn_layers[0].net[0].out_features % 16 == 0)
+
+    def _forward_fused(self, xs, sp_pos, sp_pos_wo, q_in, q_pos, q2d_feat, q2d_pos, ranges):
+        """`_forward_scene` for B >= 1 scenes with every query-row-local stretch of a layer as ONE launch (rowchain.Program):
+             A  positional query: anchor MLP -> box-modulated sine PE -> ref_point_head, the two cross-attention query projections
+                (+ the class head of the previous layer as a second program of the same launch)
+             -  masked cross-attention to the superpoints (dense.hip attention kernel, key-split pass only)
+             B  combine the key splits -> out-projection + residual + norm1 -> packed self-attention q / k / v projection
+             C  self-attention over the scene's queries -> out-projection + norm2 -> 2D-query mask bits -> 2D cross-attention -> FFN
+                -> box MLPs + refinement -> head norm (+ semantic head on the last layer)
+             -  mask logits (GEMM against the superpoints' mask features) and their attention-mask bits
+        6 launches per layer instead of ~27.  Per row the arithmetic is independent of the other rows of a launch: B scenes in one
+        call give every scene the bits of its own call."""
+        from .rowchain import Program
+        dev = xs[0].device
+        d, H, L = self.d_model, self.num_heads, self.num_layers
+        B = len(xs)
+        pk = self.packed()
+        dim_t, axis = self.pe_tables(dev)
+        s_off, q_off = [0], [0]
+        for b in range(B):
+            s_off.append(s_off[-1] + xs[b].shape[0])
+            q_off.append(q_off[-1] + q_in[b].shape[0])
+        S_tot, Q_tot = s_off[-1], q_off[-1]
+        S_b = [s_off[b + 1] - s_off[b] for b in range(B)]
+        Q_b = [q_off[b + 1] - q_off[b] for b in range(B)]
+        cat = (lambda ts: ts[0].contiguous()) if B == 1 else (lambda ts: torch.cat([t.contiguous() for t in ts]).contiguous())
+        X, SP, Qin = cat(list(xs)), cat([t.float() for t in sp_pos]), cat(list(q_in))
+        rng = torch.stack([torch.cat([lo.reshape(3), hi.reshape(3)]).float() for lo, hi in ranges]).contiguous()      # [B, 6]
+
+        # ---- superpoint side: big Linears on the existing GEMM kernels, each scene's rows on the tiling its own call would get
+        def s_linear(x, w, b=None, act=None, res=None, rows=S_b, offs=s_off, exact=False):
+            if B == 1:
+                return ops.gather_gemm(x, w, shift=b, act=act, res=res, exact=exact)
+            codes = {ops.dense_code(r, w.shape[-1], w.shape[0]) for r in rows}
+            small = all(r < ops.BF16_MIN_ROWS for r in rows)
+            if len(codes) == 1 and None not in codes and (not ops.bf16_decoder_active() or small or all(r >= ops.BF16_MIN_ROWS for r in rows)):
+                return ops.gather_gemm(x, w, shift=b, act=act, res=res, nt=codes.pop(), exact=exact or small)
+            out = torch.empty(x.shape[0], w.shape[0], dtype=torch.float32, device=dev)
+            for i in range(len(rows)):
+                ops.gather_gemm(x[offs[i]:offs[i + 1]], w, shift=b, act=act, res=None if res is None else res[offs[i]:offs[i + 1]],
+                                out=out[offs[i]:offs[i + 1]], exact=exact)
+            return out
+        SL = lambda x, layer, act=None, res=None: s_linear(x, layer.weight, layer.bias, act, res)  # noqa: E731
+        if B == 1:
+            memory_emb = ops.sine_pe(SP, rng[0], dim_t, axis)
+        else:
+            rs_s = torch.cat([torch.full((S_b[b],), b, dtype=torch.int32, device=dev) for b in range(B)])
+            memory_emb = ops.sine_pe(SP, rng, dim_t, axis, row_scene=rs_s)
+        inst = ops.layernorm(SL(X, self.input_proj[0]), self.input_proj[1].weight, self.input_proj[1].bias, act="relu")
+        mask_feats = SL(SL(X, self.x_mask[0], act="relu"), self.x_mask[2])
+        kv_all = s_linear(inst, pk["kv_w"], pk["kv_b"])                      # [S_tot, 2*L*d]: kc_0..kc_{L-1} | v_0..v_{L-1}
+        kp_all = s_linear(memory_emb, pk["kp_w"], pk["kp_b"])                # [S_tot, L*d]
+        kc0 = SL(inst, self.ca_kcontent_proj[0], res=kp_all[:, :d])          # layer 0: content + positional key (:669-672)
+        m_off, nw_b, near_off = [0], [(s + 31) // 32 for s in S_b], [0]
+        kv2d_all = near_all = None
+        if self.add_dinox_query_ca:
+            keys2d, nears = [], []
+            for b in range(B):
+                qp = q2d_pos[b]
+                if not isinstance(qp, torch.Tensor):
+                    qp = qp.tensor.type(sp_pos_wo[b].dtype).to(dev)
+                f = q2d_feat[b]
+                keys2d.append(torch.cat([f.float(), f.new_ones(1, f.shape[1], dtype=torch.float32)]))
+                m_off.append(m_off[-1] + f.shape[0] + 1)
+                nears.append(ops.near_bits(sp_pos_wo[b].float().contiguous(), qp.float().contiguous(), self.dinox_query_ca_mask_threshold).reshape(-1))
+                near_off.append(near_off[-1] + nears[-1].numel())
+            M_b = [m_off[b + 1] - m_off[b] for b in range(B)]
+            kv2d_all = s_linear(cat(keys2d), pk["kv2d_w"], pk["kv2d_b"], rows=M_b, offs=m_off)      # [sum(M_b + 1), 2*L*d]
+            near_all = nears[0] if B == 1 else torch.cat(nears)
+            if near_all.numel() == 0:                              # no 2D query in any scene: only the dummy keys, the table is never read
+                near_all = torch.zeros(1, dtype=torch.int32, device=dev)
+        nw_max = max(nw_b)
+        nw2_max = max(((m_off[b + 1] - m_off[b]) + 31) // 32 for b in range(B)) if self.add_dinox_query_ca else 0
+
+        def scene_table(bits_off=None, ca=None):
+            tab = []
+            for b in range(B):
+                sc = dict(q0=q_off[b], nq=Q_b[b], nw=nw_b[b])
+                if self.add_dinox_query_ca:
+                    sc.update(m0=m_off[b], nm=m_off[b + 1] - m_off[b], near_off=near_off[b])
+                if bits_off is not None:
+                    sc["bits_off"] = bits_off[b]
+                if ca is not None:
+                    sc.update(ksplit=ca[b][0], part_off=ca[b][1])
+                tab.append(sc)
+            return tab
+
+        def new(cols, rows=Q_tot):
+            return torch.empty(rows, cols, dtype=torch.float32, device=dev)
+
+        # ---- the prediction head's mask branch: logits = nq . mask_feats^T per scene, thresholded into one bit buffer ------------
+        logit_codes = [ops.dense_code(Q_b[b], d, S_b[b]) for b in range(B)]
+
+        def mask_head(nq):
+            pairs = [(nq[q_off[b]:q_off[b + 1]], mask_feats[s_off[b]:s_off[b + 1]]) for b in range(B)]
+            if B > 1 and all(c == -1 for c in logit_codes) and ops.GG_HOOK is None:
+                logits = ops.linear_group([(a, m, None, None, None, None) for a, m in pairs], force_small=True)
+            else:
+                logits = [ops.gather_gemm(a, m, exact=True) for a, m in pairs]
+            sizes = [Q_b[b] * nw_b[b] for b in range(B)]
+            buf = torch.empty(sum(sizes), dtype=torch.int32, device=dev)
+            offs = [0]
+            for z in sizes:
+                offs.append(offs[-1] + z)
+            views = [buf[offs[b]:offs[b + 1]].view(Q_b[b], nw_b[b]) for b in range(B)]
+            ops.mask_bits_batch(logits, S_b, self.mask_attention_threshold, out=views)
+            return logits, views, buf, offs
+
+        def cls_program(P, nq, out):
+            """class head of a prediction (feeds nothing inside the decoder): its own program next to the main chain"""
+            P.load(0, nq)
+            P.linear(1, 0, self.out_cls[0].weight, self.out_cls[0].bias, act="relu")
+            P.linear(None, 1, self.out_cls[2].weight, self.out_cls[2].bias, gout=out)
+
+        # ---- query side ---------------------------------------------------------------------------------------------------------
+        queries, nq = new(d), new(d)
+        P = Program(2)
+        P.load(0, Qin)
+        P.linear(1, 0, self.query_proj[0].weight, self.query_proj[0].bias, act="relu")
+        P.linear(0, 1, self.query_proj[2].weight, self.query_proj[2].bias, gout=queries)
+        P.ln(1, 0, self.out_norm.weight, self.out_norm.bias, gout=nq)
+        score = None
+        if self.objectness_flag:
+            score = new(1)
+            P.linear(0, 1, self.out_score[0].weight, self.out_score[0].bias, act="relu")
+            P.linear(None, 0, self.out_score[2].weight, self.out_score[2].bias, gout=score)
+        P.launch(scene_table())
+        logits, bits, bits_buf, bits_off = mask_head(nq)
+        aux = [dict(cls_preds=None, sem_preds=None, masks=logits, centers=None, sizes=None, scores=score)]
+
+        ref_points = cat([t.float() for t in q_pos])
+        if self.normalize_box_prediction:
+            size_q = cat([(1 / (hi - lo) * 0.5).float().reshape(1, 3).expand(Q_b[b], 3) for b, (lo, hi) in enumerate(ranges)])
+        else:
+            size_q = torch.full((Q_tot, 3), 0.5, dtype=torch.float32, device=dev)
+        ref_sizes = size_q
+        ncls = self.out_cls[2].out_features
+        act_ffn = "relu" if self.activation_fn == "relu" else "gelu"
+        for i in range(L):
+            ops.baton_yield()
+            # ---- A: positional query + cross-attention query projections | class head of the previous prediction
+            query_pos, qs, qc, cls_prev = new(d), new(d), new(d), new(ncls)
+            P = Program(4, rng)
+            P.load(0, queries)
+            if self.box_modulate_ca:
+                ah = self.ref_anchor_head.layers
+                P.linear(1, 0, ah[0].weight, ah[0].bias, act="relu")
+                P.linear(2, 1, ah[1].weight, ah[1].bias, act="sigmoid")
+                P.pe(3, ref_points, dim_t, axis, num_slot=2, den=ref_sizes)
+            else:
+                P.pe(3, ref_points, dim_t, axis)
+            rp = self.ref_point_head.layers
+            P.linear(1, 3, rp[0].weight, rp[0].bias, act="relu")
+            P.linear(2, 1, rp[1].weight, rp[1].bias, gout=query_pos)
+            P.linear(None, 3, self.ca_qpos_sine_proj[i].weight, self.ca_qpos_sine_proj[i].bias, gout=qs)
+            if i == 0:
+                P.linear(None, 0, pk["ca_q0_w"], pk["ca_q0_b"], src1=2, gout=qc)
+            else:
+                P.linear(None, 0, self.ca_qcontent_proj[i].weight, self.ca_qcontent_proj[i].bias, gout=qc)
+            P.begin()
+            cls_program(P, nq, cls_prev)
+            P.launch(scene_table())
+            aux[-1]["cls_preds"] = cls_prev
+            # ---- masked cross-attention to the superpoints (:668-691): key-split pass only, chain B combines
+            a = new(d)
+            kc = kc0 if i == 0 else kv_all[:, i * d:(i + 1) * d]
+            v, kp = kv_all[:, (L + i) * d:(L + i + 1) * d], kp_all[:, i * d:(i + 1) * d]
+            jobs = [(qc[q_off[b]:q_off[b + 1]], kc[s_off[b]:s_off[b + 1]], v[s_off[b]:s_off[b + 1]], bits[b], qs[q_off[b]:q_off[b + 1]],
+                     kp[s_off[b]:s_off[b + 1]], a[q_off[b]:q_off[b + 1]]) for b in range(B)]
+            ws, ca = ops.attention_parts(jobs, H, (2 * d // H) ** -0.5)
+            # ---- B: out-projection + norm1, packed self-attention projections (:690-700)
+            queries1, qkv = new(d), new(3 * d)
+            op = self.cross_attn_layers[i].out_proj
+            P = Program(3)
+            P.merge(1, ws, a)
+            P.load(0, queries)
+            P.linear(2, 1, op.weight, op.bias, res=0)
+            P.ln(0, 2, self.norm1[i].weight, self.norm1[i].bias, gout=queries1)
+            P.load(1, query_pos)
+            P.linear(None, 0, pk["sa_qkv_w"][i], pk["sa_qkv_b"][i], src1=1, gout=qkv)
+            P.launch(scene_table(ca=ca))
+            # ---- C: self-attention, 2D-query cross-attention, FFN, box refinement, head norm
+            queries, nq = new(d), new(d)
+            center = new(3)
+            size = size_metric = None
+            P = Program(8, rng)
+            P.load(0, queries1)
+            P.load(1, qkv[:, :d])
+            P.attn(2, 1, qkv[:, d:2 * d], qkv[:, 2 * d:], (d // H) ** -0.5, aux=6)
+            op = self.self_attn_layers[i].out_proj
+            P.linear(3, 2, op.weight, op.bias, res=0)
+            P.ln(0, 3, self.norm2[i].weight, self.norm2[i].bias)
+            if self.add_dinox_query_ca:
+                layer = self.dinox_query_cross_attn_layers[i]
+                P.bits2d(bits_buf, near_all)
+                P.linear(1, 0, pk["q2d_w"][i], pk["q2d_b"][i])
+                P.attn(2, 1, kv2d_all[:, i * d:(i + 1) * d], kv2d_all[:, (L + i) * d:(L + i + 1) * d], (d // H) ** -0.5, aux=6, keys_2d=True, masked=True)
+                op = layer.attn.out_proj
+                if layer.fix:
+                    P.linear(3, 2, op.weight, op.bias, res=0)
+                    P.ln(0, 3, layer.norm.weight, layer.norm.bias)
+                else:
+                    P.linear(0, 2, op.weight, op.bias, res=0)
+            ffn = self.ffn_layers[i]
+            P.linear(4, 0, ffn.net[0].weight, ffn.net[0].bias, act=act_ffn)
+            P.linear(3, 4, ffn.net[3].weight, ffn.net[3].bias, res=0)
+            P.ln(0, 3, ffn.norm.weight, ffn.norm.bias, gout=queries)
+            be = self.bbox_embed[i].layers
+            P.linear(1, 0, be[0].weight, be[0].bias, act="relu")
+            P.linear(2, 1, be[1].weight, be[1].bias, act="relu")
+            P.linear(3, 2, be[2].weight, be[2].bias)
+            if self.add_box_size_pred:
+                se = self.bbox_size_embed[i].layers
+                size, size_metric = new(3), new(3)
+                P.linear(1, 0, se[0].weight, se[0].bias, act="relu")
+                P.linear(2, 1, se[1].weight, se[1].bias, act="relu")
+                P.linear(4, 2, se[2].weight, se[2].bias)
+                P.box(ref_points, 3, center, size_prev=size_q, ds_slot=4, size=size, size_metric=size_metric, normalize=self.normalize_box_prediction)
+            else:
+                P.box(ref_points, 3, center)
+            P.ln(1, 0, self.out_norm.weight, self.out_norm.bias, gout=nq)
+            last = i == L - 1
+            sem = score = None
+            if last:
+                sem = new(self.num_semantic_classes + 1)
+                if isinstance(self.out_sem, nn.Linear):
+                    P.linear(None, 1, self.out_sem.weight, self.out_sem.bias, gout=sem)
+                else:
+                    P.linear(2, 1, self.out_sem[0].weight, self.out_sem[0].bias, act="relu")
+                    P.linear(None, 2, self.out_sem[2].weight, self.out_sem[2].bias, gout=sem)
+            if self.objectness_flag:
+                score = new(1)
+                P.linear(2, 1, self.out_score[0].weight, self.out_score[0].bias, act="relu")
+                P.linear(None, 2, self.out_score[2].weight, self.out_score[2].bias, gout=score)
+            P.launch(scene_table(bits_off=bits_off), nw_max=nw_max, nw2_max=nw2_max)
+            ref_points = center
+            if self.add_box_size_pred:
+                ref_sizes = size_q = size
+            logits, bits, bits_buf, bits_off = mask_head(nq)
+            aux.append(dict(cls_preds=None, sem_preds=sem, masks=logits, centers=center, sizes=size_metric, scores=score))
+        cls_last = new(ncls)
+        P = Program(2)
+        cls_program(P, nq, cls_last)
+        P.launch(scene_table())
+        aux[-1]["cls_preds"] = cls_last
+
+        def scene_view(entry, b):
+            q0, q1 = q_off[b], q_off[b + 1]
+            row = lambda t: None if t is None else t[q0:q1]  # noqa: E731
+            return dict(cls_preds=row(entry["cls_preds"]), sem_preds=row(entry["sem_preds"]), masks=entry["masks"][b],
+                        centers=row(entry["centers"]), sizes=row(entry["sizes"]), scores=row(entry["scores"]))
+        results = []
+        for b in range(B):
+            views = [scene_view(e, b) for e in aux]
+            final = views.pop()
+            final["hidden_states"] = queries[q_off[b]:q_off[b + 1]]
+            final["attn_mask_bits"] = bits[b]
+            results.append((final, views))
+        return results
+
     # ---- reference-shaped entry point (:417-435) --------------------------------------------------
     @ops.bound_stream
     def forward(self, x, sp_pos=None, sp_pos_wo_elastic=None, queries=None, queries_pos=None, dinox_queries=None,
@@ -820,13 +1094,19 @@ class ScanNetQueryDecoder(DerivedWeights):
                 auxes.append(a)
         else:
             assert (sp_pos is not None) and (queries_pos is not None) and (scene_range is not None)
-        batched = self.add_positional_embedding and self._batchable(x, queries, dinox_queries)
+        fused = self.add_positional_embedding and self._fusable() and len(x) <= 16 and all(q.shape[0] > 0 for q in queries)
+        if fused:
+            for f, a in self._forward_fused(x, sp_pos, sp_pos_wo_elastic if sp_pos_wo_elastic is not None else sp_pos, queries, queries_pos,
+                                            dinox_queries, dinox_query_pos, scene_range):
+                finals.append(f)
+                auxes.append(a)
+        batched = not fused and self.add_positional_embedding and self._batchable(x, queries, dinox_queries)
         if batched:
             for f, a in self._forward_batch(x, sp_pos, sp_pos_wo_elastic if sp_pos_wo_elastic is not None else sp_pos, queries, queries_pos,
                                             dinox_queries, dinox_query_pos, scene_range):
                 finals.append(f)
                 auxes.append(a)
-        for j in range(len(x) if (self.add_positional_embedding and not batched) else 0):
+        for j in range(len(x) if (self.add_positional_embedding and not batched and not fused) else 0):
             f, a = self._forward_scene(
                 x[j], sp_pos[j], sp_pos_wo_elastic[j] if sp_pos_wo_elastic is not None else sp_pos[j], queries[j],
                 queries_pos[j], dinox_queries[j] if dinox_queries is not None else None,

@@ -1036,19 +1036,67 @@ def attention_batch(jobs, num_heads, scale):
                                         ws.data_ptr(), ws.numel(), _stream()), "attention_batch")
 
 
-def mask_bits_batch(logits_list, S_list, thr):
-    """mask_bits for several scenes' logit matrices in one launch -> list of bit tensors."""
+def attention_parts(jobs, num_heads, scale):
+    """`attention_batch` WITHOUT the pass that combines the key splits (sd3d_attention_batch_parts): returns (ws, [(ksplit, part_off)])
+    - scene i's rows are final in its `out` where ksplit == 1, else its partial softmax states wait at ws (a uint8 tensor) + part_off
+    floats for the consumer that combines them (rowchain MERGE).  jobs as in `attention_batch`."""
+    global _ATTN_JOB_DT
+    import ctypes as C
+    import numpy as np
+    lib = _lib.load()
+    if _ATTN_JOB_DT is None:
+        _ATTN_JOB_DT = np.dtype([("q0", "<u8"), ("q1", "<u8"), ("k0", "<u8"), ("k1", "<u8"), ("v", "<u8"), ("bits", "<u8"), ("out", "<u8"),
+                                 ("ldq0", "<i4"), ("ldq1", "<i4"), ("ldk0", "<i4"), ("ldk1", "<i4"), ("ldv", "<i4"), ("ldo", "<i4"),
+                                 ("Lq", "<i4"), ("Lk", "<i4")], align=True)
+        assert _ATTN_JOB_DT.itemsize == 88
+    n = len(jobs)
+    tab = np.zeros(n, dtype=_ATTN_JOB_DT)
+    nb = 0
+    for i, (q, k, v, bits, q2, k2, out) in enumerate(jobs):
+        pq, ldq = _rows(q, "q")
+        pk, ldk = _rows(k, "k")
+        pv, ldv = _rows(v, "v")
+        pq2 = pk2 = ldq2 = ldk2 = 0
+        if q2 is not None:
+            pq2, ldq2 = _rows(q2, "q2")
+            pk2, ldk2 = _rows(k2, "k2")
+        Lq, Lk = q.shape[0], k.shape[0]
+        if q.shape[1] != num_heads * 32 or v.shape[1] != num_heads * 32:
+            raise ValueError("attention_parts: head slices must be 32 channels wide")
+        if bits is not None and tuple(bits.shape) != (Lq, (Lk + 31) // 32):
+            raise ValueError("attention_parts: mask bits shape mismatch")
+        po, ldo = _rows(out, "out")
+        if out.shape[0] != Lq or out.shape[1] != num_heads * 32:
+            raise ValueError("attention_parts: `out` must be fp32 [Lq, H * 32] rows")
+        tab[i] = (pq, pq2, pk, pk2, pv, 0 if bits is None else _ptr(bits, torch.int32, "mask_bits"), po, ldq, ldq2, ldk, ldk2, ldv, ldo, Lq, Lk)
+        nb += lib.sd3d_attention_ws_bytes(Lq, num_heads)
+    ws = _WS6.get(nb, jobs[0][0].device)                 # consumed by the next launch on this stream, before the next attention refills it
+    ks = (C.c_int32 * n)()
+    off = (C.c_int64 * n)()
+    _lib.check(lib.sd3d_attention_batch_parts(n, tab.ctypes.data, num_heads, float(scale), 1 if bf16_decoder_active() else 0,
+                                              ws.data_ptr(), ws.numel(), ks, off, _stream()), "attention_parts")
+    return ws, [(int(ks[i]), int(off[i])) for i in range(n)]
+
+
+def mask_bits_batch(logits_list, S_list, thr, out=None):
+    """mask_bits for several scenes' logit matrices in one launch -> list of bit tensors (`out`: contiguous int32 [Q_i, ceil(S_i / 32)]
+    tensors to write into, e.g. slices of one buffer)."""
     import ctypes as C
     lib = _lib.load()
     n = len(logits_list)
-    out = []
+    given, out = out, []
     P, I, L = (C.c_void_p * n), (C.c_int * n), (C.c_int64 * n)
     lp, ld, Q, S, bp, nw = P(), I(), L(), I(), P(), I()
     for i, (lg, s) in enumerate(zip(logits_list, S_list)):
         lp[i], ld[i] = _rows(lg, "logits")
         Q[i], S[i] = lg.shape[0], int(s)
         nw[i] = (int(s) + 31) // 32
-        bits = torch.empty(lg.shape[0], nw[i], dtype=torch.int32, device=lg.device)
+        if given is not None:
+            bits = given[i]
+            if tuple(bits.shape) != (lg.shape[0], nw[i]) or not bits.is_contiguous() or bits.dtype != torch.int32 or not bits.is_cuda:
+                raise ValueError("mask_bits_batch: `out` entries must be contiguous int32 [Q, ceil(S / 32)] device tensors")
+        else:
+            bits = torch.empty(lg.shape[0], nw[i], dtype=torch.int32, device=lg.device)
         bp[i] = bits.data_ptr()
         out.append(bits)
     _lib.check(lib.sd3d_mask_bits_batch(n, lp, ld, Q, S, bp, nw, float(thr), _stream()), "mask_bits_batch")

@@ -1,0 +1,155 @@
+"""Host side of the row-chain executor (csrc/rowchain.hip, `sd3d_row_chain`): builds the `sd3d_rc_program` a launch interprets.
+
+A program is a list of ops over LDS slots ([16 rows][260] fp32 each) that one workgroup runs for 16 consecutive query rows of one
+scene - the row-local part of a decoder layer (`instance_seg_3d_decoder.py:606-799`) as ONE launch.  The struct layout below mirrors
+`include/segdino3d_hip.h` (checked against `sd3d_row_chain_program_bytes()` when the library is loaded).
+"""
+from __future__ import annotations
+
+import numpy as np
+import torch
+
+from . import _lib, ops
+
+MAX_OPS, MAX_PROGRAMS, MAX_BATCH = 44, 4, 16
+LOAD, STORE, LINEAR, LN, PE, BOX, MERGE, BITS2D, ATTN = 1, 2, 3, 4, 5, 6, 7, 8, 9
+F_NO_LDS_DST, F_NORMALIZE, F_KEYS_2D, F_MASK_BITS2D = 1, 2, 4, 8
+NONE = 0xFF
+
+OP_DT = np.dtype([("type", "u1"), ("act", "u1"), ("src0", "u1"), ("src1", "u1"), ("dst", "u1"), ("res", "u1"), ("flag", "u1"), ("aux", "u1"),
+                  ("k0", "<u2"), ("k1", "<u2"), ("cout", "<u2"), ("pad_", "<u2"), ("ld", "<i4"), ("f0", "<f4"),
+                  ("p0", "<u8"), ("p1", "<u8"), ("p2", "<u8"), ("p3", "<u8"), ("p4", "<u8")], align=True)
+SCENE_DT = np.dtype([("q0", "<i4"), ("nq", "<i4"), ("m0", "<i4"), ("nm", "<i4"), ("bits_off", "<i4"), ("nw", "<i4"), ("near_off", "<i4"),
+                     ("ksplit", "<i4"), ("part_off", "<i8")], align=True)
+PROGRAM_DT = np.dtype([("n_scenes", "<i4"), ("n_programs", "<i4"), ("n_slots", "<i4"), ("nw_max", "<i4"), ("nw2_max", "<i4"), ("pad_", "<i4"),
+                       ("rng", "<u8"), ("tile0", "<i4", (MAX_BATCH + 1,)), ("prog_begin", "<i4", (MAX_PROGRAMS + 1,)),
+                       ("scenes", SCENE_DT, (MAX_BATCH,)), ("ops", OP_DT, (MAX_OPS,))], align=True)
+assert OP_DT.itemsize == 64 and SCENE_DT.itemsize == 40
+_checked = False
+
+
+def _f32(t, name):
+    if t is None:
+        return 0
+    if not t.is_cuda:
+        raise RuntimeError(f"row_chain {name}: expected a tensor on the HIP device, got {t.device} (no CPU fallback)")
+    if t.dtype != torch.float32:
+        raise TypeError(f"row_chain {name}: expected float32, got {t.dtype}")
+    return t.data_ptr()
+
+
+def _rows(t, name):
+    """2-D fp32 device tensor with contiguous rows -> (ptr, row stride)."""
+    if t.dim() != 2 or t.stride(1) != 1:
+        raise ValueError(f"row_chain {name}: expected a 2-D tensor with contiguous rows")
+    return _f32(t, name), t.stride(0)
+
+
+class Program:
+    """One launch of `sd3d_row_chain`.  Slots are small integers; `begin()` starts a further program (gridDim.y) over the same rows."""
+
+    def __init__(self, n_slots: int, rng=None):
+        self.buf = np.zeros(1, dtype=PROGRAM_DT)
+        self.p = self.buf[0]
+        self.n_ops = 0
+        self.n_programs = 1
+        self.p["n_slots"] = n_slots
+        self.p["rng"] = 0 if rng is None else _f32(rng, "rng")
+        self.p["prog_begin"][0] = 0
+        self._keep = [rng]
+
+    def begin(self):
+        if self.n_programs >= MAX_PROGRAMS:
+            raise ValueError("row_chain: at most 4 programs per launch")
+        self.p["prog_begin"][self.n_programs] = self.n_ops
+        self.n_programs += 1
+
+    def _op(self, keep=(), **kw):
+        self._keep.extend(keep)          # every tensor an op points at lives at least until the launch is enqueued (stream-ordered allocator)
+        if self.n_ops >= MAX_OPS:
+            raise ValueError(f"row_chain: more than {MAX_OPS} ops in one launch")
+        o = self.p["ops"][self.n_ops]
+        o["src0"] = o["src1"] = o["dst"] = o["res"] = NONE
+        for k, v in kw.items():
+            o[k] = v
+        self.n_ops += 1
+
+    # ---- ops ---------------------------------------------------------------------------------------------------------------
+    def load(self, dst, t, width=None):
+        ptr, ld = _rows(t, "LOAD")
+        self._op(keep=(t,), type=LOAD, dst=dst, cout=t.shape[1] if width is None else width, ld=ld, p0=ptr)
+
+    def store(self, src, t, width=None):
+        ptr, ld = _rows(t, "STORE")
+        self._op(keep=(t,), type=STORE, src0=src, cout=t.shape[1] if width is None else width, ld=ld, p0=ptr)
+
+    def linear(self, dst, src0, w, b=None, act=None, res=None, src1=None, gout=None):
+        """dst = act([src0 | src1] w^T + b (+ res)); dst None: only the global copy `gout` [rows, cout]."""
+        cout, K = w.shape
+        if not w.is_contiguous():
+            raise ValueError("row_chain LINEAR: weight must be contiguous")
+        k1 = K // 2 if src1 is not None else 0
+        gp, gld = (0, 0) if gout is None else _rows(gout, "LINEAR out")
+        if gout is not None and gout.shape[1] != cout:
+            raise ValueError("row_chain LINEAR: global output width != cout")
+        self._op(keep=(w, b, gout), type=LINEAR, act=ops.ACT[act], src0=src0, src1=NONE if src1 is None else src1, dst=NONE if dst is None else dst,
+                 res=NONE if res is None else res, flag=F_NO_LDS_DST if dst is None else 0, k0=K - k1, k1=k1, cout=cout, ld=gld,
+                 p0=_f32(w, "weight"), p1=_f32(b, "bias"), p2=gp)
+
+    def ln(self, dst, src, g, b, res=None, act=None, eps=1e-5, gout=None):
+        gp, gld = (0, 0) if gout is None else _rows(gout, "LN out")
+        self._op(keep=(g, b, gout), type=LN, act=ops.ACT[act], src0=src, dst=dst, res=NONE if res is None else res, f0=eps, ld=gld, p0=_f32(g, "ln weight"),
+                 p1=_f32(b, "ln bias"), p2=gp)
+
+    def pe(self, dst, xyz, dim_t, axis, num_slot=None, den=None):
+        if xyz.shape[1] != 3 or not xyz.is_contiguous() or (den is not None and (tuple(den.shape) != tuple(xyz.shape) or not den.is_contiguous())):
+            raise ValueError("row_chain PE: xyz / denominator must be contiguous [rows, 3]")
+        if axis.dtype != torch.int8:
+            raise TypeError("row_chain PE: axis table must be int8")
+        self._op(keep=(xyz, dim_t, axis, den), type=PE, dst=dst, src0=NONE if num_slot is None else num_slot, p0=_f32(xyz, "xyz"), p1=_f32(dim_t, "dim_t"), p2=axis.data_ptr(),
+                 p3=_f32(den, "den"))
+
+    def box(self, ref, dc_slot, center, size_prev=None, ds_slot=None, size=None, size_metric=None, normalize=False):
+        for t in (ref, center, size_prev, size, size_metric):
+            if t is not None and (t.dim() != 2 or t.shape[1] != 3 or not t.is_contiguous()):
+                raise ValueError("row_chain BOX: tensors must be contiguous [rows, 3]")
+        self._op(keep=(ref, center, size_prev, size, size_metric), type=BOX, src0=dc_slot, src1=NONE if ds_slot is None else ds_slot, flag=F_NORMALIZE if normalize else 0, p0=_f32(ref, "ref"),
+                 p1=_f32(size_prev, "size_prev"), p2=_f32(center, "center"), p3=_f32(size, "size"), p4=_f32(size_metric, "size_metric"))
+
+    def merge(self, dst, parts, out):
+        ptr, ld = _rows(out, "MERGE out")
+        self._op(keep=(parts, out), type=MERGE, dst=dst, ld=ld, p0=0 if parts is None else parts.data_ptr(), p1=ptr)
+
+    def bits2d(self, blocked_all, near_all):
+        self._op(keep=(blocked_all, near_all), type=BITS2D, p0=blocked_all.data_ptr(), p1=near_all.data_ptr())
+
+    def attn(self, dst, q_slot, k, v, scale, aux, keys_2d=False, masked=False):
+        kp, ldk = _rows(k, "ATTN keys")
+        vp, ldv = _rows(v, "ATTN values")
+        if ldk != ldv:
+            raise ValueError("row_chain ATTN: keys and values must share their row stride")
+        self._op(keep=(k, v), type=ATTN, dst=dst, src0=q_slot, aux=aux, flag=(F_KEYS_2D if keys_2d else 0) | (F_MASK_BITS2D if masked else 0), ld=ldk,
+                 f0=scale, p0=kp, p1=vp)
+
+    # ---- launch ------------------------------------------------------------------------------------------------------------
+    def launch(self, scenes, nw_max=0, nw2_max=0):
+        """scenes: list of dicts(q0, nq[, m0, nm, bits_off, nw, near_off, ksplit, part_off])."""
+        global _checked
+        lib = _lib.load()
+        if not _checked:
+            if lib.sd3d_row_chain_program_bytes() != PROGRAM_DT.itemsize:
+                raise RuntimeError(f"sd3d_rc_program: library {lib.sd3d_row_chain_program_bytes()} bytes, binding {PROGRAM_DT.itemsize}")
+            _checked = True
+        p = self.p
+        p["n_scenes"], p["n_programs"] = len(scenes), self.n_programs
+        p["prog_begin"][self.n_programs] = self.n_ops
+        p["nw_max"], p["nw2_max"] = nw_max, nw2_max
+        tiles = 0
+        for i, sc in enumerate(scenes):
+            p["tile0"][i] = tiles
+            tiles += (sc["nq"] + 15) // 16
+            s = p["scenes"][i]
+            for k in ("q0", "nq", "m0", "nm", "bits_off", "nw", "near_off", "ksplit", "part_off"):
+                s[k] = sc.get(k, 0)
+        p["tile0"][len(scenes)] = tiles
+        _lib.check(lib.sd3d_row_chain(self.buf.ctypes.data, ops._stream()), "row_chain")

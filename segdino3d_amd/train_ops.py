@@ -164,7 +164,11 @@ def batch_norm_act(x, bn: "torch.nn.BatchNorm1d", res=None, act=None):
     tracked = bn.track_running_stats and bn.running_mean is not None
     if tracked and bn.momentum is not None and bn.running_mean.is_contiguous() and bn.running_var.is_contiguous():
         running = (bn.running_mean, bn.running_var, bn.num_batches_tracked, bn.momentum)
-        return _BatchNormAct.apply(x, bn.weight, bn.bias, res, act, bn.eps, running)[0]
+        y = _BatchNormAct.apply(x, bn.weight, bn.bias, res, act, bn.eps, running)[0]
+        # the kernel advanced the buffers behind torch's back: bump their version counters like the mul_ / add_ it replaces did, so
+        # that DerivedWeights._sources_stamp (folded-BN copies of the eval path) sees the write whatever called this
+        torch.autograd.graph.increment_version((bn.running_mean, bn.running_var, bn.num_batches_tracked))
+        return y
     y, mean, var = _BatchNormAct.apply(x, bn.weight, bn.bias, res, act, bn.eps)
     if tracked:                                                  # momentum=None: cumulative average, needs the step count on the host
         with torch.no_grad():

@@ -30,7 +30,7 @@ def test_the_three_host_modes_hold_the_same_bits():
     from segdino3d_amd.configs import scannet200_model_cfg
     from segdino3d_amd.synth import make_scene, sharpen_random_model, structure_scene
     d = torch.device("cuda:0")
-    pts, tgt = make_scene(5, n_points=20003, n_superpoints=150, n_query2d=12)
+    pts, tgt = make_scene(1, n_points=8003, n_superpoints=64, n_query2d=8)       # (the smoke scene with a point count that is no multiple of 8)
     structure_scene(pts, tgt)
     cfg = scannet200_model_cfg(query_num=-1)
     cfg["test_cfg"]["npoint_thr"] = 20
