@@ -283,7 +283,8 @@ int sd3d_run_layers(const sd3d_layer* layers, int n_layers, const sd3d_table* ta
 #define SD3D_RC_MAX_PROGRAMS 4
 enum { SD3D_RC_LOAD = 1,   /* slot dst[:, :cout] = p0[row, :cout] (row stride ld) */
        SD3D_RC_STORE = 2,  /* p0[row, :cout] = slot src0 */
-       SD3D_RC_LINEAR = 3, /* dst = act([src0 (k0 ch) | src1 (k1 ch)] . W^T + bias (+ res)); p0 = W [cout, k0 + k1], p1 = bias | NULL,
+       SD3D_RC_LINEAR = 3, /* dst = act([src0 (k0 ch) | src1 (k1 ch)] . W^T + bias (+ res)); p0 = W [cout, K = k0 + k1] PACKED in MFMA-fragment order
+                            * P[tile = col / 16][g = ch / 16][lane = 16 * ((ch % 16) / 4) + col % 16][ch % 4] = W[min(col, cout - 1)][ch], p1 = bias | NULL,
                             * p2 = optional global copy (row stride ld); flag NO_LDS_DST: only the global copy */
        SD3D_RC_LN = 4,     /* dst = act(LayerNorm_256(src0 (+ res)) * p0 + p1), eps = f0; p2 = optional global copy (ld) */
        SD3D_RC_PE = 5,     /* dst = sine PE (utils.py:53-105) of p0[row, 0:3] in the scene's range; p1 = dim_t [256], p2 = axis int8 [256];
@@ -301,6 +302,7 @@ enum { SD3D_RC_LOAD = 1,   /* slot dst[:, :cout] = p0[row, :cout] (row stride ld
 #define SD3D_RC_F_NORMALIZE 2
 #define SD3D_RC_F_KEYS_2D 4
 #define SD3D_RC_F_MASK_BITS2D 8
+#define SD3D_RC_F_INPLACE 16           /* LINEAR: dst overlaps src0 / src1 (a barrier separates the contraction from the stores) */
 typedef struct sd3d_rc_op {
     uint8_t type, act, src0, src1, dst, res, flag, aux;
     uint16_t k0, k1, cout, pad_;

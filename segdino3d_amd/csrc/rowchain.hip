@@ -65,64 +65,102 @@ struct RCCtx {
 
 // ------------------------------------------------------------------------------------------------ LINEAR
 // acc[t][i] = out[row 4 kq + i][col (wave + 16 t) * 16 + c16]
-template <int NT, int GB>
+// NB > 0: the number of 16-MFMA blocks is a compile-time constant and the block loop is unrolled completely - straight-line code, so
+// the waitcnt pass counts the outstanding requests exactly (around a loop back-edge it falls back to vmcnt(0): every block then waits
+// for the requests issued for the NEXT two, 10 us per 256 x 256 Linear instead of 4).  NB == 0: any K, runtime loop.
+template <int NT, int GB, int NB>
 __device__ __forceinline__ void rc_linear_body(const RCOp& op, const RCCtx& cx, f32x4 (&acc)[NT]) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int c16 = lane & 15, kq = lane >> 4;
     const int K0 = op.k0, K = op.k0 + op.k1, Cout = op.cout;
-    const float* __restrict__ W = (const float*)op.p0;
+    const float* __restrict__ W = (const float*)op.p0;   // packed
     const float* a0 = cx.lds + op.src0 * RC_SLOT + c16 * rc_ld(op.k0) + 4 * kq;
     const float* a1 = cx.lds + op.src1 * RC_SLOT + c16 * rc_ld(op.k1) + 4 * kq - K0;     // indexed by the global channel
+    // W is PRE-PACKED in MFMA-fragment order (rowchain.pack_weight): [16-column tile][16-channel group][lane][4] - the 64 lanes of a
+    // request read 1 KB back to back (8 whole cache lines).  From the nn.Linear layout [cout, K] the same request touches 16 rows x
+    // 64 bytes - 16 half lines - and cost 2.3 us more per 256 x 256 Linear (8.5 vs 6.2 us, measured).
     const float* wrow[NT];
+    const int ngroups = K >> 4;
+    const int ntiles = (Cout + 15) >> 4;
 #pragma unroll
     for (int t = 0; t < NT; ++t) {
-        int col = (wave + 16 * t) * 16 + c16;
-        col = col < Cout ? col : Cout - 1;
-        wrow[t] = W + (int64_t)col * K + 4 * kq;
+        int tile = wave + 16 * t;
+        tile = tile < ntiles ? tile : ntiles - 1;
+        wrow[t] = W + ((int64_t)tile * ngroups * 64 + lane) * 4;
         acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
     }
-    const int nb = (K >> 4) / GB;
-    f32x4 cur[GB][NT], nxt[GB][NT];
+    const int nb = NB > 0 ? NB : (K >> 4) / GB;
+    // W fragments of three 16-MFMA blocks in registers: block b multiplies while b + 1 and b + 2 are in flight (one CU streams the
+    // whole W [cout, K] for its 16 rows: 64 KB per block and workgroup, 1 - 2 us of L2 / HBM latency to cover).
+    f32x4 w[3][GB][NT];
+    auto load_w = [&](f32x4 (&wb)[GB][NT], int blk) {
 #pragma unroll
-    for (int g = 0; g < GB; ++g)
+        for (int g = 0; g < GB; ++g)
 #pragma unroll
-        for (int t = 0; t < NT; ++t) cur[g][t] = *(const f32x4*)(wrow[t] + 16 * g);
-    for (int b = 0; b < nb; ++b) {
-        const int ch0 = b * GB * 16;
-        if (b + 1 < nb) {
+            for (int t = 0; t < NT; ++t) wb[g][t] = *(const f32x4*)(wrow[t] + (blk * GB + g) * 256);
+    };
+    f32x4 part[4];
 #pragma unroll
-            for (int g = 0; g < GB; ++g)
-#pragma unroll
-                for (int t = 0; t < NT; ++t) nxt[g][t] = *(const f32x4*)(wrow[t] + ch0 + 16 * (GB + g));
-        }
+    for (int e = 0; e < 4; ++e) part[e] = f32x4{0.f, 0.f, 0.f, 0.f};
+    auto mma = [&](const f32x4 (&wb)[GB][NT], int blk) {
         f32x4 a[GB];
 #pragma unroll
         for (int g = 0; g < GB; ++g) {
-            const int ch = ch0 + 16 * g;
+            const int ch = (blk * GB + g) * 16;
             a[g] = *(const f32x4*)((ch < K0 ? a0 : a1) + ch);
         }
+        // NT = 1: one output tile per wave would be ONE chain of dependent MFMAs (K / 4 of them, ~4x the issue interval apart: a lone
+        // wave needs 4.9 us for K = 256); the contraction is therefore dealt to four accumulators (channel e of every quad -> chain e)
+        // that are added in a fixed order at the end.
 #pragma unroll
         for (int g = 0; g < GB; ++g)
 #pragma unroll
             for (int e = 0; e < 4; ++e)
 #pragma unroll
-                for (int t = 0; t < NT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[g][e], cur[g][t][e], acc[t], 0, 0, 0);
+                for (int t = 0; t < NT; ++t) {
+                    if (NT == 1) part[e] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[g][e], wb[g][t][e], part[e], 0, 0, 0);
+                    else acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[g][e], wb[g][t][e], acc[t], 0, 0, 0);
+                }
+    };
+    if (NB > 0) {
+        load_w(w[0], 0);
+        if (NB > 1) load_w(w[1], 1);
 #pragma unroll
-        for (int g = 0; g < GB; ++g)
-#pragma unroll
-            for (int t = 0; t < NT; ++t) cur[g][t] = nxt[g][t];
+        for (int b = 0; b < NB; ++b) {
+            if (b + 2 < NB) load_w(w[(b + 2) % 3], b + 2);
+            __builtin_amdgcn_sched_barrier(0);                // keep the requests ABOVE the block they overlap (the scheduler sinks them to save registers)
+            mma(w[b % 3], b);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    } else {
+        // (requests past the end are clamped, not skipped: a conditional load costs an s_waitcnt vmcnt(0))
+        load_w(w[0], 0);
+        load_w(w[1], nb > 1 ? 1 : 0);
+        int b = 0;
+        while (true) {
+            load_w(w[2], b + 2 < nb ? b + 2 : nb - 1); mma(w[0], b); if (++b >= nb) break;
+            load_w(w[0], b + 2 < nb ? b + 2 : nb - 1); mma(w[1], b); if (++b >= nb) break;
+            load_w(w[1], b + 2 < nb ? b + 2 : nb - 1); mma(w[2], b); if (++b >= nb) break;
+        }
     }
+    if (NT == 1) acc[0] = (part[0] + part[1]) + (part[2] + part[3]);
 }
 
-template <int NT, int GB>
+template <int NT, int GB, int NB>
 __device__ __forceinline__ void rc_linear(const RCOp& op, const RCCtx& cx) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int c16 = lane & 15, kq = lane >> 4;
-    f32x4 acc[NT];
-    rc_linear_body<NT, GB>(op, cx, acc);
-    __syncthreads();                                          // every wave has read its inputs: dst may alias a source
     const int Cout = op.cout;
     const float* __restrict__ bias = (const float*)op.p1;
+    float bv[NT];                                             // requested before the contraction: its latency hides behind the MFMAs
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+        const int col = (wave + 16 * t) * 16 + c16;
+        bv[t] = bias ? bias[col < Cout ? col : Cout - 1] : 0.f;
+    }
+    f32x4 acc[NT];
+    if (wave * 16 < Cout) rc_linear_body<NT, GB, NB>(op, cx, acc);      // (a wave without a column tile - the 3- and 199-column heads - sits the op out)
+    if (op.flag & SD3D_RC_F_INPLACE) __syncthreads();         // dst overlaps a source: every wave must have read its inputs first
     const int ldd = rc_ld(Cout);
     float* dst = cx.lds + op.dst * RC_SLOT;
     const float* res = op.res != 0xFF ? cx.lds + op.res * RC_SLOT : nullptr;
@@ -130,12 +168,11 @@ __device__ __forceinline__ void rc_linear(const RCOp& op, const RCCtx& cx) {
 #pragma unroll
     for (int t = 0; t < NT; ++t) {
         const int col = (wave + 16 * t) * 16 + c16;
-        if (col >= Cout) continue;
-        const float bv = bias ? bias[col] : 0.f;
+        if (col >= Cout || wave * 16 >= Cout) continue;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const int r = 4 * kq + i;
-            float y = acc[t][i] + bv;
+            float y = acc[t][i] + bv[t];
             if (res) y += res[r * ldd + col];
             y = rc_act(y, op.act);
             if (!(op.flag & SD3D_RC_F_NO_LDS_DST)) dst[r * ldd + col] = y;
@@ -148,10 +185,23 @@ __device__ __forceinline__ void rc_linear_dispatch(const RCOp& op, const RCCtx& 
     const int ct = (op.cout + 15) >> 4;
     const int nt = (ct + 15) >> 4;
     const int ng = (op.k0 + op.k1) >> 4;
-    if (nt <= 1) { if ((ng & 3) == 0) rc_linear<1, 4>(op, cx); else if ((ng & 1) == 0) rc_linear<1, 2>(op, cx); else rc_linear<1, 1>(op, cx); }
-    else if (nt == 2) { if ((ng & 1) == 0) rc_linear<2, 2>(op, cx); else rc_linear<2, 1>(op, cx); }
-    else if (nt == 3) rc_linear<3, 1>(op, cx);
-    else rc_linear<4, 1>(op, cx);
+    if (nt <= 1) {                                            // <= 256 output columns: the decoder's d_model-wide Linears and the small heads
+        if (ng == 16) rc_linear<1, 4, 4>(op, cx);             // K = 256
+        else if (ng == 32) rc_linear<1, 4, 8>(op, cx);        // K = 512 ([queries | query_pos])
+        else if (ng == 64) rc_linear<1, 4, 16>(op, cx);       // K = 1024 (second FFN Linear)
+        else if (ng == 6) rc_linear<1, 2, 3>(op, cx);         // K = 96 (backbone features)
+        else if ((ng & 3) == 0) rc_linear<1, 4, 0>(op, cx);
+        else if ((ng & 1) == 0) rc_linear<1, 2, 0>(op, cx);
+        else rc_linear<1, 1, 0>(op, cx);
+    } else if (nt == 2) {
+        if ((ng & 1) == 0) rc_linear<2, 2, 0>(op, cx); else rc_linear<2, 1, 0>(op, cx);
+    } else if (nt == 3) {
+        if (ng == 32) rc_linear<3, 1, 32>(op, cx);            // packed self-attention q / k / v projection: K = 512 -> 768
+        else rc_linear<3, 1, 0>(op, cx);
+    } else {
+        if (ng == 16) rc_linear<4, 1, 16>(op, cx);            // first FFN Linear: K = 256 -> 1024
+        else rc_linear<4, 1, 0>(op, cx);
+    }
 }
 
 // ------------------------------------------------------------------------------------------------ LN (D = 256)
@@ -318,6 +368,37 @@ __device__ __forceinline__ void rc_bits2d(const RCOp& op, const RCCtx& cx, const
         uint32_t word[RC_R];
 #pragma unroll
         for (int q = 0; q < RC_R; ++q) word[q] = 0u;
+        if (nw <= 128) {
+            // <= 4096 superpoints: a lane holds two words of every near row; the rows of the unit's 16 keys are requested together
+            // (one key at a time the unit costs 16 dependent L2 round trips)
+            uint32_t nb[16][2];
+#pragma unroll
+            for (int jb = 0; jb < 16; ++jb) {
+                const int m = unit * 16 + jb;
+                const int mc = m < Mq ? m : (Mq > 0 ? Mq - 1 : 0);
+#pragma unroll
+                for (int i = 0; i < 2; ++i) {
+                    const int w = lane + 64 * i;
+                    nb[jb][i] = (Mq > 0 && w < nw) ? near[(int64_t)mc * nw + w] : 0u;
+                }
+            }
+            uint32_t o[2];
+#pragma unroll 1
+            for (int q = 0; q < RC_R; ++q) {
+                o[0] = lane < nw ? cx.open_w[q * cx.nw_max + lane] : 0u;
+                o[1] = lane + 64 < nw ? cx.open_w[q * cx.nw_max + lane + 64] : 0u;
+                uint32_t wq = 0u;
+#pragma unroll
+                for (int jb = 0; jb < 16; ++jb) {
+                    const int m = unit * 16 + jb;
+                    const bool hit = __ballot(((o[0] & nb[jb][0]) | (o[1] & nb[jb][1])) != 0u) != 0ull;
+                    const uint32_t blk = m < Mq ? (hit ? 0u : 1u) : (m == Mq ? 0u : 1u);
+                    wq |= blk << jb;
+                }
+                if (lane == 0) out16[q * (cx.nw2_max * 2) + unit] = (uint16_t)wq;
+            }
+            continue;
+        }
         for (int jb = 0; jb < 16; ++jb) {
             const int m = unit * 16 + jb;                      // wave-uniform
             uint32_t acc[RC_R];
@@ -325,9 +406,9 @@ __device__ __forceinline__ void rc_bits2d(const RCOp& op, const RCCtx& cx, const
             for (int q = 0; q < RC_R; ++q) acc[q] = 0u;
             if (m < Mq) {
                 for (int w = lane; w < nw; w += 64) {
-                    const uint32_t nb = near[(int64_t)m * nw + w];
+                    const uint32_t nbw = near[(int64_t)m * nw + w];
 #pragma unroll
-                    for (int q = 0; q < RC_R; ++q) acc[q] |= cx.open_w[q * cx.nw_max + w] & nb;
+                    for (int q = 0; q < RC_R; ++q) acc[q] |= cx.open_w[q * cx.nw_max + w] & nbw;
                 }
             }
 #pragma unroll
@@ -375,14 +456,14 @@ __device__ __forceinline__ void rc_attn(const RCOp& op, const RCCtx& cx, const R
     const int ntiles = (Lk + 15) >> 4;
     const int t_mid = (ntiles + 1) >> 1;
     const int t_begin = half ? t_mid : 0, t_end = half ? ntiles : t_mid;
-    for (int t = t_begin; t < t_end; ++t) {
-        const int kt0 = t * 16;
-        // K rows: A[i = key c16][k = channel]
+    // K rows: A[i = key c16][k = channel];  V: A[i = dv c16 (+16)][k = key 4 kq + e].  The next tile's rows are requested before this
+    // tile multiplies (a tile past the end re-reads the last one: unconditional requests).
+    auto load_tile = [&](int t, f32x4& k0, f32x4& k1, float (&v0)[4], float (&v1)[4]) {
+        const int kt0 = (t < t_end ? t : t_end - 1) * 16;
         const int krow = key0 + min(kt0 + c16, Lk - 1);
         const float* ks = Kp + (int64_t)krow * ldk + head * 32 + 4 * kq;
-        const f32x4 k0 = *(const f32x4*)ks, k1 = *(const f32x4*)(ks + 16);
-        // V: A[i = dv c16 (+16)][k = key 4 kq + e]
-        float v0[4], v1[4];
+        k0 = *(const f32x4*)ks;
+        k1 = *(const f32x4*)(ks + 16);
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
             const int vrow = key0 + min(kt0 + 4 * kq + e, Lk - 1);
@@ -390,6 +471,13 @@ __device__ __forceinline__ void rc_attn(const RCOp& op, const RCCtx& cx, const R
             v0[e] = vs[0];
             v1[e] = vs[16];
         }
+    };
+    f32x4 k0, k1, k0n, k1n;
+    float v0[4], v1[4], v0n[4], v1n[4];
+    if (t_begin < t_end) load_tile(t_begin, k0, k1, v0, v1);
+    for (int t = t_begin; t < t_end; ++t) {
+        const int kt0 = t * 16;
+        load_tile(t + 1, k0n, k1n, v0n, v1n);
         f32x4 S = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int e = 0; e < 4; ++e) S = __builtin_amdgcn_mfma_f32_16x16x4f32(k0[e], qf[0][e], S, 0, 0, 0);
@@ -427,6 +515,9 @@ __device__ __forceinline__ void rc_attn(const RCOp& op, const RCCtx& cx, const R
             O[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(v0[e], pr[e], O[0], 0, 0, 0);
             O[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(v1[e], pr[e], O[1], 0, 0, 0);
         }
+        k0 = k0n; k1 = k1n;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { v0[e] = v0n[e]; v1[e] = v1n[e]; }
     }
     l += __shfl_xor(l, 16);
     l += __shfl_xor(l, 32);

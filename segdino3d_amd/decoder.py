@@ -193,7 +193,14 @@ _F_TLS = threading.local()
 BATCH_DECODER = os.environ.get("SD3D_BATCH_DECODER", "1") != "0"
 # SD3D_FUSED_DECODER=0: evaluation runs the op-by-op decoder of rounds 1-3 (`_forward_scene` / `_forward_batch`) instead of the
 # row-chain launches (`_forward_fused`); training always runs op by op (autograd nodes)
-FUSED_DECODER = os.environ.get("SD3D_FUSED_DECODER", "1") != "0"
+# "auto" (default): a scene takes the row-chain path when it has more than FUSED_MIN_ROWS query rows (one query per superpoint,
+# the reference's evaluation mode: 15.7 -> 15.0 ms per scene); a scene with a few hundred queries stays op by op (12.6 vs 12.85 ms:
+# thirteen 16-row workgroups are bound by ONE CU's fp32 matrix rate, 3.9 us per 256 x 256 Linear, and cannot outrun ~27 small
+# launches that each use 50 - 200 CUs - profiles/EXPERIMENTS.md, round 4).  "1" / "0" force it for every scene.
+_fd = os.environ.get("SD3D_FUSED_DECODER", "auto")
+FUSED_DECODER = "auto" if _fd == "auto" else (_fd != "0")
+FUSED_MIN_ROWS = int(os.environ.get("SD3D_FUSED_MIN_ROWS", "512"))
+FUSED_SA_MAX_KEYS = int(os.environ.get("SD3D_FUSED_SA_MAX_KEYS", "1024"))
 
 
 def _F():
@@ -327,6 +334,8 @@ class ScanNetQueryDecoder(DerivedWeights):
         self._packed = None
         self._pe_tables = {}
         ops.clear_split_cache()          # bf16 roundings of the packed weights die with them
+        from . import rowchain
+        rowchain.clear_pack_cache()      # and their MFMA-fragment-order copies (row-chain LINEAR)
 
     def packed(self, live=False):
         """Packed projection weights; `live=True` keeps them attached to the parameters (training: rebuilt every step, the
@@ -805,9 +814,11 @@ class ScanNetQueryDecoder(DerivedWeights):
         return results
 
     # ---- evaluation, positional variant: the row-local work of a layer as row-chain launches (csrc/rowchain.hip) ----------------
-    def _fusable(self):
-        """The fused path covers the SegDINO3D prototypes in evaluation: sine positional embedding, 256 channels in 8 heads."""
-        return (FUSED_DECODER and not self.training and self.add_positional_embedding and self.pos_type == "sine" and self.d_model == 256
+    def _fusable(self, rows=1 << 30):
+        """Does a scene with `rows` query rows take the fused (row-chain) path?  The path covers the SegDINO3D prototypes in evaluation:
+        sine positional embedding, 256 channels in 8 heads."""
+        want = rows > FUSED_MIN_ROWS if FUSED_DECODER == "auto" else bool(FUSED_DECODER)
+        return (want and not self.training and self.add_positional_embedding and self.pos_type == "sine" and self.d_model == 256
                 and self.num_heads == 8 and self.num_queries == 0 and ops.GEMM_MODE is None and ops.GG_FORCE_NT is None
                 and self.in_channels % 16 == 0 and self.ffn_layers[0].net[0].out_features <= 1024
                 and self.ffn_layers[0].net[0].out_features % 16 == 0)
@@ -948,6 +959,9 @@ class ScanNetQueryDecoder(DerivedWeights):
             size_q = torch.full((Q_tot, 3), 0.5, dtype=torch.float32, device=dev)
         ref_sizes = size_q
         ncls = self.out_cls[2].out_features
+        # self-attention inside chain C (a workgroup walks all keys of its scene for its 16 queries: 13 us at 200 keys, 194 us at 3000)
+        # or as its own launch (130 us at 3000 x 3000 on the whole chip)
+        sa_in_chain = max(Q_b) <= FUSED_SA_MAX_KEYS
         act_ffn = "relu" if self.activation_fn == "relu" else "gelu"
         for i in range(L):
             ops.baton_yield()
@@ -998,8 +1012,14 @@ class ScanNetQueryDecoder(DerivedWeights):
             size = size_metric = None
             P = Program(8, rng)
             P.load(0, queries1)
-            P.load(1, qkv[:, :d])
-            P.attn(2, 1, qkv[:, d:2 * d], qkv[:, 2 * d:], (d // H) ** -0.5, aux=6)
+            if sa_in_chain:
+                P.load(1, qkv[:, :d])
+                P.attn(2, 1, qkv[:, d:2 * d], qkv[:, 2 * d:], (d // H) ** -0.5, aux=6)
+            else:                                                # thousands of keys: the stand-alone kernel spreads them over the chip
+                a_sa = new(d)
+                ops.attention_batch([(qkv[q_off[b]:q_off[b + 1], :d], qkv[q_off[b]:q_off[b + 1], d:2 * d], qkv[q_off[b]:q_off[b + 1], 2 * d:],
+                                      None, None, None, a_sa[q_off[b]:q_off[b + 1]]) for b in range(B)], H, (d // H) ** -0.5)
+                P.load(2, a_sa)
             op = self.self_attn_layers[i].out_proj
             P.linear(3, 2, op.weight, op.bias, res=0)
             P.ln(0, 3, self.norm2[i].weight, self.norm2[i].bias)
@@ -1086,33 +1106,36 @@ class ScanNetQueryDecoder(DerivedWeights):
             _F_TLS.f, _F_TLS.p = prev, prev_p
 
     def _forward(self, x, sp_pos, sp_pos_wo_elastic, queries, queries_pos, dinox_queries, dinox_query_pos, scene_range):
-        finals, auxes = [], []
+        n = len(x)
+        finals, auxes = [None] * n, [None] * n
         if not self.add_positional_embedding:
-            for j in range(len(x)):
-                f, a = self._forward_scene_plain(x[j], queries[j])
-                finals.append(f)
-                auxes.append(a)
+            for j in range(n):
+                finals[j], auxes[j] = self._forward_scene_plain(x[j], queries[j])
         else:
             assert (sp_pos is not None) and (queries_pos is not None) and (scene_range is not None)
-        fused = self.add_positional_embedding and self._fusable() and len(x) <= 16 and all(q.shape[0] > 0 for q in queries)
-        if fused:
-            for f, a in self._forward_fused(x, sp_pos, sp_pos_wo_elastic if sp_pos_wo_elastic is not None else sp_pos, queries, queries_pos,
-                                            dinox_queries, dinox_query_pos, scene_range):
-                finals.append(f)
-                auxes.append(a)
-        batched = not fused and self.add_positional_embedding and self._batchable(x, queries, dinox_queries)
-        if batched:
-            for f, a in self._forward_batch(x, sp_pos, sp_pos_wo_elastic if sp_pos_wo_elastic is not None else sp_pos, queries, queries_pos,
-                                            dinox_queries, dinox_query_pos, scene_range):
-                finals.append(f)
-                auxes.append(a)
-        for j in range(len(x) if (self.add_positional_embedding and not batched and not fused) else 0):
-            f, a = self._forward_scene(
-                x[j], sp_pos[j], sp_pos_wo_elastic[j] if sp_pos_wo_elastic is not None else sp_pos[j], queries[j],
-                queries_pos[j], dinox_queries[j] if dinox_queries is not None else None,
-                dinox_query_pos[j] if dinox_query_pos is not None else None, scene_range[j][0], scene_range[j][1])
-            finals.append(f)
-            auxes.append(a)
+            wo = sp_pos_wo_elastic if sp_pos_wo_elastic is not None else sp_pos
+            pick = lambda lst, ids: None if lst is None else [lst[j] for j in ids]  # noqa: E731
+            # Which path a scene takes depends on ITS OWN query rows only (`_fusable`), never on what else is in the call: a scene of a
+            # batch gets the bits of its single-scene forward.  The scenes of a kind run together.
+            fused_ids = [j for j in range(n) if queries[j].shape[0] > 0 and self._fusable(queries[j].shape[0])]
+            plain_ids = [j for j in range(n) if j not in fused_ids]
+            for c0 in range(0, len(fused_ids), 16):
+                ids = fused_ids[c0:c0 + 16]
+                out = self._forward_fused(pick(x, ids), pick(sp_pos, ids), pick(wo, ids), pick(queries, ids), pick(queries_pos, ids),
+                                          pick(dinox_queries, ids), pick(dinox_query_pos, ids), pick(scene_range, ids))
+                for j, (f, a) in zip(ids, out):
+                    finals[j], auxes[j] = f, a
+            if plain_ids and self._batchable(pick(x, plain_ids), pick(queries, plain_ids), pick(dinox_queries, plain_ids)):
+                out = self._forward_batch(pick(x, plain_ids), pick(sp_pos, plain_ids), pick(wo, plain_ids), pick(queries, plain_ids),
+                                          pick(queries_pos, plain_ids), pick(dinox_queries, plain_ids), pick(dinox_query_pos, plain_ids),
+                                          pick(scene_range, plain_ids))
+                for j, (f, a) in zip(plain_ids, out):
+                    finals[j], auxes[j] = f, a
+            else:
+                for j in plain_ids:
+                    finals[j], auxes[j] = self._forward_scene(
+                        x[j], sp_pos[j], wo[j], queries[j], queries_pos[j], dinox_queries[j] if dinox_queries is not None else None,
+                        dinox_query_pos[j] if dinox_query_pos is not None else None, scene_range[j][0], scene_range[j][1])
         B = len(finals)
         result = dict(cls_preds=[f["cls_preds"] for f in finals], sem_preds=[f["sem_preds"] for f in finals],
                       masks=[f["masks"] for f in finals], scores=[f.get("scores") for f in finals], centers=[f["centers"] for f in finals],

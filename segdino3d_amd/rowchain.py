@@ -6,6 +6,10 @@ scene - the row-local part of a decoder layer (`instance_seg_3d_decoder.py:606-7
 """
 from __future__ import annotations
 
+import ctypes as C
+import struct
+import threading
+
 import numpy as np
 import torch
 
@@ -13,7 +17,7 @@ from . import _lib, ops
 
 MAX_OPS, MAX_PROGRAMS, MAX_BATCH = 44, 4, 16
 LOAD, STORE, LINEAR, LN, PE, BOX, MERGE, BITS2D, ATTN = 1, 2, 3, 4, 5, 6, 7, 8, 9
-F_NO_LDS_DST, F_NORMALIZE, F_KEYS_2D, F_MASK_BITS2D = 1, 2, 4, 8
+F_NO_LDS_DST, F_NORMALIZE, F_KEYS_2D, F_MASK_BITS2D, F_INPLACE = 1, 2, 4, 8, 16
 NONE = 0xFF
 
 OP_DT = np.dtype([("type", "u1"), ("act", "u1"), ("src0", "u1"), ("src1", "u1"), ("dst", "u1"), ("res", "u1"), ("flag", "u1"), ("aux", "u1"),
@@ -45,33 +49,76 @@ def _rows(t, name):
     return _f32(t, name), t.stride(0)
 
 
+_OP = struct.Struct("<8B4HifQQQQQ")
+_SCENE = struct.Struct("<8iq")
+_HEAD = struct.Struct("<6iQ17i5i")
+_OFF_SCENES = _HEAD.size
+_OFF_OPS = _OFF_SCENES + MAX_BATCH * _SCENE.size
+assert _OP.size == 64 and _SCENE.size == 40 and _OFF_SCENES == 120 and _OFF_OPS + MAX_OPS * _OP.size == PROGRAM_DT.itemsize
+
+
+def _nslots(width):
+    ld = 260 if width <= 256 else width + 4
+    return (16 * ld + 4159) // 4160
+
+
+_PACK_CACHE = {}
+_PACK_LOCK = threading.Lock()
+
+
+def pack_weight(w):
+    """nn.Linear weight [cout, K] -> the MFMA-fragment order the LINEAR op streams (include/segdino3d_hip.h):
+    P[tile][group][lane = 16 * kq + c16][e] = w[min(16 * tile + c16, cout - 1)][16 * group + 4 * kq + e].  Cached per source tensor
+    (address, shape, version counter; the entry keeps its source alive); owners that rewrite weights behind the version counter
+    call `clear_pack_cache()` (ScanNetQueryDecoder._derived_reset does)."""
+    key = (w.data_ptr(), tuple(w.shape), w._version)
+    with _PACK_LOCK:
+        hit = _PACK_CACHE.get(key)
+    if hit is not None:
+        return hit[0]
+    cout, K = w.shape
+    if K % 16:
+        raise ValueError("row_chain LINEAR: K must be a multiple of 16")
+    tiles = (cout + 15) // 16
+    src = w.detach()
+    if tiles * 16 != cout:
+        src = torch.cat([src, src[-1:].expand(tiles * 16 - cout, K)])
+    packed = src.reshape(tiles, 16, K // 16, 4, 4).permute(0, 2, 3, 1, 4).contiguous()       # [tile, group, kq, c16, e]
+    with _PACK_LOCK:
+        if len(_PACK_CACHE) > 4096:
+            _PACK_CACHE.clear()
+        _PACK_CACHE[key] = (packed, w)
+    return packed
+
+
+def clear_pack_cache():
+    with _PACK_LOCK:
+        _PACK_CACHE.clear()
+
+
 class Program:
-    """One launch of `sd3d_row_chain`.  Slots are small integers; `begin()` starts a further program (gridDim.y) over the same rows."""
+    """One launch of `sd3d_row_chain`.  Slots are small integers; `begin()` starts a further program (gridDim.y) over the same rows.
+    The struct is packed with `struct.pack_into` (one call per op: the decoder issues ~300 ops per scene)."""
 
     def __init__(self, n_slots: int, rng=None):
-        self.buf = np.zeros(1, dtype=PROGRAM_DT)
-        self.p = self.buf[0]
+        self.buf = C.create_string_buffer(PROGRAM_DT.itemsize)
         self.n_ops = 0
-        self.n_programs = 1
-        self.p["n_slots"] = n_slots
-        self.p["rng"] = 0 if rng is None else _f32(rng, "rng")
-        self.p["prog_begin"][0] = 0
+        self.n_slots = n_slots
+        self.rng = 0 if rng is None else _f32(rng, "rng")
+        self.prog_begin = [0]
         self._keep = [rng]
 
     def begin(self):
-        if self.n_programs >= MAX_PROGRAMS:
+        if len(self.prog_begin) >= MAX_PROGRAMS:
             raise ValueError("row_chain: at most 4 programs per launch")
-        self.p["prog_begin"][self.n_programs] = self.n_ops
-        self.n_programs += 1
+        self.prog_begin.append(self.n_ops)
 
-    def _op(self, keep=(), **kw):
+    def _op(self, keep=(), type=0, act=0, src0=NONE, src1=NONE, dst=NONE, res=NONE, flag=0, aux=0, k0=0, k1=0, cout=0, ld=0, f0=0.0,
+            p0=0, p1=0, p2=0, p3=0, p4=0):
         self._keep.extend(keep)          # every tensor an op points at lives at least until the launch is enqueued (stream-ordered allocator)
         if self.n_ops >= MAX_OPS:
             raise ValueError(f"row_chain: more than {MAX_OPS} ops in one launch")
-        o = self.p["ops"][self.n_ops]
-        o["src0"] = o["src1"] = o["dst"] = o["res"] = NONE
-        for k, v in kw.items():
-            o[k] = v
+        _OP.pack_into(self.buf, _OFF_OPS + 64 * self.n_ops, type, act, src0, src1, dst, res, flag, aux, k0, k1, cout, 0, ld, f0, p0, p1, p2, p3, p4)
         self.n_ops += 1
 
     # ---- ops ---------------------------------------------------------------------------------------------------------------
@@ -86,15 +133,19 @@ class Program:
     def linear(self, dst, src0, w, b=None, act=None, res=None, src1=None, gout=None):
         """dst = act([src0 | src1] w^T + b (+ res)); dst None: only the global copy `gout` [rows, cout]."""
         cout, K = w.shape
-        if not w.is_contiguous():
-            raise ValueError("row_chain LINEAR: weight must be contiguous")
+        wp = pack_weight(w)
         k1 = K // 2 if src1 is not None else 0
         gp, gld = (0, 0) if gout is None else _rows(gout, "LINEAR out")
         if gout is not None and gout.shape[1] != cout:
             raise ValueError("row_chain LINEAR: global output width != cout")
-        self._op(keep=(w, b, gout), type=LINEAR, act=ops.ACT[act], src0=src0, src1=NONE if src1 is None else src1, dst=NONE if dst is None else dst,
-                 res=NONE if res is None else res, flag=F_NO_LDS_DST if dst is None else 0, k0=K - k1, k1=k1, cout=cout, ld=gld,
-                 p0=_f32(w, "weight"), p1=_f32(b, "bias"), p2=gp)
+        flag = F_NO_LDS_DST if dst is None else 0
+        if dst is not None:                                      # dst overlapping a source: the kernel separates reads from stores by a barrier
+            d0, d1 = dst, dst + _nslots(cout)
+            if (src0 < d1 and d0 < src0 + _nslots(K - k1)) or (src1 is not None and src1 < d1 and d0 < src1 + _nslots(k1)):
+                flag |= F_INPLACE
+        self._op(keep=(wp, b, gout), type=LINEAR, act=ops.ACT[act], src0=src0, src1=NONE if src1 is None else src1, dst=NONE if dst is None else dst,
+                 res=NONE if res is None else res, flag=flag, k0=K - k1, k1=k1, cout=cout, ld=gld,
+                 p0=_f32(wp, "weight"), p1=_f32(b, "bias"), p2=gp)
 
     def ln(self, dst, src, g, b, res=None, act=None, eps=1e-5, gout=None):
         gp, gld = (0, 0) if gout is None else _rows(gout, "LN out")
@@ -140,16 +191,19 @@ class Program:
             if lib.sd3d_row_chain_program_bytes() != PROGRAM_DT.itemsize:
                 raise RuntimeError(f"sd3d_rc_program: library {lib.sd3d_row_chain_program_bytes()} bytes, binding {PROGRAM_DT.itemsize}")
             _checked = True
-        p = self.p
-        p["n_scenes"], p["n_programs"] = len(scenes), self.n_programs
-        p["prog_begin"][self.n_programs] = self.n_ops
-        p["nw_max"], p["nw2_max"] = nw_max, nw2_max
-        tiles = 0
+        n = len(scenes)
+        if n > MAX_BATCH:
+            raise ValueError("row_chain: at most 16 scenes per launch")
+        tile0, tiles = [0] * (MAX_BATCH + 1), 0
         for i, sc in enumerate(scenes):
-            p["tile0"][i] = tiles
+            tile0[i] = tiles
             tiles += (sc["nq"] + 15) // 16
-            s = p["scenes"][i]
-            for k in ("q0", "nq", "m0", "nm", "bits_off", "nw", "near_off", "ksplit", "part_off"):
-                s[k] = sc.get(k, 0)
-        p["tile0"][len(scenes)] = tiles
-        _lib.check(lib.sd3d_row_chain(self.buf.ctypes.data, ops._stream()), "row_chain")
+            g = sc.get
+            _SCENE.pack_into(self.buf, _OFF_SCENES + 40 * i, sc["q0"], sc["nq"], g("m0", 0), g("nm", 0), g("bits_off", 0), g("nw", 0),
+                             g("near_off", 0), g("ksplit", 0), g("part_off", 0))
+        tile0[n] = tiles
+        pb = self.prog_begin + [self.n_ops]
+        n_prog = len(self.prog_begin)
+        pb += [0] * (MAX_PROGRAMS + 1 - len(pb))
+        _HEAD.pack_into(self.buf, 0, n, n_prog, self.n_slots, nw_max, nw2_max, 0, self.rng, *tile0, *pb)
+        _lib.check(lib.sd3d_row_chain(C.addressof(self.buf), ops._stream()), "row_chain")

@@ -250,8 +250,14 @@ def test_fused_decoder_matches_the_op_by_op_decoder(query_num, monkeypatch):
     print(f"fused vs op-by-op decoder, query_num={query_num}: worst relative deviation {worst:.2e}")
 
 
-def test_fused_decoder_batch_is_bit_identical_to_single_scene_calls():
-    model, scenes = _model_and_scenes([(30000, 300, 24), (20000, 180, 10), (25000, 333, 31)], -1)
+@pytest.mark.parametrize("policy,sizes", [(True, [(30000, 300, 24), (20000, 180, 10), (25000, 333, 31)]),
+                                          ("auto", [(30000, 300, 24), (40000, 700, 10), (25000, 333, 31), (40000, 650, 3)])])
+def test_fused_decoder_batch_is_bit_identical_to_single_scene_calls(policy, sizes, monkeypatch):
+    """policy True: every scene on the row-chain path; "auto": the scenes with more than 512 query rows take it, the others go op by op
+    in the same call - a scene's bits never depend on what else is in the batch."""
+    from segdino3d_amd import decoder as D
+    monkeypatch.setattr(D, "FUSED_DECODER", policy)
+    model, scenes = _model_and_scenes(sizes, -1)
     _, batch = _decoder_outputs(model, scenes)
     for b, sc in enumerate(scenes):
         _, single = _decoder_outputs(model, [sc])
