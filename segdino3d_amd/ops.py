@@ -530,6 +530,14 @@ def _cached_split(wt, terms):
     return hit[0]
 
 
+_IN_FLIGHT = [1]
+
+
+def scenes_in_flight_now() -> int:
+    """How many independent scenes the caller keeps in flight on this GPU (set by `scenes_in_flight`, default 1)."""
+    return _IN_FLIGHT[0]
+
+
 class scenes_in_flight:
     """Context: tell the launchers that `n` independent scenes run concurrently on this GPU (sd3d_set_scenes_in_flight)."""
 
@@ -538,10 +546,12 @@ class scenes_in_flight:
 
     def __enter__(self):
         self.prev = _lib.load().sd3d_set_scenes_in_flight(self.n)
+        self.prev_py, _IN_FLIGHT[0] = _IN_FLIGHT[0], self.n
         return self
 
     def __exit__(self, *exc):
         _lib.load().sd3d_set_scenes_in_flight(self.prev)
+        _IN_FLIGHT[0] = self.prev_py
         return False
 
 

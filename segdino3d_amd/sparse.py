@@ -65,7 +65,18 @@ def child_perm(order: str) -> np.ndarray:
 # SD3D_EXACT_PAIRS=0: do not read the rulebook sizes back (saves the second host synchronisation of a scene) and size
 # the pair lists for the worst case instead (K * V entries: 2.2 GB of partial-product scratch per stream at 150 k
 # points).  Measured the same scenes/s either way once the GPU is the limiter, so the exact sizes are the default.
-EXACT_PAIR_CAPACITY = os.environ.get("SD3D_EXACT_PAIRS", "1") == "1"
+# "auto" (default): ONE scene in flight on this GPU (single-scene latency: the synchronisation is 0.24 ms of a 12.4 ms forward) and at most
+# WORST_CASE_MAX_VOXELS voxels skips the read-back; several scenes in flight (the other scenes' kernels fill the wait, and the scratch is
+# per stream) keep the exact sizes.  The rulebooks, and therefore every output bit, are the same either way (tests/test_gpu_sparse.py).
+_ep = os.environ.get("SD3D_EXACT_PAIRS", "auto")
+EXACT_PAIR_CAPACITY = "auto" if _ep == "auto" else (_ep == "1")
+WORST_CASE_MAX_VOXELS = int(os.environ.get("SD3D_WORST_CASE_MAX_VOXELS", "250000"))
+
+
+def exact_pair_capacity(n_vox0: int) -> bool:
+    if EXACT_PAIR_CAPACITY == "auto":
+        return ops.scenes_in_flight_now() > 1 or n_vox0 > WORST_CASE_MAX_VOXELS
+    return bool(EXACT_PAIR_CAPACITY)
 
 
 # kernel offsets are enumerated symmetrically (kernel_offsets_np: off[K-1-k] == -off[k] for odd k), so a stride-1 table
@@ -136,7 +147,7 @@ class SceneMaps:
         second and last synchronisation of a scene): density[key] = pairs / (K * V_out) lets the host
         pick the pair-compacted convolution kernel for sparse maps.  same: [(level, ksize)], strides: [level]."""
         same = [(lvl, k) for (lvl, k) in same if ("same", lvl, k) not in self.density]
-        exact = EXACT_PAIR_CAPACITY or not ops.PAIR_CONV
+        exact = exact_pair_capacity(self.n_vox[0]) or not ops.PAIR_CONV
         counters = torch.zeros(max(1, len(same)), 64, dtype=torch.int32, device=self.device) if exact else None
         for i, (lvl, k) in enumerate(same):
             offs = offsets_device(k, self.order, self.device)

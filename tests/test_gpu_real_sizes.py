@@ -84,3 +84,25 @@ def test_mixed_size_batch_and_pipelined_runner_are_bit_identical_to_single_forwa
                 for k, v in seq[i].items():
                     assert torch.equal(got[k], v), f"runner (batch {batch_size}), slot {slot} (scene {i}): `{k}` differs"
     print(f"query_num={query_num}: batch of {[s[0] for s in SIZES]} points and the pipelined runner: every output bit-identical to single-scene forwards")
+
+
+def test_worst_case_pair_capacity_gives_the_same_bits(monkeypatch):
+    """`sparse.EXACT_PAIR_CAPACITY`: with ONE scene in flight the rulebook sizes are not read back (pair lists sized K x V: no second
+    host synchronisation, 0.24 ms of the single-scene latency); the rulebooks - and every output - are those of the exact-size run."""
+    from segdino3d_amd import sparse
+    from segdino3d_amd.configs import scannet200_model_cfg
+    from segdino3d_amd.synth import make_scene, structure_scene
+    d = P.dev()
+    model, _ = P._build(scannet200_model_cfg(query_num=200), d)
+    pts, tgt = make_scene(21, 150_000, 3000, 300)
+    structure_scene(pts, tgt)
+    pts, tgt = pts.to(d), tgt.to(d)
+    outs = {}
+    for mode in (True, False, "auto"):
+        monkeypatch.setattr(sparse, "EXACT_PAIR_CAPACITY", mode)
+        with torch.no_grad():
+            outs[mode] = _fields(model([pts], [copy.copy(tgt)])[0].pred_pts_seg)
+    assert outs[True]["scores"].numel() >= 50
+    for mode in (False, "auto"):
+        for k, v in outs[True].items():
+            assert torch.equal(outs[mode][k], v), (mode, k)
