@@ -35,7 +35,9 @@ def main():
     assert nf and nw, (nf, nw)                      # scenes of the two passes (the time-based pre-roll may give them different counts)
     conv = lambda n: n.startswith("pair_gemm") or n.startswith("pair_reduce") or n.startswith("pair_center")  # noqa: E731
     fam = lambda n: conv(n) or "gather_gemm" in n  # noqa: E731
-    out = {"source": f"{sys.argv[1]} + {sys.argv[2]} (rocprofv3 --kernel-trace --pmc FETCH_SIZE | WRITE_SIZE, separate passes, bench.py --streams 1)",
+    import os
+    tracked = lambda p: "profiles/" + os.path.basename(p)     # the summaries are committed under profiles/ (gpurun_out/ is scratch)  # noqa: E731
+    out = {"source": f"{tracked(sys.argv[1])} + {tracked(sys.argv[2])} (rocprofv3 --kernel-trace --pmc FETCH_SIZE | WRITE_SIZE, separate passes, bench.py --streams 1)",
            "forwards": nf, "forwards_write_pass": nw, "forwards_note": "scenes of the profiled runs (bytes_per_forward = bytes per scene)",
            "fetch_correction": "x2 (MI355X_MICROARCH.md: gfx950 FETCH_SIZE reports half the bytes of 16 B/lane reads)",
            "write_correction": "none (uncalibrated)"}
@@ -45,13 +47,13 @@ def main():
         out[f"{key}_fetch_kb_sum"], out[f"{key}_write_kb_sum"] = f_kb, w_kb
         out[f"{key}_bytes_per_forward"] = int((2.0 * f_kb / nf + w_kb / nw) * 1024)
     out["bytes_per_forward"] = out["family_bytes_per_forward"]
-    out["conv_launches_per_forward"] = round(sum(v[0] for n, v in fetch.items() if n.startswith("pair_gemm")) / nf, 2)
+    out["pass1_launches_per_scene"] = round(sum(v[0] for n, v in fetch.items() if n.startswith("pair_gemm")) / nf, 2)
     if len(sys.argv) > 4:
         for line in open(sys.argv[4]):
             if line.startswith("{"):
                 cfg = json.loads(line)["config"]
                 out["workload"] = {"points": cfg["points"], "superpoints": cfg["superpoints"], "queries_2d": cfg["queries_2d"],
-                                   "scene_layout": cfg["scene_layout"], "scenes_per_forward": cfg.get("scenes_per_forward", 1)}
+                                   "scene_layout": cfg["scene_layout"], "scenes_per_forward": cfg.get("max_scenes_per_forward", cfg.get("scenes_per_forward", 1))}
     json.dump(out, open(sys.argv[3], "w"), indent=1)
     print(json.dumps(out, indent=1))
 
