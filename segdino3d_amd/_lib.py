@@ -9,7 +9,8 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libsegdino3d_hip.so")
+# SD3D_LIB: another build of the same library (same-box A/B of kernel variants; tools/ab_lib.sh)
+LIB_PATH = os.environ.get("SD3D_LIB") or os.path.join(_HERE, "libsegdino3d_hip.so")
 ABI_VERSION = 1
 
 _lib = None

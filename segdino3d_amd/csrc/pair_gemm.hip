@@ -25,6 +25,24 @@
 static std::atomic<int> g_scenes_in_flight{1};
 extern "C" int sd3d_set_scenes_in_flight(int n) { return g_scenes_in_flight.exchange(n < 1 ? 1 : n); }
 
+// Partial products are written once by pass 1 and read once by pass 2, hundreds of megabytes per convolution.  Measured (same box,
+// tools/ab_lib.sh; conv ms per scene in the instrumented replay / single-scene latency): non-temporal READS in pass 2 7.49 -> 7.34 ms /
+// 12.10 -> 12.00 ms (they stop displacing the activation rows the next pass 1 gathers); non-temporal STORES in pass 1 7.49 -> 7.68 ms /
+// 12.1 -> 12.7 ms (one scene in flight: 7.92 -> 8.43 ms) - the plain stores are combined in L2 and part of them is still on chip when
+// pass 2 asks.  So: plain stores, non-temporal loads.
+// (with SEVERAL scenes in flight the trade flips: non-temporal stores 114.5 -> 116.8 scenes/s - the other scenes' kernels, not this
+// convolution's pass 2, are what the written-back lines would displace - so pass 1 takes the store flavour from `p.nt_part`,
+// set by the launcher from the scenes-in-flight hint.)
+#define PART_STORE4(PTR, V) do { if (p.nt_part) __builtin_nontemporal_store((V), (f32x4*)(PTR)); else *(f32x4*)(PTR) = (V); } while (0)
+#define PART_STORE1(PTR, V) do { if (p.nt_part) __builtin_nontemporal_store((V), (float*)(PTR)); else *(float*)(PTR) = (V); } while (0)
+#ifndef SD3D_NT_PART_LOAD
+#define SD3D_NT_PART_LOAD 1
+#endif
+#if SD3D_NT_PART_LOAD
+#define PART_LOAD4(PTR) __builtin_nontemporal_load((const f32x4*)(PTR))
+#else
+#define PART_LOAD4(PTR) (*(const f32x4*)(PTR))
+#endif
 #define PL_ROWS 2048            // rows per workgroup of the list-building kernels
 #define PT 128                  // pairs per tile / segment padding
 #define PBS_LD 36
@@ -281,6 +299,7 @@ struct PGParams {
     const int32_t* out_idx;
     const float* scale; const float* shift; const float* res; int ld_res;
     float* out; int ld_out; int act;
+    int nt_part;                              // 1: non-temporal partial-product stores (several scenes in flight; see PART_STORE4)
 };
 
 // scale * x + shift as ONE fused multiply-add in every epilogue of this file, so that the paths agree bit for bit
@@ -422,7 +441,7 @@ __device__ __forceinline__ void pair_gemm_body(const PGParams& p, float (*Bs)[NT
                     const int n = ncol0 + t * 32 + j;                                                                 \
                     _Pragma("unroll") for (int r = 0; r < 16; ++r) {                                                  \
                         const int64_t pr = prow0 + (r & 3) + 8 * (r >> 2) + 4 * h;                                    \
-                        if (n < p.Cout) p.part[pr * p.Cout + n] = acc[t][r];                                          \
+                        if (n < p.Cout) PART_STORE1(p.part + pr * p.Cout + n, acc[t][r]);                            \
                     }                                                                                                 \
                 }                                                                                                     \
             }                                                                                                         \
@@ -626,8 +645,8 @@ __device__ __forceinline__ void pair_gemm_ws_body(const PGParams& p, float* Ws) 
                 float* dst = p.part + prow * p.Cout + ncol0 + 4 * h;                                                  \
                 _Pragma("unroll") for (int t = 0; t < NT; ++t)                                                        \
                     _Pragma("unroll") for (int g = 0; g < 4; ++g)                                                     \
-                        *(f32x4*)(dst + t * 32 + 8 * g) = f32x4{acc[rt][t][4 * g], acc[rt][t][4 * g + 1],             \
-                                                                acc[rt][t][4 * g + 2], acc[rt][t][4 * g + 3]};        \
+                        PART_STORE4(dst + t * 32 + 8 * g, (f32x4{acc[rt][t][4 * g], acc[rt][t][4 * g + 1],            \
+                                                                 acc[rt][t][4 * g + 2], acc[rt][t][4 * g + 3]}));     \
                 }                                                                                                     \
                 _Pragma("unroll") for (int t = 0; t < NT; ++t)                                                        \
                     _Pragma("unroll") for (int r = 0; r < 16; ++r) acc[rt][t][r] = 0.f;                               \
@@ -754,7 +773,7 @@ __global__ __launch_bounds__(256) void pair_reduce_rl_kernel(const PRLParams p) 
             f32x4 v[9];
 #pragma unroll
             for (int u = 0; u < 9; ++u)
-                v[u] = i0 + u < cnt ? *(const f32x4*)(p.part + (int64_t)id_at(i0 + u) * p.Cout + q) : f32x4{0.f, 0.f, 0.f, 0.f};
+                v[u] = i0 + u < cnt ? PART_LOAD4(p.part + (int64_t)id_at(i0 + u) * p.Cout + q) : f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int u = 0; u < 9; ++u) if (i0 + u < cnt) a += v[u];
         }
@@ -764,7 +783,7 @@ __global__ __launch_bounds__(256) void pair_reduce_rl_kernel(const PRLParams p) 
         f32x4 v[4];
         const int idv[4] = {ids.x, ids.y, ids.z, ids.w};
 #pragma unroll
-        for (int u = 0; u < 4; ++u) v[u] = i0 + u < cnt ? *(const f32x4*)(p.part + (int64_t)idv[u] * p.Cout + q) : f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int u = 0; u < 4; ++u) v[u] = i0 + u < cnt ? PART_LOAD4(p.part + (int64_t)idv[u] * p.Cout + q) : f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int u = 0; u < 4; ++u) if (i0 + u < cnt) a += v[u];
     }
@@ -1071,6 +1090,10 @@ int launch_pair_conv(const float* in0, int ld0, int C0, const float* in1, int ld
     g.in0 = in0; g.ld0 = ld0; g.C0 = C0; g.in1 = in1; g.ld1 = ld1; g.in_idx = in_idx; g.tile_k = tile_k; g.wt = wt;
     g.Cin = Cin; g.Cout = Cout; g.part = part;
     g.skip_center = fused ? 1 : 0;
+    {
+        static const int nt_env = env_flag("SD3D_PAIR_NT_STORE", -1);          // -1: by the scenes-in-flight hint
+        g.nt_part = nt_env >= 0 ? (nt_env != 0) : (g_scenes_in_flight.load(std::memory_order_relaxed) > 1 ? 1 : 0);
+    }
     g.out_idx = direct ? out_idx : nullptr;
     g.scale = scale; g.shift = shift; g.res = res; g.ld_res = ld_res; g.out = out; g.ld_out = ld_out; g.act = act;
     const bool pass1 = !(fused && K == 1);                     // a K = 1 table is its own centre: the dense kernel is the whole convolution
