@@ -212,6 +212,13 @@ int sd3d_pair_conv(const float* in0, int ld0, int C0, const float* in1, int ld1,
  *   out_idx [p_cap]        output row of every list entry (-1 on padding).  Handing it to the convolution promises ONE pair per
  *                          output row - the transposed k2s2 convolutions (minkunet.py:165-192 `conv_tr`: every fine voxel has one
  *                          parent) - and pass 1 writes act(scale * product + shift + res) to the row directly: no pass 2. */
+/* center == SD3D_PAIR_CHAINED (stride-1 table of a voxel set onto itself, odd kernel with symmetric offsets off[K-1-k] == -off[k],
+ * centre K / 2): CHAINED lists - the entries of an output row that belong to one mirror group {k, K-1-k}, plus the centre in the
+ * row's first non-empty group, share ONE partial product (pass 1 accumulates across up to three consecutive sub-tiles and stores
+ * once; tile_k carries bit 30 on all but the last sub-tile of a chain).  27-44 % fewer partial rows on surface-like scenes.  For
+ * these tables pos is [K / 2 + 1, M] (partial position per mirror group), rlist is required (rl_stride >= K / 2 + 2), p_cap >=
+ * pairs + 127 * (11 * (K / 2) + 1), and the same value goes to sd3d_pair_conv_ex / sd3d_run_layers as `center`. */
+#define SD3D_PAIR_CHAINED (-2)
 typedef struct sd3d_pair_table_desc {
     const int32_t* nbr;                  /* [K, M] */
     int32_t *pos, *in_idx, *tile_k;      /* as sd3d_pair_lists */

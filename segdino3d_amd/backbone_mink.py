@@ -227,7 +227,7 @@ class Res16UNetBase(DerivedWeights):
     def forward_sparse(self, maps: SceneMaps, vox_feats: torch.Tensor) -> torch.Tensor:
         """`Res16UNetBase.forward` (`minkunet.py:531-601`): [V0, Cin_padded] -> [V0, 96]."""
         k1 = self.conv1_kernel_size
-        maps.prepare(same=[(0, k1)] + [(l, 3) for l in range(5)], strides=[0, 1, 2, 3])
+        maps.prepare(same=[(0, k1)] + [(l, 3) for l in range(5)], strides=[0, 1, 2, 3], chained=not self.training)
         if self.training:                                        # batch-statistics BatchNorm, autograd nodes over HIP kernels
             from . import train_ops
             return self._network(train_ops.TrainBackend(maps), self.packed_train(), vox_feats)

@@ -201,7 +201,7 @@ class SpConvUNet(DerivedWeights):
 
     def forward_sparse(self, maps: SceneMaps, vox_feats: torch.Tensor) -> torch.Tensor:
         nl = len(self.num_planes)
-        maps.prepare(same=[(l, 3) for l in range(nl)], strides=list(range(nl - 1)))
+        maps.prepare(same=[(l, 3) for l in range(nl)], strides=list(range(nl - 1)), chained=not self.training)
         if self.training:                                        # batch-statistics BatchNorm, autograd nodes over HIP kernels
             from . import train_ops
             return self._network(train_ops.TrainBackend(maps), self.packed_train(), vox_feats, nl)

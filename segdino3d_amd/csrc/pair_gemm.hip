@@ -283,6 +283,216 @@ __global__ __launch_bounds__(RL_ROWS) void pair_rowlist_batch_kernel(const PLBat
     rl[0] = cnt;
 }
 
+// ---- chained lists: mirror offsets and the centre share ONE partial product ----------------------------------------------------
+// A stride-1 table of a voxel set onto itself with an odd kernel (3^3) enumerates its offsets symmetrically: off[K-1-k] == -off[k],
+// centre = K / 2.  On a surface a row that has a neighbour at +d mostly has one at -d too (measured on the benchmark scene: 48 % /
+// 76 % / 75 % of the non-centre entries of levels 1 / 2 / 3 come in such mirror pairs, tools/mirror_pairs.py), and EVERY row has
+// its centre.  The pair-major convolution pays 2 x 4 x Cout bytes of HBM traffic per list entry for the partial product (written
+// by pass 1, read by pass 2).  Here the entries of one output row that belong to the same mirror group g = {k = g, K-1-g}, plus
+// the centre in the row's first non-empty group, share ONE partial product: pass 1 keeps accumulating across up to three
+// consecutive "sub-tiles" (same 128 rows, sources centre -> +d -> -d, each with its own gather indices and its own W[k]) and
+// stores once (tile_k carries PG_CHAIN on all but the last sub-tile).  Rows are sorted into SEGMENTS by (group, pattern) so that
+// every sub-tile row is a real product: no MFMA row is wasted, the flops are exactly the rulebook's.  Partial rows at 150 k points:
+// level 0 -27 %, level 1 -35 %, levels 2-4 -40...-44 %.  Pass 2 is unchanged (per-row lists of partial positions, ascending).
+//   pattern: 0 {a} 1 {b} 2 {a,b} 3 {c,a} 4 {c,b} 5 {c,a,b}   (a = nbr[g][r], b = nbr[K-1-g][r], c = the centre: idx r)
+//   segment g * 6 + pattern for g < G = K / 2;  segment 6 G = rows without any neighbour (centre alone)
+//   entry i of a segment with n sources: sub-tile (i / 128) * n + s of the segment, slot i % 128
+#define PG_CHAIN 0x40000000
+#define PG_KMASK 0x3FFFFFFF
+#define CH_NPAT 6
+struct CHTable {
+    const int32_t* nbr; int32_t* gpos; int32_t* in_idx; int32_t* tile_k; int32_t* blk_cnt; int32_t* totals; int32_t* first_g; int32_t* rlist;
+    int64_t M, p_cap;
+    int K, G, nblk, rl_stride;
+    int wg0, sg0, rb0, fb0;        // first workgroup of the table in the (G + 1) * nblk grid / the segment grid / the row-list grid / the first-group grid
+};
+struct CHBatch { int n; CHTable t[PL_MAX_TABLES]; };
+__device__ __forceinline__ int ch_find(const CHBatch& b, int wg, int by) {
+    int ti = 0;
+    for (int i = 1; i < b.n; ++i) if (wg >= (by == 0 ? b.t[i].wg0 : (by == 1 ? b.t[i].sg0 : (by == 2 ? b.t[i].rb0 : b.t[i].fb0)))) ti = i;
+    return ti;
+}
+__device__ __forceinline__ int ch_nsrc(int pat) { return pat < 2 ? 1 : (pat < 5 ? 2 : 3); }
+
+// first_g[r] = first mirror group in which row r has a neighbour (G: none)
+__global__ __launch_bounds__(256) void chain_first_kernel(const CHBatch b) {
+    const int ti = ch_find(b, blockIdx.x, 3);
+    const CHTable& T = b.t[ti];
+    const int64_t row = (int64_t)(blockIdx.x - T.fb0) * 256 + threadIdx.x;
+    if (row >= T.M) return;
+    int first = T.G;
+    for (int g = T.G - 1; g >= 0; --g)
+        if (T.nbr[(int64_t)g * T.M + row] >= 0 || T.nbr[(int64_t)(T.K - 1 - g) * T.M + row] >= 0) first = g;
+    T.first_g[row] = first;
+}
+// pattern of (group g, row): -1 none
+__device__ __forceinline__ int ch_pattern(const CHTable& T, int g, int64_t row, int& ia, int& ib) {
+    ia = ib = -1;
+    if (row >= T.M) return -1;
+    if (g == T.G) return T.first_g[row] == T.G ? 0 : -1;       // the centre-only segment (reported as pattern 0 of group G)
+    ia = T.nbr[(int64_t)g * T.M + row];
+    ib = T.nbr[(int64_t)(T.K - 1 - g) * T.M + row];
+    if (ia < 0 && ib < 0) return -1;
+    const int base = ia >= 0 ? (ib >= 0 ? 2 : 0) : 1;
+    return base + (T.first_g[row] == g ? 3 : 0);
+}
+__global__ __launch_bounds__(256) void chain_count_kernel(const CHBatch b) {
+    __shared__ int sm[4][CH_NPAT];
+    const int ti = ch_find(b, blockIdx.x, 0);
+    const CHTable& T = b.t[ti];
+    const int local = blockIdx.x - T.wg0, g = local / T.nblk, blk = local - g * T.nblk, tid = threadIdx.x;
+    int c[CH_NPAT] = {0, 0, 0, 0, 0, 0};
+    for (int i = 0; i < PL_ROWS / 256; ++i) {
+        int ia, ib;
+        const int pat = ch_pattern(T, g, (int64_t)blk * PL_ROWS + i * 256 + tid, ia, ib);
+#pragma unroll
+        for (int q = 0; q < CH_NPAT; ++q) c[q] += __popcll(__ballot(pat == q));
+    }
+    if ((tid & 63) == 0) {
+#pragma unroll
+        for (int q = 0; q < CH_NPAT; ++q) sm[tid >> 6][q] = c[q];
+    }
+    __syncthreads();
+    const int npat = g == T.G ? 1 : CH_NPAT;
+    if (tid < npat) T.blk_cnt[(int64_t)(g * CH_NPAT + tid) * T.nblk + blk] = sm[0][tid] + sm[1][tid] + sm[2][tid] + sm[3][tid];
+}
+__global__ __launch_bounds__(256) void chain_scan_kernel(const CHBatch b) {
+    __shared__ int sm[4];
+    const int ti = ch_find(b, blockIdx.x, 1);
+    const CHTable& T = b.t[ti];
+    const int seg = blockIdx.x - T.sg0, tid = threadIdx.x;
+    int running = 0;
+    for (int base = 0; base < T.nblk; base += 256) {
+        const int i = base + tid;
+        const int v = i < T.nblk ? T.blk_cnt[(int64_t)seg * T.nblk + i] : 0;
+        int total;
+        const int ex = block_excl_scan_256p(v, &total, sm);
+        if (i < T.nblk) T.blk_cnt[(int64_t)seg * T.nblk + i] = running + ex;
+        running += total;
+    }
+    if (tid == 0) T.totals[seg] = running;
+}
+__global__ __launch_bounds__(256) void chain_fill_kernel(const CHBatch b) {
+    __shared__ int sm[4];
+    __shared__ int wcnt[4][CH_NPAT];
+    const int ti = ch_find(b, blockIdx.x, 0);
+    const CHTable& T = b.t[ti];
+    const int local = blockIdx.x - T.wg0, g = local / T.nblk, blk = local - g * T.nblk;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int seg0 = g * CH_NPAT, npat = g == T.G ? 1 : CH_NPAT;
+    const int centre = T.K / 2;
+    // first tile of this group's first segment = sum over the segments before it of ceil(total / 128) * sources
+    int s = 0;
+    for (int q = tid; q < seg0; q += 256) s += (T.totals[q] + PT - 1) / PT * ch_nsrc(q % CH_NPAT);
+    int tile_base;
+    block_excl_scan_256p(s, &tile_base, sm);
+    int seg_tile[CH_NPAT], seg_tot[CH_NPAT];
+    {
+        int t = tile_base;
+#pragma unroll
+        for (int q = 0; q < CH_NPAT; ++q) {
+            seg_tot[q] = q < npat ? T.totals[seg0 + q] : 0;
+            seg_tile[q] = t;
+            t += (seg_tot[q] + PT - 1) / PT * ch_nsrc(q);
+        }
+        if (blk == 0) {
+            // tile headers and the -1 padding of this group's segments
+            for (int q = 0; q < npat; ++q) {
+                const int ns = ch_nsrc(q), nt = (seg_tot[q] + PT - 1) / PT;
+                for (int e = tid; e < nt * ns; e += 256) {
+                    const int sub = e % ns;
+                    int k;                                      // source order: centre, +d (k = g), -d (k = K - 1 - g)
+                    if (g == T.G) k = centre;
+                    else if (q == 0) k = g;
+                    else if (q == 1) k = T.K - 1 - g;
+                    else if (q == 2) k = sub == 0 ? g : T.K - 1 - g;
+                    else if (q == 3) k = sub == 0 ? centre : g;
+                    else if (q == 4) k = sub == 0 ? centre : T.K - 1 - g;
+                    else k = sub == 0 ? centre : (sub == 1 ? g : T.K - 1 - g);
+                    if ((int64_t)(seg_tile[q] + e) * PT < T.p_cap) T.tile_k[seg_tile[q] + e] = k | (sub < ns - 1 ? PG_CHAIN : 0);
+                }
+                if (nt > 0) {
+                    const int fill0 = seg_tot[q] - (nt - 1) * PT;       // real entries of the last tile row-block
+                    for (int e = tid; e < (PT - fill0) * ns; e += 256) {
+                        const int sub = e / (PT - fill0), off = fill0 + e % (PT - fill0);
+                        const int64_t pp = (int64_t)(seg_tile[q] + (nt - 1) * ns + sub) * PT + off;
+                        if (pp < T.p_cap) T.in_idx[pp] = -1;
+                    }
+                }
+            }
+        }
+        if (g == T.G) {
+            // past the last segment: unused capacity reads as "no pair"; the number of real tiles after the last slot
+            const int64_t end_tile = t;
+            const int64_t cap_tiles = T.p_cap / PT;
+            if (blk == 0 && tid == 0) { T.tile_k[cap_tiles] = (int)(end_tile < cap_tiles ? end_tile : cap_tiles); T.tile_k[cap_tiles + 1] = 0; T.tile_k[cap_tiles + 2] = 0; }
+            for (int64_t e = end_tile * PT + (int64_t)blk * 256 + tid; e < T.p_cap; e += (int64_t)T.nblk * 256) T.in_idx[e] = -1;
+            for (int64_t tt = end_tile + (int64_t)blk * 256 + tid; tt < cap_tiles; tt += (int64_t)T.nblk * 256) T.tile_k[tt] = -1;
+        }
+    }
+    int run[CH_NPAT];
+#pragma unroll
+    for (int q = 0; q < CH_NPAT; ++q) run[q] = q < npat ? T.blk_cnt[(int64_t)(seg0 + q) * T.nblk + blk] : 0;
+    const uint64_t lt = (1ull << lane) - 1ull;
+#pragma unroll 1
+    for (int i = 0; i < PL_ROWS / 256; ++i) {
+        const int64_t row = (int64_t)blk * PL_ROWS + i * 256 + tid;
+        int ia, ib;
+        const int pat = ch_pattern(T, g, row, ia, ib);
+        uint64_t bal[CH_NPAT];
+#pragma unroll
+        for (int q = 0; q < CH_NPAT; ++q) bal[q] = __ballot(pat == q);
+        if (lane == 0) {
+#pragma unroll
+            for (int q = 0; q < CH_NPAT; ++q) wcnt[wv][q] = __popcll(bal[q]);
+        }
+        __syncthreads();
+        int my = -1;
+#pragma unroll
+        for (int q = 0; q < CH_NPAT; ++q) {
+            int before = 0;
+            for (int w = 0; w < wv; ++w) before += wcnt[w][q];
+            if (pat == q) my = run[q] + before + __popcll(bal[q] & lt);
+            run[q] += wcnt[0][q] + wcnt[1][q] + wcnt[2][q] + wcnt[3][q];
+        }
+        __syncthreads();
+        int32_t gp = -1;
+        if (pat >= 0) {
+            const int ns = g == T.G ? 1 : ch_nsrc(pat);
+            const int64_t tile = seg_tile[pat] + (int64_t)(my >> 7) * ns;
+            const int off = my & (PT - 1);
+            int src[3];
+            int n = 0;
+            if (g == T.G || pat >= 3) src[n++] = (int)row;      // the centre: in = out = r
+            if (g < T.G && ia >= 0) src[n++] = ia;
+            if (g < T.G && ib >= 0) src[n++] = ib;
+            if ((tile + ns) * PT <= T.p_cap) {
+                for (int q = 0; q < ns; ++q) T.in_idx[(tile + q) * PT + off] = src[q];
+                gp = (int32_t)((tile + ns - 1) * PT + off);
+            }
+        }
+        if (row < T.M) T.gpos[(int64_t)g * T.M + row] = gp;
+    }
+}
+__global__ __launch_bounds__(RL_ROWS) void chain_rowlist_kernel(const CHBatch b) {
+    const int ti = ch_find(b, blockIdx.x, 2);
+    const CHTable& T = b.t[ti];
+    const int64_t row = (int64_t)(blockIdx.x - T.rb0) * RL_ROWS + threadIdx.x;
+    if (row >= T.M) return;
+    int32_t* rl = T.rlist + row * T.rl_stride;
+    int cnt = 0;
+    for (int g = 0; g <= T.G; ++g) {
+        const int v = T.gpos[(int64_t)g * T.M + row];
+        if (v >= 0) rl[1 + cnt++] = v;
+    }
+    rl[0] = cnt;
+}
+size_t chain_lists_ws_bytes(int K, int64_t M) {
+    const int64_t nblk = cdiv(M, PL_ROWS);
+    const int64_t nseg = (int64_t)(K / 2) * CH_NPAT + 1;
+    return (size_t)(nseg * nblk + nseg + M) * sizeof(int32_t) + 256;
+}
+
 // ---- pass 1: dense tiles over the pair list --------------------------------------------------
 struct PGParams {
     const float* in0; int ld0; int C0;
@@ -300,6 +510,7 @@ struct PGParams {
     const float* scale; const float* shift; const float* res; int ld_res;
     float* out; int ld_out; int act;
     int nt_part;                              // 1: non-temporal partial-product stores (several scenes in flight; see PART_STORE4)
+    int chained;                              // 1: tile_k carries PG_CHAIN flags (chained lists: a tile's products add onto the next tile's)
 };
 
 // scale * x + shift as ONE fused multiply-add in every epilogue of this file, so that the paths agree bit for bit
@@ -331,8 +542,13 @@ __device__ __forceinline__ void pair_gemm_body(const PGParams& p, float (*Bs)[NT
     const int skipn = p.skip_center ? p.tile_k[p.n_tiles + 2] : 0;
     const int n_real = p.tile_k[p.n_tiles] - skipn;
 #define PHYS(e) ((e) < skip0 ? (e) : (e) + skipn)
-    const int tile0 = (int)((int64_t)blockIdx.x * n_real / gridDim.x);
-    const int ntl = (int)((int64_t)(blockIdx.x + 1) * n_real / gridDim.x) - tile0;
+    int tile0 = (int)((int64_t)blockIdx.x * n_real / gridDim.x);
+    int tile1 = (int)((int64_t)(blockIdx.x + 1) * n_real / gridDim.x);
+    if (p.chained) {                                           // a chain of sub-tiles (<= 3) is never split between workgroups
+        while (tile0 > 0 && tile0 < n_real && (p.tile_k[tile0 - 1] & PG_CHAIN)) ++tile0;
+        while (tile1 > 0 && tile1 < n_real && (p.tile_k[tile1 - 1] & PG_CHAIN)) ++tile1;
+    }
+    const int ntl = tile1 - tile0;
     if (ntl <= 0) return;                                      // uniform over the workgroup
     const int ncol0 = blockIdx.y * NT * 32;
     const int nchunks = p.Cin >> 5;
@@ -351,8 +567,8 @@ __device__ __forceinline__ void pair_gemm_body(const PGParams& p, float (*Bs)[NT
         for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
 
     f32x4 bst[NT];
-    auto stage_load = [&](int k, int chunk) {
-        const float* __restrict__ W = p.wt + (int64_t)k * wstride;
+    auto stage_load = [&](int kf, int chunk) {
+        const float* __restrict__ W = p.wt + (int64_t)(kf & PG_KMASK) * wstride;
 #pragma unroll
         for (int i = 0; i < NT; ++i) {
             const int f = tid + i * 256;
@@ -420,7 +636,7 @@ __device__ __forceinline__ void pair_gemm_body(const PGParams& p, float (*Bs)[NT
                 __builtin_amdgcn_sched_barrier(0);                                                                    \
             }                                                                                                         \
         }                                                                                                             \
-        if (last_chunk) { /* tile complete: write its partial products (or, one pair per output row, the rows themselves) */ \
+        if (last_chunk && !(k_cur & PG_CHAIN)) { /* tile (chain) complete: write its partial products (or, one pair per output row, the rows themselves) */ \
             const int64_t prow0 = (int64_t)PHYS(tile0 + cur_lt) * PT + wv * 32;                                       \
             if (DIRECT) {                                                                                             \
                 _Pragma("unroll") for (int r = 0; r < 16; ++r) {                                                      \
@@ -972,7 +1188,9 @@ PAIR_CENTER_ENTRY(pair_center_g_kernel_4, 4, 2, 2, true)
 // ---- launchers --------------------------------------------------------------------------------
 size_t pair_lists_ws_bytes(int K, int64_t M) {
     const int64_t nblk = cdiv(M, PL_ROWS);
-    return (size_t)((int64_t)K * nblk + K) * sizeof(int32_t) + 256;
+    const size_t plain = (size_t)((int64_t)K * nblk + K) * sizeof(int32_t) + 256;
+    const size_t chained = (K & 1) ? chain_lists_ws_bytes(K, M) : 0;      // (a table may be built either way: size for both)
+    return plain > chained ? plain : chained;
 }
 
 // p_cap: capacity of in_idx in pairs (multiple of 128, >= pairs + K * 127); tile_k has p_cap / 128 + 1 entries
@@ -1002,11 +1220,31 @@ int launch_pair_lists_desc(int n, const sd3d_pair_table_desc* d, void* ws, size_
     if (n > PL_MAX_TABLES) return sd3d_set_error(SD3D_ERR_ARG, "pair_lists_batch: at most 16 tables per call");
     PLBatch b;
     b.n = 0;
+    CHBatch cb;
+    cb.n = 0;
     size_t off = 0;
     int wg = 0, kk = 0, rb = 0;
+    int cwg = 0, csg = 0, crb = 0, cfb = 0;
     for (int i = 0; i < n; ++i) {
         const int K = d[i].K;
         const int64_t M = d[i].M, p_cap = d[i].p_cap;
+        if (d[i].center == SD3D_PAIR_CHAINED && K > 0 && M > 0) {
+            // chained lists (mirror groups + centre share a partial product): their own builder
+            if (!(K & 1) || K < 3) return sd3d_set_error(SD3D_ERR_ARG, "pair_lists_batch: chained lists need an odd kernel (symmetric offsets)");
+            if (p_cap <= 0 || (p_cap % PT) || !d[i].rlist || !d[i].pos || d[i].rl_stride < K / 2 + 2 || (d[i].rl_stride & 3))
+                return sd3d_set_error(SD3D_ERR_ARG, "pair_lists_batch: chained lists need pos [K / 2 + 1, M], rlist and rl_stride >= K / 2 + 2");
+            CHTable& T = cb.t[cb.n++];
+            T.nbr = d[i].nbr; T.gpos = d[i].pos; T.in_idx = d[i].in_idx; T.tile_k = d[i].tile_k; T.rlist = d[i].rlist; T.M = M; T.p_cap = p_cap;
+            T.K = K; T.G = K / 2; T.nblk = (int)cdiv(M, PL_ROWS); T.rl_stride = d[i].rl_stride;
+            const int nseg = T.G * CH_NPAT + 1;
+            T.blk_cnt = (int32_t*)((char*)ws + off);
+            T.totals = T.blk_cnt + (int64_t)nseg * T.nblk;
+            T.first_g = T.totals + nseg;
+            off += align_up(chain_lists_ws_bytes(K, M), 256);
+            T.wg0 = cwg; T.sg0 = csg; T.rb0 = crb; T.fb0 = cfb;
+            cwg += (T.G + 1) * T.nblk; csg += nseg; crb += (int)cdiv(M, RL_ROWS); cfb += (int)cdiv(M, 256);
+            continue;
+        }
         if (K <= 0 || M <= 0) {                                // no rows: a later pair_conv on this table must see "0 real tiles"
             if (d[i].tile_k && p_cap > 0 && hipMemsetAsync(d[i].tile_k + p_cap / PT, 0, (d[i].meta ? 3 : 1) * sizeof(int32_t), st) != hipSuccess)
                 return sd3d_set_error(SD3D_ERR_LAUNCH, "pair_lists_batch: memset failed");
@@ -1027,6 +1265,14 @@ int launch_pair_lists_desc(int n, const sd3d_pair_table_desc* d, void* ws, size_
         rb += T.rlist ? (int)cdiv(M, RL_ROWS) : 0;
     }
     if (off > ws_bytes) return sd3d_set_error(SD3D_ERR_ARG, "pair_lists_batch: workspace too small");
+    if (cb.n > 0) {
+        hipLaunchKernelGGL(chain_first_kernel, dim3(cfb), dim3(256), 0, st, cb);
+        hipLaunchKernelGGL(chain_count_kernel, dim3(cwg), dim3(256), 0, st, cb);
+        hipLaunchKernelGGL(chain_scan_kernel, dim3(csg), dim3(256), 0, st, cb);
+        hipLaunchKernelGGL(chain_fill_kernel, dim3(cwg), dim3(256), 0, st, cb);
+        hipLaunchKernelGGL(chain_rowlist_kernel, dim3(crb), dim3(RL_ROWS), 0, st, cb);
+        SD3D_CHECK_LAUNCH();
+    }
     if (b.n == 0) return SD3D_OK;
     hipLaunchKernelGGL(pair_count_batch_kernel, dim3(wg), dim3(256), 0, st, b);
     hipLaunchKernelGGL(pair_scan_batch_kernel, dim3(kk), dim3(256), 0, st, b);
@@ -1090,6 +1336,7 @@ int launch_pair_conv(const float* in0, int ld0, int C0, const float* in1, int ld
     g.in0 = in0; g.ld0 = ld0; g.C0 = C0; g.in1 = in1; g.ld1 = ld1; g.in_idx = in_idx; g.tile_k = tile_k; g.wt = wt;
     g.Cin = Cin; g.Cout = Cout; g.part = part;
     g.skip_center = fused ? 1 : 0;
+    g.chained = center == SD3D_PAIR_CHAINED ? 1 : 0;
     {
         static const int nt_env = env_flag("SD3D_PAIR_NT_STORE", -1);          // -1: by the scenes-in-flight hint
         g.nt_part = nt_env >= 0 ? (nt_env != 0) : (g_scenes_in_flight.load(std::memory_order_relaxed) > 1 ? 1 : 0);
@@ -1117,13 +1364,13 @@ int launch_pair_conv(const float* in0, int ld0, int C0, const float* in1, int ld
     static int crowd_env = -2;
     if (crowd_env == -2) { const char* e = getenv("SD3D_PAIR_CROWD"); crowd_env = e ? atoi(e) : -1; }
     const bool crowded = crowd_env >= 0 ? crowd_env != 0 : g_scenes_in_flight.load(std::memory_order_relaxed) > 1;
-    const bool ws_one = ws_env && ((ws_mask >> (nt - 1)) & 1) && !(crowded && nt >= 3) && cgs == 1 && Cout == 32 * nt && w_lds <= 68 * 1024;
+    const bool ws_one = ws_env && !g.chained && ((ws_mask >> (nt - 1)) & 1) && !(crowded && nt >= 3) && cgs == 1 && Cout == 32 * nt && w_lds <= 68 * 1024;
     // wide layers (256 columns = two groups of 128): the group's half of W[k] (133 KB at Cin = 256) still fits LDS with ONE
     // workgroup per CU - no per-step barrier, no re-staging of weight chunks, like the narrow layers
     static int ws2_env = -1;
     if (ws2_env < 0) { const char* e = getenv("SD3D_PAIR_WS2"); ws2_env = e ? atoi(e) : 1; }
     // (measured: level-3 256->256, 1808 tiles: 358 -> 347 us; level-4, 472 tiles: 104 -> 113 us - too few tiles for half the workgroups)
-    const bool ws_two = ws_env && ws2_env && !crowded && cgs == 2 && nt == 4 && Cout == 256 && g.n_tiles >= 1024 && w_lds_cg + WS_RANGE_TILES * PT * sizeof(int32_t) + 256 <= 160 * 1024;
+    const bool ws_two = ws_env && !g.chained && ws2_env && !crowded && cgs == 2 && nt == 4 && Cout == 256 && g.n_tiles >= 1024 && w_lds_cg + WS_RANGE_TILES * PT * sizeof(int32_t) + 256 <= 160 * 1024;
     if (!pass1) {
     } else if (ws_one || ws_two) {
         static bool attr_done = false;

@@ -585,9 +585,13 @@ PAIR_CONV = _os.environ.get("SD3D_PAIR_CONV", "1") != "0"
 _PAIR_DESC_DT = None
 
 
+PAIR_CHAINED = -2          # SD3D_PAIR_CHAINED: `center` value of a chained table (include/segdino3d_hip.h)
+
+
 def pair_lists_batch(tables):
     """tables: list of (nbr int32 [K, M], n_pairs[, center[, direct]]) -> list of PairLists, built by ONE launch set
-    (csrc/pair_gemm.hip: count, scan, fill, per-row lists)."""
+    (csrc/pair_gemm.hip: count, scan, fill, per-row lists).  center = PAIR_CHAINED: chained lists (a stride-1 table of a voxel set
+    onto itself, odd symmetric kernel): the entries of a row's mirror groups and its centre share partial products."""
     global _PAIR_DESC_DT
     import numpy as np
     if _PAIR_DESC_DT is None:
@@ -607,8 +611,15 @@ def pair_lists_batch(tables):
             center = int(t[2]) if len(t) > 2 else -1
             direct = bool(t[3]) if len(t) > 3 else False
             K, M = nbr.shape
-            p_cap = (int(n_pairs) + 127 * K + 127) // 128 * 128
-            pos = torch.empty(K, M, dtype=torch.int32, device=dev)
+            chained = center == PAIR_CHAINED
+            if chained:
+                if direct or K % 2 == 0:
+                    raise ValueError("pair_lists: chained lists need an odd symmetric kernel")
+                p_cap = (int(n_pairs) + 127 * (11 * (K // 2) + 1) + 127) // 128 * 128
+                pos = torch.empty(K // 2 + 1, M, dtype=torch.int32, device=dev)          # partial position per mirror group
+            else:
+                p_cap = (int(n_pairs) + 127 * K + 127) // 128 * 128
+                pos = torch.empty(K, M, dtype=torch.int32, device=dev)
             in_idx = torch.empty(p_cap, dtype=torch.int32, device=dev)
             tile_k = torch.empty(p_cap // 128 + 3, dtype=torch.int32, device=dev)     # [p_cap / 128]: number of real tiles, then the centre run
             rl_stride = (K + 4 + 3) // 4 * 4

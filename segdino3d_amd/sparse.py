@@ -88,6 +88,18 @@ MIRRORED_MAPS = os.environ.get("SD3D_MIRRORED_MAPS", "1") != "0"
 # SLOWER than pass 1 over all offsets + the row-list pass 2 everywhere except the level-0 3^3 layers (137 vs 140 us; level 1
 # 96 -> 96: 293 vs 246 us, level 3 256 -> 256: 379 vs 340, level 4: 164 vs 105; profiles/r03_pair_paths.md), so it is opt-in.
 CENTER_KERNEL = os.environ.get("SD3D_PAIR_CENTER", "0") == "1"
+# SD3D_PAIR_CHAIN=0: plain offset-major lists for the 3^3 tables too.  Default: CHAINED lists in evaluation (csrc/pair_gemm.hip: the
+# entries of an output row's mirror offsets {k, K-1-k} and its centre share ONE partial product - 27-44 % fewer partial rows written
+# by pass 1 and read by pass 2).  Training keeps the plain lists (the weight-gradient kernels walk them offset by offset).
+PAIR_CHAIN = os.environ.get("SD3D_PAIR_CHAIN", "1") != "0"
+# Which U-Net levels get chained lists is a property of the LEVEL, never of the scene or the batch (a scene's rows must see the same
+# list format whether it runs alone or in a batch: the two formats sum in different orders).  Levels 0-2 (the tables with thousands
+# of tiles): measured same box, 4 streams x 4 scenes 118.1 -> 120.5-123 scenes/s, convolutions 7.29 -> 7.06 ms per scene in the
+# instrumented replay (0.471 -> 0.486 of the fp32 matrix peak), one scene in flight neutral (7.78 vs 7.76 ms: what the fewer partial
+# rows win, the weight-stationary pass-1 variants - which cannot chain - lose).  Levels 3-4 have few hundred to ~1800 tiles: chains
+# of three tiles on 3-4 tiles per workgroup unbalance the static ranges and the level-3 layers lose their weight-stationary variant:
+# all five levels 124.6 scenes/s with several scenes in flight but 8.27 vs 7.74 ms of convolutions with one.
+PAIR_CHAIN_LEVELS = tuple(int(v) for v in os.environ.get("SD3D_PAIR_CHAIN_LEVELS", "0,1,2").split(",") if v.strip() != "")
 
 
 class SceneMaps:
@@ -142,7 +154,7 @@ class SceneMaps:
         self.density: Dict[Tuple, float] = {}
         self.pairs: Dict[Tuple, "ops.PairLists"] = {}       # offset-major rulebooks (prepare())
 
-    def prepare(self, same=(), strides=()):
+    def prepare(self, same=(), strides=(), chained=False):
         """Build the listed neighbour tables now and read their rulebook sizes back in ONE copy (the
         second and last synchronisation of a scene): density[key] = pairs / (K * V_out) lets the host
         pick the pair-compacted convolution kernel for sparse maps.  same: [(level, ksize)], strides: [level]."""
@@ -165,7 +177,11 @@ class SceneMaps:
         for (lvl, k), c in zip(same, host):
             self.density[("same", lvl, k)] = (c / max(1, k ** 3 * self.n_vox[lvl])) if exact else None
             if ops.PAIR_CONV:                                   # stride-1 table of the level onto itself: offset k^3 // 2 pairs every row with itself
-                todo.append((("same", lvl, k), self._same[(lvl, k)], c, (k ** 3) // 2 if (k % 2 and CENTER_KERNEL) else -1, False))
+                if chained and PAIR_CHAIN and k == 3 and lvl in PAIR_CHAIN_LEVELS and not CENTER_KERNEL:
+                    center = ops.PAIR_CHAINED                    # mirror groups + centre share partial products (evaluation)
+                else:
+                    center = (k ** 3) // 2 if (k % 2 and CENTER_KERNEL) else -1
+                todo.append((("same", lvl, k), self._same[(lvl, k)], c, center, False))
         for lvl in strides:
             # every fine voxel has exactly one parent: P = V_fine pairs in both directions
             self.density[("down", lvl)] = self.n_vox[lvl] / max(1, 8 * self.n_vox[lvl + 1])
@@ -347,9 +363,9 @@ class BatchedMaps:
         self.n_vox = [self.offsets[l][-1] for l in range(n_levels)]
         self._tables: Dict[Tuple, dict] = {}
 
-    def prepare(self, same=(), strides=()):
+    def prepare(self, same=(), strides=(), chained=False):     # (training batches: `chained` is False by construction)
         for m in self.maps:
-            m.prepare(same=same, strides=strides)
+            m.prepare(same=same, strides=strides, chained=chained)
 
     def rows(self, level: int, i: int):
         return self.offsets[level][i], self.offsets[level][i + 1]

@@ -197,3 +197,69 @@ def test_plan_and_eager_agree_with_the_new_paths():
         finally:
             plan.USE_PLAN = old
     assert torch.equal(a, b)
+
+
+# ---- chained lists (round 4): mirror offsets {k, K-1-k} and the centre share one partial product --------------------------------
+@pytest.mark.parametrize("level,cin,cout,split", [(0, 96, 96, 0), (0, 128, 96, 96), (1, 32, 32, 0), (1, 96, 96, 0), (2, 64, 64, 0),
+                                                  (2, 128, 128, 0), (2, 192, 128, 128), (3, 256, 256, 0), (3, 384, 256, 256), (4, 256, 256, 0)])
+def test_chained_lists_give_the_plain_convolution(scene_maps, level, cin, cout, split):
+    """`ops.pair_lists(..., center=PAIR_CHAINED)` on the real 3^3 tables of a scene: the convolution equals the float64 model at
+    2e-6 of the row magnitude (like every other path) and the plain pair-major path at fp32 summation-order noise; it is
+    bit-reproducible; the lists hold exactly the rulebook's entries and fewer partial rows."""
+    from segdino3d_amd import ops
+    c = _case(scene_maps, ("same", level, 3), cin, cout, split=split, seed=level * 10 + cout)
+    nbr = c["nbr"]
+    K, M = nbr.shape
+    P = int((nbr >= 0).sum())
+    chained = ops.pair_lists(nbr, P, center=ops.PAIR_CHAINED)
+    assert chained.center == ops.PAIR_CHAINED and chained.rlist is not None
+    n_tiles = int(chained.tile_k[chained.p_cap // 128].item())
+    tk = chained.tile_k[:n_tiles]
+    assert int((chained.in_idx[: n_tiles * 128] >= 0).sum()) == P, "a chained list holds every rulebook entry exactly once"
+    n_partial_rows = int(chained.rlist[:, 0].sum())
+    plain_rows = int(c["pl"].rlist[:, 0].sum()) if c["pl"].rlist is not None else P
+    assert plain_rows == P and n_partial_rows < P
+    assert bool(((tk & 0x3FFFFFFF) < K).all()) and not bool((tk[-1:] & 0x40000000).any())
+    # every row's partial positions point at the LAST sub-tile of a chain
+    pos = chained.rlist[:, 1:][torch.arange(chained.rlist.shape[1] - 1, device=nbr.device)[None] < chained.rlist[:, :1]]
+    assert bool((tk[(pos // 128).long()] & 0x40000000).eq(0).all())
+    x, x2 = (c["x1"], c["x2"]) if split else (c["x"], None)
+    kw = dict(x2=x2, scale=c["scale"], shift=c["shift"], res=c["res"], act=c["act"])
+    got = ops.pair_conv(x, c["w"], chained, **kw)
+    again = ops.pair_conv(x, c["w"], chained, **kw)
+    plain = ops.pair_conv(x, c["w"], c["pl"], **kw)
+    ref = _ref64(c["x"], c["w"], nbr, c["scale"], c["shift"], c["res"], c["act"])
+    mag = ref.abs().amax(dim=1, keepdim=True).clamp_min(1e-3)
+    err = ((got.double() - ref).abs() / mag).max().item()
+    err_plain = ((plain.double() - ref).abs() / mag).max().item()
+    print(f"level {level} {cin}->{cout}: P = {P}, partial rows {plain_rows} -> {n_partial_rows} ({1 - n_partial_rows / plain_rows:.1%} fewer); "
+          f"max error / row magnitude: chained {err:.2e}, plain {err_plain:.2e}")
+    assert torch.equal(got, again)
+    assert err < 2e-6, err
+
+
+def test_chained_lists_edge_cases():
+    """Isolated voxels (centre only), a table smaller than one tile, and rows whose only neighbours are one-sided."""
+    from segdino3d_amd import ops
+    from segdino3d_amd.sparse import SceneMaps
+    d = dev()
+    g = torch.Generator().manual_seed(5)
+    # a few far-apart points, one tight cluster, and a straight line (every interior voxel has exactly the +-x mirror pair)
+    iso = torch.rand(40, 3, generator=g) * 50.0
+    cluster = 0.5 + 0.05 * torch.rand(300, 3, generator=g)
+    line = torch.stack([torch.arange(200) * 0.02 + 10.0, torch.full((200,), 3.0), torch.full((200,), 3.0)], 1)
+    pts = torch.cat([iso, cluster, line]).float()
+    pts = torch.cat([pts, torch.zeros(pts.shape[0], 3)], 1).to(d)
+    maps = SceneMaps(pts, 0.02, 2)
+    maps.prepare(same=[(0, 3), (1, 3)], strides=[0])
+    for lvl in (0, 1):
+        nbr = maps.same(lvl, 3)
+        K, M = nbr.shape
+        P = int((nbr >= 0).sum())
+        ch = ops.pair_lists(nbr, P, center=ops.PAIR_CHAINED)
+        x = torch.randn(M, 32, generator=g).to(d)
+        w = (torch.randn(K, 64, 32, generator=g) * 0.1).to(d)
+        got = ops.pair_conv(x, w, ch)
+        ref = _ref64(x, w, nbr, None, None, None, None)
+        assert ((got.double() - ref).abs() / ref.abs().amax(dim=1, keepdim=True).clamp_min(1e-3)).max().item() < 2e-6
+        assert int(ch.rlist[:, 0].min()) >= 1                       # every row has at least its centre
