@@ -1278,15 +1278,61 @@ def pack_mask_rows(masks_u8, rows=None):
     return out
 
 
+class _HostPool:
+    """Recycles the big host arrays of the unpacked instance masks: a fresh 90 MB numpy array per scene is 22 k page faults (20 - 40 ms
+    on the evaluation hosts, more than the forward itself); an array handed out here returns its memory to the pool when the LAST
+    reference to it (or to a view of it) dies.  A caller that keeps every scene's masks (the reference's evaluator until
+    `evaluate()`) simply never gives anything back - then this is `np.empty`."""
+
+    class _Lease:
+        __slots__ = ("buf", "pool", "__array_interface__")
+
+        def __init__(self, buf, pool, shape):
+            self.buf, self.pool = buf, pool
+            self.__array_interface__ = {"shape": shape, "typestr": "|b1", "data": (buf.ctypes.data, False), "version": 3}
+
+        def __del__(self):
+            try:
+                self.pool._give_back(self.buf)
+            except Exception:  # noqa: BLE001 - interpreter shutdown
+                pass
+
+    def __init__(self, max_free_bytes=2 << 30):
+        self.free, self.lock, self.max_free = [], threading.Lock(), max_free_bytes
+
+    def _give_back(self, buf):
+        with self.lock:
+            if sum(b.nbytes for b in self.free) + buf.nbytes <= self.max_free:
+                self.free.append(buf)
+
+    def bool_array(self, shape):
+        import numpy as np
+        need = int(np.prod(shape))
+        if need < (1 << 20):                                     # small arrays: the allocator's own free lists do this already
+            return np.empty(shape, dtype=np.bool_)
+        buf = None
+        with self.lock:
+            fit = [i for i, b in enumerate(self.free) if need <= b.nbytes <= need + need // 4 + (4 << 20)]
+            if fit:
+                buf = self.free.pop(min(fit, key=lambda i: self.free[i].nbytes))
+        if buf is None:
+            buf = np.empty((need + (4 << 20) - 1) // (4 << 20) * (4 << 20), dtype=np.uint8)
+        return np.asarray(self._Lease(buf, self, tuple(int(v) for v in shape)))
+
+
+_HOST_POOL = _HostPool()
+
+
 def unpack_bits_host(packed, n_points: int):
-    """HOST arrays: packed uint8 [n, ceil(N / 8)] (numpy) -> bool [n, N] (a fresh pageable array).  Runs in the C library with the
-    GIL released (sd3d_unpack_bits_host): the other scene threads keep issuing while this one expands its masks."""
+    """HOST arrays: packed uint8 [n, ceil(N / 8)] (numpy) -> bool [n, N] (pageable; large ones come from a recycling pool, `_HostPool`).
+    Runs in the C library with the GIL released (sd3d_unpack_bits_host): the other scene threads keep issuing while this one expands
+    its masks."""
     import numpy as np
     packed = np.ascontiguousarray(packed, dtype=np.uint8)
     n, nb = packed.shape
     if nb != (n_points + 7) // 8:
         raise ValueError(f"unpack_bits_host: {nb} bytes per row cannot hold {n_points} points")
-    out = np.empty((n, n_points), dtype=np.bool_)
+    out = _HOST_POOL.bool_array((n, n_points))
     _lib.check(_lib.load_nogil().sd3d_unpack_bits_host(packed.ctypes.data, n, n_points, nb, out.ctypes.data), "unpack_bits_host")
     return out
 
