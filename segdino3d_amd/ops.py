@@ -622,7 +622,8 @@ def pair_lists_batch(tables):
                 pos = torch.empty(K, M, dtype=torch.int32, device=dev)
             in_idx = torch.empty(p_cap, dtype=torch.int32, device=dev)
             tile_k = torch.empty(p_cap // 128 + 3, dtype=torch.int32, device=dev)     # [p_cap / 128]: number of real tiles, then the centre run
-            rl_stride = (K + 4 + 3) // 4 * 4
+            # per-row list {count, partial positions}: K entries at most - K / 2 + 1 (mirror groups + the lone centre) for a chained table
+            rl_stride = ((K // 2 + 2) + 3) // 4 * 4 if chained else (K + 4 + 3) // 4 * 4
             rlist = None if direct else torch.empty(M, rl_stride, dtype=torch.int32, device=dev)
             out_idx = torch.empty(p_cap, dtype=torch.int32, device=dev) if direct else None
             desc[i] = (_ptr(nbr, torch.int32, "nbr"), pos.data_ptr(), in_idx.data_ptr(), tile_k.data_ptr(),

@@ -45,4 +45,9 @@ for key, cin, cout in cases:
         t_old = timeit(lambda: ops.pair_conv(x, w, old), 5)
         what = "direct" if pairs.direct else ("centre kernel" if pairs.center >= 0 else "row lists")
         line += f" ({what}) | all offsets + row-list pass 2: {t_rl:.0f} us | all offsets + pos pass 2 (round 2): {t_old:.0f} us"
+    if os.environ.get("PAIR_CHAINED") == "1" and key[0] == "same" and key[2] == 3:      # the same convolution on CHAINED lists (round 4)
+        ch = ops.pair_lists(nbr, P, center=ops.PAIR_CHAINED)
+        t_ch = timeit(lambda: ops.pair_conv(x, w, ch), 5)
+        rows = int(ch.rlist[:, 0].sum())
+        line += f" | chained lists: {t_ch:.0f} us ({rows} partial rows = {rows / P:.0%} of the entries)"
     print(key, cin, cout, line)
