@@ -275,6 +275,11 @@ typedef struct sd3d_buf {
 } sd3d_buf;
 int sd3d_run_layers(const sd3d_layer* layers, int n_layers, const sd3d_table* tables, int n_tables, const sd3d_buf* bufs,
                     int n_bufs, float* part, size_t part_bytes, void* ws, size_t ws_bytes, void* stream);
+/* The same with table_events[n_tables] (or NULL): entry t, when not NULL, is a hipEvent_t recorded on another stream after table t's
+ * lists were built there; `stream` waits for it before the first layer that reads the table (fork / join inside a scene). */
+int sd3d_run_layers_ev(const sd3d_layer* layers, int n_layers, const sd3d_table* tables, int n_tables, const sd3d_buf* bufs,
+                       int n_bufs, float* part, size_t part_bytes, void* ws, size_t ws_bytes, const void* const* table_events,
+                       void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Decoder kernels (segdino3d/models/decoder/instance_seg_3d_decoder.py:606-799,
@@ -325,7 +330,7 @@ typedef struct sd3d_rc_scene {
     int64_t part_off;                                          /* offset (floats) of the scene's partial attention states */
 } sd3d_rc_scene;                                               /* 40 bytes */
 typedef struct sd3d_rc_program {
-    int32_t n_scenes, n_programs, n_slots, nw_max, nw2_max, pad_;
+    int32_t n_scenes, n_programs, n_slots, nw_max, nw2_max, tile_rows;
     const float* rng;                                          /* [n_scenes][6] scene ranges (lo, hi) for PE / BOX */
     int32_t tile0[SD3D_MAX_BATCH + 1];                         /* prefix sums of ceil(nq / 16) */
     int32_t prog_begin[SD3D_RC_MAX_PROGRAMS + 1];              /* op ranges of the programs (gridDim.y) */

@@ -61,6 +61,7 @@ SIGNATURES = {
     "sd3d_pair_lists_desc": (_i, [_i, _p, _p, _z, _p]),
     "sd3d_pair_conv_ex": (_i, [_p, _i, _i, _p, _i, _p, _p, _l, _p, _p, _i, _i, _p, _p, _i, _i, _i, _l, _p, _p, _p, _i, _p, _i, _i, _p, _z, _p]),
     "sd3d_run_layers": (_i, [_p, _i, _p, _i, _p, _i, _p, _z, _p, _z, _p]),
+    "sd3d_run_layers_ev": (_i, [_p, _i, _p, _i, _p, _i, _p, _z, _p, _z, _p, _p]),
     "sd3d_layernorm": (_i, [_p, _i, _p, _i, _p, _p, _f, _l, _i, _p, _i, _i, _p]),
     "sd3d_linear_layernorm": (_i, [_p, _i, _l, _i, _p, _i, _p, _p, _i, _p, _p, _f, _i, _p, _i, _p]),
     "sd3d_sine_pe": (_i, [_p, _i, _l, _p, _p, _p, _i, _p, _i, _p, _i, _p, _i, _p]),
@@ -173,7 +174,7 @@ def load_nogil():
     if _lib_nogil is None:
         load()
         lib = C.CDLL(LIB_PATH)
-        for name in ("sd3d_run_layers", "sd3d_unpack_bits_host"):
+        for name in ("sd3d_run_layers", "sd3d_run_layers_ev", "sd3d_unpack_bits_host"):
             fn = getattr(lib, name)
             fn.restype, fn.argtypes = SIGNATURES[name]
         _lib_nogil = lib

@@ -227,12 +227,14 @@ class Res16UNetBase(DerivedWeights):
     def forward_sparse(self, maps: SceneMaps, vox_feats: torch.Tensor) -> torch.Tensor:
         """`Res16UNetBase.forward` (`minkunet.py:531-601`): [V0, Cin_padded] -> [V0, 96]."""
         k1 = self.conv1_kernel_size
-        maps.prepare(same=[(0, k1)] + [(l, 3) for l in range(5)], strides=[0, 1, 2, 3], chained=not self.training)
+        use_plan = (not self.training and plan.USE_PLAN and ops.PAIR_CONV and ops.GEMM_MODE is None and ops.GG_FORCE_NT is None
+                    and ops.GG_HOOK is None)
+        maps.prepare(same=[(0, k1)] + [(l, 3) for l in range(5)], strides=[0, 1, 2, 3], chained=not self.training, fork=use_plan)
         if self.training:                                        # batch-statistics BatchNorm, autograd nodes over HIP kernels
             from . import train_ops
             return self._network(train_ops.TrainBackend(maps), self.packed_train(), vox_feats)
         pk = self.packed()
-        if plan.USE_PLAN and ops.PAIR_CONV and ops.GEMM_MODE is None and ops.GG_FORCE_NT is None and ops.GG_HOOK is None:
+        if use_plan:
             if self._plan is None:                               # one C call per scene instead of ~110
                 rec = plan.Recorder(vox_feats.shape[1])
                 self._plan = rec.finish(self._network(rec, pk, rec.input))

@@ -201,12 +201,14 @@ class SpConvUNet(DerivedWeights):
 
     def forward_sparse(self, maps: SceneMaps, vox_feats: torch.Tensor) -> torch.Tensor:
         nl = len(self.num_planes)
-        maps.prepare(same=[(l, 3) for l in range(nl)], strides=list(range(nl - 1)), chained=not self.training)
+        use_plan = (not self.training and plan.USE_PLAN and ops.PAIR_CONV and ops.GEMM_MODE is None and ops.GG_FORCE_NT is None
+                    and ops.GG_HOOK is None)
+        maps.prepare(same=[(l, 3) for l in range(nl)], strides=list(range(nl - 1)), chained=not self.training, fork=use_plan)
         if self.training:                                        # batch-statistics BatchNorm, autograd nodes over HIP kernels
             from . import train_ops
             return self._network(train_ops.TrainBackend(maps), self.packed_train(), vox_feats, nl)
         pk = self.packed()
-        if plan.USE_PLAN and ops.PAIR_CONV and ops.GEMM_MODE is None and ops.GG_FORCE_NT is None and ops.GG_HOOK is None:
+        if use_plan:
             if self._plan is None:                               # one C call per scene instead of ~130
                 rec = plan.Recorder(vox_feats.shape[1])
                 self._plan = rec.finish(self._network(rec, pk, rec.input, nl))

@@ -14,9 +14,15 @@ int launch_pair_conv(const float*, int, int, const float*, int, const int32_t*, 
 int launch_scale_shift_act(const float*, int, int, const float*, int, const float*, const float*, int, int64_t, int, const float*, int,
                            float*, int, hipStream_t);
 
-extern "C" int sd3d_run_layers(const sd3d_layer* layers, int n_layers, const sd3d_table* tables, int n_tables, const sd3d_buf* bufs,
-                               int n_bufs, float* part, size_t part_bytes, void* ws, size_t ws_bytes, void* stream) {
+// table_events[t] (optional): a hipEvent_t recorded on ANOTHER stream after table t's lists were built there (fork / join inside a
+// scene: the neighbour tables of the deeper levels are built on a side stream while the stem convolves); `stream` waits for it
+// before the first layer that reads table t.  NULL entries / a NULL array: the tables are already ordered before this call.
+extern "C" int sd3d_run_layers_ev(const sd3d_layer* layers, int n_layers, const sd3d_table* tables, int n_tables, const sd3d_buf* bufs,
+                                  int n_bufs, float* part, size_t part_bytes, void* ws, size_t ws_bytes, const void* const* table_events,
+                                  void* stream) {
     hipStream_t st = (hipStream_t)stream;
+    uint64_t waited[4] = {0, 0, 0, 0};
+    if (table_events && n_tables > 256) return sd3d_set_error(SD3D_ERR_ARG, "run_layers: at most 256 tables with events");
     for (int i = 0; i < n_layers; ++i) {
         const sd3d_layer& L = layers[i];
         if (L.src0 < 0 || L.src0 >= n_bufs || L.dst < 0 || L.dst >= n_bufs || L.src1 >= n_bufs || L.res >= n_bufs)
@@ -31,6 +37,12 @@ extern "C" int sd3d_run_layers(const sd3d_layer* layers, int n_layers, const sd3
             const sd3d_table& T = tables[L.table];
             if (T.K != L.K) return sd3d_set_error(SD3D_ERR_ARG, "run_layers: table / weight offset count mismatch");
             if (o.rows != T.M) return sd3d_set_error(SD3D_ERR_ARG, "run_layers: output buffer rows != table rows");
+            if (table_events && table_events[L.table] && !(waited[L.table >> 6] >> (L.table & 63) & 1)) {
+                if (hipStreamWaitEvent(st, (hipEvent_t)table_events[L.table], 0) != hipSuccess)
+                    return sd3d_set_error(SD3D_ERR_LAUNCH, "run_layers: hipStreamWaitEvent failed");
+                for (int t = 0; t < n_tables; ++t)               // one wait per EVENT: the tables of a group share theirs
+                    if (table_events[t] == table_events[L.table]) waited[t >> 6] |= 1ull << (t & 63);
+            }
             rc = launch_pair_conv(a.ptr, a.ld, L.C0, b ? b->ptr : nullptr, b ? b->ld : 0, T.in_idx, T.tile_k, T.p_cap, T.pos, T.rlist,
                                   T.rl_stride, T.center, T.out_idx, L.wt, L.K,
                                   L.Cin, L.Cout, T.M, L.scale, L.shift, r ? r->ptr : nullptr, r ? r->ld : 0, o.ptr, o.ld, L.act, part,
@@ -50,4 +62,9 @@ extern "C" int sd3d_run_layers(const sd3d_layer* layers, int n_layers, const sd3
         if (rc != SD3D_OK) return rc;
     }
     return SD3D_OK;
+}
+
+extern "C" int sd3d_run_layers(const sd3d_layer* layers, int n_layers, const sd3d_table* tables, int n_tables, const sd3d_buf* bufs,
+                               int n_bufs, float* part, size_t part_bytes, void* ws, size_t ws_bytes, void* stream) {
+    return sd3d_run_layers_ev(layers, n_layers, tables, n_tables, bufs, n_bufs, part, part_bytes, ws, ws_bytes, nullptr, stream);
 }

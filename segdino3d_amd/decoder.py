@@ -201,6 +201,8 @@ _fd = os.environ.get("SD3D_FUSED_DECODER", "auto")
 FUSED_DECODER = "auto" if _fd == "auto" else (_fd != "0")
 FUSED_MIN_ROWS = int(os.environ.get("SD3D_FUSED_MIN_ROWS", "512"))
 FUSED_SA_MAX_KEYS = int(os.environ.get("SD3D_FUSED_SA_MAX_KEYS", "1024"))
+# SD3D_FUSED_NARROW=1: scenes with at most FUSED_MIN_ROWS query rows take the row-chain path too, on 4-row tiles (csrc/rowchain_narrow.hip)
+FUSED_NARROW = os.environ.get("SD3D_FUSED_NARROW", "0") == "1"
 
 
 def _F():
@@ -815,15 +817,18 @@ class ScanNetQueryDecoder(DerivedWeights):
 
     # ---- evaluation, positional variant: the row-local work of a layer as row-chain launches (csrc/rowchain.hip) ----------------
     def _fusable(self, rows=1 << 30):
-        """Does a scene with `rows` query rows take the fused (row-chain) path?  The path covers the SegDINO3D prototypes in evaluation:
-        sine positional embedding, 256 channels in 8 heads."""
+        """Tile rows (16 or 4) of the fused (row-chain) path a scene with `rows` query rows takes, 0 = op by op.  The path covers the
+        SegDINO3D prototypes in evaluation: sine positional embedding, 256 channels in 8 heads."""
         want = rows > FUSED_MIN_ROWS if FUSED_DECODER == "auto" else bool(FUSED_DECODER)
-        return (want and not self.training and self.add_positional_embedding and self.pos_type == "sine" and self.d_model == 256
+        tile = 16
+        if FUSED_NARROW and rows <= FUSED_MIN_ROWS and FUSED_DECODER is not False:
+            want, tile = True, 4
+        return tile if (want and not self.training and self.add_positional_embedding and self.pos_type == "sine" and self.d_model == 256
                 and self.num_heads == 8 and self.num_queries == 0 and ops.GEMM_MODE is None and ops.GG_FORCE_NT is None
                 and self.in_channels % 16 == 0 and self.ffn_layers[0].net[0].out_features <= 1024
-                and self.ffn_layers[0].net[0].out_features % 16 == 0)
+                and self.ffn_layers[0].net[0].out_features % 16 == 0) else 0
 
-    def _forward_fused(self, xs, sp_pos, sp_pos_wo, q_in, q_pos, q2d_feat, q2d_pos, ranges):
+    def _forward_fused(self, xs, sp_pos, sp_pos_wo, q_in, q_pos, q2d_feat, q2d_pos, ranges, tile=16):
         """`_forward_scene` for B >= 1 scenes with every query-row-local stretch of a layer as ONE launch (rowchain.Program):
              A  positional query: anchor MLP -> box-modulated sine PE -> ref_point_head, the two cross-attention query projections
                 (+ the class head of the previous layer as a second program of the same launch)
@@ -834,7 +839,8 @@ class ScanNetQueryDecoder(DerivedWeights):
              -  mask logits (GEMM against the superpoints' mask features) and their attention-mask bits
         6 launches per layer instead of ~27.  Per row the arithmetic is independent of the other rows of a launch: B scenes in one
         call give every scene the bits of its own call."""
-        from .rowchain import Program
+        from .rowchain import Program as _Program
+        Program = lambda n, r=None: _Program(n, r, rows=tile)  # noqa: E731
         dev = xs[0].device
         d, H, L = self.d_model, self.num_heads, self.num_layers
         B = len(xs)
@@ -1117,14 +1123,16 @@ class ScanNetQueryDecoder(DerivedWeights):
             pick = lambda lst, ids: None if lst is None else [lst[j] for j in ids]  # noqa: E731
             # Which path a scene takes depends on ITS OWN query rows only (`_fusable`), never on what else is in the call: a scene of a
             # batch gets the bits of its single-scene forward.  The scenes of a kind run together.
-            fused_ids = [j for j in range(n) if queries[j].shape[0] > 0 and self._fusable(queries[j].shape[0])]
-            plain_ids = [j for j in range(n) if j not in fused_ids]
-            for c0 in range(0, len(fused_ids), 16):
-                ids = fused_ids[c0:c0 + 16]
-                out = self._forward_fused(pick(x, ids), pick(sp_pos, ids), pick(wo, ids), pick(queries, ids), pick(queries_pos, ids),
-                                          pick(dinox_queries, ids), pick(dinox_query_pos, ids), pick(scene_range, ids))
-                for j, (f, a) in zip(ids, out):
-                    finals[j], auxes[j] = f, a
+            kind = [self._fusable(queries[j].shape[0]) if queries[j].shape[0] > 0 else 0 for j in range(n)]
+            plain_ids = [j for j in range(n) if kind[j] == 0]
+            for tile in (16, 4):
+                fused_ids = [j for j in range(n) if kind[j] == tile]
+                for c0 in range(0, len(fused_ids), 16):
+                    ids = fused_ids[c0:c0 + 16]
+                    out = self._forward_fused(pick(x, ids), pick(sp_pos, ids), pick(wo, ids), pick(queries, ids), pick(queries_pos, ids),
+                                              pick(dinox_queries, ids), pick(dinox_query_pos, ids), pick(scene_range, ids), tile=tile)
+                    for j, (f, a) in zip(ids, out):
+                        finals[j], auxes[j] = f, a
             if plain_ids and self._batchable(pick(x, plain_ids), pick(queries, plain_ids), pick(dinox_queries, plain_ids)):
                 out = self._forward_batch(pick(x, plain_ids), pick(sp_pos, plain_ids), pick(wo, plain_ids), pick(queries, plain_ids),
                                           pick(queries_pos, plain_ids), pick(dinox_queries, plain_ids), pick(dinox_query_pos, plain_ids),

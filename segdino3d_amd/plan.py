@@ -156,20 +156,53 @@ class LayerPlan:
         if x.shape[0] != rows[0] or x.shape[1] < self.buf_ch[0] or x.stride(1) != 1 or x.dtype != torch.float32:
             raise ValueError("plan input does not match the recorded network input")
         tabs = np.zeros(len(self.table_keys), dtype=TABLE_DT)
-        part_floats = 0
-        for i, key in enumerate(self.table_keys):
-            pl = maps.pairs.get(key)
-            if pl is None:
-                raise RuntimeError(f"neighbour table {key} has no pair lists (SceneMaps.prepare not called for it)")
-            tabs[i] = (pl.in_idx.data_ptr(), pl.tile_k.data_ptr(), pl.pos.data_ptr(), pl.p_cap, pl.M, pl.K, 0,
-                       0 if pl.rlist is None else pl.rlist.data_ptr(), pl.out_idx.data_ptr() if pl.direct else 0, pl.rl_stride, pl.center)
-            part_floats = max(part_floats, pl.p_cap * int(self.table_cout[i]))
-        part = ops._WS3.get(part_floats * 4, x.device)
+        evs = np.zeros(len(self.table_keys), dtype=np.uint64)
         ws = ops._WS2.get(256, x.device)
-        rc = lib.sd3d_run_layers(self.layers.ctypes.data, len(self.layers), tabs.ctypes.data, len(tabs), bufs.ctypes.data,
-                                 len(bufs), part.data_ptr(), part.numel(), ws.data_ptr(), ws.numel(), ops._stream())
-        if rc:
-            _lib.check(rc, "run_layers")
+
+        def fill_tables():
+            """-> (floats of partial-product scratch the tables present need, do all tables exist?)"""
+            part_floats, complete = 0, True
+            pending = getattr(maps, "events", None) or {}
+            for i, key in enumerate(self.table_keys):
+                pl = maps.pairs.get(key)
+                if pl is None:
+                    complete = False
+                    continue
+                tabs[i] = (pl.in_idx.data_ptr(), pl.tile_k.data_ptr(), pl.pos.data_ptr(), pl.p_cap, pl.M, pl.K, 0,
+                           0 if pl.rlist is None else pl.rlist.data_ptr(), pl.out_idx.data_ptr() if pl.direct else 0, pl.rl_stride, pl.center)
+                ev = pending.get(key)
+                evs[i] = 0 if ev is None else ev.cuda_event
+                part_floats = max(part_floats, pl.p_cap * int(self.table_cout[i]))
+            return part_floats, complete
+
+        def run(a, b, part_floats):
+            part = ops._WS3.get(part_floats * 4, x.device)
+            rc = lib.sd3d_run_layers_ev(self.layers.ctypes.data + a * LAYER_DT.itemsize, b - a, tabs.ctypes.data, len(tabs), bufs.ctypes.data,
+                                        len(bufs), part.data_ptr(), part.numel(), ws.data_ptr(), ws.numel(),
+                                        evs.ctypes.data if evs.any() else None, ops._stream())
+            if rc:
+                _lib.check(rc, "run_layers")
+
+        # Tables built on the scene's side stream (SceneMaps.prepare(fork=True)): this stream waits for a table's event before the first
+        # layer that reads it.  Only the stem's table exists when this is called: the layers up to the first one that needs another table
+        # go first - the stem convolves while the host is still issuing table kernels - then the next group of tables, and so on.
+        n, done = len(self.layers), 0
+        while True:
+            part_floats, complete = fill_tables()
+            if complete:
+                run(done, n, part_floats)
+                break
+            have = np.array([maps.pairs.get(k) is not None for k in self.table_keys])
+            needs = (self.layers["kind"] == KIND_PAIR_CONV) & ~have[np.clip(self.layers["table"], 0, len(have) - 1)]
+            cut = int(np.argmax(needs))                          # first layer whose table does not exist yet
+            if cut > done:
+                run(done, cut, part_floats)
+                done = cut
+            if not getattr(maps, "next_fork", lambda: False)():
+                missing = [k for k in self.table_keys if maps.pairs.get(k) is None]
+                raise RuntimeError(f"neighbour tables {missing} have no pair lists (SceneMaps.prepare not called for them)")
+        if getattr(maps, "events", None):
+            maps.join()                                          # (tables no layer read: nothing of the side stream outlives this call unordered)
         o = int(offs[self.out_id])
         n = int(rows[self.out_id])
         return arena[o:o + n * self.out_ch].view(n, self.out_ch)

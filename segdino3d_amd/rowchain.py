@@ -1,7 +1,7 @@
 """Host side of the row-chain executor (csrc/rowchain.hip, `sd3d_row_chain`): builds the `sd3d_rc_program` a launch interprets.
 
-A program is a list of ops over LDS slots ([16 rows][260] fp32 each) that one workgroup runs for 16 consecutive query rows of one
-scene - the row-local part of a decoder layer (`instance_seg_3d_decoder.py:606-799`) as ONE launch.  The struct layout below mirrors
+A program is a list of ops over LDS slots ([rows][260] fp32 each, rows = 16 or 4) that one workgroup runs for that many consecutive
+query rows of one scene - the row-local part of a decoder layer (`instance_seg_3d_decoder.py:606-799`) as ONE launch.  The struct layout below mirrors
 `include/segdino3d_hip.h` (checked against `sd3d_row_chain_program_bytes()` when the library is loaded).
 """
 from __future__ import annotations
@@ -25,7 +25,7 @@ OP_DT = np.dtype([("type", "u1"), ("act", "u1"), ("src0", "u1"), ("src1", "u1"),
                   ("p0", "<u8"), ("p1", "<u8"), ("p2", "<u8"), ("p3", "<u8"), ("p4", "<u8")], align=True)
 SCENE_DT = np.dtype([("q0", "<i4"), ("nq", "<i4"), ("m0", "<i4"), ("nm", "<i4"), ("bits_off", "<i4"), ("nw", "<i4"), ("near_off", "<i4"),
                      ("ksplit", "<i4"), ("part_off", "<i8")], align=True)
-PROGRAM_DT = np.dtype([("n_scenes", "<i4"), ("n_programs", "<i4"), ("n_slots", "<i4"), ("nw_max", "<i4"), ("nw2_max", "<i4"), ("pad_", "<i4"),
+PROGRAM_DT = np.dtype([("n_scenes", "<i4"), ("n_programs", "<i4"), ("n_slots", "<i4"), ("nw_max", "<i4"), ("nw2_max", "<i4"), ("tile_rows", "<i4"),
                        ("rng", "<u8"), ("tile0", "<i4", (MAX_BATCH + 1,)), ("prog_begin", "<i4", (MAX_PROGRAMS + 1,)),
                        ("scenes", SCENE_DT, (MAX_BATCH,)), ("ops", OP_DT, (MAX_OPS,))], align=True)
 assert OP_DT.itemsize == 64 and SCENE_DT.itemsize == 40
@@ -66,12 +66,13 @@ _PACK_CACHE = {}
 _PACK_LOCK = threading.Lock()
 
 
-def pack_weight(w):
+def pack_weight(w, rows=16):
     """nn.Linear weight [cout, K] -> the MFMA-fragment order the LINEAR op streams (include/segdino3d_hip.h):
-    P[tile][group][lane = 16 * kq + c16][e] = w[min(16 * tile + c16, cout - 1)][16 * group + 4 * kq + e].  Cached per source tensor
-    (address, shape, version counter; the entry keeps its source alive); owners that rewrite weights behind the version counter
-    call `clear_pack_cache()` (ScanNetQueryDecoder._derived_reset does)."""
-    key = (w.data_ptr(), tuple(w.shape), w._version)
+    16-row tiles: P[tile][group][lane = 16 * kq + c16][e] = w[min(16 * tile + c16, cout - 1)][16 * group + 4 * kq + e];
+    4-row tiles:  P[tile][quad][lane][e] = w[min(64 * tile + lane, cout - 1)][4 * quad + e].
+    Cached per source tensor (address, shape, version counter; the entry keeps its source alive); owners that rewrite weights behind
+    the version counter call `clear_pack_cache()` (ScanNetQueryDecoder._derived_reset does)."""
+    key = (w.data_ptr(), tuple(w.shape), w._version, rows)
     with _PACK_LOCK:
         hit = _PACK_CACHE.get(key)
     if hit is not None:
@@ -79,11 +80,15 @@ def pack_weight(w):
     cout, K = w.shape
     if K % 16:
         raise ValueError("row_chain LINEAR: K must be a multiple of 16")
-    tiles = (cout + 15) // 16
+    tc = 16 if rows == 16 else 64
+    tiles = (cout + tc - 1) // tc
     src = w.detach()
-    if tiles * 16 != cout:
-        src = torch.cat([src, src[-1:].expand(tiles * 16 - cout, K)])
-    packed = src.reshape(tiles, 16, K // 16, 4, 4).permute(0, 2, 3, 1, 4).contiguous()       # [tile, group, kq, c16, e]
+    if tiles * tc != cout:
+        src = torch.cat([src, src[-1:].expand(tiles * tc - cout, K)])
+    if rows == 16:
+        packed = src.reshape(tiles, 16, K // 16, 4, 4).permute(0, 2, 3, 1, 4).contiguous()   # [tile, group, kq, c16, e]
+    else:
+        packed = src.reshape(tiles, 64, K // 4, 4).permute(0, 2, 1, 3).contiguous()          # [tile, quad, lane, e]
     with _PACK_LOCK:
         if len(_PACK_CACHE) > 4096:
             _PACK_CACHE.clear()
@@ -100,7 +105,11 @@ class Program:
     """One launch of `sd3d_row_chain`.  Slots are small integers; `begin()` starts a further program (gridDim.y) over the same rows.
     The struct is packed with `struct.pack_into` (one call per op: the decoder issues ~300 ops per scene)."""
 
-    def __init__(self, n_slots: int, rng=None):
+    def __init__(self, n_slots: int, rng=None, rows: int = 16):
+        """rows: query rows per workgroup - 16 (csrc/rowchain.hip, 16 waves) or 4 (csrc/rowchain_narrow.hip, 8 waves; a few hundred rows)."""
+        if rows not in (4, 16):
+            raise ValueError("row_chain: 16 or 4 rows per tile")
+        self.rows = rows
         self.buf = C.create_string_buffer(PROGRAM_DT.itemsize)
         self.n_ops = 0
         self.n_slots = n_slots
@@ -133,7 +142,7 @@ class Program:
     def linear(self, dst, src0, w, b=None, act=None, res=None, src1=None, gout=None):
         """dst = act([src0 | src1] w^T + b (+ res)); dst None: only the global copy `gout` [rows, cout]."""
         cout, K = w.shape
-        wp = pack_weight(w)
+        wp = pack_weight(w, self.rows)
         k1 = K // 2 if src1 is not None else 0
         gp, gld = (0, 0) if gout is None else _rows(gout, "LINEAR out")
         if gout is not None and gout.shape[1] != cout:
@@ -197,7 +206,7 @@ class Program:
         tile0, tiles = [0] * (MAX_BATCH + 1), 0
         for i, sc in enumerate(scenes):
             tile0[i] = tiles
-            tiles += (sc["nq"] + 15) // 16
+            tiles += (sc["nq"] + self.rows - 1) // self.rows
             g = sc.get
             _SCENE.pack_into(self.buf, _OFF_SCENES + 40 * i, sc["q0"], sc["nq"], g("m0", 0), g("nm", 0), g("bits_off", 0), g("nw", 0),
                              g("near_off", 0), g("ksplit", 0), g("part_off", 0))
@@ -205,5 +214,5 @@ class Program:
         pb = self.prog_begin + [self.n_ops]
         n_prog = len(self.prog_begin)
         pb += [0] * (MAX_PROGRAMS + 1 - len(pb))
-        _HEAD.pack_into(self.buf, 0, n, n_prog, self.n_slots, nw_max, nw2_max, 0, self.rng, *tile0, *pb)
+        _HEAD.pack_into(self.buf, 0, n, n_prog, self.n_slots, nw_max, nw2_max, self.rows, self.rng, *tile0, *pb)
         _lib.check(lib.sd3d_row_chain(C.addressof(self.buf), ops._stream()), "row_chain")

@@ -99,6 +99,11 @@ PAIR_CHAIN = os.environ.get("SD3D_PAIR_CHAIN", "1") != "0"
 # rows win, the weight-stationary pass-1 variants - which cannot chain - lose).  Levels 3-4 have few hundred to ~1800 tiles: chains
 # of three tiles on 3-4 tiles per workgroup unbalance the static ranges and the level-3 layers lose their weight-stationary variant:
 # all five levels 124.6 scenes/s with several scenes in flight but 8.27 vs 7.74 ms of convolutions with one.
+# SD3D_FORK_JOIN=0: every neighbour table of a scene is built on the scene's own stream before the first convolution.  Default:
+# with ONE scene in flight (worst-case list sizes, no second read-back) only the stem's table is; the other levels' hash tables,
+# kernel maps and pair lists are built on a side stream while the stem and the first blocks convolve, each table's first layer
+# waits for its event (sd3d_run_layers_ev).  Same kernels on the same data: bit-identical outputs.
+FORK_JOIN = os.environ.get("SD3D_FORK_JOIN", "1") != "0"
 PAIR_CHAIN_LEVELS = tuple(int(v) for v in os.environ.get("SD3D_PAIR_CHAIN_LEVELS", "0,1,2").split(",") if v.strip() != "")
 
 
@@ -153,13 +158,76 @@ class SceneMaps:
         self._sp_start = None
         self.density: Dict[Tuple, float] = {}
         self.pairs: Dict[Tuple, "ops.PairLists"] = {}       # offset-major rulebooks (prepare())
+        self.events: Dict[Tuple, torch.cuda.Event] = {}     # tables built on the side stream (prepare(fork=True)) -> their event
+        self._join_ev = self._late = self._stem_done = None
+        self._fork_ev = ops.stream_event()                   # everything the tables are built from is complete here
 
-    def prepare(self, same=(), strides=(), chained=False):
+    def prepare(self, same=(), strides=(), chained=False, fork=False):
         """Build the listed neighbour tables now and read their rulebook sizes back in ONE copy (the
         second and last synchronisation of a scene): density[key] = pairs / (K * V_out) lets the host
-        pick the pair-compacted convolution kernel for sparse maps.  same: [(level, ksize)], strides: [level]."""
-        same = [(lvl, k) for (lvl, k) in same if ("same", lvl, k) not in self.density]
+        pick the pair-compacted convolution kernel for sparse maps.  same: [(level, ksize)], strides: [level].
+        fork=True (the caller runs the tables through `LayerPlan.run`, which waits per table): with worst-case list sizes (no
+        read-back) only the FIRST table of `same` - the stem's - is built on this stream; the others go to the thread's side stream
+        in the order the U-Net needs them, `self.events[key]` is recorded behind each group."""
+        same = list(dict.fromkeys((lvl, k) for (lvl, k) in same if ("same", lvl, k) not in self.density))
         exact = exact_pair_capacity(self.n_vox[0]) or not ops.PAIR_CONV
+        if fork and FORK_JOIN and not exact and len(same) > 1 and not self.pairs:
+            return self._prepare_forked(same, list(strides), chained)
+        self._build_tables(same, strides, chained, exact)
+
+    def _prepare_forked(self, same, strides, chained):
+        """Fork / join inside a scene.  Everything the side stream reads was finished before the scene's host
+        synchronisation (keys, parents) or is ordered by an event (the level-0 hash table, built here for the stem)."""
+        self._build_tables(same[:1], [], chained, False)                 # stem: this stream, first in line
+        stem_done = ops.stream_event()                                   # (its hash table serves the other level-0 table as well)
+        lvl0 = same[0][0]
+        rest = same[1:]
+        # need order: the levels below the stem's downwards (one group per level: the first must be ready when the stem's convolution
+        # ends), then the deepest levels together with the stem level's other tables (the last block of the U-Net)
+        groups = []
+        for d in (1, 2):
+            groups.append(([t for t in rest if t[0] == lvl0 + d], [l for l in strides if l == lvl0 + d - 1]))
+        taken_s = [t for g in groups for t in g[0]]
+        taken_l = [l for g in groups for l in g[1]]
+        groups.append(([t for t in rest if t not in taken_s], [l for l in strides if l not in taken_l]))
+        self._stem_done = stem_done
+        # LayerPlan.run issues the groups between its segments (next_fork): the stem's convolution is enqueued before the first group
+        self._late = [(g, chained) for g in groups if g[0] or g[1]]
+
+    def _fork_side(self, group, chained):
+        g_same, g_strides = group
+        if not g_same and not g_strides:
+            return
+        side = ops.side_streams(1, self.device)[0]
+        with ops.use_stream(side):
+            side.wait_event(self._fork_ev)
+            if any(t[0] in self._hash for t in g_same):
+                side.wait_event(self._stem_done)                          # a level whose hash table exists: the stem's stream built it
+            keys = self._build_tables(g_same, g_strides, chained, False)
+            ev = ops.stream_event()
+            for key in keys:
+                self.events[key] = ev
+            self._join_ev = ev
+
+    def next_fork(self) -> bool:
+        """Enqueue the next pending table group of a forked prepare() on the side stream (LayerPlan.run calls it once the layers that
+        need no further table are enqueued).  False: nothing was pending."""
+        if not self._late:
+            return False
+        self._fork_side(*self._late.pop(0))
+        return True
+
+    def join(self):
+        """The calling stream waits for the side stream's table building (no-op without a fork)."""
+        while self.next_fork():
+            pass
+        if self._join_ev is not None:
+            torch.cuda.current_stream().wait_event(self._join_ev)
+            self._join_ev = None
+            self.events = {}
+
+    def _build_tables(self, same, strides, chained, exact):
+        """-> keys of the pair lists built (on the current stream)."""
         counters = torch.zeros(max(1, len(same)), 64, dtype=torch.int32, device=self.device) if exact else None
         for i, (lvl, k) in enumerate(same):
             offs = offsets_device(k, self.order, self.device)
@@ -195,6 +263,7 @@ class SceneMaps:
         if todo:
             for t, pl in zip(todo, ops.pair_lists_batch([t[1:] for t in todo])):
                 self.pairs[t[0]] = pl
+        return [t[0] for t in todo]
 
     # ------------------------------------------------------------------------------------------
     def table(self, level: int):
@@ -204,6 +273,7 @@ class SceneMaps:
 
     def same(self, level: int, ksize: int) -> torch.Tensor:
         """nbr [k^3, V_l] of a stride-1 convolution on level `level`."""
+        self.join()
         key = (level, ksize)
         if key not in self._same:
             offs = offsets_device(ksize, self.order, self.device)
@@ -219,10 +289,12 @@ class SceneMaps:
 
     def down(self, level: int) -> torch.Tensor:
         """nbr [8, V_{l+1}] of the k=2 s=2 convolution level -> level+1."""
+        self.join()
         return self._stride_maps(level)[0]
 
     def up(self, level: int) -> torch.Tensor:
         """nbr [8, V_l] of the transposed k=2 s=2 convolution level+1 -> level."""
+        self.join()
         return self._stride_maps(level)[1]
 
     def conv_table(self, kind: str, level: int, ksize: int = 0) -> dict:
@@ -249,6 +321,7 @@ class SceneMaps:
     def rulebook_sizes(self):
         """{(kind, level[, k]): number of (in, out, offset) pairs} of the tables built so far (for the
         roofline accounting of bench.py; costs a sync)."""
+        self.join()
         out = {}
         for (lvl, k), t in self._same.items():
             out[("same", lvl, k)] = int((t >= 0).sum())
@@ -329,6 +402,8 @@ class BatchSceneMaps(SceneMaps):
         self._perm8 = torch.from_numpy(child_perm(order)).to(self.device)
         self._sp_start = None
         self.density, self.pairs = {}, {}
+        self.events, self._join_ev, self._fork_ev = {}, None, ops.stream_event()
+        self._late = self._stem_done = None
 
     def voxel_features(self, points: Sequence[torch.Tensor], feats2d, mode: int, ld_out: int, stats=None) -> torch.Tensor:
         """points / feats2d: the scenes' tensors in batch order (feats2d None or a list)."""
@@ -363,7 +438,7 @@ class BatchedMaps:
         self.n_vox = [self.offsets[l][-1] for l in range(n_levels)]
         self._tables: Dict[Tuple, dict] = {}
 
-    def prepare(self, same=(), strides=(), chained=False):     # (training batches: `chained` is False by construction)
+    def prepare(self, same=(), strides=(), chained=False, fork=False):     # (training batches: `chained` / `fork` are False by construction)
         for m in self.maps:
             m.prepare(same=same, strides=strides, chained=chained)
 

@@ -106,3 +106,29 @@ def test_worst_case_pair_capacity_gives_the_same_bits(monkeypatch):
     for mode in (False, "auto"):
         for k, v in outs[True].items():
             assert torch.equal(outs[mode][k], v), (mode, k)
+
+
+def test_fork_join_of_the_table_building_gives_the_same_bits(monkeypatch):
+    """`sparse.FORK_JOIN`: with one scene in flight only the stem's neighbour table is built on the scene's stream, the other levels'
+    hash tables / kernel maps / pair lists on a side stream between the segments of the U-Net plan (`sd3d_run_layers_ev` waits per
+    table).  Same kernels on the same data in a different interleaving: every output of the exact run, twice in a row (a stale side
+    stream would show on the second forward)."""
+    from segdino3d_amd import sparse
+    from segdino3d_amd.configs import scannet200_model_cfg
+    from segdino3d_amd.synth import make_scene, structure_scene
+    d = P.dev()
+    model, _ = P._build(scannet200_model_cfg(query_num=200), d)
+    scenes = []
+    for seed, n, s in ((23, 150_000, 3000), (24, 60_000, 900)):
+        pts, tgt = make_scene(seed, n, s, 300)
+        structure_scene(pts, tgt)
+        scenes.append((pts.to(d), tgt.to(d)))
+    outs = {}
+    for mode in (False, True):
+        monkeypatch.setattr(sparse, "FORK_JOIN", mode)
+        with torch.no_grad():
+            outs[mode] = [_fields(model([p], [copy.copy(t)])[0].pred_pts_seg) for p, t in scenes + scenes]
+    assert outs[False][0]["scores"].numel() >= 50
+    for a, b in zip(outs[False], outs[True]):
+        for k, v in a.items():
+            assert torch.equal(b[k], v), k

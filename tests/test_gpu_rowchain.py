@@ -17,6 +17,12 @@ def _dev():
     return torch.device("cuda:0")
 
 
+@pytest.fixture(params=[16, 4], ids=["tile16", "tile4"])
+def tile(request):
+    """rows of a workgroup's tile: 16 (csrc/rowchain.hip) or 4 (csrc/rowchain_narrow.hip)"""
+    return request.param
+
+
 def _rel(a, b):
     return ((a.double() - b.double()).abs().max() / (b.double().abs().max() + 1e-30)).item()
 
@@ -26,7 +32,7 @@ def _rel(a, b):
                                                     (256, 0, 1024, "gelu", False), (1024, 0, 256, None, True), (256, 0, 3, "sigmoid", False),
                                                     (256, 0, 199, None, False), (256, 0, 1, None, False), (256, 256, 256, None, False),
                                                     (48, 0, 32, None, False)])
-def test_linear_op(rows, k0, k1, cout, act, use_res):
+def test_linear_op(rows, k0, k1, cout, act, use_res, tile):
     from segdino3d_amd.rowchain import Program
     d = _dev()
     g = torch.Generator().manual_seed(rows * 7 + cout)
@@ -37,7 +43,7 @@ def test_linear_op(rows, k0, k1, cout, act, use_res):
     res = torch.randn(rows, cout, generator=g) if use_res else None
     out = torch.full((rows, cout), float("nan"), device=d)
     out2 = torch.full((rows, cout if cout % 4 == 0 else cout), float("nan"), device=d)
-    P = Program(9)
+    P = Program(9, rows=tile)
     src = 5 if k0 > 256 else 0                                     # a 1024-wide buffer spans four slots
     dst = 0 if cout > 256 else 3
     P.load(src, x0.to(d))
@@ -58,7 +64,7 @@ def test_linear_op(rows, k0, k1, cout, act, use_res):
     assert torch.equal(out, out2)
 
 
-def test_linear_rows_are_independent_of_their_tile():
+def test_linear_rows_are_independent_of_their_tile(tile):
     """A row's bits do not depend on the rows it shares a tile / launch with (what makes batched == single-scene)."""
     from segdino3d_amd.rowchain import Program
     d = _dev()
@@ -68,7 +74,7 @@ def test_linear_rows_are_independent_of_their_tile():
 
     def run(xs, scenes):
         out = torch.empty(xs.shape[0], 256, device=d)
-        P = Program(2)
+        P = Program(2, rows=tile)
         P.load(0, xs)
         P.linear(1, 0, w, b, act="gelu", gout=out)
         P.launch(scenes)
@@ -79,7 +85,7 @@ def test_linear_rows_are_independent_of_their_tile():
     assert torch.equal(whole, two) and torch.equal(whole[7:30], part)
 
 
-def test_layernorm_pe_box_ops():
+def test_layernorm_pe_box_ops(tile):
     from segdino3d_amd import ops
     from segdino3d_amd.rowchain import Program
     d = _dev()
@@ -102,7 +108,7 @@ def test_layernorm_pe_box_ops():
     o_ln, o_pe, o_pem = (torch.empty(rows, 256, device=d) for _ in range(3))
     center, size, metric = (torch.empty(rows, 3, device=d) for _ in range(3))
     scenes = [dict(q0=0, nq=20), dict(q0=20, nq=25)]
-    P = Program(6, rng)
+    P = Program(6, rng, rows=tile)
     P.load(0, x); P.load(1, res)
     P.ln(2, 0, lw, lb, res=1, act="relu", gout=o_ln)
     P.pe(3, xyz, dim_t, axis); P.store(3, o_pe)
@@ -123,7 +129,7 @@ def test_layernorm_pe_box_ops():
 
 
 @pytest.mark.parametrize("nq,nk,masked", [(16, 16, False), (37, 37, False), (200, 200, False), (50, 301, True), (200, 13, True), (3, 1, True)])
-def test_attention_op(nq, nk, masked):
+def test_attention_op(nq, nk, masked, tile):
     """8 heads x 32 channels over the scene's own query rows (self-attention) or its 2D keys with LDS mask bits."""
     from segdino3d_amd import ops
     from segdino3d_amd.rowchain import Program
@@ -142,7 +148,7 @@ def test_attention_op(nq, nk, masked):
     scale = 32 ** -0.5
     out = torch.empty(nq + nq2, 256, device=d)
     scenes = [dict(q0=0, nq=nq), dict(q0=nq, nq=nq2)]
-    P = Program(8)
+    P = Program(8, rows=tile)
     P.load(0, q)
     bits_ref = None
     if masked:
@@ -177,7 +183,7 @@ def test_attention_op(nq, nk, masked):
         assert _rel(got, ref_k.cpu()) < TOL
 
 
-def test_merge_op_equals_the_attention_kernels_own_merge():
+def test_merge_op_equals_the_attention_kernels_own_merge(tile):
     from segdino3d_amd import ops
     from segdino3d_amd.rowchain import Program
     d = _dev()
@@ -191,7 +197,7 @@ def test_merge_op_equals_the_attention_kernels_own_merge():
         a = torch.full((Lq, 256), float("nan"), device=d)
         ws, ca = ops.attention_parts([(q, k, v, bits, q2, k2, a)], 8, 0.125)
         out = torch.empty(Lq, 256, device=d)
-        P = Program(2)
+        P = Program(2, rows=tile)
         P.merge(0, ws, a)
         P.store(0, out)
         P.launch([dict(q0=0, nq=Lq, ksplit=ca[0][0], part_off=ca[0][1])])
@@ -225,13 +231,16 @@ def _decoder_outputs(model, scenes):
     return cap.outputs, res
 
 
-@pytest.mark.parametrize("query_num", [-1, 64])
-def test_fused_decoder_matches_the_op_by_op_decoder(query_num, monkeypatch):
+@pytest.mark.parametrize("query_num,narrow", [(-1, False), (64, False), (-1, True), (64, True)])
+def test_fused_decoder_matches_the_op_by_op_decoder(query_num, narrow, monkeypatch):
     """Same weights, same scene: every decoder output of the row-chain path within fp32 summation-order noise of the op-by-op path
-    (the path the decoder goldens pinned in rounds 1-3), mask bits equal except where a logit sits on the threshold."""
+    (the path the decoder goldens pinned in rounds 1-3), mask bits equal except where a logit sits on the threshold.  narrow: the
+    scene's <= 512 query rows on 4-row tiles (csrc/rowchain_narrow.hip)."""
     from segdino3d_amd import decoder as D
     model, scenes = _model_and_scenes([(30000, 300, 24)], query_num)
     monkeypatch.setattr(D, "FUSED_DECODER", True)
+    monkeypatch.setattr(D, "FUSED_NARROW", narrow)
+    assert model.decoder._fusable(300 if query_num < 0 else 64) == (4 if narrow else 16)
     fused, _ = _decoder_outputs(model, scenes)
     monkeypatch.setattr(D, "FUSED_DECODER", False)
     plain, _ = _decoder_outputs(model, scenes)
@@ -250,13 +259,15 @@ def test_fused_decoder_matches_the_op_by_op_decoder(query_num, monkeypatch):
     print(f"fused vs op-by-op decoder, query_num={query_num}: worst relative deviation {worst:.2e}")
 
 
-@pytest.mark.parametrize("policy,sizes", [(True, [(30000, 300, 24), (20000, 180, 10), (25000, 333, 31)]),
-                                          ("auto", [(30000, 300, 24), (40000, 700, 10), (25000, 333, 31), (40000, 650, 3)])])
-def test_fused_decoder_batch_is_bit_identical_to_single_scene_calls(policy, sizes, monkeypatch):
-    """policy True: every scene on the row-chain path; "auto": the scenes with more than 512 query rows take it, the others go op by op
-    in the same call - a scene's bits never depend on what else is in the batch."""
+@pytest.mark.parametrize("policy,narrow,sizes", [(True, False, [(30000, 300, 24), (20000, 180, 10), (25000, 333, 31)]),
+                                                 ("auto", False, [(30000, 300, 24), (40000, 700, 10), (25000, 333, 31), (40000, 650, 3)]),
+                                                 ("auto", True, [(30000, 300, 24), (40000, 700, 10), (25000, 333, 31), (40000, 650, 3)])])
+def test_fused_decoder_batch_is_bit_identical_to_single_scene_calls(policy, narrow, sizes, monkeypatch):
+    """policy True: every scene on the row-chain path; "auto": the scenes with more than 512 query rows take it (16-row tiles), the
+    others go op by op - or, narrow, on 4-row tiles - in the same call: a scene's bits never depend on what else is in the batch."""
     from segdino3d_amd import decoder as D
     monkeypatch.setattr(D, "FUSED_DECODER", policy)
+    monkeypatch.setattr(D, "FUSED_NARROW", narrow)
     model, scenes = _model_and_scenes(sizes, -1)
     _, batch = _decoder_outputs(model, scenes)
     for b, sc in enumerate(scenes):

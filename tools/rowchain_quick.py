@@ -1,5 +1,5 @@
 """Per-op cost of the row-chain executor (csrc/rowchain.hip) at the decoder's shapes: us per launch for programs that repeat one op.
-usage: python tools/rowchain_quick.py [rows]"""
+usage: python tools/rowchain_quick.py [rows] [tile rows: 16 | 4]"""
 import os
 import sys
 import time
@@ -12,6 +12,7 @@ from segdino3d_amd.rowchain import Program
 
 d = torch.device("cuda:0")
 rows = int(sys.argv[1]) if len(sys.argv) > 1 else 200
+TILE = int(sys.argv[2]) if len(sys.argv) > 2 else 16          # rows per workgroup: 16 or 4
 g = torch.Generator().manual_seed(0)
 x = torch.randn(rows, 256, generator=g).to(d)
 ws = [(torch.randn(256, 256, generator=g) / 16).to(d) for _ in range(16)]
@@ -49,7 +50,7 @@ def timeit(build, n=30, **kw):
 
 def prog_linears(k):
     def f():
-        P = Program(8)
+        P = Program(8, rows=TILE)
         P.load(0, x)
         for i in range(k):
             P.linear(1 if i % 2 == 0 else 0, 0 if i % 2 == 0 else 1, ws[i % 16], b, act="relu")
@@ -58,7 +59,7 @@ def prog_linears(k):
     return f
 
 
-print(f"rows = {rows} ({(rows + 15) // 16} workgroups of 16 waves)")
+print(f"rows = {rows} ({(rows + TILE - 1) // TILE} workgroups of {16 if TILE == 16 else 8} waves, {TILE} rows each)")
 t0 = timeit(prog_linears(0))
 print(f"LOAD + STORE only: {t0:.1f} us per launch")
 for k in (1, 2, 4, 8, 16, 32):
@@ -68,7 +69,7 @@ for k in (1, 2, 4, 8, 16, 32):
 
 def prog_same_w(k):
     def f():
-        P = Program(8)
+        P = Program(8, rows=TILE)
         P.load(0, x)
         for i in range(k):
             P.linear(1 if i % 2 == 0 else 0, 0 if i % 2 == 0 else 1, ws[0], b, act="relu")
@@ -83,7 +84,7 @@ print(f"16 x LINEAR 256 -> 256 with the SAME weights (L2 / L1 warm): {t:.1f} us,
 
 def prog_ffn(k):
     def f():
-        P = Program(8)
+        P = Program(8, rows=TILE)
         P.load(0, x)
         for i in range(k):
             P.linear(4, 0, w_up, b_up, act="gelu")
@@ -99,7 +100,7 @@ print(f"4 x (LINEAR 256 -> 1024 gelu, LINEAR 1024 -> 256): {t:.1f} us, {(t - t0)
 
 def prog_op(kind, k):
     def f():
-        P = Program(8)
+        P = Program(8, rows=TILE)
         P.load(0, x)
         for i in range(k):
             if kind == "ln":
