@@ -21,7 +21,8 @@ def timeit(fn, reps=5):
 d = torch.device("cuda:0")
 pts, tgt = make_scene(0, 150000, 3000, 300)
 maps = SceneMaps(pts.to(d), 0.02, 5, superpoints=tgt.extra_features["super_point_masks"].to(d))
-maps.prepare(same=[(0, 5)] + [(l, 3) for l in range(5)], strides=[0, 1, 2, 3])
+# PAIR_CHAINED=product: the list formats of the evaluation forward (chained lists at sparse.PAIR_CHAIN_LEVELS, round 4)
+maps.prepare(same=[(0, 5)] + [(l, 3) for l in range(5)], strides=[0, 1, 2, 3], chained=os.environ.get("PAIR_CHAINED") == "product")
 g = torch.Generator().manual_seed(0)
 cases = [(("same", 0, 5), 288, 32), (("same", 0, 3), 96, 96), (("same", 0, 3), 128, 96), (("same", 1, 3), 32, 32), (("same", 1, 3), 96, 96),
          (("same", 2, 3), 64, 64), (("same", 2, 3), 128, 128), (("same", 2, 3), 192, 128), (("same", 3, 3), 128, 128), (("same", 3, 3), 256, 256),
@@ -34,7 +35,7 @@ for key, cin, cout in cases:
     K, M = nbr.shape
     n_in = int(nbr.max().item()) + 1
     x = torch.randn(n_in, cin, generator=g).to(d); w = (torch.randn(K, cout, cin, generator=g) * (K * cin) ** -0.5).to(d)
-    P = int((pairs.in_idx >= 0).sum())
+    P = int((nbr >= 0).sum()) if pairs.center == ops.PAIR_CHAINED else int((pairs.in_idx >= 0).sum())
     t = timeit(lambda: ops.pair_conv(x, w, pairs), 5)
     line = f"M={M} P={P} tiles={pairs.p_cap // 128} | {t:.0f} us | {2.0 * P * cin * cout / t / 1e6:.1f} TF/s active"
     if os.environ.get("PAIR_MODES") == "1":      # the same convolution on the other paths: per-row lists over ALL offsets, pos-based pass 2
