@@ -287,8 +287,9 @@ int sd3d_run_layers_ev(const sd3d_layer* layers, int n_layers, const sd3d_table*
  * ------------------------------------------------------------------------------------------- */
 /* ---- Row-chain executor (csrc/rowchain.hip): the row-local part of a decoder layer as ONE launch ------------------------------
  * Replaces the per-op launches of instance_seg_3d_decoder.py:606-799 between the superpoint cross-attention and the mask-logit
- * product: a workgroup owns 16 consecutive query rows of one scene, keeps their activations in LDS slots ([16][260] fp32 each; a
- * buffer wider than 256 columns has row stride width + 4 and spills into the following slots) and interprets `ops` over them.
+ * product: a workgroup owns 16 (program.tile_rows = 0 / 16) or 4 (tile_rows = 4: csrc/rowchain_narrow.hip, 8 waves) consecutive query
+ * rows of one scene, keeps their activations in LDS slots ([rows][260] fp32 each; a buffer wider than 256 columns has row stride
+ * width + 4 and spills into the following slots) and interprets `ops` over them.
  * All pointers are device pointers; global tensors hold the query rows of ALL scenes of the call back to back (row = scene.q0 +
  * row in scene).  Slot 0xFF = "none".  Per row the arithmetic does not depend on the other rows of the launch. */
 #define SD3D_RC_MAX_OPS 44
@@ -296,7 +297,8 @@ int sd3d_run_layers_ev(const sd3d_layer* layers, int n_layers, const sd3d_table*
 enum { SD3D_RC_LOAD = 1,   /* slot dst[:, :cout] = p0[row, :cout] (row stride ld) */
        SD3D_RC_STORE = 2,  /* p0[row, :cout] = slot src0 */
        SD3D_RC_LINEAR = 3, /* dst = act([src0 (k0 ch) | src1 (k1 ch)] . W^T + bias (+ res)); p0 = W [cout, K = k0 + k1] PACKED in MFMA-fragment order
-                            * P[tile = col / 16][g = ch / 16][lane = 16 * ((ch % 16) / 4) + col % 16][ch % 4] = W[min(col, cout - 1)][ch], p1 = bias | NULL,
+                            * P[tile = col / 16][g = ch / 16][lane = 16 * ((ch % 16) / 4) + col % 16][ch % 4] = W[min(col, cout - 1)][ch] (4-row tiles:
+                            * P[tile = col / 64][quad = ch / 4][lane = col % 64][ch % 4]), p1 = bias | NULL,
                             * p2 = optional global copy (row stride ld); flag NO_LDS_DST: only the global copy */
        SD3D_RC_LN = 4,     /* dst = act(LayerNorm_256(src0 (+ res)) * p0 + p1), eps = f0; p2 = optional global copy (ld) */
        SD3D_RC_PE = 5,     /* dst = sine PE (utils.py:53-105) of p0[row, 0:3] in the scene's range; p1 = dim_t [256], p2 = axis int8 [256];
@@ -332,7 +334,7 @@ typedef struct sd3d_rc_scene {
 typedef struct sd3d_rc_program {
     int32_t n_scenes, n_programs, n_slots, nw_max, nw2_max, tile_rows;
     const float* rng;                                          /* [n_scenes][6] scene ranges (lo, hi) for PE / BOX */
-    int32_t tile0[SD3D_MAX_BATCH + 1];                         /* prefix sums of ceil(nq / 16) */
+    int32_t tile0[SD3D_MAX_BATCH + 1];                         /* prefix sums of ceil(nq / tile rows) */
     int32_t prog_begin[SD3D_RC_MAX_PROGRAMS + 1];              /* op ranges of the programs (gridDim.y) */
     sd3d_rc_scene scenes[SD3D_MAX_BATCH];
     sd3d_rc_op ops[SD3D_RC_MAX_OPS];
