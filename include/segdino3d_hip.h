@@ -53,6 +53,8 @@ int sd3d_scan_exclusive_i32(const int32_t* in, int32_t* out, int64_t n, int32_t*
 /* order-preserving key builders */
 int sd3d_keys_from_f32(const float* x, int64_t n, int descending, uint64_t* keys, void* stream);
 int sd3d_keys_from_i64(const int64_t* x, int64_t n, uint64_t* keys, void* stream);
+/* The same, and *flag |= flag_value when an id does not fit `bits` bits (a radix sort over fewer key bits is then not a full sort). */
+int sd3d_keys_from_i64_checked(const int64_t* x, int64_t n, uint64_t* keys, int bits, int32_t* flag, int flag_value, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Voxelisation and coordinate maps.

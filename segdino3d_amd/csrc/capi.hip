@@ -18,6 +18,7 @@ size_t scan_ws_bytes(int64_t n);
 int scan_exclusive_i32(const int*, int*, int64_t, const int*, int*, void*, size_t, hipStream_t);
 int launch_f32_to_sortkey(const float*, int64_t, int, uint64_t*, hipStream_t);
 int launch_i64_to_sortkey(const int64_t*, int64_t, uint64_t*, hipStream_t);
+int launch_i64_to_sortkey_checked(const int64_t*, int64_t, uint64_t*, int, int32_t*, int, hipStream_t);
 int launch_scene_stats(const float*, int, int64_t, float*, void*, size_t, hipStream_t);
 int launch_pack_mask_rows(const uint8_t*, int64_t, const int32_t*, int, uint8_t*, int64_t, hipStream_t);
 int launch_row_chain(const sd3d_rc_program*, hipStream_t);
@@ -135,6 +136,9 @@ int sd3d_keys_from_f32(const float* x, int64_t n, int descending, uint64_t* keys
     return launch_f32_to_sortkey(x, n, descending, keys, ST);
 }
 int sd3d_keys_from_i64(const int64_t* x, int64_t n, uint64_t* keys, void* stream) { return launch_i64_to_sortkey(x, n, keys, ST); }
+int sd3d_keys_from_i64_checked(const int64_t* x, int64_t n, uint64_t* keys, int bits, int32_t* flag, int flag_value, void* stream) {
+    return launch_i64_to_sortkey_checked(x, n, keys, bits, flag, flag_value, ST);
+}
 
 size_t sd3d_scene_stats_ws_bytes(void) { return 256 * 9 * sizeof(float); }
 int sd3d_scene_stats(const float* points, int ld, int64_t n, float* stats, void* ws, size_t ws_bytes, void* stream) {

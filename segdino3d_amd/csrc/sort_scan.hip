@@ -359,6 +359,21 @@ int launch_i64_to_sortkey_add(const int64_t* x, int64_t n, uint64_t add, uint64_
     SD3D_CHECK_LAUNCH();
     return SD3D_OK;
 }
+__global__ void i64_to_sortkey_checked(const int64_t* __restrict__ x, int64_t n, uint64_t* __restrict__ keys, int bits, int32_t* __restrict__ flag, int value) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) {
+        const uint64_t k = (uint64_t)x[i];
+        keys[i] = k;
+        if (k >> bits) atomicOr(flag, value);
+    }
+}
+int launch_i64_to_sortkey_checked(const int64_t* x, int64_t n, uint64_t* keys, int bits, int32_t* flag, int value, hipStream_t st) {
+    if (n <= 0) return SD3D_OK;
+    if (!flag || bits < 1 || bits > 63) return sd3d_set_error(SD3D_ERR_ARG, "keys_from_i64_checked: flag pointer and 1..63 bits");
+    hipLaunchKernelGGL(i64_to_sortkey_checked, dim3((unsigned)cdiv(n, 256)), dim3(256), 0, st, x, n, keys, bits, flag, value);
+    SD3D_CHECK_LAUNCH();
+    return SD3D_OK;
+}
 int launch_i64_to_sortkey(const int64_t* x, int64_t n, uint64_t* keys, hipStream_t st) {
     if (n <= 0) return SD3D_OK;
     hipLaunchKernelGGL(i64_to_sortkey, dim3((unsigned)cdiv(n, 256)), dim3(256), 0, st, x, n, keys);

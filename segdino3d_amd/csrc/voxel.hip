@@ -120,7 +120,9 @@ __global__ __launch_bounds__(256) void voxel_keys_kernel(const float* __restrict
         r[a] = (uint32_t)rel & 0xFFFFu;
     }
     if (bad) atomicOr(err_flag, 1);
-    keys[i] = morton_encode(r[0], r[1], r[2]) | ((uint64_t)(batch & 0xFF) << SD3D_MORTON_BITS);
+    const uint64_t m = morton_encode(r[0], r[1], r[2]);
+    if (m >> 32) atomicOr(err_flag, 2);                       // a 32-bit radix sort of the Morton part would not be a full sort (sparse.OPTIMISTIC_SORT)
+    keys[i] = m | ((uint64_t)(batch & 0xFF) << SD3D_MORTON_BITS);
 }
 
 int launch_voxel_keys(const float* pts, int ld, int64_t n, float inv_voxel, const float* stats, int shift_to_min, int batch,

@@ -276,9 +276,15 @@ def keys_from_f32(x: torch.Tensor, descending=False):
     return keys
 
 
-def keys_from_i64(x: torch.Tensor):
+def keys_from_i64(x: torch.Tensor, check=None):
+    """check = (bits, flag int32 [1], value): flag |= value when an id needs more than `bits` bits."""
     lib = _lib.load()
     keys = torch.empty(x.numel(), dtype=torch.int64, device=x.device)
+    if check is not None:
+        bits, flag, value = check
+        _lib.check(lib.sd3d_keys_from_i64_checked(_ptr(x, torch.int64, "x"), x.numel(), _ptr(keys), int(bits), _ptr(flag, torch.int32, "flag"),
+                                                  int(value), _stream()), "keys_from_i64_checked")
+        return keys
     _lib.check(lib.sd3d_keys_from_i64(_ptr(x, torch.int64, "x"), x.numel(), _ptr(keys), _stream()), "keys_from_i64")
     return keys
 

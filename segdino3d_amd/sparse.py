@@ -104,6 +104,8 @@ PAIR_CHAIN = os.environ.get("SD3D_PAIR_CHAIN", "1") != "0"
 # kernel maps and pair lists are built on a side stream while the stem and the first blocks convolve, each table's first layer
 # waits for its event (sd3d_run_layers_ev).  Same kernels on the same data: bit-identical outputs.
 FORK_JOIN = os.environ.get("SD3D_FORK_JOIN", "1") != "0"
+# SD3D_OPTIMISTIC_SORT=0: a scene's voxel keys / superpoint ids are always sorted over all their bits (7 + 4 radix passes instead of 4 + 2)
+OPTIMISTIC_SORT = os.environ.get("SD3D_OPTIMISTIC_SORT", "1") != "0"
 PAIR_CHAIN_LEVELS = tuple(int(v) for v in os.environ.get("SD3D_PAIR_CHAIN_LEVELS", "0,1,2").split(",") if v.strip() != "")
 
 
@@ -123,29 +125,39 @@ class SceneMaps:
         N = points.shape[0]
         self.n_points = N
         inv = float(np.float32(1.0) / np.float32(voxel_size))
-        self.stats = ops.scene_stats(points)
-        keys, self.icoords, self.origin, err = ops.voxel_keys(points, inv, self.stats, shift_to_min)
-        skeys, self.sidx = ops.sort_pairs(keys, None, 0, 56)
-        ukeys, self.seg_start, self.inverse, n0 = ops.unique_sorted(
-            skeys, self.sidx, N, None, 0, want_seg_start=True, want_map=True, map_size=N)
-        keys_l, counts, parents = [ukeys], [n0], []
-        cap = N
-        for lvl in range(1, n_levels):
-            clip = (self.stats, inv, lvl, clip_min_shape) if clip_min_shape > 0 else None
-            uk, _, parent, nl = ops.unique_sorted(keys_l[-1], None, cap, counts[-1], 3, want_seg_start=False, want_map=True,
-                                                  clip=clip)
-            keys_l.append(uk)
-            counts.append(nl)
-            parents.append(parent)
-        extra = [err]
         self.superpoints = superpoints                    # int64 id per point (kept for the pooling backward, train_ops)
-        if superpoints is not None:
-            sp_keys = ops.keys_from_i64(superpoints)
-            self.sp_sorted, self.sp_sidx = ops.sort_pairs(sp_keys, None, 0, 32)
-            extra.append(self.sp_sorted[-1:].to(torch.int32))
-        host = ops.HostRead(torch.cat(counts + extra)).wait().tolist()   # synchronisation 1 of the scene (polled)
+        # Optimistic radix passes: the voxel keys are sorted over their low 32 bits (4 passes instead of 7: any scene up to ~20 m at 2 cm)
+        # and the superpoint ids over 16 (2 instead of 4); the key kernels raise a flag when a key needs more, the flag rides in the
+        # scene's read-back, and the chain is then redone with the full sorts (tests/test_gpu_sparse.py exercises both).
+        key_bits, sp_bits = (32, 16) if OPTIMISTIC_SORT else (56, 32)
+        while True:
+            self.stats = ops.scene_stats(points)
+            keys, self.icoords, self.origin, err = ops.voxel_keys(points, inv, self.stats, shift_to_min)
+            skeys, self.sidx = ops.sort_pairs(keys, None, 0, key_bits)
+            ukeys, self.seg_start, self.inverse, n0 = ops.unique_sorted(
+                skeys, self.sidx, N, None, 0, want_seg_start=True, want_map=True, map_size=N)
+            keys_l, counts, parents = [ukeys], [n0], []
+            cap = N
+            for lvl in range(1, n_levels):
+                clip = (self.stats, inv, lvl, clip_min_shape) if clip_min_shape > 0 else None
+                uk, _, parent, nl = ops.unique_sorted(keys_l[-1], None, cap, counts[-1], 3, want_seg_start=False, want_map=True,
+                                                      clip=clip)
+                keys_l.append(uk)
+                counts.append(nl)
+                parents.append(parent)
+            extra = [err]
+            if superpoints is not None:
+                sp_keys = ops.keys_from_i64(superpoints, check=(sp_bits, err, 4) if sp_bits < 32 else None)
+                self.sp_sorted, self.sp_sidx = ops.sort_pairs(sp_keys, None, 0, sp_bits)
+                extra.append(self.sp_sorted[-1:].to(torch.int32))
+            host = ops.HostRead(torch.cat(counts + extra)).wait().tolist()   # synchronisation 1 of the scene (polled)
+            flags = int(host[n_levels])
+            if (flags & 2 and key_bits < 56) or (flags & 4 and sp_bits < 32):
+                key_bits, sp_bits = 56, 32                                   # a key did not fit: full sorts (rare: the chain runs twice)
+                continue
+            break
         self.n_vox = [int(v) for v in host[:n_levels]]
-        if host[n_levels] != 0:
+        if int(host[n_levels]) & 1:
             raise RuntimeError("scene exceeds the 16-bit-per-axis voxel key range (extent > ~1.3 km at 2 cm)")
         self.n_superpoints = int(host[n_levels + 1]) + 1 if superpoints is not None else 0
         self.keys = [k[: self.n_vox[l]] for l, k in enumerate(keys_l)]
@@ -388,7 +400,7 @@ class BatchSceneMaps(SceneMaps):
             extra += [self.sp_sorted[c - 1:c].view(torch.int32)[:1] for c in self.point_off[1:]]
         host = ops.HostRead(torch.cat(counts + extra)).wait().tolist()   # synchronisation 1 of the batch (polled)
         self.n_vox = [int(v) for v in host[:n_levels]]
-        if host[n_levels] != 0:
+        if int(host[n_levels]) & 1:                                # (bit 1 = "more than 32 Morton bits": the batch sorts all 56 key bits anyway)
             raise RuntimeError("scene exceeds the 16-bit-per-axis voxel key range (extent > ~1.3 km at 2 cm)")
         self.sp_off = [0]
         if superpoints is not None:

@@ -565,3 +565,39 @@ def test_backbones_on_a_dense_surface_scene_match_oracle(which):
           f"features max abs err {err:.3e} at max |f| {scale:.3f} ({err / scale:.2e} relative)")
     assert per_row > 8.0
     assert err <= BACKBONE_REL_TOL * max(scale, 1.0), f"backbone features differ: max abs err {err} (scale {scale})"
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("extent_m,sp_base,redo", [(6.0, 0, False), (60.0, 0, True), (6.0, 70_000, True)])
+def test_optimistic_radix_passes_fall_back_to_the_full_sort(extent_m, sp_base, redo, monkeypatch):
+    """`sparse.OPTIMISTIC_SORT`: voxel keys sorted over 32 bits / superpoint ids over 16 when they fit (the key kernels flag the
+    scenes where they do not: > ~20 m at 2 cm, ids >= 65536 - the chain then runs again with the full sorts).  Either way the maps
+    are those of the full sorts, bit for bit."""
+    from segdino3d_amd import ops, sparse
+    from segdino3d_amd.sparse import SceneMaps
+    d = torch.device("cuda:0")
+    g = torch.Generator().manual_seed(7)
+    n = 40_000
+    pts = torch.rand(n, 3, generator=g) * torch.tensor([extent_m, extent_m * 0.7, 2.5])
+    pts = torch.cat([pts, torch.rand(n, 3, generator=g)], 1).to(d)
+    sp = (torch.randint(0, 500, (n,), generator=g) + sp_base).to(d)
+    calls = []
+    real_sort = ops.sort_pairs
+    monkeypatch.setattr(ops, "sort_pairs", lambda keys, vals=None, b=0, e=64: (calls.append(e), real_sort(keys, vals, b, e))[1])
+    maps = {}
+    for mode in (True, False):
+        monkeypatch.setattr(sparse, "OPTIMISTIC_SORT", mode)
+        calls.clear()
+        maps[mode] = SceneMaps(pts, 0.02, 5, superpoints=sp)
+        if mode:
+            assert calls == ([32, 16, 56, 32] if redo else [32, 16]), calls
+        else:
+            assert calls == [56, 32]
+    a, b = maps[True], maps[False]
+    assert a.n_vox == b.n_vox and a.n_superpoints == b.n_superpoints
+    for name in ("sidx", "seg_start", "inverse", "sp_sorted", "sp_sidx", "icoords"):
+        assert torch.equal(getattr(a, name), getattr(b, name)), name
+    for l in range(5):
+        assert torch.equal(a.keys[l], b.keys[l])
+    for l in range(4):
+        assert torch.equal(a.parents[l], b.parents[l])

@@ -1,7 +1,7 @@
 """Same-process A/B of module switches at the `single_scene` operating point (one scene in flight, back to back): the settings
 alternate every 10 forwards for `rounds` rounds, the report is the median / min of the group means - box-to-box and process-to-process
 noise (0.3 - 0.5 ms between two bench.py runs of one build) cancels.
-usage: python tools/ab_single.py [rounds] [query_num]   (switches: sparse.FORK_JOIN, decoder.FUSED_NARROW)"""
+usage: python tools/ab_single.py [rounds] [query_num]   (switches: sparse.FORK_JOIN, sparse.OPTIMISTIC_SORT, decoder.FUSED_NARROW)"""
 import os
 import statistics
 import sys
@@ -24,6 +24,7 @@ SETTINGS = {
     "fork / join": dict(fork=True, narrow=False),
     "narrow row chain": dict(fork=False, narrow=True),
     "fork / join + narrow row chain": dict(fork=True, narrow=True),
+    "fork / join, full radix sorts": dict(fork=True, narrow=False, optimistic=False),
 }
 only = os.environ.get("AB_ONLY")
 if only:
@@ -32,6 +33,7 @@ if only:
 
 def apply(s):
     sparse.FORK_JOIN = s["fork"]
+    sparse.OPTIMISTIC_SORT = s.get("optimistic", True)
     decoder.FUSED_NARROW = s["narrow"]
 
 
