@@ -440,6 +440,16 @@ int sd3d_class_scores(const float* cls, int ld, int64_t Q, int C, float* scores,
 /* labels / query index of the selected flat indices + mask-quality rescoring (:436-446). */
 int sd3d_mask_scores(const float* masks, int ld, int S, const uint32_t* flat_idx, const float* score_in, int n, int C,
                      int normalize, int32_t* labels, int32_t* qidx, float* score_out, void* stream);
+/* Index glue of predict_by_feat_instance / mask_matrix_nms as single launches (pure data movement):
+ *   take_f32: out[i] = src[idx[i]] (:434-435 `scores[topk_idx]`);  take_pair: labels / scores in the first sort's order (:71-76);
+ *   nms_finish: final_scores = scores2[order2], final_labels = labels1[order2], record = order1[order2] (int64, :133-139) and, boxes != NULL,
+ *   boxes[i] = [centers | sizes][qidx[record[i]]] ([n, 6], baseline3d.py:447-452; centers / sizes [Q, 3] contiguous). */
+int sd3d_take_f32(const float* src, const uint32_t* idx, int n, float* out, void* stream);
+int sd3d_take_pair(const uint32_t* order, const int32_t* labels, const float* scores, int n, int32_t* labels_out, float* scores_out,
+                   void* stream);
+int sd3d_nms_finish(const uint32_t* order2, const float* scores2, const int32_t* labels1, const uint32_t* order1, const int32_t* qidx,
+                    const float* centers, const float* sizes, int n, float* final_scores, int32_t* final_labels, int64_t* record,
+                    float* boxes, void* stream);
 /* sig[r] = sigmoid(masks[qidx[order[r]]]) zero-padded to ld_out, area[r] = sum (:441, :66, :80-81). */
 int sd3d_gather_sigmoid(const float* masks, int ld, int S, const int32_t* qidx, const uint32_t* order, int n, float* sig,
                         int ld_out, float* area, void* stream);

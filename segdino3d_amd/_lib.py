@@ -84,6 +84,9 @@ SIGNATURES = {
     "sd3d_scale_shift_act_add": (_i, [_p, _i, _i, _p, _i, _p, _p, _i, _l, _i, _p, _i, _p, _i, _p]),
     "sd3d_class_scores": (_i, [_p, _i, _l, _i, _p, _p, _p]),
     "sd3d_mask_scores": (_i, [_p, _i, _i, _p, _p, _i, _i, _i, _p, _p, _p, _p]),
+    "sd3d_take_f32": (_i, [_p, _p, _i, _p, _p]),
+    "sd3d_take_pair": (_i, [_p, _p, _p, _i, _p, _p, _p]),
+    "sd3d_nms_finish": (_i, [_p, _p, _p, _p, _p, _p, _p, _i, _p, _p, _p, _p, _p]),
     "sd3d_gather_sigmoid": (_i, [_p, _i, _i, _p, _p, _i, _p, _i, _p, _p]),
     "sd3d_nms_decay": (_i, [_p, _i, _p, _p, _i, _i, _f, _p, _p, _p, _p]),
     "sd3d_row_chain": (_i, [_p, _p]),

@@ -243,32 +243,32 @@ class Baseline3D(nn.Module):
         if out.get("scores") is not None and out["scores"][b] is not None:        # objectness head: scores *= out['scores'][0] (:428-429)
             flat = (flat.view(Q, C) * out["scores"][b].reshape(Q, 1)).reshape(-1).contiguous()
         order0 = _sorted_desc(flat)[:k].contiguous()                    # top-k (query, class) pairs (:434)
-        top_scores = flat[order0.long()]
+        top_scores = ops.take_f32(flat, order0)
         labels, qidx, scores = ops.mask_scores(logits, S, order0, top_scores, C, bool(_cfg_get(cfg, "obj_normalization", None)))
         S_pad = (S + 31) // 32 * 32
+        centers = out["centers"][b] if "centers" in out else None
+        sizes = out["sizes"][b] if "sizes" in out else None
+        have_boxes = centers is not None and sizes is not None
+        boxes = None
         if _cfg_get(cfg, "nms", None):
             order1 = _sorted_desc(scores)                                # mask_matrix_nms first sort (:71)
             sig, area = ops.gather_sigmoid(logits, S, qidx, order1, S_pad)
-            labels1 = labels[order1.long()].contiguous()
-            scores1 = scores[order1.long()].contiguous()
+            labels1, scores1 = ops.take_pair(order1, labels, scores)
             inter = ops.gather_gemm(sig, sig)                            # torch.mm(masks, masks^T) (:87)
             scores2 = ops.nms_decay(inter, area, labels1, scores1, kernel=_cfg_get(cfg, "matrix_nms_kernel"))
             order2 = _sorted_desc(scores2)                               # final sort (:133)
-            o2 = order2.long()
-            final_scores, final_labels = scores2[o2], labels1[o2]
-            record = order1.long()[o2]                                   # sort_inds_record (:139)
+            # scores2[order2], labels1[order2], sort_inds_record = order1[order2] (:139) and the kept queries' boxes: one launch
+            final_scores, final_labels, record, boxes = ops.nms_finish(
+                order2, scores2, labels1, order1, qidx, centers.contiguous() if have_boxes else None, sizes.contiguous() if have_boxes else None)
             src_row = order2.contiguous()
         else:
             # the reference leaves sort_inds_record undefined here; identity is the sane reading
             ident = torch.arange(k, dtype=torch.int32, device=cls.device)
             sig, area = ops.gather_sigmoid(logits, S, qidx, ident, S_pad)
             final_scores, final_labels, record, src_row = scores, labels, ident.long(), ident
-        centers = out["centers"][b] if "centers" in out else None
-        sizes = out["sizes"][b] if "sizes" in out else None
-        boxes = None
-        if centers is not None and sizes is not None:
-            q_rec = qidx.long()[record]
-            boxes = torch.cat([centers[q_rec], sizes[q_rec]], dim=-1).contiguous()
+            if have_boxes:
+                q_rec = qidx.long()[record]
+                boxes = torch.cat([centers[q_rec], sizes[q_rec]], dim=-1).contiguous()
         masks_u8, count = ops.expand_masks(sig, src_row, superpoints.contiguous(), pts, float(_cfg_get(cfg, "sp_score_thr")),
                                            boxes if self.filter_outofbox_points_eval else None)
         return dict(scores=final_scores, labels=final_labels, masks=masks_u8, count=count, boxes=boxes, topk_idx=qidx.long())

@@ -85,6 +85,10 @@ int launch_dinox_mask_bits(const uint32_t*, const uint32_t*, int, int64_t, int64
 int launch_box_refine(const float*, const float*, const float*, int, const float*, const float*, int, int64_t, float*, float*, float*, const int32_t*, hipStream_t);
 int launch_class_scores(const float*, int, int64_t, int, float*, float*, hipStream_t);
 int launch_mask_scores(const float*, int, int, const uint32_t*, const float*, int, int, int, int32_t*, int32_t*, float*, hipStream_t);
+int launch_take_f32(const float*, const uint32_t*, int, float*, hipStream_t);
+int launch_take_pair(const uint32_t*, const int32_t*, const float*, int, int32_t*, float*, hipStream_t);
+int launch_nms_finish(const uint32_t*, const float*, const int32_t*, const uint32_t*, const int32_t*, const float*, const float*, int, float*,
+                      int32_t*, int64_t*, float*, hipStream_t);
 int launch_gather_sigmoid(const float*, int, int, const int32_t*, const uint32_t*, int, float*, int, float*, hipStream_t);
 int launch_nms_decay(const float*, int, const float*, const int32_t*, int, int, float, const float*, float*, float*, hipStream_t);
 size_t expand_masks_ws_bytes(int n, int ld_sig);
@@ -398,6 +402,15 @@ int sd3d_box_refine_rows(const float* ref_points, const float* d_center, const f
 }
 int sd3d_class_scores(const float* cls, int ld, int64_t Q, int C, float* scores, float* rowmax, void* stream) {
     return launch_class_scores(cls, ld, Q, C, scores, rowmax, ST);
+}
+int sd3d_take_f32(const float* src, const uint32_t* idx, int n, float* out, void* stream) { return launch_take_f32(src, idx, n, out, ST); }
+int sd3d_take_pair(const uint32_t* order, const int32_t* labels, const float* scores, int n, int32_t* labels_out, float* scores_out, void* stream) {
+    return launch_take_pair(order, labels, scores, n, labels_out, scores_out, ST);
+}
+int sd3d_nms_finish(const uint32_t* order2, const float* scores2, const int32_t* labels1, const uint32_t* order1, const int32_t* qidx,
+                    const float* centers, const float* sizes, int n, float* final_scores, int32_t* final_labels, int64_t* record, float* boxes,
+                    void* stream) {
+    return launch_nms_finish(order2, scores2, labels1, order1, qidx, centers, sizes, n, final_scores, final_labels, record, boxes, ST);
 }
 int sd3d_mask_scores(const float* masks, int ld, int S, const uint32_t* flat_idx, const float* score_in, int n, int C, int normalize,
                      int32_t* labels, int32_t* qidx, float* score_out, void* stream) {

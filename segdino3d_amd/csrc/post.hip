@@ -548,3 +548,62 @@ int launch_mask_overlaps(const uint8_t* masks, int64_t mask_stride, int n, const
     SD3D_CHECK_LAUNCH();
     return SD3D_OK;
 }
+
+// ---------------------------------------------------------------------------------------------------------------------------
+// Index glue of predict_by_feat_instance (baseline3d.py:434-476, mask_matrix_nms :71-139) as three launches instead of sixteen
+// (`x.long()` + `y[x]` pairs, each a 4-6 us ATen launch in a phase that is a chain of ~50 dependent launches): pure data movement.
+// ---------------------------------------------------------------------------------------------------------------------------
+__global__ void take_f32_kernel(const float* __restrict__ src, const uint32_t* __restrict__ idx, int n, float* __restrict__ out) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = src[idx[i]];
+}
+int launch_take_f32(const float* src, const uint32_t* idx, int n, float* out, hipStream_t st) {
+    if (n <= 0) return SD3D_OK;
+    hipLaunchKernelGGL(take_f32_kernel, dim3((unsigned)cdiv(n, 256)), dim3(256), 0, st, src, idx, n, out);
+    SD3D_CHECK_LAUNCH();
+    return SD3D_OK;
+}
+
+// labels1 = labels[order], scores1 = scores[order]            (mask_matrix_nms first sort, :71-76)
+__global__ void take_pair_kernel(const uint32_t* __restrict__ order, const int32_t* __restrict__ labels, const float* __restrict__ scores,
+                                 int n, int32_t* __restrict__ labels_out, float* __restrict__ scores_out) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) { const uint32_t o = order[i]; labels_out[i] = labels[o]; scores_out[i] = scores[o]; }
+}
+int launch_take_pair(const uint32_t* order, const int32_t* labels, const float* scores, int n, int32_t* labels_out, float* scores_out,
+                     hipStream_t st) {
+    if (n <= 0) return SD3D_OK;
+    hipLaunchKernelGGL(take_pair_kernel, dim3((unsigned)cdiv(n, 256)), dim3(256), 0, st, order, labels, scores, n, labels_out, scores_out);
+    SD3D_CHECK_LAUNCH();
+    return SD3D_OK;
+}
+
+// the final sort's selections (:133-139) and the kept queries' boxes (baseline3d.py:447-452):
+//   final_scores = scores2[order2], final_labels = labels1[order2], record = order1[order2] (int64), boxes = [centers | sizes][qidx[record]]
+__global__ void nms_finish_kernel(const uint32_t* __restrict__ order2, const float* __restrict__ scores2, const int32_t* __restrict__ labels1,
+                                  const uint32_t* __restrict__ order1, const int32_t* __restrict__ qidx, const float* __restrict__ centers,
+                                  const float* __restrict__ sizes, int n, float* __restrict__ final_scores, int32_t* __restrict__ final_labels,
+                                  int64_t* __restrict__ record, float* __restrict__ boxes) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const uint32_t o2 = order2[i];
+    final_scores[i] = scores2[o2];
+    final_labels[i] = labels1[o2];
+    const uint32_t rec = order1[o2];
+    record[i] = (int64_t)rec;
+    if (boxes) {
+        const int64_t q = qidx[rec];
+#pragma unroll
+        for (int a = 0; a < 3; ++a) { boxes[i * 6 + a] = centers[q * 3 + a]; boxes[i * 6 + 3 + a] = sizes[q * 3 + a]; }
+    }
+}
+int launch_nms_finish(const uint32_t* order2, const float* scores2, const int32_t* labels1, const uint32_t* order1, const int32_t* qidx,
+                      const float* centers, const float* sizes, int n, float* final_scores, int32_t* final_labels, int64_t* record, float* boxes,
+                      hipStream_t st) {
+    if (n <= 0) return SD3D_OK;
+    if (boxes && (!centers || !sizes)) return sd3d_set_error(SD3D_ERR_ARG, "nms_finish: boxes need centers and sizes");
+    hipLaunchKernelGGL(nms_finish_kernel, dim3((unsigned)cdiv(n, 256)), dim3(256), 0, st, order2, scores2, labels1, order1, qidx, centers, sizes, n,
+                       final_scores, final_labels, record, boxes);
+    SD3D_CHECK_LAUNCH();
+    return SD3D_OK;
+}

@@ -1233,6 +1233,43 @@ def mask_scores(masks, S, flat_idx, score_in, C, normalize):
     return labels, qidx, out
 
 
+def take_f32(src, idx):
+    """src[idx] for an int32 index vector, one launch (ATen: `.long()` + index)."""
+    lib = _lib.load()
+    n = idx.numel()
+    out = torch.empty(n, dtype=torch.float32, device=src.device)
+    _lib.check(lib.sd3d_take_f32(_ptr(src, torch.float32, "src"), _ptr(idx, torch.int32, "idx"), n, _ptr(out), _stream()), "take_f32")
+    return out
+
+
+def take_pair(order, labels, scores):
+    """(labels[order], scores[order]) in one launch."""
+    lib = _lib.load()
+    n = order.numel()
+    lo = torch.empty(n, dtype=torch.int32, device=order.device)
+    so = torch.empty(n, dtype=torch.float32, device=order.device)
+    _lib.check(lib.sd3d_take_pair(_ptr(order, torch.int32, "order"), _ptr(labels, torch.int32, "labels"), _ptr(scores, torch.float32, "scores"), n,
+                                  _ptr(lo), _ptr(so), _stream()), "take_pair")
+    return lo, so
+
+
+def nms_finish(order2, scores2, labels1, order1, qidx, centers=None, sizes=None):
+    """-> (final_scores, final_labels int32, record int64, boxes [n, 6] | None): the selections behind matrix-NMS's final sort in one launch."""
+    lib = _lib.load()
+    n = order2.numel()
+    dev = order2.device
+    fs = torch.empty(n, dtype=torch.float32, device=dev)
+    fl = torch.empty(n, dtype=torch.int32, device=dev)
+    rec = torch.empty(n, dtype=torch.int64, device=dev)
+    boxes = torch.empty(n, 6, dtype=torch.float32, device=dev) if centers is not None and sizes is not None else None
+    _lib.check(lib.sd3d_nms_finish(_ptr(order2, torch.int32, "order2"), _ptr(scores2, torch.float32, "scores2"), _ptr(labels1, torch.int32, "labels1"),
+                                   _ptr(order1, torch.int32, "order1"), _ptr(qidx, torch.int32, "qidx"),
+                                   _ptr(centers, torch.float32, "centers") if boxes is not None else None,
+                                   _ptr(sizes, torch.float32, "sizes") if boxes is not None else None, n, _ptr(fs), _ptr(fl), _ptr(rec), _ptr(boxes),
+                                   _stream()), "nms_finish")
+    return fs, fl, rec, boxes
+
+
 def gather_sigmoid(masks, S, qidx, order, ld_out):
     lib = _lib.load()
     pm, ld = _rows(masks, "masks")

@@ -26,3 +26,7 @@ for M, cin, cout in [(3000, 256, 256), (3000, 256, 1024), (3000, 1024, 256), (30
         except Exception as e:  # noqa: BLE001
             row.append(f"{nt}:err")
     print(f"M={M} {cin}->{cout}  " + "  ".join(row))
+    if M <= 512:                                               # the decoder's shape: bias, and bias + residual
+        b, r = torch.randn(cout, generator=g).to(d), torch.randn(M, cout, generator=g).to(d)
+        print(f"      with bias: {timeit(lambda: ops.gather_gemm(x, w, shift=b)):.1f} us, bias + residual + relu: "
+              f"{timeit(lambda: ops.gather_gemm(x, w, shift=b, res=r, act='relu')):.1f} us")

@@ -56,3 +56,13 @@ text = "\n".join(out)
 print(text)
 if len(sys.argv) > 2:
     open(sys.argv[2], "w").write(text + "\n")
+if len(sys.argv) > 3:                                          # list the kernels of the last complete forward from the first kernel whose name contains argv[3]
+    seg = rows[fw[-2]:fw[-1]]
+    t0 = seg[0][1]
+    start = next((i for i, r in enumerate(seg) if sys.argv[3] in r[0]), 0)
+    lines = [f"kernels of the last complete forward from `{sys.argv[3]}` on ({len(seg) - start} launches):"]
+    for name, s_, e_, q in seg[start:]:
+        lines.append(f"  +{(s_ - t0) / 1e3:8.1f} us  {(e_ - s_) / 1e3:6.1f} us  q{q}  {name[:70]}")
+    print("\n".join(lines))
+    if len(sys.argv) > 2:
+        open(sys.argv[2], "a").write("\n".join(lines) + "\n")
