@@ -82,6 +82,12 @@ int sd3d_unique_sorted(const uint64_t* keys, const uint32_t* src_idx, int64_t n_
                        uint64_t* ukeys, int32_t* seg_start, int32_t* map, int32_t* n_unique_dev, void* ws,
                        size_t ws_bytes, const float* clip_stats, float clip_inv_voxel, int clip_level, int clip_min_shape,
                        void* stream);
+/* ALL coarser levels of a scene from its sorted level-0 unique keys in four launches: level l = 1..n_extra keeps the runs of
+ * (Morton >> 3 l).  ukeys[l - 1] [<= n_cap], parents[l - 1] [<= n_cap]: the level-l id of every level-(l - 1) voxel, counts[l - 1] = voxels
+ * of level l - the arrays sd3d_unique_sorted(shift 3, map) produces when called level after level, without the extent clip. */
+size_t sd3d_unique_levels_ws_bytes(int64_t n_cap, int n_extra);
+int sd3d_unique_levels(const uint64_t* keys, int64_t n_cap, const int32_t* n_dev, int n_extra, uint64_t* const* ukeys,
+                       int32_t* const* parents, int32_t* counts, void* ws, size_t ws_bytes, void* stream);
 /* Open-addressing hash table key -> voxel id; capacity = power of two > n. */
 int sd3d_hash_build(const uint64_t* ukeys, int64_t n, uint64_t* table_keys, int32_t* table_vals, int64_t capacity,
                     void* stream);

@@ -39,6 +39,8 @@ SIGNATURES = {
     "sd3d_scene_stats": (_i, [_p, _i, _l, _p, _p, _z, _p]),
     "sd3d_voxel_keys": (_i, [_p, _i, _l, _f, _p, _i, _i, _p, _p, _p, _p, _p]),
     "sd3d_unique_ws_bytes": (_z, [_l]),
+    "sd3d_unique_levels_ws_bytes": (_z, [_l, _i]),
+    "sd3d_unique_levels": (_i, [_p, _l, _p, _i, _p, _p, _p, _p, _z, _p]),
     "sd3d_unique_sorted": (_i, [_p, _p, _l, _p, _i, _p, _p, _p, _p, _p, _z, _p, _f, _i, _i, _p]),
     "sd3d_hash_build": (_i, [_p, _l, _p, _p, _l, _p]),
     "sd3d_kernel_map": (_i, [_p, _l, _p, _p, _l, _p, _i, _i, _p, _p, _p]),

@@ -26,6 +26,8 @@ size_t unique_ws_bytes(int64_t);
 int launch_unique_sorted(const uint64_t*, const uint32_t*, int64_t, const int*, int, uint64_t*, int32_t*, int32_t*, int32_t*,
                          void*, size_t, const float*, float, int, int, hipStream_t);
 int launch_hash_build(const uint64_t*, int64_t, uint64_t*, int32_t*, int64_t, hipStream_t);
+size_t unique_levels_ws_bytes(int64_t, int);
+int launch_unique_levels(const uint64_t*, int64_t, const int*, int, uint64_t* const*, int32_t* const*, int32_t*, void*, size_t, hipStream_t);
 int launch_kernel_map(const uint64_t*, int64_t, const uint64_t*, const int32_t*, int64_t, const int8_t*, int, int, int32_t*, int32_t*, hipStream_t);
 int launch_stride_maps(const uint64_t*, const int32_t*, int64_t, int64_t, const int32_t*, int32_t*, int32_t*, hipStream_t);
 int launch_voxel_mean(const float*, int, const float*, int, int, const float*, int64_t, const uint32_t*, const int32_t*, int64_t,
@@ -158,6 +160,11 @@ int sd3d_unique_sorted(const uint64_t* keys, const uint32_t* src_idx, int64_t n_
                        const float* clip_stats, float clip_inv_voxel, int clip_level, int clip_min_shape, void* stream) {
     return launch_unique_sorted(keys, src_idx, n_cap, n_dev, shift, ukeys, seg_start, map, n_unique_dev, ws, ws_bytes,
                                 clip_stats, clip_inv_voxel, clip_level, clip_min_shape, ST);
+}
+size_t sd3d_unique_levels_ws_bytes(int64_t n_cap, int n_extra) { return unique_levels_ws_bytes(n_cap > 0 ? n_cap : 1, n_extra > 0 ? n_extra : 1); }
+int sd3d_unique_levels(const uint64_t* keys, int64_t n_cap, const int32_t* n_dev, int n_extra, uint64_t* const* ukeys, int32_t* const* parents,
+                       int32_t* counts, void* ws, size_t ws_bytes, void* stream) {
+    return launch_unique_levels(keys, n_cap, n_dev, n_extra, ukeys, parents, counts, ws, ws_bytes, ST);
 }
 int sd3d_hash_build(const uint64_t* ukeys, int64_t n, uint64_t* table_keys, int32_t* table_vals, int64_t capacity, void* stream) {
     return launch_hash_build(ukeys, n, table_keys, table_vals, capacity, ST);

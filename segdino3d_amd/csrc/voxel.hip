@@ -235,6 +235,72 @@ int launch_unique_sorted(const uint64_t* keys, const uint32_t* src_idx, int64_t 
 }
 
 // ---------------------------------------------------------------------------------------------
+// All coarser levels of a scene from its sorted level-0 keys in FOUR launches (mark, the two scan launches over the levels' flag rows
+// back to back, emit) instead of four per level: level l's voxels are the runs of (Morton >> 3 l); a run boundary at level l + 1 is one at
+// level l, so id_l(i) = (number of level-l heads among rows <= i) - 1 and the parent of level-(l - 1) voxel id_{l-1}(i) is id_l(i).  The
+// keys, parents and counts are those of launch_unique_sorted called level after level (shift 3 each); no extent clip (MinkowskiEngine
+// semantics).  The chain before a scene's first host synchronisation is bound by its number of dependent launches, not by their work.
+// ---------------------------------------------------------------------------------------------
+#define UL_MAX 7
+struct ULParams {
+    const uint64_t* keys; int64_t cap; const int* n_dev; int nl;
+    uint64_t* ukeys[UL_MAX]; int32_t* parent[UL_MAX]; int32_t* counts;
+};
+__global__ __launch_bounds__(256) void mark_levels(const ULParams P, int* __restrict__ flags) {
+    const int64_t n = P.n_dev ? min((int64_t)*P.n_dev, P.cap) : P.cap;
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int l = blockIdx.y + 1;
+    if (i >= P.cap) return;
+    int f = 0;
+    if (i < n) f = (i == 0) || level_key(P.keys[i], 3 * l) != level_key(P.keys[i - 1], 3 * l);
+    flags[(int64_t)blockIdx.y * P.cap + i] = f;
+}
+__global__ __launch_bounds__(256) void emit_levels(const ULParams P, const int* __restrict__ flags, const int* __restrict__ excl) {
+    const int64_t n = P.n_dev ? min((int64_t)*P.n_dev, P.cap) : P.cap;
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int l = blockIdx.y + 1;
+    if (i >= n) return;
+    const int64_t row = (int64_t)blockIdx.y * P.cap;
+    const int f = flags[row + i];
+    const int id = excl[row + i] - excl[row] + f - 1;          // (the scan ran over all rows back to back: subtract the row's base)
+    if (f) P.ukeys[l - 1][id] = level_key(P.keys[i], 3 * l);
+    if (l == 1) {
+        P.parent[0][i] = id;
+    } else {
+        const int64_t prow = row - P.cap;
+        if (flags[prow + i]) P.parent[l - 1][excl[prow + i] - excl[prow]] = id;
+    }
+    if (i == n - 1) P.counts[l - 1] = id + 1;
+}
+size_t unique_levels_ws_bytes(int64_t n_cap, int n_extra) {
+    const int64_t tot = n_cap * n_extra;
+    return 2 * align_up((size_t)tot * sizeof(int), 256) + scan_ws_bytes(tot) + 256;
+}
+int launch_unique_levels(const uint64_t* keys, int64_t n_cap, const int* n_dev, int n_extra, uint64_t* const* ukeys, int32_t* const* parents,
+                         int32_t* counts, void* ws, size_t ws_bytes, hipStream_t st) {
+    if (n_cap <= 0 || n_extra < 1 || n_extra > UL_MAX) return sd3d_set_error(SD3D_ERR_ARG, "unique_levels: n_cap > 0 and 1..7 coarser levels");
+    if (!keys || !ukeys || !parents || !counts) return sd3d_set_error(SD3D_ERR_ARG, "unique_levels: null pointer");
+    if (ws_bytes < unique_levels_ws_bytes(n_cap, n_extra)) return sd3d_set_error(SD3D_ERR_WS, "unique_levels workspace too small");
+    ULParams P;
+    P.keys = keys; P.cap = n_cap; P.n_dev = n_dev; P.nl = n_extra; P.counts = counts;
+    for (int l = 0; l < UL_MAX; ++l) { P.ukeys[l] = l < n_extra ? ukeys[l] : nullptr; P.parent[l] = l < n_extra ? parents[l] : nullptr; }
+    for (int l = 0; l < n_extra; ++l) if (!P.ukeys[l] || !P.parent[l]) return sd3d_set_error(SD3D_ERR_ARG, "unique_levels: null output");
+    const int64_t tot = n_cap * n_extra;
+    const size_t a = align_up((size_t)tot * sizeof(int), 256);
+    int* flags = (int*)ws;
+    int* excl = (int*)((char*)ws + a);
+    int* total = (int*)((char*)ws + 2 * a);
+    void* sws = (char*)ws + 2 * a + 256;
+    const dim3 grid((unsigned)cdiv(n_cap, 256), (unsigned)n_extra);
+    hipLaunchKernelGGL(mark_levels, grid, dim3(256), 0, st, P, flags);
+    const int rc = scan_exclusive_i32(flags, excl, tot, nullptr, total, sws, ws_bytes - 2 * a - 256, st);
+    if (rc) return rc;
+    hipLaunchKernelGGL(emit_levels, grid, dim3(256), 0, st, P, (const int*)flags, (const int*)excl);
+    SD3D_CHECK_LAUNCH();
+    return SD3D_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
 // hash table (keys u64, values i32), capacity = power of two, EMPTY = all ones
 // ---------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void hash_insert(const uint64_t* __restrict__ ukeys, int64_t n,

@@ -6,6 +6,7 @@ there is deliberately no CPU path (the CPU restatement is oracle/, test infrastr
 """
 from __future__ import annotations
 
+import ctypes
 import threading
 from collections import OrderedDict as _collections_od
 from typing import Optional
@@ -340,6 +341,22 @@ def unique_sorted(keys, src_idx, n_cap, n_dev=None, shift=0, want_seg_start=Fals
                                       float(clip[1]) if clip else 0.0, int(clip[2]) if clip else 0,
                                       int(clip[3]) if clip else 0, _stream()), "unique_sorted")
     return ukeys, seg, mp, nuniq
+
+
+def unique_levels(keys0: torch.Tensor, n_cap: int, n0_dev: torch.Tensor, n_extra: int):
+    """All coarser levels from the sorted level-0 unique keys in four launches (`sd3d_unique_levels`): ([ukeys_1..], [parent_1..],
+    counts int32 [n_extra]) - what `unique_sorted(keys_l, None, n_cap, n_l, 3, want_map=True)` gives level after level (no extent clip)."""
+    lib = _lib.load()
+    dev = keys0.device
+    uk = torch.empty(n_extra, n_cap, dtype=torch.int64, device=dev)
+    par = torch.empty(n_extra, n_cap, dtype=torch.int32, device=dev)
+    counts = torch.empty(n_extra, dtype=torch.int32, device=dev)
+    ws = _WS.get(lib.sd3d_unique_levels_ws_bytes(n_cap, n_extra), dev)
+    up = (ctypes.c_void_p * n_extra)(*[uk.data_ptr() + 8 * n_cap * l for l in range(n_extra)])
+    pp = (ctypes.c_void_p * n_extra)(*[par.data_ptr() + 4 * n_cap * l for l in range(n_extra)])
+    _lib.check(lib.sd3d_unique_levels(_ptr(keys0, torch.int64, "keys0"), n_cap, _ptr(n0_dev, torch.int32, "n0"), n_extra,
+                                      ctypes.addressof(up), ctypes.addressof(pp), _ptr(counts), ws.data_ptr(), ws.numel(), _stream()), "unique_levels")
+    return [uk[l] for l in range(n_extra)], [par[l] for l in range(n_extra)], counts
 
 
 def hash_build(ukeys: torch.Tensor, n: int):

@@ -106,6 +106,9 @@ PAIR_CHAIN = os.environ.get("SD3D_PAIR_CHAIN", "1") != "0"
 FORK_JOIN = os.environ.get("SD3D_FORK_JOIN", "1") != "0"
 # SD3D_OPTIMISTIC_SORT=0: a scene's voxel keys / superpoint ids are always sorted over all their bits (7 + 4 radix passes instead of 4 + 2)
 OPTIMISTIC_SORT = os.environ.get("SD3D_OPTIMISTIC_SORT", "1") != "0"
+# SD3D_LEVELS_AT_ONCE=0: the coarser levels of a scene by one run-length unique per level (four launches each) instead of all of them
+# from the level-0 keys in four launches (`sd3d_unique_levels`; MinkowskiEngine semantics only - spconv's extent clip keeps the per-level path)
+LEVELS_AT_ONCE = os.environ.get("SD3D_LEVELS_AT_ONCE", "1") != "0"
 PAIR_CHAIN_LEVELS = tuple(int(v) for v in os.environ.get("SD3D_PAIR_CHAIN_LEVELS", "0,1,2").split(",") if v.strip() != "")
 
 
@@ -138,13 +141,18 @@ class SceneMaps:
                 skeys, self.sidx, N, None, 0, want_seg_start=True, want_map=True, map_size=N)
             keys_l, counts, parents = [ukeys], [n0], []
             cap = N
-            for lvl in range(1, n_levels):
-                clip = (self.stats, inv, lvl, clip_min_shape) if clip_min_shape > 0 else None
-                uk, _, parent, nl = ops.unique_sorted(keys_l[-1], None, cap, counts[-1], 3, want_seg_start=False, want_map=True,
-                                                      clip=clip)
-                keys_l.append(uk)
-                counts.append(nl)
-                parents.append(parent)
+            if LEVELS_AT_ONCE and clip_min_shape == 0 and 1 < n_levels <= 8:
+                uks, parents, cnt = ops.unique_levels(ukeys, cap, n0, n_levels - 1)     # every coarser level in four launches
+                keys_l += uks
+                counts.append(cnt)
+            else:
+                for lvl in range(1, n_levels):
+                    clip = (self.stats, inv, lvl, clip_min_shape) if clip_min_shape > 0 else None
+                    uk, _, parent, nl = ops.unique_sorted(keys_l[-1], None, cap, counts[-1], 3, want_seg_start=False, want_map=True,
+                                                          clip=clip)
+                    keys_l.append(uk)
+                    counts.append(nl)
+                    parents.append(parent)
             extra = [err]
             if superpoints is not None:
                 sp_keys = ops.keys_from_i64(superpoints, check=(sp_bits, err, 4) if sp_bits < 32 else None)
@@ -383,12 +391,17 @@ class BatchSceneMaps(SceneMaps):
         ukeys, self.seg_start, self.inverse, n0 = ops.unique_sorted(
             skeys, self.sidx, N, None, 0, want_seg_start=True, want_map=True, map_size=N)
         keys_l, counts, parents = [ukeys], [n0], []
-        for lvl in range(1, n_levels):
-            clip = (self.stats, inv, lvl, clip_min_shape) if clip_min_shape > 0 else None
-            uk, _, parent, nl = ops.unique_sorted(keys_l[-1], None, N, counts[-1], 3, want_seg_start=False, want_map=True, clip=clip)
-            keys_l.append(uk)
-            counts.append(nl)
-            parents.append(parent)
+        if LEVELS_AT_ONCE and clip_min_shape == 0 and 1 < n_levels <= 8:
+            uks, parents, cnt = ops.unique_levels(ukeys, N, n0, n_levels - 1)
+            keys_l += uks
+            counts.append(cnt)
+        else:
+            for lvl in range(1, n_levels):
+                clip = (self.stats, inv, lvl, clip_min_shape) if clip_min_shape > 0 else None
+                uk, _, parent, nl = ops.unique_sorted(keys_l[-1], None, N, counts[-1], 3, want_seg_start=False, want_map=True, clip=clip)
+                keys_l.append(uk)
+                counts.append(nl)
+                parents.append(parent)
         extra = [err]
         self.superpoints = superpoints
         if superpoints is not None:

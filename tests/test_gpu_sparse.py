@@ -601,3 +601,31 @@ def test_optimistic_radix_passes_fall_back_to_the_full_sort(extent_m, sp_base, r
         assert torch.equal(a.keys[l], b.keys[l])
     for l in range(4):
         assert torch.equal(a.parents[l], b.parents[l])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("batched", [False, True])
+def test_all_levels_at_once_equal_the_level_by_level_unique(batched, monkeypatch):
+    """`sparse.LEVELS_AT_ONCE` (`sd3d_unique_levels`: every coarser level from the sorted level-0 keys in four launches): the keys, the
+    parent maps and the voxel counts of the level-by-level run-length unique, bit for bit - one scene and a batch (scene bits in the keys)."""
+    from segdino3d_amd import sparse
+    from segdino3d_amd.sparse import BatchSceneMaps, SceneMaps
+    d = torch.device("cuda:0")
+    g = torch.Generator().manual_seed(11)
+    scenes = []
+    for n, ext in ((30_000, 5.0), (12_345, 3.0), (1, 1.0)):
+        pts = torch.cat([torch.rand(n, 3, generator=g) * ext, torch.rand(n, 3, generator=g)], 1).to(d)
+        scenes.append((pts, torch.randint(0, 200, (n,), generator=g).to(d)))
+    maps = {}
+    for mode in (True, False):
+        monkeypatch.setattr(sparse, "LEVELS_AT_ONCE", mode)
+        if batched:
+            maps[mode] = [BatchSceneMaps([p for p, _ in scenes], 0.02, 5, superpoints=[s for _, s in scenes])]
+        else:
+            maps[mode] = [SceneMaps(p, 0.02, 5, superpoints=s) for p, s in scenes]
+    for a, b in zip(maps[True], maps[False]):
+        assert a.n_vox == b.n_vox
+        for l in range(5):
+            assert torch.equal(a.keys[l], b.keys[l]), l
+        for l in range(4):
+            assert torch.equal(a.parents[l], b.parents[l]), l

@@ -25,6 +25,7 @@ SETTINGS = {
     "narrow row chain": dict(fork=False, narrow=True),
     "fork / join + narrow row chain": dict(fork=True, narrow=True),
     "fork / join, full radix sorts": dict(fork=True, narrow=False, optimistic=False),
+    "fork / join, one unique per level": dict(fork=True, narrow=False, levels=False),
 }
 only = os.environ.get("AB_ONLY")
 if only:
@@ -34,6 +35,7 @@ if only:
 def apply(s):
     sparse.FORK_JOIN = s["fork"]
     sparse.OPTIMISTIC_SORT = s.get("optimistic", True)
+    sparse.LEVELS_AT_ONCE = s.get("levels", True)
     decoder.FUSED_NARROW = s["narrow"]
 
 
