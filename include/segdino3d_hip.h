@@ -47,6 +47,11 @@ size_t sd3d_sort_ws_bytes(int64_t n);
 int sd3d_sort_pairs_u64(uint64_t* keys_in, uint32_t* vals_in, uint64_t* keys_out, uint32_t* vals_out,
                         uint32_t* vals_scratch, int64_t n, int begin_bit, int end_bit, void* ws, size_t ws_bytes,
                         void* stream);
+/* The same without the padding pass: the radix passes ping-pong between (keys_in, vals_in | vals_scratch) and (keys_out, vals_out); an
+ * EVEN number of 8-bit passes leaves the result in the former and sets *landed_in_input = 1 (sd3d_sort_pairs_u64 adds a pass over zero
+ * bits instead, so that its result is always in *_out). */
+int sd3d_sort_pairs_u64_ex(uint64_t* keys_in, uint32_t* vals_in, uint64_t* keys_out, uint32_t* vals_out, uint32_t* vals_scratch,
+                           int64_t n, int begin_bit, int end_bit, void* ws, size_t ws_bytes, int* landed_in_input, void* stream);
 size_t sd3d_scan_ws_bytes(int64_t n);
 int sd3d_scan_exclusive_i32(const int32_t* in, int32_t* out, int64_t n, int32_t* total_dev, void* ws, size_t ws_bytes,
                             void* stream);

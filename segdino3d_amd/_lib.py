@@ -30,6 +30,7 @@ SIGNATURES = {
     "sd3d_selftest_host": (_i, []),
     "sd3d_sort_ws_bytes": (_z, [_l]),
     "sd3d_sort_pairs_u64": (_i, [_p, _p, _p, _p, _p, _l, _i, _i, _p, _z, _p]),
+    "sd3d_sort_pairs_u64_ex": (_i, [_p, _p, _p, _p, _p, _l, _i, _i, _p, _z, _p, _p]),
     "sd3d_scan_ws_bytes": (_z, [_l]),
     "sd3d_scan_exclusive_i32": (_i, [_p, _p, _l, _p, _p, _z, _p]),
     "sd3d_keys_from_f32": (_i, [_p, _l, _i, _p, _p]),

@@ -13,7 +13,7 @@ int sd3d_set_error(int code, const char* msg) {
 
 // ---- internal launchers (defined in the other translation units)
 size_t sort_ws_bytes(int64_t n);
-int sort_pairs_u64(uint64_t*, uint32_t*, uint64_t*, uint32_t*, int64_t, int, int, void*, size_t, hipStream_t, uint32_t*);
+int sort_pairs_u64(uint64_t*, uint32_t*, uint64_t*, uint32_t*, int64_t, int, int, void*, size_t, hipStream_t, uint32_t*, int*);
 size_t scan_ws_bytes(int64_t n);
 int scan_exclusive_i32(const int*, int*, int64_t, const int*, int*, void*, size_t, hipStream_t);
 int launch_f32_to_sortkey(const float*, int64_t, int, uint64_t*, hipStream_t);
@@ -132,7 +132,12 @@ size_t sd3d_sort_ws_bytes(int64_t n) { return sort_ws_bytes(n); }
 int sd3d_sort_pairs_u64(uint64_t* keys_in, uint32_t* vals_in, uint64_t* keys_out, uint32_t* vals_out, uint32_t* vals_scratch,
                         int64_t n, int begin_bit, int end_bit, void* ws, size_t ws_bytes, void* stream) {
     if (n < 0 || begin_bit < 0 || end_bit > 64 || end_bit <= begin_bit) return sd3d_set_error(SD3D_ERR_ARG, "sort: bad arguments");
-    return sort_pairs_u64(keys_in, vals_in, keys_out, vals_out, n, begin_bit, end_bit, ws, ws_bytes, ST, vals_scratch);
+    return sort_pairs_u64(keys_in, vals_in, keys_out, vals_out, n, begin_bit, end_bit, ws, ws_bytes, ST, vals_scratch, nullptr);
+}
+int sd3d_sort_pairs_u64_ex(uint64_t* keys_in, uint32_t* vals_in, uint64_t* keys_out, uint32_t* vals_out, uint32_t* vals_scratch,
+                           int64_t n, int begin_bit, int end_bit, void* ws, size_t ws_bytes, int* landed_in_input, void* stream) {
+    if (n < 0 || begin_bit < 0 || end_bit > 64 || end_bit <= begin_bit || !landed_in_input) return sd3d_set_error(SD3D_ERR_ARG, "sort: bad arguments");
+    return sort_pairs_u64(keys_in, vals_in, keys_out, vals_out, n, begin_bit, end_bit, ws, ws_bytes, ST, vals_scratch, landed_in_input);
 }
 size_t sd3d_scan_ws_bytes(int64_t n) { return scan_ws_bytes(n > 0 ? n : 1); }
 int sd3d_scan_exclusive_i32(const int32_t* in, int32_t* out, int64_t n, int32_t* total_dev, void* ws, size_t ws_bytes, void* stream) {

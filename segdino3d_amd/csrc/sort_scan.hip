@@ -294,8 +294,11 @@ size_t sort_ws_bytes(int64_t n) {
 
 // Sorts by bits [begin_bit, end_bit).  keys_in/vals_in are clobbered (ping-pong); the result is in
 // keys_out/vals_out.  vals_in == NULL means "value = original index".
+// landed_in_input != NULL: no padding pass - with an even pass count the result is left in (keys_in, vals_in | vals_scratch) and
+// *landed_in_input = 1 (the caller swaps its buffer roles); NULL: an odd pass count is forced so that the result is always in *_out.
 int sort_pairs_u64(uint64_t* keys_in, uint32_t* vals_in, uint64_t* keys_out, uint32_t* vals_out, int64_t n,
-                   int begin_bit, int end_bit, void* ws, size_t ws_bytes, hipStream_t st, uint32_t* vals_scratch) {
+                   int begin_bit, int end_bit, void* ws, size_t ws_bytes, hipStream_t st, uint32_t* vals_scratch, int* landed_in_input) {
+    if (landed_in_input) *landed_in_input = 0;
     if (n <= 0) return SD3D_OK;
     if (ws_bytes < sort_ws_bytes(n)) return sd3d_set_error(SD3D_ERR_WS, "sort workspace too small");
     if (n <= RANK_SORT_MAX) {
@@ -307,7 +310,10 @@ int sort_pairs_u64(uint64_t* keys_in, uint32_t* vals_in, uint64_t* keys_out, uin
     }
     int passes = (end_bit - begin_bit + 7) / 8;
     if (passes < 1) passes = 1;
-    if ((passes & 1) == 0) ++passes;          // odd => result lands in *_out after ping-pong
+    if ((passes & 1) == 0) {
+        if (landed_in_input && (vals_in || vals_scratch)) *landed_in_input = 1;
+        else ++passes;                        // odd => result lands in *_out after ping-pong (a padding pass over zero bits: a full pass of time)
+    }
     const int nb = (int)cdiv(n, RS_TILE);
     int* hist = (int*)ws;
     // ping-pong: even passes read A (=*_in) and write B (=*_out), odd passes the other way round;

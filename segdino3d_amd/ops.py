@@ -244,7 +244,8 @@ _WS7 = _PerThread()       # slab_conv: per-workgroup rulebook scratch (+ partial
 # --------------------------------------------------------------------------------------------
 def sort_pairs(keys: torch.Tensor, vals: Optional[torch.Tensor] = None, begin_bit=0, end_bit=64):
     """Stable ascending sort of uint64-as-int64 keys; returns (sorted_keys, sorted_vals[int32]).
-    `keys` (int64 storage of u64 bit patterns) is clobbered."""
+    `keys` (int64 storage of u64 bit patterns) and `vals` are clobbered.  No padding pass: after an even number of 8-bit radix passes
+    the result sits in the input / scratch buffers and those are what is returned (`sd3d_sort_pairs_u64_ex`)."""
     lib = _lib.load()
     n = keys.numel()
     dev = keys.device
@@ -252,9 +253,12 @@ def sort_pairs(keys: torch.Tensor, vals: Optional[torch.Tensor] = None, begin_bi
     vals_out = torch.empty(n, dtype=torch.int32, device=dev)
     scratch = torch.empty(n, dtype=torch.int32, device=dev) if vals is None else None
     ws = _WS.get(lib.sd3d_sort_ws_bytes(n), dev)
-    _lib.check(lib.sd3d_sort_pairs_u64(_ptr(keys, torch.int64, "keys"), _ptr(vals, torch.int32, "vals"),
-                                       _ptr(keys_out), _ptr(vals_out), _ptr(scratch), n, begin_bit, end_bit,
-                                       ws.data_ptr(), ws.numel(), _stream()), "sort_pairs")
+    landed = ctypes.c_int(0)
+    _lib.check(lib.sd3d_sort_pairs_u64_ex(_ptr(keys, torch.int64, "keys"), _ptr(vals, torch.int32, "vals"),
+                                          _ptr(keys_out), _ptr(vals_out), _ptr(scratch), n, begin_bit, end_bit,
+                                          ws.data_ptr(), ws.numel(), ctypes.addressof(landed), _stream()), "sort_pairs")
+    if landed.value:
+        return keys, (vals if vals is not None else scratch)
     return keys_out, vals_out
 
 
