@@ -474,6 +474,14 @@ size_t sd3d_expand_masks_ws_bytes(int n, int ld_sig);
 int sd3d_expand_masks(const float* sig, int ld_sig, const uint32_t* src_row, int n, const int64_t* superpoints,
                       const float* points, int ld_points, int64_t N, float sp_thr, const float* boxes, float loose_ratio,
                       uint8_t* out, int32_t* count, void* ws, size_t ws_bytes, void* stream);
+/* The same in two steps, for callers that apply the score / point-count thresholds BEFORE expanding (count[] comes from step 1):
+ * sd3d_mask_rowbits thresholds the rows into the bit table in `ws` (sd3d_expand_masks_ws_bytes) and makes count[n];
+ * sd3d_expand_rows writes out[j] = row rows[j] for a list of m rows from the SAME ws (boxes [n, 6] indexed by the row number, or NULL):
+ * the [n, N] byte table of sd3d_expand_masks (90 MB at 600 x 150 k) is never made, only the kept rows. */
+int sd3d_mask_rowbits(const float* sig, int ld_sig, const uint32_t* src_row, int n, const int64_t* superpoints, int64_t N, float sp_thr,
+                      int32_t* count, void* ws, size_t ws_bytes, void* stream);
+int sd3d_expand_rows(const void* ws, int n, int ld_sig, const int32_t* rows, int m, const int64_t* superpoints, const float* points,
+                     int ld_points, int64_t N, const float* boxes, float loose_ratio, uint8_t* out, void* stream);
 /* Bit-packed copy of selected rows of the [n, N] byte masks of sd3d_expand_masks, for the device -> host copy of
  * `pts_instance_mask[0]` (baseline3d.py:453-454; evaluator_3d.py:178 reads it on the host): out [n_rows, nb = ceil(N/8)] bytes,
  * bit j of byte b = masks[rows[i]][8 b + j] != 0 (numpy bitorder "little"); rows NULL = rows 0..n_rows-1. */

@@ -98,6 +98,8 @@ SIGNATURES = {
     "sd3d_pack_mask_rows": (_i, [_p, _l, _p, _i, _p, _l, _p]),
     "sd3d_unpack_bits_host": (_i, [_p, _l, _l, _l, _p]),
     "sd3d_expand_masks_ws_bytes": (_z, [_i, _i]),
+    "sd3d_mask_rowbits": (_i, [_p, _i, _p, _i, _p, _l, _f, _p, _p, _z, _p]),
+    "sd3d_expand_rows": (_i, [_p, _i, _i, _p, _i, _p, _p, _i, _l, _p, _f, _p, _p]),
     "sd3d_expand_masks": (_i, [_p, _i, _p, _i, _p, _p, _i, _l, _f, _p, _f, _p, _p, _p, _z, _p]),
     "sd3d_row_argmax": (_i, [_p, _i, _l, _p, _i, _p, _p]),
     "sd3d_gather_i64": (_i, [_p, _p, _l, _i, _p, _p]),

@@ -269,15 +269,18 @@ class Baseline3D(nn.Module):
             if have_boxes:
                 q_rec = qidx.long()[record]
                 boxes = torch.cat([centers[q_rec], sizes[q_rec]], dim=-1).contiguous()
-        masks_u8, count = ops.expand_masks(sig, src_row, superpoints.contiguous(), pts, float(_cfg_get(cfg, "sp_score_thr")),
-                                           boxes if self.filter_outofbox_points_eval else None)
-        return dict(scores=final_scores, labels=final_labels, masks=masks_u8, count=count, boxes=boxes, topk_idx=qidx.long())
+        # the thresholded rows as a bit table + the point count of every candidate; the [n, N] masks are expanded in `_predict_finish`,
+        # for the rows that survive the thresholds only (`ops.MaskBits`: the whole [600, N] byte table was 90 MB written per scene)
+        bits = ops.MaskBits(sig, src_row, superpoints.contiguous(), pts, float(_cfg_get(cfg, "sp_score_thr")),
+                            boxes if self.filter_outofbox_points_eval else None)
+        return dict(scores=final_scores, labels=final_labels, bits=bits, count=bits.count, boxes=boxes, topk_idx=qidx.long(), n_points=pts.shape[0])
 
     def _select(self, common, thresholds):
         """The data-dependent selections of predict_by_feat_instance (:470-476) for several score thresholds from ONE host read:
         the k scores and point counts travel to the host (a few KB, polled), the row lists are made there and go back in one copy.
         (Boolean indexing on the device costs a synchronising nonzero per selection - three per scene before.)
-        Returns [(keep int32 rows, score_mask bool[k], npoint_mask bool[n_scored])] per threshold, tensors on the device."""
+        Returns ([(keep int32 rows, score_mask bool[k], npoint_mask bool[n_scored])] per threshold, (union rows int32, [positions of each
+        selection in the union], [selection == union])), tensors on the device."""
         return self._select_finish(common, thresholds, self._select_begin(common))
 
     def _select_begin(self, common):
@@ -291,14 +294,22 @@ class Baseline3D(nn.Module):
         host = read.wait().numpy()
         s, c = host[:k], host[k:].view(np.int32)
         npoint_all = c > int(_cfg_get(cfg, "npoint_thr"))
-        parts, lay = [], []
+        parts, lay, keeps = [], [], []
         for thr in thresholds:
             score_mask = s > np.float32(thr)
             keep = np.flatnonzero(score_mask & npoint_all).astype(np.int32)
+            keeps.append(keep)
             npoint_mask = npoint_all[score_mask]
             pad = (-(k + npoint_mask.size)) % 4                        # keeps the next int32 block aligned
             parts += [keep.view(np.uint8), score_mask.view(np.uint8), npoint_mask.view(np.uint8), np.zeros(pad, np.uint8)]
             lay.append((keep.size, npoint_mask.size, pad))
+        # rows whose point masks are needed at all = the union of the thresholds' selections (one is a subset of the other), and where
+        # each selection's rows sit in it
+        union = keeps[0]
+        for kp in keeps[1:]:
+            union = np.union1d(union, kp).astype(np.int32)
+        where = [np.searchsorted(union, kp).astype(np.int32) for kp in keeps]
+        parts += [union.view(np.uint8)] + [w.view(np.uint8) for w in where]
         dev = torch.from_numpy(np.concatenate(parts)).to(scores.device, non_blocking=True)
         out, o = [], 0
         for n_keep, n_scored, pad in lay:
@@ -306,7 +317,12 @@ class Baseline3D(nn.Module):
             score_mask = dev[o:o + k].view(torch.bool); o += k
             npoint_mask = dev[o:o + n_scored].view(torch.bool); o += n_scored + pad
             out.append((keep, score_mask, npoint_mask))
-        return out
+        union_dev = dev[o:o + 4 * union.size].view(torch.int32); o += 4 * union.size
+        where_dev = []
+        for w in where:
+            where_dev.append(dev[o:o + 4 * w.size].view(torch.int32)); o += 4 * w.size
+        same = [w.size == union.size for w in where]                   # this selection IS the union (no gather needed)
+        return out, (union_dev, where_dev, same)
 
     @ops.bound_stream
     def predict_by_feat(self, samples, out, superpoints, b=0):
@@ -320,9 +336,12 @@ class Baseline3D(nn.Module):
         cfg = self.test_cfg
         # the data-dependent selections need the scores on the host: one polled read (no host thread sits inside a blocking HIP
         # call while other scenes are being issued)
-        (keep, score_mask, npoint_mask), (pkeep, _, _) = self._select_finish(
+        ((keep, score_mask, npoint_mask), (pkeep, _, _)), (rows, (keep_u, pkeep_u), (keep_all, _)) = self._select_finish(
             com, (float(_cfg_get(cfg, "inst_score_thr")), float(_cfg_get(cfg, "pan_score_thr"))), read)
-        inst_masks = com["masks"][keep].view(torch.bool) if not self.to_host else None      # (the host path packs the kept rows directly)
+        masks_u = com["bits"].rows(rows)                           # [rows kept by either threshold, N] bytes: the only point masks made
+        inst_masks = None
+        if not self.to_host:                                       # (the host path packs the kept rows directly)
+            inst_masks = (masks_u if keep_all else masks_u[keep_u.long()]).view(torch.bool)
         inst_labels, inst_scores = com["labels"][keep].long(), com["scores"][keep]
         inst_boxes = com["boxes"][keep] if com["boxes"] is not None else None
         # semantic (:488-507)
@@ -341,7 +360,7 @@ class Baseline3D(nn.Module):
         if pkeep.numel() == 0:
             pan_sem, pan_inst = sem_stuff, sem_stuff
         else:
-            pan_sem, pan_inst = ops.panoptic(com["masks"], pkeep.contiguous(), com["labels"][pkeep].int().contiguous(),
+            pan_sem, pan_inst = ops.panoptic(masks_u, pkeep_u.contiguous(), com["labels"][pkeep].int().contiguous(),
                                              len(stuff), int(_cfg_get(cfg, "npoint_thr")), sem_stuff)
         sort_and_mask = (com["topk_idx"], score_mask, npoint_mask)
         if not self.to_host:
@@ -354,10 +373,10 @@ class Baseline3D(nn.Module):
         # polled wait, and the caller receives pageable arrays (nothing page-locked outlives the forward).  `to_host=True`: the masks are
         # expanded to the [n, N] bool array the reference's evaluator reads (evaluator_3d.py:178) by the C library with the GIL
         # released; `to_host="packed"`: they stay packed (`PackedMasks`: 8 x fewer host bytes, `np.asarray()` / `.unpack()` on demand).
-        packed = ops.pack_mask_rows(com["masks"], keep.contiguous())
+        packed = ops.pack_mask_rows(masks_u, keep_u.contiguous())
         dev = [sem_res, pan_sem, packed, pan_inst, inst_labels, inst_scores] + ([inst_boxes] if inst_boxes is not None else [])
         arr = ops.to_host_arrays(dev)
-        N = com["masks"].shape[1]
+        N = com["n_points"]
         masks_host = PackedMasks(arr[2], N) if self.to_host == "packed" else ops.unpack_bits_host(arr[2], N)
         return [PointData(
             pts_semantic_mask=[arr[0], arr[1]], pts_instance_mask=[masks_host, arr[3]], instance_labels=arr[4], instance_scores=arr[5],

@@ -94,6 +94,8 @@ int launch_nms_finish(const uint32_t*, const float*, const int32_t*, const uint3
 int launch_gather_sigmoid(const float*, int, int, const int32_t*, const uint32_t*, int, float*, int, float*, hipStream_t);
 int launch_nms_decay(const float*, int, const float*, const int32_t*, int, int, float, const float*, float*, float*, hipStream_t);
 size_t expand_masks_ws_bytes(int n, int ld_sig);
+int launch_mask_rowbits(const float*, int, const uint32_t*, int, const int64_t*, int64_t, float, int32_t*, void*, size_t, hipStream_t);
+int launch_expand_rows(const void*, int, int, const int32_t*, int, const int64_t*, const float*, int, int64_t, const float*, float, uint8_t*, hipStream_t);
 int launch_mask_overlaps(const uint8_t*, int64_t, int, const int32_t*, int64_t, int, int32_t*, hipStream_t);
 int launch_expand_masks(const float*, int, const uint32_t*, int, const int64_t*, const float*, int, int64_t, float, const float*, float, uint8_t*, int32_t*, void*, size_t, hipStream_t);
 int launch_row_argmax(const float*, int, int64_t, const int32_t*, int, int64_t*, hipStream_t);
@@ -437,6 +439,14 @@ int sd3d_nms_decay(const float* inter, int ld, const float* area, const int32_t*
     return launch_nms_decay(inter, ld, area, labels, n, gaussian, sigma, score_in, comp_ws, score_out, ST);
 }
 size_t sd3d_expand_masks_ws_bytes(int n, int ld_sig) { return expand_masks_ws_bytes(n, ld_sig); }
+int sd3d_mask_rowbits(const float* sig, int ld_sig, const uint32_t* src_row, int n, const int64_t* superpoints, int64_t N, float sp_thr,
+                      int32_t* count, void* ws, size_t ws_bytes, void* stream) {
+    return launch_mask_rowbits(sig, ld_sig, src_row, n, superpoints, N, sp_thr, count, ws, ws_bytes, ST);
+}
+int sd3d_expand_rows(const void* ws, int n, int ld_sig, const int32_t* rows, int m, const int64_t* superpoints, const float* points, int ld_points,
+                     int64_t N, const float* boxes, float loose_ratio, uint8_t* out, void* stream) {
+    return launch_expand_rows(ws, n, ld_sig, rows, m, superpoints, points, ld_points, N, boxes, loose_ratio, out, ST);
+}
 int sd3d_expand_masks(const float* sig, int ld_sig, const uint32_t* src_row, int n, const int64_t* superpoints, const float* points,
                       int ld_points, int64_t N, float sp_thr, const float* boxes, float loose_ratio, uint8_t* out, int32_t* count,
                       void* ws, size_t ws_bytes, void* stream) {

@@ -246,6 +246,68 @@ __global__ __launch_bounds__(256) void em_expand_kernel(const uint32_t* __restri
     }
 }
 
+// The same expansion for a LIST of rows (the instances that survive the score / point-count thresholds: 100 - 250 of the 600 candidates):
+// out[j][p] = row rows[j] of the bit table at point p (and inside its box).  The thresholds only need count[], which em_rowbits_kernel
+// makes at superpoint granularity - so the [600, N] byte table (90 MB written, then 20 - 40 MB of it gathered) never has to exist.
+// A thread owns 4 consecutive points and 32 listed rows; a row's word is re-read only when it differs from the previous row's.
+__global__ __launch_bounds__(256) void em_expand_rows_kernel(const uint32_t* __restrict__ bits, int W, int S, const int32_t* __restrict__ rows, int m,
+                                                             const int64_t* __restrict__ superpoints, const float* __restrict__ pts, int ld_pts,
+                                                             int64_t N, const float* __restrict__ boxes, float loose, uint8_t* __restrict__ out) {
+    const int j0 = blockIdx.y * 32;
+    const int64_t p0 = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 4;
+    const bool vec = ((N & 3) == 0);
+    const int np = p0 < N ? (int)min((int64_t)4, N - p0) : 0;
+    if (np == 0) return;
+    int64_t sp[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const int64_t v = e < np ? superpoints[p0 + e] : -1;
+        sp[e] = (v >= 0 && v < S) ? v : -1;
+    }
+    float xyz[4][3] = {{0, 0, 0}, {0, 0, 0}, {0, 0, 0}, {0, 0, 0}};
+    if (boxes) {
+        for (int e = 0; e < np; ++e)
+#pragma unroll
+            for (int a = 0; a < 3; ++a) xyz[e][a] = pts[(p0 + e) * ld_pts + a];
+    }
+    int cur_w = -1;
+    uint32_t w[4] = {0, 0, 0, 0};
+    for (int jj = 0; jj < 32; ++jj) {
+        const int j = j0 + jj;
+        if (j >= m) break;                                    // uniform per block
+        const int r = rows[j];
+        const int wi = r >> 5, rr = r & 31;
+        if (wi != cur_w) {
+            cur_w = wi;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) w[e] = sp[e] >= 0 ? bits[sp[e] * W + wi] : 0u;
+        }
+        uint8_t res[4] = {0, 0, 0, 0};
+        if (((w[0] | w[1] | w[2] | w[3]) >> rr) & 1u) {
+            float lo[3] = {0, 0, 0}, hi[3] = {0, 0, 0};
+            if (boxes) {
+#pragma unroll
+                for (int a = 0; a < 3; ++a) {
+                    const float c = boxes[r * 6 + a], sz = boxes[r * 6 + 3 + a] * (1.f + loose);
+                    lo[a] = c - sz / 2.f;
+                    hi[a] = c + sz / 2.f;
+                }
+            }
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                bool b = (w[e] >> rr) & 1u;
+                if (b && boxes) {
+#pragma unroll
+                    for (int a = 0; a < 3; ++a) b &= (xyz[e][a] >= lo[a]) & (xyz[e][a] <= hi[a]);
+                }
+                res[e] = b;
+            }
+        }
+        if (np == 4 && vec) *(uchar4*)(out + (int64_t)j * N + p0) = make_uchar4(res[0], res[1], res[2], res[3]);
+        else for (int e = 0; e < np; ++e) out[(int64_t)j * N + p0 + e] = res[e];
+    }
+}
+
 // Bit-packed copy of selected rows of the [n, N] byte masks for the host (baseline3d.py:453-454 hands the evaluator an [n, N] bool
 // array: 90 MB per scene over PCIe as bytes, 11 MB as bits): out[i][b] bit j = masks[rows[i]][8 b + j] != 0 (little-endian bit
 // order, numpy's `unpackbits(bitorder="little")`); bits past N are 0.  A thread makes one output byte from 8 consecutive mask
@@ -369,9 +431,10 @@ int launch_nms_decay(const float* inter, int ld, const float* area, const int32_
     return SD3D_OK;
 }
 size_t expand_masks_ws_bytes(int n, int ld_sig) { return (size_t)ld_sig * ((n + 31) / 32 + 1) * sizeof(uint32_t) + 256; }
-int launch_expand_masks(const float* sig, int ld_sig, const uint32_t* src, int n, const int64_t* superpoints, const float* pts,
-                        int ld_pts, int64_t N, float sp_thr, const float* boxes, float loose, uint8_t* out, int32_t* count,
-                        void* ws, size_t ws_bytes, hipStream_t st) {
+// bits [ld_sig][W] words + npts [ld_sig] ints live in `ws` (expand_masks_ws_bytes): phase 1 of expand_masks, and all of it when the
+// caller expands a list of rows later (launch_expand_rows on the same ws)
+int launch_mask_rowbits(const float* sig, int ld_sig, const uint32_t* src, int n, const int64_t* superpoints, int64_t N, float sp_thr,
+                        int32_t* count, void* ws, size_t ws_bytes, hipStream_t st) {
     if (n <= 0 || N <= 0) return SD3D_OK;
     if (ws_bytes < expand_masks_ws_bytes(n, ld_sig)) return sd3d_set_error(SD3D_ERR_ARG, "expand_masks: workspace too small");
     const int W = (n + 31) / 32, S = ld_sig;
@@ -382,7 +445,27 @@ int launch_expand_masks(const float* sig, int ld_sig, const uint32_t* src, int n
     hipLaunchKernelGGL(em_hist_kernel, dim3((unsigned)cdiv(N, 256)), dim3(256), 0, st, superpoints, N, S, npts);
     hipLaunchKernelGGL(em_rowbits_kernel, dim3((unsigned)cdiv(S, 256), (unsigned)W), dim3(256), 0, st, sig, ld_sig, src, n, S, sp_thr,
                        npts, bits, W, count);
-    hipLaunchKernelGGL(em_expand_kernel, dim3((unsigned)cdiv(N, 1024), (unsigned)cdiv(W, EM_WORDS)), dim3(256), 0, st, bits, W, n, S,
+    SD3D_CHECK_LAUNCH();
+    return SD3D_OK;
+}
+int launch_expand_rows(const void* ws, int n, int ld_sig, const int32_t* rows, int m, const int64_t* superpoints, const float* pts, int ld_pts,
+                       int64_t N, const float* boxes, float loose, uint8_t* out, hipStream_t st) {
+    if (m <= 0 || N <= 0) return SD3D_OK;
+    if (!ws || !rows || !out || n <= 0) return sd3d_set_error(SD3D_ERR_ARG, "expand_rows: null pointer");
+    const int W = (n + 31) / 32;
+    hipLaunchKernelGGL(em_expand_rows_kernel, dim3((unsigned)cdiv(N, 1024), (unsigned)cdiv(m, 32)), dim3(256), 0, st, (const uint32_t*)ws, W, ld_sig,
+                       rows, m, superpoints, pts, ld_pts, N, boxes, loose, out);
+    SD3D_CHECK_LAUNCH();
+    return SD3D_OK;
+}
+int launch_expand_masks(const float* sig, int ld_sig, const uint32_t* src, int n, const int64_t* superpoints, const float* pts,
+                        int ld_pts, int64_t N, float sp_thr, const float* boxes, float loose, uint8_t* out, int32_t* count,
+                        void* ws, size_t ws_bytes, hipStream_t st) {
+    if (n <= 0 || N <= 0) return SD3D_OK;
+    const int rc = launch_mask_rowbits(sig, ld_sig, src, n, superpoints, N, sp_thr, count, ws, ws_bytes, st);
+    if (rc) return rc;
+    const int W = (n + 31) / 32, S = ld_sig;
+    hipLaunchKernelGGL(em_expand_kernel, dim3((unsigned)cdiv(N, 1024), (unsigned)cdiv(W, EM_WORDS)), dim3(256), 0, st, (const uint32_t*)ws, W, n, S,
                        superpoints, pts, ld_pts, N, boxes, loose, out);
     SD3D_CHECK_LAUNCH();
     return SD3D_OK;

@@ -1316,6 +1316,33 @@ def nms_decay(inter, area, labels, score_in, kernel="linear", sigma=2.0):
     return out
 
 
+class MaskBits:
+    """Step 1 of the point-mask expansion (`sd3d_mask_rowbits`): the thresholded rows as a bit table over the superpoints + the point
+    count of every row.  `rows(list)` expands a list of rows to [m, N] bytes (`sd3d_expand_rows`): only the instances that survive."""
+
+    def __init__(self, sig, src_row, superpoints, points, sp_thr, boxes=None, loose_ratio=1.5):
+        lib = _lib.load()
+        ps, lds = _rows(sig, "sig")
+        self.n, self.N, self.lds = src_row.numel(), superpoints.numel(), lds
+        self.superpoints, self.points, self.boxes, self.loose = superpoints, points, boxes, float(loose_ratio)
+        self.count = torch.empty(self.n, dtype=torch.int32, device=sig.device)
+        # (a tensor of its own, not the per-stream workspace: the table must survive until the rows are expanded, after the host read)
+        self.ws = torch.empty(lib.sd3d_expand_masks_ws_bytes(self.n, lds), dtype=torch.uint8, device=sig.device)
+        _lib.check(lib.sd3d_mask_rowbits(ps, lds, _ptr(src_row, torch.int32, "src_row"), self.n, _ptr(superpoints, torch.int64, "superpoints"),
+                                         self.N, float(sp_thr), _ptr(self.count), self.ws.data_ptr(), self.ws.numel(), _stream()), "mask_rowbits")
+
+    def rows(self, rows):
+        lib = _lib.load()
+        m = rows.numel()
+        out = torch.empty(m, self.N, dtype=torch.uint8, device=self.ws.device)
+        if m:
+            pp, ldp = _rows(self.points, "points")
+            _lib.check(lib.sd3d_expand_rows(self.ws.data_ptr(), self.n, self.lds, _ptr(rows, torch.int32, "rows"), m,
+                                            _ptr(self.superpoints, torch.int64, "superpoints"), pp, ldp, self.N,
+                                            _ptr(self.boxes, torch.float32, "boxes"), self.loose, _ptr(out), _stream()), "expand_rows")
+        return out
+
+
 def expand_masks(sig, src_row, superpoints, points, sp_thr, boxes=None, loose_ratio=1.5):
     lib = _lib.load()
     ps, lds = _rows(sig, "sig")
