@@ -456,6 +456,16 @@ int sd3d_mask_scores(const float* masks, int ld, int S, const uint32_t* flat_idx
  *   nms_finish: final_scores = scores2[order2], final_labels = labels1[order2], record = order1[order2] (int64, :133-139) and, boxes != NULL,
  *   boxes[i] = [centers | sizes][qidx[record[i]]] ([n, 6], baseline3d.py:447-452; centers / sizes [Q, 3] contiguous). */
 int sd3d_take_f32(const float* src, const uint32_t* idx, int n, float* out, void* stream);
+/* The data-dependent selections of predict_by_feat_instance (:470-476) for two score thresholds on the device (all outputs sized k):
+ * keep / pkeep = rows with score > thr0 / thr1 and count > npoint_thr, ascending; union_rows = rows in either; keep_u / pkeep_u = where
+ * the rows of keep / pkeep sit in union_rows; score_mask[i] = score[i] > thr0; npoint_mask = (count > npoint_thr) compacted over the
+ * rows with score > thr0; counts[4] = {|keep|, |pkeep|, |union|, |score > thr0|} - the only thing the host has to read. */
+int sd3d_select_instances(const float* scores, const int32_t* count, int k, float thr0, float thr1, int npoint_thr, int32_t* keep,
+                          int32_t* pkeep, int32_t* union_rows, int32_t* keep_u, int32_t* pkeep_u, uint8_t* score_mask, uint8_t* npoint_mask,
+                          int32_t* counts, void* stream);
+/* labels_out (int64) / scores_out / boxes_out ([m, 6] or NULL) = rows keep[0..m) of labels / scores / boxes (baseline3d.py:470-476). */
+int sd3d_take_instances(const int32_t* keep, int m, const int32_t* labels, const float* scores, const float* boxes, int64_t* labels_out,
+                        float* scores_out, float* boxes_out, void* stream);
 int sd3d_take_pair(const uint32_t* order, const int32_t* labels, const float* scores, int n, int32_t* labels_out, float* scores_out,
                    void* stream);
 int sd3d_nms_finish(const uint32_t* order2, const float* scores2, const int32_t* labels1, const uint32_t* order1, const int32_t* qidx,

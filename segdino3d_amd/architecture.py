@@ -275,54 +275,30 @@ class Baseline3D(nn.Module):
                             boxes if self.filter_outofbox_points_eval else None)
         return dict(scores=final_scores, labels=final_labels, bits=bits, count=bits.count, boxes=boxes, topk_idx=qidx.long(), n_points=pts.shape[0])
 
-    def _select(self, common, thresholds):
-        """The data-dependent selections of predict_by_feat_instance (:470-476) for several score thresholds from ONE host read:
-        the k scores and point counts travel to the host (a few KB, polled), the row lists are made there and go back in one copy.
-        (Boolean indexing on the device costs a synchronising nonzero per selection - three per scene before.)
-        Returns ([(keep int32 rows, score_mask bool[k], npoint_mask bool[n_scored])] per threshold, (union rows int32, [positions of each
-        selection in the union], [selection == union])), tensors on the device."""
+    def _select(self, common, thresholds=None):
+        """The data-dependent selections of predict_by_feat_instance (:470-476) for the instance and the panoptic score threshold: made on
+        the device (`sd3d_select_instances`); the host reads four counts to size the outputs.  (Before: the k scores and point counts went
+        to the host, numpy built the row lists and one copy brought them back - with the GPU idle in between; boolean indexing on the
+        device would cost a synchronising nonzero per selection.)
+        Returns ([(keep int32 rows, score_mask bool[k], npoint_mask bool[n_scored]), (pkeep, None, None)], (union rows int32,
+        [positions of keep / pkeep in the union], [keep == union, pkeep == union])), tensors on the device."""
         return self._select_finish(common, thresholds, self._select_begin(common))
 
     def _select_begin(self, common):
-        """Start the host read of the k scores and point counts (asynchronous copy + event on the current stream)."""
-        return ops.HostRead(torch.cat([common["scores"], common["count"].view(torch.float32)]))
-
-    def _select_finish(self, common, thresholds, read):
+        """Launch the selection and start the host read of its four counts (asynchronous copy + event on the current stream)."""
         cfg = self.test_cfg
-        scores = common["scores"]
-        k = scores.shape[0]
-        host = read.wait().numpy()
-        s, c = host[:k], host[k:].view(np.int32)
-        npoint_all = c > int(_cfg_get(cfg, "npoint_thr"))
-        parts, lay, keeps = [], [], []
-        for thr in thresholds:
-            score_mask = s > np.float32(thr)
-            keep = np.flatnonzero(score_mask & npoint_all).astype(np.int32)
-            keeps.append(keep)
-            npoint_mask = npoint_all[score_mask]
-            pad = (-(k + npoint_mask.size)) % 4                        # keeps the next int32 block aligned
-            parts += [keep.view(np.uint8), score_mask.view(np.uint8), npoint_mask.view(np.uint8), np.zeros(pad, np.uint8)]
-            lay.append((keep.size, npoint_mask.size, pad))
-        # rows whose point masks are needed at all = the union of the thresholds' selections (one is a subset of the other), and where
-        # each selection's rows sit in it
-        union = keeps[0]
-        for kp in keeps[1:]:
-            union = np.union1d(union, kp).astype(np.int32)
-        where = [np.searchsorted(union, kp).astype(np.int32) for kp in keeps]
-        parts += [union.view(np.uint8)] + [w.view(np.uint8) for w in where]
-        dev = torch.from_numpy(np.concatenate(parts)).to(scores.device, non_blocking=True)
-        out, o = [], 0
-        for n_keep, n_scored, pad in lay:
-            keep = dev[o:o + 4 * n_keep].view(torch.int32); o += 4 * n_keep
-            score_mask = dev[o:o + k].view(torch.bool); o += k
-            npoint_mask = dev[o:o + n_scored].view(torch.bool); o += n_scored + pad
-            out.append((keep, score_mask, npoint_mask))
-        union_dev = dev[o:o + 4 * union.size].view(torch.int32); o += 4 * union.size
-        where_dev = []
-        for w in where:
-            where_dev.append(dev[o:o + 4 * w.size].view(torch.int32)); o += 4 * w.size
-        same = [w.size == union.size for w in where]                   # this selection IS the union (no gather needed)
-        return out, (union_dev, where_dev, same)
+        bufs, counts = ops.select_instances(common["scores"], common["count"], float(_cfg_get(cfg, "inst_score_thr")),
+                                            float(_cfg_get(cfg, "pan_score_thr")), int(_cfg_get(cfg, "npoint_thr")))
+        return ops.HostRead(counts), bufs
+
+    def _select_finish(self, common, thresholds, pending):
+        read, (ints, bytes_) = pending
+        n_keep, n_pkeep, n_union, n_scored = (int(v) for v in read.wait().tolist())
+        k = common["scores"].shape[0]
+        keep, pkeep, union = ints[0, :n_keep], ints[1, :n_pkeep], ints[2, :n_union]
+        keep_u, pkeep_u = ints[3, :n_keep], ints[4, :n_pkeep]
+        score_mask, npoint_mask = bytes_[0, :k].view(torch.bool), bytes_[1, :n_scored].view(torch.bool)
+        return [(keep, score_mask, npoint_mask), (pkeep, None, None)], (union, [keep_u, pkeep_u], [n_keep == n_union, n_pkeep == n_union])
 
     @ops.bound_stream
     def predict_by_feat(self, samples, out, superpoints, b=0):
@@ -342,8 +318,7 @@ class Baseline3D(nn.Module):
         inst_masks = None
         if not self.to_host:                                       # (the host path packs the kept rows directly)
             inst_masks = (masks_u if keep_all else masks_u[keep_u.long()]).view(torch.bool)
-        inst_labels, inst_scores = com["labels"][keep].long(), com["scores"][keep]
-        inst_boxes = com["boxes"][keep] if com["boxes"] is not None else None
+        inst_labels, inst_scores, inst_boxes = ops.take_instances(keep.contiguous(), com["labels"], com["scores"], com["boxes"])
         # semantic (:488-507)
         sem = out["sem_preds"][b]
         n_sem = sem.shape[1] - 1

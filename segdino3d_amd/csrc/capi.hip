@@ -88,6 +88,9 @@ int launch_box_refine(const float*, const float*, const float*, int, const float
 int launch_class_scores(const float*, int, int64_t, int, float*, float*, hipStream_t);
 int launch_mask_scores(const float*, int, int, const uint32_t*, const float*, int, int, int, int32_t*, int32_t*, float*, hipStream_t);
 int launch_take_f32(const float*, const uint32_t*, int, float*, hipStream_t);
+int launch_select_instances(const float*, const int32_t*, int, float, float, int, int32_t*, int32_t*, int32_t*, int32_t*, int32_t*, uint8_t*, uint8_t*,
+                            int32_t*, hipStream_t);
+int launch_take_instances(const int32_t*, int, const int32_t*, const float*, const float*, int64_t*, float*, float*, hipStream_t);
 int launch_take_pair(const uint32_t*, const int32_t*, const float*, int, int32_t*, float*, hipStream_t);
 int launch_nms_finish(const uint32_t*, const float*, const int32_t*, const uint32_t*, const int32_t*, const float*, const float*, int, float*,
                       int32_t*, int64_t*, float*, hipStream_t);
@@ -418,6 +421,15 @@ int sd3d_class_scores(const float* cls, int ld, int64_t Q, int C, float* scores,
     return launch_class_scores(cls, ld, Q, C, scores, rowmax, ST);
 }
 int sd3d_take_f32(const float* src, const uint32_t* idx, int n, float* out, void* stream) { return launch_take_f32(src, idx, n, out, ST); }
+int sd3d_select_instances(const float* scores, const int32_t* count, int k, float thr0, float thr1, int npoint_thr, int32_t* keep, int32_t* pkeep,
+                          int32_t* union_rows, int32_t* keep_u, int32_t* pkeep_u, uint8_t* score_mask, uint8_t* npoint_mask, int32_t* counts,
+                          void* stream) {
+    return launch_select_instances(scores, count, k, thr0, thr1, npoint_thr, keep, pkeep, union_rows, keep_u, pkeep_u, score_mask, npoint_mask, counts, ST);
+}
+int sd3d_take_instances(const int32_t* keep, int m, const int32_t* labels, const float* scores, const float* boxes, int64_t* labels_out,
+                        float* scores_out, float* boxes_out, void* stream) {
+    return launch_take_instances(keep, m, labels, scores, boxes, labels_out, scores_out, boxes_out, ST);
+}
 int sd3d_take_pair(const uint32_t* order, const int32_t* labels, const float* scores, int n, int32_t* labels_out, float* scores_out, void* stream) {
     return launch_take_pair(order, labels, scores, n, labels_out, scores_out, ST);
 }

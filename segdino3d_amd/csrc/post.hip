@@ -690,3 +690,93 @@ int launch_nms_finish(const uint32_t* order2, const float* scores2, const int32_
     SD3D_CHECK_LAUNCH();
     return SD3D_OK;
 }
+
+// the kept instances' labels (int64, as the reference returns them), scores and boxes in one launch (baseline3d.py:470-476)
+__global__ void take_instances_kernel(const int32_t* __restrict__ keep, int m, const int32_t* __restrict__ labels, const float* __restrict__ scores,
+                                      const float* __restrict__ boxes, int64_t* __restrict__ labels_out, float* __restrict__ scores_out,
+                                      float* __restrict__ boxes_out) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= m) return;
+    const int r = keep[i];
+    labels_out[i] = (int64_t)labels[r];
+    scores_out[i] = scores[r];
+    if (boxes_out) {
+#pragma unroll
+        for (int a = 0; a < 6; ++a) boxes_out[i * 6 + a] = boxes[r * 6 + a];
+    }
+}
+int launch_take_instances(const int32_t* keep, int m, const int32_t* labels, const float* scores, const float* boxes, int64_t* labels_out,
+                          float* scores_out, float* boxes_out, hipStream_t st) {
+    if (m <= 0) return SD3D_OK;
+    if (boxes_out && !boxes) return sd3d_set_error(SD3D_ERR_ARG, "take_instances: boxes_out without boxes");
+    hipLaunchKernelGGL(take_instances_kernel, dim3((unsigned)cdiv(m, 256)), dim3(256), 0, st, keep, m, labels, scores, boxes, labels_out, scores_out,
+                       boxes_out);
+    SD3D_CHECK_LAUNCH();
+    return SD3D_OK;
+}
+
+// The data-dependent selections of predict_by_feat_instance (baseline3d.py:470-476) for the two score thresholds (instances, panoptic)
+// on the device: one workgroup, k <= a few thousand candidates.  The host used to read the k scores and point counts, build the row lists
+// with numpy and copy them back - a device -> host -> device round trip with the GPU idle; now it reads four counts.
+//   keep_t = rows with score > thr_t and count > npoint_thr (ascending);  union_ = rows in either;  keep_u / pkeep_u = where keep_0 / keep_1
+//   sit in union_;  score_mask = score > thr_0 (bytes);  npoint_mask = (count > npoint_thr) over the rows with score > thr_0 (bytes);
+//   counts = {|keep_0|, |keep_1|, |union|, |score > thr_0|}
+__global__ __launch_bounds__(1024) void select_instances_kernel(const float* __restrict__ scores, const int32_t* __restrict__ count, int k, float thr0,
+                                                                float thr1, int npoint_thr, int32_t* __restrict__ keep, int32_t* __restrict__ pkeep,
+                                                                int32_t* __restrict__ union_, int32_t* __restrict__ keep_u, int32_t* __restrict__ pkeep_u,
+                                                                uint8_t* __restrict__ score_mask, uint8_t* __restrict__ npoint_mask,
+                                                                int32_t* __restrict__ counts) {
+    __shared__ int sc[4][1024];
+    __shared__ int carry[4];
+    const int t = threadIdx.x;
+    if (t < 4) carry[t] = 0;
+    __syncthreads();
+    for (int base = 0; base < k; base += 1024) {
+        const int i = base + t;
+        int f[4] = {0, 0, 0, 0};                               // keep_0, keep_1, union, score_mask_0
+        bool np_ok = false;
+        if (i < k) {
+            const float s = scores[i];
+            np_ok = count[i] > npoint_thr;
+            f[0] = (s > thr0) && np_ok;
+            f[1] = (s > thr1) && np_ok;
+            f[2] = f[0] | f[1];
+            f[3] = s > thr0;
+        }
+#pragma unroll
+        for (int a = 0; a < 4; ++a) sc[a][t] = f[a];
+        __syncthreads();
+        for (int d = 1; d < 1024; d <<= 1) {                   // inclusive scans of the four flag rows
+            int v[4];
+#pragma unroll
+            for (int a = 0; a < 4; ++a) v[a] = t >= d ? sc[a][t - d] : 0;
+            __syncthreads();
+#pragma unroll
+            for (int a = 0; a < 4; ++a) sc[a][t] += v[a];
+            __syncthreads();
+        }
+        int pos[4];
+#pragma unroll
+        for (int a = 0; a < 4; ++a) pos[a] = carry[a] + sc[a][t] - f[a];
+        if (i < k) {
+            if (f[0]) { keep[pos[0]] = i; keep_u[pos[0]] = pos[2]; }
+            if (f[1]) { pkeep[pos[1]] = i; pkeep_u[pos[1]] = pos[2]; }
+            if (f[2]) union_[pos[2]] = i;
+            score_mask[i] = (uint8_t)f[3];
+            if (f[3]) npoint_mask[pos[3]] = (uint8_t)np_ok;
+        }
+        __syncthreads();
+        if (t < 4) carry[t] += sc[t][1023];
+        __syncthreads();
+    }
+    if (t < 4) counts[t] = carry[t];
+}
+int launch_select_instances(const float* scores, const int32_t* count, int k, float thr0, float thr1, int npoint_thr, int32_t* keep, int32_t* pkeep,
+                            int32_t* union_, int32_t* keep_u, int32_t* pkeep_u, uint8_t* score_mask, uint8_t* npoint_mask, int32_t* counts,
+                            hipStream_t st) {
+    if (k < 0) return sd3d_set_error(SD3D_ERR_ARG, "select_instances: k < 0");
+    hipLaunchKernelGGL(select_instances_kernel, dim3(1), dim3(1024), 0, st, scores, count, k, thr0, thr1, npoint_thr, keep, pkeep, union_, keep_u, pkeep_u,
+                       score_mask, npoint_mask, counts);
+    SD3D_CHECK_LAUNCH();
+    return SD3D_OK;
+}

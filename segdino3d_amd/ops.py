@@ -1263,6 +1263,36 @@ def take_f32(src, idx):
     return out
 
 
+def select_instances(scores, count, thr0, thr1, npoint_thr):
+    """Row selections for the two score thresholds on the device (`sd3d_select_instances`).  Returns (buffers, counts): `buffers` =
+    (keep, pkeep, union, keep_u, pkeep_u int32 [k]; score_mask, npoint_mask uint8 [k]), `counts` int32 [4] for one small host read."""
+    lib = _lib.load()
+    k = scores.numel()
+    dev = scores.device
+    ints = torch.empty(5, max(k, 1), dtype=torch.int32, device=dev)
+    bytes_ = torch.empty(2, max(k, 1), dtype=torch.uint8, device=dev)
+    counts = torch.empty(4, dtype=torch.int32, device=dev)
+    ip, bp = ints.data_ptr(), bytes_.data_ptr()
+    st = 4 * max(k, 1)
+    _lib.check(lib.sd3d_select_instances(_ptr(scores, torch.float32, "scores"), _ptr(count, torch.int32, "count"), k, float(thr0), float(thr1),
+                                         int(npoint_thr), ip, ip + st, ip + 2 * st, ip + 3 * st, ip + 4 * st, bp, bp + max(k, 1),
+                                         _ptr(counts), _stream()), "select_instances")
+    return (ints, bytes_), counts
+
+
+def take_instances(keep, labels, scores, boxes=None):
+    """(labels[keep] as int64, scores[keep], boxes[keep] | None) in one launch."""
+    lib = _lib.load()
+    m = keep.numel()
+    dev = keep.device
+    lo = torch.empty(m, dtype=torch.int64, device=dev)
+    so = torch.empty(m, dtype=torch.float32, device=dev)
+    bo = torch.empty(m, 6, dtype=torch.float32, device=dev) if boxes is not None else None
+    _lib.check(lib.sd3d_take_instances(_ptr(keep, torch.int32, "keep"), m, _ptr(labels, torch.int32, "labels"), _ptr(scores, torch.float32, "scores"),
+                                       _ptr(boxes, torch.float32, "boxes"), _ptr(lo), _ptr(so), _ptr(bo), _stream()), "take_instances")
+    return lo, so, bo
+
+
 def take_pair(order, labels, scores):
     """(labels[order], scores[order]) in one launch."""
     lib = _lib.load()
