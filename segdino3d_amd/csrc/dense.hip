@@ -84,6 +84,11 @@ int launch_layernorm(const float* x, int ld_x, const float* res, int ld_res, con
 // variance like layernorm_kernel).  Both operands are read as dwordx4 along the channel axis: lane (i, kq) holds channels
 // 16 g + 4 kq .. + 3 of its row / column, and MFMA e of the group contracts {16 g + 4 kq + e}.
 // ---------------------------------------------------------------------------------------------
+// NG > 0: Cin = 16 NG known at compile time - the contraction is straight-line code in quarters of four 16-channel groups, the operands of
+// quarter q + 2 requested while quarter q + 1 multiplies (two quarters in flight from the start; the register roles are static, nothing is
+// copied).  The runtime loop (NG = 0) requests a group's operands right before it multiplies them: a 13-workgroup launch that is nothing
+// but exposed latency (17.5 us for 200 x 256 x 256).  The MFMA sequence per accumulator is the same in both: identical bits.
+template <int NG>
 __global__ __launch_bounds__(256) void linear_layernorm_kernel(const float* __restrict__ x, int ld_x, const float* __restrict__ wt, int Cin,
                                                                const float* __restrict__ bias, const float* __restrict__ res, int ld_res,
                                                                const float* __restrict__ g, const float* __restrict__ b, float eps, int64_t M,
@@ -98,6 +103,34 @@ __global__ __launch_bounds__(256) void linear_layernorm_kernel(const float* __re
     f32x4 acc[4];
 #pragma unroll
     for (int cb = 0; cb < 4; ++cb) acc[cb] = f32x4{0.f, 0.f, 0.f, 0.f};
+    if (NG > 0) {
+        constexpr int NQ = NG > 0 ? NG / 4 : 1;
+        f32x4 ab[2][4], wq[2][4][4];
+        auto load_q = [&](int buf, int q) {
+#pragma unroll
+            for (int gg = 0; gg < 4; ++gg) {
+                const int gi = q * 4 + gg;
+                ab[buf][gg] = *(const f32x4*)(xa + 16 * gi);
+#pragma unroll
+                for (int cb = 0; cb < 4; ++cb) wq[buf][gg][cb] = *(const f32x4*)(wb + (int64_t)cb * 16 * Cin + 16 * gi);
+            }
+        };
+        load_q(0, 0);
+        if (NQ > 1) load_q(1, 1);
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) {
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int gg = 0; gg < 4; ++gg)
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+#pragma unroll
+                    for (int cb = 0; cb < 4; ++cb)
+                        acc[cb] = __builtin_amdgcn_mfma_f32_16x16x4f32(ab[q & 1][gg][e], wq[q & 1][gg][cb][e], acc[cb], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            if (q + 2 < NQ) load_q(q & 1, q + 2);
+        }
+    } else {
     const int ngroups = Cin >> 4;
 #pragma unroll 4
     for (int gi = 0; gi < ngroups; ++gi) {
@@ -109,6 +142,7 @@ __global__ __launch_bounds__(256) void linear_layernorm_kernel(const float* __re
         for (int e = 0; e < 4; ++e)
 #pragma unroll
             for (int cb = 0; cb < 4; ++cb) acc[cb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[e], w4[cb][e], acc[cb], 0, 0, 0);
+    }
     }
     // acc[cb][i] = (x W^T)[row0 + 4 kq + i][wv * 64 + cb * 16 + c16]
     float s[4] = {0.f, 0.f, 0.f, 0.f};
@@ -173,8 +207,13 @@ int launch_linear_layernorm(const float* x, int ld_x, int64_t M, int Cin, const 
     if (M <= 0) return SD3D_OK;
     if (Cout != 256 || Cin <= 0 || (Cin & 15) || (ld_x & 3) || act < 0 || act > 1)
         return sd3d_set_error(SD3D_ERR_ARG, "linear_layernorm: Cout must be 256, Cin a multiple of 16, ld_x a multiple of 4, act 0 / 1");
-    hipLaunchKernelGGL(linear_layernorm_kernel, dim3((unsigned)cdiv(M, 16)), dim3(256), 0, st, x, ld_x, wt, Cin, bias, res, ld_res, g, b, eps, M,
-                       out, ld_out, act);
+    const dim3 grid((unsigned)cdiv(M, 16));
+    if (Cin == 256)
+        hipLaunchKernelGGL(linear_layernorm_kernel<16>, grid, dim3(256), 0, st, x, ld_x, wt, Cin, bias, res, ld_res, g, b, eps, M, out, ld_out, act);
+    else if (Cin == 1024)
+        hipLaunchKernelGGL(linear_layernorm_kernel<64>, grid, dim3(256), 0, st, x, ld_x, wt, Cin, bias, res, ld_res, g, b, eps, M, out, ld_out, act);
+    else
+        hipLaunchKernelGGL(linear_layernorm_kernel<0>, grid, dim3(256), 0, st, x, ld_x, wt, Cin, bias, res, ld_res, g, b, eps, M, out, ld_out, act);
     SD3D_CHECK_LAUNCH();
     return SD3D_OK;
 }
