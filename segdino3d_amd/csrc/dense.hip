@@ -772,8 +772,9 @@ __device__ __forceinline__ void dinox_mask_bits_body(const uint32_t* __restrict_
     uint16_t* out16 = (uint16_t*)out;                           // a wave produces 16 keys = half an output word at a time
     const int nhalf = nwords_out * 2;
     if (nwords <= 128) {
-        // up to 4096 superpoints: a lane keeps its two words of every open row in registers; the near rows of EIGHT keys are
-        // requested before the first is used (one key at a time the loop ran at the latency of one load per key)
+        // up to 4096 superpoints: a lane keeps its two words of every open row in registers; the near rows of a unit's SIXTEEN keys are
+        // requested before the first is used (one key at a time the loop ran at the latency of one load per key), and the few-hundred-query
+        // launches run eight waves per workgroup: twenty units are three rounds of one memory latency each
         uint32_t o[QB][2];
 #pragma unroll
         for (int qq = 0; qq < QB; ++qq)
@@ -786,12 +787,11 @@ __device__ __forceinline__ void dinox_mask_bits_body(const uint32_t* __restrict_
             uint32_t word[QB];
 #pragma unroll
             for (int qq = 0; qq < QB; ++qq) word[qq] = 0u;
+            {
+                uint32_t nb[16][2];                                // all sixteen keys of the unit requested before the first is used
 #pragma unroll
-            for (int g = 0; g < 2; ++g) {
-                uint32_t nb[8][2];
-#pragma unroll
-                for (int u = 0; u < 8; ++u) {
-                    const int64_t m = (int64_t)unit * 16 + g * 8 + u;
+                for (int u = 0; u < 16; ++u) {
+                    const int64_t m = (int64_t)unit * 16 + u;
                     const int64_t mc = m < Mq ? m : (Mq > 0 ? Mq - 1 : 0);
 #pragma unroll
                     for (int i = 0; i < 2; ++i) {
@@ -800,13 +800,13 @@ __device__ __forceinline__ void dinox_mask_bits_body(const uint32_t* __restrict_
                     }
                 }
 #pragma unroll
-                for (int u = 0; u < 8; ++u) {
-                    const int64_t m = (int64_t)unit * 16 + g * 8 + u;
+                for (int u = 0; u < 16; ++u) {
+                    const int64_t m = (int64_t)unit * 16 + u;
 #pragma unroll
                     for (int qq = 0; qq < QB; ++qq) {
                         const bool hit = __ballot(((o[qq][0] & nb[u][0]) | (o[qq][1] & nb[u][1])) != 0u) != 0ull;
                         const uint32_t blk = m < Mq ? (hit ? 0u : 1u) : (m == Mq ? 0u : 1u);
-                        word[qq] |= blk << (g * 8 + u);
+                        word[qq] |= blk << u;
                     }
                 }
             }
@@ -855,7 +855,7 @@ __device__ __forceinline__ void dinox_mask_bits_body(const uint32_t* __restrict_
     }
 }
 template <int QB>
-__global__ __launch_bounds__(256) void dinox_mask_bits_kernel(const uint32_t* __restrict__ blocked, const uint32_t* __restrict__ near,
+__global__ __launch_bounds__(512) void dinox_mask_bits_kernel(const uint32_t* __restrict__ blocked, const uint32_t* __restrict__ near,
                                                               int nwords, int64_t Q, int64_t Mq, uint32_t* __restrict__ out,
                                                               int nwords_out) {
     extern __shared__ uint32_t open_w[];                       // ~blocked[q0 .. q0 + QB)[:]
@@ -864,7 +864,7 @@ __global__ __launch_bounds__(256) void dinox_mask_bits_kernel(const uint32_t* __
 struct DinoxBitsBatch { int n; int wg0[SD3D_MAX_BATCH + 1]; const uint32_t* blocked[SD3D_MAX_BATCH]; const uint32_t* near[SD3D_MAX_BATCH];
                         uint32_t* out[SD3D_MAX_BATCH]; int nwords[SD3D_MAX_BATCH], Q[SD3D_MAX_BATCH], Mq[SD3D_MAX_BATCH], nwords_out[SD3D_MAX_BATCH]; };
 template <int QB>
-__global__ __launch_bounds__(256) void dinox_mask_bits_batch_kernel(const DinoxBitsBatch b) {
+__global__ __launch_bounds__(512) void dinox_mask_bits_batch_kernel(const DinoxBitsBatch b) {
     extern __shared__ uint32_t open_w[];
     int si = 0;
     for (int k = 1; k < b.n; ++k) if ((int)blockIdx.x >= b.wg0[k]) si = k;
@@ -895,7 +895,7 @@ int launch_dinox_mask_bits_batch(int n, const uint32_t* const* blocked, const ui
     if (wgs <= 0) return SD3D_OK;
     const size_t sm = (size_t)qb * wmax * sizeof(uint32_t);
     if (qb == 8) hipLaunchKernelGGL(dinox_mask_bits_batch_kernel<8>, dim3((unsigned)wgs), dim3(256), sm, st, b);
-    else hipLaunchKernelGGL(dinox_mask_bits_batch_kernel<2>, dim3((unsigned)wgs), dim3(256), sm, st, b);
+    else hipLaunchKernelGGL(dinox_mask_bits_batch_kernel<2>, dim3((unsigned)wgs), dim3(512), sm, st, b);
     SD3D_CHECK_LAUNCH();
     return SD3D_OK;
 }
@@ -914,7 +914,7 @@ int launch_dinox_mask_bits(const uint32_t* blocked, const uint32_t* near, int nw
     const size_t sm = (size_t)qb * nwords * sizeof(uint32_t);
     if (sm > 64 * 1024) return sd3d_set_error(SD3D_ERR_ARG, "dinox_mask_bits: more than 65536 superpoints");
     if (qb == 8) hipLaunchKernelGGL(dinox_mask_bits_kernel<8>, dim3((unsigned)cdiv(Q, 8)), dim3(256), sm, st, blocked, near, nwords, Q, Mq, out, nwords_out);
-    else hipLaunchKernelGGL(dinox_mask_bits_kernel<2>, dim3((unsigned)cdiv(Q, 2)), dim3(256), sm, st, blocked, near, nwords, Q, Mq, out, nwords_out);
+    else hipLaunchKernelGGL(dinox_mask_bits_kernel<2>, dim3((unsigned)cdiv(Q, 2)), dim3(512), sm, st, blocked, near, nwords, Q, Mq, out, nwords_out);
     SD3D_CHECK_LAUNCH();
     return SD3D_OK;
 }
