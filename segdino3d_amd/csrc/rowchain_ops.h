@@ -179,8 +179,8 @@ __device__ __forceinline__ void rc_merge(const RCOp& op, const RCCtx& cx, const 
             const float* b = base + z * (64 + 1024);
             const float mz = b[qq];
             const float f = (mz == -INFINITY) ? 0.f : __builtin_amdgcn_exp2f(mz - M);
-            L += b[32 + qq] * f;
-            acc += b[64 + dv * 32 + qq] * f;
+            L = __builtin_fmaf(b[32 + qq], f, L);                 // (explicit fused multiply-adds here and in dense.hip attention_merge_body:
+            acc = __builtin_fmaf(b[64 + dv * 32 + qq], f, acc);   //  the two must agree bit for bit whatever the compiler would contract)
         }
         dst[r * RC_LDW + col] = acc / L;
     }
