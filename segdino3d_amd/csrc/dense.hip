@@ -578,7 +578,10 @@ size_t attention_ws_bytes(int Lq, int H) { return (size_t)cdiv(Lq, 32) * H * 8 *
 // waves per workgroup and key split of one attention (Lq queries, Lk keys, H heads) given `ws_bytes` of split workspace
 static void attention_config(int Lq, int Lk, int H, bool have_ws, size_t ws_bytes, int* nw_out, int* ks_out) {
     const int ntiles = (Lk + 31) / 32;
-    int nw = ntiles >= 32 ? 8 : (ntiles >= 8 ? 4 : (ntiles >= 2 ? 2 : 1));
+    // 4 - 7 key tiles (the 200-key self-attention, the 301-key 2D-query attention): four waves of one or two tiles each instead of two waves
+    // of up to four (every tile is a dependent load -> MFMA round trip): decoder 1.863 -> 1.840 ms.  SD3D_ATTN_NW_SMALL=2 restores round 3.
+    static const int nw_small = [] { const char* e = getenv("SD3D_ATTN_NW_SMALL"); return e ? atoi(e) : 4; }();
+    int nw = ntiles >= 32 ? 8 : (ntiles >= 8 ? 4 : (ntiles >= 4 ? nw_small : (ntiles >= 2 ? 2 : 1)));
     // few query tiles x heads (200 queries: 56 workgroups on 256 CUs) and many key tiles: deal the key tiles to several
     // workgroups and merge their softmax states in a second, tiny pass (each wave walks its tiles serially, so the
     // single-pass kernel is bound by ~12 dependent load -> MFMA round trips per wave)
