@@ -1,5 +1,5 @@
 """Single-scene forwards, one in flight (the `single_scene` operating point), for a kernel timeline:
-   rocprofv3 --kernel-trace -d /tmp/tl -o r -- python3 tools/single_forward.py [n]      then tools/timeline.py <db>"""
+   rocprofv3 --kernel-trace -d /tmp/tl -o r -- python3 tools/single_forward.py [n]      then tools/timeline_forward.py <db>"""
 import os
 import sys
 import time
