@@ -103,6 +103,21 @@ __global__ __launch_bounds__(256) void linear_layernorm_kernel(const float* __re
     f32x4 acc[4];
 #pragma unroll
     for (int cb = 0; cb < 4; ++cb) acc[cb] = f32x4{0.f, 0.f, 0.f, 0.f};
+    // the epilogue's operands (bias, residual rows, LayerNorm weight / bias) are requested BEFORE the contraction: with one wave per SIMD
+    // nothing else hides their latency behind the last MFMA (the same values, used in the same expressions)
+    float e_bias[4], e_g[4], e_b[4], e_res[4][4];
+#pragma unroll
+    for (int cb = 0; cb < 4; ++cb) {
+        const int col = wv * 64 + cb * 16 + c16;
+        e_bias[cb] = bias ? bias[col] : 0.f;
+        e_g[cb] = g[col];
+        e_b[cb] = b[col];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int64_t r = row0 + 4 * kq + i;
+            e_res[cb][i] = (res && r < M) ? res[r * ld_res + col] : 0.f;
+        }
+    }
     if (NG > 0) {
         constexpr int NQ = NG > 0 ? NG / 4 : 1;
         f32x4 ab[2][4], wq[2][4][4];
@@ -148,13 +163,12 @@ __global__ __launch_bounds__(256) void linear_layernorm_kernel(const float* __re
     float s[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int cb = 0; cb < 4; ++cb) {
-        const int col = wv * 64 + cb * 16 + c16;
-        const float bv = bias ? bias[col] : 0.f;
+        const float bv = e_bias[cb];
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const int64_t r = row0 + 4 * kq + i;
             float t = acc[cb][i] + bv;
-            if (res && r < M) t += res[r * ld_res + col];
+            if (res && r < M) t += e_res[cb][i];
             acc[cb][i] = t;
             s[i] += t;
         }
@@ -194,7 +208,7 @@ __global__ __launch_bounds__(256) void linear_layernorm_kernel(const float* __re
 #pragma unroll
             for (int cb = 0; cb < 4; ++cb) {
                 const int col = wv * 64 + cb * 16 + c16;
-                float y = (acc[cb][i] - mean[i]) * rstd * g[col] + b[col];
+                float y = (acc[cb][i] - mean[i]) * rstd * e_g[cb] + e_b[cb];
                 if (act == 1) y = fmaxf(y, 0.f);
                 out[r * ld_out + col] = y;
             }
