@@ -190,7 +190,7 @@ def load_pmc_traffic(key):
     """HBM-side bytes per forward of the dominant kernel from the committed PMC passes (rocprofv3 cannot run inside this process) -
     ONLY if they were collected on the workload this run measures (`key`: scene shape, layout, query mode, scenes per forward).
     Returns (bytes per forward | None, source | reason)."""
-    for name in ("r04_pmc_traffic.json", "r03_pmc_traffic.json", "r02_pmc_traffic.json"):
+    for name in ("r05_pmc_traffic.json", "r04_pmc_traffic.json"):
         path = os.path.join(ROOT, "profiles", name)
         if not os.path.exists(path):
             continue
@@ -274,6 +274,10 @@ def main():
                          "same scenes/s as 1 within 1-2 %, convolutions 7 % faster (4 x the tiles per launch); `single_scene` is always one scene per forward")
     ap.add_argument("--decoder-dtype", choices=("fp32", "bf16"), default=os.environ.get("SD3D_DECODER_DTYPE", "fp32"),
                     help="bf16 = BASELINE configs[2]: bf16-MFMA attention contractions and projections, fp32 accumulation")
+    ap.add_argument("--forward-sizes", default="", help="e.g. '2,3': every stream cuts its scenes into forwards of these sizes, cyclically, in "
+                    "EVERY pipelined run of the process (counter passes on exactly the forward sizes another command line times: tools/pmc_run.sh)")
+    ap.add_argument("--skip-single-scene", action="store_true", help="no one-scene-per-forward latency groups (counter passes: every forward "
+                    "of the process then has one of --forward-sizes)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-end-to-end", action="store_true", help="skip the packed-files -> host-numpy-outputs measurement (`end_to_end`)")
     ap.add_argument("--preroll-seconds", type=float, default=2.0, help="untimed pipelined pre-roll before the timed K steps")
@@ -321,26 +325,30 @@ def main():
 
     from segdino3d_amd.dist_eval import PipelinedRunner
     runner = PipelinedRunner(model, args.streams, device, batch=args.batch)
+    if args.forward_sizes:
+        runner.forward_sizes = [int(v) for v in args.forward_sizes.split(",") if v.strip()]
     # every step gets its own target object (the forward attaches its outputs to it)
     import copy
     def scene_list(n):
         return [(pool[i % len(pool)][0], copy.copy(pool[i % len(pool)][1])) for i in range(n)]
 
     with torch.no_grad():
-        for i in range(args.warmup):
+        for i in range(0 if args.skip_single_scene else args.warmup):
             step(i)
+        if args.skip_single_scene:
+            runner.run(scene_list(max(1, args.warmup)))
         runner.run(scene_list(max(args.streams, 2) * args.batch))   # warm the worker streams' allocator pools
         torch.cuda.synchronize()
         # single-scene latency (one stream, back to back): median over four groups of five forwards (one group of five read
         # 12.5 and 13.5 ms in two runs of the same build on the same box: a host hiccup in a 60 ms window is a 8 % error)
         n_lat, groups = min(5, args.steps), []
-        for _ in range(4):
+        for _ in range(0 if args.skip_single_scene else 4):
             t0 = time.perf_counter()
             for i in range(n_lat):
                 step(i)
             torch.cuda.synchronize()
             groups.append(1e3 * (time.perf_counter() - t0) / n_lat)
-        latency_ms = sorted(groups)[1:3][0] * 0.5 + sorted(groups)[1:3][1] * 0.5
+        latency_ms = (sorted(groups)[1:3][0] * 0.5 + sorted(groups)[1:3][1] * 0.5) if groups else float("nan")
         # pipelined pre-roll (untimed): the W warm-up steps above ran on one stream; the timed region runs `streams` host
         # threads, whose allocator pools, code objects and - on a freshly booted node - host clocks need a second of the
         # real workload to settle (a cold node measured 85 -> 93 -> 98 scenes/s over three back-to-back processes without it)
@@ -371,7 +379,11 @@ def main():
         # one scene per forward, for the per-scene voxel counts of the line
         import segdino3d_amd as seg
         with seg.capture() as cap1:
-            step(0)
+            if args.skip_single_scene:                            # (still no one-scene forward in the process)
+                ids0 = plan[0][0]
+                model([work[i][0] for i in ids0], [copy.copy(work[i][1]) for i in ids0])
+            else:
+                step(0)
         # Instrumented replay of the same K steps for the roofline of the dominant kernel: a HIP-event
         # pair around every gather_gemm launch costs ~2 x 237 event records per step (+15-20 % wall),
         # so it is kept out of the region that produces `value`.  It runs the forwards of `plan` - the same scenes grouped
@@ -430,8 +442,10 @@ def main():
     # HBM-side bytes of the dominant kernel per forward: FETCH_SIZE x 2 (the guide's gfx950 correction) + WRITE_SIZE of pair_gemm_* +
     # pair_reduce_* from the committed PMC passes, reported only when they were collected on THIS workload.  They exceed the
     # algorithmic bytes by design: the partial products are written by pass 1 and re-read by pass 2.
+    # keyed on the forward sizes the timed region REALLY ran (the driver's 20 steps on 4 streams x batches of <= 4 are forwards of 2 and 3
+    # scenes): the counter passes replay those sizes on one stream (`tools/pmc_run.sh ... --forward-sizes 2,3 --skip-single-scene`)
     workload_key = {"points": args.points, "superpoints": args.superpoints, "queries_2d": args.query2d, "scene_layout": args.scene_layout,
-                    "scenes_per_forward": args.batch}           # (the PMC passes run whole batches: --steps a multiple of streams x batch)
+                    "forward_sizes": sorted({len(f) for st_plan in plan for f in st_plan})}
     traffic_fwd, traffic_src = load_pmc_traffic(workload_key)
     roofline = {"bound": "mfma",
                 "kernel": "sd3d_pair_conv_ex = pair_gemm_* (pass 1, fp32 MFMA over the offset-major rulebook) + pair_reduce_rl_kernel (pass 2 over per-row lists; "
@@ -447,7 +461,7 @@ def main():
                 # the same with the MEASURED HBM-side bytes (partial products written by pass 1 and re-read by pass 2 included)
                 "hbm_traffic_gbs": round(traffic_fwd / (conv_ms / steps) / 1e6, 1) if (traffic_fwd and conv_ms > 0) else None,
                 "hbm_traffic_frac": round(traffic_fwd / (conv_ms / steps) / 1e6 / HBM_PEAK_GBS, 4) if (traffic_fwd and conv_ms > 0) else None,
-                "share_of_single_stream_forward": round(conv_ms / steps / latency_ms, 3) if args.batch == 1 else None,
+                "share_of_single_stream_forward": round(conv_ms / steps / latency_ms, 3) if (args.batch == 1 and groups) else None,
                 "measured": "HIP events around every launch on the launching stream, single-stream instrumented replay of the timed steps"
                             + (" in the forwards of `config.forward_sizes` (`*_per_forward` figures are per SCENE, `launches_per_forward` per forward call)"
                                if args.batch > 1 else ""),
@@ -483,12 +497,14 @@ def main():
             "value": round(value, 3), "unit": "scenes/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * dt / args.steps, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32 backbone + bf16 decoder contractions" if bf16_dec else "f32", "data": "synthetic",
-            "single_scene": {"scenes_per_s": round(1e3 / latency_ms, 2), "latency_ms": round(latency_ms, 3),
-                             "latency_ms_groups_of_5": [round(g, 3) for g in groups],
-                             "note": "ONE scene in flight per GPU (SURVEY 8(d) batch = 1), same forward, same process"},
-            "config": {"workload": ("configs[2]" if bf16_dec else "configs[1]") + ": ScanNet-val-like scenes, one scene per forward (step), "
-                                   f"{args.streams} forward(s) in flight per GPU of <= {args.batch} scene(s) each (`value`; the K steps of THIS run as `forward_sizes`: "
-                                   f"<= {sum(max(st) if st else 0 for st in fwd_sizes)} scenes in flight) / one in flight (`single_scene`); "
+            "single_scene": None if not groups else {
+                "scenes_per_s": round(1e3 / latency_ms, 2), "latency_ms": round(latency_ms, 3),
+                "latency_ms_groups_of_5": [round(g, 3) for g in groups],
+                "note": "ONE scene in flight per GPU (SURVEY 8(d) batch = 1), same forward, same process"},
+            "config": {"workload": ("configs[2]" if bf16_dec else "configs[1]") + ": ScanNet-val-like scenes; a STEP is one scene; `value` times the K scenes as "
+                                   f"{sum(len(st) for st in fwd_sizes)} evaluation forwards of {'/'.join(str(v) for v in workload_key['forward_sizes'])} scenes each "
+                                   f"(`forward_sizes`), {args.streams} forward(s) in flight per GPU (<= {sum(max(st) if st else 0 for st in fwd_sizes)} scenes in flight); "
+                                   "`single_scene` = one forward of one scene in flight; "
                                    "fp32 sparse backbone (Res16UNet34C) + " + ("bf16-MFMA" if bf16_dec else "fp32") +
                                    " decoder + post-processing, device-resident in/out",
                        "points": args.points, "superpoints": args.superpoints, "queries_2d": args.query2d, "scene_layout": args.scene_layout,
@@ -497,7 +513,7 @@ def main():
                        "forward_sizes": fwd_sizes,             # per stream: scenes of each forward of the timed region (PipelinedRunner.plan_batches)
                        "scenes_in_flight_per_gpu": sum(max(st) if st else 0 for st in fwd_sizes),
                        "scenes_per_forward": round(args.steps / max(1, sum(len(st) for st in fwd_sizes)), 2),
-                       "single_stream_latency_ms": round(latency_ms, 3),
+                       "single_stream_latency_ms": round(latency_ms, 3) if groups else None,
                        "untimed_preroll_scenes": n_pre, "host_cores_per_rank": cores_per_rank, "gpu_numa_node": numa_node},
             "sustained": {"scenes_per_s": round(world * sus_n / sus_dt, 3) if sus_n else None, "timed_scenes": sus_n, "seconds": round(sus_dt, 3),
                           "note": "the same K-step list repeated back to back after the K timed steps (rank 0's clock); not `value`"},

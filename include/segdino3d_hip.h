@@ -216,12 +216,10 @@ int sd3d_pair_conv(const float* in0, int ld0, int C0, const float* in1, int ld1,
  * same fixed per-row summation order for a given table description, results reproducible bit for bit):
  *   rlist [M, rl_stride]   per output row {count, list positions of its pairs in offset order}; rl_stride a multiple of 4,
  *                          >= K + 4.  Pass 2 walks a row's own partial products instead of the K slots of pos[k][r].
- *   center                 offset whose pairs are (in = r, out = r) for EVERY row (a stride-1 table of a voxel set onto itself,
- *                          minkunet.py:135-162 `conv` with stride 1; K / 2 for the centred odd kernels), or -1.  rlist then
- *                          leaves that offset out, tile_k receives the offset's run of tiles in two extra slots (meta = 1:
- *                          tile_k has p_cap / 128 + 3 entries), pass 1 skips the run, and ONE dense kernel makes the centre
- *                          product, adds the other offsets' partial products (k ascending) and applies the epilogue: no partial
- *                          product is written or read back for the centre, each output row is written once.
+ *   center                 -1 (plain lists) or SD3D_PAIR_CHAINED (below).  (Round 3 also took an offset number here - a dense
+ *                          kernel for the centre offset of a stride-1 table; it measured slower and left the library, see
+ *                          profiles/EXPERIMENTS.md.  A value >= 0 is refused with SD3D_ERR_ARG.)  meta = 1: tile_k has
+ *                          p_cap / 128 + 3 entries (two reserved slots, written as zero, behind the tile count).
  *   out_idx [p_cap]        output row of every list entry (-1 on padding).  Handing it to the convolution promises ONE pair per
  *                          output row - the transposed k2s2 convolutions (minkunet.py:165-192 `conv_tr`: every fine voxel has one
  *                          parent) - and pass 1 writes act(scale * product + shift + res) to the row directly: no pass 2. */
@@ -246,18 +244,6 @@ int sd3d_pair_conv_ex(const float* in0, int ld0, int C0, const float* in1, int l
                       const float* shift, const float* res, int ld_res, float* out, int ld_out, int act, float* part,
                       size_t part_bytes, void* stream);
 
-/* Output-stationary sparse convolution (csrc/slab_conv.hip) - the same contract again (MinkowskiConvolution /
- * SubMConv3d / their transposes + folded BN + residual + activation; minkunet.py:135-192, spconvunet.py:21-99), straight
- * from the neighbour table nbr [K, M]: a workgroup owns a slab of consecutive output rows, keeps their fp32 sums in LDS
- * while it walks the offsets in ascending order, and writes every output row once - no partial products in HBM, no
- * second pass, no pair lists.  n_pairs (number of entries >= 0, from sd3d_kernel_map) only guides the launch geometry.
- * Cin % 32 == 0, Cout % 16 == 0, K <= 128; sd3d_slab_conv_ws_bytes returns 0 for shapes it does not handle (the caller
- * keeps sd3d_pair_conv for those).  ws: per-workgroup rulebook scratch (+ partial slabs when the offsets are split). */
-size_t sd3d_slab_conv_ws_bytes(int K, int Cin, int Cout, int64_t M, int64_t n_pairs);
-int sd3d_slab_conv(const float* in0, int ld0, int C0, const float* in1, int ld1, const int32_t* nbr, int64_t n_pairs,
-                   const float* wt, int K, int Cin, int Cout, int64_t M, const float* scale, const float* shift,
-                   const float* res, int ld_res, float* out, int ld_out, int act, void* ws, size_t ws_bytes, void* stream);
-
 /* Layer-sequence executor (csrc/executor.hip): a whole sparse U-Net forward from one call.  Replaces the
  * Python-level module loop of Res16UNetBase.forward (minkunet.py:531-601) / UBlock.forward
  * (spconvunet.py:156-201): the plan is built once per model, per scene the caller supplies the
@@ -279,7 +265,7 @@ typedef struct sd3d_table {
     int64_t p_cap, M;                        /* M = output rows of the table */
     int32_t K, pad_;
     const int32_t *rlist, *out_idx;          /* optional products of sd3d_pair_lists_desc (NULL) */
-    int32_t rl_stride, center;               /* center = -1 when the table has no all-rows centre offset */
+    int32_t rl_stride, center;               /* -1 or SD3D_PAIR_CHAINED, as in sd3d_pair_table_desc */
 } sd3d_table;
 typedef struct sd3d_buf {
     float* ptr;

@@ -59,8 +59,6 @@ SIGNATURES = {
     "sd3d_pair_lists_ws_bytes": (_z, [_i, _l]),
     "sd3d_pair_lists": (_i, [_p, _i, _l, _l, _p, _p, _p, _p, _z, _p]),
     "sd3d_pair_lists_batch": (_i, [_i, _p, _p, _p, _p, _p, _p, _p, _p, _z, _p]),
-    "sd3d_slab_conv_ws_bytes": (_z, [_i, _i, _i, _l, _l]),
-    "sd3d_slab_conv": (_i, [_p, _i, _i, _p, _i, _p, _l, _p, _i, _i, _i, _l, _p, _p, _p, _i, _p, _i, _i, _p, _z, _p]),
     "sd3d_pair_conv": (_i, [_p, _i, _i, _p, _i, _p, _p, _l, _p, _p, _i, _i, _i, _l, _p, _p, _p, _i, _p, _i, _i, _p, _z, _p]),
     "sd3d_pair_lists_desc": (_i, [_i, _p, _p, _z, _p]),
     "sd3d_pair_conv_ex": (_i, [_p, _i, _i, _p, _i, _p, _p, _l, _p, _p, _i, _i, _p, _p, _i, _i, _i, _l, _p, _p, _p, _i, _p, _i, _i, _p, _z, _p]),

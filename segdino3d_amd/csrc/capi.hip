@@ -50,9 +50,6 @@ int launch_linear_group(int, const GGParams*, hipStream_t);
 int launch_fourier_pe(const float*, int, int64_t, const float*, const float*, int, int, float*, int, const int32_t*, hipStream_t);
 int launch_pair_lists_batch(int, const int32_t* const*, const int*, const int64_t*, const int64_t*, int32_t* const*, int32_t* const*,
                             int32_t* const*, void*, size_t, hipStream_t);
-size_t slab_conv_ws_bytes(int, int, int, int64_t, int64_t);
-int launch_slab_conv(const float*, int, int, const float*, int, const int32_t*, int64_t, const float*, int, int, int, int64_t, const float*,
-                     const float*, const float*, int, float*, int, int, void*, size_t, hipStream_t);
 int launch_pair_conv(const float*, int, int, const float*, int, const int32_t*, const int32_t*, int64_t, const int32_t*, const int32_t*, int,
                      int, const int32_t*, const float*, int, int, int, int64_t, const float*, const float*, const float*, int, float*, int,
                      int, float*, size_t, hipStream_t);
@@ -290,14 +287,6 @@ int sd3d_pair_conv_ex(const float* in0, int ld0, int C0, const float* in1, int l
                       int ld_res, float* out, int ld_out, int act, float* part, size_t part_bytes, void* stream) {
     return launch_pair_conv(in0, ld0, C0, in1, ld1, in_idx, tile_k, p_cap, pos, rlist, rl_stride, center, out_idx, wt, K, Cin, Cout, M,
                             scale, shift, res, ld_res, out, ld_out, act, part, part_bytes, ST);
-}
-
-size_t sd3d_slab_conv_ws_bytes(int K, int Cin, int Cout, int64_t M, int64_t n_pairs) { return slab_conv_ws_bytes(K, Cin, Cout, M, n_pairs); }
-int sd3d_slab_conv(const float* in0, int ld0, int C0, const float* in1, int ld1, const int32_t* nbr, int64_t n_pairs, const float* wt, int K,
-                   int Cin, int Cout, int64_t M, const float* scale, const float* shift, const float* res, int ld_res, float* out,
-                   int ld_out, int act, void* ws, size_t ws_bytes, void* stream) {
-    return launch_slab_conv(in0, ld0, C0, in1, ld1, nbr, n_pairs, wt, K, Cin, Cout, M, scale, shift, res, ld_res, out, ld_out, act, ws,
-                            ws_bytes, ST);
 }
 
 int sd3d_layernorm(const float* x, int ld_x, const float* res, int ld_res, const float* w, const float* b, float eps, int64_t M,

@@ -21,7 +21,7 @@
 // (stride 8 / 16: 14 k / 3 k voxels) get their parallelism from splitting the OFFSETS over gridDim.y workgroups that write
 // partial slabs (ksplit x M x Cout floats, ~1/8 of what the pair-major partial products were), summed in k order by
 // slab_reduce_kernel together with the epilogue.
-#include "gg_common.h"
+#include "../gg_common.h"
 #include <stdlib.h>
 #include <type_traits>
 

@@ -151,8 +151,7 @@ struct PLTable {
     int32_t* out_idx;              // [p_cap]: output row of every list entry, -1 on padding (NULL: not built)
     int64_t M, p_cap;
     int K, nblk, wg0, k0;          // wg0: first workgroup of this table in the (K * nblk)-flattened grid; k0: first of the K-flattened grid
-    int center;                    // offset whose pairs are (in = r, out = r) for EVERY row r (stride-1 table of a voxel set onto itself), or -1
-    int rl_stride, rb0, meta;      // rb0: first workgroup of the table in the row-list grid; meta: tile_k carries the two centre slots
+    int rl_stride, rb0, meta;      // rb0: first workgroup of the table in the row-list grid; meta: tile_k carries two reserved (zero) slots behind the tile count
 };
 struct PLBatch { int n; PLTable t[PL_MAX_TABLES]; };
 
@@ -220,11 +219,7 @@ __global__ __launch_bounds__(256) void pair_fill_batch_kernel(const PLBatch b) {
         if (k == T.K - 1 && tid == 0) {                        // number of real tiles, after the last slot
             const int64_t end = (int64_t)seg + seg_len < T.p_cap ? (int64_t)seg + seg_len : T.p_cap;
             T.tile_k[T.p_cap / PT] = (int)(end / PT);
-            if (T.meta && T.center < 0) { T.tile_k[T.p_cap / PT + 1] = 0; T.tile_k[T.p_cap / PT + 2] = 0; }
-        }
-        if (T.meta && k == T.center && tid == 0) {             // the centre offset's run of tiles (pass 1 may skip it, pair_center_kernel owns it)
-            T.tile_k[T.p_cap / PT + 1] = seg / PT;
-            T.tile_k[T.p_cap / PT + 2] = (int64_t)seg + seg_len <= T.p_cap ? seg_len / PT : 0;
+            if (T.meta) { T.tile_k[T.p_cap / PT + 1] = 0; T.tile_k[T.p_cap / PT + 2] = 0; }
         }
     }
     if (k == T.K - 1) {
@@ -262,8 +257,7 @@ __global__ __launch_bounds__(256) void pair_fill_batch_kernel(const PLBatch b) {
 
 // Per output row: how many partial products pass 2 has to add up and where they are - {count, positions in offset order} in
 // rl_stride ints per row (the count and the first three positions arrive with ONE 16-byte load; a level-0 row has ~2 partners, so
-// walking all K slots of pos[k][r] was 27 loads for 3 hits).  The centre offset of a stride-1 table is left out: its product
-// is made inside pair_center_kernel and never stored.  One thread per row; pos is read offset-major (coalesced over rows).
+// walking all K slots of pos[k][r] was 27 loads for 3 hits).  One thread per row; pos is read offset-major (coalesced over rows).
 __global__ __launch_bounds__(RL_ROWS) void pair_rowlist_batch_kernel(const PLBatch b) {
     const int ti = pl_find_table(b, blockIdx.x, 2);
     const PLTable& T = b.t[ti];
@@ -275,7 +269,7 @@ __global__ __launch_bounds__(RL_ROWS) void pair_rowlist_batch_kernel(const PLBat
     for (int k0 = 0; k0 < T.K; k0 += 8) {
         int v[8];
 #pragma unroll
-        for (int u = 0; u < 8; ++u) v[u] = (k0 + u < T.K && k0 + u != T.center) ? T.pos[(int64_t)(k0 + u) * T.M + row] : -1;
+        for (int u = 0; u < 8; ++u) v[u] = (k0 + u < T.K) ? T.pos[(int64_t)(k0 + u) * T.M + row] : -1;
 #pragma unroll
         for (int u = 0; u < 8; ++u)
             if (v[u] >= 0) rl[1 + cnt++] = v[u];
@@ -503,7 +497,6 @@ struct PGParams {
     int Cin, Cout;
     float* part;                              // [n_tiles * 128][Cout]
     int n_tiles;                              // capacity; the real count is tile_k[n_tiles]
-    int skip_center;                          // 1: leave out the tiles tile_k[n_tiles + 1] .. + tile_k[n_tiles + 2] (pair_center_kernel makes them)
     // direct epilogue (out_idx != NULL): every output row has exactly ONE pair (transposed k2s2 convolution), so the tile's
     // products ARE the output rows: out[out_idx[p]] = act(scale * acc + shift + res) straight from pass 1, no partial products
     const int32_t* out_idx;
@@ -537,11 +530,7 @@ __device__ __forceinline__ void pair_gemm_body(const PGParams& p, float (*Bs)[NT
     const int j = lane & 31, h = lane >> 5;
     // balanced contiguous tile ranges over a grid sized to the resident workgroup slots: no wave-quantisation
     // tail (a fixed tiles-per-workgroup grid of 2.1 rounds costs 3 rounds of time)
-    // tiles are numbered WITHOUT the centre offset's run when pass 1 skips it; PHYS() maps back to list positions
-    const int skip0 = p.skip_center ? p.tile_k[p.n_tiles + 1] : 0;
-    const int skipn = p.skip_center ? p.tile_k[p.n_tiles + 2] : 0;
-    const int n_real = p.tile_k[p.n_tiles] - skipn;
-#define PHYS(e) ((e) < skip0 ? (e) : (e) + skipn)
+    const int n_real = p.tile_k[p.n_tiles];
     int tile0 = (int)((int64_t)blockIdx.x * n_real / gridDim.x);
     int tile1 = (int)((int64_t)(blockIdx.x + 1) * n_real / gridDim.x);
     if (p.chained) {                                           // a chain of sub-tiles (<= 3) is never split between workgroups
@@ -555,8 +544,8 @@ __device__ __forceinline__ void pair_gemm_body(const PGParams& p, float (*Bs)[NT
     const int nsteps = ntl * nchunks;
     const int64_t wstride = (int64_t)p.Cout * p.Cin;
 
-#define LOAD_IDX(lt) ((lt) < ntl ? p.in_idx[(int64_t)PHYS(tile0 + (lt)) * PT + wv * 32 + j] : -1)
-#define LOAD_K(lt) ((lt) < ntl ? p.tile_k[PHYS(tile0 + (lt))] : 0)
+#define LOAD_IDX(lt) ((lt) < ntl ? p.in_idx[(int64_t)(tile0 + (lt)) * PT + wv * 32 + j] : -1)
+#define LOAD_K(lt) ((lt) < ntl ? p.tile_k[(tile0 + (lt))] : 0)
     int q0 = LOAD_IDX(0), q1 = LOAD_IDX(1), q2 = LOAD_IDX(2);  // gather rows of the current tile and the next two
     int k_cur = LOAD_K(0), k_nxt = LOAD_K(1);
 
@@ -637,7 +626,7 @@ __device__ __forceinline__ void pair_gemm_body(const PGParams& p, float (*Bs)[NT
             }                                                                                                         \
         }                                                                                                             \
         if (last_chunk && !(k_cur & PG_CHAIN)) { /* tile (chain) complete: write its partial products (or, one pair per output row, the rows themselves) */ \
-            const int64_t prow0 = (int64_t)PHYS(tile0 + cur_lt) * PT + wv * 32;                                       \
+            const int64_t prow0 = (int64_t)(tile0 + cur_lt) * PT + wv * 32;                                       \
             if (DIRECT) {                                                                                             \
                 _Pragma("unroll") for (int r = 0; r < 16; ++r) {                                                      \
                     const int64_t o = p.out_idx[prow0 + (r & 3) + 8 * (r >> 2) + 4 * h];   /* uniform over the 32 lanes j */ \
@@ -733,9 +722,7 @@ __device__ __forceinline__ void pair_gemm_ws_body(const PGParams& p, float* Ws) 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);   // wave-uniform values must live in SGPRs (scalar branches)
     const int j = lane & 31, h = lane >> 5;
-    const int skip0 = p.skip_center ? p.tile_k[p.n_tiles + 1] : 0;
-    const int skipn = p.skip_center ? p.tile_k[p.n_tiles + 2] : 0;
-    const int n_real = p.tile_k[p.n_tiles] - skipn;            // PHYS(): tile number without the centre run -> list position
+    const int n_real = p.tile_k[p.n_tiles];
     const int range0 = (int)((int64_t)blockIdx.x * n_real / gridDim.x);
     const int range1 = (int)((int64_t)(blockIdx.x + 1) * n_real / gridDim.x);
     if (range1 <= range0) return;
@@ -760,14 +747,14 @@ __device__ __forceinline__ void pair_gemm_ws_body(const PGParams& p, float* Ws) 
     const int ntl = range1 - tile0 < WS_RANGE_TILES ? range1 - tile0 : WS_RANGE_TILES;
     __syncthreads();                                           // nobody still reads the previous piece's indices
     for (int f = tid; f < ntl * PT; f += 256) {
-        const int v = p.in_idx[(int64_t)PHYS(tile0 + (f >> 7)) * PT + (f & (PT - 1))];
+        const int v = p.in_idx[(int64_t)(tile0 + (f >> 7)) * PT + (f & (PT - 1))];
         Ix[f] = v < 0 ? 0 : v;                                 // their partial products are never read back
     }
     int run_start = 0;
     while (run_start < ntl) {                                  // runs of tiles with the same offset (uniform)
-        const int k = p.tile_k[PHYS(tile0 + run_start)];
+        const int k = p.tile_k[(tile0 + run_start)];
         int run_end = run_start + 1;
-        while (run_end < ntl && p.tile_k[PHYS(tile0 + run_end)] == k) ++run_end;
+        while (run_end < ntl && p.tile_k[(tile0 + run_end)] == k) ++run_end;
         __syncthreads();                                       // everyone is done reading the previous W (and Ix is written)
         {
             const float* __restrict__ W = p.wt + ((int64_t)k * p.Cout + ncol0) * p.Cin;
@@ -844,7 +831,7 @@ __device__ __forceinline__ void pair_gemm_ws_body(const PGParams& p, float* Ws) 
         if (last_chunk) { /* unit complete: lane = pair row, register group g = columns 8g + 4h .. +3 */              \
             _Pragma("unroll") for (int rt = 0; rt < RT; ++rt) {                                                       \
                 const int ue = (u0 + 4 * cur_i) * RT + rt;          /* 32-pair unit of the piece: tile ue / 4, quarter ue % 4 */ \
-                const int64_t prow = (int64_t)PHYS(tile0 + (ue >> 2)) * PT + (ue & 3) * 32 + j;                       \
+                const int64_t prow = (int64_t)(tile0 + (ue >> 2)) * PT + (ue & 3) * 32 + j;                       \
                 if (DIRECT) {                                       /* one pair per output row: write the row itself */ \
                     const int64_t o = p.out_idx[prow];                                                                \
                     if (o >= 0) {                                                                                     \
@@ -1014,177 +1001,6 @@ __global__ __launch_bounds__(256) void pair_reduce_rl_kernel(const PRLParams p) 
     *(f32x4*)(p.out + r * p.ld_out + q) = f32x4{y[0], y[1], y[2], y[3]};
 }
 
-// ---- centre offset + pass 2 in one kernel ----------------------------------------------------------------------
-// Stride-1 tables of a voxel set onto itself: the centre offset pairs every row with itself (in = out = r).  Its product is a
-// DENSE GEMM over consecutive rows - no gather indirection, perfectly balanced - and needs no partial product: this kernel makes
-// it in registers for a tile of 128 rows (weight-stationary: W[centre] sits in LDS for the whole launch, a wave owns 32 rows,
-// MFMA issued transposed so a lane owns a row), then streams the OTHER offsets' partial products of its rows in through the
-// per-row lists (k ascending), applies scale / shift / residual / activation and writes each output row once.  Versus pass 1
-// over all K offsets + pair_reduce_kernel this removes the write and the read-back of one partial row per output row (a third of
-// the partial traffic at level 0, where a voxel has ~2 neighbours) and the pass-2 stream runs under the matrix work of the other
-// waves on the CU.  Summation order per row: centre product, then the offsets ascending - fixed, so results are reproducible.
-struct PCParams {
-    const float* in0; int ld0; int C0;
-    const float* in1; int ld1;
-    const float* wt;                          // W[centre]: [Cout][Cin]
-    int Cin, Cout;
-    int64_t M;
-    const int32_t* rlist; int rl_stride;
-    const float* part;
-    const float* scale; const float* shift; const float* res; int ld_res;
-    float* out; int ld_out; int act;
-};
-
-// GLOBALW: the weight fragments come straight from global memory (W[centre] is 36-260 KB and L2-resident; the four waves of a
-// workgroup read the same fragments, so most hits are L1) instead of an LDS copy staged per workgroup.  That frees the kernel from
-// LDS and from a persistent grid: one workgroup per 128-row tile, dispatched by the hardware as slots free up - no tile
-// quantisation (level 0: 1084 tiles on 768 persistent slots were two rounds), no 38-133 KB of staging for one or two tiles, and
-// 12 waves per CU stream the partial products of their rows.
-template <int NT, int ST, bool GLOBALW>
-__device__ __forceinline__ void pair_center_body(const PCParams& p, float* Ws) {
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int j = lane & 31, h = lane >> 5;
-    const int n_tiles = (int)((p.M + PT - 1) / PT);
-    const int tile0 = (int)((int64_t)blockIdx.x * n_tiles / gridDim.x);
-    const int tile1 = (int)((int64_t)(blockIdx.x + 1) * n_tiles / gridDim.x);
-    if (tile1 <= tile0) return;
-    const int nchunks = p.Cin >> 5;
-    const int ldw = GLOBALW ? p.Cin : p.Cin + 4;               // LDS copy: conflict-free b128 rows, as in pair_gemm_ws_body
-    const int c4 = p.Cin >> 2;
-    const int npieces = 32 * NT * c4;
-    const int ncol0 = blockIdx.y * NT * 32;
-    const float* wrows = GLOBALW ? p.wt + (int64_t)ncol0 * p.Cin : Ws;
-    if (!GLOBALW) {                                            // W[centre] rows ncol0 .. ncol0 + 32 NT: once per launch
-        const float* __restrict__ W = p.wt + (int64_t)ncol0 * p.Cin;
-        for (int f0 = 0; f0 < npieces; f0 += 256 * 4) {
-            f32x4 v[4];
-#pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const int f = f0 + u * 256 + tid;
-                if (f < npieces) v[u] = *(const f32x4*)(W + (int64_t)f * 4);
-            }
-#pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const int f = f0 + u * 256 + tid;
-                if (f < npieces) {
-                    const int row = f / c4, col = f - row * c4;
-                    *(f32x4*)(Ws + row * ldw + col * 4) = v[u];
-                }
-            }
-        }
-        __syncthreads();
-    }
-
-    f32x16 acc[NT];
-#pragma unroll 1
-    for (int tile = tile0; tile < tile1; ++tile) {
-        const int64_t r = (int64_t)tile * PT + wv * 32 + j;
-        const bool ok = r < p.M;
-        const int64_t row = ok ? r : p.M - 1;                   // rows past the end load the last row and store nothing
-        const int32_t* rl = p.rlist + row * p.rl_stride;
-        const int4 head = *(const int4*)rl;                     // {count, first three list positions}: ready long before the epilogue
-#pragma unroll
-        for (int t = 0; t < NT; ++t)
-#pragma unroll
-            for (int q = 0; q < 16; ++q) acc[t][q] = 0.f;
-        auto load_step = [&](f32x4 (&A)[4], int c) {
-            const int cc = (c < nchunks ? c : 0) * 32;         // wave-uniform
-            const bool first = cc < p.C0;
-            const float* base = first ? p.in0 : p.in1;
-            const int ld = first ? p.ld0 : p.ld1;
-            const float* q = base + row * ld + (first ? cc : cc - p.C0) + h * 16;
-            LOAD_A4(A, q);
-        };
-        f32x4 a0[4], a1[4], a2[4];
-        load_step(a0, 0);
-        if (ST >= 3) load_step(a1, 1);
-        int cur_c = 0;
-#define PC_STEP(CUR, PF)                                                                                              \
-    {                                                                                                                 \
-        load_step(PF, cur_c + ST - 1);                                                                                \
-        {                                                                                                             \
-            const float* wb = wrows + j * ldw + cur_c * 32 + h * 16;                                                  \
-            f32x4 wq[2][NT];                                                                                          \
-            _Pragma("unroll") for (int t = 0; t < NT; ++t) wq[0][t] = *(const f32x4*)(wb + t * 32 * ldw);             \
-            _Pragma("unroll") for (int q = 0; q < 4; ++q) {                                                           \
-                if (q < 3) {                                                                                          \
-                    _Pragma("unroll") for (int t = 0; t < NT; ++t)                                                    \
-                        wq[(q + 1) & 1][t] = *(const f32x4*)(wb + t * 32 * ldw + (q + 1) * 4);                        \
-                }                                                                                                     \
-                _Pragma("unroll") for (int e = 0; e < 4; ++e)                                                         \
-                    _Pragma("unroll") for (int t = 0; t < NT; ++t)                                                    \
-                        acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(wq[q & 1][t][e], CUR[q][e], acc[t], 0, 0, 0);   \
-                if (!GLOBALW) __builtin_amdgcn_sched_barrier(0);                                                      \
-            }                                                                                                         \
-        }                                                                                                             \
-        if (++cur_c == nchunks) break;                                                                                \
-    }
-        if (ST == 2) {
-            for (;;) {
-                PC_STEP(a0, a1)
-                PC_STEP(a1, a0)
-            }
-        } else {
-            for (;;) {
-                PC_STEP(a0, a2)
-                PC_STEP(a1, a0)
-                PC_STEP(a2, a1)
-            }
-        }
-#undef PC_STEP
-        // ---- the other offsets' partial products of this lane's row, k ascending ----
-        const int cnt = ok ? head.x : 0;
-        const float* pbase = p.part + ncol0 + 4 * h;
-        for (int i = 0; __ballot(i < cnt) != 0ull; ++i) {
-            int id = i == 0 ? head.y : (i == 1 ? head.z : head.w);
-            if (i >= 3 && i < cnt) id = rl[1 + i];
-            if (i < cnt) {
-                const float* pp = pbase + (int64_t)id * p.Cout;
-                f32x4 v[NT][4];
-#pragma unroll
-                for (int t = 0; t < NT; ++t)
-#pragma unroll
-                    for (int g = 0; g < 4; ++g) v[t][g] = *(const f32x4*)(pp + t * 32 + 8 * g);
-#pragma unroll
-                for (int t = 0; t < NT; ++t)
-#pragma unroll
-                    for (int g = 0; g < 4; ++g) {
-                        acc[t][4 * g] += v[t][g][0]; acc[t][4 * g + 1] += v[t][g][1];
-                        acc[t][4 * g + 2] += v[t][g][2]; acc[t][4 * g + 3] += v[t][g][3];
-                    }
-            }
-        }
-        if (ok) {
-#pragma unroll
-            for (int t = 0; t < NT; ++t)
-#pragma unroll
-                for (int g = 0; g < 4; ++g) {
-                    const int c = ncol0 + 4 * h + t * 32 + 8 * g;
-                    f32x4 y;
-#pragma unroll
-                    for (int i = 0; i < 4; ++i) y[i] = pg_affine(acc[t][4 * g + i], p.scale, p.shift, c + i);
-                    if (p.res) y += *(const f32x4*)(p.res + r * p.ld_res + c);
-                    *(f32x4*)(p.out + r * p.ld_out + c) = f32x4{pg_act(y[0], p.act), pg_act(y[1], p.act), pg_act(y[2], p.act), pg_act(y[3], p.act)};
-                }
-        }
-    }
-}
-
-#define PAIR_CENTER_ENTRY(NAME, NT, ST, WAVES, GLOBALW)                                                             \
-    __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WAVES, WAVES))) void NAME(const PCParams p) { \
-        extern __shared__ __attribute__((aligned(16))) float pc_smem[];                                             \
-        pair_center_body<NT, ST, GLOBALW>(p, pc_smem);                                                              \
-    }
-PAIR_CENTER_ENTRY(pair_center_kernel_1, 1, 3, 4, false)
-PAIR_CENTER_ENTRY(pair_center_kernel_2, 2, 3, 2, false)
-PAIR_CENTER_ENTRY(pair_center_kernel_3, 3, 2, 3, false)
-PAIR_CENTER_ENTRY(pair_center_kernel_4, 4, 2, 2, false)
-PAIR_CENTER_ENTRY(pair_center_g_kernel_1, 1, 3, 4, true)
-PAIR_CENTER_ENTRY(pair_center_g_kernel_2, 2, 2, 3, true)
-PAIR_CENTER_ENTRY(pair_center_g_kernel_3, 3, 2, 3, true)
-PAIR_CENTER_ENTRY(pair_center_g_kernel_4, 4, 2, 2, true)
-
 // ---- launchers --------------------------------------------------------------------------------
 size_t pair_lists_ws_bytes(int K, int64_t M) {
     const int64_t nblk = cdiv(M, PL_ROWS);
@@ -1252,10 +1068,10 @@ int launch_pair_lists_desc(int n, const sd3d_pair_table_desc* d, void* ws, size_
         }
         if (p_cap <= 0 || (p_cap % PT)) return sd3d_set_error(SD3D_ERR_ARG, "pair_lists_batch: p_cap must be a positive multiple of 128");
         if (d[i].rlist && (d[i].rl_stride < K + 4 || (d[i].rl_stride & 3))) return sd3d_set_error(SD3D_ERR_ARG, "pair_lists_batch: rl_stride must be a multiple of 4, >= K + 4");
-        if (d[i].center >= K) return sd3d_set_error(SD3D_ERR_ARG, "pair_lists_batch: centre offset out of range");
+        if (d[i].center >= 0) return sd3d_set_error(SD3D_ERR_ARG, "pair_lists_batch: center must be -1 or SD3D_PAIR_CHAINED");
         PLTable& T = b.t[b.n++];
         T.nbr = d[i].nbr; T.pos = d[i].pos; T.in_idx = d[i].in_idx; T.tile_k = d[i].tile_k; T.M = M; T.p_cap = p_cap; T.K = K;
-        T.rlist = d[i].rlist; T.out_idx = d[i].out_idx; T.center = d[i].center; T.rl_stride = d[i].rl_stride; T.meta = d[i].meta;
+        T.rlist = d[i].rlist; T.out_idx = d[i].out_idx; T.rl_stride = d[i].rl_stride; T.meta = d[i].meta;
         T.nblk = (int)cdiv(M, PL_ROWS);
         T.blk_cnt = (int32_t*)((char*)ws + off);
         T.totals = T.blk_cnt + (int64_t)T.K * T.nblk;
@@ -1316,26 +1132,14 @@ int launch_pair_conv(const float* in0, int ld0, int C0, const float* in1, int ld
         if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return sd3d_set_error(SD3D_ERR_LAUNCH, "pair_conv: no device");
         n_cu = prop.multiProcessorCount;
     }
-    // SD3D_PAIR_CENTER / SD3D_PAIR_DIRECT / SD3D_PAIR_RL = 0 switch the round-3 paths off one by one (A/B, cross-checks in the tests)
-    static const int center_env = env_flag("SD3D_PAIR_CENTER", 1), direct_env = env_flag("SD3D_PAIR_DIRECT", 1), rl_env = env_flag("SD3D_PAIR_RL", 1);
+    // SD3D_PAIR_DIRECT / SD3D_PAIR_RL = 0 switch the round-3 paths off one by one (A/B, cross-checks in the tests)
+    static const int direct_env = env_flag("SD3D_PAIR_DIRECT", 1), rl_env = env_flag("SD3D_PAIR_RL", 1);
     if ((ld_res & 3) && res) return sd3d_set_error(SD3D_ERR_ARG, "pair_conv: residual row stride must be a multiple of 4 floats");
+    if (center >= 0) return sd3d_set_error(SD3D_ERR_ARG, "pair_conv: center must be -1 or SD3D_PAIR_CHAINED (the dense centre kernel of round 3 left the library: profiles/EXPERIMENTS.md)");
     const bool direct = out_idx != nullptr && direct_env;
-    // centre kernel configuration: NT column tiles of 32 per workgroup, W[centre] rows of the column group in LDS
-    int nt_c = 0, cgs_c = 0;
-    size_t lds_c = 0;
-    if (!direct && rlist && center_env && rl_env && center >= 0 && center < K && (Cout & 31) == 0) {
-        const int subc = Cout / 32;
-        for (int c = subc >= 4 ? 4 : subc; c >= 1; --c) {
-            if (subc % c) continue;
-            const size_t l = (size_t)(32 * c) * (Cin + 4) * sizeof(float);
-            if (l <= 150 * 1024) { nt_c = c; cgs_c = subc / c; lds_c = l; break; }
-        }
-    }
-    const bool fused = nt_c > 0;
     PGParams g;
     g.in0 = in0; g.ld0 = ld0; g.C0 = C0; g.in1 = in1; g.ld1 = ld1; g.in_idx = in_idx; g.tile_k = tile_k; g.wt = wt;
     g.Cin = Cin; g.Cout = Cout; g.part = part;
-    g.skip_center = fused ? 1 : 0;
     g.chained = center == SD3D_PAIR_CHAINED ? 1 : 0;
     {
         static const int nt_env = env_flag("SD3D_PAIR_NT_STORE", -1);          // -1: by the scenes-in-flight hint
@@ -1343,7 +1147,6 @@ int launch_pair_conv(const float* in0, int ld0, int C0, const float* in1, int ld
     }
     g.out_idx = direct ? out_idx : nullptr;
     g.scale = scale; g.shift = shift; g.res = res; g.ld_res = ld_res; g.out = out; g.ld_out = ld_out; g.act = act;
-    const bool pass1 = !(fused && K == 1);                     // a K = 1 table is its own centre: the dense kernel is the whole convolution
     const int sub = (Cout + 31) / 32;
     int nt = sub >= 4 ? 4 : sub;
     if (sub > 4 && sub % 4) { for (int c = 4; c >= 1; --c) if (sub % c == 0) { nt = c; break; } }
@@ -1371,8 +1174,7 @@ int launch_pair_conv(const float* in0, int ld0, int C0, const float* in1, int ld
     if (ws2_env < 0) { const char* e = getenv("SD3D_PAIR_WS2"); ws2_env = e ? atoi(e) : 1; }
     // (measured: level-3 256->256, 1808 tiles: 358 -> 347 us; level-4, 472 tiles: 104 -> 113 us - too few tiles for half the workgroups)
     const bool ws_two = ws_env && !g.chained && ws2_env && !crowded && cgs == 2 && nt == 4 && Cout == 256 && g.n_tiles >= 1024 && w_lds_cg + WS_RANGE_TILES * PT * sizeof(int32_t) + 256 <= 160 * 1024;
-    if (!pass1) {
-    } else if (ws_one || ws_two) {
+    if (ws_one || ws_two) {
         static bool attr_done = false;
         if (!attr_done) {
             (void)hipFuncSetAttribute((const void*)pair_gemm_ws_kernel_1, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
@@ -1434,47 +1236,7 @@ int launch_pair_conv(const float* in0, int ld0, int C0, const float* in1, int ld
         }
     }
     if (direct) {                                              // pass 1 wrote the output rows
-    } else if (fused) {
-        static bool cattr_done = false;
-        if (!cattr_done) {
-            (void)hipFuncSetAttribute((const void*)pair_center_kernel_1, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-            (void)hipFuncSetAttribute((const void*)pair_center_kernel_2, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-            (void)hipFuncSetAttribute((const void*)pair_center_kernel_3, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-            (void)hipFuncSetAttribute((const void*)pair_center_kernel_4, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-            cattr_done = true;
-        }
-        PCParams c;
-        c.in0 = in0; c.ld0 = ld0; c.C0 = C0; c.in1 = in1; c.ld1 = ld1; c.wt = wt + (int64_t)center * Cout * Cin; c.Cin = Cin; c.Cout = Cout;
-        c.M = M; c.rlist = rlist; c.rl_stride = rl_stride; c.part = part; c.scale = scale; c.shift = shift; c.res = res; c.ld_res = ld_res;
-        c.out = out; c.ld_out = ld_out; c.act = act;
-        int per_cu = nt_c == 1 ? 4 : (nt_c == 3 ? 3 : 2);       // the pinned register budgets
-        const int by_lds = (int)((160 * 1024) / (lds_c + 256));
-        per_cu = per_cu < by_lds ? per_cu : by_lds;
-        per_cu = per_cu < 1 ? 1 : per_cu;
-        static const int cslots = env_flag("SD3D_PAIR_CENTER_SLOTS", 0);
-        if (cslots > 0) per_cu = cslots;
-        const int n_tiles_c = (int)cdiv(M, PT);
-        static const int cglobal = env_flag("SD3D_PAIR_CENTER_GLOBALW", 1);
-        if (cglobal) {                                          // one workgroup per row tile, weights from L2 / L1, no LDS
-            const dim3 cgrid((unsigned)n_tiles_c, (unsigned)cgs_c);
-            switch (nt_c) {
-                case 1: hipLaunchKernelGGL(pair_center_g_kernel_1, cgrid, dim3(256), 0, st, c); break;
-                case 2: hipLaunchKernelGGL(pair_center_g_kernel_2, cgrid, dim3(256), 0, st, c); break;
-                case 3: hipLaunchKernelGGL(pair_center_g_kernel_3, cgrid, dim3(256), 0, st, c); break;
-                default: hipLaunchKernelGGL(pair_center_g_kernel_4, cgrid, dim3(256), 0, st, c); break;
-            }
-        } else {
-        int gx = n_cu * per_cu / cgs_c;
-        gx = gx < 1 ? 1 : (gx < n_tiles_c ? gx : n_tiles_c);
-        const dim3 cgrid((unsigned)gx, (unsigned)cgs_c);
-        switch (nt_c) {
-            case 1: hipLaunchKernelGGL(pair_center_kernel_1, cgrid, dim3(256), lds_c, st, c); break;
-            case 2: hipLaunchKernelGGL(pair_center_kernel_2, cgrid, dim3(256), lds_c, st, c); break;
-            case 3: hipLaunchKernelGGL(pair_center_kernel_3, cgrid, dim3(256), lds_c, st, c); break;
-            default: hipLaunchKernelGGL(pair_center_kernel_4, cgrid, dim3(256), lds_c, st, c); break;
-        }
-        }
-    } else if (rlist && rl_env && center < 0) {                 // (a list that leaves the centre out is only complete with the centre kernel)
+    } else if (rlist && rl_env) {               
         PRLParams r;
         r.rlist = rlist; r.rl_stride = rl_stride; r.M = M; r.part = part; r.Cout = Cout; r.scale = scale; r.shift = shift; r.res = res;
         r.ld_res = ld_res; r.out = out; r.ld_out = ld_out; r.act = act;

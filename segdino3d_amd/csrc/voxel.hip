@@ -251,6 +251,7 @@ __global__ __launch_bounds__(256) void mark_levels(const ULParams P, int* __rest
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
     const int l = blockIdx.y + 1;
     if (i >= P.cap) return;
+    if (i == 0 && n <= 0) P.counts[l - 1] = 0;                 // an empty / fully filtered scene: emit_levels has no row n - 1 to write the count from
     int f = 0;
     if (i < n) f = (i == 0) || level_key(P.keys[i], 3 * l) != level_key(P.keys[i - 1], 3 * l);
     flags[(int64_t)blockIdx.y * P.cap + i] = f;

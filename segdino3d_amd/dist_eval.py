@@ -90,11 +90,14 @@ def rank_commands(script: str, argv: Sequence[str], n_ranks: int, port: int, pyt
     return out
 
 
-def kfd_gpu_bdfs(sysfs_root: str = "/sys") -> List[str]:
+def kfd_gpu_bdfs(sysfs_root: str = "/sys", dev_root: str = "/dev") -> List[str]:
     """PCI addresses ('dddd:bb:dd.f') of the GPU agents of this node in KFD order, read from
     `<sysfs>/class/kfd/kfd/topology/nodes/<i>/properties` - no HIP / HSA call, so a launcher parent that uses it stays
     provably GPU-free (`torch.cuda.device_count()` may open /dev/kfd on a ROCm build without amdsmi).  A node is a GPU when its
-    `simd_count` is non-zero (CPU agents report 0); `location_id` = bus << 8 | device << 3 | function, `domain` the PCI domain."""
+    `simd_count` is non-zero (CPU agents report 0); `location_id` = bus << 8 | device << 3 | function, `domain` the PCI domain.
+    sysfs lists every GPU of the HOST even inside a container that was handed only some `/dev/dri/renderD*` nodes: a GPU whose render
+    node (`drm_render_minor`) this process cannot open read-write is not counted - the runtime would not enumerate it either, and a
+    rank started for it would fail at `set_device` after its peers have entered `init_process_group`."""
     base = os.path.join(sysfs_root, "class", "kfd", "kfd", "topology", "nodes")
     try:
         ids = sorted((int(n) for n in os.listdir(base) if n.isdigit()))
@@ -113,17 +116,20 @@ def kfd_gpu_bdfs(sysfs_root: str = "/sys") -> List[str]:
             continue
         if props.get("simd_count", 0) <= 0:
             continue
+        minor = props.get("drm_render_minor", 0)
+        if minor > 0 and not os.access(os.path.join(dev_root, "dri", f"renderD{minor}"), os.R_OK | os.W_OK):
+            continue
         loc, dom = props.get("location_id", 0), props.get("domain", 0)
         out.append(f"{dom:04x}:{(loc >> 8) & 0xff:02x}:{(loc >> 3) & 0x1f:02x}.{loc & 7}")
     return out
 
 
-def visible_gpu_bdfs(sysfs_root: str = "/sys", env=None) -> List[str]:
+def visible_gpu_bdfs(sysfs_root: str = "/sys", env=None, dev_root: str = "/dev") -> List[str]:
     """`kfd_gpu_bdfs` filtered the way the runtime will filter the devices of a child process: ROCR_VISIBLE_DEVICES first (it
     renumbers the agents), then HIP_VISIBLE_DEVICES / CUDA_VISIBLE_DEVICES on the renumbered list.  Only integer lists are
     interpreted (UUID entries leave the list as it is); an empty string hides every GPU, as in the runtime."""
     env = os.environ if env is None else env
-    gpus = kfd_gpu_bdfs(sysfs_root)
+    gpus = kfd_gpu_bdfs(sysfs_root, dev_root)
     for var in ("ROCR_VISIBLE_DEVICES", "HIP_VISIBLE_DEVICES"):
         val = env.get(var)
         if val is None and var == "HIP_VISIBLE_DEVICES":
@@ -287,8 +293,16 @@ class PipelinedRunner:
         so a short list (the driver's 20 steps on 4 streams x batches of 4: five scenes per stream, forwards of 3 + 2) keeps all
         streams busy to the end instead of leaving one stream a whole extra batch.  -> [[scene ids of a forward, ...] per stream]"""
         plan = []
+        forced = getattr(self, "forward_sizes", None)            # e.g. [2, 3]: every stream cuts its scenes into forwards of these sizes, cyclically
         for w in range(self.n):
             mine = list(range(w, n_scenes, self.n))
+            if forced:
+                cuts, k = [0], 0
+                while cuts[-1] < len(mine):
+                    cuts.append(min(len(mine), cuts[-1] + max(1, int(forced[k % len(forced)]))))
+                    k += 1
+                plan.append([mine[cuts[k]:cuts[k + 1]] for k in range(len(cuts) - 1)])
+                continue
             nb = (len(mine) + self.batch - 1) // self.batch
             cuts = [len(mine) * k // nb for k in range(nb + 1)] if nb else [0]
             plan.append([mine[cuts[k]:cuts[k + 1]] for k in range(nb)])

@@ -236,7 +236,6 @@ _WS3 = _PerThread()       # partial products of pair_conv
 _WS4 = _PerThread()       # pair_lists scratch
 _WS5 = _PerThread()       # expand_masks bit table
 _WS6 = _PerThread()       # attention key-split partial states
-_WS7 = _PerThread()       # slab_conv: per-workgroup rulebook scratch (+ partial slabs of the offset split)
 
 
 # --------------------------------------------------------------------------------------------
@@ -589,9 +588,9 @@ def clear_split_cache():
 
 class PairLists:
     """Offset-major layout of one neighbour table (csrc/pair_gemm.hip): shared by every convolution that uses it.
-    Optional round-3 products (sd3d_pair_lists_desc): `rlist` [M, rl_stride] per-row partial-product lists, `center` = the
-    offset that pairs every row with itself (its product is made by the dense centre kernel, never stored), `direct` = every
-    output row has exactly one pair (`out_idx` is then built and pass 1 writes the output rows itself)."""
+    Optional products (sd3d_pair_lists_desc): `rlist` [M, rl_stride] per-row partial-product lists, `center` = -1 (plain lists) or
+    PAIR_CHAINED (mirror offsets + centre share one partial product), `direct` = every output row has exactly one pair (`out_idx`
+    is then built and pass 1 writes the output rows itself)."""
     __slots__ = ("pos", "in_idx", "tile_k", "p_cap", "K", "M", "out_idx", "rlist", "rl_stride", "center", "direct")
 
     def __init__(self, pos, in_idx, tile_k, p_cap, K, M, rlist=None, rl_stride=0, center=-1, out_idx=None, direct=False):
@@ -602,7 +601,7 @@ class PairLists:
 
 def pair_lists(nbr, n_pairs, center=-1, direct=False):
     """nbr int32 [K, M]; n_pairs = number of entries >= 0 (host int, e.g. from kernel_map's pair counter).  `center` / `direct`:
-    see PairLists (the caller vouches for them: a stride-1 table of a voxel set onto itself / a one-pair-per-row table)."""
+    see PairLists (the caller vouches for them: an odd stride-1 table of a voxel set onto itself / a one-pair-per-row table)."""
     return pair_lists_batch([(nbr, n_pairs, center, direct)])[0]
 
 
@@ -775,50 +774,6 @@ def linear_group(jobs, force_small=False):
         if rc:
             _lib.check(rc, "linear_group")
     return outs
-
-
-def slab_conv_supported(K, Cin, Cout, M, n_pairs) -> bool:
-    return _lib.load().sd3d_slab_conv_ws_bytes(K, Cin, Cout, M, int(n_pairs)) > 0
-
-
-def slab_conv(x, wt, nbr, n_pairs=None, x2=None, scale=None, shift=None, res=None, act=None, out=None):
-    """Same contract as gather_gemm(x, wt, nbr=...): output-stationary sparse convolution straight from the neighbour
-    table (csrc/slab_conv.hip).  `n_pairs` (entries >= 0 of `nbr`) only guides the launch geometry."""
-    lib = _lib.load()
-    K, Cout, Cin = wt.shape
-    if nbr.shape[0] != K:
-        raise ValueError(f"weights have {K} offsets, the neighbour table {nbr.shape[0]}")
-    M = nbr.shape[1]
-    p0, ld0 = _rows(x, "x")
-    C0 = x.shape[1]
-    p1, ld1 = (None, 0)
-    if x2 is not None:
-        p1, ld1 = _rows(x2, "x2")
-        if C0 + x2.shape[1] != Cin:
-            raise ValueError(f"concat channels {C0}+{x2.shape[1]} != Cin {Cin}")
-    elif C0 != Cin:
-        raise ValueError(f"input channels {C0} != Cin {Cin}")
-    if out is None:
-        out = torch.empty(M, Cout, dtype=torch.float32, device=x.device)
-    po, ldo = _rows(out, "out")
-    pr, ldr = (None, 0)
-    if res is not None:
-        pr, ldr = _rows(res, "res")
-    if n_pairs is None:
-        n_pairs = K * M // 2
-    nb = lib.sd3d_slab_conv_ws_bytes(K, Cin, Cout, M, int(n_pairs))
-    if nb == 0:
-        raise ValueError(f"slab_conv: shape K={K} Cin={Cin} Cout={Cout} is not supported")
-    ws = _WS7.get(nb, x.device)
-    hook = GG_HOOK
-    if hook is not None:
-        hook.before(dict(K=K, Cin=Cin, Cout=Cout, M=M, nbr=nbr, slab=True))
-    _lib.check(lib.sd3d_slab_conv(p0, ld0, C0, p1, ld1, _ptr(nbr, torch.int32, "nbr"), int(n_pairs), _ptr(wt, torch.float32, "wt"),
-                                  K, Cin, Cout, M, _ptr(scale, torch.float32, "scale"), _ptr(shift, torch.float32, "shift"), pr, ldr,
-                                  po, ldo, ACT[act], ws.data_ptr(), ws.numel(), _stream()), "slab_conv")
-    if hook is not None:
-        hook.after()
-    return out
 
 
 def _dense_linear(x, wt, x2, shift, res, act):
@@ -1419,7 +1374,11 @@ class _HostPool:
             except Exception:  # noqa: BLE001 - interpreter shutdown
                 pass
 
-    def __init__(self, max_free_bytes=2 << 30):
+    def __init__(self, max_free_bytes=None):
+        # SD3D_HOST_POOL_BYTES: most freed host bytes the pool keeps for the life of the process (default 512 MiB = five 90 MB mask
+        # arrays, one per scene in flight plus one; 0 switches the recycling off)
+        if max_free_bytes is None:
+            max_free_bytes = int(_os.environ.get("SD3D_HOST_POOL_BYTES", str(512 << 20)))
         self.free, self.lock, self.max_free = [], threading.Lock(), max_free_bytes
 
     def _give_back(self, buf):

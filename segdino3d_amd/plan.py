@@ -203,6 +203,7 @@ class LayerPlan:
                 raise RuntimeError(f"neighbour tables {missing} have no pair lists (SceneMaps.prepare not called for them)")
         if getattr(maps, "events", None):
             maps.join()                                          # (tables no layer read: nothing of the side stream outlives this call unordered)
+        getattr(maps, "release_side", lambda: None)()            # the side stream's pool may reuse the tables' blocks only behind these layers
         o = int(offs[self.out_id])
         n = int(rows[self.out_id])
         return arena[o:o + n * self.out_ch].view(n, self.out_ch)

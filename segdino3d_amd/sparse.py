@@ -73,9 +73,25 @@ EXACT_PAIR_CAPACITY = "auto" if _ep == "auto" else (_ep == "1")
 WORST_CASE_MAX_VOXELS = int(os.environ.get("SD3D_WORST_CASE_MAX_VOXELS", "250000"))
 
 
-def exact_pair_capacity(n_vox0: int) -> bool:
+# Footprint of the worst-case sizing (grow-only scratch per (thread, stream)): the 5^3 stem's partial products are 125 x V x 32 x 4 B =
+# 16 KB per level-0 voxel (2.2 GB at 138 k voxels, 4 GB at 250 k) plus ~0.1 GB of list entries.  "auto" takes it only while that stays
+# under WORST_CASE_MEM_FRACTION of the device's memory (2 %: 5.8 GB of an MI355X's 288 GB - the voxel limit above is the tighter one
+# there; on a 64 GB device scenes above 80 k voxels keep the exact sizes and the second read-back).
+WORST_CASE_MEM_FRACTION = float(os.environ.get("SD3D_WORST_CASE_MEM_FRACTION", "0.02"))
+_TOTAL_MEM = {}
+
+
+def _device_memory(device) -> int:
+    idx = torch.cuda.current_device() if device is None or device.index is None else device.index
+    if idx not in _TOTAL_MEM:
+        _TOTAL_MEM[idx] = int(torch.cuda.get_device_properties(idx).total_memory)
+    return _TOTAL_MEM[idx]
+
+
+def exact_pair_capacity(n_vox0: int, device=None) -> bool:
     if EXACT_PAIR_CAPACITY == "auto":
-        return ops.scenes_in_flight_now() > 1 or n_vox0 > WORST_CASE_MAX_VOXELS
+        return (ops.scenes_in_flight_now() > 1 or n_vox0 > WORST_CASE_MAX_VOXELS
+                or 125 * 32 * 4 * n_vox0 > WORST_CASE_MEM_FRACTION * _device_memory(device))
     return bool(EXACT_PAIR_CAPACITY)
 
 
@@ -83,11 +99,6 @@ def exact_pair_capacity(n_vox0: int) -> bool:
 # needs only half its hash probes.  SD3D_MIRRORED_MAPS=0 probes every offset (cross-check).
 MIRRORED_MAPS = os.environ.get("SD3D_MIRRORED_MAPS", "1") != "0"
 
-# SD3D_PAIR_CENTER=1: stride-1 tables hand their centre offset to the dense centre kernel (csrc/pair_gemm.hip pair_center_kernel:
-# no partial product stored for the centre, pass 2 fused behind the dense GEMM).  Parity-green and bit-reproducible, but measured
-# SLOWER than pass 1 over all offsets + the row-list pass 2 everywhere except the level-0 3^3 layers (137 vs 140 us; level 1
-# 96 -> 96: 293 vs 246 us, level 3 256 -> 256: 379 vs 340, level 4: 164 vs 105; profiles/r03_pair_paths.md), so it is opt-in.
-CENTER_KERNEL = os.environ.get("SD3D_PAIR_CENTER", "0") == "1"
 # SD3D_PAIR_CHAIN=0: plain offset-major lists for the 3^3 tables too.  Default: CHAINED lists in evaluation (csrc/pair_gemm.hip: the
 # entries of an output row's mirror offsets {k, K-1-k} and its centre share ONE partial product - 27-44 % fewer partial rows written
 # by pass 1 and read by pass 2).  Training keeps the plain lists (the weight-gradient kernels walk them offset by offset).
@@ -190,7 +201,7 @@ class SceneMaps:
         read-back) only the FIRST table of `same` - the stem's - is built on this stream; the others go to the thread's side stream
         in the order the U-Net needs them, `self.events[key]` is recorded behind each group."""
         same = list(dict.fromkeys((lvl, k) for (lvl, k) in same if ("same", lvl, k) not in self.density))
-        exact = exact_pair_capacity(self.n_vox[0]) or not ops.PAIR_CONV
+        exact = exact_pair_capacity(self.n_vox[0], self.device) or not ops.PAIR_CONV
         if fork and FORK_JOIN and not exact and len(same) > 1 and not self.pairs:
             return self._prepare_forked(same, list(strides), chained)
         self._build_tables(same, strides, chained, exact)
@@ -219,6 +230,7 @@ class SceneMaps:
         if not g_same and not g_strides:
             return
         side = ops.side_streams(1, self.device)[0]
+        self._side_used = True
         with ops.use_stream(side):
             side.wait_event(self._fork_ev)
             if any(t[0] in self._hash for t in g_same):
@@ -236,6 +248,16 @@ class SceneMaps:
             return False
         self._fork_side(*self._late.pop(0))
         return True
+
+    def release_side(self):
+        """After the last kernel that reads a side-built table is enqueued (LayerPlan.run calls it): the side stream waits for
+        everything the scene's stream holds so far.  The tables come out of the SIDE stream's allocator pool but are read by the
+        scene's stream; when this SceneMaps dies their blocks return to that pool at once, and without this edge only the next
+        scene's fork event - recorded on whatever stream THAT forward runs on - would keep later side-stream work from overwriting
+        them under the U-Net kernels that still read them."""
+        if getattr(self, "_side_used", False):
+            ops.side_streams(1, self.device)[0].wait_event(ops.stream_event())
+            self._side_used = False
 
     def join(self):
         """The calling stream waits for the side stream's table building (no-op without a fork)."""
@@ -265,10 +287,10 @@ class SceneMaps:
         for (lvl, k), c in zip(same, host):
             self.density[("same", lvl, k)] = (c / max(1, k ** 3 * self.n_vox[lvl])) if exact else None
             if ops.PAIR_CONV:                                   # stride-1 table of the level onto itself: offset k^3 // 2 pairs every row with itself
-                if chained and PAIR_CHAIN and k == 3 and lvl in PAIR_CHAIN_LEVELS and not CENTER_KERNEL:
+                if chained and PAIR_CHAIN and k == 3 and lvl in PAIR_CHAIN_LEVELS:
                     center = ops.PAIR_CHAINED                    # mirror groups + centre share partial products (evaluation)
                 else:
-                    center = (k ** 3) // 2 if (k % 2 and CENTER_KERNEL) else -1
+                    center = -1
                 todo.append((("same", lvl, k), self._same[(lvl, k)], c, center, False))
         for lvl in strides:
             # every fine voxel has exactly one parent: P = V_fine pairs in both directions

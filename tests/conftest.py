@@ -13,6 +13,8 @@ if GOLDEN not in sys.path:
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    config.addinivalue_line("markers", "experimental: exercises libsegdino3d_hip_experimental.so (kernels outside the product library; "
+                            "skipped when it is not built)")
 
 
 @pytest.fixture(scope="session")

@@ -7,8 +7,8 @@ import re
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def _prototypes():
-    text = open(os.path.join(ROOT, "include", "segdino3d_hip.h")).read()
+def _prototypes(header="segdino3d_hip.h"):
+    text = open(os.path.join(ROOT, "include", header)).read()
     text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
     protos = {}
     for m in re.finditer(r"\b(int|size_t|const char\*)\s+(sd3d_\w+)\s*\(([^;]*?)\)\s*;", text, flags=re.S):
@@ -45,6 +45,29 @@ def test_library_loads_and_exports_every_symbol():
     assert lib.sd3d_abi_version() == _lib.ABI_VERSION
     assert lib.sd3d_selftest_host() == 0, lib.sd3d_last_error()
     assert lib.sd3d_sort_ws_bytes(150000) > 0 and lib.sd3d_unique_ws_bytes(1000) > 0
+
+
+def test_experimental_library_is_separate_from_the_product_library():
+    """Kernels that are not on the product path live in their own library with their own header: the product library exports none
+    of them, nothing under segdino3d_amd/ (but the binding module itself) imports the binding, and header == binding == exports."""
+    import subprocess
+    from segdino3d_amd import _lib, experimental
+    protos = _prototypes("segdino3d_hip_experimental.h")
+    assert set(protos) == set(experimental.SIGNATURES) and not (set(protos) & set(_lib.SIGNATURES))
+    for name, (ret, args) in protos.items():
+        res, argtypes = experimental.SIGNATURES[name]
+        assert list(argtypes) == [_ctype_of(a) for a in args], name
+    exported = subprocess.run(["nm", "-D", "--defined-only", _lib.LIB_PATH], capture_output=True, text=True, check=True).stdout
+    for name in protos:
+        assert f" {name}\n" not in exported, f"{name} must not be part of the product library"
+    pkg = os.path.join(ROOT, "segdino3d_amd")
+    for fn in os.listdir(pkg):
+        if fn.endswith(".py") and fn != "experimental.py":
+            assert "experimental" not in open(os.path.join(pkg, fn)).read(), f"segdino3d_amd/{fn} must not depend on the experimental library"
+    if experimental.available():
+        lib = experimental.load()
+        for name in protos:
+            assert hasattr(lib, name), name
 
 
 def test_product_path_refuses_cpu_tensors():

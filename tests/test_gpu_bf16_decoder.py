@@ -127,7 +127,8 @@ def test_bf16_decoder_stays_close_to_fp32_decoder():
     assert same_cls >= 0.85, same_cls          # random-weight logits over 198 classes are nearly tied; a trained head separates them
 
 
-def test_bf16_decoder_against_reference_under_autocast():
+@pytest.mark.parametrize("path", ["op_by_op", "rowchain16", "rowchain4"])
+def test_bf16_decoder_against_reference_under_autocast(path, monkeypatch):
     """Pinned to the REFERENCE: `tests/golden/decoder_bf16_s500_q32.npz` holds the reference decoder's outputs under
     `torch.autocast("cpu", bfloat16)` (what `train_engine_3d.py:88-100` does with `cfg.amp`) and its own fp32 outputs, on the
     inputs and weights of the fp32 fixture `decoder_s500_q32` (generator: tests/golden/make_golden_bf16.py).
@@ -145,6 +146,11 @@ def test_bf16_decoder_against_reference_under_autocast():
     dec.compute_dtype = "bf16"
     ids = g32["query_ids"].long()
     assert torch.equal(ids, gb["query_ids"].long())
+    # every decoder path (the row-chain paths keep their row-local Linears in fp32 and take bf16 operands in the attention contractions)
+    from segdino3d_amd import decoder as D
+    monkeypatch.setattr(D, "FUSED_DECODER", path != "op_by_op")
+    monkeypatch.setattr(D, "FUSED_NARROW", path == "rowchain4")
+    assert dec._fusable(len(ids)) == {"op_by_op": 0, "rowchain16": 16, "rowchain4": 4}[path]
     t = lambda a: a.to(d)
     out = dec([t(g32["x"])], [t(g32["pos"])], [t(g32["pos_wo"])], [t(g32["x"][ids])], [t(g32["pos"][ids])], [t(g32["q2d_feat"])],
               [t(g32["q2d_pos"])], [(t(g32["lo"]), t(g32["hi"]))])

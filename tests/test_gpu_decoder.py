@@ -155,6 +155,26 @@ def _mask_agree(a, b, thr=0.0):
     return ((a > thr) == (b > thr)).float().mean().item()
 
 
+# The three evaluation paths of the decoder (segdino3d_amd/decoder.py): op by op (`_forward_scene`), the row-chain path on 16-row
+# tiles (csrc/rowchain.hip) and on 4-row tiles (csrc/rowchain_narrow.hip).  Every reference golden runs on all three.
+DECODER_PATHS = ["op_by_op", "rowchain16", "rowchain4"]
+
+
+def _set_decoder_path(monkeypatch, path, dec, rows):
+    """Force one decoder path; returns False when the decoder variant has no row-chain path (it runs op by op whatever the switch)."""
+    from segdino3d_amd import decoder as D
+    monkeypatch.setattr(D, "FUSED_DECODER", path != "op_by_op")
+    monkeypatch.setattr(D, "FUSED_NARROW", path == "rowchain4")
+    tile = dec._fusable(rows)
+    if path == "op_by_op":
+        assert tile == 0
+        return True
+    if tile == 0:
+        return False
+    assert tile == (16 if path == "rowchain16" else 4), (path, tile)
+    return True
+
+
 # largest accepted fraction of query rows outside the tolerance at a layer after the first mask feedback, per fixture: the
 # measured value is 0 rows on every fixture (profiles/r02_parity_numbers.md); a fixture whose near-zero logit flips a mask bit
 # on some future kernel change would list its measured fraction here
@@ -166,12 +186,15 @@ BAD_ROWS_MAX = {"decoder_s64_q64": 0.0, "decoder_s96_q16": 0.0, "decoder_s500_q3
     ("decoder_v2_s48", dict(num_instance_classes=18, num_semantic_classes=20, in_channels=32, normalize_box_prediction=False),
      dict(in_channels=32, n_inst=18, n_sem=20, size_embed_scale=0.05)),
     ("decoder_fourier_s48", dict(pos_type="fourier", box_modulate_ca=False), dict(fourier=True))])
-def test_decoder_matches_reference_golden(name, kw, sdkw):
+@pytest.mark.parametrize("path", DECODER_PATHS)
+def test_decoder_matches_reference_golden(name, kw, sdkw, path, monkeypatch):
     d = dev()
     g = load(name)
     dec, _ = _build_decoder(kw, sdkw)
     dec.to(d)
     ids = g["query_ids"].long()
+    if not _set_decoder_path(monkeypatch, path, dec, len(ids)):
+        pytest.skip(f"{name}: this decoder variant has no row-chain path (it runs op by op, covered by the op_by_op case)")
     t = lambda x: x.to(d)
     out = dec([t(g["x"])], [t(g["pos"])], [t(g["pos_wo"])], [t(g["x"][ids])], [t(g["pos"][ids])], [t(g["q2d_feat"])],
               [t(g["q2d_pos"])], [(t(g["lo"]), t(g["hi"]))])
@@ -245,9 +268,11 @@ class _StoredBackbone(torch.nn.Module):
 
 @pytest.mark.parametrize("name,query_num,box", [("arch_qall", -1, True), ("arch_q40", 40, True), ("arch_qall_nobox", -1, False),
                                                 ("arch_qall_widebox", -1, True), ("arch_q40_widebox", 40, True)])
-def test_architecture_matches_reference_golden(name, query_num, box):
+@pytest.mark.parametrize("path", DECODER_PATHS)
+def test_architecture_matches_reference_golden(name, query_num, box, path, monkeypatch):
     """The *_widebox fixtures grow the predicted boxes (a bias on the size heads, make_golden.golden_architecture) so that
-    filter_outofbox_points keeps ~28 % of the mask points instead of < 1 %: the filter is exercised on real content."""
+    filter_outofbox_points keeps ~28 % of the mask points instead of < 1 %: the filter is exercised on real content.
+    Runs on every decoder path (op by op, row chain on 16-row and on 4-row tiles)."""
     import segdino3d_amd as seg
     from segdino3d_amd.gtypes import GD3DTarget
     d = dev()
@@ -264,6 +289,8 @@ def test_architecture_matches_reference_golden(name, query_num, box):
     model.decoder.load_state_dict({k[len("decoder."):]: v for k, v in sd.items()})
     model.to(d)
     model.backbone.f, model.backbone.p = g["sp_feat"].to(d), g["sp_pos"].to(d)
+    n_rows = g["sp_feat"].shape[0] if query_num < 0 else query_num
+    assert _set_decoder_path(monkeypatch, path, model.decoder, n_rows), "the SegDINO3D prototype decoder has a row-chain path"
     tgt = GD3DTarget(masks=g["gt_masks"], extra_features=dict(super_point_masks=g["superpoints"].long(),
                      query2d_feats=g["q2d_feat"], query2d_pos=g["q2d_pos"])).to(d)
     res = model([g["points"].to(d)], [tgt])
@@ -289,10 +316,30 @@ def test_architecture_matches_reference_golden(name, query_num, box):
     aligned = len(ia) / max(1, len(ref_keys))
     twins = sum((Counter(ref_keys) & Counter(got_keys)).values()) / max(1, ref_masks.shape[0])
     in_place = (pd.instance_labels == g["inst_labels"].numpy()).mean()
-    print(f"{name}: {int(ref_masks.sum())} mask points in the reference, {int(got_masks.sum())} here; rows aligned in order {aligned:.4f}, "
-          f"with an identical (label, mask) twin anywhere {twins:.4f}, equal labels in place {in_place:.4f}")
+    bits_in_place = float((got_masks == ref_masks).mean())
+    print(f"{name} [{path}]: {int(ref_masks.sum())} mask points in the reference, {int(got_masks.sum())} here; rows aligned in order {aligned:.4f}, "
+          f"with an identical (label, mask) twin anywhere {twins:.4f}, equal labels in place {in_place:.4f}, mask bits equal in place {bits_in_place:.6f}")
     assert aligned >= 0.99 and twins >= 0.99, (aligned, twins)
     np.testing.assert_allclose(got_scores[ib], ref_scores[ia], rtol=5e-3, atol=1e-5)
+    # What the alignment lets through is bounded: a reference row outside the aligned set must be a DISPLACED row - its
+    # (label, point mask) twin exists here and its score moved by no more than one thresholded superpoint moves a mask score
+    # (~1e-2, see above) - or, failing that, one of at most 0.5 % of the rows; and the in-place agreement keeps a floor: a displaced
+    # row shifts the rows between its two places by one, it does not scramble the table.
+    got_by_key = {}
+    for i, k in enumerate(got_keys):
+        got_by_key.setdefault(k, []).append(i)
+    lost, worst_move = 0, 0.0
+    for i in sorted(set(range(len(ref_keys))) - set(ia.tolist())):
+        cand = got_by_key.get(ref_keys[i], [])
+        if not cand:
+            lost += 1
+            continue
+        worst_move = max(worst_move, min(abs(float(got_scores[c]) - float(ref_scores[i])) for c in cand))
+    print(f"{name} [{path}]: {len(ref_keys) - len(ia)} reference rows outside the alignment, {lost} without a twin, largest score move of a displaced row {worst_move:.2e}")
+    assert worst_move <= 2e-2, worst_move
+    assert lost <= 0.005 * len(ref_keys), lost
+    assert bits_in_place >= 0.995, bits_in_place
+    assert in_place >= 0.9, in_place
     box_ok = np.isclose(pd.instance_boxes[ib], g["inst_boxes"].numpy()[ia], rtol=5e-3, atol=5e-3).all(axis=1).mean()
     assert box_ok > 0.99, box_ok
     assert (pd.pts_semantic_mask[0] != g["sem_mask"].numpy()).mean() < 5e-3
@@ -302,11 +349,37 @@ def test_architecture_matches_reference_golden(name, query_num, box):
     from collections import Counter as _C
     diff = _C(pd.sort_and_mask[0].cpu().tolist()) - _C(g["topk_idx"].tolist())
     assert sum(diff.values()) <= 2, diff
+    # STRICT mode (the asserts of rounds 1-3, before the summation order of the attention merge / the row chain changed): where a
+    # path reproduces the reference's row ORDER exactly, everything is compared in place with no alignment at all.
+    if aligned == 1.0 and len(ref_keys) == len(got_keys):
+        np.testing.assert_allclose(got_scores, ref_scores, rtol=5e-3, atol=1e-5)
+        assert (pd.instance_labels == g["inst_labels"].numpy()).all()
+        assert bits_in_place == 1.0
+        STRICT_SEEN.add((name, path))
 
 
-def test_plain_decoder_matches_reference_golden():
-    """Non-positional decoder variant of the Baseline_ScanNet200 prototype."""
+STRICT_SEEN = set()
+
+
+def test_architecture_goldens_hold_in_place_on_the_op_by_op_path():
+    """Runs after the parametrised golden test (same module, definition order): on the op-by-op decoder path at least three of the
+    five architecture fixtures must have matched the reference IN PLACE, row for row (no alignment) - so the aligned comparison
+    above is a tolerance for near-tied scores, not a way of passing whatever comes out."""
+    if not any(p == "op_by_op" for _, p in STRICT_SEEN) and not STRICT_SEEN:
+        pytest.skip("the parametrised architecture golden test did not run in this session")
+    n = sum(1 for _, p in STRICT_SEEN if p == "op_by_op")
+    print(f"architecture fixtures reproduced in place: {sorted(STRICT_SEEN)}")
+    assert n >= 3, sorted(STRICT_SEEN)
+
+
+@pytest.mark.parametrize("path", DECODER_PATHS)
+def test_plain_decoder_matches_reference_golden(path, monkeypatch):
+    """Non-positional decoder variant of the Baseline_ScanNet200 prototype.  It has no row-chain path (`_fusable` = 0 whatever the
+    switches say): the three cases pin that the switches do not change what this variant computes."""
+    from segdino3d_amd import decoder as D
     from segdino3d_amd.decoder import ScanNetQueryDecoder
+    monkeypatch.setattr(D, "FUSED_DECODER", path != "op_by_op")
+    monkeypatch.setattr(D, "FUSED_NARROW", path == "rowchain4")
     from test_oracle_golden import plain_decoder_state_dict
     d = dev()
     g = load("decoder_plain_s40")
@@ -317,6 +390,7 @@ def test_plain_decoder_matches_reference_golden():
     sd = plain_decoder_state_dict()
     dec.load_state_dict({k[len("decoder."):]: v for k, v in sd.items()})
     dec.to(d)
+    assert dec._fusable(g["x"].shape[0]) == 0
     out = dec([g["x"].to(d)], None, None, [g["x"].to(d)], None, None, None, None)
     assert len(out["aux_outputs"]) == 5 and out["centers"][0] is None
 

@@ -1,10 +1,8 @@
 """The round-3 paths of the pair-major sparse convolution (csrc/pair_gemm.hip, entry sd3d_pair_conv_ex) against each other and
 against a float64 model of `ME.MinkowskiConvolution(Transpose) + BN + ReLU + residual` (`minkunet.py:135-192, 234-250`):
-  * centre kernel: a stride-1 table's centre offset as a dense GEMM whose epilogue adds the other offsets' partial products
-    (pass 1 skips the centre run; no partial product stored for it),
-  * per-row partial-product lists in pass 2 (down convolutions),
+  * per-row partial-product lists in pass 2 (stride-1 tables, down convolutions),
   * direct epilogue: one pair per output row (transposed k2s2 convolutions) - pass 1 writes the output rows, no pass 2.
-The three older combinations (pos-based pass 2 over all offsets) stay reachable by stripping the optional products from a
+The older combination (pos-based pass 2 over all offsets) stays reachable by stripping the optional products from a
 PairLists object, so every path is compared in ONE process on the same rulebook.  fp32 tolerance 2e-6 of the row magnitude
 (the paths differ in summation order only); each path must be bit-reproducible run to run."""
 
@@ -59,14 +57,11 @@ def _ref64(x, w, nbr, scale, shift, res, act):
     return torch.relu(out) if act == "relu" else out
 
 
-def _case(maps, key, cin, cout, split=0, use_res=True, act="relu", seed=0, center=False):
-    from segdino3d_amd import ops
+def _case(maps, key, cin, cout, split=0, use_res=True, act="relu", seed=0):
     d = maps.device
     tab = maps.conv_table(*key)
     nbr, pl = tab["nbr"], tab["pairs"]
     K, M = nbr.shape
-    if center:                                                   # the same table with its centre offset handed to the dense kernel
-        pl = ops.pair_lists(nbr, int((nbr >= 0).sum()), center=K // 2)
     n_in = int(nbr.max().item()) + 1
     g = torch.Generator().manual_seed(seed)
     x = torch.randn(n_in, cin, generator=g).to(d)
@@ -97,49 +92,42 @@ def _close(a, ref, tol=2e-6):
     (("same", 0, 3), 96, 96, 0), (("same", 0, 3), 128, 96, 96), (("same", 1, 3), 32, 32, 0), (("same", 2, 3), 64, 64, 0),
     (("same", 2, 3), 192, 128, 128), (("same", 3, 3), 256, 256, 0), (("same", 3, 3), 384, 256, 256), (("same", 4, 3), 256, 256, 0),
     (("same", 0, 5), 288, 32, 0), (("same", 1, 3), 160, 96, 96)])
-def test_centre_kernel_matches_the_all_offsets_path(scene_maps, key, cin, cout, split):
-    c = _case(scene_maps, key, cin, cout, split, center=True)
+def test_stride1_row_lists_match_pos_based_pass2(scene_maps, key, cin, cout, split):
+    """The stride-1 tables (plain lists): per-row lists = the row's neighbours in offset order; pass 2 over them equals the pos-based
+    pass 2 of rounds 1-2 bit for bit; both sit at fp32 round-off of the float64 model."""
+    c = _case(scene_maps, key, cin, cout, split)
     pl = c["pl"]
-    assert pl.center == pl.K // 2 and pl.rlist is not None
-    # the centre offset really pairs every row with itself, and the centre run recorded in tile_k covers exactly those pairs
-    assert torch.equal(c["nbr"][pl.center], torch.arange(pl.M, dtype=torch.int32, device=pl.pos.device))
-    meta = pl.tile_k[pl.p_cap // 128: pl.p_cap // 128 + 3].tolist()
-    assert meta[2] == (pl.M + 127) // 128 and bool((pl.tile_k[meta[1]:meta[1] + meta[2]] == pl.center).all())
-    assert int(pl.pos[pl.center][0]) == meta[1] * 128
-    # per-row lists: count = neighbours without the centre, entries = pos[k][r] in offset order
-    cnt_ref = (c["nbr"] >= 0).sum(dim=0) - 1
+    assert pl.center == -1 and pl.rlist is not None
+    cnt_ref = (c["nbr"] >= 0).sum(dim=0)
     assert torch.equal(pl.rlist[:, 0].long(), cnt_ref)
     r = int(cnt_ref.argmax())
-    ks = [k for k in range(pl.K) if k != pl.center and int(c["nbr"][k][r]) >= 0]
+    ks = [k for k in range(pl.K) if int(c["nbr"][k][r]) >= 0]
     assert pl.rlist[r, 1:1 + len(ks)].tolist() == [int(pl.pos[k][r]) for k in ks]
-    fused = _run(c, pl)
-    again = _run(c, pl)
-    assert torch.equal(fused, again), "the centre path must be bit-reproducible"
-    old = _run(c, _variant(pl, rlist=None, center=-1))                     # round-1/2 path: pass 1 over all offsets + pos-based pass 2
-    plain = scene_maps.conv_table(*key)["pairs"]                            # the product path: all offsets + row-list pass 2
-    assert plain.center == -1 and plain.rlist is not None
-    rl = _run(c, plain)
+    rl = _run(c, pl)
+    assert torch.equal(rl, _run(c, pl)), "the convolution must be bit-reproducible"
+    old = _run(c, _variant(pl, rlist=None))                                 # round-1/2 path: pass 1 over all offsets + pos-based pass 2
     assert torch.equal(rl, old), "same offsets in the same order: the row-list pass 2 must equal the pos-based one bit for bit"
     ref = _ref64(c["x"], c["w"], c["nbr"], c["scale"], c["shift"], c["res"], c["act"])
-    e_f, e_o = _close(fused, ref), _close(old, ref)
-    print(f"{key} {cin}->{cout}: centre path err {e_f:.2e}, all-offsets path err {e_o:.2e} (of the row magnitude)")
-    assert e_f < 2e-6 and e_o < 2e-6
+    e = _close(rl, ref)
+    print(f"{key} {cin}->{cout}: err {e:.2e} of the row magnitude")
+    assert e < 2e-6
 
 
-def test_identity_table_runs_on_the_centre_kernel_alone():
-    """K = 1 (a 1x1 convolution as a pair table, train_ops identity lists): the centre kernel is the whole convolution."""
+def test_identity_table_as_a_pair_table():
+    """K = 1 (a 1x1 convolution as a pair table, train_ops identity lists)."""
     from segdino3d_amd import ops
     d = dev()
     M = 5000
     nbr = torch.arange(M, dtype=torch.int32, device=d).view(1, M)
-    pl = ops.pair_lists(nbr, M, center=0)
+    pl = ops.pair_lists(nbr, M)
     g = torch.Generator().manual_seed(1)
     x, w = torch.randn(M, 64, generator=g).to(d), (torch.randn(1, 96, 64, generator=g) * 0.1).to(d)
     res = torch.randn(M, 96, generator=g).to(d)
     y = ops.pair_conv(x, w, pl, res=res, act="relu")
     ref = torch.relu(x.double() @ w[0].double().t() + res.double())
     assert _close(y, ref) < 2e-6
-    assert bool((pl.rlist[:, 0] == 0).all())
+    with pytest.raises(Exception):                              # the dense centre kernel of round 3 is gone: a centre offset is refused
+        ops.pair_lists(nbr, M, center=0)
 
 
 @pytest.mark.parametrize("lvl,cin,cout", [(0, 32, 32), (1, 32, 64), (2, 64, 128), (3, 128, 256)])

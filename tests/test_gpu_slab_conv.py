@@ -1,4 +1,5 @@
-"""Output-stationary sparse convolution (csrc/slab_conv.hip, C entry sd3d_slab_conv) against a float64 gather + matmul model
+"""EXPERIMENTAL library (`make -C segdino3d_amd/csrc experimental`, include/segdino3d_hip_experimental.h) - not on the product path.
+Output-stationary sparse convolution (csrc/experimental/slab_conv.hip, C entry sd3d_slab_conv) against a float64 gather + matmul model
 and against the pair-major kernel it replaces, on real neighbour tables: every (Cin, Cout) shape of the two U-Nets,
 concatenated inputs, residual, folded BatchNorm, ReLU, k=2 stride / transposed tables, the 5^3 stem, levels with few rows
 (offset split + slab_reduce_kernel), a ragged last slab, rows without any neighbour, and run-to-run determinism."""
@@ -6,12 +7,15 @@ import numpy as np
 import pytest
 import torch
 
-pytestmark = pytest.mark.gpu
+pytestmark = [pytest.mark.gpu, pytest.mark.experimental]
 
 
 def dev():
     if not torch.cuda.is_available():
         pytest.skip("needs a HIP device")
+    from segdino3d_amd import experimental
+    if not experimental.available():
+        pytest.skip("libsegdino3d_hip_experimental.so is not built (make -C segdino3d_amd/csrc experimental)")
     return torch.device("cuda:0")
 
 
@@ -58,13 +62,13 @@ CASES = [  # (table, Cin, Cout, concat split or 0)
 
 @pytest.mark.parametrize("key,cin,cout,split", CASES)
 def test_slab_conv_matches_fp64_and_pair_major(maps, key, cin, cout, split):
-    from segdino3d_amd import ops
+    from segdino3d_amd import experimental, ops
     d = dev()
     tab = maps.conv_table(*key)
     nbr, pairs = tab["nbr"], tab["pairs"]
     K, M = nbr.shape
     P = int((nbr >= 0).sum())
-    assert ops.slab_conv_supported(K, cin, cout, M, P)
+    assert experimental.slab_conv_supported(K, cin, cout, M, P)
     g = torch.Generator().manual_seed(hash((key, cin, cout)) % 1000)
     n_in = int(nbr.max().item()) + 1
     x = torch.randn(n_in, cin, generator=g) * torch.exp(0.5 * torch.randn(n_in, 1, generator=g))
@@ -75,8 +79,8 @@ def test_slab_conv_matches_fp64_and_pair_major(maps, key, cin, cout, split):
     xin, x2 = (xd[:, :split], xd[:, split:]) if split else (xd, None)
     for kw, (sc, sh, rs, relu) in ((dict(scale=scale.to(d), shift=shift.to(d), res=res.to(d), act="relu"), (scale, shift, res, True)),
                                    (dict(), (None, None, None, False))):
-        got = ops.slab_conv(xin, wd, nbr, n_pairs=P, x2=x2, **kw)
-        again = ops.slab_conv(xin, wd, nbr, n_pairs=P, x2=x2, **kw)
+        got = experimental.slab_conv(xin, wd, nbr, n_pairs=P, x2=x2, **kw)
+        again = experimental.slab_conv(xin, wd, nbr, n_pairs=P, x2=x2, **kw)
         assert torch.equal(got, again), "slab_conv is not deterministic"
         ref, mag = _fp64_conv(x, w, nbr, sc, sh, rs, relu)
         err = ((got.double().cpu() - ref).abs() / mag).max().item()
@@ -89,25 +93,25 @@ def test_slab_conv_matches_fp64_and_pair_major(maps, key, cin, cout, split):
 def test_unsupported_shapes_are_reported_not_guessed():
     """Shapes without a kernel variant (the 288-channel stem, odd widths) answer 0 workspace bytes = "keep the pair-major
     path"; calling anyway raises."""
-    from segdino3d_amd import ops
+    from segdino3d_amd import experimental, ops
     d = dev()
-    assert not ops.slab_conv_supported(125, 288, 32, 1000, 5000)
-    assert not ops.slab_conv_supported(27, 96, 100, 1000, 5000)
+    assert not experimental.slab_conv_supported(125, 288, 32, 1000, 5000)
+    assert not experimental.slab_conv_supported(27, 96, 100, 1000, 5000)
     with pytest.raises(ValueError):
-        ops.slab_conv(torch.zeros(10, 288, device=d), torch.zeros(125, 32, 288, device=d), torch.zeros(125, 10, dtype=torch.int32, device=d))
+        experimental.slab_conv(torch.zeros(10, 288, device=d), torch.zeros(125, 32, 288, device=d), torch.zeros(125, 10, dtype=torch.int32, device=d))
 
 
 def test_rows_without_neighbours_and_ragged_slabs():
     """A table whose rows mostly have NO neighbour at all (output = epilogue of zero), M not a multiple of the slab size, and
     a single-row table."""
-    from segdino3d_amd import ops
+    from segdino3d_amd import experimental, ops
     d = dev()
     g = torch.Generator().manual_seed(0)
     for M, n_in, K, p in ((1000 + 37, 500, 27, 0.02), (1, 5, 8, 0.5), (70, 70, 27, 1.0)):
         nbr = torch.where(torch.rand(K, M, generator=g) < p, torch.randint(0, n_in, (K, M), generator=g), torch.full((K, M), -1)).int()
         x, w = torch.randn(n_in, 64, generator=g), torch.randn(K, 64, 64, generator=g) * 0.05
         shift = torch.randn(64, generator=g)
-        got = ops.slab_conv(x.to(d), w.to(d), nbr.to(d), shift=shift.to(d), act="relu").double().cpu()
+        got = experimental.slab_conv(x.to(d), w.to(d), nbr.to(d), shift=shift.to(d), act="relu").double().cpu()
         ref, mag = _fp64_conv(x, w, nbr, torch.ones(64), shift, None, True)
         assert ((got - ref).abs() / mag).max().item() < 2e-6
         empty = (nbr < 0).all(dim=0)

@@ -629,3 +629,16 @@ def test_all_levels_at_once_equal_the_level_by_level_unique(batched, monkeypatch
             assert torch.equal(a.keys[l], b.keys[l]), l
         for l in range(4):
             assert torch.equal(a.parents[l], b.parents[l]), l
+
+
+def test_unique_levels_of_an_empty_scene_report_zero_voxels():
+    """`sd3d_unique_levels` with a device-side row count of 0 (an empty or fully filtered scene): every coarser level reports 0
+    voxels - the counts are written by the kernels, never left as allocated."""
+    from segdino3d_amd import ops
+    d = torch.device("cuda:0")
+    keys = torch.arange(1000, dtype=torch.int64, device=d)
+    for n0 in (0, 1000):
+        for _ in range(3):                                      # (fresh `torch.empty` counts each call: garbage would show)
+            _, _, counts = ops.unique_levels(keys, 1000, torch.tensor([n0], dtype=torch.int32, device=d), 4)
+            ref = [0] * 4 if n0 == 0 else [len(torch.unique(keys >> (3 * l))) for l in range(1, 5)]
+            assert counts.tolist() == ref, (n0, counts.tolist())

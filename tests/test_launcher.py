@@ -140,6 +140,24 @@ def test_gpus_are_counted_from_sysfs_without_hip(tmp_path):
     assert kfd_gpu_bdfs(str(tmp_path / "nothing")) == []
 
 
+def test_gpus_without_an_accessible_render_node_are_not_counted(tmp_path):
+    """A container that was given only some /dev/dri/renderD* nodes still sees every GPU of the host in sysfs: a GPU whose render node
+    cannot be opened read-write is left out of the count and of the index -> PCI address list NUMA pinning uses."""
+    from segdino3d_amd.dist_eval import kfd_gpu_bdfs, visible_gpu_bdfs
+    root = _fake_kfd(tmp_path, [(0, 0, 0), (1024, 0, 0x0500), (1024, 0, 0x1500), (1024, 0, 0x2500)])
+    nodes = tmp_path / "class" / "kfd" / "kfd" / "topology" / "nodes"
+    for i, minor in ((1, 128), (2, 129), (3, 130)):
+        with open(nodes / str(i) / "properties", "a") as f:
+            f.write(f"drm_render_minor {minor}\n")
+    dev = tmp_path / "dev"
+    (dev / "dri").mkdir(parents=True)
+    (dev / "dri" / "renderD128").write_text("")
+    (dev / "dri" / "renderD130").write_text("")
+    assert kfd_gpu_bdfs(root, str(dev)) == ["0000:05:00.0", "0000:25:00.0"]
+    assert visible_gpu_bdfs(root, env={"HIP_VISIBLE_DEVICES": "1"}, dev_root=str(dev)) == ["0000:25:00.0"]
+    assert kfd_gpu_bdfs(root, str(tmp_path / "no_dev")) == []
+
+
 def test_bench_parent_does_not_import_a_gpu_count_from_torch():
     """`launch_ranks` / `pin_rank_to_cores` in bench.py must not call torch.cuda.* (the parent stays GPU-free; a rank only touches ITS GPU)."""
     import ast

@@ -53,7 +53,8 @@ def main():
             if line.startswith("{"):
                 cfg = json.loads(line)["config"]
                 out["workload"] = {"points": cfg["points"], "superpoints": cfg["superpoints"], "queries_2d": cfg["queries_2d"],
-                                   "scene_layout": cfg["scene_layout"], "scenes_per_forward": cfg.get("max_scenes_per_forward", cfg.get("scenes_per_forward", 1))}
+                                   "scene_layout": cfg["scene_layout"],
+                                   "forward_sizes": sorted({n for st in cfg["forward_sizes"] for n in st})}   # sizes of the profiled forwards
     json.dump(out, open(sys.argv[3], "w"), indent=1)
     print(json.dumps(out, indent=1))
 

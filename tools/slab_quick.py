@@ -1,7 +1,7 @@
 """Slab (output-stationary) vs pair-major sparse convolution on the benchmark scene's rulebooks: us per conv, active TFLOP/s."""
 import os, sys, torch
 sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", "/root/repo"))
-from segdino3d_amd import ops
+from segdino3d_amd import experimental, ops
 from segdino3d_amd.sparse import SceneMaps
 from segdino3d_amd.synth import make_scene
 
@@ -40,9 +40,9 @@ for key, cin, cout, mult in cases:
     x = torch.randn(n_in, cin, generator=g).to(d); w = (torch.randn(K, cout, cin, generator=g) * (K * cin) ** -0.5).to(d)
     P = int((nbr >= 0).sum())
     t_pair = timeit(lambda: ops.pair_conv(x, w, pairs), 5)
-    if ops.slab_conv_supported(K, cin, cout, M, P):
-        t_slab = timeit(lambda: ops.slab_conv(x, w, nbr, n_pairs=P), 5)
-        diff = (ops.slab_conv(x, w, nbr, n_pairs=P) - ops.pair_conv(x, w, pairs)).abs().max().item()
+    if experimental.slab_conv_supported(K, cin, cout, M, P):
+        t_slab = timeit(lambda: experimental.slab_conv(x, w, nbr, n_pairs=P), 5)
+        diff = (experimental.slab_conv(x, w, nbr, n_pairs=P) - ops.pair_conv(x, w, pairs)).abs().max().item()
     else:
         t_slab, diff = float("nan"), float("nan")
     fl = 2.0 * P * cin * cout
