@@ -104,6 +104,18 @@ int sd3d_hash_build(const uint64_t* ukeys, int64_t n, uint64_t* table_keys, int3
  * offsets are probed and every hit is written to both mirror slots. */
 int sd3d_kernel_map(const uint64_t* out_keys, int64_t n_out, const uint64_t* table_keys, const int32_t* table_vals,
                     int64_t capacity, const int8_t* offsets, int K, int mirrored, int32_t* nbr, int32_t* pair_count, void* stream);
+/* The 3^3 kernel maps of EVERY level of a scene (and the 5^3 map of the finest level) from one call, without hash tables: through the
+ * hierarchy of the sorted keys (level l + 1 = unique(key >> 3): the children of a coarse voxel are consecutive rows, the neighbour of a
+ * voxel lies in one of the 27 cells around its parent).  keys[l] / n[l]: the levels' sorted keys (finest first, as sd3d_unique_levels
+ * leaves them), parent[l][j] = row of voxel j's parent on level l + 1 (NULL for the coarsest level; no extent clip: every parent
+ * exists), nbr3[l] [27, n_l] outputs, nbr5 [125, n_0] output or NULL, offsets3 / offsets5 device int8 [K, 3] in the enumeration order
+ * of the weights, inv27 (HOST) maps (dx + 1) + 3 (dy + 1) + 9 (dz + 1) to the row of offsets3.  pair_counts: NULL or device int32
+ * [(n_levels + 1) x 64], zeroed - 64 partial rulebook counters per table (levels 0 .. n_levels - 1, then the 5^3 table).  The tables
+ * are those of sd3d_kernel_map, entry for entry (MinkowskiEngine kernel map generation: minkunet.py:146-162). */
+size_t sd3d_kernel_maps_hier_ws_bytes(int n_levels, const int64_t* n);
+int sd3d_kernel_maps_hier(int n_levels, const uint64_t* const* keys, const int32_t* const* parent, const int64_t* n,
+                          int32_t* const* nbr3, int32_t* nbr5, const int8_t* offsets3, const int8_t* offsets5, const int8_t* inv27,
+                          int32_t* pair_counts, void* ws, size_t ws_bytes, void* stream);
 /* 2x2x2 stride-2 maps from the parent array: nbr_down [8, n_coarse], nbr_up [8, n_fine]; perm8[8]
  * maps the child's Z-order position (x | y<<1 | z<<2) to the weight index. */
 int sd3d_stride_maps(const uint64_t* fine_keys, const int32_t* parent, int64_t n_fine, int64_t n_coarse,

@@ -517,37 +517,38 @@ __device__ __forceinline__ float pg_act(float t, int act) {
     return t;
 }
 
-// A workgroup walks its range of consecutive 128-pair tiles as ONE flat stream of (tile, 32-channel
-// chunk) steps: the weight chunk of step s+1 is staged global -> registers -> LDS while step s runs on
-// the matrix cores, and the gathered activation rows are prefetched TWO steps ahead (three register
-// stages), across tile boundaries, so the dependent in_idx -> row gather latency of a new tile never
-// stalls the MFMA pipe.  The four waves share the weight chunk (lock-step, one barrier per step); each
-// owns 32 pairs x (32*NT) output columns.
+// ---- pass 1, lock-step variant ------------------------------------------------------------------------------------------
+// A workgroup walks its range of consecutive 128-pair tiles as ONE flat stream of (tile, 32-channel chunk) steps: the weight chunk
+// of step s + 1 is staged global -> registers -> LDS while step s runs on the matrix cores, the gathered activation rows are
+// requested TWO steps ahead (three register stages, renamed by unrolling), across tile boundaries.  The four waves share the weight
+// chunk (lock-step, one barrier per step); each owns 32 pairs x (32 NT) output columns.
+// Round 5 form.  The ISA of the round 1-4 form (hipcc 7.2, -save-temps) showed two full memory round trips outside the matrix work:
+// every tile switch loaded the next gather indices and the next tile's offset from global memory and waited for them on the spot
+// (`s_waitcnt vmcnt(0)`: the offset must become a scalar, the index register is copied) with all four waves parked behind the
+// barrier - every third step of a 96-channel layer, EVERY step of a 32-channel one - and the step at the loop header waited
+// `vmcnt(0)` right after it had ISSUED the next weight chunk's loads.  Here the range's metadata (gather rows, offsets) sits in LDS,
+// a piece of PG_PIECE tiles at a time, so the steady state has no global load whose value is needed at once, and a step issues its
+// requests (next weight chunk, the rows of step s + 2) BEHIND its first group of MFMAs, so whatever the compiler waits for at the top
+// of a step was requested a whole step earlier.  Same tiles, same MFMA order per accumulator, same stores: the partial products are
+// bit-identical to the old form's.  Measured (tools/r05_pair_ab.sh, profiles/EXPERIMENTS.md): -4 % on the 96-column layers of
+// levels 0-1, -1...-3 % elsewhere - the other workgroup of the CU was already covering most of those waits.
+#define PG_PIECE 24
 template <int NT, bool DIRECT>
-__device__ __forceinline__ void pair_gemm_body(const PGParams& p, float (*Bs)[NT * 32 * PBS_LD]) {
+__device__ __forceinline__ void pair_gemm_body(const PGParams& p, float (*Bs)[NT * 32 * PBS_LD], int* Ix, int* Kx) {
     const int tid = threadIdx.x, lane = tid & 63;
-    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);   // wave-uniform values must live in SGPRs (scalar branches)
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int j = lane & 31, h = lane >> 5;
-    // balanced contiguous tile ranges over a grid sized to the resident workgroup slots: no wave-quantisation
-    // tail (a fixed tiles-per-workgroup grid of 2.1 rounds costs 3 rounds of time)
     const int n_real = p.tile_k[p.n_tiles];
-    int tile0 = (int)((int64_t)blockIdx.x * n_real / gridDim.x);
-    int tile1 = (int)((int64_t)(blockIdx.x + 1) * n_real / gridDim.x);
+    int range0 = (int)((int64_t)blockIdx.x * n_real / gridDim.x);
+    int range1 = (int)((int64_t)(blockIdx.x + 1) * n_real / gridDim.x);
     if (p.chained) {                                           // a chain of sub-tiles (<= 3) is never split between workgroups
-        while (tile0 > 0 && tile0 < n_real && (p.tile_k[tile0 - 1] & PG_CHAIN)) ++tile0;
-        while (tile1 > 0 && tile1 < n_real && (p.tile_k[tile1 - 1] & PG_CHAIN)) ++tile1;
+        while (range0 > 0 && range0 < n_real && (p.tile_k[range0 - 1] & PG_CHAIN)) ++range0;
+        while (range1 > 0 && range1 < n_real && (p.tile_k[range1 - 1] & PG_CHAIN)) ++range1;
     }
-    const int ntl = tile1 - tile0;
-    if (ntl <= 0) return;                                      // uniform over the workgroup
+    if (range1 <= range0) return;                              // uniform over the workgroup
     const int ncol0 = blockIdx.y * NT * 32;
     const int nchunks = p.Cin >> 5;
-    const int nsteps = ntl * nchunks;
     const int64_t wstride = (int64_t)p.Cout * p.Cin;
-
-#define LOAD_IDX(lt) ((lt) < ntl ? p.in_idx[(int64_t)(tile0 + (lt)) * PT + wv * 32 + j] : -1)
-#define LOAD_K(lt) ((lt) < ntl ? p.tile_k[(tile0 + (lt))] : 0)
-    int q0 = LOAD_IDX(0), q1 = LOAD_IDX(1), q2 = LOAD_IDX(2);  // gather rows of the current tile and the next two
-    int k_cur = LOAD_K(0), k_nxt = LOAD_K(1);
 
     f32x16 acc[NT];
 #pragma unroll
@@ -573,44 +574,46 @@ __device__ __forceinline__ void pair_gemm_body(const PGParams& p, float (*Bs)[NT
             *(f32x4*)(&Bs[buf][(f >> 3) * PBS_LD + (f & 7) * 4]) = bst[i];
         }
     };
-    // Branch-free on purpose: padding entries (idx < 0) read row 0 - their partial products are never
-    // read back - and the concat source is picked by a wave-uniform select.  Any exec-masked region here
-    // makes the compiler fall back to s_waitcnt vmcnt(0) at the next use, which drains the prefetches that
-    // were just issued (measured: the whole two-step lookahead was lost to it).
-    auto load_a = [&](f32x4 (&a)[4], int idx, int chunk) {
+    auto load_a = [&](f32x4 (&a)[4], int row, int chunk) {      // branch-free (see the first form): row >= 0 always here
         const int cc = chunk * 32;                              // wave-uniform
         const bool first = cc < p.C0;
         const float* base = first ? p.in0 : p.in1;
         const int ld = first ? p.ld0 : p.ld1;
         const int coff = (first ? cc : cc - p.C0) + h * 16;
-        const int row = idx < 0 ? 0 : idx;
         const float* src = base + (int64_t)row * ld + coff;
 #pragma unroll
         for (int q = 0; q < 4; ++q) a[q] = *(const f32x4*)(src + q * 4);
     };
 
-    // prefetch pointer (pf_d tiles ahead of the current tile, chunk pf_c) = step s + 2
-    f32x4 a0[4], a1[4], a2[4];
-    int pf_d = 0, pf_c = 0;
-#define PF_IDX() (pf_d == 0 ? q0 : (pf_d == 1 ? q1 : q2))
-#define PF_ADVANCE() do { if (++pf_c == nchunks) { pf_c = 0; ++pf_d; } } while (0)
-    load_a(a0, PF_IDX(), pf_c); PF_ADVANCE();
-    if (nsteps > 1) { load_a(a1, PF_IDX(), pf_c); PF_ADVANCE(); }
-    stage_load(k_cur, 0);
-    stage_store(0);
-    __syncthreads();
-    int buf = 0, cur_lt = 0, cur_c = 0, s = 0;
-    // One step: CUR = this step's activation fragments, PF = the stage that receives step s+2's.  The ring is
-    // rotated by unrolling the loop three times with the roles renamed - copying a stage would make the
-    // compiler wait for the loads that are still in flight into it and cut the prefetch back to one step.
-#define PAIR_STEP(CUR, PF)                                                                                            \
+    for (int piece0 = range0; piece0 < range1; piece0 += PG_PIECE) {
+        const int ntl = range1 - piece0 < PG_PIECE ? range1 - piece0 : PG_PIECE;
+        __syncthreads();                                       // nobody still reads the previous piece's metadata / weight buffers
+        for (int f = tid; f < ntl * PT; f += 256) {
+            const int v = p.in_idx[(int64_t)piece0 * PT + f];
+            Ix[f] = v < 0 ? 0 : v;                             // padding gathers row 0: its products are never read back
+        }
+        if (tid < PG_PIECE + 2) Kx[tid] = tid < ntl ? p.tile_k[piece0 + tid] : 0;
+        __syncthreads();
+        const int nsteps = ntl * nchunks;
+        const int* Iw = Ix + wv * 32 + j;                       // this lane's gather row of tile t: Iw[t * PT]
+        int k_cur = __builtin_amdgcn_readfirstlane(Kx[0]), k_nxt = __builtin_amdgcn_readfirstlane(Kx[1]);
+        f32x4 a0[4], a1[4], a2[4];
+        int pf_t = 0, pf_c = 0;                                 // prefetch pointer = step s + 2
+#define PF_ADVANCE() do { if (++pf_c == nchunks) { pf_c = 0; ++pf_t; } } while (0)
+#define PF_ROW() Iw[(pf_t < ntl ? pf_t : ntl - 1) * PT]        /* past the end: a harmless reload of the last tile's row */
+        load_a(a0, PF_ROW(), pf_c); PF_ADVANCE();
+        load_a(a1, PF_ROW(), pf_c); PF_ADVANCE();
+        stage_load(k_cur, 0);
+        stage_store(0);
+        __syncthreads();
+        int buf = 0, cur_lt = 0, cur_c = 0, s = 0;
+#define PAIR_STEP(CUR, PF)                                                                                           \
     {                                                                                                                 \
         const bool has_next = s + 1 < nsteps;                                                                         \
         const bool last_chunk = cur_c + 1 == nchunks;                                                                 \
-        if (has_next) stage_load(last_chunk ? k_nxt : k_cur, last_chunk ? 0 : cur_c + 1);                             \
-        load_a(PF, PF_IDX(), pf_c); PF_ADVANCE(); /* past the end: idx = -1 -> row 0, harmless */                     \
+        const int pf_row = PF_ROW();                /* LDS: asked for before the matrix work, used behind its first group */ \
+        const int k_after = Kx[cur_lt + 2];                                                                           \
         {                                                                                                             \
-            /* weight fragments double-buffered by hand: left alone the compiler hoists all four groups (64 VGPRs) */ \
             const float* bb = &Bs[buf][j * PBS_LD + h * 16];                                                          \
             f32x4 bq[2][NT];                                                                                          \
             _Pragma("unroll") for (int t = 0; t < NT; ++t) bq[0][t] = *(const f32x4*)(bb + t * 32 * PBS_LD);          \
@@ -623,13 +626,20 @@ __device__ __forceinline__ void pair_gemm_body(const PGParams& p, float (*Bs)[NT
                     _Pragma("unroll") for (int t = 0; t < NT; ++t)                                                    \
                         acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(CUR[q][e], bq[q & 1][t][e], acc[t], 0, 0, 0);   \
                 __builtin_amdgcn_sched_barrier(0);                                                                    \
+                if (q == 0) {   /* this step's requests, behind 4 NT MFMAs: next weight chunk first (consumed first) */ \
+                    if (has_next) stage_load(last_chunk ? k_nxt : k_cur, last_chunk ? 0 : cur_c + 1);                 \
+                    load_a(PF, pf_row, pf_c); PF_ADVANCE();                                                           \
+                    __builtin_amdgcn_sched_barrier(0);                                                                \
+                }                                                                                                     \
             }                                                                                                         \
         }                                                                                                             \
-        if (last_chunk && !(k_cur & PG_CHAIN)) { /* tile (chain) complete: write its partial products (or, one pair per output row, the rows themselves) */ \
-            const int64_t prow0 = (int64_t)(tile0 + cur_lt) * PT + wv * 32;                                       \
+        if (last_chunk && !(k_cur & PG_CHAIN)) { /* tile (chain) complete */                                          \
+            const int64_t prow0 = (int64_t)(piece0 + cur_lt) * PT + wv * 32;                                          \
             if (DIRECT) {                                                                                             \
+                int32_t orow[16];                   /* all sixteen output rows asked for before the first is used */ \
+                _Pragma("unroll") for (int r = 0; r < 16; ++r) orow[r] = p.out_idx[prow0 + (r & 3) + 8 * (r >> 2) + 4 * h]; \
                 _Pragma("unroll") for (int r = 0; r < 16; ++r) {                                                      \
-                    const int64_t o = p.out_idx[prow0 + (r & 3) + 8 * (r >> 2) + 4 * h];   /* uniform over the 32 lanes j */ \
+                    const int64_t o = orow[r];                                              /* uniform over the 32 lanes j */ \
                     if (o >= 0) {                                                                                     \
                         _Pragma("unroll") for (int t = 0; t < NT; ++t) {                                              \
                             const int n = ncol0 + t * 32 + j;                                                         \
@@ -659,38 +669,34 @@ __device__ __forceinline__ void pair_gemm_body(const PGParams& p, float (*Bs)[NT
         buf ^= 1;                                                                                                     \
         ++s;                                                                                                          \
         if (last_chunk) {                                                                                             \
-            cur_c = 0; ++cur_lt; --pf_d;                                                                              \
-            q0 = q1; q1 = q2; q2 = LOAD_IDX(cur_lt + 2);                                                              \
-            k_cur = k_nxt; k_nxt = LOAD_K(cur_lt + 1);                                                                \
+            cur_c = 0; ++cur_lt;                                                                                      \
+            k_cur = k_nxt; k_nxt = __builtin_amdgcn_readfirstlane(k_after);                                           \
         } else {                                                                                                      \
             ++cur_c;                                                                                                  \
         }                                                                                                             \
     }
-    for (;;) {
-        PAIR_STEP(a0, a2)
-        PAIR_STEP(a1, a0)
-        PAIR_STEP(a2, a1)
-    }
+        for (;;) {
+            PAIR_STEP(a0, a2)
+            PAIR_STEP(a1, a0)
+            PAIR_STEP(a2, a1)
+        }
 #undef PAIR_STEP
-#undef LOAD_IDX
-#undef LOAD_K
-#undef PF_IDX
 #undef PF_ADVANCE
+#undef PF_ROW
+    }
 }
 
-// One entry per column-tile count: the register budget (waves per SIMD) is pinned per variant, which
-// also stops the compiler from splitting the file into VGPR + AGPR halves with separate alignment
-// (272 registers and one wave per SIMD for NT = 4 otherwise).
-#define PAIR_GEMM_ENTRY(NAME, NT, WAVES, DIRECT)                                                                 \
+#define PAIR_GEMM_ENTRY(NAME, NT, WAVES, DIRECT)                                                                \
     __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WAVES, WAVES))) void NAME(const PGParams p) { \
         __shared__ __attribute__((aligned(16))) float Bs[2][NT * 32 * PBS_LD];                                  \
-        pair_gemm_body<NT, DIRECT>(p, Bs);                                                                      \
+        __shared__ int Ix[PG_PIECE * PT];                                                                       \
+        __shared__ int Kx[PG_PIECE + 2];                                                                        \
+        pair_gemm_body<NT, DIRECT>(p, Bs, Ix, Kx);                                                             \
     }
 PAIR_GEMM_ENTRY(pair_gemm_kernel_1, 1, 3, false)
 PAIR_GEMM_ENTRY(pair_gemm_kernel_2, 2, 2, false)
 PAIR_GEMM_ENTRY(pair_gemm_kernel_3, 3, 2, false)
 PAIR_GEMM_ENTRY(pair_gemm_kernel_4, 4, 2, false)
-// one pair per output row (transposed k2s2 convolutions): the epilogue writes the output rows themselves
 PAIR_GEMM_ENTRY(pair_gemm_direct_kernel_1, 1, 3, true)
 PAIR_GEMM_ENTRY(pair_gemm_direct_kernel_2, 2, 2, true)
 PAIR_GEMM_ENTRY(pair_gemm_direct_kernel_3, 3, 2, true)

@@ -444,6 +444,156 @@ int launch_kernel_map(const uint64_t* okeys, int64_t n_out, const uint64_t* tkey
     return SD3D_OK;
 }
 
+// ---------------------------------------------------------------------------------------------
+// Kernel maps WITHOUT a hash table: through the level hierarchy the sorted keys already carry.
+// The voxels of every level are sorted along the Z-order curve and level l + 1 is unique(key >> 3), so (a) the children of a coarse
+// voxel are CONSECUTIVE rows of the finer level, ordered by their low three Morton bits, and (b) the neighbour of voxel v at offset d
+// (|d| <= 2 per axis) lies in the parent cell P(v) + pd with pd = floor((bit(v) + d) / 2) in {-1, 0, 1} per axis: ONE entry of the
+// parent level's 3^3 map finds that cell, and its {first child, 8-bit child mask} record finds the row:
+//     nbr[k][v] = first[Q] + popcount(mask[Q] & ((1 << cb) - 1))  if mask[Q] has bit cb,   Q = nbr3_parent[pd][P(v)],  cb = low bits of v + d
+// Two dependent, cache-friendly loads per probe (a wave's 64 consecutive rows share one or two parents) instead of a random 64-byte
+// line of an open-addressing table per probe and table slot - the hash probes fetched 0.5-1.1 GB per scene for ~0.1 GB of useful bytes
+// (profiles/r04_pmc_fetch.md).  No Morton arithmetic, no coordinate range checks (a cell outside the key range has no parent entry), no
+// insert pass, no table memsets, and every entry of nbr is written by its own thread: coalesced, nothing to pre-fill.  The coarsest level
+// (a few thousand rows) is searched directly: binary search of the encoded neighbour key in its sorted keys.
+// Same table as kernel_map_kernel (MinkowskiEngine kernel map, minkunet.py:146-162), entry for entry.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void kmap_top_kernel(const uint64_t* __restrict__ keys, int64_t n, const int8_t* __restrict__ offs, int K,
+                                                       int32_t* __restrict__ nbr, int32_t* __restrict__ pair_count) {
+    __shared__ int wsum[4];
+    const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    int id = -1;
+    if (t < (int64_t)K * n) {
+        const int k = (int)(t / n);
+        const int64_t v = t - (int64_t)k * n;
+        const uint64_t key = keys[v];
+        uint32_t x, y, z;
+        morton_decode(key & SD3D_MORTON_MASK, x, y, z);
+        const int nx = (int)x + offs[k * 3 + 0], ny = (int)y + offs[k * 3 + 1], nz = (int)z + offs[k * 3 + 2];
+        if (((nx | ny | nz) >= 0) && nx < 65536 && ny < 65536 && nz < 65536) {
+            const uint64_t q = morton_encode((uint32_t)nx, (uint32_t)ny, (uint32_t)nz) | (key & ~SD3D_MORTON_MASK);
+            int64_t lo = 0, hi = n;                             // first row with key >= q
+            while (lo < hi) {
+                const int64_t mid = (lo + hi) >> 1;
+                if (keys[mid] < q) lo = mid + 1; else hi = mid;
+            }
+            if (lo < n && keys[lo] == q) id = (int)lo;
+        }
+        nbr[t] = id;
+    }
+    if (pair_count) {
+        const int c = __popcll(__ballot(id >= 0));
+        if ((threadIdx.x & 63) == 0) wsum[threadIdx.x >> 6] = c;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            const int tot = wsum[0] + wsum[1] + wsum[2] + wsum[3];
+            if (tot) atomicAdd(&pair_count[blockIdx.x & 63], tot);
+        }
+    }
+}
+
+// cinfo[p] = {first child row, child mask} of every coarse voxel: the thread of a parent's FIRST child walks its (<= 8) siblings.
+__global__ __launch_bounds__(256) void child_info_kernel(const uint64_t* __restrict__ fkeys, const int32_t* __restrict__ parent, int64_t n_fine,
+                                                         int2* __restrict__ cinfo) {
+    const int64_t j = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (j >= n_fine) return;
+    const int p = parent[j];
+    if (j > 0 && parent[j - 1] == p) return;
+    int mask = 0;
+#pragma unroll
+    for (int c = 0; c < 8; ++c)
+        if (j + c < n_fine && parent[j + c] == p) mask |= 1 << (int)(fkeys[j + c] & 7ull);
+    cinfo[p] = make_int2((int)j, mask);
+}
+
+#define KH_UNROLL 4                 // offsets per thread: their loads are all requested before the first is used
+struct KHParams {
+    const uint64_t* keys; const int32_t* parent; int64_t n;          // this level: keys, parent row of every voxel
+    const int32_t* nbr3p; int64_t np;                                 // the parent level's 3^3 map [27, np]
+    const int2* cinfo;                                                // per parent-level voxel: {first child, child mask}
+    const int8_t* offs; int K;                                        // this table's offsets (|d| <= 2)
+    int8_t inv27[27];                                                 // (pdx + 1) + 3 (pdy + 1) + 9 (pdz + 1) -> offset index of the parent level's 3^3 map
+    int32_t* nbr; int32_t* pair_count;
+};
+__global__ __launch_bounds__(256) void kmap_hier_kernel(const KHParams P) {
+    __shared__ int wsum[4];
+    const int64_t v = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int k0 = blockIdx.y * KH_UNROLL;
+    int found = 0;
+    if (v < P.n) {
+        const int bits = (int)(P.keys[v] & 7ull);                     // Morton bit 0 = x, 1 = y, 2 = z
+        const int par = P.parent[v];
+        int q[KH_UNROLL], cb[KH_UNROLL];
+#pragma unroll
+        for (int u = 0; u < KH_UNROLL; ++u) {
+            const int k = k0 + u < P.K ? k0 + u : P.K - 1;
+            const int sx = (bits & 1) + P.offs[k * 3 + 0], sy = ((bits >> 1) & 1) + P.offs[k * 3 + 1], sz = ((bits >> 2) & 1) + P.offs[k * 3 + 2];
+            const int pd = ((sx >> 1) + 1) + 3 * ((sy >> 1) + 1) + 9 * ((sz >> 1) + 1);     // arithmetic shift = floor
+            cb[u] = (sx & 1) | ((sy & 1) << 1) | ((sz & 1) << 2);
+            q[u] = pd == 13 ? par : P.nbr3p[(int64_t)P.inv27[pd] * P.np + par];
+        }
+        int2 ci[KH_UNROLL];
+#pragma unroll
+        for (int u = 0; u < KH_UNROLL; ++u) ci[u] = q[u] >= 0 ? P.cinfo[q[u]] : make_int2(0, 0);
+#pragma unroll
+        for (int u = 0; u < KH_UNROLL; ++u) {
+            if (k0 + u < P.K) {
+                const int hit = (ci[u].y >> cb[u]) & 1;
+                P.nbr[(int64_t)(k0 + u) * P.n + v] = hit ? ci[u].x + __popc((unsigned)ci[u].y & ((1u << cb[u]) - 1u)) : -1;
+                found += hit;
+            }
+        }
+    }
+    if (P.pair_count) {
+        int c = found;
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) c += __shfl_xor(c, d);
+        if ((threadIdx.x & 63) == 0) wsum[threadIdx.x >> 6] = c;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            const int tot = wsum[0] + wsum[1] + wsum[2] + wsum[3];
+            if (tot) atomicAdd(&P.pair_count[(blockIdx.x + blockIdx.y) & 63], tot);
+        }
+    }
+}
+
+size_t kernel_maps_hier_ws_bytes(int n_levels, const int64_t* n) {
+    size_t b = 256;
+    for (int l = 1; l < n_levels; ++l) b += align_up((size_t)n[l] * sizeof(int2), 256);
+    return b;
+}
+// levels[0] = finest.  nbr3[l]: [27, n_l] (every level), nbr5: [125, n_0] or NULL.  offs3 / offs5: device [K, 3] int8 offset tables (the same
+// enumeration order for every level); inv27: HOST table (pd index as above -> row of offs3).  pair_counts: NULL or device int32
+// [(n_levels + 1) * 64], zeroed: 64 partial counters per table (levels 0 .. n_levels - 1, then the 5^3 table).
+int launch_kernel_maps_hier(int n_levels, const uint64_t* const* keys, const int32_t* const* parent, const int64_t* n, int32_t* const* nbr3,
+                            int32_t* nbr5, const int8_t* offs3, const int8_t* offs5, const int8_t* inv27, int32_t* pair_counts, void* ws,
+                            size_t ws_bytes, hipStream_t st) {
+    if (n_levels < 1 || n_levels > 8) return sd3d_set_error(SD3D_ERR_ARG, "kernel_maps_hier: 1..8 levels");
+    if (ws_bytes < kernel_maps_hier_ws_bytes(n_levels, n)) return sd3d_set_error(SD3D_ERR_WS, "kernel_maps_hier: workspace too small");
+    for (int l = 0; l < n_levels; ++l)
+        if (n[l] <= 0 || !keys[l] || !nbr3[l] || (l + 1 < n_levels && !parent[l])) return sd3d_set_error(SD3D_ERR_ARG, "kernel_maps_hier: empty level or null pointer");
+    int2* cinfo[8] = {};
+    size_t off = 0;
+    for (int l = 1; l < n_levels; ++l) { cinfo[l] = (int2*)((char*)ws + off); off += align_up((size_t)n[l] * sizeof(int2), 256); }
+    const int top = n_levels - 1;
+    hipLaunchKernelGGL(kmap_top_kernel, dim3((unsigned)cdiv(27 * n[top], 256)), dim3(256), 0, st, keys[top], n[top], offs3, 27, nbr3[top],
+                       pair_counts ? pair_counts + 64 * top : nullptr);
+    for (int l = top - 1; l >= 0; --l) {
+        hipLaunchKernelGGL(child_info_kernel, dim3((unsigned)cdiv(n[l], 256)), dim3(256), 0, st, keys[l], parent[l], n[l], cinfo[l + 1]);
+        KHParams P;
+        P.keys = keys[l]; P.parent = parent[l]; P.n = n[l]; P.nbr3p = nbr3[l + 1]; P.np = n[l + 1]; P.cinfo = cinfo[l + 1];
+        for (int i = 0; i < 27; ++i) P.inv27[i] = inv27[i];
+        if (l == 0 && nbr5) {                                  // the stem's table first: the first convolution of the U-Net waits for it
+            P.offs = offs5; P.K = 125; P.nbr = nbr5; P.pair_count = pair_counts ? pair_counts + 64 * n_levels : nullptr;
+            hipLaunchKernelGGL(kmap_hier_kernel, dim3((unsigned)cdiv(n[l], 256), (unsigned)cdiv(125, KH_UNROLL)), dim3(256), 0, st, P);
+        }
+        P.offs = offs3; P.K = 27; P.nbr = nbr3[l]; P.pair_count = pair_counts ? pair_counts + 64 * l : nullptr;
+        hipLaunchKernelGGL(kmap_hier_kernel, dim3((unsigned)cdiv(n[l], 256), (unsigned)cdiv(27, KH_UNROLL)), dim3(256), 0, st, P);
+    }
+    SD3D_CHECK_LAUNCH();
+    return SD3D_OK;
+}
+
 // Stride-2, kernel-2 maps from the parent array.  The child's position inside its parent is the low
 // three Z-order bits (x | y<<1 | z<<2); perm8 maps it to the weight index of the library whose
 // checkpoint is loaded (identity for MinkowskiEngine's x-fastest order, bit-reversal for spconv).
@@ -611,6 +761,7 @@ __global__ __launch_bounds__(256) void segment_starts_kernel(const uint64_t* __r
     for (int64_t s = prev + 1; s <= cur; ++s) start[s] = (int32_t)j;
 }
 
+#define PS_ROWS 16
 __global__ __launch_bounds__(256) void pool_superpoints_kernel(const float* __restrict__ feat, int ld_feat, int C,
                                                                const int32_t* __restrict__ inverse,
                                                                const int32_t* __restrict__ icoords, float voxel_size,
@@ -635,23 +786,30 @@ __global__ __launch_bounds__(256) void pool_superpoints_kernel(const float* __re
         const int nmine = (j1 - jr - half + 1) >> 1;           // points of this half in the round (<= 32)
         const int ni = nmine < 32 ? nmine : 32;
         const int nloop = ((j1 - jr + 1) >> 1) < 32 ? ((j1 - jr + 1) >> 1) : 32;   // wave-uniform trip count (half 0 may hold one point more)
-        for (int i0 = 0; i0 < nloop; i0 += 8) {                // the shuffles stay outside the lane-dependent branches
-            int vv[8], pq[8];
+        // sixteen feature rows per lane in flight (round 5; eight before): a superpoint of ~50 points is two request rounds per half
+        // instead of four - the launch is a chain of memory latencies (3000 waves, all resident at once), not a stream.  Same order of
+        // additions per half: the same bits.
+        for (int i0 = 0; i0 < nloop; i0 += PS_ROWS) {          // the shuffles stay outside the lane-dependent branches
+            int vv[PS_ROWS], pq[PS_ROWS];
 #pragma unroll
-            for (int u = 0; u < 8; ++u) {
+            for (int u = 0; u < PS_ROWS; ++u) {
                 const int src = (i0 + u < 32 ? i0 + u : 31) + 32 * half;
                 vv[u] = __shfl(vm, src);
                 pq[u] = __shfl((int)pm, src);
             }
             if (li < nvec) {
-                f32x4 xx[8];
+                f32x4 xx[PS_ROWS];
 #pragma unroll
-                for (int u = 0; u < 8; ++u) xx[u] = *(const f32x4*)(feat + (int64_t)(i0 + u < ni ? vv[u] : 0) * ld_feat + li * 4);
+                for (int u = 0; u < PS_ROWS; ++u)
+                    xx[u] = __builtin_nontemporal_load((const f32x4*)(feat + (int64_t)(i0 + u < ni ? vv[u] : 0) * ld_feat + li * 4));
 #pragma unroll
-                for (int u = 0; u < 8; ++u) if (i0 + u < ni) acc += xx[u];
+                for (int u = 0; u < PS_ROWS; ++u) if (i0 + u < ni) acc += xx[u];
             } else if (li < nvec + 3) {
+                int cc[PS_ROWS];
 #pragma unroll
-                for (int u = 0; u < 8; ++u) if (i0 + u < ni) pacc += (float)icoords[(int64_t)pq[u] * 3 + (li - nvec)] * voxel_size;
+                for (int u = 0; u < PS_ROWS; ++u) cc[u] = i0 + u < ni ? icoords[(int64_t)pq[u] * 3 + (li - nvec)] : 0;
+#pragma unroll
+                for (int u = 0; u < PS_ROWS; ++u) if (i0 + u < ni) pacc += (float)cc[u] * voxel_size;
             }
         }
     }

@@ -77,7 +77,7 @@ def slab_conv(x, wt, nbr, n_pairs=None, x2=None, scale=None, shift=None, res=Non
         hook.before(dict(K=K, Cin=Cin, Cout=Cout, M=M, nbr=nbr, slab=True))
     _lib.check(lib.sd3d_slab_conv(p0, ld0, C0, p1, ld1, ops._ptr(nbr, torch.int32, "nbr"), int(n_pairs), ops._ptr(wt, torch.float32, "wt"),
                                   K, Cin, Cout, M, ops._ptr(scale, torch.float32, "scale"), ops._ptr(shift, torch.float32, "shift"), pr, ldr,
-                                  po, ldo, ops.ACT[act], ws.dataops._ptr(), ws.numel(), ops._stream()), "slab_conv")
+                                  po, ldo, ops.ACT[act], ws.data_ptr(), ws.numel(), ops._stream()), "slab_conv")
     if hook is not None:
         hook.after()
     return out

@@ -95,6 +95,25 @@ def exact_pair_capacity(n_vox0: int, device=None) -> bool:
     return bool(EXACT_PAIR_CAPACITY)
 
 
+# SD3D_HIER_MAPS=0: kernel maps by hash-table probes (rounds 1-4: one table + one probe launch per level).  Default: every 3^3 map of a
+# scene and the stem's 5^3 map from ONE call through the level hierarchy of the sorted keys (csrc/voxel.hip kmap_hier_kernel: two
+# cache-friendly loads per probe, no hash tables, no memsets) whenever the levels came from `sd3d_unique_levels` (MinkowskiEngine
+# semantics: every parent exists).  Entry for entry the same tables.
+HIER_MAPS = os.environ.get("SD3D_HIER_MAPS", "1") != "0"
+_INV27 = {}
+
+
+def inv27_table(order: str) -> np.ndarray:
+    """(dx + 1) + 3 (dy + 1) + 9 (dz + 1) -> row of the 3^3 offset table in the weights' enumeration order"""
+    if order not in _INV27:
+        offs = kernel_offsets_np(3, order).astype(np.int64)
+        inv = np.zeros(27, dtype=np.int8)
+        for k, (dx, dy, dz) in enumerate(offs):
+            inv[(dx + 1) + 3 * (dy + 1) + 9 * (dz + 1)] = k
+        _INV27[order] = inv
+    return _INV27[order]
+
+
 # kernel offsets are enumerated symmetrically (kernel_offsets_np: off[K-1-k] == -off[k] for odd k), so a stride-1 table
 # needs only half its hash probes.  SD3D_MIRRORED_MAPS=0 probes every offset (cross-check).
 MIRRORED_MAPS = os.environ.get("SD3D_MIRRORED_MAPS", "1") != "0"
@@ -233,8 +252,8 @@ class SceneMaps:
         self._side_used = True
         with ops.use_stream(side):
             side.wait_event(self._fork_ev)
-            if any(t[0] in self._hash for t in g_same):
-                side.wait_event(self._stem_done)                          # a level whose hash table exists: the stem's stream built it
+            if getattr(self, "_hier_built", False) or any(t[0] in self._hash for t in g_same):
+                side.wait_event(self._stem_done)                          # maps / a hash table the stem's stream built
             keys = self._build_tables(g_same, g_strides, chained, False)
             ev = ops.stream_event()
             for key in keys:
@@ -271,7 +290,28 @@ class SceneMaps:
     def _build_tables(self, same, strides, chained, exact):
         """-> keys of the pair lists built (on the current stream)."""
         counters = torch.zeros(max(1, len(same)), 64, dtype=torch.int32, device=self.device) if exact else None
+        L = len(self.keys)
+        hier = (HIER_MAPS and same and not self.clipped and not self._same and len(self.parents) == L - 1 and min(self.n_vox) > 0
+                and all((k == 3) or (k == 5 and lvl == 0) for lvl, k in same))
+        if hier:
+            # all maps of the scene now, whatever subset this call asks for (a forked prepare() calls again for the other levels and
+            # finds them): the hierarchy runs coarse to fine, and the whole chain costs less than one level's hash probes did
+            want5 = (0, 5) in same
+            cnt_all = torch.zeros(L + 1, 64, dtype=torch.int32, device=self.device) if exact else None
+            nbr3, nbr5 = ops.kernel_maps_hier(self.keys, self.parents, self.n_vox, offsets_device(3, self.order, self.device),
+                                              offsets_device(5, self.order, self.device) if want5 else None, inv27_table(self.order), cnt_all)
+            for l in range(L):
+                self._same[(l, 3)] = nbr3[l]
+            if want5:
+                self._same[(0, 5)] = nbr5
+            self._hier_built = True
+            if exact:
+                counters = cnt_all[[L if k == 5 else lvl for lvl, k in same]]
         for i, (lvl, k) in enumerate(same):
+            if (lvl, k) in self._same:
+                if exact and not hier:                           # (built earlier without a counter: count the table's entries)
+                    counters[i, 0] = (self._same[(lvl, k)] >= 0).sum().to(torch.int32)
+                continue
             offs = offsets_device(k, self.order, self.device)
             self._same[(lvl, k)] = ops.kernel_map(self.keys[lvl], self.n_vox[lvl], self.table(lvl), offs,
                                                   counters[i] if exact else None, mirrored=MIRRORED_MAPS and k % 2 == 1)

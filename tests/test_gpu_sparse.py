@@ -631,6 +631,40 @@ def test_all_levels_at_once_equal_the_level_by_level_unique(batched, monkeypatch
             assert torch.equal(a.parents[l], b.parents[l]), l
 
 
+@pytest.mark.parametrize("batched", [False, True])
+@pytest.mark.parametrize("order", ["x_fastest", "z_fastest"])
+def test_hierarchical_kernel_maps_equal_the_hash_probed_maps(batched, order, monkeypatch):
+    """`sparse.HIER_MAPS` (`sd3d_kernel_maps_hier`: every 3^3 map and the stem's 5^3 map through the level hierarchy of the sorted keys,
+    no hash tables) against the hash-probed maps of rounds 1-4 (which the oracle pins, test_voxelise_levels_maps_match_oracle): every
+    table entry for entry, and the rulebook sizes the exact-capacity mode reads back - one scene (incl. a single-voxel one) and a batch."""
+    from segdino3d_amd import sparse
+    from segdino3d_amd.sparse import BatchSceneMaps, SceneMaps
+    d = torch.device("cuda:0")
+    g = torch.Generator().manual_seed(5)
+    scenes = []
+    for n, ext in ((40_000, 6.0), (9_000, 2.5), (1, 1.0), (20_000, 0.3)):                 # (a dense blob: most of the 125 offsets occupied)
+        pts = torch.cat([torch.rand(n, 3, generator=g) * ext - 0.4 * ext, torch.rand(n, 3, generator=g)], 1).to(d)
+        scenes.append(pts)
+    monkeypatch.setattr(sparse, "EXACT_PAIR_CAPACITY", True)
+    built = {}
+    for mode in (True, False):
+        monkeypatch.setattr(sparse, "HIER_MAPS", mode)
+        if batched:
+            ms = [BatchSceneMaps(scenes, 0.02, 5, order=order)]
+        else:
+            ms = [SceneMaps(p, 0.02, 5, order=order) for p in scenes]
+        for m in ms:
+            m.prepare(same=[(0, 5)] + [(l, 3) for l in range(5)], strides=[0, 1, 2, 3])
+        built[mode] = ms
+    for a, b in zip(built[True], built[False]):
+        assert getattr(a, "_hier_built", False) and not getattr(b, "_hier_built", False) and not a._hash and b._hash
+        for key in [(0, 5)] + [(l, 3) for l in range(5)]:
+            assert torch.equal(a._same[key], b._same[key]), key
+            assert a.density[("same",) + key] == b.density[("same",) + key], key
+            pa, pb = a.pairs[("same",) + key], b.pairs[("same",) + key]
+            assert torch.equal(pa.in_idx, pb.in_idx) and torch.equal(pa.tile_k, pb.tile_k), key
+
+
 def test_unique_levels_of_an_empty_scene_report_zero_voxels():
     """`sd3d_unique_levels` with a device-side row count of 0 (an empty or fully filtered scene): every coarser level reports 0
     voxels - the counts are written by the kernels, never left as allocated."""
