@@ -111,11 +111,14 @@ int sd3d_kernel_map(const uint64_t* out_keys, int64_t n_out, const uint64_t* tab
  * exists), nbr3[l] [27, n_l] outputs, nbr5 [125, n_0] output or NULL, offsets3 / offsets5 device int8 [K, 3] in the enumeration order
  * of the weights, inv27 (HOST) maps (dx + 1) + 3 (dy + 1) + 9 (dz + 1) to the row of offsets3.  pair_counts: NULL or device int32
  * [(n_levels + 1) x 64], zeroed - 64 partial rulebook counters per table (levels 0 .. n_levels - 1, then the 5^3 table).  The tables
- * are those of sd3d_kernel_map, entry for entry (MinkowskiEngine kernel map generation: minkunet.py:146-162). */
+ * are those of sd3d_kernel_map, entry for entry (MinkowskiEngine kernel map generation: minkunet.py:146-162).
+ * perm8 + nbr_down[l] [8, n_{l+1}] / nbr_up[l] [8, n_l] for l < n_levels - 1 (all optional: NULL): the stride-2 maps of every level pair
+ * (the tables of sd3d_stride_maps) from the same launches, every entry written by the thread that owns it (no pre-fill). */
 size_t sd3d_kernel_maps_hier_ws_bytes(int n_levels, const int64_t* n);
 int sd3d_kernel_maps_hier(int n_levels, const uint64_t* const* keys, const int32_t* const* parent, const int64_t* n,
                           int32_t* const* nbr3, int32_t* nbr5, const int8_t* offsets3, const int8_t* offsets5, const int8_t* inv27,
-                          int32_t* pair_counts, void* ws, size_t ws_bytes, void* stream);
+                          int32_t* pair_counts, const int32_t* perm8, int32_t* const* nbr_down, int32_t* const* nbr_up, void* ws,
+                          size_t ws_bytes, void* stream);
 /* 2x2x2 stride-2 maps from the parent array: nbr_down [8, n_coarse], nbr_up [8, n_fine]; perm8[8]
  * maps the child's Z-order position (x | y<<1 | z<<2) to the weight index. */
 int sd3d_stride_maps(const uint64_t* fine_keys, const int32_t* parent, int64_t n_fine, int64_t n_coarse,

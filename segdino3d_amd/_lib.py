@@ -46,7 +46,7 @@ SIGNATURES = {
     "sd3d_hash_build": (_i, [_p, _l, _p, _p, _l, _p]),
     "sd3d_kernel_map": (_i, [_p, _l, _p, _p, _l, _p, _i, _i, _p, _p, _p]),
     "sd3d_kernel_maps_hier_ws_bytes": (_z, [_i, _p]),
-    "sd3d_kernel_maps_hier": (_i, [_i, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _z, _p]),
+    "sd3d_kernel_maps_hier": (_i, [_i, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _z, _p]),
     "sd3d_stride_maps": (_i, [_p, _p, _l, _l, _p, _p, _p, _p]),
     "sd3d_voxel_mean": (_i, [_p, _i, _p, _i, _i, _p, _l, _p, _p, _l, _p, _i, _p]),
     "sd3d_segment_starts": (_i, [_p, _l, _l, _p, _p]),

@@ -56,7 +56,7 @@ int launch_pair_conv(const float*, int, int, const float*, int, const int32_t*, 
 int launch_pair_lists_desc(int, const sd3d_pair_table_desc*, void*, size_t, hipStream_t);
 size_t kernel_maps_hier_ws_bytes(int, const int64_t*);
 int launch_kernel_maps_hier(int, const uint64_t* const*, const int32_t* const*, const int64_t*, int32_t* const*, int32_t*, const int8_t*,
-                            const int8_t*, const int8_t*, int32_t*, void*, size_t, hipStream_t);
+                            const int8_t*, const int8_t*, int32_t*, const int32_t*, int32_t* const*, int32_t* const*, void*, size_t, hipStream_t);
 
 int launch_layernorm(const float*, int, const float*, int, const float*, const float*, float, int64_t, int, float*, int, int, hipStream_t);
 int launch_linear_layernorm(const float*, int, int64_t, int, const float*, int, const float*, const float*, int, const float*, const float*, float, int,
@@ -186,10 +186,11 @@ int sd3d_kernel_map(const uint64_t* out_keys, int64_t n_out, const uint64_t* tab
 }
 size_t sd3d_kernel_maps_hier_ws_bytes(int n_levels, const int64_t* n) { return kernel_maps_hier_ws_bytes(n_levels, n); }
 int sd3d_kernel_maps_hier(int n_levels, const uint64_t* const* keys, const int32_t* const* parent, const int64_t* n, int32_t* const* nbr3,
-                          int32_t* nbr5, const int8_t* offsets3, const int8_t* offsets5, const int8_t* inv27, int32_t* pair_counts, void* ws,
-                          size_t ws_bytes, void* stream) {
+                          int32_t* nbr5, const int8_t* offsets3, const int8_t* offsets5, const int8_t* inv27, int32_t* pair_counts,
+                          const int32_t* perm8, int32_t* const* nbr_down, int32_t* const* nbr_up, void* ws, size_t ws_bytes, void* stream) {
     if (!keys || !parent || !n || !nbr3 || !offsets3 || !inv27 || (nbr5 && !offsets5)) return sd3d_set_error(SD3D_ERR_ARG, "kernel_maps_hier: null pointer");
-    return launch_kernel_maps_hier(n_levels, keys, parent, n, nbr3, nbr5, offsets3, offsets5, inv27, pair_counts, ws, ws_bytes, ST);
+    return launch_kernel_maps_hier(n_levels, keys, parent, n, nbr3, nbr5, offsets3, offsets5, inv27, pair_counts, perm8, nbr_down, nbr_up, ws,
+                                   ws_bytes, ST);
 }
 int sd3d_stride_maps(const uint64_t* fine_keys, const int32_t* parent, int64_t n_fine, int64_t n_coarse, const int32_t* perm8,
                      int32_t* nbr_down, int32_t* nbr_up, void* stream) {

@@ -493,17 +493,31 @@ __global__ __launch_bounds__(256) void kmap_top_kernel(const uint64_t* __restric
 }
 
 // cinfo[p] = {first child row, child mask} of every coarse voxel: the thread of a parent's FIRST child walks its (<= 8) siblings.
+// The same launch writes the level pair's stride-2 maps (launch_stride_maps' tables, entry for entry) when asked to: every fine voxel
+// its column of nbr_up [8, n_fine] (its parent in the row of its own kernel offset, -1 in the other seven), every first child the
+// column of its parent in nbr_down [8, n_coarse] - each entry written by the thread that owns it, nothing to pre-fill.
 __global__ __launch_bounds__(256) void child_info_kernel(const uint64_t* __restrict__ fkeys, const int32_t* __restrict__ parent, int64_t n_fine,
-                                                         int2* __restrict__ cinfo) {
+                                                         int64_t n_coarse, int2* __restrict__ cinfo, const int32_t* __restrict__ perm8,
+                                                         int32_t* __restrict__ nbr_down, int32_t* __restrict__ nbr_up) {
     const int64_t j = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (j >= n_fine) return;
     const int p = parent[j];
+    if (nbr_up) {
+        const int mine = perm8[(int)(fkeys[j] & 7ull)];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) nbr_up[(int64_t)k * n_fine + j] = k == mine ? p : -1;
+    }
     if (j > 0 && parent[j - 1] == p) return;
     int mask = 0;
 #pragma unroll
     for (int c = 0; c < 8; ++c)
         if (j + c < n_fine && parent[j + c] == p) mask |= 1 << (int)(fkeys[j + c] & 7ull);
     cinfo[p] = make_int2((int)j, mask);
+    if (nbr_down) {
+#pragma unroll
+        for (int c = 0; c < 8; ++c)
+            nbr_down[(int64_t)perm8[c] * n_coarse + p] = ((mask >> c) & 1) ? (int)j + __popc((unsigned)mask & ((1u << c) - 1u)) : -1;
+    }
 }
 
 #define KH_UNROLL 4                 // offsets per thread: their loads are all requested before the first is used
@@ -565,9 +579,10 @@ size_t kernel_maps_hier_ws_bytes(int n_levels, const int64_t* n) {
 // levels[0] = finest.  nbr3[l]: [27, n_l] (every level), nbr5: [125, n_0] or NULL.  offs3 / offs5: device [K, 3] int8 offset tables (the same
 // enumeration order for every level); inv27: HOST table (pd index as above -> row of offs3).  pair_counts: NULL or device int32
 // [(n_levels + 1) * 64], zeroed: 64 partial counters per table (levels 0 .. n_levels - 1, then the 5^3 table).
+// nbr_down[l] [8, n_{l+1}] / nbr_up[l] [8, n_l] (l < n_levels - 1): optional stride-2 maps of the level pair (NULL arrays or entries: not built).
 int launch_kernel_maps_hier(int n_levels, const uint64_t* const* keys, const int32_t* const* parent, const int64_t* n, int32_t* const* nbr3,
-                            int32_t* nbr5, const int8_t* offs3, const int8_t* offs5, const int8_t* inv27, int32_t* pair_counts, void* ws,
-                            size_t ws_bytes, hipStream_t st) {
+                            int32_t* nbr5, const int8_t* offs3, const int8_t* offs5, const int8_t* inv27, int32_t* pair_counts,
+                            const int32_t* perm8, int32_t* const* nbr_down, int32_t* const* nbr_up, void* ws, size_t ws_bytes, hipStream_t st) {
     if (n_levels < 1 || n_levels > 8) return sd3d_set_error(SD3D_ERR_ARG, "kernel_maps_hier: 1..8 levels");
     if (ws_bytes < kernel_maps_hier_ws_bytes(n_levels, n)) return sd3d_set_error(SD3D_ERR_WS, "kernel_maps_hier: workspace too small");
     for (int l = 0; l < n_levels; ++l)
@@ -579,7 +594,8 @@ int launch_kernel_maps_hier(int n_levels, const uint64_t* const* keys, const int
     hipLaunchKernelGGL(kmap_top_kernel, dim3((unsigned)cdiv(27 * n[top], 256)), dim3(256), 0, st, keys[top], n[top], offs3, 27, nbr3[top],
                        pair_counts ? pair_counts + 64 * top : nullptr);
     for (int l = top - 1; l >= 0; --l) {
-        hipLaunchKernelGGL(child_info_kernel, dim3((unsigned)cdiv(n[l], 256)), dim3(256), 0, st, keys[l], parent[l], n[l], cinfo[l + 1]);
+        hipLaunchKernelGGL(child_info_kernel, dim3((unsigned)cdiv(n[l], 256)), dim3(256), 0, st, keys[l], parent[l], n[l], n[l + 1], cinfo[l + 1],
+                           perm8, perm8 && nbr_down ? nbr_down[l] : nullptr, perm8 && nbr_up ? nbr_up[l] : nullptr);
         KHParams P;
         P.keys = keys[l]; P.parent = parent[l]; P.n = n[l]; P.nbr3p = nbr3[l + 1]; P.np = n[l + 1]; P.cinfo = cinfo[l + 1];
         for (int i = 0; i < 27; ++i) P.inv27[i] = inv27[i];

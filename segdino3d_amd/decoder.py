@@ -620,8 +620,8 @@ class ScanNetQueryDecoder(DerivedWeights):
         every scene gets the same tiling code (ops.dense_code) for every Linear of its three row families, the query tensors have few
         hundred rows (grouped launches, fused Linear + LayerNorm) and no instrumentation / opt-in arithmetic mode is active;
         anything else runs scene by scene."""
-        if self.training or not self.add_positional_embedding or len(x) < 2 or not BATCH_DECODER or ops.GG_HOOK is not None:
-            return False
+        if self.training or not self.add_positional_embedding or not 2 <= len(x) <= 16 or not BATCH_DECODER or ops.GG_HOOK is not None:
+            return False                                        # (the batched launches hold at most SD3D_MAX_BATCH = 16 scenes)
         lim = ops.LINEAR_LN_MAX_ROWS
         if lim <= 0 or ops.GEMM_MODE is not None or ops.GG_FORCE_NT is not None:
             return False

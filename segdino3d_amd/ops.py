@@ -387,11 +387,12 @@ def kernel_map(out_keys, n_out, table, offsets_i8, pair_count=None, mirrored=Fal
     return nbr
 
 
-def kernel_maps_hier(keys, parents, n_vox, offs3, offs5, inv27, pair_counts=None):
+def kernel_maps_hier(keys, parents, n_vox, offs3, offs5, inv27, pair_counts=None, perm8=None):
     """The 3^3 kernel maps of every level (+ the 5^3 map of level 0 when `offs5` is given) from ONE call, through the level hierarchy of
     the sorted keys instead of hash tables (`sd3d_kernel_maps_hier`).  keys: per level int64 [n_l] (finest first); parents: per level
     but the last int32 [n_l]; offs3 / offs5: device int8 [27, 3] / [125, 3]; inv27: numpy int8 [27] ((dx+1) + 3 (dy+1) + 9 (dz+1) -> row
-    of offs3).  pair_counts: zeroed int32 [(L + 1), 64] or None.  -> ([nbr3 per level], nbr5 | None)"""
+    of offs3).  pair_counts: zeroed int32 [(L + 1), 64] or None.  perm8 (int32 [8], as `stride_maps`): the stride-2 maps of every level
+    pair come out of the same launches.  -> ([nbr3 per level], nbr5 | None, [(nbr_down, nbr_up) per level pair] | None)"""
     lib = _lib.load()
     L = len(keys)
     dev = keys[0].device
@@ -402,12 +403,20 @@ def kernel_maps_hier(keys, parents, n_vox, offs3, offs5, inv27, pair_counts=None
     pp = (ctypes.c_void_p * L)(*[(_ptr(parents[l], torch.int32, "parent") if l + 1 < L else None) for l in range(L)])
     np_ = (ctypes.c_void_p * L)(*[t.data_ptr() for t in nbr3])
     inv = (ctypes.c_int8 * 27)(*[int(v) for v in inv27])
+    strides, dp, up = None, None, None
+    if perm8 is not None and L > 1:
+        strides = [(torch.empty(8, int(n_vox[l + 1]), dtype=torch.int32, device=dev), torch.empty(8, int(n_vox[l]), dtype=torch.int32, device=dev))
+                   for l in range(L - 1)]
+        dp = (ctypes.c_void_p * L)(*([t[0].data_ptr() for t in strides] + [None]))
+        up = (ctypes.c_void_p * L)(*([t[1].data_ptr() for t in strides] + [None]))
     ws = _WS.get(lib.sd3d_kernel_maps_hier_ws_bytes(L, ctypes.addressof(n)), dev)
     _lib.check(lib.sd3d_kernel_maps_hier(L, ctypes.addressof(kp), ctypes.addressof(pp), ctypes.addressof(n), ctypes.addressof(np_),
                                          _ptr(nbr5), _ptr(offs3, torch.int8, "offs3"), _ptr(offs5, torch.int8, "offs5"),
-                                         ctypes.addressof(inv), _ptr(pair_counts, torch.int32, "pair_counts"), ws.data_ptr(), ws.numel(),
-                                         _stream()), "kernel_maps_hier")
-    return nbr3, nbr5
+                                         ctypes.addressof(inv), _ptr(pair_counts, torch.int32, "pair_counts"),
+                                         _ptr(perm8, torch.int32, "perm8") if strides is not None else None,
+                                         ctypes.addressof(dp) if strides is not None else None, ctypes.addressof(up) if strides is not None else None,
+                                         ws.data_ptr(), ws.numel(), _stream()), "kernel_maps_hier")
+    return nbr3, nbr5, strides
 
 
 def stride_maps(fine_keys, parent, n_fine, n_coarse, perm8, want_down=True, want_up=True):

@@ -298,8 +298,11 @@ class SceneMaps:
             # finds them): the hierarchy runs coarse to fine, and the whole chain costs less than one level's hash probes did
             want5 = (0, 5) in same
             cnt_all = torch.zeros(L + 1, 64, dtype=torch.int32, device=self.device) if exact else None
-            nbr3, nbr5 = ops.kernel_maps_hier(self.keys, self.parents, self.n_vox, offsets_device(3, self.order, self.device),
-                                              offsets_device(5, self.order, self.device) if want5 else None, inv27_table(self.order), cnt_all)
+            nbr3, nbr5, st_maps = ops.kernel_maps_hier(self.keys, self.parents, self.n_vox, offsets_device(3, self.order, self.device),
+                                                       offsets_device(5, self.order, self.device) if want5 else None, inv27_table(self.order),
+                                                       cnt_all, perm8=self._perm8 if not self._stride else None)
+            for l, t in enumerate(st_maps or []):                # the stride-2 maps of every level pair ride in the same launches
+                self._stride[l] = t
             for l in range(L):
                 self._same[(l, 3)] = nbr3[l]
             if want5:

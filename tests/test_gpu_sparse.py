@@ -663,6 +663,8 @@ def test_hierarchical_kernel_maps_equal_the_hash_probed_maps(batched, order, mon
             assert a.density[("same",) + key] == b.density[("same",) + key], key
             pa, pb = a.pairs[("same",) + key], b.pairs[("same",) + key]
             assert torch.equal(pa.in_idx, pb.in_idx) and torch.equal(pa.tile_k, pb.tile_k), key
+        for l in range(4):                                     # the stride-2 maps came out of the same launches
+            assert torch.equal(a.down(l), b.down(l)) and torch.equal(a.up(l), b.up(l)), l
 
 
 def test_unique_levels_of_an_empty_scene_report_zero_voxels():
