@@ -506,14 +506,19 @@ struct PGParams {
     int chained;                              // 1: tile_k carries PG_CHAIN flags (chained lists: a tile's products add onto the next tile's)
 };
 
+
 // scale * x + shift as ONE fused multiply-add in every epilogue of this file, so that the paths agree bit for bit
 __device__ __forceinline__ float pg_affine(float x, const float* scale, const float* shift, int n) {
     return __builtin_fmaf(x, scale ? scale[n] : 1.f, shift ? shift[n] : 0.f);
 }
+// (GELU / sigmoid never follow a sparse convolution in the shipped networks: kept out of line so that the 64 epilogue sites of a
+//  kernel do not each carry an inlined erff / expf)
+__device__ __attribute__((noinline)) float pg_act_slow(float t, int act) {
+    return act == 2 ? 0.5f * t * (1.f + erff(t * 0.70710678118654752440f)) : 1.f / (1.f + expf(-t));
+}
 __device__ __forceinline__ float pg_act(float t, int act) {
     if (act == 1) t = fmaxf(t, 0.f);
-    else if (act == 2) t = 0.5f * t * (1.f + erff(t * 0.70710678118654752440f));
-    else if (act == 3) t = 1.f / (1.f + expf(-t));
+    else if (act >= 2) t = pg_act_slow(t, act);
     return t;
 }
 
@@ -533,6 +538,13 @@ __device__ __forceinline__ float pg_act(float t, int act) {
 // bit-identical to the old form's.  Measured (tools/r05_pair_ab.sh, profiles/EXPERIMENTS.md): -4 % on the 96-column layers of
 // levels 0-1, -1...-3 % elsewhere - the other workgroup of the CU was already covering most of those waits.
 #define PG_PIECE 24
+// The fp32 MFMA runs at the fp32 VECTOR rate on the same lanes (MI355X_MICROARCH.md): every VALU instruction of the step - address
+// arithmetic, register copies, the epilogue's per-store index products - is matrix time lost, not work hidden in a shadow (ablations of
+// round 5, profiles/EXPERIMENTS.md: a launch takes its MFMA time PLUS its non-MFMA time).  So the step is written for few VALU
+// instructions: the MFMA is issued transposed (A = weights, B = gathered rows: a lane owns one pair row and its accumulator groups are
+// four consecutive columns - 4 NT `dwordx4` stores from ONE 64-bit address per tile instead of 16 NT dword stores with an index product
+// each), the weight requests are a wave-uniform 64-bit base (scalar unit) + a per-thread 32-bit offset fixed for the launch, a gather
+// request is one 64-bit multiply-add per step.
 template <int NT, bool DIRECT>
 __device__ __forceinline__ void pair_gemm_body(const PGParams& p, float (*Bs)[NT * 32 * PBS_LD], int* Ix, int* Kx) {
     const int tid = threadIdx.x, lane = tid & 63;
@@ -548,42 +560,44 @@ __device__ __forceinline__ void pair_gemm_body(const PGParams& p, float (*Bs)[NT
     if (range1 <= range0) return;                              // uniform over the workgroup
     const int ncol0 = blockIdx.y * NT * 32;
     const int nchunks = p.Cin >> 5;
-    const int64_t wstride = (int64_t)p.Cout * p.Cin;
+    const uint64_t wstride_b = (uint64_t)p.Cout * (uint64_t)p.Cin * 4ull;
 
     f32x16 acc[NT];
-#pragma unroll
-    for (int t = 0; t < NT; ++t)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+    const f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    bool fresh = true;                                         // the next product starts a new tile (chain): its MFMA takes C = 0 instead of 16 NT register clears per tile
 
+    // weight staging: thread f = tid + 256 i moves 16 bytes of row (f >> 3) of the chunk; its byte offset inside W[k] and its LDS slot
+    // are fixed for the launch, the (offset, chunk) part of the address is wave-uniform
     f32x4 bst[NT];
-    auto stage_load = [&](int kf, int chunk) {
-        const float* __restrict__ W = p.wt + (int64_t)(kf & PG_KMASK) * wstride;
+    uint32_t woff[NT];
 #pragma unroll
-        for (int i = 0; i < NT; ++i) {
-            const int f = tid + i * 256;
-            int n = ncol0 + (f >> 3);
-            n = n < p.Cout ? n : p.Cout - 1;
-            bst[i] = *(const f32x4*)(W + (int64_t)n * p.Cin + chunk * 32 + (f & 7) * 4);
-        }
+    for (int i = 0; i < NT; ++i) {
+        const int f = tid + i * 256;
+        int n = ncol0 + (f >> 3);
+        n = n < p.Cout ? n : p.Cout - 1;
+        woff[i] = (uint32_t)(n * p.Cin + (f & 7) * 4) * 4u;
+    }
+    float* const sts = &Bs[0][(tid >> 3) * PBS_LD + (tid & 7) * 4];         // + i * 32 rows, + buf * buffer
+    auto stage_load = [&](int kf, int chunk) {
+        const char* Wk = (const char*)p.wt + (uint64_t)(uint32_t)(kf & PG_KMASK) * wstride_b + (uint32_t)chunk * 128u;    // scalar
+#pragma unroll
+        for (int i = 0; i < NT; ++i) bst[i] = *(const f32x4*)(Wk + woff[i]);
     };
     auto stage_store = [&](int buf) {
 #pragma unroll
-        for (int i = 0; i < NT; ++i) {
-            const int f = tid + i * 256;
-            *(f32x4*)(&Bs[buf][(f >> 3) * PBS_LD + (f & 7) * 4]) = bst[i];
-        }
+        for (int i = 0; i < NT; ++i) *(f32x4*)(sts + buf * (NT * 32 * PBS_LD) + i * 32 * PBS_LD) = bst[i];
     };
-    auto load_a = [&](f32x4 (&a)[4], int row, int chunk) {      // branch-free (see the first form): row >= 0 always here
-        const int cc = chunk * 32;                              // wave-uniform
+    const uint64_t lane_b = (uint64_t)(h * 64);                 // this lane's 16 channels of a 32-channel chunk
+    auto load_a = [&](f32x4 (&a)[4], int row, int chunk) {      // branch-free: row >= 0 always (padding reads row 0)
+        const int cc = chunk * 32;                              // wave-uniform from here ...
         const bool first = cc < p.C0;
-        const float* base = first ? p.in0 : p.in1;
-        const int ld = first ? p.ld0 : p.ld1;
-        const int coff = (first ? cc : cc - p.C0) + h * 16;
-        const float* src = base + (int64_t)row * ld + coff;
+        const char* base = (const char*)(first ? p.in0 : p.in1) + (uint32_t)(first ? cc : cc - p.C0) * 4u;
+        const uint32_t ld4 = (uint32_t)(first ? p.ld0 : p.ld1) * 4u;
+        const char* src = base + ((uint64_t)(uint32_t)row * ld4 + lane_b);                 // ... one 64-bit multiply-add per lane
 #pragma unroll
-        for (int q = 0; q < 4; ++q) a[q] = *(const f32x4*)(src + q * 4);
+        for (int q = 0; q < 4; ++q) a[q] = *(const f32x4*)(src + q * 16);
     };
+    const bool full_cols = ncol0 + NT * 32 <= p.Cout;           // every layer of the shipped networks (Cout a multiple of 32 NT)
 
     for (int piece0 = range0; piece0 < range1; piece0 += PG_PIECE) {
         const int ntl = range1 - piece0 < PG_PIECE ? range1 - piece0 : PG_PIECE;
@@ -607,7 +621,7 @@ __device__ __forceinline__ void pair_gemm_body(const PGParams& p, float (*Bs)[NT
         stage_store(0);
         __syncthreads();
         int buf = 0, cur_lt = 0, cur_c = 0, s = 0;
-#define PAIR_STEP(CUR, PF)                                                                                           \
+#define PAIR_STEP(CUR, PF)                                                                                            \
     {                                                                                                                 \
         const bool has_next = s + 1 < nsteps;                                                                         \
         const bool last_chunk = cur_c + 1 == nchunks;                                                                 \
@@ -622,9 +636,20 @@ __device__ __forceinline__ void pair_gemm_body(const PGParams& p, float (*Bs)[NT
                     _Pragma("unroll") for (int t = 0; t < NT; ++t)                                                    \
                         bq[(q + 1) & 1][t] = *(const f32x4*)(bb + t * 32 * PBS_LD + (q + 1) * 4);                     \
                 }                                                                                                     \
-                _Pragma("unroll") for (int e = 0; e < 4; ++e)                                                         \
-                    _Pragma("unroll") for (int t = 0; t < NT; ++t)                                                    \
-                        acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(CUR[q][e], bq[q & 1][t][e], acc[t], 0, 0, 0);   \
+                _Pragma("unroll") for (int e = 0; e < 4; ++e) {                                                       \
+                    if (q == 0 && e == 0) {                                                                           \
+                        if (fresh) {                                                                                  \
+                            _Pragma("unroll") for (int t = 0; t < NT; ++t)                                            \
+                                acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(bq[0][t][0], CUR[0][0], zero16, 0, 0, 0); \
+                        } else {                                                                                      \
+                            _Pragma("unroll") for (int t = 0; t < NT; ++t)                                            \
+                                acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(bq[0][t][0], CUR[0][0], acc[t], 0, 0, 0); \
+                        }                                                                                             \
+                    } else {                                                                                          \
+                        _Pragma("unroll") for (int t = 0; t < NT; ++t)                                                \
+                            acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(bq[q & 1][t][e], CUR[q][e], acc[t], 0, 0, 0); \
+                    }                                                                                                 \
+                }                                                                                                     \
                 __builtin_amdgcn_sched_barrier(0);                                                                    \
                 if (q == 0) {   /* this step's requests, behind 4 NT MFMAs: next weight chunk first (consumed first) */ \
                     if (has_next) stage_load(last_chunk ? k_nxt : k_cur, last_chunk ? 0 : cur_c + 1);                 \
@@ -633,35 +658,33 @@ __device__ __forceinline__ void pair_gemm_body(const PGParams& p, float (*Bs)[NT
                 }                                                                                                     \
             }                                                                                                         \
         }                                                                                                             \
-        if (last_chunk && !(k_cur & PG_CHAIN)) { /* tile (chain) complete */                                          \
-            const int64_t prow0 = (int64_t)(piece0 + cur_lt) * PT + wv * 32;                                          \
-            if (DIRECT) {                                                                                             \
-                int32_t orow[16];                   /* all sixteen output rows asked for before the first is used */ \
-                _Pragma("unroll") for (int r = 0; r < 16; ++r) orow[r] = p.out_idx[prow0 + (r & 3) + 8 * (r >> 2) + 4 * h]; \
-                _Pragma("unroll") for (int r = 0; r < 16; ++r) {                                                      \
-                    const int64_t o = orow[r];                                              /* uniform over the 32 lanes j */ \
-                    if (o >= 0) {                                                                                     \
-                        _Pragma("unroll") for (int t = 0; t < NT; ++t) {                                              \
-                            const int n = ncol0 + t * 32 + j;                                                         \
-                            if (n < p.Cout) {                                                                         \
-                                float y = pg_affine(acc[t][r], p.scale, p.shift, n);                                  \
-                                if (p.res) y += p.res[o * p.ld_res + n];                                              \
-                                p.out[o * p.ld_out + n] = pg_act(y, p.act);                                           \
+        if (last_chunk && !(k_cur & PG_CHAIN)) { /* tile (chain) complete: lane = pair row, register group g = columns 8g + 4h .. +3 */ \
+            const int64_t prow = (int64_t)(piece0 + cur_lt) * PT + wv * 32 + j;                                       \
+            if (DIRECT) {                               /* one pair per output row: write the row itself */          \
+                const int64_t o = p.out_idx[prow];                                                                    \
+                if (o >= 0) {                                                                                         \
+                    _Pragma("unroll") for (int t = 0; t < NT; ++t)                                                    \
+                        _Pragma("unroll") for (int g = 0; g < 4; ++g) {                                               \
+                            const int c = ncol0 + 4 * h + t * 32 + 8 * g;                                             \
+                            if (full_cols || c < p.Cout) {                                                            \
+                                f32x4 y;                                                                              \
+                                _Pragma("unroll") for (int i = 0; i < 4; ++i) y[i] = pg_affine(acc[t][4 * g + i], p.scale, p.shift, c + i); \
+                                if (p.res) y += *(const f32x4*)(p.res + o * p.ld_res + c);                            \
+                                *(f32x4*)(p.out + o * p.ld_out + c) = f32x4{pg_act(y[0], p.act), pg_act(y[1], p.act), pg_act(y[2], p.act), pg_act(y[3], p.act)}; \
                             }                                                                                         \
                         }                                                                                             \
-                    }                                                                                                 \
                 }                                                                                                     \
             } else {                                                                                                  \
-                _Pragma("unroll") for (int t = 0; t < NT; ++t) {                                                      \
-                    const int n = ncol0 + t * 32 + j;                                                                 \
-                    _Pragma("unroll") for (int r = 0; r < 16; ++r) {                                                  \
-                        const int64_t pr = prow0 + (r & 3) + 8 * (r >> 2) + 4 * h;                                    \
-                        if (n < p.Cout) PART_STORE1(p.part + pr * p.Cout + n, acc[t][r]);                            \
-                    }                                                                                                 \
-                }                                                                                                     \
+                float* dst = p.part + prow * p.Cout + ncol0 + 4 * h;                                                  \
+                _Pragma("unroll") for (int t = 0; t < NT; ++t)                                                        \
+                    _Pragma("unroll") for (int g = 0; g < 4; ++g)                                                     \
+                        if (full_cols || ncol0 + 4 * h + t * 32 + 8 * g < p.Cout)                                     \
+                            PART_STORE4(dst + t * 32 + 8 * g, (f32x4{acc[t][4 * g], acc[t][4 * g + 1],                \
+                                                                     acc[t][4 * g + 2], acc[t][4 * g + 3]}));         \
             }                                                                                                         \
-            _Pragma("unroll") for (int t = 0; t < NT; ++t)                                                            \
-                _Pragma("unroll") for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;                                       \
+            fresh = true;                                                                                             \
+        } else {                                                                                                      \
+            fresh = false;                                                                                            \
         }                                                                                                             \
         if (!has_next) break;                                                                                         \
         stage_store(buf ^ 1);                                                                                         \
@@ -740,12 +763,8 @@ __device__ __forceinline__ void pair_gemm_ws_body(const PGParams& p, float* Ws) 
     int* Ix = (int*)(Ws + 32 * NT * ldw);                      // gather rows of this workgroup's pairs; padding (-1) -> row 0
 
     f32x16 acc[RT][NT];
-#pragma unroll
-    for (int rt = 0; rt < RT; ++rt)
-#pragma unroll
-        for (int t = 0; t < NT; ++t)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[rt][t][r] = 0.f;
+    const f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    bool fresh = true;                                         // the next product starts a new unit: its MFMAs take C = 0 (no register clears: VALU time is matrix time here)
 
   // the range is walked in pieces whose gather indices fit the LDS buffer (the capacity-sized lists of a scene that
   // skipped the rulebook-size read-back can make a range longer than that)
@@ -826,11 +845,18 @@ __device__ __forceinline__ void pair_gemm_ws_body(const PGParams& p, float* Ws) 
                     _Pragma("unroll") for (int t = 0; t < NT; ++t)                                                    \
                         wq[(q + 1) & 1][t] = *(const f32x4*)(wb + t * 32 * ldw + (q + 1) * 4);                        \
                 }                                                                                                     \
-                _Pragma("unroll") for (int e = 0; e < 4; ++e)                                                         \
-                    _Pragma("unroll") for (int t = 0; t < NT; ++t)                                                    \
-                        _Pragma("unroll") for (int rt = 0; rt < RT; ++rt)                                             \
-                            acc[rt][t] = __builtin_amdgcn_mfma_f32_32x32x2f32(wq[q & 1][t][e], CUR[rt][q][e],         \
-                                                                              acc[rt][t], 0, 0, 0);                   \
+                _Pragma("unroll") for (int e = 0; e < 4; ++e) {                                                       \
+                    if (q == 0 && e == 0 && fresh) {                                                                  \
+                        _Pragma("unroll") for (int t = 0; t < NT; ++t)                                                \
+                            _Pragma("unroll") for (int rt = 0; rt < RT; ++rt)                                         \
+                                acc[rt][t] = __builtin_amdgcn_mfma_f32_32x32x2f32(wq[0][t][0], CUR[rt][0][0], zero16, 0, 0, 0); \
+                    } else {                                                                                          \
+                        _Pragma("unroll") for (int t = 0; t < NT; ++t)                                                \
+                            _Pragma("unroll") for (int rt = 0; rt < RT; ++rt)                                         \
+                                acc[rt][t] = __builtin_amdgcn_mfma_f32_32x32x2f32(wq[q & 1][t][e], CUR[rt][q][e],     \
+                                                                                  acc[rt][t], 0, 0, 0);               \
+                    }                                                                                                 \
+                }                                                                                                     \
                 __builtin_amdgcn_sched_barrier(0);                                                                    \
             }                                                                                                         \
         }                                                                                                             \
@@ -857,10 +883,9 @@ __device__ __forceinline__ void pair_gemm_ws_body(const PGParams& p, float* Ws) 
                         PART_STORE4(dst + t * 32 + 8 * g, (f32x4{acc[rt][t][4 * g], acc[rt][t][4 * g + 1],            \
                                                                  acc[rt][t][4 * g + 2], acc[rt][t][4 * g + 3]}));     \
                 }                                                                                                     \
-                _Pragma("unroll") for (int t = 0; t < NT; ++t)                                                        \
-                    _Pragma("unroll") for (int r = 0; r < 16; ++r) acc[rt][t][r] = 0.f;                               \
             }                                                                                                         \
         }                                                                                                             \
+        fresh = last_chunk;                                                                                           \
         if (s + 1 >= nsteps) break;                                                                                   \
         ++s;                                                                                                          \
         if (last_chunk) { cur_c = 0; ++cur_i; } else { ++cur_c; }                                                     \
