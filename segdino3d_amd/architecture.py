@@ -154,7 +154,9 @@ class Baseline3D(nn.Module):
             if self.query_thr < 1:
                 n = (1 - self.query_thr) * torch.rand(1) + self.query_thr           # host RNG, like the reference
                 n = (n * len(x[i])).int()
-                ids = torch.randperm(len(x[i]))[:n].to(x[i].device)
+                # (pinned staging + an asynchronous copy: a pageable host -> device copy blocks the host until the stream has drained - the
+                #  whole backbone the host had run ahead of - and the decoder's ~340 autograd nodes then start from an empty queue)
+                ids = torch.randperm(len(x[i]))[:n].pin_memory().to(x[i].device, non_blocking=True)
                 queries.append(x[i][ids])
                 targets[i].query_inst_sem_masks = targets[i].sp_inst_sem_masks[:, ids]
                 if x_pos is not None and queries_pos is not None:

@@ -426,6 +426,9 @@ static int lds_column_tiles(int sub, int64_t tiles, bool gathered) {
     return nt;
 }
 
+int launch_pair_dense(const GGParams&, hipStream_t);             // pair_gemm.hip
+#define GG_PAIR_DENSE_MIN_ROWS 16384
+
 int launch_gather_gemm(const GGParams& p_in, int nt, void* ws, size_t ws_bytes, hipStream_t st) {
     GGParams p = p_in;
     p.ksplit = 1;
@@ -438,6 +441,11 @@ int launch_gather_gemm(const GGParams& p_in, int nt, void* ws, size_t ws_bytes, 
     if ((p.ld0 & 3) || (p.in1 && (p.ld1 & 3))) return sd3d_set_error(SD3D_ERR_ARG, "gather_gemm: input row stride must be a multiple of 4 floats");
     if (p.K > 128) return sd3d_set_error(SD3D_ERR_ARG, "gather_gemm: at most 128 kernel offsets");
     if (!p.nbr && p.K != 1) return sd3d_set_error(SD3D_ERR_ARG, "gather_gemm: identity gather needs K == 1");
+    // dense products on tens of thousands of rows (the U-Net's 1x1 convolutions; no decoder Linear reaches this many rows per scene, and
+    // the batched decoder passes its tiling code explicitly): the persistent pass-1 kernel with the identity rulebook
+    static const int pd_env = [] { const char* e = getenv("SD3D_PAIR_DENSE"); return e ? atoi(e) : 1; }();
+    if (pd_env && nt == 0 && !p.nbr && p.K == 1 && p.M >= GG_PAIR_DENSE_MIN_ROWS && !(p.Cout & 3) && !(p.ld_out & 3) && (!p.res || !(p.ld_res & 3)))
+        return launch_pair_dense(p, st);
     const int sub = (p.Cout + 31) / 32;
     const int64_t tiles = cdiv(p.M, 32);
     int ks = 1;

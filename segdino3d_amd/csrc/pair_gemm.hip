@@ -314,9 +314,21 @@ __global__ __launch_bounds__(256) void chain_first_kernel(const CHBatch b) {
     const CHTable& T = b.t[ti];
     const int64_t row = (int64_t)(blockIdx.x - T.fb0) * 256 + threadIdx.x;
     if (row >= T.M) return;
+    // every load of a batch of groups requested before the first is looked at (the short-circuit form was a chain of up to 2 G dependent
+    // memory latencies per row: 39 us per table; the loads are coalesced over the rows and independent)
     int first = T.G;
-    for (int g = T.G - 1; g >= 0; --g)
-        if (T.nbr[(int64_t)g * T.M + row] >= 0 || T.nbr[(int64_t)(T.K - 1 - g) * T.M + row] >= 0) first = g;
+    for (int g0 = 0; g0 < T.G; g0 += 7) {
+        int a[7], b[7];
+#pragma unroll
+        for (int u = 0; u < 7; ++u) {
+            const int g = g0 + u < T.G ? g0 + u : T.G - 1;
+            a[u] = T.nbr[(int64_t)g * T.M + row];
+            b[u] = T.nbr[(int64_t)(T.K - 1 - g) * T.M + row];
+        }
+#pragma unroll
+        for (int u = 6; u >= 0; --u)
+            if (g0 + u < T.G && (a[u] >= 0 || b[u] >= 0) && g0 + u < first) first = g0 + u;
+    }
     T.first_g[row] = first;
 }
 // pattern of (group g, row): -1 none
@@ -504,6 +516,7 @@ struct PGParams {
     float* out; int ld_out; int act;
     int nt_part;                              // 1: non-temporal partial-product stores (several scenes in flight; see PART_STORE4)
     int chained;                              // 1: tile_k carries PG_CHAIN flags (chained lists: a tile's products add onto the next tile's)
+    int64_t dense_rows;                       // > 0: no lists at all - pair p is (in = out = row p) of a dense [rows, Cin] x W[0]^T product (direct epilogue)
 };
 
 
@@ -550,7 +563,8 @@ __device__ __forceinline__ void pair_gemm_body(const PGParams& p, float (*Bs)[NT
     const int tid = threadIdx.x, lane = tid & 63;
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int j = lane & 31, h = lane >> 5;
-    const int n_real = p.tile_k[p.n_tiles];
+    const bool dense = DIRECT && p.dense_rows > 0;
+    const int n_real = dense ? (int)((p.dense_rows + PT - 1) / PT) : p.tile_k[p.n_tiles];
     int range0 = (int)((int64_t)blockIdx.x * n_real / gridDim.x);
     int range1 = (int)((int64_t)(blockIdx.x + 1) * n_real / gridDim.x);
     if (p.chained) {                                           // a chain of sub-tiles (<= 3) is never split between workgroups
@@ -602,11 +616,19 @@ __device__ __forceinline__ void pair_gemm_body(const PGParams& p, float (*Bs)[NT
     for (int piece0 = range0; piece0 < range1; piece0 += PG_PIECE) {
         const int ntl = range1 - piece0 < PG_PIECE ? range1 - piece0 : PG_PIECE;
         __syncthreads();                                       // nobody still reads the previous piece's metadata / weight buffers
+        if (dense) {
+            for (int f = tid; f < ntl * PT; f += 256) {
+                const int64_t r = (int64_t)piece0 * PT + f;
+                Ix[f] = (int)(r < p.dense_rows ? r : p.dense_rows - 1);
+            }
+            if (tid < PG_PIECE + 2) Kx[tid] = 0;
+        } else {
         for (int f = tid; f < ntl * PT; f += 256) {
             const int v = p.in_idx[(int64_t)piece0 * PT + f];
             Ix[f] = v < 0 ? 0 : v;                             // padding gathers row 0: its products are never read back
         }
         if (tid < PG_PIECE + 2) Kx[tid] = tid < ntl ? p.tile_k[piece0 + tid] : 0;
+        }
         __syncthreads();
         const int nsteps = ntl * nchunks;
         const int* Iw = Ix + wv * 32 + j;                       // this lane's gather row of tile t: Iw[t * PT]
@@ -661,7 +683,7 @@ __device__ __forceinline__ void pair_gemm_body(const PGParams& p, float (*Bs)[NT
         if (last_chunk && !(k_cur & PG_CHAIN)) { /* tile (chain) complete: lane = pair row, register group g = columns 8g + 4h .. +3 */ \
             const int64_t prow = (int64_t)(piece0 + cur_lt) * PT + wv * 32 + j;                                       \
             if (DIRECT) {                               /* one pair per output row: write the row itself */          \
-                const int64_t o = p.out_idx[prow];                                                                    \
+                const int64_t o = dense ? (prow < p.dense_rows ? prow : -1) : (int64_t)p.out_idx[prow];               \
                 if (o >= 0) {                                                                                         \
                     _Pragma("unroll") for (int t = 0; t < NT; ++t)                                                    \
                         _Pragma("unroll") for (int g = 0; g < 4; ++g) {                                               \
@@ -1176,6 +1198,7 @@ int launch_pair_conv(const float* in0, int ld0, int C0, const float* in1, int ld
         static const int nt_env = env_flag("SD3D_PAIR_NT_STORE", -1);          // -1: by the scenes-in-flight hint
         g.nt_part = nt_env >= 0 ? (nt_env != 0) : (g_scenes_in_flight.load(std::memory_order_relaxed) > 1 ? 1 : 0);
     }
+    g.dense_rows = 0;
     g.out_idx = direct ? out_idx : nullptr;
     g.scale = scale; g.shift = shift; g.res = res; g.ld_res = ld_res; g.out = out; g.ld_out = ld_out; g.act = act;
     const int sub = (Cout + 31) / 32;
@@ -1277,6 +1300,40 @@ int launch_pair_conv(const float* in0, int ld0, int C0, const float* in1, int ld
         r.pos = pos; r.K = K; r.M = M; r.part = part; r.Cout = Cout; r.scale = scale; r.shift = shift; r.res = res; r.ld_res = ld_res;
         r.out = out; r.ld_out = ld_out; r.act = act;
         hipLaunchKernelGGL(pair_reduce_kernel, dim3((unsigned)cdiv(M * (Cout / 4), 256)), dim3(256), 0, st, r);
+    }
+    SD3D_CHECK_LAUNCH();
+    return SD3D_OK;
+}
+
+// A dense [M, Cin] x W^T product (+ scale / shift / residual / activation) on the pass-1 kernel: the 1x1 convolutions of the U-Net
+// (BasicBlockBase.downsample, minkunet.py:314-328) on tens of thousands of rows.  The one-tile-per-workgroup kernel of gather_gemm.hip
+// spends most of such a launch on its prologue and epilogue (Cin / 32 = 4 - 12 steps per workgroup: 49 TFLOP/s at level 0); here a
+// persistent workgroup walks its share of the 128-row tiles through the same software pipeline as the sparse convolutions, the
+// "rulebook" being the identity (no lists are read) and the epilogue writing the output rows themselves.
+int launch_pair_dense(const GGParams& q, hipStream_t st) {
+    static int n_cu = 0;
+    if (!n_cu) {
+        int dev = 0; hipDeviceProp_t prop;
+        if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return sd3d_set_error(SD3D_ERR_LAUNCH, "pair_dense: no device");
+        n_cu = prop.multiProcessorCount;
+    }
+    PGParams g;
+    g.in0 = q.in0; g.ld0 = q.ld0; g.C0 = q.in1 ? q.C0 : q.Cin; g.in1 = q.in1; g.ld1 = q.ld1; g.in_idx = nullptr; g.tile_k = nullptr; g.wt = q.wt;
+    g.Cin = q.Cin; g.Cout = q.Cout; g.part = nullptr; g.n_tiles = 0; g.out_idx = nullptr; g.scale = q.scale; g.shift = q.shift; g.res = q.res;
+    g.ld_res = q.ld_res; g.out = q.out; g.ld_out = q.ld_out; g.act = q.act; g.nt_part = 0; g.chained = 0; g.dense_rows = q.M;
+    const int sub = (q.Cout + 31) / 32;
+    int nt = sub >= 4 ? 4 : sub;
+    if (sub > 4 && sub % 4) { for (int c = 4; c >= 1; --c) if (sub % c == 0) { nt = c; break; } }
+    const int cgs = (int)cdiv(sub, nt);
+    const int64_t tiles = cdiv(q.M, PT);
+    int gx = n_cu * (nt == 1 ? 3 : 2) / cgs;
+    gx = gx < 1 ? 1 : (gx < tiles ? gx : (int)tiles);
+    const dim3 grid((unsigned)gx, (unsigned)cgs);
+    switch (nt) {
+        case 1: hipLaunchKernelGGL(pair_gemm_direct_kernel_1, grid, dim3(256), 0, st, g); break;
+        case 2: hipLaunchKernelGGL(pair_gemm_direct_kernel_2, grid, dim3(256), 0, st, g); break;
+        case 3: hipLaunchKernelGGL(pair_gemm_direct_kernel_3, grid, dim3(256), 0, st, g); break;
+        default: hipLaunchKernelGGL(pair_gemm_direct_kernel_4, grid, dim3(256), 0, st, g); break;
     }
     SD3D_CHECK_LAUNCH();
     return SD3D_OK;

@@ -322,9 +322,9 @@ def test_architecture_matches_reference_golden(name, query_num, box, path, monke
     assert aligned >= 0.99 and twins >= 0.99, (aligned, twins)
     np.testing.assert_allclose(got_scores[ib], ref_scores[ia], rtol=5e-3, atol=1e-5)
     # What the alignment lets through is bounded: a reference row outside the aligned set must be a DISPLACED row - its
-    # (label, point mask) twin exists here and its score moved by no more than one thresholded superpoint moves a mask score
-    # (~1e-2, see above) - or, failing that, one of at most 0.5 % of the rows; and the in-place agreement keeps a floor: a displaced
-    # row shifts the rows between its two places by one, it does not scramble the table.
+    # (label, point mask) twin exists here and its score is the reference's (a tie that sorted the other way) - or, failing that, one
+    # of at most two rows; and the in-place agreement keeps a floor: a displaced row shifts the rows between its two places by one, it
+    # does not scramble the table.
     got_by_key = {}
     for i, k in enumerate(got_keys):
         got_by_key.setdefault(k, []).append(i)
@@ -336,10 +336,12 @@ def test_architecture_matches_reference_golden(name, query_num, box, path, monke
             continue
         worst_move = max(worst_move, min(abs(float(got_scores[c]) - float(ref_scores[i])) for c in cand))
     print(f"{name} [{path}]: {len(ref_keys) - len(ia)} reference rows outside the alignment, {lost} without a twin, largest score move of a displaced row {worst_move:.2e}")
-    assert worst_move <= 2e-2, worst_move
-    assert lost <= 0.005 * len(ref_keys), lost
-    assert bits_in_place >= 0.995, bits_in_place
-    assert in_place >= 0.9, in_place
+    # measured on MI355X, all five fixtures x three decoder paths (profiles/r05_parity_numbers.md): at most 2 of 600 rows outside the
+    # alignment, every one of them with a twin whose score moved <= 6e-9 (an exact tie swapped), bits equal in place >= 0.99857
+    assert worst_move <= 1e-6, worst_move
+    assert lost <= 2, lost
+    assert bits_in_place >= 0.998, bits_in_place
+    assert in_place >= 0.99, in_place
     box_ok = np.isclose(pd.instance_boxes[ib], g["inst_boxes"].numpy()[ia], rtol=5e-3, atol=5e-3).all(axis=1).mean()
     assert box_ok > 0.99, box_ok
     assert (pd.pts_semantic_mask[0] != g["sem_mask"].numpy()).mean() < 5e-3
