@@ -517,7 +517,20 @@ struct PGParams {
     int nt_part;                              // 1: non-temporal partial-product stores (several scenes in flight; see PART_STORE4)
     int chained;                              // 1: tile_k carries PG_CHAIN flags (chained lists: a tile's products add onto the next tile's)
     int64_t dense_rows;                       // > 0: no lists at all - pair p is (in = out = row p) of a dense [rows, Cin] x W[0]^T product (direct epilogue)
+    unsigned int* pool_ctr;                   // lock-step kernel: {next unit, workgroups done} per column group of this launch (zero before and after it), or NULL
 };
+
+// The shared tail of a lock-step launch.  A static partition gives every workgroup the same number of tiles, not the same time: a chained
+// table's ranges are snapped to chain boundaries (+-2 tiles of the 6 - 10 a workgroup has at levels 0 - 2), the workgroups of a CU are
+// served oldest first, the tiles' gathers hit or miss L2 - the counters of profiles/r05_pmc_pair_gemm.md put the MEAN wave lifetime at
+// 68 - 80 % of a launch while the pipe is 73 - 82 % busy during a wave's lifetime: a fifth of every launch is waiting for the last
+// workgroups.  So only the first 13/16 of the tile list is dealt out statically; the rest is a pool of small units (>= 6 steps each) that
+// the workgroups draw from an atomic counter as they run dry.  Which workgroup multiplies a tile never changes what is stored for it: the
+// results are the same bits.  The counters live in a ring of launch slots in device memory (zero-initialised with the code object); the
+// last workgroup of a launch leaves its slot zeroed, so no launch needs a memset.
+#define PG_POOL_SLOTS 16384
+#define PG_POOL_INTS 8                                          // per slot: {next, done} x up to 4 column groups
+__device__ unsigned int g_pool_ctr[PG_POOL_SLOTS * PG_POOL_INTS];
 
 
 // scale * x + shift as ONE fused multiply-add in every epilogue of this file, so that the paths agree bit for bit
@@ -551,10 +564,8 @@ __device__ __forceinline__ float pg_act(float t, int act) {
 // bit-identical to the old form's.  Measured (tools/r05_pair_ab.sh, profiles/EXPERIMENTS.md): -4 % on the 96-column layers of
 // levels 0-1, -1...-3 % elsewhere - the other workgroup of the CU was already covering most of those waits.
 #define PG_PIECE 24
-// The fp32 MFMA runs at the fp32 VECTOR rate on the same lanes (MI355X_MICROARCH.md): every VALU instruction of the step - address
-// arithmetic, register copies, the epilogue's per-store index products - is matrix time lost, not work hidden in a shadow (ablations of
-// round 5, profiles/EXPERIMENTS.md: a launch takes its MFMA time PLUS its non-MFMA time).  So the step is written for few VALU
-// instructions: the MFMA is issued transposed (A = weights, B = gathered rows: a lane owns one pair row and its accumulator groups are
+// The step is written for few vector instructions (376 instead of ~2400 per 204 MFMAs at NT = 4; it bought ~1 %, which is how the round
+// learned that instruction issue is not what bounds this kernel - profiles/EXPERIMENTS.md): the MFMA is issued transposed (A = weights, B = gathered rows: a lane owns one pair row and its accumulator groups are
 // four consecutive columns - 4 NT `dwordx4` stores from ONE 64-bit address per tile instead of 16 NT dword stores with an index product
 // each), the weight requests are a wave-uniform 64-bit base (scalar unit) + a per-thread 32-bit offset fixed for the launch, a gather
 // request is one 64-bit multiply-add per step.
@@ -565,15 +576,26 @@ __device__ __forceinline__ void pair_gemm_body(const PGParams& p, float (*Bs)[NT
     const int j = lane & 31, h = lane >> 5;
     const bool dense = DIRECT && p.dense_rows > 0;
     const int n_real = dense ? (int)((p.dense_rows + PT - 1) / PT) : p.tile_k[p.n_tiles];
-    int range0 = (int)((int64_t)blockIdx.x * n_real / gridDim.x);
-    int range1 = (int)((int64_t)(blockIdx.x + 1) * n_real / gridDim.x);
-    if (p.chained) {                                           // a chain of sub-tiles (<= 3) is never split between workgroups
-        while (range0 > 0 && range0 < n_real && (p.tile_k[range0 - 1] & PG_CHAIN)) ++range0;
-        while (range1 > 0 && range1 < n_real && (p.tile_k[range1 - 1] & PG_CHAIN)) ++range1;
-    }
-    if (range1 <= range0) return;                              // uniform over the workgroup
-    const int ncol0 = blockIdx.y * NT * 32;
     const int nchunks = p.Cin >> 5;
+    // static part [0, n_static) in equal ranges, then the pool [n_static, n_real) in units of `unit` tiles (see g_pool_ctr above)
+    // (not for the 32- / 64-channel layers: a unit of six one- or two-step tiles is shorter than the pipeline restart it costs - measured
+    //  +12 % / +4 % on the level-1 32 -> 32 and level-2 64 -> 64 layers, -3 ... -5 % on the 96- ... 192-channel ones)
+    const bool pool = p.pool_ctr != nullptr && nchunks >= 3 && n_real >= 6 * (int)gridDim.x;
+    int n_static = n_real;
+    const int unit = (6 + nchunks - 1) / nchunks;
+    if (pool) {
+        n_static = (int)((int64_t)n_real * 13 / 16);
+        if (p.chained) while (n_static < n_real && (p.tile_k[n_static - 1] & PG_CHAIN)) ++n_static;
+    }
+    int range0 = (int)((int64_t)blockIdx.x * n_static / gridDim.x);
+    int range1 = (int)((int64_t)(blockIdx.x + 1) * n_static / gridDim.x);
+    if (p.chained) {                                           // a chain of sub-tiles (<= 3) is never split between workgroups
+        while (range0 > 0 && range0 < n_static && (p.tile_k[range0 - 1] & PG_CHAIN)) ++range0;
+        while (range1 > 0 && range1 < n_static && (p.tile_k[range1 - 1] & PG_CHAIN)) ++range1;
+    }
+    if (range1 <= range0 && !pool) return;                     // uniform over the workgroup
+    const int ncol0 = blockIdx.y * NT * 32;
+    __shared__ int pool_unit;
     const uint64_t wstride_b = (uint64_t)p.Cout * (uint64_t)p.Cin * 4ull;
 
     f32x16 acc[NT];
@@ -613,6 +635,7 @@ __device__ __forceinline__ void pair_gemm_body(const PGParams& p, float (*Bs)[NT
     };
     const bool full_cols = ncol0 + NT * 32 <= p.Cout;           // every layer of the shipped networks (Cout a multiple of 32 NT)
 
+  for (;;) {                                                     // the static range, then pool units until the pool is empty
     for (int piece0 = range0; piece0 < range1; piece0 += PG_PIECE) {
         const int ntl = range1 - piece0 < PG_PIECE ? range1 - piece0 : PG_PIECE;
         __syncthreads();                                       // nobody still reads the previous piece's metadata / weight buffers
@@ -729,6 +752,26 @@ __device__ __forceinline__ void pair_gemm_body(const PGParams& p, float (*Bs)[NT
 #undef PF_ADVANCE
 #undef PF_ROW
     }
+    if (!pool) break;
+    __syncthreads();
+    if (tid == 0) pool_unit = (int)atomicAdd(p.pool_ctr + 2 * blockIdx.y, 1u);
+    __syncthreads();
+    const int u = __builtin_amdgcn_readfirstlane(pool_unit);
+    range0 = n_static + u * unit;
+    if (range0 >= n_real) break;
+    range1 = range0 + unit < n_real ? range0 + unit : n_real;
+    if (p.chained) {                                           // the same snapping rule at both ends: the units tile the pool without gaps or overlaps
+        while (range0 < n_real && (p.tile_k[range0 - 1] & PG_CHAIN)) ++range0;
+        while (range1 < n_real && (p.tile_k[range1 - 1] & PG_CHAIN)) ++range1;
+    }
+  }
+    if (pool) {                                                // the last workgroup of the column group leaves the launch slot zeroed
+        __syncthreads();
+        if (tid == 0) {
+            const unsigned done = atomicAdd(p.pool_ctr + 2 * blockIdx.y + 1, 1u);
+            if (done == gridDim.x - 1) { atomicExch(p.pool_ctr + 2 * blockIdx.y, 0u); atomicExch(p.pool_ctr + 2 * blockIdx.y + 1, 0u); }
+        }
+    }
 }
 
 #define PAIR_GEMM_ENTRY(NAME, NT, WAVES, DIRECT)                                                                \
@@ -754,6 +797,7 @@ PAIR_GEMM_ENTRY(pair_gemm_direct_kernel_4, 4, 2, true)
 // The MFMA is issued transposed (A = weights, B = gathered rows) so a lane owns one pair row and its
 // accumulator registers are 4-column groups: the partial products leave as dwordx4 stores.
 #define WS_RANGE_TILES 24       // most tiles one workgroup may be given: its gather indices live in LDS (12 KB)
+#define WS_STAGE_BATCH 16       // 16-byte weight requests per thread in flight while W[k] is staged
 
 // (An inline-asm variant of the gather with hand-counted s_waitcnt vmcnt(N) was tried to keep two steps
 // of loads in flight past hipcc's conservative waits: it was not faster - latency is not what limits this
@@ -805,15 +849,19 @@ __device__ __forceinline__ void pair_gemm_ws_body(const PGParams& p, float* Ws) 
         __syncthreads();                                       // everyone is done reading the previous W (and Ix is written)
         {
             const float* __restrict__ W = p.wt + ((int64_t)k * p.Cout + ncol0) * p.Cin;
-            for (int f0 = 0; f0 < npieces; f0 += 256 * 4) {
-                f32x4 v[4];
+            // sixteen requests per thread in flight (four before round 5): staging W[k] was 4 - 8 dependent L2 round trips of ~1.5 us before
+            // a workgroup's first MFMA - a fifth of a level-3 128 -> 128 launch, where a workgroup has 3.5 tiles.  Unconditional loads
+            // (clamped), conditional LDS writes: no exec-masked load for the compiler to wait on.
+            constexpr int SB = (NT == 1 || NT == 3) ? WS_STAGE_BATCH / 2 : WS_STAGE_BATCH;    // (the 3- and 4-waves-per-SIMD variants have 128 / 168 registers)
+            for (int f0 = 0; f0 < npieces; f0 += 256 * SB) {
+                f32x4 v[SB];
 #pragma unroll
-                for (int u = 0; u < 4; ++u) {
+                for (int u = 0; u < SB; ++u) {
                     const int f = f0 + u * 256 + tid;
-                    if (f < npieces) v[u] = *(const f32x4*)(W + (int64_t)f * 4);
+                    v[u] = *(const f32x4*)(W + (int64_t)(f < npieces ? f : npieces - 1) * 4);
                 }
 #pragma unroll
-                for (int u = 0; u < 4; ++u) {
+                for (int u = 0; u < SB; ++u) {
                     const int f = f0 + u * 256 + tid;
                     if (f < npieces) {
                         const int row = f / c4, col = f - row * c4;
@@ -1199,6 +1247,7 @@ int launch_pair_conv(const float* in0, int ld0, int C0, const float* in1, int ld
         g.nt_part = nt_env >= 0 ? (nt_env != 0) : (g_scenes_in_flight.load(std::memory_order_relaxed) > 1 ? 1 : 0);
     }
     g.dense_rows = 0;
+    g.pool_ctr = nullptr;
     g.out_idx = direct ? out_idx : nullptr;
     g.scale = scale; g.shift = shift; g.res = res; g.ld_res = ld_res; g.out = out; g.ld_out = ld_out; g.act = act;
     const int sub = (Cout + 31) / 32;
@@ -1273,6 +1322,14 @@ int launch_pair_conv(const float* in0, int ld0, int C0, const float* in1, int ld
         int gx = n_cu * per_cu / cgs;
         gx = gx < 1 ? 1 : (gx < g.n_tiles ? gx : g.n_tiles);
         const dim3 grid((unsigned)gx, (unsigned)cgs);
+        {   // SD3D_PAIR_POOL=0: every tile dealt out statically (rounds 1-4)
+            static const int pool_env = env_flag("SD3D_PAIR_POOL", 1);
+            static unsigned int* pool_base = nullptr;
+            static std::atomic<unsigned> pool_next{0};
+            if (pool_env && !pool_base && hipGetSymbolAddress((void**)&pool_base, HIP_SYMBOL(g_pool_ctr)) != hipSuccess) pool_base = nullptr;
+            if (pool_env && pool_base && 2 * cgs <= PG_POOL_INTS)
+                g.pool_ctr = pool_base + (size_t)(pool_next.fetch_add(1, std::memory_order_relaxed) % PG_POOL_SLOTS) * PG_POOL_INTS;
+        }
         if (direct) {
             switch (nt) {
                 case 1: hipLaunchKernelGGL(pair_gemm_direct_kernel_1, grid, dim3(256), 0, st, g); break;
@@ -1320,7 +1377,7 @@ int launch_pair_dense(const GGParams& q, hipStream_t st) {
     PGParams g;
     g.in0 = q.in0; g.ld0 = q.ld0; g.C0 = q.in1 ? q.C0 : q.Cin; g.in1 = q.in1; g.ld1 = q.ld1; g.in_idx = nullptr; g.tile_k = nullptr; g.wt = q.wt;
     g.Cin = q.Cin; g.Cout = q.Cout; g.part = nullptr; g.n_tiles = 0; g.out_idx = nullptr; g.scale = q.scale; g.shift = q.shift; g.res = q.res;
-    g.ld_res = q.ld_res; g.out = q.out; g.ld_out = q.ld_out; g.act = q.act; g.nt_part = 0; g.chained = 0; g.dense_rows = q.M;
+    g.ld_res = q.ld_res; g.out = q.out; g.ld_out = q.ld_out; g.act = q.act; g.nt_part = 0; g.chained = 0; g.dense_rows = q.M; g.pool_ctr = nullptr;
     const int sub = (q.Cout + 31) / 32;
     int nt = sub >= 4 ? 4 : sub;
     if (sub > 4 && sub % 4) { for (int c = 4; c >= 1; --c) if (sub % c == 0) { nt = c; break; } }
