@@ -242,7 +242,7 @@ int sd3d_pair_conv(const float* in0, int ld0, int C0, const float* in1, int ld1,
  * centre K / 2): CHAINED lists - the entries of an output row that belong to one mirror group {k, K-1-k}, plus the centre in the
  * row's first non-empty group, share ONE partial product (pass 1 accumulates across up to three consecutive sub-tiles and stores
  * once; tile_k carries bit 30 on all but the last sub-tile of a chain).  27-44 % fewer partial rows on surface-like scenes.  For
- * these tables pos is [K / 2 + 1, M] (partial position per mirror group), rlist is required (rl_stride >= K / 2 + 2), p_cap >=
+ * these tables pos is not written (may be NULL: a row's partial positions are its rlist), rlist is required (rl_stride >= K / 2 + 2), K <= 125, p_cap >=
  * pairs + 127 * (11 * (K / 2) + 1), and the same value goes to sd3d_pair_conv_ex / sd3d_run_layers as `center`. */
 #define SD3D_PAIR_CHAINED (-2)
 typedef struct sd3d_pair_table_desc {

@@ -294,73 +294,82 @@ __global__ __launch_bounds__(RL_ROWS) void pair_rowlist_batch_kernel(const PLBat
 #define PG_CHAIN 0x40000000
 #define PG_KMASK 0x3FFFFFFF
 #define CH_NPAT 6
+#define CH_ROWS 256              // rows per workgroup of the chained builder (one row per thread)
+#define CH_GB 7                  // mirror groups whose two columns are requested together
+#define CH_MAX_G 62              // K <= 125
+#define CH_MAX_SEG (CH_MAX_G * CH_NPAT + 1)
+// Round 5 form of the builder: a workgroup owns 256 ROWS and walks all mirror groups of them (before: one workgroup per (group, 2048
+// rows), five launches - first group per row, count, scan, fill, per-row lists - with the group positions [G + 1][M] and the first
+// groups [M] going through memory in between: 0.49 ms of kernel time per scene).  A row's first non-empty group is known on the fly
+// when the groups are walked in ascending order, so the count launch needs no first-group pass, and the fill launch knows ALL partial
+// positions of its rows: it writes the per-row lists itself.  Three launches (count, scan, fill); the table is read twice instead of
+// ~4.5 times and nothing but the per-(segment, row block) counters sits between them.  The lists are the same, entry for entry.
 struct CHTable {
-    const int32_t* nbr; int32_t* gpos; int32_t* in_idx; int32_t* tile_k; int32_t* blk_cnt; int32_t* totals; int32_t* first_g; int32_t* rlist;
+    const int32_t* nbr; int32_t* in_idx; int32_t* tile_k; int32_t* blk_cnt; int32_t* totals; int32_t* rlist;
     int64_t M, p_cap;
     int K, G, nblk, rl_stride;
-    int wg0, sg0, rb0, fb0;        // first workgroup of the table in the (G + 1) * nblk grid / the segment grid / the row-list grid / the first-group grid
+    int wg0, sg0;                  // first workgroup of the table in the row-block grid / the segment grid
 };
 struct CHBatch { int n; CHTable t[PL_MAX_TABLES]; };
 __device__ __forceinline__ int ch_find(const CHBatch& b, int wg, int by) {
     int ti = 0;
-    for (int i = 1; i < b.n; ++i) if (wg >= (by == 0 ? b.t[i].wg0 : (by == 1 ? b.t[i].sg0 : (by == 2 ? b.t[i].rb0 : b.t[i].fb0)))) ti = i;
+    for (int i = 1; i < b.n; ++i) if (wg >= (by == 0 ? b.t[i].wg0 : b.t[i].sg0)) ti = i;
     return ti;
 }
 __device__ __forceinline__ int ch_nsrc(int pat) { return pat < 2 ? 1 : (pat < 5 ? 2 : 3); }
 
-// first_g[r] = first mirror group in which row r has a neighbour (G: none)
-__global__ __launch_bounds__(256) void chain_first_kernel(const CHBatch b) {
-    const int ti = ch_find(b, blockIdx.x, 3);
-    const CHTable& T = b.t[ti];
-    const int64_t row = (int64_t)(blockIdx.x - T.fb0) * 256 + threadIdx.x;
-    if (row >= T.M) return;
-    // every load of a batch of groups requested before the first is looked at (the short-circuit form was a chain of up to 2 G dependent
-    // memory latencies per row: 39 us per table; the loads are coalesced over the rows and independent)
-    int first = T.G;
-    for (int g0 = 0; g0 < T.G; g0 += 7) {
-        int a[7], b[7];
+// The mirror groups of one row in ascending order: f(g, pattern, ia, ib) for EVERY group (pattern -1: no neighbour in it; the calls are
+// wave-uniform, f may ballot).  Returns whether the row has any neighbour at all.  The two columns of CH_GB groups are requested
+// together (coalesced over the rows, independent).
+template <class F>
+__device__ __forceinline__ bool ch_walk(const CHTable& T, int64_t row, bool live, F&& f) {
+    bool seen = false;
+    const int64_t rc = live ? row : 0;
+    for (int g0 = 0; g0 < T.G; g0 += CH_GB) {
+        int a[CH_GB], b[CH_GB];
 #pragma unroll
-        for (int u = 0; u < 7; ++u) {
+        for (int u = 0; u < CH_GB; ++u) {
             const int g = g0 + u < T.G ? g0 + u : T.G - 1;
-            a[u] = T.nbr[(int64_t)g * T.M + row];
-            b[u] = T.nbr[(int64_t)(T.K - 1 - g) * T.M + row];
+            a[u] = T.nbr[(int64_t)g * T.M + rc];
+            b[u] = T.nbr[(int64_t)(T.K - 1 - g) * T.M + rc];
         }
 #pragma unroll
-        for (int u = 6; u >= 0; --u)
-            if (g0 + u < T.G && (a[u] >= 0 || b[u] >= 0) && g0 + u < first) first = g0 + u;
+        for (int u = 0; u < CH_GB; ++u) {
+            if (g0 + u < T.G) {
+                const int ia = live ? a[u] : -1, ib = live ? b[u] : -1;
+                int pat = -1;
+                if (ia >= 0 || ib >= 0) {
+                    pat = (ia >= 0 ? (ib >= 0 ? 2 : 0) : 1) + (seen ? 0 : 3);     // the centre rides in the row's first non-empty group
+                    seen = true;
+                }
+                f(g0 + u, pat, ia, ib);
+            }
+        }
     }
-    T.first_g[row] = first;
+    return seen;
 }
-// pattern of (group g, row): -1 none
-__device__ __forceinline__ int ch_pattern(const CHTable& T, int g, int64_t row, int& ia, int& ib) {
-    ia = ib = -1;
-    if (row >= T.M) return -1;
-    if (g == T.G) return T.first_g[row] == T.G ? 0 : -1;       // the centre-only segment (reported as pattern 0 of group G)
-    ia = T.nbr[(int64_t)g * T.M + row];
-    ib = T.nbr[(int64_t)(T.K - 1 - g) * T.M + row];
-    if (ia < 0 && ib < 0) return -1;
-    const int base = ia >= 0 ? (ib >= 0 ? 2 : 0) : 1;
-    return base + (T.first_g[row] == g ? 3 : 0);
-}
+
 __global__ __launch_bounds__(256) void chain_count_kernel(const CHBatch b) {
-    __shared__ int sm[4][CH_NPAT];
+    __shared__ int wc[4][CH_MAX_SEG];
     const int ti = ch_find(b, blockIdx.x, 0);
     const CHTable& T = b.t[ti];
-    const int local = blockIdx.x - T.wg0, g = local / T.nblk, blk = local - g * T.nblk, tid = threadIdx.x;
-    int c[CH_NPAT] = {0, 0, 0, 0, 0, 0};
-    for (int i = 0; i < PL_ROWS / 256; ++i) {
-        int ia, ib;
-        const int pat = ch_pattern(T, g, (int64_t)blk * PL_ROWS + i * 256 + tid, ia, ib);
+    const int blk = blockIdx.x - T.wg0, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int64_t row = (int64_t)blk * CH_ROWS + tid;
+    const bool live = row < T.M;
+    const bool seen = ch_walk(T, row, live, [&](int g, int pat, int, int) {
 #pragma unroll
-        for (int q = 0; q < CH_NPAT; ++q) c[q] += __popcll(__ballot(pat == q));
-    }
-    if ((tid & 63) == 0) {
-#pragma unroll
-        for (int q = 0; q < CH_NPAT; ++q) sm[tid >> 6][q] = c[q];
+        for (int q = 0; q < CH_NPAT; ++q) {
+            const int c = __popcll(__ballot(pat == q));
+            if (lane == 0) wc[wv][g * CH_NPAT + q] = c;
+        }
+    });
+    {
+        const int c = __popcll(__ballot(live && !seen));        // the centre-only segment
+        if (lane == 0) wc[wv][T.G * CH_NPAT] = c;
     }
     __syncthreads();
-    const int npat = g == T.G ? 1 : CH_NPAT;
-    if (tid < npat) T.blk_cnt[(int64_t)(g * CH_NPAT + tid) * T.nblk + blk] = sm[0][tid] + sm[1][tid] + sm[2][tid] + sm[3][tid];
+    const int nseg = T.G * CH_NPAT + 1;
+    for (int sg = tid; sg < nseg; sg += 256) T.blk_cnt[(int64_t)sg * T.nblk + blk] = wc[0][sg] + wc[1][sg] + wc[2][sg] + wc[3][sg];
 }
 __global__ __launch_bounds__(256) void chain_scan_kernel(const CHBatch b) {
     __shared__ int sm[4];
@@ -380,123 +389,117 @@ __global__ __launch_bounds__(256) void chain_scan_kernel(const CHBatch b) {
 }
 __global__ __launch_bounds__(256) void chain_fill_kernel(const CHBatch b) {
     __shared__ int sm[4];
-    __shared__ int wcnt[4][CH_NPAT];
+    __shared__ int wb[4][CH_MAX_SEG];          // per wave: entries of the segment in this wave, then its first position in the segment
+    __shared__ int seg_tile[CH_MAX_SEG], seg_tot[CH_MAX_SEG];
     const int ti = ch_find(b, blockIdx.x, 0);
     const CHTable& T = b.t[ti];
-    const int local = blockIdx.x - T.wg0, g = local / T.nblk, blk = local - g * T.nblk;
-    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-    const int seg0 = g * CH_NPAT, npat = g == T.G ? 1 : CH_NPAT;
-    const int centre = T.K / 2;
-    // first tile of this group's first segment = sum over the segments before it of ceil(total / 128) * sources
-    int s = 0;
-    for (int q = tid; q < seg0; q += 256) s += (T.totals[q] + PT - 1) / PT * ch_nsrc(q % CH_NPAT);
-    int tile_base;
-    block_excl_scan_256p(s, &tile_base, sm);
-    int seg_tile[CH_NPAT], seg_tot[CH_NPAT];
+    const int blk = blockIdx.x - T.wg0, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int nseg = T.G * CH_NPAT + 1, centre = T.K / 2;
+    const int64_t row = (int64_t)blk * CH_ROWS + tid;
+    const bool live = row < T.M;
+    // first tile of every segment = sum over the segments before it of ceil(total / 128) * sources
+    int end_tile = 0;
+    for (int base = 0; base < nseg; base += 256) {
+        const int sg = base + tid;
+        const int tot = sg < nseg ? T.totals[sg] : 0;
+        const int v = (tot + PT - 1) / PT * (sg == nseg - 1 ? 1 : ch_nsrc(sg % CH_NPAT));
+        int total;
+        const int ex = block_excl_scan_256p(v, &total, sm);
+        if (sg < nseg) { seg_tile[sg] = end_tile + ex; seg_tot[sg] = tot; }
+        end_tile += total;
+    }
+    // this wave's entries per segment, then their first position: the block's start in the segment + the waves before this one
+    const bool any = ch_walk(T, row, live, [&](int g, int pat, int, int) {
+#pragma unroll
+        for (int q = 0; q < CH_NPAT; ++q) {
+            const int c = __popcll(__ballot(pat == q));
+            if (lane == 0) wb[wv][g * CH_NPAT + q] = c;
+        }
+    });
     {
-        int t = tile_base;
+        const int c = __popcll(__ballot(live && !any));
+        if (lane == 0) wb[wv][T.G * CH_NPAT] = c;
+    }
+    __syncthreads();
+    for (int sg = tid; sg < nseg; sg += 256) {
+        int run = T.blk_cnt[(int64_t)sg * T.nblk + blk];
 #pragma unroll
-        for (int q = 0; q < CH_NPAT; ++q) {
-            seg_tot[q] = q < npat ? T.totals[seg0 + q] : 0;
-            seg_tile[q] = t;
-            t += (seg_tot[q] + PT - 1) / PT * ch_nsrc(q);
+        for (int w = 0; w < 4; ++w) { const int c = wb[w][sg]; wb[w][sg] = run; run += c; }
+    }
+    __syncthreads();
+    // tile headers and the -1 padding of the segments, dealt out to the row blocks
+    for (int sg = blk; sg < nseg; sg += T.nblk) {
+        const int g = sg / CH_NPAT, q = sg - g * CH_NPAT;
+        const int ns = g == T.G ? 1 : ch_nsrc(q), nt = (seg_tot[sg] + PT - 1) / PT;
+        for (int e = tid; e < nt * ns; e += 256) {
+            const int sub = e % ns;
+            int k;                                      // source order: centre, +d (k = g), -d (k = K - 1 - g)
+            if (g == T.G) k = centre;
+            else if (q == 0) k = g;
+            else if (q == 1) k = T.K - 1 - g;
+            else if (q == 2) k = sub == 0 ? g : T.K - 1 - g;
+            else if (q == 3) k = sub == 0 ? centre : g;
+            else if (q == 4) k = sub == 0 ? centre : T.K - 1 - g;
+            else k = sub == 0 ? centre : (sub == 1 ? g : T.K - 1 - g);
+            if ((int64_t)(seg_tile[sg] + e) * PT < T.p_cap) T.tile_k[seg_tile[sg] + e] = k | (sub < ns - 1 ? PG_CHAIN : 0);
         }
-        if (blk == 0) {
-            // tile headers and the -1 padding of this group's segments
-            for (int q = 0; q < npat; ++q) {
-                const int ns = ch_nsrc(q), nt = (seg_tot[q] + PT - 1) / PT;
-                for (int e = tid; e < nt * ns; e += 256) {
-                    const int sub = e % ns;
-                    int k;                                      // source order: centre, +d (k = g), -d (k = K - 1 - g)
-                    if (g == T.G) k = centre;
-                    else if (q == 0) k = g;
-                    else if (q == 1) k = T.K - 1 - g;
-                    else if (q == 2) k = sub == 0 ? g : T.K - 1 - g;
-                    else if (q == 3) k = sub == 0 ? centre : g;
-                    else if (q == 4) k = sub == 0 ? centre : T.K - 1 - g;
-                    else k = sub == 0 ? centre : (sub == 1 ? g : T.K - 1 - g);
-                    if ((int64_t)(seg_tile[q] + e) * PT < T.p_cap) T.tile_k[seg_tile[q] + e] = k | (sub < ns - 1 ? PG_CHAIN : 0);
-                }
-                if (nt > 0) {
-                    const int fill0 = seg_tot[q] - (nt - 1) * PT;       // real entries of the last tile row-block
-                    for (int e = tid; e < (PT - fill0) * ns; e += 256) {
-                        const int sub = e / (PT - fill0), off = fill0 + e % (PT - fill0);
-                        const int64_t pp = (int64_t)(seg_tile[q] + (nt - 1) * ns + sub) * PT + off;
-                        if (pp < T.p_cap) T.in_idx[pp] = -1;
-                    }
-                }
+        if (nt > 0) {
+            const int fill0 = seg_tot[sg] - (nt - 1) * PT;       // real entries of the last tile row-block
+            for (int e = tid; e < (PT - fill0) * ns; e += 256) {
+                const int sub = e / (PT - fill0), off = fill0 + e % (PT - fill0);
+                const int64_t pp = (int64_t)(seg_tile[sg] + (nt - 1) * ns + sub) * PT + off;
+                if (pp < T.p_cap) T.in_idx[pp] = -1;
             }
         }
-        if (g == T.G) {
-            // past the last segment: unused capacity reads as "no pair"; the number of real tiles after the last slot
-            const int64_t end_tile = t;
-            const int64_t cap_tiles = T.p_cap / PT;
-            if (blk == 0 && tid == 0) { T.tile_k[cap_tiles] = (int)(end_tile < cap_tiles ? end_tile : cap_tiles); T.tile_k[cap_tiles + 1] = 0; T.tile_k[cap_tiles + 2] = 0; }
-            for (int64_t e = end_tile * PT + (int64_t)blk * 256 + tid; e < T.p_cap; e += (int64_t)T.nblk * 256) T.in_idx[e] = -1;
-            for (int64_t tt = end_tile + (int64_t)blk * 256 + tid; tt < cap_tiles; tt += (int64_t)T.nblk * 256) T.tile_k[tt] = -1;
-        }
     }
-    int run[CH_NPAT];
-#pragma unroll
-    for (int q = 0; q < CH_NPAT; ++q) run[q] = q < npat ? T.blk_cnt[(int64_t)(seg0 + q) * T.nblk + blk] : 0;
+    {
+        // past the last segment: unused capacity reads as "no pair"; the number of real tiles after the last slot
+        const int64_t cap_tiles = T.p_cap / PT;
+        if (blk == 0 && tid == 0) { T.tile_k[cap_tiles] = (int)(end_tile < cap_tiles ? end_tile : cap_tiles); T.tile_k[cap_tiles + 1] = 0; T.tile_k[cap_tiles + 2] = 0; }
+        for (int64_t e = (int64_t)end_tile * PT + (int64_t)blk * 256 + tid; e < T.p_cap; e += (int64_t)T.nblk * 256) T.in_idx[e] = -1;
+        for (int64_t tt = end_tile + (int64_t)blk * 256 + tid; tt < cap_tiles; tt += (int64_t)T.nblk * 256) T.tile_k[tt] = -1;
+    }
+    // the entries of this row, group by group, and its list of partial positions (the last sub-tile of each of its chains, ascending)
     const uint64_t lt = (1ull << lane) - 1ull;
-#pragma unroll 1
-    for (int i = 0; i < PL_ROWS / 256; ++i) {
-        const int64_t row = (int64_t)blk * PL_ROWS + i * 256 + tid;
-        int ia, ib;
-        const int pat = ch_pattern(T, g, row, ia, ib);
-        uint64_t bal[CH_NPAT];
-#pragma unroll
-        for (int q = 0; q < CH_NPAT; ++q) bal[q] = __ballot(pat == q);
-        if (lane == 0) {
-#pragma unroll
-            for (int q = 0; q < CH_NPAT; ++q) wcnt[wv][q] = __popcll(bal[q]);
-        }
-        __syncthreads();
-        int my = -1;
+    int32_t* rl = T.rlist + (live ? row : 0) * T.rl_stride;
+    int cnt = 0;
+    ch_walk(T, row, live, [&](int g, int pat, int ia, int ib) {
+        uint64_t mine = 0;
 #pragma unroll
         for (int q = 0; q < CH_NPAT; ++q) {
-            int before = 0;
-            for (int w = 0; w < wv; ++w) before += wcnt[w][q];
-            if (pat == q) my = run[q] + before + __popcll(bal[q] & lt);
-            run[q] += wcnt[0][q] + wcnt[1][q] + wcnt[2][q] + wcnt[3][q];
+            const uint64_t bal = __ballot(pat == q);
+            if (pat == q) mine = bal;
         }
-        __syncthreads();
-        int32_t gp = -1;
         if (pat >= 0) {
-            const int ns = g == T.G ? 1 : ch_nsrc(pat);
-            const int64_t tile = seg_tile[pat] + (int64_t)(my >> 7) * ns;
+            const int sg = g * CH_NPAT + pat, ns = ch_nsrc(pat);
+            const int my = wb[wv][sg] + __popcll(mine & lt);
+            const int64_t tile = seg_tile[sg] + (int64_t)(my >> 7) * ns;
             const int off = my & (PT - 1);
-            int src[3];
-            int n = 0;
-            if (g == T.G || pat >= 3) src[n++] = (int)row;      // the centre: in = out = r
-            if (g < T.G && ia >= 0) src[n++] = ia;
-            if (g < T.G && ib >= 0) src[n++] = ib;
             if ((tile + ns) * PT <= T.p_cap) {
-                for (int q = 0; q < ns; ++q) T.in_idx[(tile + q) * PT + off] = src[q];
-                gp = (int32_t)((tile + ns - 1) * PT + off);
+                int64_t pp = tile * PT + off;
+                if (pat >= 3) { T.in_idx[pp] = (int)row; pp += PT; }      // the centre: in = out = r
+                if (ia >= 0) { T.in_idx[pp] = ia; pp += PT; }
+                if (ib >= 0) { T.in_idx[pp] = ib; pp += PT; }
+                rl[1 + cnt++] = (int32_t)(pp - PT);
             }
         }
-        if (row < T.M) T.gpos[(int64_t)g * T.M + row] = gp;
+    });
+    {
+        const bool lone = live && !any;
+        const uint64_t bal = __ballot(lone);
+        if (lone) {
+            const int sg = T.G * CH_NPAT;
+            const int my = wb[wv][sg] + __popcll(bal & lt);
+            const int64_t pp = (int64_t)(seg_tile[sg] + (my >> 7)) * PT + (my & (PT - 1));
+            if (pp < T.p_cap) { T.in_idx[pp] = (int)row; rl[1 + cnt++] = (int32_t)pp; }
+        }
     }
-}
-__global__ __launch_bounds__(RL_ROWS) void chain_rowlist_kernel(const CHBatch b) {
-    const int ti = ch_find(b, blockIdx.x, 2);
-    const CHTable& T = b.t[ti];
-    const int64_t row = (int64_t)(blockIdx.x - T.rb0) * RL_ROWS + threadIdx.x;
-    if (row >= T.M) return;
-    int32_t* rl = T.rlist + row * T.rl_stride;
-    int cnt = 0;
-    for (int g = 0; g <= T.G; ++g) {
-        const int v = T.gpos[(int64_t)g * T.M + row];
-        if (v >= 0) rl[1 + cnt++] = v;
-    }
-    rl[0] = cnt;
+    if (live) rl[0] = cnt;
 }
 size_t chain_lists_ws_bytes(int K, int64_t M) {
-    const int64_t nblk = cdiv(M, PL_ROWS);
+    const int64_t nblk = cdiv(M, CH_ROWS);
     const int64_t nseg = (int64_t)(K / 2) * CH_NPAT + 1;
-    return (size_t)(nseg * nblk + nseg + M) * sizeof(int32_t) + 256;
+    return (size_t)(nseg * nblk + nseg) * sizeof(int32_t) + 256;
 }
 
 // ---- pass 1: dense tiles over the pair list --------------------------------------------------
@@ -1141,25 +1144,25 @@ int launch_pair_lists_desc(int n, const sd3d_pair_table_desc* d, void* ws, size_
     cb.n = 0;
     size_t off = 0;
     int wg = 0, kk = 0, rb = 0;
-    int cwg = 0, csg = 0, crb = 0, cfb = 0;
+    int cwg = 0, csg = 0;
     for (int i = 0; i < n; ++i) {
         const int K = d[i].K;
         const int64_t M = d[i].M, p_cap = d[i].p_cap;
         if (d[i].center == SD3D_PAIR_CHAINED && K > 0 && M > 0) {
             // chained lists (mirror groups + centre share a partial product): their own builder
             if (!(K & 1) || K < 3) return sd3d_set_error(SD3D_ERR_ARG, "pair_lists_batch: chained lists need an odd kernel (symmetric offsets)");
-            if (p_cap <= 0 || (p_cap % PT) || !d[i].rlist || !d[i].pos || d[i].rl_stride < K / 2 + 2 || (d[i].rl_stride & 3))
-                return sd3d_set_error(SD3D_ERR_ARG, "pair_lists_batch: chained lists need pos [K / 2 + 1, M], rlist and rl_stride >= K / 2 + 2");
+            if (K / 2 > CH_MAX_G) return sd3d_set_error(SD3D_ERR_ARG, "pair_lists_batch: chained lists take kernels up to 5^3");
+            if (p_cap <= 0 || (p_cap % PT) || !d[i].rlist || d[i].rl_stride < K / 2 + 2 || (d[i].rl_stride & 3))
+                return sd3d_set_error(SD3D_ERR_ARG, "pair_lists_batch: chained lists need rlist and rl_stride >= K / 2 + 2");
             CHTable& T = cb.t[cb.n++];
-            T.nbr = d[i].nbr; T.gpos = d[i].pos; T.in_idx = d[i].in_idx; T.tile_k = d[i].tile_k; T.rlist = d[i].rlist; T.M = M; T.p_cap = p_cap;
-            T.K = K; T.G = K / 2; T.nblk = (int)cdiv(M, PL_ROWS); T.rl_stride = d[i].rl_stride;
+            T.nbr = d[i].nbr; T.in_idx = d[i].in_idx; T.tile_k = d[i].tile_k; T.rlist = d[i].rlist; T.M = M; T.p_cap = p_cap;
+            T.K = K; T.G = K / 2; T.nblk = (int)cdiv(M, CH_ROWS); T.rl_stride = d[i].rl_stride;
             const int nseg = T.G * CH_NPAT + 1;
             T.blk_cnt = (int32_t*)((char*)ws + off);
             T.totals = T.blk_cnt + (int64_t)nseg * T.nblk;
-            T.first_g = T.totals + nseg;
             off += align_up(chain_lists_ws_bytes(K, M), 256);
-            T.wg0 = cwg; T.sg0 = csg; T.rb0 = crb; T.fb0 = cfb;
-            cwg += (T.G + 1) * T.nblk; csg += nseg; crb += (int)cdiv(M, RL_ROWS); cfb += (int)cdiv(M, 256);
+            T.wg0 = cwg; T.sg0 = csg;
+            cwg += T.nblk; csg += nseg;
             continue;
         }
         if (K <= 0 || M <= 0) {                                // no rows: a later pair_conv on this table must see "0 real tiles"
@@ -1183,11 +1186,9 @@ int launch_pair_lists_desc(int n, const sd3d_pair_table_desc* d, void* ws, size_
     }
     if (off > ws_bytes) return sd3d_set_error(SD3D_ERR_ARG, "pair_lists_batch: workspace too small");
     if (cb.n > 0) {
-        hipLaunchKernelGGL(chain_first_kernel, dim3(cfb), dim3(256), 0, st, cb);
         hipLaunchKernelGGL(chain_count_kernel, dim3(cwg), dim3(256), 0, st, cb);
         hipLaunchKernelGGL(chain_scan_kernel, dim3(csg), dim3(256), 0, st, cb);
         hipLaunchKernelGGL(chain_fill_kernel, dim3(cwg), dim3(256), 0, st, cb);
-        hipLaunchKernelGGL(chain_rowlist_kernel, dim3(crb), dim3(RL_ROWS), 0, st, cb);
         SD3D_CHECK_LAUNCH();
     }
     if (b.n == 0) return SD3D_OK;

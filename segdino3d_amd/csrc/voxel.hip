@@ -763,7 +763,7 @@ int launch_voxel_mean_batch(const sd3d_scene_src* scenes, int n_scenes, int F, i
 // ---------------------------------------------------------------------------------------------
 // superpoint pooling: segment starts from sorted superpoint ids, then fused devoxelise
 // (`x.slice(field)` = F[inverse[p]]) + scatter_mean of features and of floor-quantised positions
-// (minkunet.py:631-656).  One wave per superpoint; the wave's two 32-lane halves take alternate
+// (minkunet.py:631-656).  One workgroup per superpoint (see the kernel); a wave's two 32-lane halves take alternate
 // members (C/4 lanes x float4 each, 3 more lanes for xyz) and are combined with one cross-half
 // shuffle, so the summation order is fixed.
 // ---------------------------------------------------------------------------------------------
@@ -777,58 +777,68 @@ __global__ __launch_bounds__(256) void segment_starts_kernel(const uint64_t* __r
     for (int64_t s = prev + 1; s <= cur; ++s) start[s] = (int32_t)j;
 }
 
-#define PS_ROWS 16
+// Round 5: one WORKGROUP (four waves) per superpoint, the rows staged through LDS.  With one wave per superpoint the launch lasted as
+// long as its largest superpoint (176 points on the benchmark scene against a mean of 50): three rounds of {sidx -> inverse -> two
+// batches of feature rows}, twelve dependent memory latencies, 36 us for 58 MB.  Now the 256 threads resolve the sidx -> inverse chain
+// of up to 256 points with ONE pair of dependent loads, the four waves request the feature rows of a 64-point pass together (16 rows
+// per wave, all in flight) and park them in LDS, and wave 0 adds them up from there IN THE ORDER OF THE OLD KERNEL (its 32-lane half h
+// takes the points h, h + 2, h + 4, ... of the superpoint in ascending order, the halves are combined by one shuffle at the end): the
+// sums are the same bits as before, only the loads are no longer serialised behind the additions.
+#define PS_PASS 64               // points per pass
+#define PS_LD 100                // floats per staged row: C <= 96 feature columns + 3 coordinates (+ 1 pad)
 __global__ __launch_bounds__(256) void pool_superpoints_kernel(const float* __restrict__ feat, int ld_feat, int C,
                                                                const int32_t* __restrict__ inverse,
                                                                const int32_t* __restrict__ icoords, float voxel_size,
                                                                const uint32_t* __restrict__ sidx, const int32_t* __restrict__ start,
                                                                int64_t S, float* __restrict__ out_feat, float* __restrict__ out_pos) {
-    const int lane = threadIdx.x & 63;
-    const int64_t s = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (s >= S) return;
+    __shared__ __attribute__((aligned(16))) float rows[PS_PASS][PS_LD];
+    __shared__ int vix[256], pix[256];
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int64_t s = blockIdx.x;
     const int half = lane >> 5, li = lane & 31;
     const int nvec = C >> 2;
     const int j0 = start[s], j1 = start[s + 1];
     f32x4 acc = {0.f, 0.f, 0.f, 0.f};
     float pacc = 0.f;
-    // The sidx -> inverse -> feature chain is three dependent loads per point and a superpoint has only ~50 points.  The first two
-    // are resolved for 64 points at once (lane (half, i) fetches the half's i-th point), then every lane walks its half's points
-    // with eight feature rows in flight; each half still adds its points in ascending order, so the sums are bit-identical to
-    // the one-by-one loop (53 us -> the launch is now bound by the 58 MB it gathers).
-    for (int jr = j0; jr < j1; jr += 64) {
-        const int jm = jr + half + 2 * li;                     // this lane's point of the round
-        const int64_t pm = jm < j1 ? (int64_t)sidx[jm] : -1;
-        const int vm = pm >= 0 ? inverse[pm] : 0;
-        const int nmine = (j1 - jr - half + 1) >> 1;           // points of this half in the round (<= 32)
-        const int ni = nmine < 32 ? nmine : 32;
-        const int nloop = ((j1 - jr + 1) >> 1) < 32 ? ((j1 - jr + 1) >> 1) : 32;   // wave-uniform trip count (half 0 may hold one point more)
-        // sixteen feature rows per lane in flight (round 5; eight before): a superpoint of ~50 points is two request rounds per half
-        // instead of four - the launch is a chain of memory latencies (3000 waves, all resident at once), not a stream.  Same order of
-        // additions per half: the same bits.
-        for (int i0 = 0; i0 < nloop; i0 += PS_ROWS) {          // the shuffles stay outside the lane-dependent branches
-            int vv[PS_ROWS], pq[PS_ROWS];
+    for (int jp = j0; jp < j1; jp += 256) {
+        const int jm = jp + tid;
+        const uint32_t pm = jm < j1 ? sidx[jm] : 0u;
+        const int vm = jm < j1 ? inverse[pm] : 0;
+        __syncthreads();                                        // (the previous chunk's last pass is summed)
+        vix[tid] = vm;
+        pix[tid] = (int)pm;
+        __syncthreads();
+        const int npts = j1 - jp < 256 ? j1 - jp : 256;
+        for (int p0 = 0; p0 < npts; p0 += PS_PASS) {
+            const int np = npts - p0 < PS_PASS ? npts - p0 : PS_PASS;      // points of this pass
+            f32x4 xx[8];
+            int cc[8];
 #pragma unroll
-            for (int u = 0; u < PS_ROWS; ++u) {
-                const int src = (i0 + u < 32 ? i0 + u : 31) + 32 * half;
-                vv[u] = __shfl(vm, src);
-                pq[u] = __shfl((int)pm, src);
+            for (int r = 0; r < 8; ++r) {
+                const int q = 16 * w + 2 * r + half;            // slot of the pass
+                const int pt = q < np ? p0 + q : p0;            // (a slot past the end re-reads the pass's first row: never added)
+                if (li < nvec) xx[r] = __builtin_nontemporal_load((const f32x4*)(feat + (int64_t)vix[pt] * ld_feat + li * 4));
+                else if (li < nvec + 3) cc[r] = icoords[(int64_t)pix[pt] * 3 + (li - nvec)];
             }
-            if (li < nvec) {
-                f32x4 xx[PS_ROWS];
+            __syncthreads();                                    // wave 0 is done with the previous pass's rows
 #pragma unroll
-                for (int u = 0; u < PS_ROWS; ++u)
-                    xx[u] = __builtin_nontemporal_load((const f32x4*)(feat + (int64_t)(i0 + u < ni ? vv[u] : 0) * ld_feat + li * 4));
-#pragma unroll
-                for (int u = 0; u < PS_ROWS; ++u) if (i0 + u < ni) acc += xx[u];
-            } else if (li < nvec + 3) {
-                int cc[PS_ROWS];
-#pragma unroll
-                for (int u = 0; u < PS_ROWS; ++u) cc[u] = i0 + u < ni ? icoords[(int64_t)pq[u] * 3 + (li - nvec)] : 0;
-#pragma unroll
-                for (int u = 0; u < PS_ROWS; ++u) if (i0 + u < ni) pacc += (float)cc[u] * voxel_size;
+            for (int r = 0; r < 8; ++r) {
+                const int q = 16 * w + 2 * r + half;
+                if (li < nvec) *(f32x4*)&rows[q][li * 4] = xx[r];
+                else if (li < nvec + 3) rows[q][96 + (li - nvec)] = (float)cc[r];
+            }
+            __syncthreads();
+            if (w == 0) {
+                const int ni = (np - half + 1) >> 1;            // this half's points of the pass
+                if (li < nvec) {
+                    for (int i = 0; i < ni; ++i) acc += *(const f32x4*)&rows[half + 2 * i][li * 4];
+                } else if (li < nvec + 3) {
+                    for (int i = 0; i < ni; ++i) pacc += rows[half + 2 * i][96 + (li - nvec)] * voxel_size;
+                }
             }
         }
     }
+    if (w != 0) return;
 #pragma unroll
     for (int q = 0; q < 4; ++q) acc[q] += __shfl_xor(acc[q], 32);
     pacc += __shfl_xor(pacc, 32);
@@ -882,9 +892,9 @@ int launch_pool_superpoints(const float* feat, int ld_feat, int C, const int32_t
                             float voxel_size, const uint32_t* sidx, const int32_t* start, int64_t S, float* out_feat,
                             float* out_pos, hipStream_t st) {
     if (S <= 0) return SD3D_OK;
-    if ((C & 3) || (C >> 2) + 3 > 32 || (ld_feat & 3))
-        return sd3d_set_error(SD3D_ERR_ARG, "pool_superpoints: C must be a multiple of 4 and <= 116");
-    hipLaunchKernelGGL(pool_superpoints_kernel, dim3((unsigned)cdiv(S, 4)), dim3(256), 0, st, feat, ld_feat, C, inverse,
+    if ((C & 3) || C > 96 || (ld_feat & 3))
+        return sd3d_set_error(SD3D_ERR_ARG, "pool_superpoints: C must be a multiple of 4 and <= 96");
+    hipLaunchKernelGGL(pool_superpoints_kernel, dim3((unsigned)S), dim3(256), 0, st, feat, ld_feat, C, inverse,
                        icoords, voxel_size, sidx, start, S, out_feat, out_pos);
     SD3D_CHECK_LAUNCH();
     return SD3D_OK;

@@ -674,7 +674,7 @@ def pair_lists_batch(tables):
                 if direct or K % 2 == 0:
                     raise ValueError("pair_lists: chained lists need an odd symmetric kernel")
                 p_cap = (int(n_pairs) + 127 * (11 * (K // 2) + 1) + 127) // 128 * 128
-                pos = torch.empty(K // 2 + 1, M, dtype=torch.int32, device=dev)          # partial position per mirror group
+                pos = torch.empty(0, dtype=torch.int32, device=dev)       # (a chained table has no [K, M] position table: its rows' partial positions are `rlist`)
             else:
                 p_cap = (int(n_pairs) + 127 * K + 127) // 128 * 128
                 pos = torch.empty(K, M, dtype=torch.int32, device=dev)
