@@ -60,6 +60,15 @@ int sd3d_keys_from_f32(const float* x, int64_t n, int descending, uint64_t* keys
 int sd3d_keys_from_i64(const int64_t* x, int64_t n, uint64_t* keys, void* stream);
 /* The same, and *flag |= flag_value when an id does not fit `bits` bits (a radix sort over fewer key bits is then not a full sort). */
 int sd3d_keys_from_i64_checked(const int64_t* x, int64_t n, uint64_t* keys, int bits, int32_t* flag, int flag_value, void* stream);
+/* ... and *max_out = max(*max_out, largest id, clamped to INT32_MAX) - the caller zeroes it; bits = 64: no check.  The superpoint count of a
+ * scene (largest id + 1; `minkunet.py:631-639` scatter_mean sizes its output the same way) is known without waiting for the sort of the ids. */
+int sd3d_keys_from_i64_checked_max(const int64_t* x, int64_t n, uint64_t* keys, int bits, int32_t* flag, int flag_value, int32_t* max_out,
+                                   void* stream);
+
+/* keys[i] = x[i] + add (sd3d_keys_from_i64_offset: the scene's bits of a batch-wide key) with the check and the maximum of
+ * sd3d_keys_from_i64_checked_max taken on x[i]. */
+int sd3d_keys_from_i64_offset_checked_max(const int64_t* x, int64_t n, int64_t add, uint64_t* keys, int bits, int32_t* flag, int flag_value,
+                                          int32_t* max_out, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Voxelisation and coordinate maps.
@@ -93,6 +102,30 @@ int sd3d_unique_sorted(const uint64_t* keys, const uint32_t* src_idx, int64_t n_
 size_t sd3d_unique_levels_ws_bytes(int64_t n_cap, int n_extra);
 int sd3d_unique_levels(const uint64_t* keys, int64_t n_cap, const int32_t* n_dev, int n_extra, uint64_t* const* ukeys,
                        int32_t* const* parents, int32_t* counts, void* ws, size_t ws_bytes, void* stream);
+/* One scene's voxelisation chain from ONE call (sd3d_scene_stats, sd3d_voxel_keys, the radix sort of the keys, sd3d_unique_sorted with
+ * segment starts and the point -> voxel map, sd3d_unique_levels, the superpoint ids' sort keys): ~28 launches that take the GPU ~0.25 ms
+ * but cost a Python host ~0.5 ms when issued one by one in front of everything else of the scene.  Same kernels, same order, same
+ * outputs as the separate calls (`minkunet.py:624-630`: batch_sparse_collate + TensorField.sparse() + inverse_mapping).
+ *   readback [n_levels + 2] is zeroed here and receives {voxels of level 0 .. n_levels - 1, flags, largest superpoint id}
+ *     (flags: 1 = key range exceeded, 2 = a Morton key needs more than key_bits bits, 4 = a superpoint id needs more than sp_bits bits);
+ *   the sorted (key, point) pairs ping-pong between (keys_a, vals_a) and (keys_b, vals_b): *sorted_in_a tells where they landed;
+ *   superpoints NULL: no ids (sp_keys unused); sp_bits = 64: no check of the ids' width. */
+typedef struct sd3d_voxelise_desc {
+    const float* points; int64_t n; int ld; int shift_to_min; float inv_voxel; int key_bits; int n_levels; int sp_bits;
+    float* stats;                           /* [9] */
+    int32_t *origin, *icoords;              /* [3], [n, 3] */
+    uint64_t *keys_a, *keys_b;              /* [n] each */
+    uint32_t *vals_a, *vals_b;              /* [n] each */
+    uint64_t* ukeys0;                       /* [n] */
+    int32_t *seg_start, *inverse;           /* [n + 1], [n] */
+    uint64_t* const* ukeys;                 /* n_levels - 1 pointers, [n] each */
+    int32_t* const* parents;                /* n_levels - 1 pointers, [n] each */
+    int32_t* readback;                      /* [n_levels + 2] */
+    const int64_t* superpoints; uint64_t* sp_keys;   /* [n] each, optional */
+    void* ws; size_t ws_bytes;              /* >= sd3d_voxelise_scene_ws_bytes(n, n_levels) */
+} sd3d_voxelise_desc;
+size_t sd3d_voxelise_scene_ws_bytes(int64_t n, int n_levels);
+int sd3d_voxelise_scene(const sd3d_voxelise_desc* d, int* sorted_in_a, void* stream);
 /* Open-addressing hash table key -> voxel id; capacity = power of two > n. */
 int sd3d_hash_build(const uint64_t* ukeys, int64_t n, uint64_t* table_keys, int32_t* table_vals, int64_t capacity,
                     void* stream);

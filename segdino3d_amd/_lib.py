@@ -36,6 +36,10 @@ SIGNATURES = {
     "sd3d_keys_from_f32": (_i, [_p, _l, _i, _p, _p]),
     "sd3d_keys_from_i64": (_i, [_p, _l, _p, _p]),
     "sd3d_keys_from_i64_checked": (_i, [_p, _l, _p, _i, _p, _i, _p]),
+    "sd3d_keys_from_i64_checked_max": (_i, [_p, _l, _p, _i, _p, _i, _p, _p]),
+    "sd3d_keys_from_i64_offset_checked_max": (_i, [_p, _l, _l, _p, _i, _p, _i, _p, _p]),
+    "sd3d_voxelise_scene_ws_bytes": (_z, [_l, _i]),
+    "sd3d_voxelise_scene": (_i, [_p, _p, _p]),
     "sd3d_scene_stats_ws_bytes": (_z, []),
     "sd3d_scene_stats": (_i, [_p, _i, _l, _p, _p, _z, _p]),
     "sd3d_voxel_keys": (_i, [_p, _i, _l, _f, _p, _i, _i, _p, _p, _p, _p, _p]),

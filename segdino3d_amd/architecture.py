@@ -172,9 +172,11 @@ class Baseline3D(nn.Module):
     @ops.bound_stream
     def forward(self, samples, targets: List = None):
         samples = [s.float().contiguous() for s in samples]
+        sp_features_3d, sp_pos, sp_pos_wo_elastic = self.forward_backbone(samples, targets)
+        # (baseline3d.py:317 computes these before the backbone; nothing in the backbone reads them, and behind it their launches queue up under the
+        #  U-Net's kernels instead of standing - host-bound - in front of the voxelisation every later kernel of the scene waits for)
         scene_range = self.get_extra_instance_data(samples, targets, self.add_positional_embedding,
                                                    self.decoder.add_box_size_pred)
-        sp_features_3d, sp_pos, sp_pos_wo_elastic = self.forward_backbone(samples, targets)
         queries, queries_pos, targets = self._select_queries(sp_features_3d, sp_pos, targets)
         self.decoder.return_hidden_states = not self.training
         self.decoder.return_aux_outputs = True

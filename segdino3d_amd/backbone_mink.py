@@ -224,8 +224,9 @@ class Res16UNetBase(DerivedWeights):
         out = self._stage(be, pk, "block8", Ly[7], out, k3[0], x2=out_p1)
         return out
 
-    def forward_sparse(self, maps: SceneMaps, vox_feats: torch.Tensor) -> torch.Tensor:
-        """`Res16UNetBase.forward` (`minkunet.py:531-601`): [V0, Cin_padded] -> [V0, 96]."""
+    def forward_sparse(self, maps: SceneMaps, vox_feats: torch.Tensor, pk=None) -> torch.Tensor:
+        """`Res16UNetBase.forward` (`minkunet.py:531-601`): [V0, Cin_padded] -> [V0, 96].  pk: `self.packed()` of this forward when
+        the caller already has it (`_scene_inputs` validates the derived weights while the scene's read-back travels)."""
         k1 = self.conv1_kernel_size
         use_plan = (not self.training and plan.USE_PLAN and ops.PAIR_CONV and ops.GEMM_MODE is None and ops.GG_FORCE_NT is None
                     and ops.GG_HOOK is None)
@@ -233,7 +234,8 @@ class Res16UNetBase(DerivedWeights):
         if self.training:                                        # batch-statistics BatchNorm, autograd nodes over HIP kernels
             from . import train_ops
             return self._network(train_ops.TrainBackend(maps), self.packed_train(), vox_feats)
-        pk = self.packed()
+        if pk is None:
+            pk = self.packed()
         if use_plan:
             if self._plan is None:                               # one C call per scene instead of ~110
                 rec = plan.Recorder(vox_feats.shape[1])
@@ -242,7 +244,7 @@ class Res16UNetBase(DerivedWeights):
         return self._network(plan.EagerBackend(maps), pk, vox_feats)
 
     def _scene_inputs(self, pts, tgt):
-        """-> (maps, voxel features, undistorted points, superpoints, elastic?) of one scene (`:604-630`)."""
+        """-> (maps, voxel features, undistorted points, superpoints, elastic?, packed weights | None) of one scene (`:604-630`)."""
         ef = tgt["extra_features"]
         pts = pts.float().contiguous()
         sp = ef["super_point_masks"].contiguous()
@@ -255,9 +257,17 @@ class Res16UNetBase(DerivedWeights):
         if elastic is not None:                                  # voxelise the elastically distorted scene (:606-608), colours as they are
             geo = pts.clone()
             geo[:, :3] = elastic.to(pts.device).float() * self.voxel_size
-        maps = SceneMaps(geo, self.voxel_size, 5, shift_to_min=False, order=self.KERNEL_ORDER, superpoints=sp)
-        vf = maps.voxel_features(geo, f2d, mode, _round32(self.in_channels))
-        return maps, vf, pts, sp, elastic
+        # evaluation: the validity check of the derived weights (~0.1 ms of host time per forward, segdino3d_amd/_cache.py) runs while the
+        # host would otherwise sleep on the scene's read-back, not between the table building and the first convolution
+        held = []
+        cin = _round32(self.in_channels)
+
+        def hook(m):
+            held.append(self.packed())
+        maps = SceneMaps(geo, self.voxel_size, 5, shift_to_min=False, order=self.KERNEL_ORDER, superpoints=sp,
+                         while_waiting=None if self.training else hook)
+        vf = maps.voxel_features(geo, f2d, mode, cin)
+        return maps, vf, pts, sp, elastic, (held[0] if held else None)
 
     def _positions_wo_elastic(self, pts, sp, x):
         """superpoint means of the undistorted voxel coordinates (:665-682)"""
@@ -309,9 +319,9 @@ class Res16UNetBase(DerivedWeights):
             outs = [x_all[slice(*batch.rows(0, i))] for i in range(len(scenes))]
         else:
             outs = []
-            for maps, vf, _, _, _ in scenes:
-                outs.append(self.forward_sparse(maps, vf))
-        for (maps, _, pts, sp, elastic), x in zip(scenes, outs):
+            for maps, vf, _, _, _, pk in scenes:
+                outs.append(self.forward_sparse(maps, vf, pk))
+        for (maps, _, pts, sp, elastic, _), x in zip(scenes, outs):
             if self.training:
                 from . import train_ops
                 f, p = train_ops.pool_superpoints(x.contiguous(), maps, self.out_planes)

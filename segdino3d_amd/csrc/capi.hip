@@ -19,6 +19,7 @@ int scan_exclusive_i32(const int*, int*, int64_t, const int*, int*, void*, size_
 int launch_f32_to_sortkey(const float*, int64_t, int, uint64_t*, hipStream_t);
 int launch_i64_to_sortkey(const int64_t*, int64_t, uint64_t*, hipStream_t);
 int launch_i64_to_sortkey_checked(const int64_t*, int64_t, uint64_t*, int, int32_t*, int, hipStream_t);
+int launch_i64_to_sortkey_checked_max(const int64_t*, int64_t, uint64_t*, int, int32_t*, int, int32_t*, hipStream_t, uint64_t);
 int launch_scene_stats(const float*, int, int64_t, float*, void*, size_t, hipStream_t);
 int launch_pack_mask_rows(const uint8_t*, int64_t, const int32_t*, int, uint8_t*, int64_t, hipStream_t);
 int launch_row_chain(const sd3d_rc_program*, hipStream_t);
@@ -155,6 +156,13 @@ int sd3d_keys_from_i64(const int64_t* x, int64_t n, uint64_t* keys, void* stream
 int sd3d_keys_from_i64_checked(const int64_t* x, int64_t n, uint64_t* keys, int bits, int32_t* flag, int flag_value, void* stream) {
     return launch_i64_to_sortkey_checked(x, n, keys, bits, flag, flag_value, ST);
 }
+int sd3d_keys_from_i64_checked_max(const int64_t* x, int64_t n, uint64_t* keys, int bits, int32_t* flag, int flag_value, int32_t* max_out, void* stream) {
+    return launch_i64_to_sortkey_checked_max(x, n, keys, bits, flag, flag_value, max_out, ST, 0);
+}
+int sd3d_keys_from_i64_offset_checked_max(const int64_t* x, int64_t n, int64_t add, uint64_t* keys, int bits, int32_t* flag, int flag_value,
+                                          int32_t* max_out, void* stream) {
+    return launch_i64_to_sortkey_checked_max(x, n, keys, bits, flag, flag_value, max_out, ST, (uint64_t)add);
+}
 
 size_t sd3d_scene_stats_ws_bytes(void) { return 256 * 9 * sizeof(float); }
 int sd3d_scene_stats(const float* points, int ld, int64_t n, float* stats, void* ws, size_t ws_bytes, void* stream) {
@@ -175,6 +183,46 @@ size_t sd3d_unique_levels_ws_bytes(int64_t n_cap, int n_extra) { return unique_l
 int sd3d_unique_levels(const uint64_t* keys, int64_t n_cap, const int32_t* n_dev, int n_extra, uint64_t* const* ukeys, int32_t* const* parents,
                        int32_t* counts, void* ws, size_t ws_bytes, void* stream) {
     return launch_unique_levels(keys, n_cap, n_dev, n_extra, ukeys, parents, counts, ws, ws_bytes, ST);
+}
+size_t sd3d_voxelise_scene_ws_bytes(int64_t n, int n_levels) {
+    n = n > 0 ? n : 1;
+    size_t b = sd3d_scene_stats_ws_bytes();
+    const size_t c[3] = {sort_ws_bytes(n), unique_ws_bytes(n), n_levels > 1 ? unique_levels_ws_bytes(n, n_levels - 1) : 0};
+    for (size_t v : c) b = v > b ? v : b;
+    return b;
+}
+int sd3d_voxelise_scene(const sd3d_voxelise_desc* d, int* sorted_in_a, void* stream) {
+    if (!d || !sorted_in_a || !d->points || !d->stats || !d->origin || !d->keys_a || !d->keys_b || !d->vals_a || !d->vals_b || !d->ukeys0 ||
+        !d->seg_start || !d->inverse || !d->readback || !d->ws)
+        return sd3d_set_error(SD3D_ERR_ARG, "voxelise_scene: null pointer");
+    if (d->n <= 0 || d->n_levels < 1 || d->n_levels > 9 || (d->n_levels > 1 && (!d->ukeys || !d->parents)) || d->key_bits < 8 || d->key_bits > 64)
+        return sd3d_set_error(SD3D_ERR_ARG, "voxelise_scene: n > 0, 1..9 levels, 8..64 key bits");
+    if (d->ws_bytes < sd3d_voxelise_scene_ws_bytes(d->n, d->n_levels)) return sd3d_set_error(SD3D_ERR_ARG, "voxelise_scene: workspace too small");
+    if (d->superpoints && !d->sp_keys) return sd3d_set_error(SD3D_ERR_ARG, "voxelise_scene: superpoints without sp_keys");
+    hipStream_t st = (hipStream_t)stream;
+    const int L = d->n_levels;
+    if (hipMemsetAsync(d->readback, 0, (size_t)(L + 2) * sizeof(int32_t), st) != hipSuccess) return sd3d_set_error(SD3D_ERR_LAUNCH, "voxelise_scene: memset failed");
+    int rc = launch_scene_stats(d->points, d->ld, d->n, d->stats, d->ws, d->ws_bytes, st);
+    if (rc) return rc;
+    rc = launch_voxel_keys(d->points, d->ld, d->n, d->inv_voxel, d->stats, d->shift_to_min, 0, d->origin, d->keys_a, d->icoords, d->readback + L, st);
+    if (rc) return rc;
+    int landed = 0;
+    rc = sort_pairs_u64(d->keys_a, nullptr, d->keys_b, d->vals_b, d->n, 0, d->key_bits, d->ws, d->ws_bytes, st, d->vals_a, &landed);
+    if (rc) return rc;
+    *sorted_in_a = landed;
+    const uint64_t* skeys = landed ? d->keys_a : d->keys_b;
+    const uint32_t* sidx = landed ? d->vals_a : d->vals_b;
+    rc = launch_unique_sorted(skeys, sidx, d->n, nullptr, 0, d->ukeys0, d->seg_start, d->inverse, d->readback, d->ws, d->ws_bytes, nullptr, 0.f, 0, 0, st);
+    if (rc) return rc;
+    if (L > 1) {
+        rc = launch_unique_levels(d->ukeys0, d->n, d->readback, L - 1, d->ukeys, d->parents, d->readback + 1, d->ws, d->ws_bytes, st);
+        if (rc) return rc;
+    }
+    if (d->superpoints) {
+        rc = launch_i64_to_sortkey_checked_max(d->superpoints, d->n, d->sp_keys, d->sp_bits, d->readback + L, 4, d->readback + L + 1, st, 0);
+        if (rc) return rc;
+    }
+    return SD3D_OK;
 }
 int sd3d_hash_build(const uint64_t* ukeys, int64_t n, uint64_t* table_keys, int32_t* table_vals, int64_t capacity, void* stream) {
     return launch_hash_build(ukeys, n, table_keys, table_vals, capacity, ST);

@@ -232,26 +232,40 @@ __global__ __launch_bounds__(256) void pair_fill_batch_kernel(const PLBatch b) {
         }
         for (int64_t t = end / PT + (int64_t)blk * 256 + tid; t < T.p_cap / PT; t += (int64_t)T.nblk * 256) T.tile_k[t] = -1;
     }
+    // Round 5: a wave owns 512 consecutive rows of the block and requests all eight of its 64-row slices at once; the waves meet ONCE
+    // (their totals through LDS).  Before: eight rounds of {load, ballot, two barriers} per workgroup - 84 us for the stem's 5^3 table,
+    // whose 12.5 M slots it walks at 1.2 TB/s.  Same positions (rows ascending within an offset).
     int base = seg + T.blk_cnt[(int64_t)k * T.nblk + blk];
     const uint64_t lt = (1ull << lane) - 1ull;
-#pragma unroll 1
-    for (int i = 0; i < PL_ROWS / 256; ++i) {
-        const int64_t row = (int64_t)blk * PL_ROWS + i * 256 + tid;
-        const int id = row < T.M ? T.nbr[(int64_t)k * T.M + row] : -1;
-        const uint64_t bal = __ballot(id >= 0);
-        if (lane == 0) wcnt[wv] = __popcll(bal);
-        __syncthreads();
-        int before = 0;
-        for (int w = 0; w < wv; ++w) before += wcnt[w];
-        const int all = wcnt[0] + wcnt[1] + wcnt[2] + wcnt[3];
-        __syncthreads();
-        const int p = base + before + __popcll(bal & lt);
-        if (row < T.M) T.pos[(int64_t)k * T.M + row] = (id >= 0 && p < T.p_cap) ? p : -1;
-        if (id >= 0 && p < T.p_cap) {
-            T.in_idx[p] = id;
+    constexpr int NS = PL_ROWS / 256;
+    const int64_t row0 = (int64_t)blk * PL_ROWS + (int64_t)wv * (PL_ROWS / 4) + lane;
+    int id[NS];
+    uint64_t bal[NS];
+#pragma unroll
+    for (int i = 0; i < NS; ++i) {
+        const int64_t row = row0 + i * 64;
+        id[i] = T.nbr[(int64_t)k * T.M + (row < T.M ? row : 0)];
+        if (row >= T.M) id[i] = -1;
+    }
+    int wtot = 0;
+#pragma unroll
+    for (int i = 0; i < NS; ++i) {
+        bal[i] = __ballot(id[i] >= 0);
+        wtot += __popcll(bal[i]);
+    }
+    if (lane == 0) wcnt[wv] = wtot;
+    __syncthreads();
+    for (int w = 0; w < wv; ++w) base += wcnt[w];
+#pragma unroll
+    for (int i = 0; i < NS; ++i) {
+        const int64_t row = row0 + i * 64;
+        const int p = base + __popcll(bal[i] & lt);
+        if (row < T.M) T.pos[(int64_t)k * T.M + row] = (id[i] >= 0 && p < T.p_cap) ? p : -1;
+        if (id[i] >= 0 && p < T.p_cap) {
+            T.in_idx[p] = id[i];
             if (T.out_idx) T.out_idx[p] = (int32_t)row;
         }
-        base += all;
+        base += __popcll(bal[i]);
     }
 }
 
@@ -266,12 +280,15 @@ __global__ __launch_bounds__(RL_ROWS) void pair_rowlist_batch_kernel(const PLBat
     if (row >= T.M) return;
     int32_t* rl = T.rlist + row * T.rl_stride;
     int cnt = 0;
-    for (int k0 = 0; k0 < T.K; k0 += 8) {
-        int v[8];
+    for (int k0 = 0; k0 < T.K; k0 += 16) {                    // sixteen columns requested together (the stem's table has 125)
+        int v[16];
 #pragma unroll
-        for (int u = 0; u < 8; ++u) v[u] = (k0 + u < T.K) ? T.pos[(int64_t)(k0 + u) * T.M + row] : -1;
+        for (int u = 0; u < 16; ++u) {
+            v[u] = T.pos[(int64_t)(k0 + u < T.K ? k0 + u : T.K - 1) * T.M + row];
+            if (k0 + u >= T.K) v[u] = -1;
+        }
 #pragma unroll
-        for (int u = 0; u < 8; ++u)
+        for (int u = 0; u < 16; ++u)
             if (v[u] >= 0) rl[1 + cnt++] = v[u];
     }
     rl[0] = cnt;

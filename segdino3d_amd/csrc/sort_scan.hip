@@ -385,6 +385,30 @@ int launch_i64_to_sortkey_checked(const int64_t* x, int64_t n, uint64_t* keys, i
     SD3D_CHECK_LAUNCH();
     return SD3D_OK;
 }
+// ... and *max_out = max(*max_out, largest id) (one atomic per wave): the number of superpoints of a scene rides in the scene's
+// read-back without waiting for the sort of the ids
+__global__ void i64_to_sortkey_checked_max(const int64_t* __restrict__ x, int64_t n, uint64_t* __restrict__ keys, int bits, int32_t* __restrict__ flag,
+                                           int value, int32_t* __restrict__ max_out, uint64_t add) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    int m = 0;
+    if (i < n) {
+        const uint64_t k = (uint64_t)x[i];
+        keys[i] = k + add;                                      // (add: the scene's bits of a batch-wide key; the check and the maximum see the id)
+        if (bits < 64 && (k >> bits)) atomicOr(flag, value);
+        m = k > 0x7FFFFFFFull ? 0x7FFFFFFF : (int)k;
+    }
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) { const int t = __shfl_xor(m, d); m = t > m ? t : m; }
+    if ((threadIdx.x & 63) == 0 && m > 0) atomicMax(max_out, m);
+}
+int launch_i64_to_sortkey_checked_max(const int64_t* x, int64_t n, uint64_t* keys, int bits, int32_t* flag, int value, int32_t* max_out, hipStream_t st,
+                                      uint64_t add) {
+    if (n <= 0) return SD3D_OK;
+    if (!flag || !max_out || bits < 1 || bits > 64) return sd3d_set_error(SD3D_ERR_ARG, "keys_from_i64_checked_max: flag / max pointers and 1..64 bits");
+    hipLaunchKernelGGL(i64_to_sortkey_checked_max, dim3((unsigned)cdiv(n, 256)), dim3(256), 0, st, x, n, keys, bits, flag, value, max_out, add);
+    SD3D_CHECK_LAUNCH();
+    return SD3D_OK;
+}
 int launch_i64_to_sortkey(const int64_t* x, int64_t n, uint64_t* keys, hipStream_t st) {
     if (n <= 0) return SD3D_OK;
     hipLaunchKernelGGL(i64_to_sortkey, dim3((unsigned)cdiv(n, 256)), dim3(256), 0, st, x, n, keys);

@@ -280,10 +280,16 @@ def keys_from_f32(x: torch.Tensor, descending=False):
     return keys
 
 
-def keys_from_i64(x: torch.Tensor, check=None):
-    """check = (bits, flag int32 [1], value): flag |= value when an id needs more than `bits` bits."""
+def keys_from_i64(x: torch.Tensor, check=None, max_out=None):
+    """check = (bits, flag int32 [1], value): flag |= value when an id needs more than `bits` bits.  max_out int32 [1] (zeroed by the
+    caller; needs `check`, bits = 64 for none): receives the largest id."""
     lib = _lib.load()
     keys = torch.empty(x.numel(), dtype=torch.int64, device=x.device)
+    if max_out is not None:
+        bits, flag, value = check
+        _lib.check(lib.sd3d_keys_from_i64_checked_max(_ptr(x, torch.int64, "x"), x.numel(), _ptr(keys), int(bits), _ptr(flag, torch.int32, "flag"),
+                                                      int(value), _ptr(max_out, torch.int32, "max_out"), _stream()), "keys_from_i64_checked_max")
+        return keys
     if check is not None:
         bits, flag, value = check
         _lib.check(lib.sd3d_keys_from_i64_checked(_ptr(x, torch.int64, "x"), x.numel(), _ptr(keys), int(bits), _ptr(flag, torch.int32, "flag"),
@@ -307,7 +313,7 @@ def scene_stats(points: torch.Tensor, out: Optional[torch.Tensor] = None):
     return stats
 
 
-def voxel_keys(points, inv_voxel: float, stats, shift_to_min=False, batch_index=0, want_icoords=True, out=None):
+def voxel_keys(points, inv_voxel: float, stats, shift_to_min=False, batch_index=0, want_icoords=True, out=None, err=None):
     """`out` = (keys [n] int64, icoords [n, 3] int32 | None, err [1] int32): slices of batch-wide buffers to write into
     (the error flag is OR-ed, so several scenes may share it)."""
     lib = _lib.load()
@@ -319,7 +325,8 @@ def voxel_keys(points, inv_voxel: float, stats, shift_to_min=False, batch_index=
     else:
         keys = torch.empty(n, dtype=torch.int64, device=dev)
         icoords = torch.empty(n, 3, dtype=torch.int32, device=dev) if want_icoords else None
-        err = torch.zeros(1, dtype=torch.int32, device=dev)
+        if err is None:
+            err = torch.zeros(1, dtype=torch.int32, device=dev)
     origin = torch.empty(3, dtype=torch.int32, device=dev)
     _lib.check(lib.sd3d_voxel_keys(p, ld, n, float(inv_voxel), _ptr(stats, torch.float32, "stats"), int(shift_to_min),
                                    int(batch_index), _ptr(origin), _ptr(keys), _ptr(icoords), _ptr(err), _stream()),
@@ -328,14 +335,14 @@ def voxel_keys(points, inv_voxel: float, stats, shift_to_min=False, batch_index=
 
 
 def unique_sorted(keys, src_idx, n_cap, n_dev=None, shift=0, want_seg_start=False, want_map=True, map_size=None,
-                  clip=None):
+                  clip=None, nuniq_out=None):
     """Run-length unique over sorted keys.  Returns (ukeys[n_cap], seg_start[n_cap+1]|None, map|None, n_unique[1])."""
     lib = _lib.load()
     dev = keys.device
     ukeys = torch.empty(n_cap, dtype=torch.int64, device=dev)
     seg = torch.empty(n_cap + 1, dtype=torch.int32, device=dev) if want_seg_start else None
     mp = torch.empty(map_size if map_size is not None else n_cap, dtype=torch.int32, device=dev) if want_map else None
-    nuniq = torch.empty(1, dtype=torch.int32, device=dev)
+    nuniq = torch.empty(1, dtype=torch.int32, device=dev) if nuniq_out is None else nuniq_out
     ws = _WS.get(lib.sd3d_unique_ws_bytes(n_cap), dev)
     _lib.check(lib.sd3d_unique_sorted(_ptr(keys, torch.int64, "keys"), _ptr(src_idx, torch.int32, "src_idx"), n_cap,
                                       _ptr(n_dev, torch.int32, "n_dev"), shift, _ptr(ukeys), _ptr(seg), _ptr(mp),
@@ -346,20 +353,65 @@ def unique_sorted(keys, src_idx, n_cap, n_dev=None, shift=0, want_seg_start=Fals
     return ukeys, seg, mp, nuniq
 
 
-def unique_levels(keys0: torch.Tensor, n_cap: int, n0_dev: torch.Tensor, n_extra: int):
+def unique_levels(keys0: torch.Tensor, n_cap: int, n0_dev: torch.Tensor, n_extra: int, counts_out=None):
     """All coarser levels from the sorted level-0 unique keys in four launches (`sd3d_unique_levels`): ([ukeys_1..], [parent_1..],
     counts int32 [n_extra]) - what `unique_sorted(keys_l, None, n_cap, n_l, 3, want_map=True)` gives level after level (no extent clip)."""
     lib = _lib.load()
     dev = keys0.device
     uk = torch.empty(n_extra, n_cap, dtype=torch.int64, device=dev)
     par = torch.empty(n_extra, n_cap, dtype=torch.int32, device=dev)
-    counts = torch.empty(n_extra, dtype=torch.int32, device=dev)
+    counts = torch.empty(n_extra, dtype=torch.int32, device=dev) if counts_out is None else counts_out
     ws = _WS.get(lib.sd3d_unique_levels_ws_bytes(n_cap, n_extra), dev)
     up = (ctypes.c_void_p * n_extra)(*[uk.data_ptr() + 8 * n_cap * l for l in range(n_extra)])
     pp = (ctypes.c_void_p * n_extra)(*[par.data_ptr() + 4 * n_cap * l for l in range(n_extra)])
     _lib.check(lib.sd3d_unique_levels(_ptr(keys0, torch.int64, "keys0"), n_cap, _ptr(n0_dev, torch.int32, "n0"), n_extra,
                                       ctypes.addressof(up), ctypes.addressof(pp), _ptr(counts), ws.data_ptr(), ws.numel(), _stream()), "unique_levels")
     return [uk[l] for l in range(n_extra)], [par[l] for l in range(n_extra)], counts
+
+
+_VOX_DESC_DT = None
+
+
+def voxelise_scene(points, inv_voxel: float, shift_to_min: bool, key_bits: int, n_levels: int, superpoints=None, sp_bits: int = 64):
+    """One scene's voxelisation chain from ONE C call (`sd3d_voxelise_scene`): what scene_stats + voxel_keys + sort_pairs + unique_sorted
+    (segment starts, point -> voxel map) + unique_levels + keys_from_i64(max_out) give when called one after the other - the same kernels
+    in the same order, issued from C instead of from ~10 Python calls in front of everything else the scene needs.
+    -> dict(stats, origin, icoords, skeys, sidx, ukeys [L x [N]], seg_start, inverse, parents [L-1 x [N]], readback int32 [L + 2], sp_keys | None)"""
+    global _VOX_DESC_DT
+    import numpy as np
+    if _VOX_DESC_DT is None:
+        _VOX_DESC_DT = np.dtype([("points", "<u8"), ("n", "<i8"), ("ld", "<i4"), ("shift_to_min", "<i4"), ("inv_voxel", "<f4"), ("key_bits", "<i4"),
+                                 ("n_levels", "<i4"), ("sp_bits", "<i4"), ("stats", "<u8"), ("origin", "<u8"), ("icoords", "<u8"),
+                                 ("keys_a", "<u8"), ("keys_b", "<u8"), ("vals_a", "<u8"), ("vals_b", "<u8"), ("ukeys0", "<u8"),
+                                 ("seg_start", "<u8"), ("inverse", "<u8"), ("ukeys", "<u8"), ("parents", "<u8"), ("readback", "<u8"),
+                                 ("superpoints", "<u8"), ("sp_keys", "<u8"), ("ws", "<u8"), ("ws_bytes", "<u8")], align=True)
+        assert _VOX_DESC_DT.itemsize == 176, _VOX_DESC_DT.itemsize
+    lib = _lib.load()
+    p, ld = _rows(points, "points")
+    N, dev, L = points.shape[0], points.device, int(n_levels)
+    Np = (N + 63) // 64 * 64                                                                                 # (every array keeps the alignment of an allocation of its own)
+    i64 = torch.empty(L + 2 + (1 if superpoints is not None else 0), Np, dtype=torch.int64, device=dev)[:, :N]   # key ping-pong, unique keys per level, id keys
+    i32 = torch.empty(L + 2, Np, dtype=torch.int32, device=dev)[:, :N]                                       # value ping-pong, map, parents per level
+    icoords = torch.empty(N, 3, dtype=torch.int32, device=dev)
+    seg = torch.empty(N + 1, dtype=torch.int32, device=dev)
+    stats = torch.empty(9, dtype=torch.float32, device=dev)
+    small = torch.empty(3 + L + 2, dtype=torch.int32, device=dev)                                            # origin, read-back
+    origin, rb = small[:3], small[3:]
+    uk_ptr = (ctypes.c_void_p * max(1, L - 1))(*[i64[3 + l].data_ptr() for l in range(L - 1)])
+    par_ptr = (ctypes.c_void_p * max(1, L - 1))(*[i32[3 + l].data_ptr() for l in range(L - 1)])
+    ws = _WS.get(lib.sd3d_voxelise_scene_ws_bytes(N, L), dev)
+    sp_keys = i64[L + 2] if superpoints is not None else None
+    d = np.zeros(1, dtype=_VOX_DESC_DT)
+    d[0] = (p, N, ld, int(bool(shift_to_min)), float(inv_voxel), int(key_bits), L, int(sp_bits), stats.data_ptr(), origin.data_ptr(), icoords.data_ptr(),
+            i64[0].data_ptr(), i64[1].data_ptr(), i32[0].data_ptr(), i32[1].data_ptr(), i64[2].data_ptr(), seg.data_ptr(), i32[2].data_ptr(),
+            ctypes.addressof(uk_ptr), ctypes.addressof(par_ptr), rb.data_ptr(),
+            0 if superpoints is None else _ptr(superpoints, torch.int64, "superpoints"), 0 if sp_keys is None else sp_keys.data_ptr(),
+            ws.data_ptr(), ws.numel())
+    in_a = ctypes.c_int(0)
+    _lib.check(lib.sd3d_voxelise_scene(d.ctypes.data, ctypes.addressof(in_a), _stream()), "voxelise_scene")
+    a = 0 if in_a.value else 1
+    return dict(stats=stats, origin=origin, icoords=icoords, skeys=i64[a], sidx=i32[a], ukeys=[i64[2]] + [i64[3 + l] for l in range(L - 1)],
+                seg_start=seg, inverse=i32[2], parents=[i32[3 + l] for l in range(L - 1)], readback=rb, sp_keys=sp_keys)
 
 
 def hash_build(ukeys: torch.Tensor, n: int):
@@ -468,11 +520,18 @@ def voxel_mean_batch(scenes, mode, ukeys, sorted_idx, seg_start, n_vox, ld_out):
     return out
 
 
-def keys_from_i64_offset(x: torch.Tensor, add: int, out: torch.Tensor):
-    """out[i] = x[i] + add (out: a contiguous int64 slice of the batch-wide key buffer)."""
+def keys_from_i64_offset(x: torch.Tensor, add: int, out: torch.Tensor, check=None, max_out=None):
+    """out[i] = x[i] + add (out: a contiguous int64 slice of the batch-wide key buffer).  check = (bits, flag, value) + max_out: as
+    `keys_from_i64`, taken on x[i]."""
     lib = _lib.load()
     if out.numel() != x.numel():
         raise ValueError("keys_from_i64_offset: output slice has another length")
+    if max_out is not None:
+        bits, flag, value = check
+        _lib.check(lib.sd3d_keys_from_i64_offset_checked_max(_ptr(x, torch.int64, "x"), x.numel(), int(add), _ptr(out, torch.int64, "out"), int(bits),
+                                                             _ptr(flag, torch.int32, "flag"), int(value), _ptr(max_out, torch.int32, "max_out"),
+                                                             _stream()), "keys_from_i64_offset_checked_max")
+        return out
     _lib.check(lib.sd3d_keys_from_i64_offset(_ptr(x, torch.int64, "x"), x.numel(), int(add), _ptr(out, torch.int64, "out"), _stream()),
                "keys_from_i64_offset")
     return out

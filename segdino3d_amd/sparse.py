@@ -51,6 +51,14 @@ def offsets_device(ksize: int, order: str, device) -> torch.Tensor:
     return _OFFSET_CACHE[key]
 
 
+def perm8_device(order: str, device) -> torch.Tensor:
+    """`child_perm(order)` on the device, once per (order, device) - not one pageable, i.e. blocking, host-to-device copy per scene"""
+    key = ("perm8", order, str(device))
+    if key not in _OFFSET_CACHE:
+        _OFFSET_CACHE[key] = torch.from_numpy(child_perm(order)).to(device)
+    return _OFFSET_CACHE[key]
+
+
 def child_perm(order: str) -> np.ndarray:
     """Z-order child position (x | y<<1 | z<<2) -> weight index of a 2x2x2 kernel."""
     if order == "x_fastest":
@@ -139,6 +147,9 @@ OPTIMISTIC_SORT = os.environ.get("SD3D_OPTIMISTIC_SORT", "1") != "0"
 # SD3D_LEVELS_AT_ONCE=0: the coarser levels of a scene by one run-length unique per level (four launches each) instead of all of them
 # from the level-0 keys in four launches (`sd3d_unique_levels`; MinkowskiEngine semantics only - spconv's extent clip keeps the per-level path)
 LEVELS_AT_ONCE = os.environ.get("SD3D_LEVELS_AT_ONCE", "1") != "0"
+MORTON_BITS = 48               # SD3D_MORTON_BITS (csrc/common.h): the Z-order code of a voxel; a batch's scene index sits above it
+# SD3D_VOXELISE_ONE_CALL=0: the voxelisation chain of a scene as ~10 Python calls (the round 1 - 4 path; the clipped / per-level variants keep it)
+VOXELISE_ONE_CALL = os.environ.get("SD3D_VOXELISE_ONE_CALL", "1") != "0"
 PAIR_CHAIN_LEVELS = tuple(int(v) for v in os.environ.get("SD3D_PAIR_CHAIN_LEVELS", "0,1,2").split(",") if v.strip() != "")
 
 
@@ -146,9 +157,11 @@ class SceneMaps:
     """Voxelisation + coordinate levels + neighbour tables of ONE scene, all on the HIP device."""
 
     def __init__(self, points: torch.Tensor, voxel_size: float, n_levels: int, shift_to_min: bool = False,
-                 order: str = "x_fastest", superpoints: Optional[torch.Tensor] = None, clip_min_shape: int = 0):
+                 order: str = "x_fastest", superpoints: Optional[torch.Tensor] = None, clip_min_shape: int = 0, while_waiting=None):
         """clip_min_shape > 0 enables spconv's output-extent rule for the strided levels (needs
-        shift_to_min coordinates); 0 = MinkowskiEngine semantics (every parent voxel exists)."""
+        shift_to_min coordinates); 0 = MinkowskiEngine semantics (every parent voxel exists).
+        while_waiting(self): called once between issuing the scene's read-back and waiting for it - host work that needs no size of the
+        scene (the validity check of the derived weights) costs nothing there, the host would sleep."""
         if not points.is_cuda:
             raise RuntimeError("SceneMaps needs device-resident points (no CPU fallback in the product path)")
         self.order = order
@@ -163,32 +176,60 @@ class SceneMaps:
         # and the superpoint ids over 16 (2 instead of 4); the key kernels raise a flag when a key needs more, the flag rides in the
         # scene's read-back, and the chain is then redone with the full sorts (tests/test_gpu_sparse.py exercises both).
         key_bits, sp_bits = (32, 16) if OPTIMISTIC_SORT else (56, 32)
+        at_once = LEVELS_AT_ONCE and clip_min_shape == 0 and 1 < n_levels <= 8
         while True:
+            if at_once and VOXELISE_ONE_CALL:
+                # the whole chain below from one C call (same kernels, same order): ~28 launches of 4 - 13 us that a Python host issues
+                # slower than the GPU runs them, in front of everything else of the scene
+                v = ops.voxelise_scene(points, inv, shift_to_min, key_bits, n_levels, superpoints,
+                                       (sp_bits if sp_bits < 32 else 64) if superpoints is not None else 64)
+                self.stats, self.icoords, self.origin, self.sidx = v["stats"], v["icoords"], v["origin"], v["sidx"]
+                self.seg_start, self.inverse, keys_l, parents = v["seg_start"], v["inverse"], v["ukeys"], v["parents"]
+                self._rb_dev = v["readback"]
+                read = ops.HostRead(v["readback"])           # synchronisation 1 of the scene (polled)
+                if superpoints is not None:                  # sorted while the read-back travels
+                    self.sp_sorted, self.sp_sidx = ops.sort_pairs(v["sp_keys"], None, 0, sp_bits)
+                if while_waiting is not None:
+                    while_waiting(self)
+                    while_waiting = None
+                host = read.wait().tolist()
+                flags = int(host[n_levels])
+                if (flags & 2 and key_bits < 56) or (flags & 4 and sp_bits < 32):
+                    key_bits, sp_bits = 56, 32
+                    continue
+                break
+            # the scene's read-back, written in place by the kernels (no concatenation launch): [n_0 .. n_{L-1}, flags, largest superpoint id]
+            rb = torch.zeros(n_levels + 2, dtype=torch.int32, device=self.device)
+            err = rb[n_levels:n_levels + 1]
             self.stats = ops.scene_stats(points)
-            keys, self.icoords, self.origin, err = ops.voxel_keys(points, inv, self.stats, shift_to_min)
+            keys, self.icoords, self.origin, _ = ops.voxel_keys(points, inv, self.stats, shift_to_min, err=err)
             skeys, self.sidx = ops.sort_pairs(keys, None, 0, key_bits)
             ukeys, self.seg_start, self.inverse, n0 = ops.unique_sorted(
-                skeys, self.sidx, N, None, 0, want_seg_start=True, want_map=True, map_size=N)
-            keys_l, counts, parents = [ukeys], [n0], []
+                skeys, self.sidx, N, None, 0, want_seg_start=True, want_map=True, map_size=N, nuniq_out=rb[0:1])
+            keys_l, parents = [ukeys], []
             cap = N
-            if LEVELS_AT_ONCE and clip_min_shape == 0 and 1 < n_levels <= 8:
-                uks, parents, cnt = ops.unique_levels(ukeys, cap, n0, n_levels - 1)     # every coarser level in four launches
+            if at_once:
+                uks, parents, _ = ops.unique_levels(ukeys, cap, n0, n_levels - 1, counts_out=rb[1:n_levels])   # every coarser level in four launches
                 keys_l += uks
-                counts.append(cnt)
             else:
+                n_prev = n0
                 for lvl in range(1, n_levels):
                     clip = (self.stats, inv, lvl, clip_min_shape) if clip_min_shape > 0 else None
-                    uk, _, parent, nl = ops.unique_sorted(keys_l[-1], None, cap, counts[-1], 3, want_seg_start=False, want_map=True,
-                                                          clip=clip)
+                    uk, _, parent, n_prev = ops.unique_sorted(keys_l[-1], None, cap, n_prev, 3, want_seg_start=False, want_map=True,
+                                                              clip=clip, nuniq_out=rb[lvl:lvl + 1])
                     keys_l.append(uk)
-                    counts.append(nl)
                     parents.append(parent)
-            extra = [err]
-            if superpoints is not None:
-                sp_keys = ops.keys_from_i64(superpoints, check=(sp_bits, err, 4) if sp_bits < 32 else None)
+            sp_keys = None
+            if superpoints is not None:                  # (the ids' largest value - the superpoint count - does not wait for their sort)
+                sp_keys = ops.keys_from_i64(superpoints, check=(sp_bits if sp_bits < 32 else 64, err, 4), max_out=rb[n_levels + 1:])
+            self._rb_dev = rb
+            read = ops.HostRead(rb)                      # synchronisation 1 of the scene (polled)
+            if sp_keys is not None:                      # sorted while the read-back travels
                 self.sp_sorted, self.sp_sidx = ops.sort_pairs(sp_keys, None, 0, sp_bits)
-                extra.append(self.sp_sorted[-1:].to(torch.int32))
-            host = ops.HostRead(torch.cat(counts + extra)).wait().tolist()   # synchronisation 1 of the scene (polled)
+            if while_waiting is not None:
+                while_waiting(self)
+                while_waiting = None
+            host = read.wait().tolist()
             flags = int(host[n_levels])
             if (flags & 2 and key_bits < 56) or (flags & 4 and sp_bits < 32):
                 key_bits, sp_bits = 56, 32                                   # a key did not fit: full sorts (rare: the chain runs twice)
@@ -204,7 +245,7 @@ class SceneMaps:
         self._hash: Dict[int, Tuple[torch.Tensor, torch.Tensor]] = {}
         self._same: Dict[Tuple[int, int], torch.Tensor] = {}
         self._stride: Dict[int, Tuple[torch.Tensor, torch.Tensor]] = {}
-        self._perm8 = torch.from_numpy(child_perm(order)).to(self.device)
+        self._perm8 = perm8_device(order, self.device)
         self._sp_start = None
         self.density: Dict[Tuple, float] = {}
         self.pairs: Dict[Tuple, "ops.PairLists"] = {}       # offset-major rulebooks (prepare())
@@ -445,38 +486,60 @@ class BatchSceneMaps(SceneMaps):
         self.n_points = N
         inv = float(np.float32(1.0) / np.float32(voxel_size))
         self.stats = torch.empty(B, 9, dtype=torch.float32, device=dev)
-        keys = torch.empty(N, dtype=torch.int64, device=dev)
-        self.icoords = torch.empty(N, 3, dtype=torch.int32, device=dev)
-        err = torch.zeros(1, dtype=torch.int32, device=dev)
-        for i, p in enumerate(points):
-            a, b = self.point_off[i], self.point_off[i + 1]
-            ops.scene_stats(p, out=self.stats[i])
-            ops.voxel_keys(p, inv, self.stats[i], shift_to_min, batch_index=i, out=(keys[a:b], self.icoords[a:b], err))
-        skeys, self.sidx = ops.sort_pairs(keys, None, 0, 56)
-        ukeys, self.seg_start, self.inverse, n0 = ops.unique_sorted(
-            skeys, self.sidx, N, None, 0, want_seg_start=True, want_map=True, map_size=N)
-        keys_l, counts, parents = [ukeys], [n0], []
-        if LEVELS_AT_ONCE and clip_min_shape == 0 and 1 < n_levels <= 8:
-            uks, parents, cnt = ops.unique_levels(ukeys, N, n0, n_levels - 1)
-            keys_l += uks
-            counts.append(cnt)
-        else:
-            for lvl in range(1, n_levels):
-                clip = (self.stats, inv, lvl, clip_min_shape) if clip_min_shape > 0 else None
-                uk, _, parent, nl = ops.unique_sorted(keys_l[-1], None, N, counts[-1], 3, want_seg_start=False, want_map=True, clip=clip)
-                keys_l.append(uk)
-                counts.append(nl)
-                parents.append(parent)
-        extra = [err]
         self.superpoints = superpoints
-        if superpoints is not None:
-            sp_keys = torch.empty(N, dtype=torch.int64, device=dev)
-            for i, sp in enumerate(superpoints):
-                ops.keys_from_i64_offset(sp.contiguous(), i << 32, sp_keys[self.point_off[i]:self.point_off[i + 1]])
-            self.sp_sorted, self.sp_sidx = ops.sort_pairs(sp_keys, None, 0, 32 + max(1, (B - 1).bit_length()))
-            # largest id of scene i = low word of the last key of its run (the scenes' runs have the known lengths N_i)
-            extra += [self.sp_sorted[c - 1:c].view(torch.int32)[:1] for c in self.point_off[1:]]
-        host = ops.HostRead(torch.cat(counts + extra)).wait().tolist()   # synchronisation 1 of the batch (polled)
+        scene_bits = max(1, (B - 1).bit_length())
+        # Optimistic radix passes as for one scene: Morton parts that fit 32 bits are sorted over those and then over the scene bits
+        # (5 passes instead of 7), superpoint ids that fit 16 bits likewise (3 instead of 5); the key kernels raise a flag otherwise and
+        # the chain runs again with the full sorts.  Either way the arrays are those of the full sorts.
+        optimistic = OPTIMISTIC_SORT
+        while True:
+            # the batch's read-back, written in place by the kernels: [n_0 .. n_{L-1}, flags, largest superpoint id of scene 0 .. B-1]
+            rb = torch.zeros(n_levels + 1 + B, dtype=torch.int32, device=dev)
+            err = rb[n_levels:n_levels + 1]
+            keys = torch.empty(N, dtype=torch.int64, device=dev)
+            self.icoords = torch.empty(N, 3, dtype=torch.int32, device=dev)
+            for i, p in enumerate(points):
+                a, b = self.point_off[i], self.point_off[i + 1]
+                ops.scene_stats(p, out=self.stats[i])
+                ops.voxel_keys(p, inv, self.stats[i], shift_to_min, batch_index=i, out=(keys[a:b], self.icoords[a:b], err))
+            if optimistic:
+                skeys, self.sidx = ops.sort_pairs(keys, None, 0, 32)
+                skeys, self.sidx = ops.sort_pairs(skeys, self.sidx, MORTON_BITS, MORTON_BITS + scene_bits)
+            else:
+                skeys, self.sidx = ops.sort_pairs(keys, None, 0, 56)
+            ukeys, self.seg_start, self.inverse, n0 = ops.unique_sorted(
+                skeys, self.sidx, N, None, 0, want_seg_start=True, want_map=True, map_size=N, nuniq_out=rb[0:1])
+            keys_l, parents = [ukeys], []
+            if LEVELS_AT_ONCE and clip_min_shape == 0 and 1 < n_levels <= 8:
+                uks, parents, _ = ops.unique_levels(ukeys, N, n0, n_levels - 1, counts_out=rb[1:n_levels])
+                keys_l += uks
+            else:
+                n_prev = n0
+                for lvl in range(1, n_levels):
+                    clip = (self.stats, inv, lvl, clip_min_shape) if clip_min_shape > 0 else None
+                    uk, _, parent, n_prev = ops.unique_sorted(keys_l[-1], None, N, n_prev, 3, want_seg_start=False, want_map=True, clip=clip,
+                                                              nuniq_out=rb[lvl:lvl + 1])
+                    keys_l.append(uk)
+                    parents.append(parent)
+            sp_keys = None
+            if superpoints is not None:                        # (every scene's largest id - its superpoint count - does not wait for the sort)
+                sp_keys = torch.empty(N, dtype=torch.int64, device=dev)
+                for i, sp in enumerate(superpoints):
+                    ops.keys_from_i64_offset(sp.contiguous(), i << 32, sp_keys[self.point_off[i]:self.point_off[i + 1]],
+                                             check=(16 if optimistic else 64, err, 4), max_out=rb[n_levels + 1 + i:n_levels + 2 + i])
+            read = ops.HostRead(rb)                            # synchronisation 1 of the batch (polled)
+            if sp_keys is not None:                            # sorted while the read-back travels
+                if optimistic:
+                    k1, v1 = ops.sort_pairs(sp_keys, None, 0, 16)
+                    self.sp_sorted, self.sp_sidx = ops.sort_pairs(k1, v1, 32, 32 + scene_bits)
+                else:
+                    self.sp_sorted, self.sp_sidx = ops.sort_pairs(sp_keys, None, 0, 32 + scene_bits)
+            host = read.wait().tolist()
+            flags = int(host[n_levels])
+            if optimistic and flags & 6:
+                optimistic = False                             # a key did not fit: full sorts (rare: the chain runs twice)
+                continue
+            break
         self.n_vox = [int(v) for v in host[:n_levels]]
         if int(host[n_levels]) & 1:                                # (bit 1 = "more than 32 Morton bits": the batch sorts all 56 key bits anyway)
             raise RuntimeError("scene exceeds the 16-bit-per-axis voxel key range (extent > ~1.3 km at 2 cm)")
@@ -489,7 +552,7 @@ class BatchSceneMaps(SceneMaps):
         self.parents = [p[: self.n_vox[l]] for l, p in enumerate(parents)]
         self.seg_start = self.seg_start[: self.n_vox[0] + 1]
         self._hash, self._same, self._stride = {}, {}, {}
-        self._perm8 = torch.from_numpy(child_perm(order)).to(self.device)
+        self._perm8 = perm8_device(order, self.device)
         self._sp_start = None
         self.density, self.pairs = {}, {}
         self.events, self._join_ev, self._fork_ev = {}, None, ops.stream_event()

@@ -568,8 +568,9 @@ def test_backbones_on_a_dense_surface_scene_match_oracle(which):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("one_call", [True, False])
 @pytest.mark.parametrize("extent_m,sp_base,redo", [(6.0, 0, False), (60.0, 0, True), (6.0, 70_000, True)])
-def test_optimistic_radix_passes_fall_back_to_the_full_sort(extent_m, sp_base, redo, monkeypatch):
+def test_optimistic_radix_passes_fall_back_to_the_full_sort(extent_m, sp_base, redo, one_call, monkeypatch):
     """`sparse.OPTIMISTIC_SORT`: voxel keys sorted over 32 bits / superpoint ids over 16 when they fit (the key kernels flag the
     scenes where they do not: > ~20 m at 2 cm, ids >= 65536 - the chain then runs again with the full sorts).  Either way the maps
     are those of the full sorts, bit for bit."""
@@ -585,14 +586,16 @@ def test_optimistic_radix_passes_fall_back_to_the_full_sort(extent_m, sp_base, r
     real_sort = ops.sort_pairs
     monkeypatch.setattr(ops, "sort_pairs", lambda keys, vals=None, b=0, e=64: (calls.append(e), real_sort(keys, vals, b, e))[1])
     maps = {}
+    # one_call: the voxel keys are sorted inside `sd3d_voxelise_scene` (round 5), only the superpoint ids' sort is a call of its own
+    monkeypatch.setattr(sparse, "VOXELISE_ONE_CALL", one_call)
     for mode in (True, False):
         monkeypatch.setattr(sparse, "OPTIMISTIC_SORT", mode)
         calls.clear()
         maps[mode] = SceneMaps(pts, 0.02, 5, superpoints=sp)
         if mode:
-            assert calls == ([32, 16, 56, 32] if redo else [32, 16]), calls
+            assert calls == (([16, 32] if redo else [16]) if one_call else ([32, 16, 56, 32] if redo else [32, 16])), calls
         else:
-            assert calls == [56, 32]
+            assert calls == ([32] if one_call else [56, 32])
     a, b = maps[True], maps[False]
     assert a.n_vox == b.n_vox and a.n_superpoints == b.n_superpoints
     for name in ("sidx", "seg_start", "inverse", "sp_sorted", "sp_sidx", "icoords"):
@@ -601,6 +604,74 @@ def test_optimistic_radix_passes_fall_back_to_the_full_sort(extent_m, sp_base, r
         assert torch.equal(a.keys[l], b.keys[l])
     for l in range(4):
         assert torch.equal(a.parents[l], b.parents[l])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("extent_m,sp_base,redo", [(6.0, 0, False), (60.0, 0, True), (6.0, 70_000, True)])
+def test_batch_optimistic_radix_passes_fall_back_to_the_full_sort(extent_m, sp_base, redo, monkeypatch):
+    """The same for a batch (round 5): Morton parts over 32 bits + the scene bits (5 passes instead of 7), ids over 16 bits + the
+    scene bits (3 instead of 5), the flags of ANY scene of the batch send the whole chain through the full sorts.  The maps are those
+    of the full sorts, bit for bit, and every scene's superpoint count is its largest id + 1."""
+    from segdino3d_amd import ops, sparse
+    from segdino3d_amd.sparse import BatchSceneMaps
+    d = torch.device("cuda:0")
+    g = torch.Generator().manual_seed(9)
+    scenes = []
+    for i, n in enumerate((20_000, 7_001, 33_333)):
+        ext = extent_m if i == 1 else 5.0                       # only ONE scene of the batch is the large one
+        pts = torch.cat([torch.rand(n, 3, generator=g) * torch.tensor([ext, ext * 0.7, 2.5]), torch.rand(n, 3, generator=g)], 1).to(d)
+        sp = (torch.randint(0, 300 + 10 * i, (n,), generator=g) + (sp_base if i == 2 else 0)).to(d)
+        scenes.append((pts, sp))
+    calls = []
+    real_sort = ops.sort_pairs
+    monkeypatch.setattr(ops, "sort_pairs", lambda keys, vals=None, b=0, e=64: (calls.append((b, e)), real_sort(keys, vals, b, e))[1])
+    maps = {}
+    for mode in (True, False):
+        monkeypatch.setattr(sparse, "OPTIMISTIC_SORT", mode)
+        calls.clear()
+        maps[mode] = BatchSceneMaps([p for p, _ in scenes], 0.02, 5, superpoints=[s for _, s in scenes])
+        opt, full = [(0, 32), (48, 50), (0, 16), (32, 34)], [(0, 56), (0, 34)]
+        assert calls == ((opt + full if redo else opt) if mode else full), calls
+    a, b = maps[True], maps[False]
+    assert a.n_vox == b.n_vox and a.sp_off == b.sp_off
+    assert a.sp_off == [0] + list(torch.tensor([int(s.max()) + 1 for _, s in scenes]).cumsum(0).tolist())
+    for name in ("sidx", "seg_start", "inverse", "sp_sorted", "sp_sidx", "icoords", "stats"):
+        assert torch.equal(getattr(a, name), getattr(b, name)), name
+    for l in range(5):
+        assert torch.equal(a.keys[l], b.keys[l])
+    for l in range(4):
+        assert torch.equal(a.parents[l], b.parents[l])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n,ext,with_sp", [(30_000, 5.0, True), (12_345, 3.0, True), (1, 1.0, True), (150_001, 9.0, False), (4097, 30.0, True)])
+def test_voxelisation_from_one_call_equals_the_separate_calls(n, ext, with_sp, monkeypatch):
+    """`sd3d_voxelise_scene` (round 5: the voxelisation chain of a scene issued by ONE C call) against the chain of separate calls
+    (scene_stats, voxel_keys, sort_pairs, unique_sorted, unique_levels, keys_from_i64): every array and every count, bit for bit -
+    odd sizes (row padding of the shared buffers), one point, a scene that needs the full key sort, no superpoints."""
+    from segdino3d_amd import sparse
+    from segdino3d_amd.sparse import SceneMaps
+    d = torch.device("cuda:0")
+    g = torch.Generator().manual_seed(n)
+    pts = torch.cat([torch.rand(n, 3, generator=g) * ext - 1.0, torch.rand(n, 3, generator=g)], 1).to(d)
+    sp = torch.randint(0, 300, (n,), generator=g).to(d) if with_sp else None
+    maps = {}
+    for mode in (True, False):
+        monkeypatch.setattr(sparse, "VOXELISE_ONE_CALL", mode)
+        ran = []
+        maps[mode] = SceneMaps(pts, 0.02, 5, superpoints=sp, while_waiting=lambda m: ran.append(m.n_points))
+        assert ran == [n], "the hook of the read-back wait runs exactly once"
+    a, b = maps[True], maps[False]
+    assert a.n_vox == b.n_vox and a.n_superpoints == b.n_superpoints and a.n_vox[0] > 0
+    names = ("stats", "origin", "icoords", "sidx", "seg_start", "inverse") + (("sp_sorted", "sp_sidx") if with_sp else ())
+    for name in names:
+        assert torch.equal(getattr(a, name), getattr(b, name)), name
+    for l in range(5):
+        assert torch.equal(a.keys[l], b.keys[l]), ("keys", l)
+    for l in range(4):
+        assert torch.equal(a.parents[l], b.parents[l]), ("parents", l)
+    if with_sp:
+        assert a.n_superpoints == int(sp.max()) + 1
 
 
 @pytest.mark.gpu

@@ -26,6 +26,7 @@ SETTINGS = {
     "fork / join + narrow row chain": dict(fork=True, narrow=True),
     "fork / join, full radix sorts": dict(fork=True, narrow=False, optimistic=False),
     "fork / join, one unique per level": dict(fork=True, narrow=False, levels=False),
+    "fork / join, voxelisation by separate calls": dict(fork=True, narrow=False, one_call=False),
 }
 only = os.environ.get("AB_ONLY")
 if only:
@@ -36,16 +37,43 @@ def apply(s):
     sparse.FORK_JOIN = s["fork"]
     sparse.OPTIMISTIC_SORT = s.get("optimistic", True)
     sparse.LEVELS_AT_ONCE = s.get("levels", True)
+    sparse.VOXELISE_ONE_CALL = s.get("one_call", True)
     decoder.FUSED_NARROW = s["narrow"]
 
 
-def group(n=10):
+# prologue = GPU time from the forward's first launch to the point where the U-Net's first layer may start (an event on the scene's stream
+# right before `LayerPlan.run` enqueues it): what the voxelisation / map / list work in front of the convolutions costs the scene
+from segdino3d_amd import plan as _plan
+_marks = []
+_run = _plan.LayerPlan.run
+
+
+def _run_marked(self, maps, x):
+    e = torch.cuda.Event(enable_timing=True)
+    e.record()
+    _marks.append(e)
+    return _run(self, maps, x)
+
+
+_plan.LayerPlan.run = _run_marked
+prologue = {}
+
+
+def group(n=10, key=None):
     torch.cuda.synchronize()
+    _marks.clear()
+    begins = []
     t0 = time.perf_counter()
     for i in range(n):
+        b = torch.cuda.Event(enable_timing=True)
+        b.record()
+        begins.append(b)
         model([pool[i % 2][0]], [pool[i % 2][1]])
     torch.cuda.synchronize()
-    return 1e3 * (time.perf_counter() - t0) / n
+    dt = 1e3 * (time.perf_counter() - t0) / n
+    if key is not None and len(_marks) == n:
+        prologue.setdefault(key, []).append(statistics.median(b.elapsed_time(e) for b, e in zip(begins, _marks)))
+    return dt
 
 
 res = {k: [] for k in SETTINGS}
@@ -56,9 +84,10 @@ with torch.no_grad():
     for r in range(rounds):
         for k, s in SETTINGS.items():
             apply(s)
-            res[k].append(group())
+            res[k].append(group(key=k))
 for k, v in res.items():
-    print(f"{k:40s} median {statistics.median(v):7.3f} ms   min {min(v):7.3f}   max {max(v):7.3f}   (groups of 10 forwards, {len(v)} rounds)")
+    pro = f"   prologue (forward start -> first convolution may start) median {statistics.median(prologue[k]):6.3f} ms" if k in prologue else ""
+    print(f"{k:40s} median {statistics.median(v):7.3f} ms   min {min(v):7.3f}   max {max(v):7.3f}   (groups of 10 forwards, {len(v)} rounds){pro}")
 if os.environ.get("AB_HOST") == "1":                          # host time of the phases that precede the first convolution
     from segdino3d_amd import plan
     acc = {}

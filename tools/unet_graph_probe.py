@@ -20,7 +20,7 @@ pts, tgt = pts.to(d), tgt.to(d)
 sparse.FORK_JOIN = False
 with torch.no_grad():
     model([pts], [tgt])                                         # builds the plan, warms everything
-    maps, vf, _, _, _ = bb._scene_inputs(pts.float().contiguous(), tgt)
+    maps, vf, _, _, _, _ = bb._scene_inputs(pts.float().contiguous(), tgt)
     k1 = bb.conv1_kernel_size
     maps.prepare(same=[(0, k1)] + [(l, 3) for l in range(5)], strides=[0, 1, 2, 3], chained=True)
     plan = bb._plan
