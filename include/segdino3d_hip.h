@@ -490,6 +490,10 @@ int sd3d_mask_scores(const float* masks, int ld, int S, const uint32_t* flat_idx
  *   nms_finish: final_scores = scores2[order2], final_labels = labels1[order2], record = order1[order2] (int64, :133-139) and, boxes != NULL,
  *   boxes[i] = [centers | sizes][qidx[record[i]]] ([n, 6], baseline3d.py:447-452; centers / sizes [Q, 3] contiguous). */
 int sd3d_take_f32(const float* src, const uint32_t* idx, int n, float* out, void* stream);
+/* idx[0..k) = the first k entries of the STABLE descending sort of x[0..n) (ties: lower index first) - what
+ * sd3d_keys_from_f32(descending) + sd3d_sort_pairs_u64 give, from one launch of one workgroup (radix select + rank of the k survivors).
+ * `scores.flatten(0, 1).topk(topk_insts)` of predict_by_feat_instance (baseline3d.py:434).  1 <= k <= 1024, k <= n <= 40 960 (forty scores per thread of the one workgroup, in registers). */
+int sd3d_topk_desc_f32(const float* x, int64_t n, int k, uint32_t* idx, void* stream);
 /* The data-dependent selections of predict_by_feat_instance (:470-476) for two score thresholds on the device (all outputs sized k):
  * keep / pkeep = rows with score > thr0 / thr1 and count > npoint_thr, ascending; union_rows = rows in either; keep_u / pkeep_u = where
  * the rows of keep / pkeep sit in union_rows; score_mask[i] = score[i] > thr0; npoint_mask = (count > npoint_thr) compacted over the

@@ -92,6 +92,7 @@ SIGNATURES = {
     "sd3d_class_scores": (_i, [_p, _i, _l, _i, _p, _p, _p]),
     "sd3d_mask_scores": (_i, [_p, _i, _i, _p, _p, _i, _i, _i, _p, _p, _p, _p]),
     "sd3d_take_f32": (_i, [_p, _p, _i, _p, _p]),
+    "sd3d_topk_desc_f32": (_i, [_p, _l, _i, _p, _p]),
     "sd3d_select_instances": (_i, [_p, _p, _i, _f, _f, _i, _p, _p, _p, _p, _p, _p, _p, _p, _p]),
     "sd3d_take_instances": (_i, [_p, _i, _p, _p, _p, _p, _p, _p, _p]),
     "sd3d_take_pair": (_i, [_p, _p, _p, _i, _p, _p, _p]),

@@ -59,6 +59,10 @@ def _cfg_get(cfg, key, default=None):
     return getattr(cfg, key, default) if not hasattr(cfg, "get") else cfg.get(key, default)
 
 
+# SD3D_TOPK_SELECT=0: the top-k (query, class) pairs of the post-processing by a full radix sort of all Q x C scores (rounds 1 - 4)
+TOPK_SELECT = _os.environ.get("SD3D_TOPK_SELECT", "1") != "0"
+
+
 def _sorted_desc(score: torch.Tensor):
     """indices (int32) that sort `score` descending (stable) via the radix sort kernels."""
     keys = ops.keys_from_f32(score, descending=True)
@@ -204,7 +208,7 @@ class Baseline3D(nn.Module):
         B = len(samples)
         main = torch.cuda.current_stream()
         sides = ops.side_streams(B, samples[0].device)
-        outs, coms, reads = [None] * B, [None] * B, [None] * B
+        outs, coms, reads, sems = [None] * B, [None] * B, [None] * B, [None] * B
         pick = lambda lst, b: None if lst is None else [lst[b]]      # noqa: E731
         for b, st in enumerate(sides):
             st.wait_stream(main)
@@ -216,9 +220,11 @@ class Baseline3D(nn.Module):
             with ops.use_stream(st):
                 coms[b] = self._instances_common([samples[b]], outs[b], targets[b]["extra_features"]["super_point_masks"])
                 reads[b] = self._select_begin(coms[b])
+                sems[b] = self._semantic(outs[b], targets[b]["extra_features"]["super_point_masks"])
         for b, st in enumerate(sides):
             with ops.use_stream(st):
-                pred = self._predict_finish([samples[b]], outs[b], targets[b]["extra_features"]["super_point_masks"], coms[b], reads[b])
+                pred = self._predict_finish([samples[b]], outs[b], targets[b]["extra_features"]["super_point_masks"], coms[b], reads[b],
+                                            sem_pre=sems[b])
             targets[b].pred_pts_seg = pred[0]
             main.wait_stream(st)
         cap = _trace.active()
@@ -246,7 +252,10 @@ class Baseline3D(nn.Module):
         flat, _ = ops.class_scores(cls, C)
         if out.get("scores") is not None and out["scores"][b] is not None:        # objectness head: scores *= out['scores'][0] (:428-429)
             flat = (flat.view(Q, C) * out["scores"][b].reshape(Q, 1)).reshape(-1).contiguous()
-        order0 = _sorted_desc(flat)[:k].contiguous()                    # top-k (query, class) pairs (:434)
+        if TOPK_SELECT and flat.numel() <= ops.TOPK_SELECT_MAX_N and k <= 1024:
+            order0 = ops.topk_desc(flat, k)                              # top-k (query, class) pairs (:434): radix select, one launch
+        else:
+            order0 = _sorted_desc(flat)[:k].contiguous()
         top_scores = ops.take_f32(flat, order0)
         labels, qidx, scores = ops.mask_scores(logits, S, order0, top_scores, C, bool(_cfg_get(cfg, "obj_normalization", None)))
         S_pad = (S + 31) // 32 * 32
@@ -309,10 +318,29 @@ class Baseline3D(nn.Module):
         cfg = self.test_cfg
         ops.baton_yield()
         com = self._instances_common(samples, out, superpoints, b)
-        return self._predict_finish(samples, out, superpoints, com, self._select_begin(com), b)
+        read = self._select_begin(com)
+        return self._predict_finish(samples, out, superpoints, com, read, b, sem_pre=self._semantic(out, superpoints, b))
 
-    def _predict_finish(self, samples, out, superpoints, com, read, b=0):
-        """The part of predict_by_feat behind the host read of the scores (data-dependent selections, semantic, panoptic)."""
+    def _semantic(self, out, superpoints, b=0):
+        """Semantic labels per point (:488-507) and the stuff-class labels the panoptic map starts from (:509-520): four launches that
+        depend on no selection - issued BEHIND the read of the selection counts, they run while the counts travel to the host."""
+        cfg = self.test_cfg
+        sem = out["sem_preds"][b]
+        n_sem = sem.shape[1] - 1
+        use_index = self.query_num == -1
+        sem_res = ops.gather_i64(ops.row_argmax(sem, ncols=n_sem), superpoints, use_index)
+        stuff = list(_cfg_get(cfg, "stuff_classes"))
+        cols = self._stuff_cols.get(str(sem.device)) if tuple(stuff) == self._stuff_cols.get("classes") else None
+        if cols is None:                                         # one H2D copy per device, not one per scene
+            if tuple(stuff) != self._stuff_cols.get("classes"):
+                self._stuff_cols = {"classes": tuple(stuff)}
+            cols = self._stuff_cols[str(sem.device)] = torch.tensor(stuff, dtype=torch.int32, device=sem.device)
+        sem_stuff = ops.gather_i64(ops.row_argmax(sem, cols=cols), superpoints, use_index)
+        return sem_res, sem_stuff, stuff
+
+    def _predict_finish(self, samples, out, superpoints, com, read, b=0, sem_pre=None):
+        """The part of predict_by_feat behind the host read of the scores (data-dependent selections, panoptic; the semantic maps too
+        unless the caller launched them while the read travelled: `sem_pre` = `_semantic(...)`)."""
         cfg = self.test_cfg
         # the data-dependent selections need the scores on the host: one polled read (no host thread sits inside a blocking HIP
         # call while other scenes are being issued)
@@ -323,19 +351,7 @@ class Baseline3D(nn.Module):
         if not self.to_host:                                       # (the host path packs the kept rows directly)
             inst_masks = (masks_u if keep_all else masks_u[keep_u.long()]).view(torch.bool)
         inst_labels, inst_scores, inst_boxes = ops.take_instances(keep.contiguous(), com["labels"], com["scores"], com["boxes"])
-        # semantic (:488-507)
-        sem = out["sem_preds"][b]
-        n_sem = sem.shape[1] - 1
-        use_index = self.query_num == -1
-        sem_res = ops.gather_i64(ops.row_argmax(sem, ncols=n_sem), superpoints, use_index)
-        # panoptic (:509-556)
-        stuff = list(_cfg_get(cfg, "stuff_classes"))
-        cols = self._stuff_cols.get(str(sem.device)) if tuple(stuff) == self._stuff_cols.get("classes") else None
-        if cols is None:                                         # one H2D copy per device, not one per scene
-            if tuple(stuff) != self._stuff_cols.get("classes"):
-                self._stuff_cols = {"classes": tuple(stuff)}
-            cols = self._stuff_cols[str(sem.device)] = torch.tensor(stuff, dtype=torch.int32, device=sem.device)
-        sem_stuff = ops.gather_i64(ops.row_argmax(sem, cols=cols), superpoints, use_index)
+        sem_res, sem_stuff, stuff = self._semantic(out, superpoints, b) if sem_pre is None else sem_pre
         if pkeep.numel() == 0:
             pan_sem, pan_inst = sem_stuff, sem_stuff
         else:

@@ -89,6 +89,7 @@ int launch_box_refine(const float*, const float*, const float*, int, const float
 int launch_class_scores(const float*, int, int64_t, int, float*, float*, hipStream_t);
 int launch_mask_scores(const float*, int, int, const uint32_t*, const float*, int, int, int, int32_t*, int32_t*, float*, hipStream_t);
 int launch_take_f32(const float*, const uint32_t*, int, float*, hipStream_t);
+int launch_topk_desc(const float*, int64_t, int, uint32_t*, hipStream_t);
 int launch_select_instances(const float*, const int32_t*, int, float, float, int, int32_t*, int32_t*, int32_t*, int32_t*, int32_t*, uint8_t*, uint8_t*,
                             int32_t*, hipStream_t);
 int launch_take_instances(const int32_t*, int, const int32_t*, const float*, const float*, int64_t*, float*, float*, hipStream_t);
@@ -469,6 +470,7 @@ int sd3d_class_scores(const float* cls, int ld, int64_t Q, int C, float* scores,
     return launch_class_scores(cls, ld, Q, C, scores, rowmax, ST);
 }
 int sd3d_take_f32(const float* src, const uint32_t* idx, int n, float* out, void* stream) { return launch_take_f32(src, idx, n, out, ST); }
+int sd3d_topk_desc_f32(const float* x, int64_t n, int k, uint32_t* idx, void* stream) { return launch_topk_desc(x, n, k, idx, ST); }
 int sd3d_select_instances(const float* scores, const int32_t* count, int k, float thr0, float thr1, int npoint_thr, int32_t* keep, int32_t* pkeep,
                           int32_t* union_rows, int32_t* keep_u, int32_t* pkeep_u, uint8_t* score_mask, uint8_t* npoint_mask, int32_t* counts,
                           void* stream) {

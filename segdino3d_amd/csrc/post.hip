@@ -636,6 +636,136 @@ int launch_mask_overlaps(const uint8_t* masks, int64_t mask_stride, int n, const
 // Index glue of predict_by_feat_instance (baseline3d.py:434-476, mask_matrix_nms :71-139) as three launches instead of sixteen
 // (`x.long()` + `y[x]` pairs, each a 4-6 us ATen launch in a phase that is a chain of ~50 dependent launches): pure data movement.
 // ---------------------------------------------------------------------------------------------------------------------------
+// ---- top-k of a score vector: the first k entries of the stable descending sort, without the sort ------------------------------------
+// `predict_by_feat_instance` keeps the topk_insts = 600 best of Q x C = 39 600 (query, class) scores (:434).  Sorting all of them was
+// four radix passes = eight dependent launches (60 us) for an answer of 600 numbers.  ONE workgroup: an 8-bit radix SELECT over the
+// order-preserving keys (four histogram passes over the L2-resident scores) finds the key of the k-th entry and how many of its ties
+// belong to the answer (the ones with the lowest indices - what a stable sort keeps), the k entries are collected and ranked by
+// (key, index) in LDS.  Bit for bit the index vector `sort_pairs(keys_from_f32(x, descending))[:k]` returns.
+#define TK_THREADS 1024
+#define TK_MAX_K 1024
+#define TK_NPT 40                                                   // scores per thread, held in registers: n <= 40 960
+__device__ __forceinline__ uint32_t tk_key(float v) {              // f32_to_sortkey(desc = 1): ascending keys = descending scores
+    uint32_t u = __float_as_uint(v);
+    u = (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+    return ~u;
+}
+__global__ __launch_bounds__(TK_THREADS) void topk_desc_kernel(const float* __restrict__ x, int n, int k, uint32_t* __restrict__ out) {
+    __shared__ int hist[256];
+    __shared__ int s_bucket, s_remaining, s_slot;
+    __shared__ int tie[TK_NPT * (TK_THREADS / 64)];               // ties per (row of 1024 scores, wave), then their exclusive scan
+    __shared__ int wsum[TK_THREADS / 64];
+    __shared__ uint64_t sel[TK_MAX_K + 8];                        // (key << 32 | index) of the survivors
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    // all scores of the thread requested at once (score j of thread t = x[1024 j + t]: coalesced), then everything runs on registers
+    uint32_t uc[TK_NPT];
+#pragma unroll
+    for (int j = 0; j < TK_NPT; ++j) {
+        const int i = j * TK_THREADS + tid;
+        uc[j] = tk_key(x[i < n ? i : 0]);
+    }
+    uint32_t prefix = 0;
+    int remaining = k;
+    for (int pass = 0; pass < 4; ++pass) {
+        const int shift = 24 - 8 * pass;
+        if (tid < 256) hist[tid] = 0;
+        __syncthreads();
+        const uint32_t hi_mask = pass == 0 ? 0u : (0xFFFFFFFFu << (shift + 8));
+        // (scores are sigmoid products: their top byte - sign and exponent - takes a handful of values, and 39 600 LDS atomics on a
+        //  handful of addresses serialise; a thread adds up the run of equal digits it sees and flushes when the digit changes)
+        int last = -1, run = 0;
+#pragma unroll
+        for (int j = 0; j < TK_NPT; ++j) {
+            const uint32_t u = uc[j];
+            if (j * TK_THREADS + tid < n && (u & hi_mask) == prefix) {
+                const int dgt = (int)((u >> shift) & 255);
+                if (dgt == last) ++run;
+                else {
+                    if (run) atomicAdd(&hist[last], run);
+                    last = dgt;
+                    run = 1;
+                }
+            }
+        }
+        if (run) atomicAdd(&hist[last], run);
+        __syncthreads();
+        if (tid < 64) {                                             // one wave finds the bucket that holds the remaining-th smallest key
+            int c[4], sum = 0;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) { c[q] = hist[tid * 4 + q]; sum += c[q]; }
+            int inc = sum;
+#pragma unroll
+            for (int d = 1; d < 64; d <<= 1) { const int t = __shfl_up(inc, d); if (tid >= d) inc += t; }
+            int before = inc - sum;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                if (before < remaining && remaining <= before + c[q]) { s_bucket = tid * 4 + q; s_remaining = remaining - before; }
+                before += c[q];
+            }
+        }
+        __syncthreads();
+        prefix |= (uint32_t)s_bucket << shift;
+        remaining = s_remaining;
+        __syncthreads();
+    }
+    // prefix = key of the k-th entry; `remaining` of the entries with exactly that key belong to the answer: the ones with the lowest
+    // indices.  Index order = (row j, wave, lane): ties per (row, wave) by ballot, an exclusive scan over the 640 counters.
+#pragma unroll
+    for (int j = 0; j < TK_NPT; ++j) {
+        const uint64_t bal = __ballot(j * TK_THREADS + tid < n && uc[j] == prefix);
+        if (lane == 0) tie[j * (TK_THREADS / 64) + wv] = __popcll(bal);
+    }
+    if (tid == 0) s_slot = 0;
+    __syncthreads();
+    {
+        const int v = tid < TK_NPT * (TK_THREADS / 64) ? tie[tid] : 0;
+        int inc = v;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) { const int t = __shfl_up(inc, d); if (lane >= d) inc += t; }
+        if (lane == 63) wsum[wv] = inc;
+        __syncthreads();
+        int base = 0;
+        for (int w = 0; w < wv; ++w) base += wsum[w];
+        if (tid < TK_NPT * (TK_THREADS / 64)) tie[tid] = base + inc - v;
+        __syncthreads();
+    }
+    const uint64_t lt = (1ull << lane) - 1ull;
+#pragma unroll
+    for (int j = 0; j < TK_NPT; ++j) {
+        const bool valid = j * TK_THREADS + tid < n;
+        const bool is_tie = valid && uc[j] == prefix;
+        const uint64_t bal = __ballot(is_tie);
+        bool take = valid && uc[j] < prefix;
+        if (is_tie) take = tie[j * (TK_THREADS / 64) + wv] + __popcll(bal & lt) < remaining;
+        if (take) {
+            const int slot = atomicAdd(&s_slot, 1);
+            sel[slot] = ((uint64_t)uc[j] << 32) | (uint32_t)(j * TK_THREADS + tid);
+        }
+    }
+    if (tid < 8) sel[k + tid] = ~0ull;                             // (the rank loop below walks the list eight at a time)
+    __syncthreads();
+    // rank by (key, index): the order of the stable sort.  One 64-bit compare per pair, eight broadcast reads in flight.
+    for (int e = tid; e < k; e += TK_THREADS) {
+        const uint64_t me = sel[e];
+        int rank = 0;
+        for (int j0 = 0; j0 < k; j0 += 8) {
+            uint64_t v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v[u] = sel[j0 + u];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) rank += v[u] < me;
+        }
+        out[rank] = (uint32_t)me;
+    }
+}
+int launch_topk_desc(const float* x, int64_t n, int k, uint32_t* out, hipStream_t st) {
+    if (k <= 0) return SD3D_OK;
+    if (n < k || k > TK_MAX_K || n > TK_NPT * TK_THREADS) return sd3d_set_error(SD3D_ERR_ARG, "topk_desc: 1 <= k <= 1024, k <= n <= 40960");
+    hipLaunchKernelGGL(topk_desc_kernel, dim3(1), dim3(TK_THREADS), 0, st, x, (int)n, k, out);
+    SD3D_CHECK_LAUNCH();
+    return SD3D_OK;
+}
+
 __global__ void take_f32_kernel(const float* __restrict__ src, const uint32_t* __restrict__ idx, int n, float* __restrict__ out) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) out[i] = src[idx[i]];

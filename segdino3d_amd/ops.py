@@ -1300,6 +1300,17 @@ def mask_scores(masks, S, flat_idx, score_in, C, normalize):
     return labels, qidx, out
 
 
+TOPK_SELECT_MAX_N = 40 * 1024    # what the one workgroup of the select holds in registers; above it: the radix sort
+
+
+def topk_desc(x: torch.Tensor, k: int):
+    """int32 [k]: the first k indices of the stable descending sort of the fp32 vector x (`sd3d_topk_desc_f32`: one launch)."""
+    lib = _lib.load()
+    out = torch.empty(k, dtype=torch.int32, device=x.device)
+    _lib.check(lib.sd3d_topk_desc_f32(_ptr(x, torch.float32, "x"), x.numel(), int(k), _ptr(out), _stream()), "topk_desc")
+    return out
+
+
 def take_f32(src, idx):
     """src[idx] for an int32 index vector, one launch (ATen: `.long()` + index)."""
     lib = _lib.load()

@@ -88,3 +88,52 @@ def test_index_glue_kernels():
     assert lo.dtype == torch.int64 and torch.equal(lo, fl[keep.long()].long()) and torch.equal(so, fs[keep.long()]) and torch.equal(bo, boxes[keep.long()])
     lo, so, bo = ops.take_instances(keep[:0], fl, fs, None)
     assert lo.numel() == 0 and bo is None
+
+
+@pytest.mark.parametrize("n,k,kind", [(39_600, 600, "sigmoid"), (39_600, 600, "ties"), (40_960, 1024, "normal"), (600, 600, "sigmoid"),
+                                      (1000, 1, "normal"), (5000, 37, "constant"), (20_000, 600, "signed")])
+def test_topk_select_equals_the_head_of_the_stable_sort(n, k, kind):
+    """`sd3d_topk_desc_f32` (round 5: radix select + rank in one workgroup) == `sort_pairs(keys_from_f32(x, descending))[:k]`, the
+    index vector `predict_by_feat_instance` took from the full sort before (`baseline3d.py:434`), bit for bit - sigmoid products (top
+    byte nearly constant), heavy ties across the k-th place (a stable sort keeps the lower indices), k = n, negative values, zeros."""
+    from segdino3d_amd import ops
+    d = _dev()
+    g = torch.Generator().manual_seed(n + k)
+    if kind == "sigmoid":
+        x = torch.sigmoid(torch.randn(n, generator=g) * 3) * torch.sigmoid(torch.randn(n, generator=g))
+    elif kind == "ties":
+        x = (torch.randint(0, 40, (n,), generator=g).float() / 40.0)          # ~1000 copies of every value: the k-th place falls inside a tie
+    elif kind == "constant":
+        x = torch.full((n,), 0.25)
+    elif kind == "signed":
+        x = torch.randn(n, generator=g)
+        x[::5] = 0.0
+        x[1::7] = -0.0
+    else:
+        x = torch.randn(n, generator=g).abs()
+    x = x.to(d)
+    _, idx = ops.sort_pairs(ops.keys_from_f32(x, descending=True), None, 0, 32)
+    got = ops.topk_desc(x, k)
+    assert got.dtype == torch.int32 and got.shape == (k,)
+    assert torch.equal(got, idx[:k].to(torch.int32))
+
+
+def test_post_processing_is_the_same_with_the_select_and_with_the_sort(monkeypatch):
+    """`Baseline3D._instances_common` on random decoder outputs: the radix select leaves every product of the threshold-independent
+    part (scores, labels, records, mask bits) exactly as the full sort left it."""
+    from segdino3d_amd import architecture as A
+    import bench
+    d = _dev()
+    model = bench.build_model(200, d)
+    from segdino3d_amd.synth import make_scene
+    pts, tgt = make_scene(3, 20000, 400, 50)
+    pts, tgt = pts.to(d), tgt.to(d)
+    outs = {}
+    with torch.no_grad():
+        for mode in (True, False):
+            monkeypatch.setattr(A, "TOPK_SELECT", mode)
+            outs[mode] = model([pts], [tgt])[0].pred_pts_seg
+    a, b = outs[True], outs[False]
+    assert torch.equal(a.instance_scores, b.instance_scores) and torch.equal(a.instance_labels, b.instance_labels)
+    assert torch.equal(a.pts_instance_mask[0], b.pts_instance_mask[0]) and torch.equal(a.pts_instance_mask[1], b.pts_instance_mask[1])
+    assert torch.equal(a.pts_semantic_mask[0], b.pts_semantic_mask[0]) and torch.equal(a.pts_semantic_mask[1], b.pts_semantic_mask[1])
