@@ -219,12 +219,13 @@ __global__ __launch_bounds__(256) void pair_fill_batch_kernel(const PLBatch b) {
         if (k == T.K - 1 && tid == 0) {                        // number of real tiles, after the last slot
             const int64_t end = (int64_t)seg + seg_len < T.p_cap ? (int64_t)seg + seg_len : T.p_cap;
             T.tile_k[T.p_cap / PT] = (int)(end / PT);
-            if (T.meta) { T.tile_k[T.p_cap / PT + 1] = 0; T.tile_k[T.p_cap / PT + 2] = 0; }
+            if (T.meta & 1) { T.tile_k[T.p_cap / PT + 1] = 0; T.tile_k[T.p_cap / PT + 2] = 0; }
         }
     }
-    if (k == T.K - 1) {
+    if (k == T.K - 1 && !(T.meta & 2)) {
         // past the last segment: unused capacity reads as "no pair".  Every row block of the last offset fills its slice
-        // (with worst-case sized lists, SD3D_EXACT_PAIRS=0, the tail is tens of MB: one workgroup would sit on the critical path)
+        // (with worst-case sized lists, SD3D_EXACT_PAIRS=0, the tail is tens of MB: one workgroup would sit on the critical path;
+        //  meta & 2: the caller's consumers walk tile_k[p_cap / 128] tiles and nothing else - the tail stays unwritten)
         const int64_t end = (int64_t)seg + seg_len < T.p_cap ? (int64_t)seg + seg_len : T.p_cap;
         for (int64_t e = end + (int64_t)blk * 256 + tid; e < T.p_cap; e += (int64_t)T.nblk * 256) {
             T.in_idx[e] = -1;
@@ -260,7 +261,7 @@ __global__ __launch_bounds__(256) void pair_fill_batch_kernel(const PLBatch b) {
     for (int i = 0; i < NS; ++i) {
         const int64_t row = row0 + i * 64;
         const int p = base + __popcll(bal[i] & lt);
-        if (row < T.M) T.pos[(int64_t)k * T.M + row] = (id[i] >= 0 && p < T.p_cap) ? p : -1;
+        if (T.pos && row < T.M) T.pos[(int64_t)k * T.M + row] = (id[i] >= 0 && p < T.p_cap) ? p : -1;
         if (id[i] >= 0 && p < T.p_cap) {
             T.in_idx[p] = id[i];
             if (T.out_idx) T.out_idx[p] = (int32_t)row;
@@ -292,6 +293,107 @@ __global__ __launch_bounds__(RL_ROWS) void pair_rowlist_batch_kernel(const PLBat
             if (v[u] >= 0) rl[1 + cnt++] = v[u];
     }
     rl[0] = cnt;
+}
+
+// ---- plain lists without a position table (round 5) -------------------------------------------------------------------------------
+// An evaluation forward never reads pos [K, M]: pass 2 walks the per-row lists.  For the stem's 5^3 table pos is 69 MB written by the
+// fill launch and read back by the row-list launch (and the lists' unused capacity, sized for the worst case when one scene is in
+// flight, another 55 MB of -1).  When the caller asks for row lists but no pos (pos == NULL), the builder takes the row-block form
+// of the chained builder: a workgroup owns 256 rows and walks all K offsets of them, the fill launch writes the rows' lists itself.
+// Same in_idx / tile_k / rlist as the (offset, row block) form, entry for entry.
+#define PR_MAX_K 128
+template <class F>
+__device__ __forceinline__ void pr_walk(const PLTable& T, int64_t row, bool live, F&& f) {
+    const int64_t rc = live ? row : 0;
+    for (int k0 = 0; k0 < T.K; k0 += 8) {
+        int id[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) id[u] = T.nbr[(int64_t)(k0 + u < T.K ? k0 + u : T.K - 1) * T.M + rc];
+#pragma unroll
+        for (int u = 0; u < 8; ++u)
+            if (k0 + u < T.K) f(k0 + u, live ? id[u] : -1);
+    }
+}
+__global__ __launch_bounds__(256) void pair_count_rows_kernel(const PLBatch b) {
+    __shared__ int wc[4][PR_MAX_K];
+    const int ti = pl_find_table(b, blockIdx.x, 0);
+    const PLTable& T = b.t[ti];
+    const int blk = blockIdx.x - T.wg0, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int64_t row = (int64_t)blk * 256 + tid;
+    pr_walk(T, row, row < T.M, [&](int k, int id) {
+        const int c = __popcll(__ballot(id >= 0));
+        if (lane == 0) wc[wv][k] = c;
+    });
+    __syncthreads();
+    if (tid < T.K) T.blk_cnt[(int64_t)tid * T.nblk + blk] = wc[0][tid] + wc[1][tid] + wc[2][tid] + wc[3][tid];
+}
+__global__ __launch_bounds__(256) void pair_fill_rows_kernel(const PLBatch b) {
+    __shared__ int sm[4];
+    __shared__ int wb[4][PR_MAX_K];
+    __shared__ int seg[PR_MAX_K + 1], tot[PR_MAX_K];
+    const int ti = pl_find_table(b, blockIdx.x, 0);
+    const PLTable& T = b.t[ti];
+    const int blk = blockIdx.x - T.wg0, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int64_t row = (int64_t)blk * 256 + tid;
+    const bool live = row < T.M;
+    {   // first list position of every offset's segment = the padded totals before it
+        const int t = tid < T.K ? T.totals[tid] : 0;
+        int end;
+        const int ex = block_excl_scan_256p((t + PT - 1) / PT * PT, &end, sm);
+        if (tid < T.K) { seg[tid] = ex; tot[tid] = t; }
+        if (tid == 0) seg[T.K] = end;
+    }
+    pr_walk(T, row, live, [&](int k, int id) {
+        const int c = __popcll(__ballot(id >= 0));
+        if (lane == 0) wb[wv][k] = c;
+    });
+    __syncthreads();
+    if (tid < T.K) {
+        int run = T.blk_cnt[(int64_t)tid * T.nblk + blk];
+#pragma unroll
+        for (int w = 0; w < 4; ++w) { const int c = wb[w][tid]; wb[w][tid] = run; run += c; }
+    }
+    __syncthreads();
+    for (int k = blk; k < T.K; k += T.nblk) {                      // tile headers and the -1 padding of the segments, dealt out to the row blocks
+        const int seg_len = (tot[k] + PT - 1) / PT * PT;
+        for (int t = tid; t < seg_len / PT; t += 256)
+            if ((int64_t)(seg[k] / PT + t) * PT < T.p_cap) T.tile_k[seg[k] / PT + t] = k;
+        for (int e = tot[k] + tid; e < seg_len; e += 256)
+            if ((int64_t)seg[k] + e < T.p_cap) {
+                T.in_idx[seg[k] + e] = -1;
+                if (T.out_idx) T.out_idx[seg[k] + e] = -1;
+            }
+    }
+    {
+        const int64_t end = (int64_t)seg[T.K] < T.p_cap ? (int64_t)seg[T.K] : T.p_cap;
+        if (blk == 0 && tid == 0) {
+            T.tile_k[T.p_cap / PT] = (int)(end / PT);
+            if (T.meta & 1) { T.tile_k[T.p_cap / PT + 1] = 0; T.tile_k[T.p_cap / PT + 2] = 0; }
+        }
+        if (!(T.meta & 2)) {
+            for (int64_t e = end + (int64_t)blk * 256 + tid; e < T.p_cap; e += (int64_t)T.nblk * 256) {
+                T.in_idx[e] = -1;
+                if (T.out_idx) T.out_idx[e] = -1;
+            }
+            for (int64_t t = end / PT + (int64_t)blk * 256 + tid; t < T.p_cap / PT; t += (int64_t)T.nblk * 256) T.tile_k[t] = -1;
+        }
+    }
+    const uint64_t lt = (1ull << lane) - 1ull;
+    int32_t* rl = T.rlist ? T.rlist + (live ? row : 0) * T.rl_stride : nullptr;
+    int cnt = 0;
+    pr_walk(T, row, live, [&](int k, int id) {
+        const uint64_t bal = __ballot(id >= 0);
+        if (id >= 0) {
+            const int p = seg[k] + wb[wv][k] + __popcll(bal & lt);
+            if (p < T.p_cap) {
+                T.in_idx[p] = id;
+                if (T.out_idx) T.out_idx[p] = (int32_t)row;
+                if (rl) rl[1 + cnt] = p;
+            }
+            ++cnt;
+        }
+    });
+    if (live && rl) rl[0] = cnt;
 }
 
 // ---- chained lists: mirror offsets and the centre share ONE partial product ----------------------------------------------------
@@ -326,6 +428,7 @@ struct CHTable {
     int64_t M, p_cap;
     int K, G, nblk, rl_stride;
     int wg0, sg0;                  // first workgroup of the table in the row-block grid / the segment grid
+    int lean;                      // 1: the unused capacity behind the last segment stays unwritten (sd3d_pair_table_desc.meta & 2)
 };
 struct CHBatch { int n; CHTable t[PL_MAX_TABLES]; };
 __device__ __forceinline__ int ch_find(const CHBatch& b, int wg, int by) {
@@ -473,8 +576,10 @@ __global__ __launch_bounds__(256) void chain_fill_kernel(const CHBatch b) {
         // past the last segment: unused capacity reads as "no pair"; the number of real tiles after the last slot
         const int64_t cap_tiles = T.p_cap / PT;
         if (blk == 0 && tid == 0) { T.tile_k[cap_tiles] = (int)(end_tile < cap_tiles ? end_tile : cap_tiles); T.tile_k[cap_tiles + 1] = 0; T.tile_k[cap_tiles + 2] = 0; }
-        for (int64_t e = (int64_t)end_tile * PT + (int64_t)blk * 256 + tid; e < T.p_cap; e += (int64_t)T.nblk * 256) T.in_idx[e] = -1;
-        for (int64_t tt = end_tile + (int64_t)blk * 256 + tid; tt < cap_tiles; tt += (int64_t)T.nblk * 256) T.tile_k[tt] = -1;
+        if (!T.lean) {
+            for (int64_t e = (int64_t)end_tile * PT + (int64_t)blk * 256 + tid; e < T.p_cap; e += (int64_t)T.nblk * 256) T.in_idx[e] = -1;
+            for (int64_t tt = end_tile + (int64_t)blk * 256 + tid; tt < cap_tiles; tt += (int64_t)T.nblk * 256) T.tile_k[tt] = -1;
+        }
     }
     // the entries of this row, group by group, and its list of partial positions (the last sub-tile of each of its chains, ascending)
     const uint64_t lt = (1ull << lane) - 1ull;
@@ -602,6 +707,7 @@ __device__ __forceinline__ void pair_gemm_body(const PGParams& p, float (*Bs)[NT
     //  +12 % / +4 % on the level-1 32 -> 32 and level-2 64 -> 64 layers, -3 ... -5 % on the 96- ... 192-channel ones)
     const bool pool = p.pool_ctr != nullptr && nchunks >= 3 && n_real >= 6 * (int)gridDim.x;
     int n_static = n_real;
+    // (13/16 static and units of six steps: the best of a sweep over 11 - 14 sixteenths x 4 - 12 steps, profiles/r05_pool_sweep.txt)
     const int unit = (6 + nchunks - 1) / nchunks;
     if (pool) {
         n_static = (int)((int64_t)n_real * 13 / 16);
@@ -1126,8 +1232,10 @@ __global__ __launch_bounds__(256) void pair_reduce_rl_kernel(const PRLParams p) 
 size_t pair_lists_ws_bytes(int K, int64_t M) {
     const int64_t nblk = cdiv(M, PL_ROWS);
     const size_t plain = (size_t)((int64_t)K * nblk + K) * sizeof(int32_t) + 256;
-    const size_t chained = (K & 1) ? chain_lists_ws_bytes(K, M) : 0;      // (a table may be built either way: size for both)
-    return plain > chained ? plain : chained;
+    const size_t chained = (K & 1) ? chain_lists_ws_bytes(K, M) : 0;      // (a table may be built either way: size for all)
+    const size_t rows = (size_t)((int64_t)K * cdiv(M, 256) + K) * sizeof(int32_t) + 256;
+    const size_t m = plain > chained ? plain : chained;
+    return m > rows ? m : rows;
 }
 
 // p_cap: capacity of in_idx in pairs (multiple of 128, >= pairs + K * 127); tile_k has p_cap / 128 + 1 entries
@@ -1155,8 +1263,10 @@ int launch_pair_lists(const int32_t* nbr, int K, int64_t M, int64_t p_cap, int32
 int launch_pair_lists_desc(int n, const sd3d_pair_table_desc* d, void* ws, size_t ws_bytes, hipStream_t st) {
     if (n <= 0) return SD3D_OK;
     if (n > PL_MAX_TABLES) return sd3d_set_error(SD3D_ERR_ARG, "pair_lists_batch: at most 16 tables per call");
-    PLBatch b;
+    PLBatch b, rbt;                                            // (offset, row block) form / row-block form (no pos table)
     b.n = 0;
+    rbt.n = 0;
+    int rwg = 0, rkk = 0;
     CHBatch cb;
     cb.n = 0;
     size_t off = 0;
@@ -1178,18 +1288,33 @@ int launch_pair_lists_desc(int n, const sd3d_pair_table_desc* d, void* ws, size_
             T.blk_cnt = (int32_t*)((char*)ws + off);
             T.totals = T.blk_cnt + (int64_t)nseg * T.nblk;
             off += align_up(chain_lists_ws_bytes(K, M), 256);
-            T.wg0 = cwg; T.sg0 = csg;
+            T.wg0 = cwg; T.sg0 = csg; T.lean = (d[i].meta & 2) ? 1 : 0;
             cwg += T.nblk; csg += nseg;
             continue;
         }
         if (K <= 0 || M <= 0) {                                // no rows: a later pair_conv on this table must see "0 real tiles"
-            if (d[i].tile_k && p_cap > 0 && hipMemsetAsync(d[i].tile_k + p_cap / PT, 0, (d[i].meta ? 3 : 1) * sizeof(int32_t), st) != hipSuccess)
+            if (d[i].tile_k && p_cap > 0 && hipMemsetAsync(d[i].tile_k + p_cap / PT, 0, ((d[i].meta & 1) ? 3 : 1) * sizeof(int32_t), st) != hipSuccess)
                 return sd3d_set_error(SD3D_ERR_LAUNCH, "pair_lists_batch: memset failed");
             continue;
         }
         if (p_cap <= 0 || (p_cap % PT)) return sd3d_set_error(SD3D_ERR_ARG, "pair_lists_batch: p_cap must be a positive multiple of 128");
         if (d[i].rlist && (d[i].rl_stride < K + 4 || (d[i].rl_stride & 3))) return sd3d_set_error(SD3D_ERR_ARG, "pair_lists_batch: rl_stride must be a multiple of 4, >= K + 4");
         if (d[i].center >= 0) return sd3d_set_error(SD3D_ERR_ARG, "pair_lists_batch: center must be -1 or SD3D_PAIR_CHAINED");
+        if (!d[i].pos && !d[i].rlist && !d[i].out_idx)
+            return sd3d_set_error(SD3D_ERR_ARG, "pair_lists_batch: a table without pos needs rlist or out_idx (nothing could run pass 2 on it)");
+        if (!d[i].pos && K <= PR_MAX_K) {                      // no position table wanted: the row-block form (three launches, the rows' lists from the fill)
+            PLTable& T = rbt.t[rbt.n++];
+            T.nbr = d[i].nbr; T.pos = nullptr; T.in_idx = d[i].in_idx; T.tile_k = d[i].tile_k; T.M = M; T.p_cap = p_cap; T.K = K;
+            T.rlist = d[i].rlist; T.out_idx = d[i].out_idx; T.rl_stride = d[i].rl_stride; T.meta = d[i].meta;
+            T.nblk = (int)cdiv(M, 256);
+            T.blk_cnt = (int32_t*)((char*)ws + off);
+            T.totals = T.blk_cnt + (int64_t)T.K * T.nblk;
+            off += align_up(pair_lists_ws_bytes(K, M), 256);
+            T.wg0 = rwg; T.k0 = rkk; T.rb0 = 0;
+            rwg += T.nblk; rkk += T.K;
+            continue;
+        }
+        if (!d[i].pos && d[i].rlist) return sd3d_set_error(SD3D_ERR_ARG, "pair_lists_batch: row lists without pos take kernels up to 128 offsets");
         PLTable& T = b.t[b.n++];
         T.nbr = d[i].nbr; T.pos = d[i].pos; T.in_idx = d[i].in_idx; T.tile_k = d[i].tile_k; T.M = M; T.p_cap = p_cap; T.K = K;
         T.rlist = d[i].rlist; T.out_idx = d[i].out_idx; T.rl_stride = d[i].rl_stride; T.meta = d[i].meta;
@@ -1206,6 +1331,12 @@ int launch_pair_lists_desc(int n, const sd3d_pair_table_desc* d, void* ws, size_
         hipLaunchKernelGGL(chain_count_kernel, dim3(cwg), dim3(256), 0, st, cb);
         hipLaunchKernelGGL(chain_scan_kernel, dim3(csg), dim3(256), 0, st, cb);
         hipLaunchKernelGGL(chain_fill_kernel, dim3(cwg), dim3(256), 0, st, cb);
+        SD3D_CHECK_LAUNCH();
+    }
+    if (rbt.n > 0) {
+        hipLaunchKernelGGL(pair_count_rows_kernel, dim3(rwg), dim3(256), 0, st, rbt);
+        hipLaunchKernelGGL(pair_scan_batch_kernel, dim3(rkk), dim3(256), 0, st, rbt);
+        hipLaunchKernelGGL(pair_fill_rows_kernel, dim3(rwg), dim3(256), 0, st, rbt);
         SD3D_CHECK_LAUNCH();
     }
     if (b.n == 0) return SD3D_OK;

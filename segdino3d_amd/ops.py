@@ -706,7 +706,7 @@ PAIR_CHAINED = -2          # SD3D_PAIR_CHAINED: `center` value of a chained tabl
 
 
 def pair_lists_batch(tables):
-    """tables: list of (nbr int32 [K, M], n_pairs[, center[, direct]]) -> list of PairLists, built by ONE launch set
+    """tables: list of (nbr int32 [K, M], n_pairs[, center[, direct[, lean]]]) -> list of PairLists, built by ONE launch set
     (csrc/pair_gemm.hip: count, scan, fill, per-row lists).  center = PAIR_CHAINED: chained lists (a stride-1 table of a voxel set
     onto itself, odd symmetric kernel): the entries of a row's mirror groups and its centre share partial products."""
     global _PAIR_DESC_DT
@@ -727,6 +727,7 @@ def pair_lists_batch(tables):
             nbr, n_pairs = t[0], t[1]
             center = int(t[2]) if len(t) > 2 else -1
             direct = bool(t[3]) if len(t) > 3 else False
+            lean = bool(t[4]) if len(t) > 4 else False            # evaluation: no [K, M] position table, the unused capacity stays unwritten
             K, M = nbr.shape
             chained = center == PAIR_CHAINED
             if chained:
@@ -736,16 +737,17 @@ def pair_lists_batch(tables):
                 pos = torch.empty(0, dtype=torch.int32, device=dev)       # (a chained table has no [K, M] position table: its rows' partial positions are `rlist`)
             else:
                 p_cap = (int(n_pairs) + 127 * K + 127) // 128 * 128
-                pos = torch.empty(K, M, dtype=torch.int32, device=dev)
+                lean = lean and K <= 128
+                pos = None if lean else torch.empty(K, M, dtype=torch.int32, device=dev)
             in_idx = torch.empty(p_cap, dtype=torch.int32, device=dev)
             tile_k = torch.empty(p_cap // 128 + 3, dtype=torch.int32, device=dev)     # [p_cap / 128]: number of real tiles, then the centre run
             # per-row list {count, partial positions}: K entries at most - K / 2 + 1 (mirror groups + the lone centre) for a chained table
             rl_stride = ((K // 2 + 2) + 3) // 4 * 4 if chained else (K + 4 + 3) // 4 * 4
             rlist = None if direct else torch.empty(M, rl_stride, dtype=torch.int32, device=dev)
             out_idx = torch.empty(p_cap, dtype=torch.int32, device=dev) if direct else None
-            desc[i] = (_ptr(nbr, torch.int32, "nbr"), pos.data_ptr(), in_idx.data_ptr(), tile_k.data_ptr(),
+            desc[i] = (_ptr(nbr, torch.int32, "nbr"), 0 if pos is None else pos.data_ptr(), in_idx.data_ptr(), tile_k.data_ptr(),
                        0 if rlist is None else rlist.data_ptr(), 0 if out_idx is None else out_idx.data_ptr(), M, p_cap, K, center,
-                       rl_stride, 1)
+                       rl_stride, 3 if lean else 1)
             nb += (lib.sd3d_pair_lists_ws_bytes(K, M) + 255) // 256 * 256
             res.append(PairLists(pos, in_idx, tile_k, p_cap, K, M, rlist=rlist, rl_stride=rl_stride, center=center, out_idx=out_idx,
                                  direct=direct))
@@ -782,7 +784,7 @@ def pair_conv(x, wt, pairs, x2=None, scale=None, shift=None, res=None, act=None,
     if hook is not None:
         hook.before(dict(K=K, Cin=Cin, Cout=Cout, M=M, nbr=None, pairs=pairs))
     _lib.check(lib.sd3d_pair_conv_ex(p0, ld0, C0, p1, ld1, pairs.in_idx.data_ptr(), pairs.tile_k.data_ptr(), pairs.p_cap,
-                                     pairs.pos.data_ptr(), None if pairs.rlist is None else pairs.rlist.data_ptr(), pairs.rl_stride,
+                                     None if pairs.pos is None else pairs.pos.data_ptr(), None if pairs.rlist is None else pairs.rlist.data_ptr(), pairs.rl_stride,
                                      pairs.center, pairs.out_idx.data_ptr() if pairs.direct else None,
                                      _ptr(wt, torch.float32, "wt"), K, Cin, Cout, M,
                                      _ptr(scale, torch.float32, "scale"), _ptr(shift, torch.float32, "shift"), pr, ldr, po, ldo,

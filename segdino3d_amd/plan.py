@@ -168,7 +168,7 @@ class LayerPlan:
                 if pl is None:
                     complete = False
                     continue
-                tabs[i] = (pl.in_idx.data_ptr(), pl.tile_k.data_ptr(), pl.pos.data_ptr(), pl.p_cap, pl.M, pl.K, 0,
+                tabs[i] = (pl.in_idx.data_ptr(), pl.tile_k.data_ptr(), 0 if pl.pos is None else pl.pos.data_ptr(), pl.p_cap, pl.M, pl.K, 0,
                            0 if pl.rlist is None else pl.rlist.data_ptr(), pl.out_idx.data_ptr() if pl.direct else 0, pl.rl_stride, pl.center)
                 ev = pending.get(key)
                 evs[i] = 0 if ev is None else ev.cuda_event

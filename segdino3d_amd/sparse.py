@@ -147,6 +147,8 @@ OPTIMISTIC_SORT = os.environ.get("SD3D_OPTIMISTIC_SORT", "1") != "0"
 # SD3D_LEVELS_AT_ONCE=0: the coarser levels of a scene by one run-length unique per level (four launches each) instead of all of them
 # from the level-0 keys in four launches (`sd3d_unique_levels`; MinkowskiEngine semantics only - spconv's extent clip keeps the per-level path)
 LEVELS_AT_ONCE = os.environ.get("SD3D_LEVELS_AT_ONCE", "1") != "0"
+# SD3D_LEAN_LISTS=0: evaluation tables with their [K, M] position table and -1-filled unused capacity (rounds 1 - 4)
+LEAN_LISTS = os.environ.get("SD3D_LEAN_LISTS", "1") != "0"
 MORTON_BITS = 48               # SD3D_MORTON_BITS (csrc/common.h): the Z-order code of a voxel; a batch's scene index sits above it
 # SD3D_VOXELISE_ONE_CALL=0: the voxelisation chain of a scene as ~10 Python calls (the round 1 - 4 path; the clipped / per-level variants keep it)
 VOXELISE_ONE_CALL = os.environ.get("SD3D_VOXELISE_ONE_CALL", "1") != "0"
@@ -367,6 +369,9 @@ class SceneMaps:
             # no read-back: size the pair lists for the worst case (every offset of every voxel has a neighbour).  The
             # kernels walk the REAL tile count, which the list builder leaves on the device; only allocations grow.
             host = [k ** 3 * self.n_vox[lvl] for (lvl, k) in same]
+        # evaluation (`chained`): nothing reads a [K, M] position table or the lists' unused capacity - pass 2 walks per-row lists, pass 1 the
+        # real tiles (csrc/pair_gemm.hip, "plain lists without a position table"); training keeps both (pair_out_rows, the weight gradient)
+        lean = bool(chained) and LEAN_LISTS
         todo = []                                               # (key, nbr, pairs): all rulebooks of the scene in one launch set
         for (lvl, k), c in zip(same, host):
             self.density[("same", lvl, k)] = (c / max(1, k ** 3 * self.n_vox[lvl])) if exact else None
@@ -375,17 +380,17 @@ class SceneMaps:
                     center = ops.PAIR_CHAINED                    # mirror groups + centre share partial products (evaluation)
                 else:
                     center = -1
-                todo.append((("same", lvl, k), self._same[(lvl, k)], c, center, False))
+                todo.append((("same", lvl, k), self._same[(lvl, k)], c, center, False, lean))
         for lvl in strides:
             # every fine voxel has exactly one parent: P = V_fine pairs in both directions
             self.density[("down", lvl)] = self.n_vox[lvl] / max(1, 8 * self.n_vox[lvl + 1])
             self.density[("up", lvl)] = 1.0 / 8.0
             if ops.PAIR_CONV and ("down", lvl) not in self.pairs:
                 dn, up = self._stride_maps(lvl)
-                todo.append((("down", lvl), dn, self.n_vox[lvl], -1, False))
+                todo.append((("down", lvl), dn, self.n_vox[lvl], -1, False, lean))
                 # transposed convolution: every fine voxel has exactly one parent - one pair per output row.  (Not with spconv's
                 # output-extent clip: fine voxels whose parent was dropped have NO pair and must still receive shift / activation.)
-                todo.append((("up", lvl), up, self.n_vox[lvl], -1, not self.clipped))
+                todo.append((("up", lvl), up, self.n_vox[lvl], -1, not self.clipped, lean and not self.clipped))
         if todo:
             for t, pl in zip(todo, ops.pair_lists_batch([t[1:] for t in todo])):
                 self.pairs[t[0]] = pl

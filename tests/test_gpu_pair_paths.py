@@ -251,3 +251,34 @@ def test_chained_lists_edge_cases():
         ref = _ref64(x, w, nbr, None, None, None, None)
         assert ((got.double() - ref).abs() / ref.abs().amax(dim=1, keepdim=True).clamp_min(1e-3)).max().item() < 2e-6
         assert int(ch.rlist[:, 0].min()) >= 1                       # every row has at least its centre
+
+
+@pytest.mark.parametrize("which", ["same5", "same3", "down", "up", "chained"])
+def test_lean_tables_equal_the_full_tables(scene_maps, which):
+    """`ops.pair_lists(..., lean=True)` (round 5: the evaluation forward's tables - no [K, M] position table, built by the row-block
+    kernels, the unused capacity behind the last tile left unwritten): in_idx / tile_k over the real tiles, the tile count, the
+    per-row lists and out_idx are those of the full builder, entry for entry, and a convolution on them gives the same bits."""
+    from segdino3d_amd import ops
+    maps = scene_maps
+    nbr, direct, center = {"same5": (maps.same(0, 5), False, -1), "same3": (maps.same(3, 3), False, -1), "down": (maps.down(1), False, -1),
+                           "up": (maps.up(1), True, -1), "chained": (maps.same(1, 3), False, ops.PAIR_CHAINED)}[which]
+    K, M = nbr.shape
+    P = int((nbr >= 0).sum())
+    full, lean = ops.pair_lists_batch([(nbr, K * M, center, direct, False), (nbr, K * M, center, direct, True)])   # worst-case capacity: a long unused tail
+    assert lean.pos is None or which == "chained"
+    nt = int(full.tile_k[full.p_cap // 128])
+    assert nt == int(lean.tile_k[lean.p_cap // 128]) and full.p_cap == lean.p_cap
+    assert full.tile_k[-3:].tolist() == lean.tile_k[-3:].tolist()
+    assert torch.equal(full.tile_k[:nt], lean.tile_k[:nt]) and torch.equal(full.in_idx[: nt * 128], lean.in_idx[: nt * 128])
+    if direct:
+        assert torch.equal(full.out_idx[: nt * 128], lean.out_idx[: nt * 128])
+    else:
+        cnt = full.rlist[:, 0]
+        assert torch.equal(cnt, lean.rlist[:, 0])
+        live = torch.arange(full.rlist.shape[1] - 1, device=nbr.device)[None] < cnt[:, None]
+        assert torch.equal(full.rlist[:, 1:][live], lean.rlist[:, 1:][live])
+    g = torch.Generator().manual_seed(5)
+    cin, cout = 32, 32
+    x = torch.randn(int(nbr.max()) + 1, cin, generator=g).to(nbr.device)
+    w = (torch.randn(K, cout, cin, generator=g) * 0.1).to(nbr.device)
+    assert torch.equal(ops.pair_conv(x, w, full), ops.pair_conv(x, w, lean))

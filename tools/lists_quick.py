@@ -37,12 +37,14 @@ def all_maps():
 print(f"all kernel maps of the scene (sd3d_kernel_maps_hier): {timed(all_maps):8.1f} us")
 nbr3, nbr5, strides = all_maps()
 worst = lambda t: t.shape[0] * t.shape[1]
-chained = [(nbr3[l], worst(nbr3[l]), ops.PAIR_CHAINED, False) for l in range(3)]
-plain3 = [(nbr3[l], worst(nbr3[l]), -1, False) for l in (3, 4)]
-stem = [(nbr5, worst(nbr5), -1, False)]
+LEAN = os.environ.get("LISTS_LEAN", "1") != "0"          # the evaluation forward's tables: no position table, unused capacity unwritten
+chained = [(nbr3[l], worst(nbr3[l]), ops.PAIR_CHAINED, False, LEAN) for l in range(3)]
+plain3 = [(nbr3[l], worst(nbr3[l]), -1, False, LEAN) for l in (3, 4)]
+stem = [(nbr5, worst(nbr5), -1, False, LEAN)]
 updown = []
 for l, (dn, up) in enumerate(strides):
-    updown += [(dn, maps.n_vox[l], -1, False), (up, maps.n_vox[l], -1, True)]
+    updown += [(dn, maps.n_vox[l], -1, False, LEAN), (up, maps.n_vox[l], -1, True, LEAN)]
+print("lean tables" if LEAN else "tables with position table and filled capacity (training; rounds 1 - 4)")
 print(f"chained lists of levels 0-2 (3 launches):              {timed(lambda: ops.pair_lists_batch(chained)):8.1f} us")
 print(f"stem 5^3 list (4 launches):                            {timed(lambda: ops.pair_lists_batch(stem)):8.1f} us")
 print(f"plain 3^3 lists of levels 3-4 + 8 stride-2 lists:      {timed(lambda: ops.pair_lists_batch(plain3 + updown)):8.1f} us")

@@ -35,7 +35,7 @@ for key, cin, cout in cases:
     K, M = nbr.shape
     n_in = int(nbr.max().item()) + 1
     x = torch.randn(n_in, cin, generator=g).to(d); w = (torch.randn(K, cout, cin, generator=g) * (K * cin) ** -0.5).to(d)
-    P = int((nbr >= 0).sum()) if pairs.center == ops.PAIR_CHAINED else int((pairs.in_idx >= 0).sum())
+    P = int((nbr >= 0).sum())
     t = timeit(lambda: ops.pair_conv(x, w, pairs), 5)
     line = f"M={M} P={P} tiles={pairs.p_cap // 128} | {t:.0f} us | {2.0 * P * cin * cout / t / 1e6:.1f} TF/s active"
     if os.environ.get("PAIR_MODES") == "1":      # the same convolution on the other paths: per-row lists over ALL offsets, pos-based pass 2
