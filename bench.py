@@ -416,10 +416,20 @@ def main():
     conv_ms = conv_flops = conv_bytes = conv_n = 0      # the sparse convolutions alone (sd3d_pair_conv: pass 1 + pass 2)
     for e0_, e1_, meta in timer.records:
         nbr = meta["nbr"]
-        if meta.get("pairs") is not None:              # pair-major convolution: count the real list entries
-            nbr = meta["pairs"].in_idx
+        if meta.get("pairs") is not None:              # pair-major convolution: count the real list entries (the REAL tiles: an evaluation
+            pl = meta["pairs"]                          # table's capacity behind them is unwritten memory, segdino3d_amd/sparse.py LEAN_LISTS)
+            key = (pl.in_idx.data_ptr(), pl.p_cap)
+            if key not in pair_cache:
+                n_real = int(pl.tile_k[pl.p_cap // 128].item())
+                pair_cache[key] = int((pl.in_idx[: n_real * 128] >= 0).sum().item())
+            nbr = pl.in_idx.new_empty(0)
+            nbr_key = key
+        else:
+            nbr_key = None
         if nbr is None:
             P = meta["M"]
+        elif nbr_key is not None:
+            P = pair_cache[nbr_key]
         else:
             key = (nbr.data_ptr(), tuple(nbr.shape))
             if key not in pair_cache:

@@ -266,8 +266,14 @@ int sd3d_pair_conv(const float* in0, int ld0, int C0, const float* in1, int ld1,
  *                          >= K + 4.  Pass 2 walks a row's own partial products instead of the K slots of pos[k][r].
  *   center                 -1 (plain lists) or SD3D_PAIR_CHAINED (below).  (Round 3 also took an offset number here - a dense
  *                          kernel for the centre offset of a stride-1 table; it measured slower and left the library, see
- *                          profiles/EXPERIMENTS.md.  A value >= 0 is refused with SD3D_ERR_ARG.)  meta = 1: tile_k has
- *                          p_cap / 128 + 3 entries (two reserved slots, written as zero, behind the tile count).
+ *                          profiles/EXPERIMENTS.md.  A value >= 0 is refused with SD3D_ERR_ARG.)
+ *   meta                   bit 0: tile_k has p_cap / 128 + 3 entries (two reserved slots, written as zero, behind the tile count);
+ *                          bit 1: the capacity behind the last real tile (in_idx, out_idx, tile_k) is left UNWRITTEN - for callers
+ *                          whose consumers walk tile_k[p_cap / 128] tiles and nothing else (sd3d_pair_conv_ex / sd3d_run_layers do);
+ *                          with worst-case capacities that tail is tens of MB per table.
+ *   pos == NULL            (round 5) no position table: needs rlist or out_idx, K <= 128.  The builder then takes the row-block form
+ *                          (a workgroup owns 256 rows and walks all offsets; three launches; the per-row lists come out of the fill
+ *                          launch).  What an evaluation forward uses: the stem's [125, V] table alone is 69 MB written and read back.
  *   out_idx [p_cap]        output row of every list entry (-1 on padding).  Handing it to the convolution promises ONE pair per
  *                          output row - the transposed k2s2 convolutions (minkunet.py:165-192 `conv_tr`: every fine voxel has one
  *                          parent) - and pass 1 writes act(scale * product + shift + res) to the row directly: no pass 2. */
