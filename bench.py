@@ -457,7 +457,10 @@ def main():
     workload_key = {"points": args.points, "superpoints": args.superpoints, "queries_2d": args.query2d, "scene_layout": args.scene_layout,
                     "forward_sizes": sorted({len(f) for st_plan in plan for f in st_plan})}
     traffic_fwd, traffic_src = load_pmc_traffic(workload_key)
-    roofline = {"bound": "mfma",
+    suspect = conv_tf > FP32_MFMA_PEAK_TFLOPS or fam_tf > FP32_MFMA_PEAK_TFLOPS
+    if suspect:   # more flops than the matrix pipe can issue: the accounting, not the GPU (e.g. list entries counted beyond the real tiles)
+        print(f"bench.py: roofline accounting is off: {conv_tf:.1f} / {fam_tf:.1f} TFLOP/s exceed the fp32 matrix peak", file=sys.stderr)
+    roofline = {"bound": "mfma", **({"accounting_suspect": True} if suspect else {}),
                 "kernel": "sd3d_pair_conv_ex = pair_gemm_* (pass 1, fp32 MFMA over the offset-major rulebook) + pair_reduce_rl_kernel (pass 2 over per-row lists; "
                           "none for the transposed convolutions): the 55 sparse convolutions of Res16UNet34C",
                 "achieved": round(conv_tf, 2), "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
