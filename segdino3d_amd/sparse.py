@@ -141,7 +141,10 @@ PAIR_CHAIN = os.environ.get("SD3D_PAIR_CHAIN", "1") != "0"
 # with ONE scene in flight (worst-case list sizes, no second read-back) only the stem's table is; the other levels' hash tables,
 # kernel maps and pair lists are built on a side stream while the stem and the first blocks convolve, each table's first layer
 # waits for its event (sd3d_run_layers_ev).  Same kernels on the same data: bit-identical outputs.
-FORK_JOIN = os.environ.get("SD3D_FORK_JOIN", "1") != "0"
+# Round 5: OFF by default.  The fork bought 0.2 ms when a scene's maps and lists cost 0.96 ms of kernels; alone on the GPU they now take 0.24 ms
+# (hierarchical maps, row-block list builders, lean tables), and three cross-stream hand-offs cost the host about what the overlap still
+# wins: same-process A/B 10.565 - 10.570 ms without the fork against 10.582 - 10.584 with it (profiles/EXPERIMENTS.md).  SD3D_FORK_JOIN=1 restores it.
+FORK_JOIN = os.environ.get("SD3D_FORK_JOIN", "0") != "0"
 # SD3D_OPTIMISTIC_SORT=0: a scene's voxel keys / superpoint ids are always sorted over all their bits (7 + 4 radix passes instead of 4 + 2)
 OPTIMISTIC_SORT = os.environ.get("SD3D_OPTIMISTIC_SORT", "1") != "0"
 # SD3D_LEVELS_AT_ONCE=0: the coarser levels of a scene by one run-length unique per level (four launches each) instead of all of them
