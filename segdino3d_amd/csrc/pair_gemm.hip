@@ -178,11 +178,11 @@ __global__ __launch_bounds__(256) void pair_count_batch_kernel(const PLBatch b) 
     if (tid == 0) T.blk_cnt[(int64_t)k * T.nblk + blk] = sm[0] + sm[1] + sm[2] + sm[3];
 }
 
-__global__ __launch_bounds__(256) void pair_scan_batch_kernel(const PLBatch b) {
+__device__ __forceinline__ void pair_scan_batch_body(const PLBatch& b, const int bx) {
     __shared__ int sm[4];
-    const int ti = pl_find_table(b, blockIdx.x, 1);
+    const int ti = pl_find_table(b, bx, 1);
     const PLTable& T = b.t[ti];
-    const int k = blockIdx.x - T.k0, tid = threadIdx.x;
+    const int k = bx - T.k0, tid = threadIdx.x;
     int running = 0;
     for (int base = 0; base < T.nblk; base += 256) {
         const int i = base + tid;
@@ -194,6 +194,7 @@ __global__ __launch_bounds__(256) void pair_scan_batch_kernel(const PLBatch b) {
     }
     if (tid == 0) T.totals[k] = running;
 }
+__global__ __launch_bounds__(256) void pair_scan_batch_kernel(const PLBatch b) { pair_scan_batch_body(b, (int)blockIdx.x); }
 
 __global__ __launch_bounds__(256) void pair_fill_batch_kernel(const PLBatch b) {
     __shared__ int sm[4];
@@ -314,11 +315,11 @@ __device__ __forceinline__ void pr_walk(const PLTable& T, int64_t row, bool live
             if (k0 + u < T.K) f(k0 + u, live ? id[u] : -1);
     }
 }
-__global__ __launch_bounds__(256) void pair_count_rows_kernel(const PLBatch b) {
+__device__ __forceinline__ void pair_count_rows_body(const PLBatch& b, const int bx) {
     __shared__ int wc[4][PR_MAX_K];
-    const int ti = pl_find_table(b, blockIdx.x, 0);
+    const int ti = pl_find_table(b, bx, 0);
     const PLTable& T = b.t[ti];
-    const int blk = blockIdx.x - T.wg0, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int blk = bx - T.wg0, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int64_t row = (int64_t)blk * 256 + tid;
     pr_walk(T, row, row < T.M, [&](int k, int id) {
         const int c = __popcll(__ballot(id >= 0));
@@ -327,13 +328,14 @@ __global__ __launch_bounds__(256) void pair_count_rows_kernel(const PLBatch b) {
     __syncthreads();
     if (tid < T.K) T.blk_cnt[(int64_t)tid * T.nblk + blk] = wc[0][tid] + wc[1][tid] + wc[2][tid] + wc[3][tid];
 }
-__global__ __launch_bounds__(256) void pair_fill_rows_kernel(const PLBatch b) {
+__global__ __launch_bounds__(256) void pair_count_rows_kernel(const PLBatch b) { pair_count_rows_body(b, (int)blockIdx.x); }
+__device__ __forceinline__ void pair_fill_rows_body(const PLBatch& b, const int bx) {
     __shared__ int sm[4];
     __shared__ int wb[4][PR_MAX_K];
     __shared__ int seg[PR_MAX_K + 1], tot[PR_MAX_K];
-    const int ti = pl_find_table(b, blockIdx.x, 0);
+    const int ti = pl_find_table(b, bx, 0);
     const PLTable& T = b.t[ti];
-    const int blk = blockIdx.x - T.wg0, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int blk = bx - T.wg0, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int64_t row = (int64_t)blk * 256 + tid;
     const bool live = row < T.M;
     {   // first list position of every offset's segment = the padded totals before it
@@ -395,6 +397,7 @@ __global__ __launch_bounds__(256) void pair_fill_rows_kernel(const PLBatch b) {
     });
     if (live && rl) rl[0] = cnt;
 }
+__global__ __launch_bounds__(256) void pair_fill_rows_kernel(const PLBatch b) { pair_fill_rows_body(b, (int)blockIdx.x); }
 
 // ---- chained lists: mirror offsets and the centre share ONE partial product ----------------------------------------------------
 // A stride-1 table of a voxel set onto itself with an odd kernel (3^3) enumerates its offsets symmetrically: off[K-1-k] == -off[k],
@@ -469,11 +472,11 @@ __device__ __forceinline__ bool ch_walk(const CHTable& T, int64_t row, bool live
     return seen;
 }
 
-__global__ __launch_bounds__(256) void chain_count_kernel(const CHBatch b) {
+__device__ __forceinline__ void chain_count_body(const CHBatch& b, const int bx) {
     __shared__ int wc[4][CH_MAX_SEG];
-    const int ti = ch_find(b, blockIdx.x, 0);
+    const int ti = ch_find(b, bx, 0);
     const CHTable& T = b.t[ti];
-    const int blk = blockIdx.x - T.wg0, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int blk = bx - T.wg0, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int64_t row = (int64_t)blk * CH_ROWS + tid;
     const bool live = row < T.M;
     const bool seen = ch_walk(T, row, live, [&](int g, int pat, int, int) {
@@ -491,11 +494,12 @@ __global__ __launch_bounds__(256) void chain_count_kernel(const CHBatch b) {
     const int nseg = T.G * CH_NPAT + 1;
     for (int sg = tid; sg < nseg; sg += 256) T.blk_cnt[(int64_t)sg * T.nblk + blk] = wc[0][sg] + wc[1][sg] + wc[2][sg] + wc[3][sg];
 }
-__global__ __launch_bounds__(256) void chain_scan_kernel(const CHBatch b) {
+__global__ __launch_bounds__(256) void chain_count_kernel(const CHBatch b) { chain_count_body(b, (int)blockIdx.x); }
+__device__ __forceinline__ void chain_scan_body(const CHBatch& b, const int bx) {
     __shared__ int sm[4];
-    const int ti = ch_find(b, blockIdx.x, 1);
+    const int ti = ch_find(b, bx, 1);
     const CHTable& T = b.t[ti];
-    const int seg = blockIdx.x - T.sg0, tid = threadIdx.x;
+    const int seg = bx - T.sg0, tid = threadIdx.x;
     int running = 0;
     for (int base = 0; base < T.nblk; base += 256) {
         const int i = base + tid;
@@ -507,13 +511,14 @@ __global__ __launch_bounds__(256) void chain_scan_kernel(const CHBatch b) {
     }
     if (tid == 0) T.totals[seg] = running;
 }
-__global__ __launch_bounds__(256) void chain_fill_kernel(const CHBatch b) {
+__global__ __launch_bounds__(256) void chain_scan_kernel(const CHBatch b) { chain_scan_body(b, (int)blockIdx.x); }
+__device__ __forceinline__ void chain_fill_body(const CHBatch& b, const int bx) {
     __shared__ int sm[4];
     __shared__ int wb[4][CH_MAX_SEG];          // per wave: entries of the segment in this wave, then its first position in the segment
     __shared__ int seg_tile[CH_MAX_SEG], seg_tot[CH_MAX_SEG];
-    const int ti = ch_find(b, blockIdx.x, 0);
+    const int ti = ch_find(b, bx, 0);
     const CHTable& T = b.t[ti];
-    const int blk = blockIdx.x - T.wg0, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int blk = bx - T.wg0, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int nseg = T.G * CH_NPAT + 1, centre = T.K / 2;
     const int64_t row = (int64_t)blk * CH_ROWS + tid;
     const bool live = row < T.M;
@@ -617,6 +622,22 @@ __global__ __launch_bounds__(256) void chain_fill_kernel(const CHBatch b) {
         }
     }
     if (live) rl[0] = cnt;
+}
+__global__ __launch_bounds__(256) void chain_fill_kernel(const CHBatch b) { chain_fill_body(b, (int)blockIdx.x); }
+// The chained tables and the position-free plain tables of a scene in the SAME three launches (count, scan, fill): two independent
+// chains of three dependent launches on one stream were six launch latencies in front of the first convolution.  A workgroup below
+// `n_chain` runs the chained builder's body, the others the row-block builder's - the same code on the same data.
+__global__ __launch_bounds__(256) void lists_count_kernel(const CHBatch cb, const PLBatch rb, const int n_chain) {
+    if ((int)blockIdx.x < n_chain) chain_count_body(cb, (int)blockIdx.x);
+    else pair_count_rows_body(rb, (int)blockIdx.x - n_chain);
+}
+__global__ __launch_bounds__(256) void lists_scan_kernel(const CHBatch cb, const PLBatch rb, const int n_chain) {
+    if ((int)blockIdx.x < n_chain) chain_scan_body(cb, (int)blockIdx.x);
+    else pair_scan_batch_body(rb, (int)blockIdx.x - n_chain);
+}
+__global__ __launch_bounds__(256) void lists_fill_kernel(const CHBatch cb, const PLBatch rb, const int n_chain) {
+    if ((int)blockIdx.x < n_chain) chain_fill_body(cb, (int)blockIdx.x);
+    else pair_fill_rows_body(rb, (int)blockIdx.x - n_chain);
 }
 size_t chain_lists_ws_bytes(int K, int64_t M) {
     const int64_t nblk = cdiv(M, CH_ROWS);
@@ -1327,13 +1348,17 @@ int launch_pair_lists_desc(int n, const sd3d_pair_table_desc* d, void* ws, size_
         rb += T.rlist ? (int)cdiv(M, RL_ROWS) : 0;
     }
     if (off > ws_bytes) return sd3d_set_error(SD3D_ERR_ARG, "pair_lists_batch: workspace too small");
-    if (cb.n > 0) {
+    if (cb.n > 0 && rbt.n > 0) {
+        hipLaunchKernelGGL(lists_count_kernel, dim3(cwg + rwg), dim3(256), 0, st, cb, rbt, cwg);
+        hipLaunchKernelGGL(lists_scan_kernel, dim3(csg + rkk), dim3(256), 0, st, cb, rbt, csg);
+        hipLaunchKernelGGL(lists_fill_kernel, dim3(cwg + rwg), dim3(256), 0, st, cb, rbt, cwg);
+        SD3D_CHECK_LAUNCH();
+    } else if (cb.n > 0) {
         hipLaunchKernelGGL(chain_count_kernel, dim3(cwg), dim3(256), 0, st, cb);
         hipLaunchKernelGGL(chain_scan_kernel, dim3(csg), dim3(256), 0, st, cb);
         hipLaunchKernelGGL(chain_fill_kernel, dim3(cwg), dim3(256), 0, st, cb);
         SD3D_CHECK_LAUNCH();
-    }
-    if (rbt.n > 0) {
+    } else if (rbt.n > 0) {
         hipLaunchKernelGGL(pair_count_rows_kernel, dim3(rwg), dim3(256), 0, st, rbt);
         hipLaunchKernelGGL(pair_scan_batch_kernel, dim3(rkk), dim3(256), 0, st, rbt);
         hipLaunchKernelGGL(pair_fill_rows_kernel, dim3(rwg), dim3(256), 0, st, rbt);
