@@ -458,10 +458,10 @@ int launch_kernel_map(const uint64_t* okeys, int64_t n_out, const uint64_t* tkey
 // (a few thousand rows) is searched directly: binary search of the encoded neighbour key in its sorted keys.
 // Same table as kernel_map_kernel (MinkowskiEngine kernel map, minkunet.py:146-162), entry for entry.
 // ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void kmap_top_kernel(const uint64_t* __restrict__ keys, int64_t n, const int8_t* __restrict__ offs, int K,
-                                                       int32_t* __restrict__ nbr, int32_t* __restrict__ pair_count) {
+__device__ __forceinline__ void kmap_top_body(const uint64_t* __restrict__ keys, int64_t n, const int8_t* __restrict__ offs, int K,
+                                              int32_t* __restrict__ nbr, int32_t* __restrict__ pair_count, const int bx) {
     __shared__ int wsum[4];
-    const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int64_t t = (int64_t)bx * 256 + threadIdx.x;
     int id = -1;
     if (t < (int64_t)K * n) {
         const int k = (int)(t / n);
@@ -487,7 +487,7 @@ __global__ __launch_bounds__(256) void kmap_top_kernel(const uint64_t* __restric
         __syncthreads();
         if (threadIdx.x == 0) {
             const int tot = wsum[0] + wsum[1] + wsum[2] + wsum[3];
-            if (tot) atomicAdd(&pair_count[blockIdx.x & 63], tot);
+            if (tot) atomicAdd(&pair_count[bx & 63], tot);
         }
     }
 }
@@ -496,10 +496,10 @@ __global__ __launch_bounds__(256) void kmap_top_kernel(const uint64_t* __restric
 // The same launch writes the level pair's stride-2 maps (launch_stride_maps' tables, entry for entry) when asked to: every fine voxel
 // its column of nbr_up [8, n_fine] (its parent in the row of its own kernel offset, -1 in the other seven), every first child the
 // column of its parent in nbr_down [8, n_coarse] - each entry written by the thread that owns it, nothing to pre-fill.
-__global__ __launch_bounds__(256) void child_info_kernel(const uint64_t* __restrict__ fkeys, const int32_t* __restrict__ parent, int64_t n_fine,
-                                                         int64_t n_coarse, int2* __restrict__ cinfo, const int32_t* __restrict__ perm8,
-                                                         int32_t* __restrict__ nbr_down, int32_t* __restrict__ nbr_up) {
-    const int64_t j = (int64_t)blockIdx.x * 256 + threadIdx.x;
+__device__ __forceinline__ void child_info_body(const uint64_t* __restrict__ fkeys, const int32_t* __restrict__ parent, int64_t n_fine,
+                                                int64_t n_coarse, int2* __restrict__ cinfo, const int32_t* __restrict__ perm8,
+                                                int32_t* __restrict__ nbr_down, int32_t* __restrict__ nbr_up, const int bx) {
+    const int64_t j = (int64_t)bx * 256 + threadIdx.x;
     if (j >= n_fine) return;
     const int p = parent[j];
     if (nbr_up) {
@@ -520,6 +520,23 @@ __global__ __launch_bounds__(256) void child_info_kernel(const uint64_t* __restr
     }
 }
 
+// Everything of the hierarchy that needs no map of another level, in ONE launch (round 5; before: one launch for the coarsest level's
+// map and one child-info launch per level pair, each in the chain of dependent launches in front of the first convolution): the
+// coarsest level's 3^3 map by binary search and the child records / stride-2 maps of EVERY level pair.
+struct KRoots {
+    const uint64_t* top_keys; int64_t top_n; const int8_t* offs3; int32_t* top_nbr; int32_t* top_count; int top_blocks;
+    int n_pairs;                                                      // level pairs (fine level l = 0 .. n_pairs - 1)
+    const uint64_t* fkeys[7]; const int32_t* parent[7]; int64_t n_fine[7], n_coarse[7]; int2* cinfo[7];
+    const int32_t* perm8; int32_t* nbr_down[7]; int32_t* nbr_up[7]; int blk0[8];          // blk0[l]: first workgroup of pair l behind the top's
+};
+__global__ __launch_bounds__(256) void kmap_roots_kernel(const KRoots R) {
+    const int bx = (int)blockIdx.x;
+    if (bx < R.top_blocks) { kmap_top_body(R.top_keys, R.top_n, R.offs3, 27, R.top_nbr, R.top_count, bx); return; }
+    int l = 0;
+    for (int i = 1; i < R.n_pairs; ++i) if (bx >= R.blk0[i]) l = i;
+    child_info_body(R.fkeys[l], R.parent[l], R.n_fine[l], R.n_coarse[l], R.cinfo[l], R.perm8, R.nbr_down[l], R.nbr_up[l], bx - R.blk0[l]);
+}
+
 #define KH_UNROLL 4                 // offsets per thread: their loads are all requested before the first is used
 struct KHParams {
     const uint64_t* keys; const int32_t* parent; int64_t n;          // this level: keys, parent row of every voxel
@@ -528,11 +545,20 @@ struct KHParams {
     const int8_t* offs; int K;                                        // this table's offsets (|d| <= 2)
     int8_t inv27[27];                                                 // (pdx + 1) + 3 (pdy + 1) + 9 (pdz + 1) -> offset index of the parent level's 3^3 map
     int32_t* nbr; int32_t* pair_count;
+    // a second table of the SAME level in the same launch (the finest level's 5^3 map next to its 3^3 map): y-blocks >= y_split
+    const int8_t* offs_b; int K_b; int32_t* nbr_b; int32_t* pair_count_b; int y_split;
 };
 __global__ __launch_bounds__(256) void kmap_hier_kernel(const KHParams P) {
     __shared__ int wsum[4];
+    // (the table of this y-block: selected field by field - a modified COPY of the argument struct would move inv27[] to scratch)
+    const bool second = P.nbr_b != nullptr && (int)blockIdx.y >= P.y_split;
+    const int by = second ? (int)blockIdx.y - P.y_split : (int)blockIdx.y;
+    const int8_t* __restrict__ t_offs = second ? P.offs_b : P.offs;
+    const int t_K = second ? P.K_b : P.K;
+    int32_t* __restrict__ t_nbr = second ? P.nbr_b : P.nbr;
+    int32_t* __restrict__ t_count = second ? P.pair_count_b : P.pair_count;
     const int64_t v = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    const int k0 = blockIdx.y * KH_UNROLL;
+    const int k0 = by * KH_UNROLL;
     int found = 0;
     if (v < P.n) {
         const int bits = (int)(P.keys[v] & 7ull);                     // Morton bit 0 = x, 1 = y, 2 = z
@@ -540,8 +566,8 @@ __global__ __launch_bounds__(256) void kmap_hier_kernel(const KHParams P) {
         int q[KH_UNROLL], cb[KH_UNROLL];
 #pragma unroll
         for (int u = 0; u < KH_UNROLL; ++u) {
-            const int k = k0 + u < P.K ? k0 + u : P.K - 1;
-            const int sx = (bits & 1) + P.offs[k * 3 + 0], sy = ((bits >> 1) & 1) + P.offs[k * 3 + 1], sz = ((bits >> 2) & 1) + P.offs[k * 3 + 2];
+            const int k = k0 + u < t_K ? k0 + u : t_K - 1;
+            const int sx = (bits & 1) + t_offs[k * 3 + 0], sy = ((bits >> 1) & 1) + t_offs[k * 3 + 1], sz = ((bits >> 2) & 1) + t_offs[k * 3 + 2];
             const int pd = ((sx >> 1) + 1) + 3 * ((sy >> 1) + 1) + 9 * ((sz >> 1) + 1);     // arithmetic shift = floor
             cb[u] = (sx & 1) | ((sy & 1) << 1) | ((sz & 1) << 2);
             q[u] = pd == 13 ? par : P.nbr3p[(int64_t)P.inv27[pd] * P.np + par];
@@ -551,14 +577,14 @@ __global__ __launch_bounds__(256) void kmap_hier_kernel(const KHParams P) {
         for (int u = 0; u < KH_UNROLL; ++u) ci[u] = q[u] >= 0 ? P.cinfo[q[u]] : make_int2(0, 0);
 #pragma unroll
         for (int u = 0; u < KH_UNROLL; ++u) {
-            if (k0 + u < P.K) {
+            if (k0 + u < t_K) {
                 const int hit = (ci[u].y >> cb[u]) & 1;
-                P.nbr[(int64_t)(k0 + u) * P.n + v] = hit ? ci[u].x + __popc((unsigned)ci[u].y & ((1u << cb[u]) - 1u)) : -1;
+                t_nbr[(int64_t)(k0 + u) * P.n + v] = hit ? ci[u].x + __popc((unsigned)ci[u].y & ((1u << cb[u]) - 1u)) : -1;
                 found += hit;
             }
         }
     }
-    if (P.pair_count) {
+    if (t_count) {
         int c = found;
 #pragma unroll
         for (int d = 32; d >= 1; d >>= 1) c += __shfl_xor(c, d);
@@ -566,7 +592,7 @@ __global__ __launch_bounds__(256) void kmap_hier_kernel(const KHParams P) {
         __syncthreads();
         if (threadIdx.x == 0) {
             const int tot = wsum[0] + wsum[1] + wsum[2] + wsum[3];
-            if (tot) atomicAdd(&P.pair_count[(blockIdx.x + blockIdx.y) & 63], tot);
+            if (tot) atomicAdd(&t_count[(blockIdx.x + by) & 63], tot);
         }
     }
 }
@@ -591,20 +617,35 @@ int launch_kernel_maps_hier(int n_levels, const uint64_t* const* keys, const int
     size_t off = 0;
     for (int l = 1; l < n_levels; ++l) { cinfo[l] = (int2*)((char*)ws + off); off += align_up((size_t)n[l] * sizeof(int2), 256); }
     const int top = n_levels - 1;
-    hipLaunchKernelGGL(kmap_top_kernel, dim3((unsigned)cdiv(27 * n[top], 256)), dim3(256), 0, st, keys[top], n[top], offs3, 27, nbr3[top],
-                       pair_counts ? pair_counts + 64 * top : nullptr);
+    {
+        KRoots R;
+        R.top_keys = keys[top]; R.top_n = n[top]; R.offs3 = offs3; R.top_nbr = nbr3[top]; R.top_count = pair_counts ? pair_counts + 64 * top : nullptr;
+        R.top_blocks = (int)cdiv(27 * n[top], 256);
+        R.n_pairs = top; R.perm8 = perm8;
+        int blocks = R.top_blocks;
+        for (int l = 0; l < 7; ++l) {
+            const bool live = l < top;
+            R.fkeys[l] = live ? keys[l] : nullptr; R.parent[l] = live ? parent[l] : nullptr;
+            R.n_fine[l] = live ? n[l] : 0; R.n_coarse[l] = live ? n[l + 1] : 0; R.cinfo[l] = live ? cinfo[l + 1] : nullptr;
+            R.nbr_down[l] = live && perm8 && nbr_down ? nbr_down[l] : nullptr; R.nbr_up[l] = live && perm8 && nbr_up ? nbr_up[l] : nullptr;
+            R.blk0[l] = blocks;
+            if (live) blocks += (int)cdiv(n[l], 256);
+        }
+        R.blk0[7] = blocks;
+        hipLaunchKernelGGL(kmap_roots_kernel, dim3((unsigned)blocks), dim3(256), 0, st, R);
+    }
     for (int l = top - 1; l >= 0; --l) {
-        hipLaunchKernelGGL(child_info_kernel, dim3((unsigned)cdiv(n[l], 256)), dim3(256), 0, st, keys[l], parent[l], n[l], n[l + 1], cinfo[l + 1],
-                           perm8, perm8 && nbr_down ? nbr_down[l] : nullptr, perm8 && nbr_up ? nbr_up[l] : nullptr);
         KHParams P;
         P.keys = keys[l]; P.parent = parent[l]; P.n = n[l]; P.nbr3p = nbr3[l + 1]; P.np = n[l + 1]; P.cinfo = cinfo[l + 1];
         for (int i = 0; i < 27; ++i) P.inv27[i] = inv27[i];
-        if (l == 0 && nbr5) {                                  // the stem's table first: the first convolution of the U-Net waits for it
-            P.offs = offs5; P.K = 125; P.nbr = nbr5; P.pair_count = pair_counts ? pair_counts + 64 * n_levels : nullptr;
-            hipLaunchKernelGGL(kmap_hier_kernel, dim3((unsigned)cdiv(n[l], 256), (unsigned)cdiv(125, KH_UNROLL)), dim3(256), 0, st, P);
-        }
         P.offs = offs3; P.K = 27; P.nbr = nbr3[l]; P.pair_count = pair_counts ? pair_counts + 64 * l : nullptr;
-        hipLaunchKernelGGL(kmap_hier_kernel, dim3((unsigned)cdiv(n[l], 256), (unsigned)cdiv(27, KH_UNROLL)), dim3(256), 0, st, P);
+        P.offs_b = nullptr; P.K_b = 0; P.nbr_b = nullptr; P.pair_count_b = nullptr; P.y_split = (int)cdiv(27, KH_UNROLL);
+        unsigned gy = (unsigned)P.y_split;
+        if (l == 0 && nbr5) {                                  // the stem's 5^3 table rides in the finest level's launch
+            P.offs_b = offs5; P.K_b = 125; P.nbr_b = nbr5; P.pair_count_b = pair_counts ? pair_counts + 64 * n_levels : nullptr;
+            gy += (unsigned)cdiv(125, KH_UNROLL);
+        }
+        hipLaunchKernelGGL(kmap_hier_kernel, dim3((unsigned)cdiv(n[l], 256), gy), dim3(256), 0, st, P);
     }
     SD3D_CHECK_LAUNCH();
     return SD3D_OK;
