@@ -20,7 +20,7 @@ int launch_f32_to_sortkey(const float*, int64_t, int, uint64_t*, hipStream_t);
 int launch_i64_to_sortkey(const int64_t*, int64_t, uint64_t*, hipStream_t);
 int launch_i64_to_sortkey_checked(const int64_t*, int64_t, uint64_t*, int, int32_t*, int, hipStream_t);
 int launch_i64_to_sortkey_checked_max(const int64_t*, int64_t, uint64_t*, int, int32_t*, int, int32_t*, hipStream_t, uint64_t);
-int launch_scene_stats(const float*, int, int64_t, float*, void*, size_t, hipStream_t);
+int launch_scene_stats(const float*, int, int64_t, float*, void*, size_t, hipStream_t, int32_t*, int);
 int launch_pack_mask_rows(const uint8_t*, int64_t, const int32_t*, int, uint8_t*, int64_t, hipStream_t);
 int launch_row_chain(const sd3d_rc_program*, hipStream_t);
 size_t unique_ws_bytes(int64_t);
@@ -29,6 +29,8 @@ int launch_unique_sorted(const uint64_t*, const uint32_t*, int64_t, const int*, 
 int launch_hash_build(const uint64_t*, int64_t, uint64_t*, int32_t*, int64_t, hipStream_t);
 size_t unique_levels_ws_bytes(int64_t, int);
 int launch_unique_levels(const uint64_t*, int64_t, const int*, int, uint64_t* const*, int32_t* const*, int32_t*, void*, size_t, hipStream_t);
+int launch_voxel_levels_all(const uint64_t*, const uint32_t*, int64_t, int, uint64_t* const*, int32_t*, int32_t*, int32_t* const*, int32_t*, void*, size_t,
+                            hipStream_t);
 int launch_kernel_map(const uint64_t*, int64_t, const uint64_t*, const int32_t*, int64_t, const int8_t*, int, int, int32_t*, int32_t*, hipStream_t);
 int launch_stride_maps(const uint64_t*, const int32_t*, int64_t, int64_t, const int32_t*, int32_t*, int32_t*, hipStream_t);
 int launch_voxel_mean(const float*, int, const float*, int, int, const float*, int64_t, const uint32_t*, const int32_t*, int64_t,
@@ -167,7 +169,7 @@ int sd3d_keys_from_i64_offset_checked_max(const int64_t* x, int64_t n, int64_t a
 
 size_t sd3d_scene_stats_ws_bytes(void) { return 256 * 9 * sizeof(float); }
 int sd3d_scene_stats(const float* points, int ld, int64_t n, float* stats, void* ws, size_t ws_bytes, void* stream) {
-    return launch_scene_stats(points, ld, n, stats, ws, ws_bytes, ST);
+    return launch_scene_stats(points, ld, n, stats, ws, ws_bytes, ST, nullptr, 0);
 }
 int sd3d_voxel_keys(const float* points, int ld, int64_t n, float inv_voxel, const float* stats, int shift_to_min,
                     int batch_index, int32_t* origin, uint64_t* keys, int32_t* icoords, int32_t* err_flag, void* stream) {
@@ -188,7 +190,7 @@ int sd3d_unique_levels(const uint64_t* keys, int64_t n_cap, const int32_t* n_dev
 size_t sd3d_voxelise_scene_ws_bytes(int64_t n, int n_levels) {
     n = n > 0 ? n : 1;
     size_t b = sd3d_scene_stats_ws_bytes();
-    const size_t c[3] = {sort_ws_bytes(n), unique_ws_bytes(n), n_levels > 1 ? unique_levels_ws_bytes(n, n_levels - 1) : 0};
+    const size_t c[3] = {sort_ws_bytes(n), unique_ws_bytes(n), unique_levels_ws_bytes(n, n_levels > 1 ? n_levels : 1)};
     for (size_t v : c) b = v > b ? v : b;
     return b;
 }
@@ -196,14 +198,13 @@ int sd3d_voxelise_scene(const sd3d_voxelise_desc* d, int* sorted_in_a, void* str
     if (!d || !sorted_in_a || !d->points || !d->stats || !d->origin || !d->keys_a || !d->keys_b || !d->vals_a || !d->vals_b || !d->ukeys0 ||
         !d->seg_start || !d->inverse || !d->readback || !d->ws)
         return sd3d_set_error(SD3D_ERR_ARG, "voxelise_scene: null pointer");
-    if (d->n <= 0 || d->n_levels < 1 || d->n_levels > 9 || (d->n_levels > 1 && (!d->ukeys || !d->parents)) || d->key_bits < 8 || d->key_bits > 64)
-        return sd3d_set_error(SD3D_ERR_ARG, "voxelise_scene: n > 0, 1..9 levels, 8..64 key bits");
+    if (d->n <= 0 || d->n_levels < 1 || d->n_levels > 8 || (d->n_levels > 1 && (!d->ukeys || !d->parents)) || d->key_bits < 8 || d->key_bits > 64)
+        return sd3d_set_error(SD3D_ERR_ARG, "voxelise_scene: n > 0, 1..8 levels, 8..64 key bits");
     if (d->ws_bytes < sd3d_voxelise_scene_ws_bytes(d->n, d->n_levels)) return sd3d_set_error(SD3D_ERR_ARG, "voxelise_scene: workspace too small");
     if (d->superpoints && !d->sp_keys) return sd3d_set_error(SD3D_ERR_ARG, "voxelise_scene: superpoints without sp_keys");
     hipStream_t st = (hipStream_t)stream;
     const int L = d->n_levels;
-    if (hipMemsetAsync(d->readback, 0, (size_t)(L + 2) * sizeof(int32_t), st) != hipSuccess) return sd3d_set_error(SD3D_ERR_LAUNCH, "voxelise_scene: memset failed");
-    int rc = launch_scene_stats(d->points, d->ld, d->n, d->stats, d->ws, d->ws_bytes, st);
+    int rc = launch_scene_stats(d->points, d->ld, d->n, d->stats, d->ws, d->ws_bytes, st, d->readback, L + 2);     // (zeroes the read-back array too)
     if (rc) return rc;
     rc = launch_voxel_keys(d->points, d->ld, d->n, d->inv_voxel, d->stats, d->shift_to_min, 0, d->origin, d->keys_a, d->icoords, d->readback + L, st);
     if (rc) return rc;
@@ -213,10 +214,11 @@ int sd3d_voxelise_scene(const sd3d_voxelise_desc* d, int* sorted_in_a, void* str
     *sorted_in_a = landed;
     const uint64_t* skeys = landed ? d->keys_a : d->keys_b;
     const uint32_t* sidx = landed ? d->vals_a : d->vals_b;
-    rc = launch_unique_sorted(skeys, sidx, d->n, nullptr, 0, d->ukeys0, d->seg_start, d->inverse, d->readback, d->ws, d->ws_bytes, nullptr, 0.f, 0, 0, st);
-    if (rc) return rc;
-    if (L > 1) {
-        rc = launch_unique_levels(d->ukeys0, d->n, d->readback, L - 1, d->ukeys, d->parents, d->readback + 1, d->ws, d->ws_bytes, st);
+    {   // every level from the sorted point keys in four launches (level 0 and the coarser levels used to be four each)
+        uint64_t* uk[9];
+        uk[0] = d->ukeys0;
+        for (int l = 1; l < L; ++l) uk[l] = d->ukeys[l - 1];
+        rc = launch_voxel_levels_all(skeys, sidx, d->n, L, uk, d->seg_start, d->inverse, d->parents, d->readback, d->ws, d->ws_bytes, st);
         if (rc) return rc;
     }
     if (d->superpoints) {

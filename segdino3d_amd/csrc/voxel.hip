@@ -63,7 +63,9 @@ __global__ __launch_bounds__(256) void scene_stats_partial(const float* __restri
 }
 // one wave per statistic: lanes stride over the per-block partials, then a butterfly (fixed order; nine threads walking all the
 // partials one after the other took 39 us)
-__global__ __launch_bounds__(576) void scene_stats_final(const float* __restrict__ part, int nb, float* __restrict__ stats) {
+__global__ __launch_bounds__(576) void scene_stats_final(const float* __restrict__ part, int nb, float* __restrict__ stats, int32_t* __restrict__ zero,
+                                                         int n_zero) {
+    if ((int)threadIdx.x < n_zero) zero[threadIdx.x] = 0;      // (the counters of the launches behind this one: saves their memset launch)
     const int c = threadIdx.x >> 6, lane = threadIdx.x & 63;
     float r = c < 3 ? INFINITY : (c < 6 ? -INFINITY : 0.f);
     for (int b = lane; b < nb; b += 64) {
@@ -74,12 +76,13 @@ __global__ __launch_bounds__(576) void scene_stats_final(const float* __restrict
     if (lane == 0) stats[c] = r;
 }
 
-int launch_scene_stats(const float* pts, int ld, int64_t n, float* stats, void* ws, size_t ws_bytes, hipStream_t st) {
+int launch_scene_stats(const float* pts, int ld, int64_t n, float* stats, void* ws, size_t ws_bytes, hipStream_t st, int32_t* zero, int n_zero) {
+    if (n_zero < 0 || n_zero > 576 || (n_zero > 0 && !zero)) return sd3d_set_error(SD3D_ERR_ARG, "scene_stats: at most 576 counters to zero");
     if (n <= 0) return sd3d_set_error(SD3D_ERR_ARG, "scene_stats: empty scene");
     if (ws_bytes < STAT_BLOCKS * 9 * sizeof(float)) return sd3d_set_error(SD3D_ERR_WS, "scene_stats workspace");
     const int nb = (int)min((int64_t)STAT_BLOCKS, cdiv(n, 256));
     hipLaunchKernelGGL(scene_stats_partial, dim3(nb), dim3(256), 0, st, pts, ld, n, (float*)ws);
-    hipLaunchKernelGGL(scene_stats_final, dim3(1), dim3(576), 0, st, (const float*)ws, nb, stats);
+    hipLaunchKernelGGL(scene_stats_final, dim3(1), dim3(576), 0, st, (const float*)ws, nb, stats, zero, n_zero);
     SD3D_CHECK_LAUNCH();
     return SD3D_OK;
 }
@@ -300,6 +303,65 @@ int launch_unique_levels(const uint64_t* keys, int64_t n_cap, const int* n_dev, 
     SD3D_CHECK_LAUNCH();
     return SD3D_OK;
 }
+
+// ---------------------------------------------------------------------------------------------
+// Round 5: EVERY level of a scene - the level-0 unique (keys, segment starts, point -> voxel map) and all coarser levels (keys, parents) -
+// from the sorted POINT keys in four launches (mark, two scan launches, emit) instead of four for level 0 plus four for the rest: a
+// run boundary of (Morton >> 3 l) over the sorted point keys is a run boundary over the unique keys of any finer level, so the
+// arrays are those of launch_unique_sorted(shift 0) followed by launch_unique_levels, entry for entry.  No extent clip.
+// ---------------------------------------------------------------------------------------------
+struct VLParams {
+    const uint64_t* keys; const uint32_t* src_idx; int64_t n; int nl;                   // sorted point keys, their points; nl levels (level 0 included)
+    uint64_t* ukeys[UL_MAX + 1]; int32_t* parent[UL_MAX]; int32_t* seg_start; int32_t* map; int32_t* counts;
+};
+__global__ __launch_bounds__(256) void mark_all_levels(const VLParams P, int* __restrict__ flags) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int l = blockIdx.y;
+    if (i >= P.n) return;
+    flags[(int64_t)l * P.n + i] = (i == 0) || level_key(P.keys[i], 3 * l) != level_key(P.keys[i - 1], 3 * l);
+}
+__global__ __launch_bounds__(256) void emit_all_levels(const VLParams P, const int* __restrict__ flags, const int* __restrict__ excl) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int l = blockIdx.y;
+    if (i >= P.n) return;
+    const int64_t row = (int64_t)l * P.n;
+    const int f = flags[row + i];
+    const int id = excl[row + i] - excl[row] + f - 1;          // (the scan ran over all rows back to back: subtract the row's base)
+    if (f) P.ukeys[l][id] = level_key(P.keys[i], 3 * l);
+    if (l == 0) {
+        if (f) P.seg_start[id] = (int32_t)i;
+        P.map[P.src_idx ? (int64_t)P.src_idx[i] : i] = id;
+        if (i == P.n - 1) P.seg_start[id + 1] = (int32_t)P.n;
+    } else {
+        const int64_t prow = row - P.n;
+        if (flags[prow + i]) P.parent[l - 1][excl[prow + i] - excl[prow]] = id;      // written by the first point of the finer voxel
+    }
+    if (i == P.n - 1) P.counts[l] = id + 1;
+}
+int launch_voxel_levels_all(const uint64_t* keys, const uint32_t* src_idx, int64_t n, int n_levels, uint64_t* const* ukeys, int32_t* seg_start,
+                            int32_t* map, int32_t* const* parents, int32_t* counts, void* ws, size_t ws_bytes, hipStream_t st) {
+    if (n <= 0 || n_levels < 1 || n_levels > UL_MAX + 1) return sd3d_set_error(SD3D_ERR_ARG, "voxel_levels_all: n > 0 and 1..8 levels");
+    if (!keys || !ukeys || !seg_start || !map || !counts || (n_levels > 1 && !parents)) return sd3d_set_error(SD3D_ERR_ARG, "voxel_levels_all: null pointer");
+    if (ws_bytes < unique_levels_ws_bytes(n, n_levels)) return sd3d_set_error(SD3D_ERR_WS, "voxel_levels_all workspace too small");
+    VLParams P;
+    P.keys = keys; P.src_idx = src_idx; P.n = n; P.nl = n_levels; P.seg_start = seg_start; P.map = map; P.counts = counts;
+    for (int l = 0; l <= UL_MAX; ++l) P.ukeys[l] = l < n_levels ? ukeys[l] : nullptr;
+    for (int l = 0; l < UL_MAX; ++l) P.parent[l] = l + 1 < n_levels ? parents[l] : nullptr;
+    const int64_t tot = n * n_levels;
+    const size_t a = align_up((size_t)tot * sizeof(int), 256);
+    int* flags = (int*)ws;
+    int* excl = (int*)((char*)ws + a);
+    int* total = (int*)((char*)ws + 2 * a);
+    void* sws = (char*)ws + 2 * a + 256;
+    const dim3 grid((unsigned)cdiv(n, 256), (unsigned)n_levels);
+    hipLaunchKernelGGL(mark_all_levels, grid, dim3(256), 0, st, P, flags);
+    const int rc = scan_exclusive_i32(flags, excl, tot, nullptr, total, sws, ws_bytes - 2 * a - 256, st);
+    if (rc) return rc;
+    hipLaunchKernelGGL(emit_all_levels, grid, dim3(256), 0, st, P, (const int*)flags, (const int*)excl);
+    SD3D_CHECK_LAUNCH();
+    return SD3D_OK;
+}
+
 
 // ---------------------------------------------------------------------------------------------
 // hash table (keys u64, values i32), capacity = power of two, EMPTY = all ones
