@@ -126,6 +126,12 @@ typedef struct sd3d_voxelise_desc {
 } sd3d_voxelise_desc;
 size_t sd3d_voxelise_scene_ws_bytes(int64_t n, int n_levels);
 int sd3d_voxelise_scene(const sd3d_voxelise_desc* d, int* sorted_in_a, void* stream);
+/* sd3d_unique_sorted(shift 0, seg_start, map) + sd3d_unique_levels in ONE set of four launches, from the sorted POINT keys: ukeys[l] [<= n]
+ * (l = 0 .. n_levels - 1, level 0 included), seg_start [<= n + 1], map[src_idx ? src_idx[j] : j] = level-0 id, parents[l] [<= n] (l < n_levels - 1:
+ * level-(l + 1) id of every level-l voxel), counts[l] = voxels of level l.  1 <= n_levels <= 8, no extent clip; entry for entry the arrays of the
+ * two separate calls.  Workspace: sd3d_unique_levels_ws_bytes(n, n_levels). */
+int sd3d_voxel_levels_all(const uint64_t* sorted_keys, const uint32_t* src_idx, int64_t n, int n_levels, uint64_t* const* ukeys, int32_t* seg_start,
+                          int32_t* map, int32_t* const* parents, int32_t* counts, void* ws, size_t ws_bytes, void* stream);
 /* Open-addressing hash table key -> voxel id; capacity = power of two > n. */
 int sd3d_hash_build(const uint64_t* ukeys, int64_t n, uint64_t* table_keys, int32_t* table_vals, int64_t capacity,
                     void* stream);

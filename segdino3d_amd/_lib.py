@@ -38,6 +38,7 @@ SIGNATURES = {
     "sd3d_keys_from_i64_checked": (_i, [_p, _l, _p, _i, _p, _i, _p]),
     "sd3d_keys_from_i64_checked_max": (_i, [_p, _l, _p, _i, _p, _i, _p, _p]),
     "sd3d_keys_from_i64_offset_checked_max": (_i, [_p, _l, _l, _p, _i, _p, _i, _p, _p]),
+    "sd3d_voxel_levels_all": (_i, [_p, _p, _l, _i, _p, _p, _p, _p, _p, _p, _z, _p]),
     "sd3d_voxelise_scene_ws_bytes": (_z, [_l, _i]),
     "sd3d_voxelise_scene": (_i, [_p, _p, _p]),
     "sd3d_scene_stats_ws_bytes": (_z, []),

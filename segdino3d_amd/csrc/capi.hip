@@ -187,6 +187,10 @@ int sd3d_unique_levels(const uint64_t* keys, int64_t n_cap, const int32_t* n_dev
                        int32_t* counts, void* ws, size_t ws_bytes, void* stream) {
     return launch_unique_levels(keys, n_cap, n_dev, n_extra, ukeys, parents, counts, ws, ws_bytes, ST);
 }
+int sd3d_voxel_levels_all(const uint64_t* sorted_keys, const uint32_t* src_idx, int64_t n, int n_levels, uint64_t* const* ukeys, int32_t* seg_start,
+                          int32_t* map, int32_t* const* parents, int32_t* counts, void* ws, size_t ws_bytes, void* stream) {
+    return launch_voxel_levels_all(sorted_keys, src_idx, n, n_levels, ukeys, seg_start, map, parents, counts, ws, ws_bytes, ST);
+}
 size_t sd3d_voxelise_scene_ws_bytes(int64_t n, int n_levels) {
     n = n > 0 ? n : 1;
     size_t b = sd3d_scene_stats_ws_bytes();

@@ -369,6 +369,25 @@ def unique_levels(keys0: torch.Tensor, n_cap: int, n0_dev: torch.Tensor, n_extra
     return [uk[l] for l in range(n_extra)], [par[l] for l in range(n_extra)], counts
 
 
+def voxel_levels_all(skeys, sidx, n_levels: int, counts_out):
+    """Every level of a (batch of) scene(s) from its sorted point keys in four launches (`sd3d_voxel_levels_all`): what
+    `unique_sorted(skeys, sidx, N, None, 0, want_seg_start=True, want_map=True)` followed by `unique_levels` returns -
+    (ukeys [L x [N]], seg_start [N + 1], inverse [N], parents [(L - 1) x [N]]); counts_out int32 [L] receives the voxels per level."""
+    lib = _lib.load()
+    N, dev, L = skeys.numel(), skeys.device, int(n_levels)
+    uk = torch.empty(L, N, dtype=torch.int64, device=dev)
+    par = torch.empty(max(1, L - 1), N, dtype=torch.int32, device=dev)
+    seg = torch.empty(N + 1, dtype=torch.int32, device=dev)
+    inv = torch.empty(N, dtype=torch.int32, device=dev)
+    ws = _WS.get(lib.sd3d_unique_levels_ws_bytes(N, L), dev)
+    up = (ctypes.c_void_p * L)(*[uk.data_ptr() + 8 * N * l for l in range(L)])
+    pp = (ctypes.c_void_p * max(1, L - 1))(*[par.data_ptr() + 4 * N * l for l in range(L - 1)])
+    _lib.check(lib.sd3d_voxel_levels_all(_ptr(skeys, torch.int64, "skeys"), _ptr(sidx, torch.int32, "sidx"), N, L, ctypes.addressof(up), _ptr(seg),
+                                         _ptr(inv), ctypes.addressof(pp), _ptr(counts_out, torch.int32, "counts_out"), ws.data_ptr(), ws.numel(),
+                                         _stream()), "voxel_levels_all")
+    return [uk[l] for l in range(L)], seg, inv, [par[l] for l in range(L - 1)]
+
+
 _VOX_DESC_DT = None
 
 

@@ -515,13 +515,18 @@ class BatchSceneMaps(SceneMaps):
                 skeys, self.sidx = ops.sort_pairs(skeys, self.sidx, MORTON_BITS, MORTON_BITS + scene_bits)
             else:
                 skeys, self.sidx = ops.sort_pairs(keys, None, 0, 56)
-            ukeys, self.seg_start, self.inverse, n0 = ops.unique_sorted(
-                skeys, self.sidx, N, None, 0, want_seg_start=True, want_map=True, map_size=N, nuniq_out=rb[0:1])
-            keys_l, parents = [ukeys], []
-            if LEVELS_AT_ONCE and clip_min_shape == 0 and 1 < n_levels <= 8:
+            if LEVELS_AT_ONCE and VOXELISE_ONE_CALL and clip_min_shape == 0 and 1 < n_levels <= 8:
+                # every level from the sorted point keys in four launches (round 5; level 0 and the coarser levels were four each)
+                keys_l, self.seg_start, self.inverse, parents = ops.voxel_levels_all(skeys, self.sidx, n_levels, rb[0:n_levels])
+            elif LEVELS_AT_ONCE and clip_min_shape == 0 and 1 < n_levels <= 8:
+                ukeys, self.seg_start, self.inverse, n0 = ops.unique_sorted(
+                    skeys, self.sidx, N, None, 0, want_seg_start=True, want_map=True, map_size=N, nuniq_out=rb[0:1])
                 uks, parents, _ = ops.unique_levels(ukeys, N, n0, n_levels - 1, counts_out=rb[1:n_levels])
-                keys_l += uks
+                keys_l = [ukeys] + uks
             else:
+                ukeys, self.seg_start, self.inverse, n0 = ops.unique_sorted(
+                    skeys, self.sidx, N, None, 0, want_seg_start=True, want_map=True, map_size=N, nuniq_out=rb[0:1])
+                keys_l, parents = [ukeys], []
                 n_prev = n0
                 for lvl in range(1, n_levels):
                     clip = (self.stats, inv, lvl, clip_min_shape) if clip_min_shape > 0 else None
