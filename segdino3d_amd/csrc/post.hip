@@ -430,7 +430,8 @@ int launch_nms_decay(const float* inter, int ld, const float* area, const int32_
     SD3D_CHECK_LAUNCH();
     return SD3D_OK;
 }
-size_t expand_masks_ws_bytes(int n, int ld_sig) { return (size_t)ld_sig * ((n + 31) / 32 + 1) * sizeof(uint32_t) + 256; }
+// (+ n ints behind npts: a caller that places `count` there - ops.MaskBits - gets both zeroed by ONE memset launch)
+size_t expand_masks_ws_bytes(int n, int ld_sig) { return ((size_t)ld_sig * ((n + 31) / 32 + 1) + (size_t)n) * sizeof(uint32_t) + 256; }
 // bits [ld_sig][W] words + npts [ld_sig] ints live in `ws` (expand_masks_ws_bytes): phase 1 of expand_masks, and all of it when the
 // caller expands a list of rows later (launch_expand_rows on the same ws)
 int launch_mask_rowbits(const float* sig, int ld_sig, const uint32_t* src, int n, const int64_t* superpoints, int64_t N, float sp_thr,
@@ -440,8 +441,12 @@ int launch_mask_rowbits(const float* sig, int ld_sig, const uint32_t* src, int n
     const int W = (n + 31) / 32, S = ld_sig;
     uint32_t* bits = (uint32_t*)ws;
     int32_t* npts = (int32_t*)(bits + (size_t)S * W);
-    (void)hipMemsetAsync(count, 0, (size_t)n * sizeof(int32_t), st);
-    (void)hipMemsetAsync(npts, 0, (size_t)S * sizeof(int32_t), st);
+    if (count == npts + S) {
+        (void)hipMemsetAsync(npts, 0, (size_t)(S + n) * sizeof(int32_t), st);
+    } else {
+        (void)hipMemsetAsync(count, 0, (size_t)n * sizeof(int32_t), st);
+        (void)hipMemsetAsync(npts, 0, (size_t)S * sizeof(int32_t), st);
+    }
     hipLaunchKernelGGL(em_hist_kernel, dim3((unsigned)cdiv(N, 256)), dim3(256), 0, st, superpoints, N, S, npts);
     hipLaunchKernelGGL(em_rowbits_kernel, dim3((unsigned)cdiv(S, 256), (unsigned)W), dim3(256), 0, st, sig, ld_sig, src, n, S, sp_thr,
                        npts, bits, W, count);

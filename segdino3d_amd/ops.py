@@ -1433,9 +1433,11 @@ class MaskBits:
         ps, lds = _rows(sig, "sig")
         self.n, self.N, self.lds = src_row.numel(), superpoints.numel(), lds
         self.superpoints, self.points, self.boxes, self.loose = superpoints, points, boxes, float(loose_ratio)
-        self.count = torch.empty(self.n, dtype=torch.int32, device=sig.device)
         # (a tensor of its own, not the per-stream workspace: the table must survive until the rows are expanded, after the host read)
         self.ws = torch.empty(lib.sd3d_expand_masks_ws_bytes(self.n, lds), dtype=torch.uint8, device=sig.device)
+        # the point counts sit right behind the table's superpoint sizes: the library zeroes both with one memset launch
+        c0 = 4 * lds * ((self.n + 31) // 32 + 1)
+        self.count = self.ws[c0:c0 + 4 * self.n].view(torch.int32)
         _lib.check(lib.sd3d_mask_rowbits(ps, lds, _ptr(src_row, torch.int32, "src_row"), self.n, _ptr(superpoints, torch.int64, "superpoints"),
                                          self.N, float(sp_thr), _ptr(self.count), self.ws.data_ptr(), self.ws.numel(), _stream()), "mask_rowbits")
 

@@ -45,7 +45,7 @@ updown = []
 for l, (dn, up) in enumerate(strides):
     updown += [(dn, maps.n_vox[l], -1, False, LEAN), (up, maps.n_vox[l], -1, True, LEAN)]
 print("lean tables" if LEAN else "tables with position table and filled capacity (training; rounds 1 - 4)")
-print(f"chained lists of levels 0-2 (3 launches):              {timed(lambda: ops.pair_lists_batch(chained)):8.1f} us")
-print(f"stem 5^3 list (4 launches):                            {timed(lambda: ops.pair_lists_batch(stem)):8.1f} us")
+print(f"chained lists of levels 0-2:                            {timed(lambda: ops.pair_lists_batch(chained)):8.1f} us")
+print(f"stem 5^3 list:                                           {timed(lambda: ops.pair_lists_batch(stem)):8.1f} us")
 print(f"plain 3^3 lists of levels 3-4 + 8 stride-2 lists:      {timed(lambda: ops.pair_lists_batch(plain3 + updown)):8.1f} us")
-print(f"all 14 tables in one call (7 launches):                {timed(lambda: ops.pair_lists_batch(chained + stem + plain3 + updown)):8.1f} us")
+print(f"all 14 tables in one call:                              {timed(lambda: ops.pair_lists_batch(chained + stem + plain3 + updown)):8.1f} us")
