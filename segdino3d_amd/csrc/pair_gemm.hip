@@ -1498,9 +1498,16 @@ int launch_pair_conv(const float* in0, int ld0, int C0, const float* in1, int ld
         const dim3 grid((unsigned)gx, (unsigned)cgs);
         {   // SD3D_PAIR_POOL=0: every tile dealt out statically (rounds 1-4)
             static const int pool_env = env_flag("SD3D_PAIR_POOL", 1);
-            static unsigned int* pool_base = nullptr;
+            // (the counters are a per-device symbol: a process that drives several GPUs gets each device's own address)
+            static std::atomic<unsigned int*> pool_bases[64];
             static std::atomic<unsigned> pool_next{0};
-            if (pool_env && !pool_base && hipGetSymbolAddress((void**)&pool_base, HIP_SYMBOL(g_pool_ctr)) != hipSuccess) pool_base = nullptr;
+            int dev = 0;
+            unsigned int* pool_base = nullptr;
+            if (pool_env && hipGetDevice(&dev) == hipSuccess && dev >= 0 && dev < 64) {
+                pool_base = pool_bases[dev].load(std::memory_order_acquire);
+                if (!pool_base && hipGetSymbolAddress((void**)&pool_base, HIP_SYMBOL(g_pool_ctr)) == hipSuccess)
+                    pool_bases[dev].store(pool_base, std::memory_order_release);
+            }
             if (pool_env && pool_base && 2 * cgs <= PG_POOL_INTS)
                 g.pool_ctr = pool_base + (size_t)(pool_next.fetch_add(1, std::memory_order_relaxed) % PG_POOL_SLOTS) * PG_POOL_INTS;
         }
