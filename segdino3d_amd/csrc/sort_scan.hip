@@ -399,9 +399,17 @@ __global__ void i64_to_sortkey_checked_max(const int64_t* __restrict__ x, int64_
     }
 #pragma unroll
     for (int d = 32; d >= 1; d >>= 1) { const int t = __shfl_xor(m, d); m = t > m ? t : m; }
-    // (one atomic per wave on ONE address was 2300 serialised L2 round trips - 29 us for 150 k ids; the maximum only grows, so a wave
-    //  whose own maximum does not exceed what is already there has nothing to add - a stale read only costs a redundant atomic)
-    if ((threadIdx.x & 63) == 0 && m > 0 && m > __builtin_nontemporal_load(max_out)) atomicMax(max_out, m);
+    // (one atomic per wave on ONE address was 2300 serialised L2 round trips - 29 us for 150 k ids: one per workgroup, and only when the
+    //  workgroup's maximum exceeds what is already there - the maximum only grows, a stale read costs a redundant atomic at worst)
+    __shared__ int wmax[4];
+    if ((threadIdx.x & 63) == 0) wmax[(threadIdx.x >> 6) & 3] = m;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const int nw = (int)(blockDim.x + 63) >> 6;
+        int bm = wmax[0];
+        for (int w = 1; w < nw && w < 4; ++w) bm = wmax[w] > bm ? wmax[w] : bm;
+        if (bm > 0 && bm > __builtin_nontemporal_load(max_out)) atomicMax(max_out, bm);
+    }
 }
 int launch_i64_to_sortkey_checked_max(const int64_t* x, int64_t n, uint64_t* keys, int bits, int32_t* flag, int value, int32_t* max_out, hipStream_t st,
                                       uint64_t add) {
