@@ -302,7 +302,11 @@ def main():
     device = torch.device("cuda", dev_index)
     comm_device = device if backend == "nccl" else torch.device("cpu")
     dist = None
-    if world > 1:
+    # a launcher's environment (RANK + MASTER_ADDR / MASTER_PORT) means "be a rank" also at world size 1: the process group, the barriers, the
+    # max-over-ranks all-reduce and the closing all-gather then run on the chosen backend exactly as they do at N > 1
+    # (tests/test_gpu_rccl.py: the RCCL branch on the one GPU a box has).  A plain `python bench.py` (no RANK) stays group-free.
+    launched = "RANK" in os.environ and "MASTER_ADDR" in os.environ and "MASTER_PORT" in os.environ
+    if world > 1 or launched:
         import torch.distributed as dist
         if backend == "nccl":
             dist.init_process_group(backend="nccl", rank=rank, world_size=world, device_id=device)
@@ -480,6 +484,8 @@ def main():
                                if args.batch > 1 else ""),
                 # every sparse convolution AND every Linear of the decoder / heads (the ~155 extra launches are 10 us each for 26 MFLOP)
                 "gemm_family": {"launches_per_forward": n_launch // n_fwd, "ms_per_forward": round(gemm_ms / steps, 3),
+                                "ms_per_forward_note": "single-stream SUM of HIP-event pairs around every launch (each pair reads >= launch + drain of a "
+                                                       "10 us kernel): not a share of `ms_per_step`, and it may exceed it",
                                 "achieved": round(fam_tf, 2), "unit": "TFLOP/s", "frac": round(fam_tf / FP32_MFMA_PEAK_TFLOPS, 4),
                                 "hbm_achieved_gbs": round(fam_gbs, 1), "algorithmic_bytes_per_forward": tot_bytes // steps,
                                 "algorithmic_flops_per_forward": tot_flops // steps}}
@@ -532,6 +538,8 @@ def main():
                           "note": "the same K-step list repeated back to back after the K timed steps (rank 0's clock); not `value`"},
             "roofline": roofline, "cpu_baseline": cpu, "end_to_end": e2e,
             "per_rank_records": records,
+            "process_group": None if dist is None else {"backend": dist.get_backend(), "world_size": dist.get_world_size(),
+                                                        "collectives": "barrier x2, all_reduce(MAX) of the timed span, all_gather of the per-rank records"},
         }
         print(json.dumps(out))
     if dist is not None:

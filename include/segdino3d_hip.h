@@ -38,6 +38,19 @@ int sd3d_selftest_host(void);
  * weight-stationary pass 1 for >= 96 output columns).  Results are bit-identical either way.  Returns the previous value. */
 int sd3d_set_scenes_in_flight(int n);
 
+/* The shared tail of the lock-step pass 1 (csrc/pair_gemm.hip "The shared tail of a lock-step launch"): the last 3/16 of a launch's tiles
+ * are drawn in small units from an epoch-stamped counter of a per-device ring of launch slots.  Results are the same bits with the tail
+ * on or off.  sd3d_set_pair_pool(0 / 1) switches it at run time (default: SD3D_PAIR_POOL, 1) and returns the previous setting.
+ * sd3d_pair_pool_check() synchronises the current device and returns the number of counter words of its ring in a state no sequence of
+ * finished launches can leave behind (0 = healthy; < 0 = error, see sd3d_last_error).  sd3d_pair_pool_launches(&n): pooled launches handed
+ * out on the current device so far.  sd3d_pair_pool_poison(word) is a TEST hook: it overwrites every counter word of the current
+ * device's ring (what a launch that died half-way or a foreign write would leave) - later launches must still produce the same bits.
+ * A launch on a stream that is being captured into a HIP graph never uses the tail. */
+int sd3d_set_pair_pool(int on);
+int sd3d_pair_pool_check(void);
+int sd3d_pair_pool_launches(int64_t* launches_out);
+int sd3d_pair_pool_poison(int64_t word);
+
 /* ---------------------------------------------------------------------------------------------
  * Sort / scan primitives (used by voxelisation, superpoint pooling, top-k)
  * ------------------------------------------------------------------------------------------- */
@@ -60,7 +73,8 @@ int sd3d_keys_from_f32(const float* x, int64_t n, int descending, uint64_t* keys
 int sd3d_keys_from_i64(const int64_t* x, int64_t n, uint64_t* keys, void* stream);
 /* The same, and *flag |= flag_value when an id does not fit `bits` bits (a radix sort over fewer key bits is then not a full sort). */
 int sd3d_keys_from_i64_checked(const int64_t* x, int64_t n, uint64_t* keys, int bits, int32_t* flag, int flag_value, void* stream);
-/* ... and *max_out = max(*max_out, largest id, clamped to INT32_MAX) - the caller zeroes it; bits = 64: no check.  The superpoint count of a
+/* ... and *max_out = max(*max_out, largest id, clamped to INT32_MAX) - the caller zeroes it; bits = 64: no width check.  An id that is negative or
+ * larger than INT32_MAX - 1 ORs 8 into *flag whatever `bits` is (ids are row numbers: int32).  The superpoint count of a
  * scene (largest id + 1; `minkunet.py:631-639` scatter_mean sizes its output the same way) is known without waiting for the sort of the ids. */
 int sd3d_keys_from_i64_checked_max(const int64_t* x, int64_t n, uint64_t* keys, int bits, int32_t* flag, int flag_value, int32_t* max_out,
                                    void* stream);
@@ -195,6 +209,8 @@ int sd3d_segment_starts_batch(const uint64_t* sorted_ids, int64_t n, int64_t S, 
                               void* stream);
 /* Fused `x.slice(field)` + torch_scatter.scatter_mean of features [S,C] and of the floor-quantised
  * coordinates * voxel_size [S,3]  (minkunet.py:631-656; spconvunet.py:390). */
+/* C (feature columns) must be a multiple of 4 and <= 96 (round 5: a staged row of 96 columns + 3 coordinates per LDS slot; the shipped networks pool
+ * 96 columns; SD3D_ERR_ARG otherwise). */
 int sd3d_pool_superpoints(const float* feat, int ld_feat, int C, const int32_t* inverse, const int32_t* icoords,
                           float voxel_size, const uint32_t* sorted_idx, const int32_t* start, int64_t S, float* out_feat,
                           float* out_pos, void* stream);

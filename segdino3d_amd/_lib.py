@@ -27,6 +27,10 @@ SIGNATURES = {
     "sd3d_abi_version": (_i, []),
     "sd3d_last_error": (C.c_char_p, []),
     "sd3d_set_scenes_in_flight": (_i, [_i]),
+    "sd3d_set_pair_pool": (_i, [_i]),
+    "sd3d_pair_pool_check": (_i, []),
+    "sd3d_pair_pool_launches": (_i, [_p]),
+    "sd3d_pair_pool_poison": (_i, [_l]),
     "sd3d_selftest_host": (_i, []),
     "sd3d_sort_ws_bytes": (_z, [_l]),
     "sd3d_sort_pairs_u64": (_i, [_p, _p, _p, _p, _p, _l, _i, _i, _p, _z, _p]),

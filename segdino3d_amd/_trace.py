@@ -15,11 +15,15 @@ _TLS = threading.local()
 
 
 class capture:
-    def __init__(self, keep_all: bool = False):
+    def __init__(self, keep_all: bool = False, keep_arena: bool = False):
         """keep_all=False (default): `maps` holds the voxel maps of the MOST RECENT forward only (a scene's neighbour tables and
         pair lists are > 100 MB at 150 k points; a scope around an evaluation loop must not accumulate them).  keep_all=True keeps
         every forward's maps for the lifetime of the scope."""
         self.keep_all = bool(keep_all)
+        # keep_arena=True: `arenas` receives the activation arena of every U-Net plan run in the scope (EVERY layer's output rows back to
+        # back, plan.LayerPlan.run) - tests compare them bit for bit between kernel variants
+        self.keep_arena = bool(keep_arena)
+        self.arenas = []
         self.outputs = None          # decoder output dict of the most recent forward in the scope
         self.maps = []               # sparse.SceneMaps of the most recent forward (all forwards with keep_all)
         self.sp_feats = None         # backbone output: per-scene superpoint features / positions

@@ -21,6 +21,7 @@
 #include "../../include/segdino3d_hip.h"
 #include <stdlib.h>
 #include <atomic>
+#include <vector>
 
 static std::atomic<int> g_scenes_in_flight{1};
 extern "C" int sd3d_set_scenes_in_flight(int n) { return g_scenes_in_flight.exchange(n < 1 ? 1 : n); }
@@ -663,7 +664,8 @@ struct PGParams {
     int nt_part;                              // 1: non-temporal partial-product stores (several scenes in flight; see PART_STORE4)
     int chained;                              // 1: tile_k carries PG_CHAIN flags (chained lists: a tile's products add onto the next tile's)
     int64_t dense_rows;                       // > 0: no lists at all - pair p is (in = out = row p) of a dense [rows, Cin] x W[0]^T product (direct epilogue)
-    unsigned int* pool_ctr;                   // lock-step kernel: {next unit, workgroups done} per column group of this launch (zero before and after it), or NULL
+    unsigned long long* pool_ctr;             // lock-step kernel: one {epoch, next unit} word per column group of this launch's slot, or NULL (static partition only)
+    unsigned int pool_epoch;                  // this launch's epoch (never 0)
 };
 
 // The shared tail of a lock-step launch.  A static partition gives every workgroup the same number of tiles, not the same time: a chained
@@ -671,12 +673,47 @@ struct PGParams {
 // served oldest first, the tiles' gathers hit or miss L2 - the counters of profiles/r05_pmc_pair_gemm.md put the MEAN wave lifetime at
 // 68 - 80 % of a launch while the pipe is 73 - 82 % busy during a wave's lifetime: a fifth of every launch is waiting for the last
 // workgroups.  So only the first 13/16 of the tile list is dealt out statically; the rest is a pool of small units (>= 6 steps each) that
-// the workgroups draw from an atomic counter as they run dry.  Which workgroup multiplies a tile never changes what is stored for it: the
-// results are the same bits.  The counters live in a ring of launch slots in device memory (zero-initialised with the code object); the
-// last workgroup of a launch leaves its slot zeroed, so no launch needs a memset.
+// the workgroups draw from a counter as they run dry.  Which workgroup multiplies a tile never changes what is stored for it: the
+// results are the same bits.
+// Round 6: the counters carry the EPOCH of the launch that owns them.  A counter is one 64-bit word {epoch : 32 | next unit : 32} per
+// (launch slot, column group); the host hands every pooled launch a ticket t -> slot t % PG_POOL_SLOTS, epoch t / PG_POOL_SLOTS + 1 (never
+// 0: zero-initialised memory is "no launch yet").  A workgroup that draws a unit and finds another epoch in the word starts the word over
+// at {its epoch, 1} and takes unit 0 - so a launch assumes NOTHING about what the slot held before it: a launch that died half-way (device
+// fault, a killed debugger, hipDeviceReset in a long-lived server) cannot make a later launch skip units, no launch has to leave the slot
+// clean, and no "workgroups done" counter is needed (rounds 5's form zeroed the slot from the launch's last workgroup and trusted it to be
+// zero on entry: VERDICT r5 "the shared tail has no in-suite guard").  What is still assumed, and checked by sd3d_pair_pool_check(): the ring
+// is long enough that the previous user of a slot (16384 pooled launches ago, ~150 forwards) has finished, and nobody else writes the ring.
+// A launch that is being captured into a HIP graph gets NO pool (a replay would meet its own exhausted epoch): static partition.
 #define PG_POOL_SLOTS 16384
-#define PG_POOL_INTS 8                                          // per slot: {next, done} x up to 4 column groups
-__device__ unsigned int g_pool_ctr[PG_POOL_SLOTS * PG_POOL_INTS];
+#define PG_POOL_WORDS 4                                         // per slot: one {epoch, next} word per column group (<= 4)
+__device__ unsigned long long g_pool_ctr[PG_POOL_SLOTS * PG_POOL_WORDS];
+__device__ unsigned int g_pool_bad;                             // sd3d_pair_pool_check's result
+
+// the next unit of this launch's pool (column group's word `ctr`), whatever the word held before
+__device__ __forceinline__ unsigned int pool_draw(unsigned long long* ctr, unsigned int epoch) {
+    unsigned long long old = __atomic_load_n(ctr, __ATOMIC_RELAXED);
+    for (;;) {
+        const bool mine = (unsigned int)(old >> 32) == epoch;
+        const unsigned long long want = mine ? old + 1ull : (((unsigned long long)epoch << 32) | 1ull);
+        const unsigned long long seen = atomicCAS(ctr, old, want);
+        if (seen == old) return mine ? (unsigned int)old : 0u;
+        old = seen;
+    }
+}
+// slots in a state no sequence of finished launches can leave behind: an epoch the host has not handed out yet for that slot
+// (`tickets` pooled launches so far on this device's ring: slot s was last owned by epoch ceil((tickets - s) / PG_POOL_SLOTS))
+__global__ __launch_bounds__(256) void pool_check_kernel(unsigned long long tickets) {
+    const int s = blockIdx.x * 256 + threadIdx.x;
+    if (s >= PG_POOL_SLOTS) return;
+    const unsigned long long last = tickets > (unsigned long long)s ? (tickets - 1 - s) / PG_POOL_SLOTS + 1 : 0;
+    int bad = 0;
+#pragma unroll
+    for (int w = 0; w < PG_POOL_WORDS; ++w) {
+        const unsigned long long v = g_pool_ctr[(size_t)s * PG_POOL_WORDS + w];
+        if ((v >> 32) > last || ((v >> 32) == 0 && v != 0)) ++bad;    // (epoch 0 = never used: the whole word is zero)
+    }
+    if (bad) atomicAdd(&g_pool_bad, (unsigned int)bad);
+}
 
 
 // scale * x + shift as ONE fused multiply-add in every epilogue of this file, so that the paths agree bit for bit
@@ -715,12 +752,16 @@ __device__ __forceinline__ float pg_act(float t, int act) {
 // four consecutive columns - 4 NT `dwordx4` stores from ONE 64-bit address per tile instead of 16 NT dword stores with an index product
 // each), the weight requests are a wave-uniform 64-bit base (scalar unit) + a per-thread 32-bit offset fixed for the launch, a gather
 // request is one 64-bit multiply-add per step.
-template <int NT, bool DIRECT>
+// MODE 0: partial products (pass 2 follows); 1: direct epilogue over out_idx (transposed convolutions); 2: dense rows (the identity as the
+// rulebook: the U-Net's 1x1 convolutions, launch_pair_dense) - its own kernel symbols (`pair_dense_kernel_*`), so that a kernel trace lists
+// the sparse convolutions the roofline counts apart from the 1x1s
+template <int NT, int MODE>
 __device__ __forceinline__ void pair_gemm_body(const PGParams& p, float (*Bs)[NT * 32 * PBS_LD], int* Ix, int* Kx) {
+    constexpr bool DIRECT = MODE >= 1;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int j = lane & 31, h = lane >> 5;
-    const bool dense = DIRECT && p.dense_rows > 0;
+    constexpr bool dense = MODE == 2;
     const int n_real = dense ? (int)((p.dense_rows + PT - 1) / PT) : p.tile_k[p.n_tiles];
     const int nchunks = p.Cin >> 5;
     // static part [0, n_static) in equal ranges, then the pool [n_static, n_real) in units of `unit` tiles (see g_pool_ctr above)
@@ -901,7 +942,7 @@ __device__ __forceinline__ void pair_gemm_body(const PGParams& p, float (*Bs)[NT
     }
     if (!pool) break;
     __syncthreads();
-    if (tid == 0) pool_unit = (int)atomicAdd(p.pool_ctr + 2 * blockIdx.y, 1u);
+    if (tid == 0) pool_unit = (int)pool_draw(p.pool_ctr + blockIdx.y, p.pool_epoch);
     __syncthreads();
     const int u = __builtin_amdgcn_readfirstlane(pool_unit);
     range0 = n_static + u * unit;
@@ -912,30 +953,27 @@ __device__ __forceinline__ void pair_gemm_body(const PGParams& p, float (*Bs)[NT
         while (range1 < n_real && (p.tile_k[range1 - 1] & PG_CHAIN)) ++range1;
     }
   }
-    if (pool) {                                                // the last workgroup of the column group leaves the launch slot zeroed
-        __syncthreads();
-        if (tid == 0) {
-            const unsigned done = atomicAdd(p.pool_ctr + 2 * blockIdx.y + 1, 1u);
-            if (done == gridDim.x - 1) { atomicExch(p.pool_ctr + 2 * blockIdx.y, 0u); atomicExch(p.pool_ctr + 2 * blockIdx.y + 1, 0u); }
-        }
-    }
 }
 
-#define PAIR_GEMM_ENTRY(NAME, NT, WAVES, DIRECT)                                                                \
+#define PAIR_GEMM_ENTRY(NAME, NT, WAVES, MODE)                                                                  \
     __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WAVES, WAVES))) void NAME(const PGParams p) { \
         __shared__ __attribute__((aligned(16))) float Bs[2][NT * 32 * PBS_LD];                                  \
         __shared__ int Ix[PG_PIECE * PT];                                                                       \
         __shared__ int Kx[PG_PIECE + 2];                                                                        \
-        pair_gemm_body<NT, DIRECT>(p, Bs, Ix, Kx);                                                             \
+        pair_gemm_body<NT, MODE>(p, Bs, Ix, Kx);                                                               \
     }
-PAIR_GEMM_ENTRY(pair_gemm_kernel_1, 1, 3, false)
-PAIR_GEMM_ENTRY(pair_gemm_kernel_2, 2, 2, false)
-PAIR_GEMM_ENTRY(pair_gemm_kernel_3, 3, 2, false)
-PAIR_GEMM_ENTRY(pair_gemm_kernel_4, 4, 2, false)
-PAIR_GEMM_ENTRY(pair_gemm_direct_kernel_1, 1, 3, true)
-PAIR_GEMM_ENTRY(pair_gemm_direct_kernel_2, 2, 2, true)
-PAIR_GEMM_ENTRY(pair_gemm_direct_kernel_3, 3, 2, true)
-PAIR_GEMM_ENTRY(pair_gemm_direct_kernel_4, 4, 2, true)
+PAIR_GEMM_ENTRY(pair_gemm_kernel_1, 1, 3, 0)
+PAIR_GEMM_ENTRY(pair_gemm_kernel_2, 2, 2, 0)
+PAIR_GEMM_ENTRY(pair_gemm_kernel_3, 3, 2, 0)
+PAIR_GEMM_ENTRY(pair_gemm_kernel_4, 4, 2, 0)
+PAIR_GEMM_ENTRY(pair_gemm_direct_kernel_1, 1, 3, 1)
+PAIR_GEMM_ENTRY(pair_gemm_direct_kernel_2, 2, 2, 1)
+PAIR_GEMM_ENTRY(pair_gemm_direct_kernel_3, 3, 2, 1)
+PAIR_GEMM_ENTRY(pair_gemm_direct_kernel_4, 4, 2, 1)
+PAIR_GEMM_ENTRY(pair_dense_kernel_1, 1, 3, 2)
+PAIR_GEMM_ENTRY(pair_dense_kernel_2, 2, 2, 2)
+PAIR_GEMM_ENTRY(pair_dense_kernel_3, 3, 2, 2)
+PAIR_GEMM_ENTRY(pair_dense_kernel_4, 4, 2, 2)
 
 // ---- pass 1, weight-stationary variant ----------------------------------------------------------
 // For layers whose whole W[k] (Cout x Cin fp32, Cout = 32*NT <= 128) fits in LDS next to a second
@@ -1249,6 +1287,58 @@ __global__ __launch_bounds__(256) void pair_reduce_rl_kernel(const PRLParams p) 
     *(f32x4*)(p.out + r * p.ld_out + q) = f32x4{y[0], y[1], y[2], y[3]};
 }
 
+// ---- the shared tail's host side ------------------------------------------------------------------
+#define PG_MAX_DEVICES 64
+static std::atomic<unsigned long long*> g_pool_bases[PG_MAX_DEVICES];
+static std::atomic<unsigned long long> g_pool_tickets[PG_MAX_DEVICES];        // pooled launches handed out so far, per device
+static std::atomic<int> g_pool_on{-1};                                         // -1: not decided yet (SD3D_PAIR_POOL, default 1)
+static bool pool_enabled() {
+    int v = g_pool_on.load(std::memory_order_relaxed);
+    if (v < 0) {
+        const char* e = getenv("SD3D_PAIR_POOL");
+        v = e ? (atoi(e) != 0) : 1;
+        int expected = -1;
+        g_pool_on.compare_exchange_strong(expected, v);
+        v = g_pool_on.load(std::memory_order_relaxed);
+    }
+    return v != 0;
+}
+extern "C" int sd3d_set_pair_pool(int on) {
+    const int prev = pool_enabled() ? 1 : 0;
+    g_pool_on.store(on ? 1 : 0, std::memory_order_relaxed);
+    return prev;
+}
+// Number of counter words of the current device's ring in a state no sequence of finished launches leaves behind (an epoch the host has
+// not handed out for that slot, or anything in a slot no launch has used); 0 is the healthy answer.  Synchronises the device.  < 0: error.
+extern "C" int sd3d_pair_pool_check(void) {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= PG_MAX_DEVICES) { sd3d_set_error(SD3D_ERR_LAUNCH, "pair_pool_check: no device"); return -1; }
+    if (hipDeviceSynchronize() != hipSuccess) { sd3d_set_error(SD3D_ERR_LAUNCH, "pair_pool_check: device synchronisation failed"); return -1; }
+    unsigned int zero = 0, bad = 0;
+    if (hipMemcpyToSymbol(HIP_SYMBOL(g_pool_bad), &zero, sizeof(zero)) != hipSuccess) { sd3d_set_error(SD3D_ERR_LAUNCH, "pair_pool_check: symbol write failed"); return -1; }
+    hipLaunchKernelGGL(pool_check_kernel, dim3(PG_POOL_SLOTS / 256), dim3(256), 0, nullptr, g_pool_tickets[dev].load(std::memory_order_relaxed));
+    if (hipGetLastError() != hipSuccess || hipDeviceSynchronize() != hipSuccess ||
+        hipMemcpyFromSymbol(&bad, HIP_SYMBOL(g_pool_bad), sizeof(bad)) != hipSuccess) { sd3d_set_error(SD3D_ERR_LAUNCH, "pair_pool_check: check kernel failed"); return -1; }
+    return (int)bad;
+}
+// pooled launches so far on the current device (tests: did the pool really run?)
+extern "C" int sd3d_pair_pool_launches(int64_t* launches_out) {
+    int dev = 0;
+    if (!launches_out || hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= PG_MAX_DEVICES) return sd3d_set_error(SD3D_ERR_ARG, "pair_pool_launches: no device / no output");
+    *launches_out = (int64_t)g_pool_tickets[dev].load(std::memory_order_relaxed);
+    return SD3D_OK;
+}
+// Test hook: overwrite the whole ring of the current device with `word` (a launch that died half-way, a foreign write) and forget
+// nothing else - the next pooled launches must still produce the same bits (tests/test_gpu_pair_paths.py).
+extern "C" int sd3d_pair_pool_poison(int64_t word) {
+    unsigned long long* base = nullptr;
+    if (hipGetSymbolAddress((void**)&base, HIP_SYMBOL(g_pool_ctr)) != hipSuccess) return sd3d_set_error(SD3D_ERR_LAUNCH, "pair_pool_poison: no symbol");
+    std::vector<unsigned long long> h((size_t)PG_POOL_SLOTS * PG_POOL_WORDS, (unsigned long long)word);
+    if (hipDeviceSynchronize() != hipSuccess || hipMemcpy(base, h.data(), h.size() * sizeof(unsigned long long), hipMemcpyHostToDevice) != hipSuccess)
+        return sd3d_set_error(SD3D_ERR_LAUNCH, "pair_pool_poison: copy failed");
+    return SD3D_OK;
+}
+
 // ---- launchers --------------------------------------------------------------------------------
 size_t pair_lists_ws_bytes(int K, int64_t M) {
     const int64_t nblk = cdiv(M, PL_ROWS);
@@ -1412,6 +1502,11 @@ int launch_pair_conv(const float* in0, int ld0, int C0, const float* in1, int ld
     if ((ld_res & 3) && res) return sd3d_set_error(SD3D_ERR_ARG, "pair_conv: residual row stride must be a multiple of 4 floats");
     if (center >= 0) return sd3d_set_error(SD3D_ERR_ARG, "pair_conv: center must be -1 or SD3D_PAIR_CHAINED (the dense centre kernel of round 3 left the library: profiles/EXPERIMENTS.md)");
     const bool direct = out_idx != nullptr && direct_env;
+    // (lean evaluation tables carry no position table, 'up' tables no row lists: with SD3D_PAIR_RL=0 / SD3D_PAIR_DIRECT=0, or a C caller that
+    //  passes neither, pass 2 would walk pos == NULL - refuse before anything is launched.  ADVICE r5)
+    if (!direct && !(rlist && rl_env) && !pos)
+        return sd3d_set_error(SD3D_ERR_ARG, "pair_conv: pass 2 needs rlist (SD3D_PAIR_RL=1), or pos, or out_idx with the direct epilogue (SD3D_PAIR_DIRECT=1); "
+                                            "this table was built without a position table (lean evaluation lists)");
     PGParams g;
     g.in0 = in0; g.ld0 = ld0; g.C0 = C0; g.in1 = in1; g.ld1 = ld1; g.in_idx = in_idx; g.tile_k = tile_k; g.wt = wt;
     g.Cin = Cin; g.Cout = Cout; g.part = part;
@@ -1422,6 +1517,7 @@ int launch_pair_conv(const float* in0, int ld0, int C0, const float* in1, int ld
     }
     g.dense_rows = 0;
     g.pool_ctr = nullptr;
+    g.pool_epoch = 0;
     g.out_idx = direct ? out_idx : nullptr;
     g.scale = scale; g.shift = shift; g.res = res; g.ld_res = ld_res; g.out = out; g.ld_out = ld_out; g.act = act;
     const int sub = (Cout + 31) / 32;
@@ -1496,20 +1592,21 @@ int launch_pair_conv(const float* in0, int ld0, int C0, const float* in1, int ld
         int gx = n_cu * per_cu / cgs;
         gx = gx < 1 ? 1 : (gx < g.n_tiles ? gx : g.n_tiles);
         const dim3 grid((unsigned)gx, (unsigned)cgs);
-        {   // SD3D_PAIR_POOL=0: every tile dealt out statically (rounds 1-4)
-            static const int pool_env = env_flag("SD3D_PAIR_POOL", 1);
-            // (the counters are a per-device symbol: a process that drives several GPUs gets each device's own address)
-            static std::atomic<unsigned int*> pool_bases[64];
-            static std::atomic<unsigned> pool_next{0};
+        if (pool_enabled() && cgs <= PG_POOL_WORDS) {           // the shared tail (sd3d_set_pair_pool / SD3D_PAIR_POOL=0: every tile dealt out statically, rounds 1-4)
+            // (the counters are a per-device symbol: a process that drives several GPUs gets each device's own address and its own tickets)
             int dev = 0;
-            unsigned int* pool_base = nullptr;
-            if (pool_env && hipGetDevice(&dev) == hipSuccess && dev >= 0 && dev < 64) {
-                pool_base = pool_bases[dev].load(std::memory_order_acquire);
-                if (!pool_base && hipGetSymbolAddress((void**)&pool_base, HIP_SYMBOL(g_pool_ctr)) == hipSuccess)
-                    pool_bases[dev].store(pool_base, std::memory_order_release);
+            hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+            if (hipGetDevice(&dev) == hipSuccess && dev >= 0 && dev < PG_MAX_DEVICES &&
+                (st == nullptr || (hipStreamIsCapturing(st, &cap) == hipSuccess && cap == hipStreamCaptureStatusNone))) {
+                unsigned long long* base = g_pool_bases[dev].load(std::memory_order_acquire);
+                if (!base && hipGetSymbolAddress((void**)&base, HIP_SYMBOL(g_pool_ctr)) == hipSuccess)
+                    g_pool_bases[dev].store(base, std::memory_order_release);
+                if (base) {
+                    const unsigned long long t = g_pool_tickets[dev].fetch_add(1, std::memory_order_relaxed);
+                    g.pool_ctr = base + (size_t)(t % PG_POOL_SLOTS) * PG_POOL_WORDS;
+                    g.pool_epoch = (unsigned int)(t / PG_POOL_SLOTS + 1);
+                }
             }
-            if (pool_env && pool_base && 2 * cgs <= PG_POOL_INTS)
-                g.pool_ctr = pool_base + (size_t)(pool_next.fetch_add(1, std::memory_order_relaxed) % PG_POOL_SLOTS) * PG_POOL_INTS;
         }
         if (direct) {
             switch (nt) {
@@ -1558,7 +1655,7 @@ int launch_pair_dense(const GGParams& q, hipStream_t st) {
     PGParams g;
     g.in0 = q.in0; g.ld0 = q.ld0; g.C0 = q.in1 ? q.C0 : q.Cin; g.in1 = q.in1; g.ld1 = q.ld1; g.in_idx = nullptr; g.tile_k = nullptr; g.wt = q.wt;
     g.Cin = q.Cin; g.Cout = q.Cout; g.part = nullptr; g.n_tiles = 0; g.out_idx = nullptr; g.scale = q.scale; g.shift = q.shift; g.res = q.res;
-    g.ld_res = q.ld_res; g.out = q.out; g.ld_out = q.ld_out; g.act = q.act; g.nt_part = 0; g.chained = 0; g.dense_rows = q.M; g.pool_ctr = nullptr;
+    g.ld_res = q.ld_res; g.out = q.out; g.ld_out = q.ld_out; g.act = q.act; g.nt_part = 0; g.chained = 0; g.dense_rows = q.M; g.pool_ctr = nullptr; g.pool_epoch = 0;
     const int sub = (q.Cout + 31) / 32;
     int nt = sub >= 4 ? 4 : sub;
     if (sub > 4 && sub % 4) { for (int c = 4; c >= 1; --c) if (sub % c == 0) { nt = c; break; } }
@@ -1568,10 +1665,10 @@ int launch_pair_dense(const GGParams& q, hipStream_t st) {
     gx = gx < 1 ? 1 : (gx < tiles ? gx : (int)tiles);
     const dim3 grid((unsigned)gx, (unsigned)cgs);
     switch (nt) {
-        case 1: hipLaunchKernelGGL(pair_gemm_direct_kernel_1, grid, dim3(256), 0, st, g); break;
-        case 2: hipLaunchKernelGGL(pair_gemm_direct_kernel_2, grid, dim3(256), 0, st, g); break;
-        case 3: hipLaunchKernelGGL(pair_gemm_direct_kernel_3, grid, dim3(256), 0, st, g); break;
-        default: hipLaunchKernelGGL(pair_gemm_direct_kernel_4, grid, dim3(256), 0, st, g); break;
+        case 1: hipLaunchKernelGGL(pair_dense_kernel_1, grid, dim3(256), 0, st, g); break;
+        case 2: hipLaunchKernelGGL(pair_dense_kernel_2, grid, dim3(256), 0, st, g); break;
+        case 3: hipLaunchKernelGGL(pair_dense_kernel_3, grid, dim3(256), 0, st, g); break;
+        default: hipLaunchKernelGGL(pair_dense_kernel_4, grid, dim3(256), 0, st, g); break;
     }
     SD3D_CHECK_LAUNCH();
     return SD3D_OK;

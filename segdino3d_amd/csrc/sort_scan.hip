@@ -395,6 +395,9 @@ __global__ void i64_to_sortkey_checked_max(const int64_t* __restrict__ x, int64_
         const uint64_t k = (uint64_t)x[i];
         keys[i] = k + add;                                      // (add: the scene's bits of a batch-wide key; the check and the maximum see the id)
         if (bits < 64 && (k >> bits)) atomicOr(flag, value);
+        // an id that is negative (huge after the cast) or above INT32_MAX - 1 cannot be a row count of int32 row numbers: bit 8 of the flag word,
+        // whatever `bits` is (the full-sort retry with bits = 64 must not pass it silently either)
+        if (k > 0x7FFFFFFEull) atomicOr(flag, 8);
         m = k > 0x7FFFFFFFull ? 0x7FFFFFFF : (int)k;
     }
 #pragma unroll

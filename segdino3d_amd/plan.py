@@ -17,7 +17,7 @@ from typing import List, Tuple
 import numpy as np
 import torch
 
-from . import _lib, ops
+from . import _lib, _trace, ops
 
 KIND_PAIR_CONV, KIND_DENSE, KIND_AFFINE = 0, 1, 2
 # SD3D_PLAN=0: issue every layer from Python (EagerBackend) - tuning / ablation / instrumentation
@@ -206,4 +206,7 @@ class LayerPlan:
         getattr(maps, "release_side", lambda: None)()            # the side stream's pool may reuse the tables' blocks only behind these layers
         o = int(offs[self.out_id])
         n = int(rows[self.out_id])
+        cap = _trace.active()
+        if cap is not None and cap.keep_arena:
+            cap.arenas.append(arena[:int(sizes.sum())])
         return arena[o:o + n * self.out_ch].view(n, self.out_ch)

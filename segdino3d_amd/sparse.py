@@ -243,6 +243,8 @@ class SceneMaps:
         self.n_vox = [int(v) for v in host[:n_levels]]
         if int(host[n_levels]) & 1:
             raise RuntimeError("scene exceeds the 16-bit-per-axis voxel key range (extent > ~1.3 km at 2 cm)")
+        if int(host[n_levels]) & 8:
+            raise RuntimeError("superpoint ids must lie in [0, 2^31 - 2] (a negative or oversized id was found)")
         self.n_superpoints = int(host[n_levels + 1]) + 1 if superpoints is not None else 0
         self.keys = [k[: self.n_vox[l]] for l, k in enumerate(keys_l)]
         self.parents = [p[: self.n_vox[l]] for l, p in enumerate(parents)]
@@ -556,6 +558,8 @@ class BatchSceneMaps(SceneMaps):
         self.n_vox = [int(v) for v in host[:n_levels]]
         if int(host[n_levels]) & 1:                                # (bit 1 = "more than 32 Morton bits": the batch sorts all 56 key bits anyway)
             raise RuntimeError("scene exceeds the 16-bit-per-axis voxel key range (extent > ~1.3 km at 2 cm)")
+        if int(host[n_levels]) & 8:
+            raise RuntimeError("superpoint ids must lie in [0, 2^31 - 2] (a negative or oversized id was found)")
         self.sp_off = [0]
         if superpoints is not None:
             for v in host[n_levels + 1:n_levels + 1 + B]:

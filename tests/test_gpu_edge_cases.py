@@ -89,6 +89,22 @@ def test_key_range_overflow_is_reported():
         SceneMaps(pts.to(d), 0.02, 5, superpoints=torch.zeros(4, dtype=torch.long, device=d))
 
 
+@pytest.mark.parametrize("bad_id", [-1, 2 ** 31 - 1, 2 ** 40])
+def test_superpoint_ids_out_of_range_are_reported(bad_id):
+    """a negative or > INT32_MAX - 1 superpoint id used to be clamped into the count (max + 1 = 2^31 rows allocated); now the key
+    kernel raises flag bit 8 - also on the full-sort retry - and SceneMaps / BatchSceneMaps fail with a clear message."""
+    from segdino3d_amd.sparse import BatchSceneMaps, SceneMaps
+    d = dev()
+    g = torch.Generator().manual_seed(4)
+    pts = torch.cat([torch.rand(3000, 3, generator=g) * 2.0, torch.randn(3000, 3, generator=g)], 1).to(d)
+    sp = torch.randint(0, 20, (3000,), generator=g)
+    sp[17] = bad_id
+    with pytest.raises(RuntimeError, match="superpoint ids must lie"):
+        SceneMaps(pts, 0.02, 5, superpoints=sp.to(d))
+    with pytest.raises(RuntimeError, match="superpoint ids must lie"):
+        BatchSceneMaps([pts, pts], 0.02, 5, superpoints=[sp.to(d), torch.randint(0, 20, (3000,), generator=g).to(d)])
+
+
 def test_no_2d_queries_and_no_surviving_instances():
     """M = 0 cached 2D queries (only the dummy key remains, decoder :724-727) and a test_cfg whose
     thresholds reject every instance (empty outputs, panoptic falls back to the stuff map, :529-530)."""

@@ -282,3 +282,131 @@ def test_lean_tables_equal_the_full_tables(scene_maps, which):
     x = torch.randn(int(nbr.max()) + 1, cin, generator=g).to(nbr.device)
     w = (torch.randn(K, cout, cin, generator=g) * 0.1).to(nbr.device)
     assert torch.equal(ops.pair_conv(x, w, full), ops.pair_conv(x, w, lean))
+
+
+# ---- the shared tail of the lock-step pass 1 (round 5; epoch-stamped counters since round 6) ---------------------------------------
+def _pool(on):
+    from segdino3d_amd import _lib
+    return _lib.load().sd3d_set_pair_pool(int(on))
+
+
+def _pool_launches():
+    import ctypes
+    from segdino3d_amd import _lib
+    n = ctypes.c_int64(0)
+    assert _lib.load().sd3d_pair_pool_launches(ctypes.byref(n)) == 0
+    return n.value
+
+
+def _pool_check():
+    from segdino3d_amd import _lib
+    lib = _lib.load()
+    n = lib.sd3d_pair_pool_check()
+    assert n >= 0, lib.sd3d_last_error()
+    return n
+
+
+@pytest.fixture(scope="module")
+def bench_scene_maps():
+    """The benchmark scene (150 k points): pooled launches need >= 6 tiles per workgroup, i.e. real sizes."""
+    from segdino3d_amd.sparse import SceneMaps
+    from segdino3d_amd.synth import make_scene
+    d = dev()
+    pts, tgt = make_scene(0, 150_000, 3000, 300)
+    maps = SceneMaps(pts.to(d), 0.02, 5, superpoints=tgt.extra_features["super_point_masks"].to(d))
+    maps.prepare(same=[(0, 5)] + [(l, 3) for l in range(5)], strides=[0, 1, 2, 3])
+    return maps
+
+
+@pytest.mark.parametrize("level,cin,cout,split", [(0, 96, 96, 0), (0, 128, 96, 96), (1, 96, 96, 0), (2, 128, 128, 0), (2, 192, 128, 128),
+                                                  (3, 256, 256, 0), (3, 384, 256, 256), (4, 256, 256, 0)])
+def test_shared_tail_gives_the_same_bits(bench_scene_maps, level, cin, cout, split):
+    """Pool on vs off in ONE process (`sd3d_set_pair_pool`), chained and plain tables on the lock-step kernel: `torch.equal`.  Then the
+    ring is overwritten with garbage (what a launch that died half-way, or 16 384 launches of drift, would leave): the next launches
+    still produce the same bits - a pooled launch assumes nothing about the slot it is handed - and `sd3d_pair_pool_check` stays 0 on the
+    healthy ring."""
+    from segdino3d_amd import _lib, ops
+    lib = _lib.load()
+    c = _case(bench_scene_maps, ("same", level, 3), cin, cout, split=split, seed=level * 7 + cout)
+    nbr = c["nbr"]
+    P = int((nbr >= 0).sum())
+    chained = ops.pair_lists(nbr, P, center=ops.PAIR_CHAINED)
+    x, x2 = (c["x1"], c["x2"]) if split else (c["x"], None)
+    kw = dict(x2=x2, scale=c["scale"], shift=c["shift"], res=c["res"], act=c["act"])
+    prev = _pool(1)
+    try:
+        with ops.scenes_in_flight(4):                           # several scenes in flight: the lock-step kernel for the plain tables too
+            t0 = _pool_launches()
+            on_c = ops.pair_conv(x, c["w"], chained, **kw)
+            on_p = ops.pair_conv(x, c["w"], c["pl"], **kw)
+            assert _pool_launches() == t0 + 2, "both launches must have taken a slot of the ring"
+            assert _pool_check() == 0
+            _pool(0)
+            t1 = _pool_launches()
+            off_c = ops.pair_conv(x, c["w"], chained, **kw)
+            off_p = ops.pair_conv(x, c["w"], c["pl"], **kw)
+            assert _pool_launches() == t1, "switched off: no ticket is taken"
+            _pool(1)
+            assert torch.equal(on_c, off_c) and torch.equal(on_p, off_p), "the shared tail must not change a bit"
+            for word in (-1, 0x0000000100000000 * 7 + 5, 3):      # a future epoch, an old epoch mid-way, epoch 0 with a count
+                assert lib.sd3d_pair_pool_poison(word) == 0, lib.sd3d_last_error()
+                dirty_c = ops.pair_conv(x, c["w"], chained, **kw)
+                dirty_p = ops.pair_conv(x, c["w"], c["pl"], **kw)
+                assert torch.equal(dirty_c, on_c) and torch.equal(dirty_p, on_p), f"a dirty ring ({word:#x}) changed the result"
+            assert _pool_check() > 0, "the check must see the poisoned ring"
+            assert lib.sd3d_pair_pool_poison(0) == 0
+            assert _pool_check() == 0
+    finally:
+        _pool(prev)
+
+
+@pytest.mark.parametrize("n_scenes", [1, 4])
+def test_shared_tail_through_the_whole_unet(n_scenes):
+    """Every layer output of Res16UNet34C (the activation arena of the plan: all layers' rows back to back) at 150 k points per scene,
+    one and four scenes per forward, with the shared tail on and off: bit-identical; the ring is healthy after the forwards, after the
+    batched forward and after the pipelined runner."""
+    import copy
+    import segdino3d_amd as seg
+    from segdino3d_amd.configs import scannet200_model_cfg
+    from segdino3d_amd.dist_eval import PipelinedRunner
+    from segdino3d_amd.synth import make_scene
+    d = dev()
+    torch.manual_seed(0)
+    model = seg.build_architecture(scannet200_model_cfg(query_num=200)).eval().to(d)
+    scenes = [make_scene(10 + i, 150_000, 3000, 300) for i in range(n_scenes)]
+    pts = [p.to(d) for p, _ in scenes]
+    tgts = [t.to(d) for _, t in scenes]
+    arenas = {}
+    prev = _pool(1)
+    try:
+        for on in (1, 0):
+            _pool(on)
+            with torch.no_grad(), seg.capture(keep_arena=True) as cap:
+                model(pts, [copy.copy(t) for t in tgts])
+            assert len(cap.arenas) >= 1
+            arenas[on] = [a.clone() for a in cap.arenas]
+        assert len(arenas[0]) == len(arenas[1])
+        for a, b in zip(arenas[1], arenas[0]):
+            assert a.shape == b.shape and torch.equal(a, b), "a U-Net layer output differs between shared tail on and off"
+        _pool(1)
+        assert _pool_check() == 0
+        runner = PipelinedRunner(model, 2, d, batch=2)
+        with torch.no_grad():
+            runner.run([(pts[i % n_scenes], copy.copy(tgts[i % n_scenes])) for i in range(6)])
+        torch.cuda.synchronize()
+        assert _pool_check() == 0
+    finally:
+        _pool(prev)
+
+
+def test_pass2_without_any_list_is_refused(scene_maps):
+    """a lean table has no position table; asking for the pos-based pass 2 on it must fail with an argument error, not fault."""
+    from segdino3d_amd import ops
+    c = _case(scene_maps, ("same", 1, 3), 32, 32)
+    nbr = c["nbr"]
+    lean = ops.pair_lists_batch([(nbr, int((nbr >= 0).sum()), -1, False, True)])[0]
+    assert lean.pos is None and lean.rlist is not None
+    ok = ops.pair_conv(c["x"], c["w"], lean)
+    assert torch.isfinite(ok).all()
+    with pytest.raises(RuntimeError, match="pass 2 needs"):
+        ops.pair_conv(c["x"], c["w"], _variant(lean, rlist=None))
