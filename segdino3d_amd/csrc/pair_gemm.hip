@@ -666,7 +666,16 @@ struct PGParams {
     int64_t dense_rows;                       // > 0: no lists at all - pair p is (in = out = row p) of a dense [rows, Cin] x W[0]^T product (direct epilogue)
     unsigned long long* pool_ctr;             // lock-step kernel: one {epoch, next unit} word per column group of this launch's slot, or NULL (static partition only)
     unsigned int pool_epoch;                  // this launch's epoch (never 0)
+#ifdef PG_ABLATE
+    int dbg;                                  // timing-only switches of the lab build (tools/ablate.sh): 1 no epilogue stores, 2 gathers from row 0, 4 weights from chunk 0, 8 no step barrier
+#endif
 };
+#ifdef PG_ABLATE
+#define PG_DBG(p, bit) ((p).dbg & (bit))
+static int pg_dbg_env() { static const int v = [] { const char* e = getenv("SD3D_PG_ABLATE"); return e ? atoi(e) : 0; }(); return v; }
+#else
+#define PG_DBG(p, bit) 0
+#endif
 
 // The shared tail of a lock-step launch.  A static partition gives every workgroup the same number of tiles, not the same time: a chained
 // table's ranges are snapped to chain boundaries (+-2 tiles of the 6 - 10 a workgroup has at levels 0 - 2), the workgroups of a CU are
@@ -688,17 +697,22 @@ struct PGParams {
 #define PG_POOL_WORDS 4                                         // per slot: one {epoch, next} word per column group (<= 4)
 __device__ unsigned long long g_pool_ctr[PG_POOL_SLOTS * PG_POOL_WORDS];
 __device__ unsigned int g_pool_bad;                             // sd3d_pair_pool_check's result
+__device__ unsigned int g_pool_bad_seen;                        // workgroups that met a poisoned word since the last check (they fell back to a static split)
 
-// the next unit of this launch's pool (column group's word `ctr`), whatever the word held before
+// A workgroup CLAIMS its launch's word when it starts - an atomic max with {epoch, 0}, no return value waited for: epochs of a slot only
+// grow, so whatever an older launch left (finished or dead) is replaced by the first claim and every later claim is a no-op - and DRAWS
+// with one atomic add when it runs dry: its own claim precedes its draw in program order on the same address, so a draw sees this launch's
+// epoch or - only after a foreign write - a newer one.  (Rejected forms: a compare-and-swap loop per draw cost 1 - 2 ms per launch, the
+// ~500 workgroups of a launch run dry together and retry against each other; claim-on-first-draw tripled the atomics at that moment:
+// +25 us on the 400 us layers.)  A newer epoch cannot come from any launch: POOL_POISONED tells the caller to split the pool statically,
+// and the event is counted in g_pool_bad_seen for sd3d_pair_pool_check.
+#define POOL_POISONED 0xFFFFFFFFu
+__device__ __forceinline__ void pool_claim(unsigned long long* ctr, unsigned int epoch) {
+    (void)__hip_atomic_fetch_max(ctr, (unsigned long long)epoch << 32, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
 __device__ __forceinline__ unsigned int pool_draw(unsigned long long* ctr, unsigned int epoch) {
-    unsigned long long old = __atomic_load_n(ctr, __ATOMIC_RELAXED);
-    for (;;) {
-        const bool mine = (unsigned int)(old >> 32) == epoch;
-        const unsigned long long want = mine ? old + 1ull : (((unsigned long long)epoch << 32) | 1ull);
-        const unsigned long long seen = atomicCAS(ctr, old, want);
-        if (seen == old) return mine ? (unsigned int)old : 0u;
-        old = seen;
-    }
+    const unsigned long long old = __hip_atomic_fetch_add(ctr, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    return (unsigned int)(old >> 32) == epoch ? (unsigned int)old : POOL_POISONED;
 }
 // slots in a state no sequence of finished launches can leave behind: an epoch the host has not handed out yet for that slot
 // (`tickets` pooled launches so far on this device's ring: slot s was last owned by epoch ceil((tickets - s) / PG_POOL_SLOTS))
@@ -772,6 +786,7 @@ __device__ __forceinline__ void pair_gemm_body(const PGParams& p, float (*Bs)[NT
     // (13/16 static and units of six steps: the best of a sweep over 11 - 14 sixteenths x 4 - 12 steps, profiles/r05_pool_sweep.txt)
     const int unit = (6 + nchunks - 1) / nchunks;
     if (pool) {
+        if (tid == 0) pool_claim(p.pool_ctr + blockIdx.y, p.pool_epoch);
         n_static = (int)((int64_t)n_real * 13 / 16);
         if (p.chained) while (n_static < n_real && (p.tile_k[n_static - 1] & PG_CHAIN)) ++n_static;
     }
@@ -784,6 +799,8 @@ __device__ __forceinline__ void pair_gemm_body(const PGParams& p, float (*Bs)[NT
     if (range1 <= range0 && !pool) return;                     // uniform over the workgroup
     const int ncol0 = blockIdx.y * NT * 32;
     __shared__ int pool_unit;
+    bool poisoned = false;                                     // (uniform) this workgroup met a counter word no launch can have written
+    int fallback_round = 0;
     const uint64_t wstride_b = (uint64_t)p.Cout * (uint64_t)p.Cin * 4ull;
 
     f32x16 acc[NT];
@@ -803,6 +820,7 @@ __device__ __forceinline__ void pair_gemm_body(const PGParams& p, float (*Bs)[NT
     }
     float* const sts = &Bs[0][(tid >> 3) * PBS_LD + (tid & 7) * 4];         // + i * 32 rows, + buf * buffer
     auto stage_load = [&](int kf, int chunk) {
+        if (PG_DBG(p, 4)) { kf = 0; chunk = 0; }
         const char* Wk = (const char*)p.wt + (uint64_t)(uint32_t)(kf & PG_KMASK) * wstride_b + (uint32_t)chunk * 128u;    // scalar
 #pragma unroll
         for (int i = 0; i < NT; ++i) bst[i] = *(const f32x4*)(Wk + woff[i]);
@@ -813,6 +831,7 @@ __device__ __forceinline__ void pair_gemm_body(const PGParams& p, float (*Bs)[NT
     };
     const uint64_t lane_b = (uint64_t)(h * 64);                 // this lane's 16 channels of a 32-channel chunk
     auto load_a = [&](f32x4 (&a)[4], int row, int chunk) {      // branch-free: row >= 0 always (padding reads row 0)
+        if (PG_DBG(p, 2)) row = 0;
         const int cc = chunk * 32;                              // wave-uniform from here ...
         const bool first = cc < p.C0;
         const char* base = (const char*)(first ? p.in0 : p.in1) + (uint32_t)(first ? cc : cc - p.C0) * 4u;
@@ -892,8 +911,11 @@ __device__ __forceinline__ void pair_gemm_body(const PGParams& p, float (*Bs)[NT
             }                                                                                                         \
         }                                                                                                             \
         if (last_chunk && !(k_cur & PG_CHAIN)) { /* tile (chain) complete: lane = pair row, register group g = columns 8g + 4h .. +3 */ \
-            const int64_t prow = (int64_t)(piece0 + cur_lt) * PT + wv * 32 + j;                                       \
-            if (DIRECT) {                               /* one pair per output row: write the row itself */          \
+            int64_t prow = (int64_t)(piece0 + cur_lt) * PT + wv * 32 + j;                                             \
+            if (PG_DBG(p, 16)) prow = (prow & 127) + (int64_t)(blockIdx.x & 63) * 128;   /* every store lands in an L2-resident window */ \
+            if (PG_DBG(p, 1)) {                                                                                       \
+                if (p.Cin < 0) { _Pragma("unroll") for (int t = 0; t < NT; ++t) p.part[prow + t] = acc[t][0] + acc[t][5] + acc[t][10] + acc[t][15]; } \
+            } else if (DIRECT) {                               /* one pair per output row: write the row itself */          \
                 const int64_t o = dense ? (prow < p.dense_rows ? prow : -1) : (int64_t)p.out_idx[prow];               \
                 if (o >= 0) {                                                                                         \
                     _Pragma("unroll") for (int t = 0; t < NT; ++t)                                                    \
@@ -921,7 +943,7 @@ __device__ __forceinline__ void pair_gemm_body(const PGParams& p, float (*Bs)[NT
         }                                                                                                             \
         if (!has_next) break;                                                                                         \
         stage_store(buf ^ 1);                                                                                         \
-        __syncthreads();                                                                                              \
+        if (!PG_DBG(p, 8)) __syncthreads();                                                                           \
         buf ^= 1;                                                                                                     \
         ++s;                                                                                                          \
         if (last_chunk) {                                                                                             \
@@ -942,9 +964,19 @@ __device__ __forceinline__ void pair_gemm_body(const PGParams& p, float (*Bs)[NT
     }
     if (!pool) break;
     __syncthreads();
-    if (tid == 0) pool_unit = (int)pool_draw(p.pool_ctr + blockIdx.y, p.pool_epoch);
+    if (tid == 0) {
+        unsigned int d = poisoned ? POOL_POISONED : pool_draw(p.pool_ctr + blockIdx.y, p.pool_epoch);
+        if (d == POOL_POISONED) {                              // a foreign write in the slot: the pool is split statically, unit b, b + grid, ...
+            if (!poisoned) atomicAdd(&g_pool_bad_seen, 1u);
+            d = blockIdx.x + (unsigned)fallback_round * gridDim.x;
+            pool_unit = -1 - (int)d;
+        } else {
+            pool_unit = (int)d;
+        }
+    }
     __syncthreads();
-    const int u = __builtin_amdgcn_readfirstlane(pool_unit);
+    int u = __builtin_amdgcn_readfirstlane(pool_unit);
+    if (u < 0) { poisoned = true; ++fallback_round; u = -1 - u; }
     range0 = n_static + u * unit;
     if (range0 >= n_real) break;
     range1 = range0 + unit < n_real ? range0 + unit : n_real;
@@ -974,6 +1006,281 @@ PAIR_GEMM_ENTRY(pair_dense_kernel_1, 1, 3, 2)
 PAIR_GEMM_ENTRY(pair_dense_kernel_2, 2, 2, 2)
 PAIR_GEMM_ENTRY(pair_dense_kernel_3, 3, 2, 2)
 PAIR_GEMM_ENTRY(pair_dense_kernel_4, 4, 2, 2)
+
+#ifdef SD3D_WITH_PC
+// ---- pass 1, producer / consumer variant (round 6; LAB BUILD ONLY: -DSD3D_WITH_PC, tools/ablate.sh) ---------------------------------
+// Built, bit-identical to the lock-step kernel on every table of the benchmark scene, measured 9 - 70 % SLOWER (profiles/r06_pc_check.md,
+// profiles/r06_ablate_pc.md; the reading is in profiles/EXPERIMENTS.md round 6): not in the product library.
+// What the round-6 ablations of the lock-step kernel say (profiles/r06_ablate.md, profiles/r06_dense_ceiling.md): with the IDENTITY as
+// rulebook (no gather randomness, no partial products) the kernel reaches the same 0.43 - 0.58 of the fp32 matrix peak it reaches on the
+// real rulebooks - the lists and the chains are not what bounds pass 1; removing the per-step barrier or the weight requests changes
+// nothing; removing the epilogue STORES (even when they land in an L2-resident window) and serving the gathers from cache lifts it to
+// 0.64 - 0.75.  A wave that multiplies also issues 4 gathers + NT weight requests per step and 16 NT scattered 16-byte stores per tile
+// through the CU's one address unit, in order with its own `s_waitcnt vmcnt`: what the matrix pipe waits for is its own wave's memory
+// instructions.  Here the roles are split by WAVE: four consumer waves (one per SIMD) only read LDS and issue MFMAs; four producer waves
+// stage the next step's gathered rows and weight chunk global -> registers -> LDS (row-coalesced: eight lanes per 128-byte row), and
+// carry a finished tile from its LDS staging area to memory with full-line stores.  One `s_barrier` per step is the only
+// synchronisation (no flags, no polling: round 2's ring-and-counter version lost to its own flag traffic).  The MFMA order per
+// accumulator is the lock-step kernel's (chunk, then q, e; offsets of a chain in list order): the partial products are the same bits.
+#define PC_LD 36                 // floats per LDS row of a 32-channel chunk (32 + 4: conflict-free b128 reads of a lane's 16 channels)
+template <int NT, int MODE>
+__device__ __forceinline__ void pair_gemm_pc_body(const PGParams& p, float* smem, const int n_os) {
+    constexpr bool DIRECT = MODE >= 1;
+    constexpr bool dense = MODE == 2;
+    constexpr int WSZ = NT * 32 * PC_LD, ASZ = PT * PC_LD, LDO = NT * 32 + 4, OSZ = PT * LDO;
+    float* const Ws = smem;                                   // [2][NT * 32][PC_LD]  weight chunk of a step
+    float* const As = Ws + 2 * WSZ;                           // [2][128][PC_LD]      gathered rows of a step
+    float* const Os = As + 2 * ASZ;                           // [n_os][128][LDO]     a finished tile on its way out
+    int* const Ix = (int*)(Os + n_os * OSZ);                  // gather rows of the piece
+    int* const Kx = Ix + PG_PIECE * PT;                       // offsets (+ chain flags) of the piece's tiles
+    __shared__ int pool_unit;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const bool mma = wave < 4;                                // consumer (MFMA) wave / producer (memory) wave
+    const int wv = wave & 3;                                  // consumer: its 32 rows of the tile; producer: its quarter of the staging work
+    const int j = lane & 31, h = lane >> 5;
+    const int r8 = lane >> 3, s8 = lane & 7;                  // producer: row within a group of eight, 16-byte segment of the 128-byte row
+    const int n_real = dense ? (int)((p.dense_rows + PT - 1) / PT) : p.tile_k[p.n_tiles];
+    const int nchunks = p.Cin >> 5;
+    const bool pool = p.pool_ctr != nullptr && nchunks >= 3 && n_real >= 6 * (int)gridDim.x;
+    int n_static = n_real;
+    const int unit = (6 + nchunks - 1) / nchunks;
+    if (pool) {
+        if (tid == 0) pool_claim(p.pool_ctr + blockIdx.y, p.pool_epoch);
+        n_static = (int)((int64_t)n_real * 13 / 16);
+        if (p.chained) while (n_static < n_real && (p.tile_k[n_static - 1] & PG_CHAIN)) ++n_static;
+    }
+    int range0 = (int)((int64_t)blockIdx.x * n_static / gridDim.x);
+    int range1 = (int)((int64_t)(blockIdx.x + 1) * n_static / gridDim.x);
+    if (p.chained) {
+        while (range0 > 0 && range0 < n_static && (p.tile_k[range0 - 1] & PG_CHAIN)) ++range0;
+        while (range1 > 0 && range1 < n_static && (p.tile_k[range1 - 1] & PG_CHAIN)) ++range1;
+    }
+    if (range1 <= range0 && !pool) return;
+    const int ncol0 = blockIdx.y * NT * 32;
+    const uint64_t wstride_b = (uint64_t)p.Cout * (uint64_t)p.Cin * 4ull;
+    const bool full_cols = ncol0 + NT * 32 <= p.Cout;
+    bool poisoned = false;
+    int fallback_round = 0;
+
+    // consumer state
+    f32x16 acc[NT];
+    const f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    bool fresh = true;
+    // producer state: two register sets (steps of even / odd parity), byte offsets of its weight rows fixed for the launch
+    f32x4 ga0[4], ga1[4], gw0[NT], gw1[NT];
+    uint32_t woff[NT];
+#pragma unroll
+    for (int i = 0; i < NT; ++i) {
+        int n = ncol0 + wv * (NT * 8) + i * 8 + r8;
+        n = n < p.Cout ? n : p.Cout - 1;
+        woff[i] = (uint32_t)(n * p.Cin + s8 * 4) * 4u;
+    }
+    auto issue = [&](f32x4 (&ga)[4], f32x4 (&gw)[NT], int lt, int c, int kf) {          // the requests of step (tile lt of the piece, chunk c)
+        const int cc = c * 32;
+        const bool first = cc < p.C0;
+        const char* base = (const char*)(first ? p.in0 : p.in1) + (uint32_t)((first ? cc : cc - p.C0) + s8 * 4) * 4u;
+        const uint32_t ld4 = (uint32_t)(first ? p.ld0 : p.ld1) * 4u;
+        const int* ix = Ix + lt * PT + wv * 32 + r8;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) ga[i] = *(const f32x4*)(base + (uint64_t)(uint32_t)(PG_DBG(p, 2) ? 0 : ix[i * 8]) * ld4);
+        if (PG_DBG(p, 4)) { kf = 0; c = 0; }
+        const char* Wk = (const char*)p.wt + (uint64_t)(uint32_t)(kf & PG_KMASK) * wstride_b + (uint32_t)c * 128u;
+#pragma unroll
+        for (int i = 0; i < NT; ++i) gw[i] = *(const f32x4*)(Wk + woff[i]);
+    };
+    auto put = [&](const f32x4 (&ga)[4], const f32x4 (&gw)[NT], int st) {
+        float* a = As + st * ASZ + (wv * 32 + r8) * PC_LD + s8 * 4;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) *(f32x4*)(a + i * 8 * PC_LD) = ga[i];
+        float* w = Ws + st * WSZ + (wv * (NT * 8) + r8) * PC_LD + s8 * 4;
+#pragma unroll
+        for (int i = 0; i < NT; ++i) *(f32x4*)(w + i * 8 * PC_LD) = gw[i];
+    };
+    // a finished tile: Os -> memory.  A producer wave owns 32 rows; an instruction moves 64 / (8 NT) whole rows of 32 NT floats
+    constexpr int LPR = NT * 8, RPI = 64 / LPR, NOUT = (32 + RPI - 1) / RPI;
+    auto copy_out = [&](int tile, int par) {
+        if (PG_DBG(p, 1)) return;
+        const bool act_lane = lane < RPI * LPR;
+        const int rr = lane / LPR, cs = (lane - rr * LPR) * 4;
+        const float* o = Os + par * OSZ + (wv * 32 + rr) * LDO + cs;
+        const int c = ncol0 + cs;
+        constexpr int HB = DIRECT ? (NOUT + 3) / 4 : (NOUT + 1) / 2;    // batches of requests (registers: the accumulators of the consumer role are allocated in every wave)
+#pragma unroll
+        for (int b0 = 0; b0 < NOUT; b0 += HB) {
+            f32x4 v[HB];
+#pragma unroll
+            for (int i = 0; i < HB; ++i) v[i] = *(const f32x4*)(o + ((b0 + i) * RPI < 32 - rr ? (b0 + i) * RPI : 0) * LDO);
+#pragma unroll
+            for (int i = 0; i < HB; ++i) {
+                const int ri = (b0 + i) * RPI + rr;
+                if (b0 + i >= NOUT || !act_lane || ri >= 32 || !(full_cols || c < p.Cout)) continue;
+                const int64_t prow = (int64_t)tile * PT + wv * 32 + ri;
+                if (DIRECT) {
+                    const int64_t orow = dense ? (prow < p.dense_rows ? prow : -1) : (int64_t)p.out_idx[prow];
+                    if (orow >= 0) {
+                        f32x4 y;
+#pragma unroll
+                        for (int u = 0; u < 4; ++u) y[u] = pg_affine(v[i][u], p.scale, p.shift, c + u);
+                        if (p.res) y += *(const f32x4*)(p.res + orow * p.ld_res + c);
+                        *(f32x4*)(p.out + orow * p.ld_out + c) = f32x4{pg_act(y[0], p.act), pg_act(y[1], p.act), pg_act(y[2], p.act), pg_act(y[3], p.act)};
+                    }
+                } else {
+                    PART_STORE4(p.part + prow * p.Cout + c, v[i]);
+                }
+            }
+        }
+    };
+
+  for (;;) {
+    for (int piece0 = range0; piece0 < range1; piece0 += PG_PIECE) {
+        const int ntl = range1 - piece0 < PG_PIECE ? range1 - piece0 : PG_PIECE;
+        __syncthreads();
+        if (dense) {
+            for (int f = tid; f < ntl * PT; f += 512) {
+                const int64_t r = (int64_t)piece0 * PT + f;
+                Ix[f] = (int)(r < p.dense_rows ? r : p.dense_rows - 1);
+            }
+            if (tid < PG_PIECE + 2) Kx[tid] = 0;
+        } else {
+            for (int f = tid; f < ntl * PT; f += 512) {
+                const int v = p.in_idx[(int64_t)piece0 * PT + f];
+                Ix[f] = v < 0 ? 0 : v;
+            }
+            if (tid < PG_PIECE + 2) Kx[tid] = tid < ntl ? p.tile_k[piece0 + tid] : 0;
+        }
+        __syncthreads();
+        const int nsteps = ntl * nchunks;
+        int k_cur = __builtin_amdgcn_readfirstlane(Kx[0]), k_nxt = __builtin_amdgcn_readfirstlane(Kx[1]);
+        int pf_t = 0, pf_c = 0;                                 // the producers' request pointer = step s + 2
+#define PC_ADVANCE() do { if (++pf_c == nchunks) { pf_c = 0; ++pf_t; } } while (0)
+#define PC_TILE() (pf_t < ntl ? pf_t : ntl - 1)
+        if (!mma) {
+            { const int t_ = PC_TILE(); issue(ga0, gw0, t_, pf_c, Kx[t_]); } PC_ADVANCE();
+            { const int t_ = PC_TILE(); issue(ga1, gw1, t_, pf_c, Kx[t_]); } PC_ADVANCE();
+            put(ga0, gw0, 0);
+        } else {
+            PC_ADVANCE(); PC_ADVANCE();
+        }
+        __syncthreads();
+        int buf = 0, cur_lt = 0, cur_c = 0, s = 0;
+        int out_tile = -1, out_par = 0, os_par = 0;             // a tile waiting in Os[out_par]; the Os slot the next finished tile takes
+#define PC_STEP(PUT_A, PUT_W, LD_A, LD_W)                                                                            \
+    {                                                                                                                 \
+        const bool has_next = s + 1 < nsteps;                                                                         \
+        const bool last_chunk = cur_c + 1 == nchunks;                                                                 \
+        const bool tile_done = last_chunk && !(k_cur & PG_CHAIN);                                                     \
+        const int k_after = Kx[cur_lt + 2];                                                                           \
+        if (mma) {                                                                                                    \
+            const float* wb = Ws + buf * WSZ + j * PC_LD + h * 16;                                                    \
+            const float* ab = As + buf * ASZ + (wv * 32 + j) * PC_LD + h * 16;                                        \
+            f32x4 a[4], wq[2][NT];                                                                                    \
+            _Pragma("unroll") for (int q = 0; q < 4; ++q) a[q] = *(const f32x4*)(ab + q * 4);                         \
+            _Pragma("unroll") for (int t = 0; t < NT; ++t) wq[0][t] = *(const f32x4*)(wb + t * 32 * PC_LD);           \
+            _Pragma("unroll") for (int q = 0; q < 4; ++q) {                                                           \
+                if (q < 3) {    /* the next group's weight fragments are requested BEFORE this group's MFMAs (pinned: hipcc sinks them behind the MFMAs otherwise) */ \
+                    _Pragma("unroll") for (int t = 0; t < NT; ++t) wq[(q + 1) & 1][t] = *(const f32x4*)(wb + t * 32 * PC_LD + (q + 1) * 4); \
+                }                                                                                                     \
+                __builtin_amdgcn_sched_barrier(0);                                                                    \
+                _Pragma("unroll") for (int e = 0; e < 4; ++e) {                                                       \
+                    if (q == 0 && e == 0) {                                                                           \
+                        if (fresh) {                                                                                  \
+                            _Pragma("unroll") for (int t = 0; t < NT; ++t)                                            \
+                                acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(wq[0][t][0], a[0][0], zero16, 0, 0, 0); \
+                        } else {                                                                                      \
+                            _Pragma("unroll") for (int t = 0; t < NT; ++t)                                            \
+                                acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(wq[0][t][0], a[0][0], acc[t], 0, 0, 0); \
+                        }                                                                                             \
+                    } else {                                                                                          \
+                        _Pragma("unroll") for (int t = 0; t < NT; ++t)                                                \
+                            acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(wq[q & 1][t][e], a[q][e], acc[t], 0, 0, 0); \
+                    }                                                                                                 \
+                }                                                                                                     \
+                __builtin_amdgcn_sched_barrier(0);                                                                    \
+            }                                                                                                         \
+            if (tile_done && !(PG_DBG(p, 32) && p.Cin > 0)) {     /* lane = pair row, register group g = columns 8g + 4h .. + 3 of column block t */   \
+                float* o = Os + os_par * OSZ + (wv * 32 + j) * LDO + 4 * h;                                           \
+                _Pragma("unroll") for (int t = 0; t < NT; ++t)                                                        \
+                    _Pragma("unroll") for (int g = 0; g < 4; ++g)                                                     \
+                        *(f32x4*)(o + t * 32 + 8 * g) = f32x4{acc[t][4 * g], acc[t][4 * g + 1], acc[t][4 * g + 2], acc[t][4 * g + 3]}; \
+            }                                                                                                         \
+            fresh = tile_done;                                                                                        \
+        } else {                                                                                                      \
+            if (out_tile >= 0) copy_out(out_tile, out_par);     /* the tile finished one step ago */                  \
+            if (has_next) put(PUT_A, PUT_W, buf ^ 1);                                                                 \
+            if (s + 2 < nsteps) { const int t_ = PC_TILE(); issue(LD_A, LD_W, t_, pf_c, Kx[t_]); }                    \
+        }                                                                                                             \
+        PC_ADVANCE();                                                                                                 \
+        out_tile = tile_done ? piece0 + cur_lt : -1;                                                                  \
+        out_par = os_par;                                                                                             \
+        if (tile_done && n_os > 1) os_par ^= 1;                                                                       \
+        __syncthreads();                                                                                              \
+        if (!has_next) break;                                                                                         \
+        buf ^= 1;                                                                                                     \
+        ++s;                                                                                                          \
+        if (last_chunk) {                                                                                             \
+            cur_c = 0; ++cur_lt;                                                                                      \
+            k_cur = k_nxt; k_nxt = __builtin_amdgcn_readfirstlane(k_after);                                           \
+        } else {                                                                                                      \
+            ++cur_c;                                                                                                  \
+        }                                                                                                             \
+    }
+        for (;;) {
+            PC_STEP(ga1, gw1, ga0, gw0)
+            PC_STEP(ga0, gw0, ga1, gw1)
+        }
+#undef PC_STEP
+#undef PC_ADVANCE
+#undef PC_TILE
+        if (!mma && out_tile >= 0) copy_out(out_tile, out_par);  // the piece's last tile (the barrier at the top of the next piece / of the pool draw frees Os)
+    }
+    if (!pool) break;
+    __syncthreads();
+    if (tid == 0) {
+        unsigned int d = poisoned ? POOL_POISONED : pool_draw(p.pool_ctr + blockIdx.y, p.pool_epoch);
+        if (d == POOL_POISONED) {
+            if (!poisoned) atomicAdd(&g_pool_bad_seen, 1u);
+            d = blockIdx.x + (unsigned)fallback_round * gridDim.x;
+            pool_unit = -1 - (int)d;
+        } else {
+            pool_unit = (int)d;
+        }
+    }
+    __syncthreads();
+    int u = __builtin_amdgcn_readfirstlane(pool_unit);
+    if (u < 0) { poisoned = true; ++fallback_round; u = -1 - u; }
+    range0 = n_static + u * unit;
+    if (range0 >= n_real) break;
+    range1 = range0 + unit < n_real ? range0 + unit : n_real;
+    if (p.chained) {
+        while (range0 < n_real && (p.tile_k[range0 - 1] & PG_CHAIN)) ++range0;
+        while (range1 < n_real && (p.tile_k[range1 - 1] & PG_CHAIN)) ++range1;
+    }
+  }
+}
+
+static size_t pair_pc_lds_bytes(int nt, int n_os) {
+    return (size_t)(2 * nt * 32 * PC_LD + 2 * PT * PC_LD + n_os * PT * (nt * 32 + 4)) * sizeof(float) + (size_t)(PG_PIECE * PT + PG_PIECE + 2) * sizeof(int);
+}
+#define PAIR_GEMM_PC_ENTRY(NAME, NT, MODE)                                                                           \
+    __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) void NAME(const PGParams p, const int n_os) { \
+        extern __shared__ __attribute__((aligned(16))) float pc_smem[];                                              \
+        pair_gemm_pc_body<NT, MODE>(p, pc_smem, n_os);                                                               \
+    }
+PAIR_GEMM_PC_ENTRY(pair_gemm_pc_kernel_1, 1, 0)
+PAIR_GEMM_PC_ENTRY(pair_gemm_pc_kernel_2, 2, 0)
+PAIR_GEMM_PC_ENTRY(pair_gemm_pc_kernel_3, 3, 0)
+PAIR_GEMM_PC_ENTRY(pair_gemm_pc_kernel_4, 4, 0)
+PAIR_GEMM_PC_ENTRY(pair_gemm_pc_direct_kernel_1, 1, 1)
+PAIR_GEMM_PC_ENTRY(pair_gemm_pc_direct_kernel_2, 2, 1)
+PAIR_GEMM_PC_ENTRY(pair_gemm_pc_direct_kernel_3, 3, 1)
+PAIR_GEMM_PC_ENTRY(pair_gemm_pc_direct_kernel_4, 4, 1)
+PAIR_GEMM_PC_ENTRY(pair_dense_pc_kernel_1, 1, 2)
+PAIR_GEMM_PC_ENTRY(pair_dense_pc_kernel_2, 2, 2)
+PAIR_GEMM_PC_ENTRY(pair_dense_pc_kernel_3, 3, 2)
+PAIR_GEMM_PC_ENTRY(pair_dense_pc_kernel_4, 4, 2)
+
+#endif  // SD3D_WITH_PC
 
 // ---- pass 1, weight-stationary variant ----------------------------------------------------------
 // For layers whose whole W[k] (Cout x Cin fp32, Cout = 32*NT <= 128) fits in LDS next to a second
@@ -1289,6 +1596,9 @@ __global__ __launch_bounds__(256) void pair_reduce_rl_kernel(const PRLParams p) 
 
 // ---- the shared tail's host side ------------------------------------------------------------------
 #define PG_MAX_DEVICES 64
+#ifndef SD3D_PAIR_PC_DEFAULT
+#define SD3D_PAIR_PC_DEFAULT 0
+#endif
 static std::atomic<unsigned long long*> g_pool_bases[PG_MAX_DEVICES];
 static std::atomic<unsigned long long> g_pool_tickets[PG_MAX_DEVICES];        // pooled launches handed out so far, per device
 static std::atomic<int> g_pool_on{-1};                                         // -1: not decided yet (SD3D_PAIR_POOL, default 1)
@@ -1303,22 +1613,93 @@ static bool pool_enabled() {
     }
     return v != 0;
 }
+#ifdef SD3D_WITH_PC
+// pass-1 variant: 0 = lock-step / weight-stationary by the launcher's rules (rounds 1-5), 1 = the producer / consumer kernel wherever the
+// lock-step kernel would run, 2 = everywhere (SD3D_PAIR_PC; sd3d_set_pair_pc at run time: tests compare the variants bit for bit in one process)
+static std::atomic<int> g_pc_mode{-1};
+static int pair_pc_mode() {
+    int v = g_pc_mode.load(std::memory_order_relaxed);
+    if (v < 0) {
+        const char* e = getenv("SD3D_PAIR_PC");
+        v = e ? atoi(e) : SD3D_PAIR_PC_DEFAULT;
+        int expected = -1;
+        g_pc_mode.compare_exchange_strong(expected, v);
+        v = g_pc_mode.load(std::memory_order_relaxed);
+    }
+    return v;
+}
+extern "C" int sd3d_set_pair_pc(int mode) {
+    const int prev = pair_pc_mode();
+    g_pc_mode.store(mode < 0 ? 0 : (mode > 2 ? 2 : mode), std::memory_order_relaxed);
+    return prev;
+}
+template <class K>
+static void pc_launch(K kern, dim3 grid, size_t lds, hipStream_t st, const PGParams& g, int n_os) {
+    static thread_local const void* done[16];                  // (attribute set once per kernel and thread; the call is cheap and idempotent)
+    bool seen = false;
+    for (const void* d : done) if (d == (const void*)kern) seen = true;
+    if (!seen) {
+        (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256);   // (the kernel also has a few static bytes)
+        for (auto& d : done) if (!d) { d = (const void*)kern; break; }
+    }
+    hipLaunchKernelGGL(kern, grid, dim3(512), lds, st, g, n_os);
+}
+// -> true when the producer / consumer kernel took the launch
+static bool launch_pair_pc(PGParams& g, int nt, int cgs, int mode_kernel, int n_cu, int64_t n_tiles, hipStream_t st) {
+    const int n_os = (g.Cin >> 5) == 1 ? 2 : 1;                // one-step tiles finish back to back: two staging slots
+    const size_t lds = pair_pc_lds_bytes(nt, n_os);
+    if (lds > 160 * 1024 - 256) return false;
+    int gx = n_cu / cgs;
+    gx = gx < 1 ? 1 : (gx < n_tiles ? gx : (int)n_tiles);
+    { static int gx_env = -1; if (gx_env < 0) { const char* e = getenv("SD3D_PAIR_GX"); gx_env = e ? atoi(e) : 0; } if (gx_env > 0) gx = gx_env; }
+    const dim3 grid((unsigned)gx, (unsigned)cgs);
+    if (mode_kernel == 0) {
+        switch (nt) {
+            case 1: pc_launch(pair_gemm_pc_kernel_1, grid, lds, st, g, n_os); break;
+            case 2: pc_launch(pair_gemm_pc_kernel_2, grid, lds, st, g, n_os); break;
+            case 3: pc_launch(pair_gemm_pc_kernel_3, grid, lds, st, g, n_os); break;
+            default: pc_launch(pair_gemm_pc_kernel_4, grid, lds, st, g, n_os); break;
+        }
+    } else if (mode_kernel == 1) {
+        switch (nt) {
+            case 1: pc_launch(pair_gemm_pc_direct_kernel_1, grid, lds, st, g, n_os); break;
+            case 2: pc_launch(pair_gemm_pc_direct_kernel_2, grid, lds, st, g, n_os); break;
+            case 3: pc_launch(pair_gemm_pc_direct_kernel_3, grid, lds, st, g, n_os); break;
+            default: pc_launch(pair_gemm_pc_direct_kernel_4, grid, lds, st, g, n_os); break;
+        }
+    } else {
+        switch (nt) {
+            case 1: pc_launch(pair_dense_pc_kernel_1, grid, lds, st, g, n_os); break;
+            case 2: pc_launch(pair_dense_pc_kernel_2, grid, lds, st, g, n_os); break;
+            case 3: pc_launch(pair_dense_pc_kernel_3, grid, lds, st, g, n_os); break;
+            default: pc_launch(pair_dense_pc_kernel_4, grid, lds, st, g, n_os); break;
+        }
+    }
+    return true;
+}
+#endif  // SD3D_WITH_PC
 extern "C" int sd3d_set_pair_pool(int on) {
     const int prev = pool_enabled() ? 1 : 0;
     g_pool_on.store(on ? 1 : 0, std::memory_order_relaxed);
     return prev;
 }
 // Number of counter words of the current device's ring in a state no sequence of finished launches leaves behind (an epoch the host has
-// not handed out for that slot, or anything in a slot no launch has used); 0 is the healthy answer.  Synchronises the device.  < 0: error.
+// not handed out for that slot, or anything in a slot no launch has used) + the workgroups that met such a word since the last call (they
+// fell back to a static split of their pool: the results are unaffected, the event is reported here and through sd3d_last_error);
+// 0 is the healthy answer.  Synchronises the device.  < 0: error.
 extern "C" int sd3d_pair_pool_check(void) {
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= PG_MAX_DEVICES) { sd3d_set_error(SD3D_ERR_LAUNCH, "pair_pool_check: no device"); return -1; }
     if (hipDeviceSynchronize() != hipSuccess) { sd3d_set_error(SD3D_ERR_LAUNCH, "pair_pool_check: device synchronisation failed"); return -1; }
-    unsigned int zero = 0, bad = 0;
+    unsigned int zero = 0, bad = 0, seen = 0;
     if (hipMemcpyToSymbol(HIP_SYMBOL(g_pool_bad), &zero, sizeof(zero)) != hipSuccess) { sd3d_set_error(SD3D_ERR_LAUNCH, "pair_pool_check: symbol write failed"); return -1; }
     hipLaunchKernelGGL(pool_check_kernel, dim3(PG_POOL_SLOTS / 256), dim3(256), 0, nullptr, g_pool_tickets[dev].load(std::memory_order_relaxed));
     if (hipGetLastError() != hipSuccess || hipDeviceSynchronize() != hipSuccess ||
-        hipMemcpyFromSymbol(&bad, HIP_SYMBOL(g_pool_bad), sizeof(bad)) != hipSuccess) { sd3d_set_error(SD3D_ERR_LAUNCH, "pair_pool_check: check kernel failed"); return -1; }
+        hipMemcpyFromSymbol(&bad, HIP_SYMBOL(g_pool_bad), sizeof(bad)) != hipSuccess ||
+        hipMemcpyFromSymbol(&seen, HIP_SYMBOL(g_pool_bad_seen), sizeof(seen)) != hipSuccess ||
+        hipMemcpyToSymbol(HIP_SYMBOL(g_pool_bad_seen), &zero, sizeof(zero)) != hipSuccess) { sd3d_set_error(SD3D_ERR_LAUNCH, "pair_pool_check: check kernel failed"); return -1; }
+    if (seen) sd3d_set_error(SD3D_ERR_LAUNCH, "pair_pool_check: launches met counter words no launch can have written (they fell back to a static split of their shared tail: results unaffected)");
+    bad += seen;                                               // (workgroups that fell back since the last check)
     return (int)bad;
 }
 // pooled launches so far on the current device (tests: did the pool really run?)
@@ -1518,6 +1899,9 @@ int launch_pair_conv(const float* in0, int ld0, int C0, const float* in1, int ld
     g.dense_rows = 0;
     g.pool_ctr = nullptr;
     g.pool_epoch = 0;
+#ifdef PG_ABLATE
+    g.dbg = pg_dbg_env();
+#endif
     g.out_idx = direct ? out_idx : nullptr;
     g.scale = scale; g.shift = shift; g.res = res; g.ld_res = ld_res; g.out = out; g.ld_out = ld_out; g.act = act;
     const int sub = (Cout + 31) / 32;
@@ -1547,7 +1931,35 @@ int launch_pair_conv(const float* in0, int ld0, int C0, const float* in1, int ld
     if (ws2_env < 0) { const char* e = getenv("SD3D_PAIR_WS2"); ws2_env = e ? atoi(e) : 1; }
     // (measured: level-3 256->256, 1808 tiles: 358 -> 347 us; level-4, 472 tiles: 104 -> 113 us - too few tiles for half the workgroups)
     const bool ws_two = ws_env && !g.chained && ws2_env && !crowded && cgs == 2 && nt == 4 && Cout == 256 && g.n_tiles >= 1024 && w_lds_cg + WS_RANGE_TILES * PT * sizeof(int32_t) + 256 <= 160 * 1024;
-    if (ws_one || ws_two) {
+    auto setup_pool = [&]() {
+    if (pool_enabled() && cgs <= PG_POOL_WORDS) {           // the shared tail (sd3d_set_pair_pool / SD3D_PAIR_POOL=0: every tile dealt out statically, rounds 1-4)
+        // (the counters are a per-device symbol: a process that drives several GPUs gets each device's own address and its own tickets)
+        int dev = 0;
+        hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+        if (hipGetDevice(&dev) == hipSuccess && dev >= 0 && dev < PG_MAX_DEVICES &&
+            (st == nullptr || (hipStreamIsCapturing(st, &cap) == hipSuccess && cap == hipStreamCaptureStatusNone))) {
+            unsigned long long* base = g_pool_bases[dev].load(std::memory_order_acquire);
+            if (!base && hipGetSymbolAddress((void**)&base, HIP_SYMBOL(g_pool_ctr)) == hipSuccess)
+                g_pool_bases[dev].store(base, std::memory_order_release);
+            if (base) {
+                const unsigned long long t = g_pool_tickets[dev].fetch_add(1, std::memory_order_relaxed);
+                g.pool_ctr = base + (size_t)(t % PG_POOL_SLOTS) * PG_POOL_WORDS;
+                g.pool_epoch = (unsigned int)(t / PG_POOL_SLOTS + 1);
+            }
+        }
+    }
+    };
+    bool pc_done = false;
+#ifdef SD3D_WITH_PC
+    const int pc_mode = pair_pc_mode();
+    if (pc_mode == 2 || (pc_mode == 1 && !(ws_one || ws_two))) {
+        setup_pool();
+        pc_done = launch_pair_pc(g, nt, cgs, direct ? 1 : 0, n_cu, g.n_tiles, st);
+        if (!pc_done) { g.pool_ctr = nullptr; g.pool_epoch = 0; }
+    }
+#endif
+    if (pc_done) {
+    } else if (ws_one || ws_two) {
         static bool attr_done = false;
         if (!attr_done) {
             (void)hipFuncSetAttribute((const void*)pair_gemm_ws_kernel_1, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
@@ -1592,22 +2004,7 @@ int launch_pair_conv(const float* in0, int ld0, int C0, const float* in1, int ld
         int gx = n_cu * per_cu / cgs;
         gx = gx < 1 ? 1 : (gx < g.n_tiles ? gx : g.n_tiles);
         const dim3 grid((unsigned)gx, (unsigned)cgs);
-        if (pool_enabled() && cgs <= PG_POOL_WORDS) {           // the shared tail (sd3d_set_pair_pool / SD3D_PAIR_POOL=0: every tile dealt out statically, rounds 1-4)
-            // (the counters are a per-device symbol: a process that drives several GPUs gets each device's own address and its own tickets)
-            int dev = 0;
-            hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
-            if (hipGetDevice(&dev) == hipSuccess && dev >= 0 && dev < PG_MAX_DEVICES &&
-                (st == nullptr || (hipStreamIsCapturing(st, &cap) == hipSuccess && cap == hipStreamCaptureStatusNone))) {
-                unsigned long long* base = g_pool_bases[dev].load(std::memory_order_acquire);
-                if (!base && hipGetSymbolAddress((void**)&base, HIP_SYMBOL(g_pool_ctr)) == hipSuccess)
-                    g_pool_bases[dev].store(base, std::memory_order_release);
-                if (base) {
-                    const unsigned long long t = g_pool_tickets[dev].fetch_add(1, std::memory_order_relaxed);
-                    g.pool_ctr = base + (size_t)(t % PG_POOL_SLOTS) * PG_POOL_WORDS;
-                    g.pool_epoch = (unsigned int)(t / PG_POOL_SLOTS + 1);
-                }
-            }
-        }
+        setup_pool();
         if (direct) {
             switch (nt) {
                 case 1: hipLaunchKernelGGL(pair_gemm_direct_kernel_1, grid, dim3(256), 0, st, g); break;
@@ -1656,11 +2053,20 @@ int launch_pair_dense(const GGParams& q, hipStream_t st) {
     g.in0 = q.in0; g.ld0 = q.ld0; g.C0 = q.in1 ? q.C0 : q.Cin; g.in1 = q.in1; g.ld1 = q.ld1; g.in_idx = nullptr; g.tile_k = nullptr; g.wt = q.wt;
     g.Cin = q.Cin; g.Cout = q.Cout; g.part = nullptr; g.n_tiles = 0; g.out_idx = nullptr; g.scale = q.scale; g.shift = q.shift; g.res = q.res;
     g.ld_res = q.ld_res; g.out = q.out; g.ld_out = q.ld_out; g.act = q.act; g.nt_part = 0; g.chained = 0; g.dense_rows = q.M; g.pool_ctr = nullptr; g.pool_epoch = 0;
+#ifdef PG_ABLATE
+    g.dbg = pg_dbg_env();
+#endif
     const int sub = (q.Cout + 31) / 32;
     int nt = sub >= 4 ? 4 : sub;
     if (sub > 4 && sub % 4) { for (int c = 4; c >= 1; --c) if (sub % c == 0) { nt = c; break; } }
     const int cgs = (int)cdiv(sub, nt);
     const int64_t tiles = cdiv(q.M, PT);
+#ifdef SD3D_WITH_PC
+    if (pair_pc_mode() >= 1 && launch_pair_pc(g, nt, cgs, 2, n_cu, tiles, st)) {
+        SD3D_CHECK_LAUNCH();
+        return SD3D_OK;
+    }
+#endif
     int gx = n_cu * (nt == 1 ? 3 : 2) / cgs;
     gx = gx < 1 ? 1 : (gx < tiles ? gx : (int)tiles);
     const dim3 grid((unsigned)gx, (unsigned)cgs);

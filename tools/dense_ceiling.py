@@ -44,6 +44,9 @@ for lvl, cin, cout, P in shapes:
     out = torch.empty(P, cout, device=d)
     flops = 2.0 * P * cin * cout
     t_ls = timeit(lambda: ops.gather_gemm(x, w, out=out))
+    if os.environ.get("CEIL_ONLY_LS") == "1":
+        print(f"| {lvl} | {cin} -> {cout} | {P} | {t_ls:.0f} ({flops / t_ls / 1e6:.1f}, {flops / t_ls / 1e6 / PEAK:.2f}) | | |")
+        continue
     nbr = torch.arange(P, dtype=torch.int32, device=d).view(1, P)
     pl = ops.pair_lists(nbr, P, direct=True)
     t_ws = timeit(lambda: ops.pair_conv(x, w, pl, out=out))
