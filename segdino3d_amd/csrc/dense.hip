@@ -341,10 +341,6 @@ typedef __bf16 abf16x8 __attribute__((ext_vector_type(8)));
 // the VALU, not the matrix pipe, bounded the kernel at one query per superpoint - 42 % pipe busy).  M / lse leave the kernel
 // converted back to natural units.  The next tile's keys and mask word are requested while the current tile multiplies, and a
 // key tile whose 32 x 32 mask block is all "blocked" is skipped before its keys are touched (wave-uniform).
-#ifndef SD3D_ATTN_STAGGER_DEFAULT
-#define SD3D_ATTN_STAGGER_DEFAULT 0
-#endif
-__device__ int g_attn_stagger;       // start-up delay of the second wave of every SIMD, in units of 512 cycles (launch_attention sets it)
 #define SD3D_LOG2E 1.4426950408889634f
 #define SD3D_LN2 0.6931471805599453f
 template <int NSRC, bool BF16>
@@ -404,13 +400,6 @@ __device__ __forceinline__ void attention_body(const AttnParams& p, const int bx
     constexpr bool KPF = !BF16;                         // next tile's keys in flight while this one multiplies: fp32 187 vs 198 us at Q = S = 3000;
                                                         // the bf16 kernel is better off with the registers (4 waves per SIMD: 91 vs 105 us)
     int t = blockIdx.z * nw + wave;
-    // The two waves of a SIMD (waves w and w + nw / 2 of an eight-wave workgroup) run the same code on the same data shapes: left alone they
-    // multiply together - sharing the matrix pipe - and exponentiate together - leaving it idle.  The second one starts part of a key tile late,
-    // so that one wave's softmax runs beside the other's MFMA chain; the offset sustains itself (whoever finds the pipe free runs ahead).
-    if (nw == 8 && wave >= 4) {
-        const int st_n = g_attn_stagger;
-        for (int d = 0; d < st_n; ++d) __builtin_amdgcn_s_sleep(8);
-    }
     uint32_t word = load_word(t);
     f32x4 kcur[NSRC][4], knxt[NSRC][4];
     if (KPF && t < ntiles) load_k(kcur, t);
@@ -625,15 +614,6 @@ static void attention_config(int Lq, int Lk, int H, bool have_ws, size_t ws_byte
 
 int launch_attention(const AttnParams& p_in, int nsrc, void* ws, size_t ws_bytes, hipStream_t st, bool merge = true) {
     AttnParams p = p_in;
-    {   // SD3D_ATTN_STAGGER: see attention_body (units of 512 cycles; default below)
-        static thread_local int done_dev = -1;
-        int dev = 0;
-        if (hipGetDevice(&dev) == hipSuccess && dev != done_dev) {
-            static const int v = [] { const char* e = getenv("SD3D_ATTN_STAGGER"); return e ? atoi(e) : SD3D_ATTN_STAGGER_DEFAULT; }();
-            (void)hipMemcpyToSymbolAsync(HIP_SYMBOL(g_attn_stagger), &v, sizeof(int), 0, hipMemcpyHostToDevice, st);
-            done_dev = dev;
-        }
-    }
     if (p.Lq <= 0 || p.Lk <= 0) return sd3d_set_error(SD3D_ERR_ARG, "attention: empty query or key set");
     for (int s = 0; s < nsrc; ++s)
         if ((p.ldq[s] & 3) || (p.ldk[s] & 3)) return sd3d_set_error(SD3D_ERR_ARG, "attention: q/k strides must be multiples of 4");
