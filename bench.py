@@ -268,10 +268,12 @@ def main():
                     help="synth.make_scene layout: 'benchmark' = the scene of every reported number; 'scan' = mesh-like surface sampling")
     ap.add_argument("--streams", type=int, default=4,
                     help="scenes in flight per GPU (host threads x HIP streams, segdino3d_amd.dist_eval.PipelinedRunner)")
-    ap.add_argument("--batch", type=int, default=int(os.environ.get("SD3D_BENCH_BATCH", "4")),
+    ap.add_argument("--batch", type=int, default=int(os.environ.get("SD3D_BENCH_BATCH", "5")),
                     help="scenes per forward: > 1 runs them as ONE block-diagonal sparse tensor (sparse.BatchSceneMaps + the batched decoder, every "
-                         "scene's outputs bit-identical to its single-scene forward); each stream then keeps a whole batch in flight.  Default 4: "
-                         "same scenes/s as 1 within 1-2 %, convolutions 7 % faster (4 x the tiles per launch); `single_scene` is always one scene per forward")
+                         "scene's outputs bit-identical to its single-scene forward); each stream then keeps a whole batch in flight.  Default 5 "
+                         "(round 6; 4 before): the driver's 20 steps on 4 streams are then ONE forward of 5 scenes per stream instead of forwards of 2 + 3 "
+                         "(convolutions 7.10 -> 6.83 ms per scene, `value` 124.1 -> 126.3 in the same-box sweep profiles/r06_ab_driver_batch.txt); "
+                         "`single_scene` is always one scene per forward")
     ap.add_argument("--decoder-dtype", choices=("fp32", "bf16"), default=os.environ.get("SD3D_DECODER_DTYPE", "fp32"),
                     help="bf16 = BASELINE configs[2]: bf16-MFMA attention contractions and projections, fp32 accumulation")
     ap.add_argument("--forward-sizes", default="", help="e.g. '2,3': every stream cuts its scenes into forwards of these sizes, cyclically, in "
