@@ -306,6 +306,11 @@ int sd3d_pair_conv(const float* in0, int ld0, int C0, const float* in1, int ld1,
  * these tables pos is not written (may be NULL: a row's partial positions are its rlist), rlist is required (rl_stride >= K / 2 + 2), K <= 125, p_cap >=
  * pairs + 127 * (11 * (K / 2) + 1), and the same value goes to sd3d_pair_conv_ex / sd3d_run_layers as `center`. */
 #define SD3D_PAIR_CHAINED (-2)
+/* sd3d_pair_conv_ex only: `center` - 2 (i.e. -3 for plain, -4 for chained lists) = the same lists with the weight matrices taken in MIRRORED offset
+ * order, W[K - 1 - k] for offset k.  The input gradient of a stride-1 convolution is the forward convolution on the same table with the offsets
+ * mirrored and the matrices transposed (csrc/pair_wgrad.hip header): a parameter kept as [K, Cin, Cout] (ME.MinkowskiConvolution.kernel) IS that
+ * transposed set, so the training step passes it as it lies - no flipped / transposed copy per layer and step. */
+#define SD3D_PAIR_MIRROR_W(center) ((center) - 2)
 typedef struct sd3d_pair_table_desc {
     const int32_t* nbr;                  /* [K, M] */
     int32_t *pos, *in_idx, *tile_k;      /* as sd3d_pair_lists */
@@ -709,7 +714,8 @@ int sd3d_elastic_displace(float* coords, int64_t n, const float* noise, int D0, 
  * (`x.grad = dy @ W` of every nn.Linear in instance_seg_3d_decoder.py), made at once instead of one copy kernel per weight. */
 typedef struct sd3d_transpose_job {
     const float* src; float* dst;
-    int32_t rows, cols, ld_dst, pad_;
+    int32_t rows, cols, ld_dst, batch;   /* batch > 1: that many matrices back to back in src ([rows, cols] each) and dst ([cols, ld_dst] each): the
+                                          * [K, Cin, Cout] -> [K, Cout, Cin] weights of a sparse convolution as ONE job (0 / 1: one matrix) */
 } sd3d_transpose_job;
 int sd3d_transpose_batch(int n, const sd3d_transpose_job* jobs, void* stream);
 int sd3d_act_backward(const float* dy, int ld_dy, const float* ref, int ld_ref, int act, int64_t M, int C, int C_pad, float* g, int ld_g,

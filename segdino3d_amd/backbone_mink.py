@@ -18,6 +18,7 @@ autograd nodes over HIP kernels).
 from __future__ import annotations
 
 import math
+import os
 from typing import List
 
 import torch
@@ -33,6 +34,10 @@ BN_EPS = 1e-5      # MinkowskiBatchNorm wraps nn.BatchNorm1d with the default ep
 # block-diagonal sparse tensor, sparse.BatchSceneMaps)
 import os as _os
 BATCH_EVAL = _os.environ.get("SD3D_BATCH_EVAL", "1") != "0"
+
+
+# SD3D_NATIVE_TRAIN_WEIGHTS=0: the round-2 training path (a permuted autograd copy per convolution and step, flipped / transposed copies in backward)
+NATIVE_TRAIN_WEIGHTS = os.environ.get("SD3D_NATIVE_TRAIN_WEIGHTS", "1") != "0"
 
 
 class MinkConv(nn.Module):
@@ -170,16 +175,25 @@ class Res16UNetBase(DerivedWeights):
     def packed_train(self):
         """name -> [K, Cout, Cin] autograd view of the live convolution parameter / the nn.BatchNorm1d module: what
         `_network` runs on with train_ops.TrainBackend (training step)."""
-        pk = {}
+        from . import train_ops
+        pk, kernels, pad = {}, {}, {}
         for n, m in self.named_modules():
             if isinstance(m, MinkConv):
-                w = m.kernel if m.kernel.dim() == 3 else m.kernel.unsqueeze(0)
-                w = w.permute(0, 2, 1)
-                if n == "conv0p1s1" and _round32(self.in_channels) > w.shape[2]:
-                    w = torch.nn.functional.pad(w, (0, _round32(self.in_channels) - w.shape[2]))
-                pk[n] = w.contiguous()
+                kernels[n] = m.kernel
+                if n == "conv0p1s1" and _round32(self.in_channels) > m.kernel.shape[-2]:
+                    pad[n] = _round32(self.in_channels)
             elif isinstance(m, MinkBN):
                 pk[n] = m.bn
+        if NATIVE_TRAIN_WEIGHTS:
+            # every [K, Cin, Cout] parameter -> the [K, Cout, Cin] copy the forward kernels read, in ONE launch; the backward reads the parameters as they lie
+            pk.update(train_ops.transpose_all(kernels, pad))
+        else:
+            for n, k in kernels.items():
+                w = k if k.dim() == 3 else k.unsqueeze(0)
+                w = w.permute(0, 2, 1)
+                if n in pad:
+                    w = torch.nn.functional.pad(w, (0, pad[n] - w.shape[2]))
+                pk[n] = w.contiguous()
         return pk
 
     # ---- network ---------------------------------------------------------------------------------

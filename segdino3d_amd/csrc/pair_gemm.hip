@@ -666,6 +666,7 @@ struct PGParams {
     int64_t dense_rows;                       // > 0: no lists at all - pair p is (in = out = row p) of a dense [rows, Cin] x W[0]^T product (direct epilogue)
     unsigned long long* pool_ctr;             // lock-step kernel: one {epoch, next unit} word per column group of this launch's slot, or NULL (static partition only)
     unsigned int pool_epoch;                  // this launch's epoch (never 0)
+    int k_flip;                               // >= 0: the weight matrix of offset k is W[k_flip - k] (mirrored offset order: SD3D_PAIR_MIRROR_W), -1: W[k]
 #ifdef PG_ABLATE
     int dbg;                                  // timing-only switches of the lab build (tools/ablate.sh): 1 no epilogue stores, 2 gathers from row 0, 4 weights from chunk 0, 8 no step barrier
 #endif
@@ -821,7 +822,8 @@ __device__ __forceinline__ void pair_gemm_body(const PGParams& p, float (*Bs)[NT
     float* const sts = &Bs[0][(tid >> 3) * PBS_LD + (tid & 7) * 4];         // + i * 32 rows, + buf * buffer
     auto stage_load = [&](int kf, int chunk) {
         if (PG_DBG(p, 4)) { kf = 0; chunk = 0; }
-        const char* Wk = (const char*)p.wt + (uint64_t)(uint32_t)(kf & PG_KMASK) * wstride_b + (uint32_t)chunk * 128u;    // scalar
+        const int kw = p.k_flip >= 0 ? p.k_flip - (kf & PG_KMASK) : (kf & PG_KMASK);
+        const char* Wk = (const char*)p.wt + (uint64_t)(uint32_t)kw * wstride_b + (uint32_t)chunk * 128u;    // scalar
 #pragma unroll
         for (int i = 0; i < NT; ++i) bst[i] = *(const f32x4*)(Wk + woff[i]);
     };
@@ -1085,7 +1087,8 @@ __device__ __forceinline__ void pair_gemm_pc_body(const PGParams& p, float* smem
 #pragma unroll
         for (int i = 0; i < 4; ++i) ga[i] = *(const f32x4*)(base + (uint64_t)(uint32_t)(PG_DBG(p, 2) ? 0 : ix[i * 8]) * ld4);
         if (PG_DBG(p, 4)) { kf = 0; c = 0; }
-        const char* Wk = (const char*)p.wt + (uint64_t)(uint32_t)(kf & PG_KMASK) * wstride_b + (uint32_t)c * 128u;
+        const int kw = p.k_flip >= 0 ? p.k_flip - (kf & PG_KMASK) : (kf & PG_KMASK);
+        const char* Wk = (const char*)p.wt + (uint64_t)(uint32_t)kw * wstride_b + (uint32_t)c * 128u;
 #pragma unroll
         for (int i = 0; i < NT; ++i) gw[i] = *(const f32x4*)(Wk + woff[i]);
     };
@@ -1340,7 +1343,7 @@ __device__ __forceinline__ void pair_gemm_ws_body(const PGParams& p, float* Ws) 
         while (run_end < ntl && p.tile_k[(tile0 + run_end)] == k) ++run_end;
         __syncthreads();                                       // everyone is done reading the previous W (and Ix is written)
         {
-            const float* __restrict__ W = p.wt + ((int64_t)k * p.Cout + ncol0) * p.Cin;
+            const float* __restrict__ W = p.wt + ((int64_t)(p.k_flip >= 0 ? p.k_flip - k : k) * p.Cout + ncol0) * p.Cin;
             // sixteen requests per thread in flight (four before round 5): staging W[k] was 4 - 8 dependent L2 round trips of ~1.5 us before
             // a workgroup's first MFMA - a fifth of a level-3 128 -> 128 launch, where a workgroup has 3.5 tiles.  Unconditional loads
             // (clamped), conditional LDS writes: no exec-masked load for the compiler to wait on.
@@ -1881,7 +1884,9 @@ int launch_pair_conv(const float* in0, int ld0, int C0, const float* in1, int ld
     // SD3D_PAIR_DIRECT / SD3D_PAIR_RL = 0 switch the round-3 paths off one by one (A/B, cross-checks in the tests)
     static const int direct_env = env_flag("SD3D_PAIR_DIRECT", 1), rl_env = env_flag("SD3D_PAIR_RL", 1);
     if ((ld_res & 3) && res) return sd3d_set_error(SD3D_ERR_ARG, "pair_conv: residual row stride must be a multiple of 4 floats");
-    if (center >= 0) return sd3d_set_error(SD3D_ERR_ARG, "pair_conv: center must be -1 or SD3D_PAIR_CHAINED (the dense centre kernel of round 3 left the library: profiles/EXPERIMENTS.md)");
+    const bool mirror_w = center == SD3D_PAIR_MIRROR_W(-1) || center == SD3D_PAIR_MIRROR_W(SD3D_PAIR_CHAINED);
+    if (mirror_w) center += 2;
+    if (center >= 0 || center < SD3D_PAIR_CHAINED) return sd3d_set_error(SD3D_ERR_ARG, "pair_conv: center must be -1 or SD3D_PAIR_CHAINED, or SD3D_PAIR_MIRROR_W of them (the dense centre kernel of round 3 left the library: profiles/EXPERIMENTS.md)");
     const bool direct = out_idx != nullptr && direct_env;
     // (lean evaluation tables carry no position table, 'up' tables no row lists: with SD3D_PAIR_RL=0 / SD3D_PAIR_DIRECT=0, or a C caller that
     //  passes neither, pass 2 would walk pos == NULL - refuse before anything is launched.  ADVICE r5)
@@ -1899,6 +1904,7 @@ int launch_pair_conv(const float* in0, int ld0, int C0, const float* in1, int ld
     g.dense_rows = 0;
     g.pool_ctr = nullptr;
     g.pool_epoch = 0;
+    g.k_flip = mirror_w ? K - 1 : -1;
 #ifdef PG_ABLATE
     g.dbg = pg_dbg_env();
 #endif
@@ -2052,7 +2058,7 @@ int launch_pair_dense(const GGParams& q, hipStream_t st) {
     PGParams g;
     g.in0 = q.in0; g.ld0 = q.ld0; g.C0 = q.in1 ? q.C0 : q.Cin; g.in1 = q.in1; g.ld1 = q.ld1; g.in_idx = nullptr; g.tile_k = nullptr; g.wt = q.wt;
     g.Cin = q.Cin; g.Cout = q.Cout; g.part = nullptr; g.n_tiles = 0; g.out_idx = nullptr; g.scale = q.scale; g.shift = q.shift; g.res = q.res;
-    g.ld_res = q.ld_res; g.out = q.out; g.ld_out = q.ld_out; g.act = q.act; g.nt_part = 0; g.chained = 0; g.dense_rows = q.M; g.pool_ctr = nullptr; g.pool_epoch = 0;
+    g.ld_res = q.ld_res; g.out = q.out; g.ld_out = q.ld_out; g.act = q.act; g.nt_part = 0; g.chained = 0; g.dense_rows = q.M; g.pool_ctr = nullptr; g.pool_epoch = 0; g.k_flip = -1;
 #ifdef PG_ABLATE
     g.dbg = pg_dbg_env();
 #endif

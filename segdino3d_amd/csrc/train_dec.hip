@@ -178,20 +178,24 @@ static __global__ __launch_bounds__(256) void transpose_batch_kernel(const TBatc
     const int wg = blockIdx.x;
     while (lo < hi) { const int mid = (lo + hi + 1) >> 1; if (b.tile0[mid] <= wg) lo = mid; else hi = mid - 1; }
     const sd3d_transpose_job& J = b.job[lo];
-    const int tx = (J.ld_dst + 31) / 32;                       // tiles along the destination's columns (= source rows, padded)
-    const int t = wg - b.tile0[lo];
+    const int tx = (J.ld_dst + 31) / 32, ty = (J.cols + 31) / 32;      // tiles along the destination's columns (= source rows, padded) / rows
+    int t = wg - b.tile0[lo];
+    const int m = t / (tx * ty);                               // matrix of the job (J.batch matrices back to back)
+    t -= m * (tx * ty);
+    const float* src = J.src + (int64_t)m * J.rows * J.cols;
+    float* dst = J.dst + (int64_t)m * J.cols * J.ld_dst;
     const int r0 = (t % tx) * 32, c0 = (t / tx) * 32;          // source row / column of the tile's corner
     const int x = threadIdx.x & 31, y = threadIdx.x >> 5;
 #pragma unroll
     for (int i = 0; i < 32; i += 8) {
         const int r = r0 + y + i, c = c0 + x;
-        tile[y + i][x] = (r < J.rows && c < J.cols) ? J.src[(int64_t)r * J.cols + c] : 0.f;
+        tile[y + i][x] = (r < J.rows && c < J.cols) ? src[(int64_t)r * J.cols + c] : 0.f;
     }
     __syncthreads();
 #pragma unroll
     for (int i = 0; i < 32; i += 8) {
         const int c = c0 + y + i, r = r0 + x;                  // destination row c, destination column r
-        if (c < J.cols && r < J.ld_dst) J.dst[(int64_t)c * J.ld_dst + r] = tile[x][y + i];
+        if (c < J.cols && r < J.ld_dst) dst[(int64_t)c * J.ld_dst + r] = tile[x][y + i];
     }
 }
 
@@ -209,7 +213,7 @@ int sd3d_transpose_batch(int n, const sd3d_transpose_job* jobs, void* stream) {
                 return sd3d_set_error(SD3D_ERR_ARG, "transpose_batch: bad job");
             b.job[i] = J;
             b.tile0[i] = tiles;
-            tiles += ((J.ld_dst + 31) / 32) * ((J.cols + 31) / 32);
+            tiles += (J.batch > 1 ? J.batch : 1) * ((J.ld_dst + 31) / 32) * ((J.cols + 31) / 32);
         }
         b.tile0[b.n] = tiles;
         transpose_batch_kernel<<<tiles, 256, 0, ST>>>(b);

@@ -776,8 +776,10 @@ def pair_lists_batch(tables):
     return out
 
 
-def pair_conv(x, wt, pairs, x2=None, scale=None, shift=None, res=None, act=None, out=None):
-    """Same contract as gather_gemm(x, wt, nbr=...) for the table `pairs` was built from."""
+def pair_conv(x, wt, pairs, x2=None, scale=None, shift=None, res=None, act=None, out=None, mirror_w=False):
+    """Same contract as gather_gemm(x, wt, nbr=...) for the table `pairs` was built from.
+    mirror_w: offset k multiplies wt[K - 1 - k] (SD3D_PAIR_MIRROR_W: the input gradient of a stride-1 convolution on its own table with
+    the parameter in its native [K, Cin, Cout] layout, train_ops.SparseConvNative)."""
     lib = _lib.load()
     K, Cout, Cin = wt.shape
     if K != pairs.K:
@@ -804,7 +806,7 @@ def pair_conv(x, wt, pairs, x2=None, scale=None, shift=None, res=None, act=None,
         hook.before(dict(K=K, Cin=Cin, Cout=Cout, M=M, nbr=None, pairs=pairs))
     _lib.check(lib.sd3d_pair_conv_ex(p0, ld0, C0, p1, ld1, pairs.in_idx.data_ptr(), pairs.tile_k.data_ptr(), pairs.p_cap,
                                      None if pairs.pos is None else pairs.pos.data_ptr(), None if pairs.rlist is None else pairs.rlist.data_ptr(), pairs.rl_stride,
-                                     pairs.center, pairs.out_idx.data_ptr() if pairs.direct else None,
+                                     pairs.center - 2 if mirror_w else pairs.center, pairs.out_idx.data_ptr() if pairs.direct else None,
                                      _ptr(wt, torch.float32, "wt"), K, Cin, Cout, M,
                                      _ptr(scale, torch.float32, "scale"), _ptr(shift, torch.float32, "shift"), pr, ldr, po, ldo,
                                      ACT[act], part.data_ptr(), part.numel(), _stream()), "pair_conv")

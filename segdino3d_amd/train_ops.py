@@ -64,6 +64,87 @@ def pair_wgrad(dy: torch.Tensor, x: torch.Tensor, pairs: "ops.PairLists", dw: to
     return dw
 
 
+def pair_wgrad_native(dy: torch.Tensor, x: torch.Tensor, pairs: "ops.PairLists") -> torch.Tensor:
+    """The weight gradient in the PARAMETER's layout [K, Cin, Cout] (`ME.MinkowskiConvolution.kernel`): the same kernel with the two
+    operands - and their index lists - exchanged (dW^T[k][ci][co] = sum_p x[in(p)][ci] dy[out(p)][co]); no transposed copy afterwards."""
+    lib = _lib.load()
+    pdy, ldy = ops._rows(dy, "dy")
+    px, ldx = ops._rows(x, "x")
+    Cout, Cin, K = dy.shape[1], x.shape[1], pairs.K
+    if dy.shape[0] != pairs.M:
+        raise ValueError(f"dy has {dy.shape[0]} rows, the rulebook {pairs.M} outputs")
+    dw = torch.empty(K, Cin, Cout, dtype=torch.float32, device=dy.device)
+    nb = lib.sd3d_pair_wgrad_ws_bytes(K, Cout, Cin)
+    ws = _WS.get(nb, dy.device)
+    _lib.check(lib.sd3d_pair_wgrad(px, ldx, pdy, ldy, pair_out_rows(pairs).data_ptr(), pairs.in_idx.data_ptr(), pairs.tile_k.data_ptr(),
+                                   pairs.p_cap, K, Cout, Cin, dw.data_ptr(), 0, ws.data_ptr(), ws.numel(), ops._stream()), "pair_wgrad")
+    return dw
+
+
+class TrainWeight:
+    """A convolution parameter in its native layout (`kernel` [K, Cin, Cout], or [Cin, Cout] for a 1x1) together with the [K, Cout, Cin]
+    copy the forward kernels read, made for ALL convolutions of a network by one launch per step (`transpose_all`)."""
+    __slots__ = ("param", "fwd", "pad_cin")
+
+    def __init__(self, param, fwd, pad_cin=0):
+        self.param, self.fwd, self.pad_cin = param, fwd, pad_cin
+
+
+def transpose_all(named_params, pad_cin=None):
+    """{name: kernel parameter} -> {name: TrainWeight}: every [K, Cin, Cout] -> [K, Cout, Cin (zero-padded to pad_cin[name])] in ONE launch
+    (sd3d_transpose_batch, one job of K matrices per convolution).  Replaces a permute + copy per convolution in every forward (61 launches
+    for Res16UNet34C) and the flipped / transposed copies of every backward."""
+    import numpy as np
+    from .train_dec import _TJOB_DT
+    pad_cin = pad_cin or {}
+    names = list(named_params)
+    arr = np.zeros(len(names), dtype=_TJOB_DT)
+    out, keep = {}, []
+    for i, n in enumerate(names):
+        p = named_params[n]
+        k3 = p.detach() if p.dim() == 3 else p.detach().unsqueeze(0)
+        if not k3.is_contiguous() or k3.dtype != torch.float32:
+            k3 = k3.contiguous().float()
+        K, cin, cout = k3.shape
+        ld = max(int(pad_cin.get(n, 0)), cin)
+        fwd = torch.empty(K, cout, ld, dtype=torch.float32, device=p.device)
+        arr[i] = (k3.data_ptr(), fwd.data_ptr(), cin, cout, ld, K)
+        keep.append(k3)
+        out[n] = TrainWeight(p, fwd, ld)
+    if names:
+        _lib.check(_lib.load().sd3d_transpose_batch(len(names), arr.ctypes.data, ops._stream()), "transpose_batch")
+    return out
+
+
+class SparseConvNative(torch.autograd.Function):
+    """y = pair_conv(x, W) with the parameter in its native layout: forward on the per-step [K, Cout, Cin] copy (`TrainWeight.fwd`), input
+    gradient on the parameter AS IT LIES (mirrored offsets for a stride-1 table: `ops.pair_conv(mirror_w=True)`), weight gradient written in
+    the parameter's layout (`pair_wgrad_native`).  Same kernels and the same bits as `SparseConv` fed with permuted copies."""
+
+    @staticmethod
+    def forward(ctx, x, kernel, fwd, pairs, pairs_t, mirrored, res=None):
+        ctx.save_for_backward(x, kernel)
+        ctx.pairs, ctx.pairs_t, ctx.mirrored = pairs, pairs_t, mirrored
+        return ops.pair_conv(x.detach(), fwd, pairs, res=None if res is None else res.detach())
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, kernel = ctx.saved_tensors
+        dy = dy.contiguous()
+        dx = dk = None
+        k3 = kernel.detach() if kernel.dim() == 3 else kernel.detach().unsqueeze(0)       # [K, Cin, Cout] = the transposed set [K, Cout', Cin']
+        if ctx.needs_input_grad[0]:
+            if k3.shape[1] != x.shape[1]:                       # (the stem's input channels are zero-padded to a multiple of 32: it needs no input gradient)
+                raise NotImplementedError("SparseConvNative: input gradient through a channel-padded convolution")
+            dx = ops.pair_conv(dy, k3, ctx.pairs_t, mirror_w=ctx.mirrored)
+        if ctx.needs_input_grad[1]:
+            dk = pair_wgrad_native(dy, x, ctx.pairs)            # [K, Cin (padded), Cout]
+            if dk.shape[1] != k3.shape[1]:
+                dk = dk[:, :k3.shape[1]]
+            dk = dk.reshape(kernel.shape) if dk.is_contiguous() else dk.contiguous().reshape(kernel.shape)
+        return dx, dk, None, None, None, None, (dy if len(ctx.needs_input_grad) > 6 and ctx.needs_input_grad[6] else None)
+
+
 def transposed_weights(w: torch.Tensor, mirrored: bool) -> torch.Tensor:
     """[K, Cout, Cin] -> [K, Cin, Cout] for the transposed rulebook (offsets mirrored for a submanifold table)."""
     wt = w.transpose(1, 2)
@@ -229,27 +310,42 @@ class TrainBackend:
     def _cat(x, x2):
         return x if x2 is None else torch.cat([x, x2], dim=1)
 
+    def _conv(self, xin, wt, kind, level, ksize, res=None):
+        if isinstance(wt, TrainWeight):
+            if kind == "same":
+                t = self.maps.conv_table("same", level, ksize)["pairs"]
+                return SparseConvNative.apply(xin, wt.param, wt.fwd, t, t, True, res)
+            other = "up" if kind == "down" else "down"
+            return SparseConvNative.apply(xin, wt.param, wt.fwd, self.maps.conv_table(kind, level)["pairs"],
+                                          self.maps.conv_table(other, level)["pairs"], False, res)
+        return sparse_conv(xin, wt, self.maps, kind, level, ksize, res=res)
+
     def conv(self, x, wt, affine, key, x2=None, res=None, act=None):
         kind, level = key[0], key[1]
         act = None if self.IGNORE_ACT else act
+        ksize = key[2] if kind == "same" else 2
         if affine is None:
             if act is not None:
                 raise NotImplementedError("TrainBackend: activation without BatchNorm")
-            return sparse_conv(self._cat(x, x2), wt, self.maps, kind, level, key[2] if kind == "same" else 2, res=res)
-        y = sparse_conv(self._cat(x, x2), wt, self.maps, kind, level, key[2] if kind == "same" else 2)
+            return self._conv(self._cat(x, x2), wt, kind, level, ksize, res=res)
+        y = self._conv(self._cat(x, x2), wt, kind, level, ksize)
         return batch_norm_act(y, affine, res=res, act=act)
 
     def dense(self, x, wt, affine, x2=None, res=None, act=None):
         xin = self._cat(x, x2)
-        if wt.dim() == 2:
-            wt = wt.unsqueeze(0)
         pairs = self._identity_pairs(xin.shape[0], xin.device)
         act = None if self.IGNORE_ACT else act
+        if isinstance(wt, TrainWeight):
+            apply = lambda r: SparseConvNative.apply(xin, wt.param, wt.fwd, pairs, pairs, True, r)      # noqa: E731
+        else:
+            if wt.dim() == 2:
+                wt = wt.unsqueeze(0)
+            apply = lambda r: SparseConv.apply(xin, wt, pairs, pairs, True, r)                           # noqa: E731
         if affine is None:
             if act is not None:
                 raise NotImplementedError("TrainBackend: activation without BatchNorm")
-            return SparseConv.apply(xin, wt, pairs, pairs, True, res)
-        y = SparseConv.apply(xin, wt, pairs, pairs, True, None)                 # K = 1: its own mirror
+            return apply(res)
+        y = apply(None)                                                         # K = 1: its own mirror
         return batch_norm_act(y, affine, res=res, act=act)
 
     def affine(self, x, affine, x2=None, act=None, add=None):
