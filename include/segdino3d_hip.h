@@ -709,6 +709,42 @@ int sd3d_elastic_displace(float* coords, int64_t n, const float* noise, int D0, 
  *   sd3d_layernorm_backward: for y = act(LayerNorm(x + res) * w + b): dxin = d/d(x + res) [M, D], dw, db (act 0 / 1 = relu).
  *   sd3d_sine_pe_mod_backward: gradient of sd3d_sine_pe's box modulation w.r.t. mod_num [n, 3] (positions and mod_den are
  *                            detached in the reference, :740, :753). */
+/* ---------------------------------------------------------------------------------------------
+ * Training step of a sparse U-Net from two calls (csrc/train_plan.hip; segdino3d_amd/train_plan.py records the plan): the forward of every
+ * {sparse convolution -> batch-statistics BatchNorm (+ residual) -> ReLU} layer of Res16UNetBase.forward (minkunet.py:531-601), and the
+ * backward of the same list in reverse (what `loss.backward()` of train_engine_3d.py:88-122 gets from MinkowskiEngine's autograd).
+ * A buffer (sd3d_buf) may hold the outputs of several layers side by side (`*_col` = first column of a layer's slice): a skip concatenation
+ * is the two producers writing into one buffer.  Every pointer is device memory owned by the caller; the calls only enqueue.
+ * ------------------------------------------------------------------------------------------- */
+typedef struct sd3d_train_table {
+    const int32_t *in_idx, *tile_k, *pos, *rlist;   /* sd3d_pair_lists_desc products of the table (plain lists, with the position table) */
+    const int32_t *out_rows;                        /* [p_cap] output row of every list entry (sd3d_pair_out_rows / the table's out_idx) */
+    int64_t p_cap, M;
+    int32_t K, rl_stride, center, direct;           /* direct = 1: one pair per output row (transposed k2s2 convolution): pass 1 writes the rows */
+} sd3d_train_table;
+typedef struct sd3d_train_layer {
+    int32_t table, table_t, mirrored;               /* forward table; table of the transposed rulebook (-1: no input gradient); 1: stride-1 table (its own transpose, offsets mirrored) */
+    int32_t src, src_col, res, res_col, dst, dst_col;   /* buffer ids + first column of the slice; res = -1: no residual */
+    int32_t raw;                                    /* raw[] id of the convolution output in front of the BatchNorm, [rows, Cout] */
+    int32_t K, Cin, Cout, act;                      /* Cin = columns read from src (the stem's are zero-padded to a multiple of 32) */
+    int32_t need_dx, dx_accum;                      /* need_dx = 0: the input carries no gradient; dx_accum = 1: grad[src] already holds one when this layer's arrives */
+    int32_t stats, pad_;                            /* offset (floats) of {mean, var, rstd} x Cout in the statistics arena */
+    float eps, momentum;
+    const float *wt_fwd, *kernel;                   /* [K, Cout, Cin] copy for the forward; the parameter [K, Cin, Cout] (input gradient) */
+    float* dkernel;                                 /* [K, Cin, Cout] gradient of the parameter */
+    const float *gamma, *beta;
+    float *dgamma, *dbeta, *running_mean, *running_var;
+    int64_t* num_batches;
+} sd3d_train_layer;
+int sd3d_unet_train_forward(const sd3d_train_layer* layers, int n_layers, const sd3d_train_table* tables, int n_tables, const sd3d_buf* act,
+                            int n_bufs, const sd3d_buf* raw, int n_raw, float* stats, float* part, size_t part_bytes, void* ws, size_t ws_bytes,
+                            void* stream);
+/* grad[]: gradient buffers, ids / shapes of act[] (d loss / d output already in the output's buffer); graw: scratch of max(rows x Cout) floats;
+ * ws >= max(sd3d_bn_ws_bytes, sd3d_pair_wgrad_ws_bytes) over the layers. */
+int sd3d_unet_train_backward(const sd3d_train_layer* layers, int n_layers, const sd3d_train_table* tables, int n_tables, const sd3d_buf* act,
+                             const sd3d_buf* grad, int n_bufs, const sd3d_buf* raw, int n_raw, const float* stats, float* graw, size_t graw_floats,
+                             float* part, size_t part_bytes, void* ws, size_t ws_bytes, void* stream);
+
 /* dst_i [cols_i, ld_dst_i] = src_i [rows_i, cols_i]^T, columns rows_i .. ld_dst_i - 1 zero, for n matrices in as few launches as
  * their descriptors fit (112 per launch): all the W^T the Linear input gradients of one backward pass need
  * (`x.grad = dy @ W` of every nn.Linear in instance_seg_3d_decoder.py), made at once instead of one copy kernel per weight. */

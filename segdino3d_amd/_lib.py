@@ -131,6 +131,8 @@ SIGNATURES = {
     "sd3d_bn_ws_bytes": (_z, [_l, _i]),
     "sd3d_bn_stats": (_i, [_p, _i, _l, _i, _f, _p, _p, _p, _p, _z, _p]),
     "sd3d_transpose_batch": (_i, [_i, _p, _p]),
+    "sd3d_unet_train_forward": (_i, [_p, _i, _p, _i, _p, _i, _p, _i, _p, _p, _z, _p, _z, _p]),
+    "sd3d_unet_train_backward": (_i, [_p, _i, _p, _i, _p, _p, _i, _p, _i, _p, _p, _z, _p, _z, _p, _z, _p]),
     "sd3d_bn_stats_running": (_i, [_p, _i, _l, _i, _f, _p, _p, _p, _p, _p, _p, _f, _p, _z, _p]),
     "sd3d_bn_apply": (_i, [_p, _i, _p, _p, _p, _p, _p, _i, _l, _i, _i, _p, _i, _p]),
     "sd3d_bn_backward": (_i, [_p, _i, _p, _i, _p, _i, _p, _p, _p, _l, _i, _i, _p, _i, _p, _i, _p, _p, _p, _z, _p]),
@@ -195,7 +197,7 @@ def load_nogil():
     if _lib_nogil is None:
         load()
         lib = C.CDLL(LIB_PATH)
-        for name in ("sd3d_run_layers", "sd3d_run_layers_ev", "sd3d_unpack_bits_host"):
+        for name in ("sd3d_run_layers", "sd3d_run_layers_ev", "sd3d_unpack_bits_host", "sd3d_unet_train_forward", "sd3d_unet_train_backward"):
             fn = getattr(lib, name)
             fn.restype, fn.argtypes = SIGNATURES[name]
         _lib_nogil = lib

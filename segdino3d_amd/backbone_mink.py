@@ -136,6 +136,7 @@ class Res16UNetBase(DerivedWeights):
         self.out_planes = P[7]
         self._packed = None
         self._plan = None
+        self._train_plan = None
 
     def _make_layer(self, planes, blocks, mom):
         down = None
@@ -152,6 +153,7 @@ class Res16UNetBase(DerivedWeights):
         super()._derived_reset()
         self._packed = None
         self._plan = None
+        self._train_plan = None
 
     def _load_from_state_dict(self, *a, **k):
         self._derived_reset()
@@ -245,9 +247,18 @@ class Res16UNetBase(DerivedWeights):
         use_plan = (not self.training and plan.USE_PLAN and ops.PAIR_CONV and ops.GEMM_MODE is None and ops.GG_FORCE_NT is None
                     and ops.GG_HOOK is None)
         maps.prepare(same=[(0, k1)] + [(l, 3) for l in range(5)], strides=[0, 1, 2, 3], chained=not self.training, fork=use_plan)
-        if self.training:                                        # batch-statistics BatchNorm, autograd nodes over HIP kernels
-            from . import train_ops
-            return self._network(train_ops.TrainBackend(maps), self.packed_train(), vox_feats)
+        if self.training:                                        # batch-statistics BatchNorm; backward through HIP kernels
+            from . import train_ops, train_plan
+            pk = self.packed_train()
+            if (train_plan.USE_TRAIN_PLAN and NATIVE_TRAIN_WEIGHTS and torch.is_grad_enabled() and not train_ops.TrainBackend.IGNORE_ACT
+                    and train_plan.supported([v for v in pk.values() if isinstance(v, nn.BatchNorm1d)])):
+                # the whole U-Net as ONE autograd node over two C calls (csrc/train_plan.hip)
+                if self._train_plan is None:
+                    rec = train_plan.TrainRecorder(vox_feats.shape[1])
+                    self._train_plan = rec.finish(self._network(rec, pk, rec.input))
+                by_param = {id(v.param): v.fwd for v in pk.values() if isinstance(v, train_ops.TrainWeight)}
+                return train_plan.run(self._train_plan, maps, vox_feats, [by_param[id(p)] for p in self._train_plan.params])
+            return self._network(train_ops.TrainBackend(maps), pk, vox_feats)
         if pk is None:
             pk = self.packed()
         if use_plan:

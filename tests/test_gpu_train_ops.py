@@ -271,6 +271,52 @@ def test_spconvunet_backward_without_relu_matches_float64_oracle(normalize_befor
     assert worst[0][0] <= 2e-4, f"parameter gradients differ: {worst[:5]}"
 
 
+@pytest.mark.parametrize("n_scenes", [1, 2])
+def test_train_plan_equals_the_autograd_node_path(n_scenes):
+    """The U-Net's training step as ONE autograd node over two C calls (`segdino3d_amd/train_plan.py`, csrc/train_plan.hip) against the
+    node-per-layer path (`train_ops.TrainBackend`): same kernels, same order per tensor - the features are the same bits, every parameter
+    gradient agrees to fp32 association noise (a tensor with three consumers adds its gradients in another order), the BatchNorm running
+    statistics advance identically.  One scene and a batch of two (block-diagonal tables, batch statistics)."""
+    import copy, os, sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden"))
+    from _det import det_param
+    from segdino3d_amd import train_plan
+    from segdino3d_amd.backbone_mink import Res16UNet34C
+    from segdino3d_amd.synth import make_scene
+    d = dev()
+    scenes = [make_scene(50 + i, n_points=15000 + 3000 * i, n_superpoints=120, n_query2d=12) for i in range(n_scenes)]
+    m = Res16UNet34C(in_channels=259, out_channels=96, config=dict(dilations=[1, 1, 1, 1], conv1_kernel_size=5, bn_momentum=0.02),
+                     voxel_size=0.02, mode_fuse_2d_feat="early_fusion", add_positional_embedding=True)
+    sd = {k: det_param("backbone." + k, v.shape).to(v.dtype) for k, v in m.state_dict().items()}
+    m.load_state_dict(sd)
+    m.to(d).train()
+    g = torch.Generator().manual_seed(2)
+    res = {}
+    old = train_plan.USE_TRAIN_PLAN
+    try:
+        for use in (True, False):
+            train_plan.USE_TRAIN_PLAN = use
+            m.load_state_dict(sd)
+            m.zero_grad(set_to_none=True)
+            feats, _, _ = m.forward_wrapper([p.to(d) for p, _ in scenes], [copy.copy(t).to(d) for _, t in scenes], return_sp_mean_pos=True)
+            if use:
+                assert m._train_plan is not None and m._train_plan.n == 62
+                R_w = [torch.randn(f.shape, generator=g).to(d) for f in feats]
+            sum((f * w).sum() for f, w in zip(feats, R_w)).backward()
+            res[use] = ([f.detach().clone() for f in feats], {n: p.grad.detach().clone() for n, p in m.named_parameters()},
+                        {n: b.detach().clone() for n, b in m.named_buffers()})
+    finally:
+        train_plan.USE_TRAIN_PLAN = old
+    for a, b in zip(res[True][0], res[False][0]):
+        assert torch.equal(a, b), "the forward of the plan must give the bits of the node-per-layer path"
+    assert set(res[True][1]) == set(res[False][1])
+    worst = sorted(((_rel(res[True][1][n], res[False][1][n].double()), n) for n in res[True][1]), reverse=True)
+    print("plan vs autograd nodes, worst parameter gradients:", worst[:3])
+    assert worst[0][0] <= 2e-5, worst[:5]
+    for n in res[True][2]:
+        assert torch.equal(res[True][2][n], res[False][2][n]), f"running statistics differ: {n}"
+
+
 def test_batched_training_uses_batch_statistics_like_minkowski():
     """Two scenes in one training batch: ME collates them into ONE sparse tensor (minkunet.py:624-627), so every BatchNorm takes
     its statistics over the voxels of both scenes while convolutions stay inside their scene.  Oracle: the single-scene network
