@@ -190,7 +190,7 @@ def load_pmc_traffic(key):
     """HBM-side bytes per forward of the dominant kernel from the committed PMC passes (rocprofv3 cannot run inside this process) -
     ONLY if they were collected on the workload this run measures (`key`: scene shape, layout, query mode, scenes per forward).
     Returns (bytes per forward | None, source | reason)."""
-    for name in ("r05_pmc_traffic.json", "r04_pmc_traffic.json"):
+    for name in ("r06_pmc_traffic.json", "r05_pmc_traffic.json", "r04_pmc_traffic.json"):
         path = os.path.join(ROOT, "profiles", name)
         if not os.path.exists(path):
             continue
