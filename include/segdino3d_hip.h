@@ -655,6 +655,14 @@ int sd3d_pair_wgrad(const float* dy, int ld_dy, const float* x, int ld_x, const 
                     const int32_t* tile_k, int64_t p_cap, int K, int Cin, int Cout, float* dw, int flags, void* ws, size_t ws_bytes,
                     void* stream);
 
+/* Weight and bias gradient of a Linear on a few thousand rows in ONE launch (the decoder's ~130 Linears per training step):
+ * dw [Cout, Cin] (+)= g^T x, db [Cout] (+)= column sums of g (db may be NULL); g [M, ld_g >= round4(Cout)] (act'-scaled output gradient),
+ * x [M, ld_x >= round4(Cin)], both strides multiples of 4 floats.  A workgroup owns a 32 x 32 block of dw for all rows (rounds of 128 rows staged
+ * in LDS, sixteen waves, their accumulators summed in a fixed order: bit-reproducible).
+ * flags: SD3D_WGRAD_ACCUMULATE, SD3D_WGRAD_BF16_OPERANDS.  For tens of thousands of rows sd3d_pair_wgrad (row ranges + reduce) is the one. */
+int sd3d_linear_wgrad(const float* g, int ld_g, const float* x, int ld_x, int64_t M, int Cin, int Cout, float* dw, float* db, int flags,
+                      void* stream);
+
 /* ---------------------------------------------------------------------------------------------
  * Training-mode BatchNorm over voxel rows (ME.MinkowskiBatchNorm = nn.BatchNorm1d, minkunet.py:302-304) with the
  * BasicBlock's residual add and ReLU folded in (:234-250), and the backward of sd3d_pool_superpoints (:668-676).

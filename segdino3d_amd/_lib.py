@@ -128,6 +128,7 @@ SIGNATURES = {
     "sd3d_pair_out_rows": (_i, [_p, _i, _l, _l, _p, _p]),
     "sd3d_pair_wgrad_ws_bytes": (_z, [_i, _i, _i]),
     "sd3d_pair_wgrad": (_i, [_p, _i, _p, _i, _p, _p, _p, _l, _i, _i, _i, _p, _i, _p, _z, _p]),
+    "sd3d_linear_wgrad": (_i, [_p, _i, _p, _i, _l, _i, _i, _p, _p, _i, _p]),
     "sd3d_bn_ws_bytes": (_z, [_l, _i]),
     "sd3d_bn_stats": (_i, [_p, _i, _l, _i, _f, _p, _p, _p, _p, _z, _p]),
     "sd3d_transpose_batch": (_i, [_i, _p, _p]),

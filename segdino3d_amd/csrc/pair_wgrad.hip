@@ -236,6 +236,126 @@ __global__ __launch_bounds__(256) void pair_wgrad_reduce_kernel(const float* __r
     }
 }
 
+// ---- weight (and bias) gradient of a Linear on a few thousand rows: ONE launch, no partial blocks -------------------------------------
+// dW[co][ci] = sum_m g[m][co] x[m][ci] for the decoder's Linears (M = 2 441 queries / 3 000 superpoints per step, ~130 of them): through the
+// pair-list kernel above such a product is two launches (20 one-tile ranges write 20 partial blocks, the reduce adds them up): 21 + 13 us
+// for 0.3 GFLOP.  Here a workgroup owns one 32 x 32 block of dW for ALL rows: rounds of 128 rows are staged in LDS (one dwordx4 per thread and operand), each of its sixteen waves multiplies eight of them
+// (four v_mfma_f32_32x32x2_f32), and the sixteen accumulators are added through
+// LDS in a fixed order - bit-reproducible, no atomics.  db (column sums of g) rides along in the workgroups of the first ci block.
+#define LW_WAVES 16
+#define LW_ROWS 128              // rows staged per round: eight per wave = four MFMA steps
+#define LW_STAGES 4              // rounds of requests in flight per thread
+#define LW_LD 36                 // floats per staged row (32 + 4: rows stay 16-byte aligned, the two rows of an MFMA step fall into different banks)
+__global__ __launch_bounds__(LW_WAVES * 64) void linear_wgrad_small_kernel(const float* __restrict__ g, int ld_g, const float* __restrict__ x, int ld_x,
+                                                                         int64_t M, int Cin, int Cout, float* __restrict__ dw, float* __restrict__ db,
+                                                                         int bf16, int accumulate) {
+    // (a first version fed the MFMAs straight from memory, one dword per lane and operand: two wave-wide loads per MFMA through the CU's
+    //  one address unit - 29 us per 256 x 256 x 2 441 product whatever the number of waves or loads in flight; here a round of 128 rows is
+    //  fetched with one dwordx4 per thread and operand and multiplied out of LDS)
+    __shared__ __attribute__((aligned(16))) float smem[2 * LW_ROWS * LW_LD > (LW_WAVES / 2) * 1024 ? 2 * LW_ROWS * LW_LD : (LW_WAVES / 2) * 1024];
+    __shared__ float bred[LW_WAVES][32];
+    float* const As = smem;                                    // [LW_ROWS][LW_LD]  g rows (this block's 32 output columns)
+    float* const Bs = smem + LW_ROWS * LW_LD;                  // [LW_ROWS][LW_LD]  x rows (this block's 32 input columns)
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int i = lane & 31, k = lane >> 5;
+    const int co0 = blockIdx.x * 32, ci0 = blockIdx.y * 32;
+    const int srow = tid >> 3, seg = (tid & 7) * 4;            // staging: thread = (row of the round, four columns)
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    float bs = 0.f;
+    // fetch = the two requests and nothing else (clamped addresses: unconditional, nothing looks at the values until the round is staged -
+    // a select or a rounding right behind the load, or a load under a branch, makes hipcc wait for it on the spot: `global_load; s_waitcnt
+    // vmcnt(0)` put one memory round trip into every round of the first versions); finish = masks (+ bf16 rounding) when the round is staged
+    const bool a_in = co0 + seg < ((Cout + 3) & ~3), b_in = ci0 + seg < ((Cin + 3) & ~3);
+    const float* const gp = g + (a_in ? co0 + seg : 0);
+    const float* const xp = x + (b_in ? ci0 + seg : 0);
+    auto fetch = [&](int64_t r0, f32x4& va, f32x4& vb) {
+        const int64_t row = r0 + srow;
+        const int64_t rc = row < M ? row : M - 1;
+        va = *(const f32x4*)(gp + rc * ld_g);
+        vb = *(const f32x4*)(xp + rc * ld_x);
+    };
+    auto finish = [&](int64_t r0, f32x4& va, f32x4& vb) {
+        const bool row_ok = r0 + srow < M;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            if (!row_ok || co0 + seg + c >= Cout) va[c] = 0.f;
+            if (!row_ok || ci0 + seg + c >= Cin) vb[c] = 0.f;
+        }
+        if (bf16) {
+#pragma unroll
+            for (int c = 0; c < 4; ++c) { va[c] = round_to_bf16(va[c]); vb[c] = round_to_bf16(vb[c]); }
+        }
+    };
+    // LW_STAGES rounds of requests in flight (registers): a round multiplies for ~0.3 us, a request takes 1 - 2 us - with one round in flight the
+    // launch lasted 20 rounds x the memory latency, 25 us whatever the number of workgroups (profiles/EXPERIMENTS.md round 6)
+    f32x4 va[LW_STAGES], vb[LW_STAGES];
+    const int64_t nrounds = (M + LW_ROWS - 1) / LW_ROWS;
+#pragma unroll
+    for (int u = 0; u < LW_STAGES; ++u) fetch((int64_t)(u < nrounds ? u : nrounds - 1) * LW_ROWS, va[u], vb[u]);
+    for (int64_t rd = 0; rd < nrounds; rd += LW_STAGES) {
+#pragma unroll
+        for (int u = 0; u < LW_STAGES; ++u) {
+            if (rd + u < nrounds) {                             // uniform
+                finish((rd + u) * LW_ROWS, va[u], vb[u]);
+                __syncthreads();                                // the previous round's products have read LDS
+                *(f32x4*)(As + srow * LW_LD + seg) = va[u];
+                *(f32x4*)(Bs + srow * LW_LD + seg) = vb[u];
+                __syncthreads();
+                {   // UNCONDITIONAL (a round past the end reloads the last one: hipcc waits on the spot for loads it issues under a branch)
+                    const int64_t nx = rd + u + LW_STAGES;
+                    fetch((nx < nrounds ? nx : nrounds - 1) * LW_ROWS, va[u], vb[u]);
+                }
+                const float* ar = As + (8 * wv + k) * LW_LD + i;
+                const float* br = Bs + (8 * wv + k) * LW_LD + i;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const float a = ar[2 * q * LW_LD], b = br[2 * q * LW_LD];
+                    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc, 0, 0, 0);
+                    bs += a;
+                }
+            }
+        }
+    }
+    // D[row][col]: lane holds column (lane & 31), register r row 8 (r >> 2) + 4 (lane >> 5) + (r & 3).  Waves 8 .. 15 hand their block to
+    // waves 0 .. 7 (acc_w + acc_{w + 8}), then the eight sums are added in wave order: one fixed order whatever the timing.
+    float (*red)[1024] = (float (*)[1024])smem;
+    bs += __shfl_xor(bs, 32);
+    if (k == 0) bred[wv][i] = bs;
+    __syncthreads();                                            // the staging area becomes the reduction area
+    if (wv >= LW_WAVES / 2) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) red[wv - LW_WAVES / 2][(8 * (r >> 2) + 4 * k + (r & 3)) * 32 + i] = acc[r];
+    }
+    __syncthreads();
+    if (wv < LW_WAVES / 2) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            float* slot = &red[wv][(8 * (r >> 2) + 4 * k + (r & 3)) * 32 + i];
+            *slot = acc[r] + *slot;
+        }
+    }
+    __syncthreads();
+    for (int e = tid; e < 1024; e += LW_WAVES * 64) {
+        float a = 0.f;
+#pragma unroll
+        for (int w = 0; w < LW_WAVES / 2; ++w) a += red[w][e];
+        const int row = co0 + (e >> 5), col = ci0 + (e & 31);
+        if (row < Cout && col < Cin) {
+            float* d = dw + (int64_t)row * Cin + col;
+            *d = accumulate ? *d + a : a;
+        }
+    }
+    if (db && blockIdx.y == 0 && tid < 32 && co0 + tid < Cout) {
+        float a = 0.f;
+#pragma unroll
+        for (int w = 0; w < LW_WAVES; ++w) a += bred[w][tid];
+        db[co0 + tid] = accumulate ? db[co0 + tid] + a : a;
+    }
+}
+
 // tile ranges (= workgroups per output block): enough to fill the chip, never more than there are tiles (a 200-row Linear of
 // the decoder has two tiles: 768 ranges would leave 766 empty slots for pass 2 to scan)
 static int wgrad_ranges(int K, int Cin, int Cout, int64_t p_cap) {
@@ -315,6 +435,19 @@ int sd3d_pair_wgrad(const float* dy, int ld_dy, const float* x, int ld_x, const 
     const int64_t cap = 2048 / K > 64 ? 2048 / K : 64;
     gx = gx < cap ? gx : cap;
     pair_wgrad_reduce_kernel<<<dim3((unsigned)gx, K), 256, 0, ST>>>(p.wpart, p.slot_k, p.n_slots, elems, dw, accumulate);
+    SD3D_CHECK_LAUNCH();
+    return SD3D_OK;
+}
+
+int sd3d_linear_wgrad(const float* g, int ld_g, const float* x, int ld_x, int64_t M, int Cin, int Cout, float* dw, float* db, int flags,
+                      void* stream) {
+    if (M <= 0 || Cin <= 0 || Cout <= 0) return SD3D_OK;
+    if (!g || !x || !dw) return sd3d_set_error(SD3D_ERR_ARG, "linear_wgrad: null pointer");
+    if ((ld_g & 3) || (ld_x & 3) || ld_g < ((Cout + 3) & ~3) || ld_x < ((Cin + 3) & ~3))
+        return sd3d_set_error(SD3D_ERR_ARG, "linear_wgrad: row strides must be multiples of 4 floats and cover the columns rounded up to 4");
+    const dim3 grid((unsigned)cdiv(Cout, 32), (unsigned)cdiv(Cin, 32));
+    linear_wgrad_small_kernel<<<grid, LW_WAVES * 64, 0, ST>>>(g, ld_g, x, ld_x, M, Cin, Cout, dw, db, (flags & SD3D_WGRAD_BF16_OPERANDS) ? 1 : 0,
+                                                             (flags & SD3D_WGRAD_ACCUMULATE) ? 1 : 0);
     SD3D_CHECK_LAUNCH();
     return SD3D_OK;
 }

@@ -31,6 +31,8 @@ _IDENTITY = {}
 import os as _os
 BF16_BACKWARD = _os.environ.get("SD3D_BF16_BACKWARD", "0") == "1"
 BATCH_WT = _os.environ.get("SD3D_BATCH_WT", "1") != "0"
+# rows up to which a Linear's weight gradient takes the one-launch kernel (sd3d_linear_wgrad); 0: always the pair-list kernel + reduce (rounds 2 - 5)
+LINEAR_WGRAD_ROWS = int(_os.environ.get("SD3D_LINEAR_WGRAD_ROWS", "8192"))
 
 
 def _identity_pairs(n_rows: int, device):
@@ -203,11 +205,20 @@ class _Linear(torch.autograd.Function):
             # operands, so there the sums keep their own fp32 pass
             want_b = ctx.has_b and ctx.needs_input_grad[2]
             fuse_b = want_b and not ctx.bf16_bwd
-            dwp = train_ops.pair_wgrad(g, xin.contiguous(), _identity_pairs(g.shape[0], g.device), bf16_operands=ctx.bf16_bwd, bias=fuse_b)   # [1, c_pad, cin(+pad)]
-            if fuse_b:
-                dwp, dbp = dwp
-                db = dbp[:cout]
-            dw = dwp[0, :cout, :cin]
+            if 0 < g.shape[0] <= LINEAR_WGRAD_ROWS:
+                # a few thousand rows (the decoder's Linears): ONE launch, a 32 x 32 block of dW per workgroup over all rows (round 6; the
+                # pair-list kernel splits the rows into ranges and adds their partial blocks in a second launch: 21 + 13 us for 0.3 GFLOP)
+                xin = xin.contiguous()
+                dw = torch.empty(cout, cin, dtype=torch.float32, device=g.device)
+                db = torch.empty(cout, dtype=torch.float32, device=g.device) if fuse_b else None
+                _lib.check(_lib.load().sd3d_linear_wgrad(g.data_ptr(), g.stride(0), xin.data_ptr(), xin.stride(0), g.shape[0], cin, cout, dw.data_ptr(),
+                                                         None if db is None else db.data_ptr(), 2 if ctx.bf16_bwd else 0, ops._stream()), "linear_wgrad")
+            else:
+                dwp = train_ops.pair_wgrad(g, xin.contiguous(), _identity_pairs(g.shape[0], g.device), bf16_operands=ctx.bf16_bwd, bias=fuse_b)   # [1, c_pad, cin(+pad)]
+                if fuse_b:
+                    dwp, dbp = dwp
+                    db = dbp[:cout]
+                dw = dwp[0, :cout, :cin]
         if db is None and ctx.has_b and ctx.needs_input_grad[2]:
             db = col_sums(g)[:cout]
         if ctx.has_res and ctx.needs_input_grad[4]:

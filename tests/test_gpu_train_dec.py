@@ -461,3 +461,41 @@ def test_training_step_is_bit_reproducible():
     diff = [n for n in runs[0][2] if not torch.equal(runs[0][2][n], runs[1][2][n])]
     assert not diff, f"{len(diff)} parameter gradients differ between two identical steps, e.g. {diff[:3]}"
     assert all(bool(torch.isfinite(g).all()) for g in runs[0][2].values())
+
+
+@pytest.mark.parametrize("M,cin,cout", [(2441, 256, 256), (3000, 96, 256), (777, 1024, 256), (5, 256, 3), (2441, 260, 200), (4096, 256, 1024), (1, 32, 32)])
+def test_linear_wgrad_one_launch_matches_float64(M, cin, cout):
+    """`sd3d_linear_wgrad` (round 6: weight + bias gradient of a Linear on a few thousand rows in one launch) against a float64 product, the
+    pair-list kernel it replaces for such shapes, itself run twice (bit-reproducible), and its accumulate flag."""
+    import ctypes
+    from segdino3d_amd import _lib, ops, train_ops
+    d = dev()
+    lib = _lib.load()
+    gen = torch.Generator().manual_seed(M + cin + cout)
+    c_pad = (cout + 31) // 32 * 32
+    g = torch.zeros(M, c_pad)
+    g[:, :cout] = torch.randn(M, cout, generator=gen)
+    x = torch.randn(M, cin, generator=gen)
+    g, x = g.to(d), x.to(d)
+
+    def run(flags=0, dw=None, db=None):
+        dw = torch.empty(cout, cin, device=d) if dw is None else dw
+        db = torch.empty(cout, device=d) if db is None else db
+        rc = lib.sd3d_linear_wgrad(g.data_ptr(), g.stride(0), x.data_ptr(), x.stride(0), M, cin, cout, dw.data_ptr(), db.data_ptr(), flags, ops._stream())
+        assert rc == 0, lib.sd3d_last_error()
+        return dw, db
+    dw, db = run()
+    dw2, db2 = run()
+    assert torch.equal(dw, dw2) and torch.equal(db, db2), "must be bit-reproducible"
+    ref_w = g[:, :cout].double().t() @ x.double()
+    ref_b = g[:, :cout].double().sum(0)
+    scale = max(ref_w.abs().max().item(), 1.0)
+    assert (dw.double() - ref_w).abs().max().item() <= 3e-5 * scale
+    assert (db.double() - ref_b).abs().max().item() <= 3e-5 * max(ref_b.abs().max().item(), 1.0)
+    acc_w, acc_b = run(flags=1, dw=dw.clone(), db=db.clone())                 # SD3D_WGRAD_ACCUMULATE
+    assert torch.allclose(acc_w, 2 * dw, rtol=1e-6, atol=0) and torch.allclose(acc_b, 2 * db, rtol=1e-6, atol=0)
+    if cin % 4 == 0 and M >= 2:                                               # the two-launch path on identity pair lists
+        nbr = torch.arange(M, dtype=torch.int32, device=d).unsqueeze(0).contiguous()
+        old = train_ops.pair_wgrad(g, x, ops.pair_lists(nbr, M))[0, :cout, :cin]
+        assert (old.double() - ref_w).abs().max().item() <= 3e-5 * scale
+        assert (old - dw).abs().max().item() <= 3e-5 * scale
